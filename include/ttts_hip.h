@@ -1,0 +1,144 @@
+/* ttts_hip.h -- C ABI of libttts_hip.so: hand-written gfx950 (MI355X / CDNA4) HIP kernels for the
+ * teacher-forced Transformer-TTS forward/backward hot path.
+ *
+ * The reference (Orca0917/TransformerTTS, /root/reference) has no FFI of its own: it is pure Python
+ * and delegates its arithmetic to stock torch ops.  Each entry point below therefore names the torch
+ * call site in the reference that it replaces (file:line relative to /root/reference;
+ * "torch/..." = the un-vendored PyTorch the reference runs on).
+ *
+ * Conventions:
+ *   - plain pointers + sizes only; activations are row-major contiguous (B,T,C) fp32, weights keep the
+ *     state-dict layouts ((out,in) linear, (Cout,Cin,K) conv, packed (3d,d) in-proj); lengths are int64.
+ *   - every function only ENQUEUES work on `stream` (a hipStream_t passed as void*); no allocation,
+ *     no synchronisation, no global state.  Workspaces are owned by the caller.
+ *   - return 0 on success, a negative TTTS_ERR_* otherwise (never throws / exits);
+ *     ttts_last_error() returns a thread-local message for the last failure.
+ *   - dropout masks are a pure function of (seed, flat element index), so backward entry points
+ *     regenerate the forward mask from the same seed; p = 0 disables dropout.
+ */
+#ifndef TTTS_HIP_H
+#define TTTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTTS_OK 0
+#define TTTS_ERR_INVALID (-1) /* bad argument (shape, alignment, null pointer) */
+#define TTTS_ERR_LAUNCH (-2)  /* hipLaunchKernel reported an error */
+
+#define TTTS_ACT_NONE 0
+#define TTTS_ACT_RELU 1
+#define TTTS_ACT_TANH 2
+
+const char* ttts_last_error(void);
+int ttts_abi_version(void);
+
+/* ------------------------------------------------------------------ linear (nn.Linear / LinearNorm)
+ * y[M,N] = drop(act(x[M,K] . w[N,K]^T + bias)) + residual          K % 16 == 0
+ * Replaces: LinearNorm.forward (model/module.py:52-53); MHA in/out projections
+ * (torch/nn/functional.py:6206+ in_proj, out_proj); FFN `_ff_block`
+ * (torch/nn/modules/transformer.py:980-982,1197-1199) incl. its ReLU, Dropout and the residual add
+ * of model/layers.py:47-50; DecoderPreNet (model/model.py:65-66).
+ * row_shift = -1 with T = frames per utterance folds the go-frame shift of model/model.py:278-279
+ * into the loader (row (b,t) reads x[b,t-1], zeros at t = 0). */
+int ttts_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, int64_t M,
+                    int N, int K, int act, float drop_p, uint64_t seed, int row_shift, int T, void* stream);
+/* dx[M,K] = dy[M,N] . w[N,K] (+ residual[M,K])                      N % 16 == 0, K % 4 == 0 */
+int ttts_linear_bwd_data(const float* dy, const float* w, const float* residual, float* dx, int64_t M, int N, int K,
+                         void* stream);
+/* dw[N,K] = dy[M,N]^T . x[M,K] (x rows shifted as in forward); dbias[N] = column sums of dy (optional) */
+size_t ttts_wgrad_workspace_bytes(int64_t M, int N, int K, int taps);
+int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
+                           int64_t M, int N, int K, int row_shift, int T, void* stream);
+
+/* ------------------------------------------------------------------ Conv1d (k taps, same padding) on (B,T,C)
+ * Replaces ConvNormBN's permute -> nn.Conv1d(pad=(k-1)//2) -> permute (model/module.py:28-33) as an
+ * implicit GEMM directly on the (B,T,C) layout.  Weights are re-laid once per call by
+ * ttts_conv1d_pack_weight: w[co][ci][tap] -> w_fwd[co][tap][ci] and/or w_bwd[ci][tap][co]. */
+size_t ttts_conv1d_pack_bytes(int cout, int cin, int taps);
+int ttts_conv1d_pack_weight(const float* w, float* w_fwd, float* w_bwd, int cout, int cin, int taps, void* stream);
+int ttts_conv1d_fwd(const float* x, const float* w_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
+                    int taps, void* stream);
+int ttts_conv1d_bwd_data(const float* dy, const float* w_bwd, float* dx, int B, int T, int cin, int cout, int taps,
+                         void* stream);
+int ttts_conv1d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
+                           int T, int cin, int cout, int taps, void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm1d over (M = B*T rows, C channels)
+ * Replaces nn.BatchNorm1d inside ConvNormBN (model/module.py:19,31) plus the Tanh / Dropout entries that
+ * follow it in EncoderPreNet / PostNet (model/model.py:29-33,113-126).
+ * train: batch statistics over all rows (padding included), running stats updated with momentum and the
+ * unbiased variance, num_batches_tracked += 1.  eval: normalise with the running statistics. */
+size_t ttts_bn_workspace_bytes(int64_t M, int C);
+int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float* ws, size_t ws_bytes, int64_t M, int C, float momentum,
+                        float eps, void* stream);
+int ttts_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C, float eps,
+                       void* stream);
+/* z = drop(act((x - mean) * invstd * gamma + beta)) */
+int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      float* z, int64_t M, int C, int act, float drop_p, uint64_t seed, void* stream);
+/* train-mode backward through drop/act/BN: dx, dgamma, dbeta from dz and the saved x, mean, invstd */
+int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float* invstd, const float* gamma,
+                const float* beta, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int C,
+                int act, float drop_p, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------ LayerNorm over the last dim (d % 64 == 0, d <= 1024)
+ * Replaces nn.LayerNorm norm1/2/3 of the encoder/decoder layers (torch/nn/modules/transformer.py:951-956,
+ * model/layers.py:47-50).  The residual sum is produced by the preceding GEMM's epilogue. */
+int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       int64_t M, int d, float eps, void* stream);
+size_t ttts_layernorm_bwd_workspace_bytes(int d);
+int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
+                       void* stream);
+
+/* ------------------------------------------------------------------ attention (head_dim = 64)
+ * Scaled dot-product attention with masks computed from lengths in-kernel (no mask tensors):
+ * key j of batch b is dead when j >= key_lens[b], or (causal) j > i.  q is scaled by sqrt(1/64) before
+ * q.k^T exactly as torch does (torch/nn/functional.py:6578).  q/k/v/o are addressed as
+ * ptr[(b*T + t)*ld + h*64 + c], so packed in-proj outputs are consumed in place.
+ * Replaces: encoder self-attention and decoder `_sa_block` (torch/nn/modules/transformer.py:961-978,
+ * 1158-1175 -> F.scaled_dot_product_attention, torch/nn/functional.py:6629) and the decoder's
+ * `_mha_block` cross-attention with need_weights=True, average_attn_weights=False
+ * (model/layers.py:54-74; torch/nn/functional.py:6576-6610).
+ * attn (optional) receives the per-head, post-dropout weights (B,H,Tq,Tk); lse (B,H,Tq) is saved for backward. */
+int ttts_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
+                       const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
+                       int causal, float drop_p, uint64_t seed, void* stream);
+/* dq, dk, dv from do_ (recomputes the probabilities from q, k and lse); delta (B,H,Tq) is scratch */
+int ttts_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* do_,
+                       const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
+                       int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                       int causal, float drop_p, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------ small row / element-wise pieces
+ * nn.Embedding gather / scatter-add (model/model.py:168,288; no padding_idx) */
+int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d, void* stream);
+int ttts_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t n, int vocab, int d, void* stream);
+/* PositionalEncoding.forward (model/model.py:91-97): y = drop(x + alpha * pe[t]) */
+int ttts_posenc_fwd(const float* x, const float* pe, const float* alpha, float* y, int B, int T, int d, float drop_p,
+                    uint64_t seed, void* stream);
+size_t ttts_posenc_bwd_workspace_bytes(void);
+int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, float* ws, size_t ws_bytes, int B, int T,
+                    int d, float drop_p, uint64_t seed, void* stream);
+/* dx = dy * 1[out > 0] / (1-p): backward of drop(relu(.)) given the forward output */
+int ttts_relu_dropout_bwd(const float* dy, const float* out, float* dx, int64_t n, float drop_p, void* stream);
+/* dx = dy * keep(seed, i) / (1-p) */
+int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, void* stream);
+/* z = x + y */
+int ttts_add(const float* x, const float* y, float* z, int64_t n, void* stream);
+/* stop-token head, LinearNorm(d_model, 1) (model/model.py:226,313): y[m] = x[m,:].w + b, and its backward */
+int ttts_rowdot_fwd(const float* x, const float* w, const float* b, float* y, int64_t M, int d, void* stream);
+size_t ttts_rowdot_bwd_workspace_bytes(int d);
+int ttts_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx_accum, float* dw, float* db, float* ws,
+                    size_t ws_bytes, int64_t M, int d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTTS_HIP_H */

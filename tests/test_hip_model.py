@@ -1,0 +1,159 @@
+"""End-to-end parity of the HIP TransformerTTS against the CPU oracle (fp64 evaluation of the restated
+reference) on identical seed-defined weights and batches, dropout disabled exactly as for the golden fixtures
+(all nn.Dropout.p = 0, MultiheadAttention.dropout = 0).  Gate: 1e-4 rel-L2 (north_star) on pred_melspec,
+post_melspec, pred_stop, every alignment map, every parameter gradient and the updated BN buffers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+GATE = 1e-4
+
+
+def _no_dropout(m):
+    from transformertts_amd.model.layers import MultiheadAttention
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, MultiheadAttention):
+            mod.dropout = 0.0
+
+
+def _build(cfg_name, w_seed):
+    from oracle import model_config, fill_state
+    from transformertts_amd.model import TransformerTTS
+    cfg = model_config(cfg_name)
+    m = TransformerTTS(**cfg, device="cuda")
+    m.load_state_dict(fill_state(cfg, w_seed), strict=True)
+    m = m.to("cuda")
+    _no_dropout(m)
+    return cfg, m
+
+
+def _oracle64(cfg, w_seed):
+    from oracle import fill_state
+    sd = fill_state(cfg, w_seed)
+    for k in list(sd):
+        if sd[k].is_floating_point():
+            sd[k] = sd[k].double()
+            if "running" not in k and k != "pe.pe":
+                sd[k].requires_grad_(True)
+    return sd
+
+
+@pytest.mark.parametrize("cfg_name,B,Tp,Tm,w_seed,b_seed", [("tiny", 3, 12, 40, 11, 21), ("base", 2, 60, 300, 12, 22),
+                                                            ("base", 4, 100, 870, 13, 23)])
+def test_forward_backward_vs_oracle(cfg_name, B, Tp, Tm, w_seed, b_seed):
+    from oracle import synth_batch, oracle_forward, oracle_loss
+    from transformertts_amd.loss import TransformerTTSLoss
+    cfg, m = _build(cfg_name, w_seed)
+    batch = synth_batch(B, Tp, Tm, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=b_seed)
+    dev = torch.device("cuda")
+    args = [batch[k].to(dev) for k in ("phoneme", "melspec", "phoneme_lens", "melspec_lens")]
+
+    # eval forward
+    m.eval()
+    with torch.no_grad():
+        out = m(*args)
+    sd = _oracle64(cfg, w_seed)
+    with torch.no_grad():
+        ref = oracle_forward(sd, cfg, batch["phoneme"], batch["melspec"].double(), batch["phoneme_lens"],
+                             batch["melspec_lens"], training=False)
+    for k in ("pred_melspec", "post_melspec", "pred_stop"):
+        assert rel_l2(out[k], ref[k]) < GATE, ("eval", k, rel_l2(out[k], ref[k]))
+    for a, r in zip(out["alignments"], ref["alignments"]):
+        assert rel_l2(a, r) < GATE
+
+    # train forward + loss + backward
+    m.train()
+    out = m(*args)
+    crit = TransformerTTSLoss(8.0).to(dev)
+    loss = crit(out, args[1], args[3])
+    loss["total"].backward()
+    ref = oracle_forward(sd, cfg, batch["phoneme"], batch["melspec"].double(), batch["phoneme_lens"],
+                         batch["melspec_lens"], training=True, dropout=False)
+    rloss = oracle_loss(ref, batch["melspec"].double(), batch["melspec_lens"])
+    rloss["total"].backward()
+    errs = {}
+    for k in ("pred_melspec", "post_melspec", "pred_stop"):
+        errs[k] = rel_l2(out[k], ref[k])
+    for i, (a, r) in enumerate(zip(out["alignments"], ref["alignments"])):
+        errs[f"align{i}"] = rel_l2(a, r)
+    errs["loss"] = abs(loss["total"].item() - rloss["total"].item()) / abs(rloss["total"].item())
+    gerrs = {}
+    for name, p in m.named_parameters():
+        rg = sd[name].grad
+        if rg.norm().item() < 1e-7 * max(1.0, sd[name].detach().norm().item()):   # analytically-zero grads (conv bias before BN)
+            assert p.grad.abs().max().item() < 1e-4, name
+            continue
+        gerrs[name] = rel_l2(p.grad, rg)
+    for name, buf in m.named_buffers():
+        if "running_" in name:
+            errs[name] = rel_l2(buf, sd[name])
+        if "num_batches" in name:
+            assert int(buf.item()) == int(sd[name])
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/parity_{cfg_name}_B{B}_Tm{Tm}.txt", "w") as f:
+        for k, v in sorted({**errs, **{"grad/" + k: v for k, v in gerrs.items()}}.items(), key=lambda kv: -kv[1]):
+            f.write(f"{v:.3e} {k}\n")
+    bad = {k: v for k, v in {**errs, **gerrs}.items() if not v < GATE}
+    assert not bad, bad
+
+
+def test_golden_outputs_direct(golden_dir):
+    """HIP path against the committed reference outputs themselves (fp32 reference run), base config."""
+    from oracle import synth_batch
+    g = np.load(os.path.join(golden_dir, "base_model.npz"))
+    cfg, m = _build(str(g["meta/cfg_name"]), int(g["meta/w_seed"]))
+    batch = synth_batch(int(g["meta/B"]), int(g["meta/Tp"]), int(g["meta/Tm"]), cfg["n_mels"], cfg["n_phon"], ragged=True,
+                        seed=int(g["meta/b_seed"]))
+    args = [batch[k].to("cuda") for k in ("phoneme", "melspec", "phoneme_lens", "melspec_lens")]
+    st = int(g["meta/align_stride"])
+    m.train()
+    out = m(*args)
+    for k in ("pred_melspec", "post_melspec", "pred_stop"):
+        assert rel_l2(out[k], torch.from_numpy(g[f"train/{k}"])) < GATE, k
+    for i, a in enumerate(out["alignments"]):
+        assert rel_l2(a[:, :, ::st], torch.from_numpy(g[f"train/align{i}"])) < GATE
+
+
+def test_training_step_surface():
+    """LightningModule.training_step: loss/gradients vs the oracle's restated step (dropout off, p_tf < 1 so the
+    scheduled-sampling mix is exercised with an injected uniform draw)."""
+    import transformertts_amd.utils.util as U
+    from oracle import model_config, fill_state, synth_batch, oracle_training_step
+    from transformertts_amd.lightning_module import LightningModule
+    cfg = model_config("tiny")
+    config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
+              "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000}}
+    lm = LightningModule(config).to("cuda")
+    lm.model.load_state_dict(fill_state(cfg, 11), strict=True)
+    _no_dropout(lm)
+    lm.train()
+    lm.current_epoch = 120
+    batch = synth_batch(3, 12, 40, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=21)
+    u = torch.rand(3, 1, batch["melspec"].size(1), generator=torch.Generator().manual_seed(5))
+    orig = torch.rand
+    torch.rand = lambda *a, **k: u.to(k.get("device", "cpu"))
+    try:
+        loss = lm.training_step(dict(batch), 1)
+    finally:
+        torch.rand = orig
+    loss.backward()
+    sd = _oracle64(cfg, 11)
+    b64 = dict(batch, melspec=batch["melspec"].double())
+    rloss, _, _ = oracle_training_step(sd, cfg, b64, epoch=120, seed_u=u.double())
+    rloss["total"].backward()
+    assert abs(loss.item() - rloss["total"].item()) < 1e-4 * abs(rloss["total"].item())
+    for name, p in lm.model.named_parameters():
+        rg = sd[name].grad
+        if rg.norm().item() < 1e-7:
+            continue
+        assert rel_l2(p.grad, rg) < 2e-4, (name, rel_l2(p.grad, rg))
+    for name, buf in lm.model.named_buffers():
+        if "num_batches" in name:
+            assert int(buf.item()) == 2

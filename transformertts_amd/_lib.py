@@ -1,0 +1,83 @@
+"""ctypes binding of libttts_hip.so (the C ABI declared in include/ttts_hip.h).
+
+There is deliberately no fallback: if the shared library has not been built (run
+`python -m transformertts_amd.build` or `__graft_entry__.build()`), importing a kernel raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libttts_hip.so")
+
+P, I, L, F, U, Z = c_void_p, c_int, c_int64, c_float, c_uint64, c_size_t
+
+# name -> (restype, argtypes); mirrors include/ttts_hip.h one to one
+SIGNATURES = {
+    "ttts_last_error": (c_char_p, []),
+    "ttts_abi_version": (I, []),
+    "ttts_linear_fwd": (I, [P, P, P, P, P, L, I, I, I, F, U, I, I, P]),
+    "ttts_linear_bwd_data": (I, [P, P, P, P, L, I, I, P]),
+    "ttts_wgrad_workspace_bytes": (Z, [L, I, I, I]),
+    "ttts_linear_bwd_weight": (I, [P, P, P, P, P, Z, L, I, I, I, I, P]),
+    "ttts_conv1d_pack_bytes": (Z, [I, I, I]),
+    "ttts_conv1d_pack_weight": (I, [P, P, P, I, I, I, P]),
+    "ttts_conv1d_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "ttts_conv1d_bwd_data": (I, [P, P, P, I, I, I, I, I, P]),
+    "ttts_conv1d_bwd_weight": (I, [P, P, P, P, P, Z, I, I, I, I, I, P]),
+    "ttts_bn_workspace_bytes": (Z, [L, I]),
+    "ttts_bn_train_stats": (I, [P, P, P, P, P, P, P, Z, L, I, F, F, P]),
+    "ttts_bn_eval_stats": (I, [P, P, P, P, I, F, P]),
+    "ttts_bn_apply_fwd": (I, [P, P, P, P, P, P, L, I, I, F, U, P]),
+    "ttts_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, Z, L, I, I, F, U, P]),
+    "ttts_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
+    "ttts_layernorm_bwd_workspace_bytes": (Z, [I]),
+    "ttts_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, P]),
+    "ttts_attention_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P]),
+    "ttts_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P]),
+    "ttts_embedding_fwd": (I, [P, P, P, L, I, I, P]),
+    "ttts_embedding_bwd": (I, [P, P, P, L, I, I, P]),
+    "ttts_posenc_fwd": (I, [P, P, P, P, I, I, I, F, U, P]),
+    "ttts_posenc_bwd_workspace_bytes": (Z, []),
+    "ttts_posenc_bwd": (I, [P, P, P, P, P, Z, I, I, I, F, U, P]),
+    "ttts_relu_dropout_bwd": (I, [P, P, P, L, F, P]),
+    "ttts_dropout_bwd": (I, [P, P, L, F, U, P]),
+    "ttts_add": (I, [P, P, P, L, P]),
+    "ttts_rowdot_fwd": (I, [P, P, P, P, L, I, P]),
+    "ttts_rowdot_bwd_workspace_bytes": (Z, [I]),
+    "ttts_rowdot_bwd": (I, [P, P, P, P, P, P, P, Z, L, I, P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library; raises (never falls back) when it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. "
+            "Run `python -m transformertts_amd.build` (needs hipcc); there is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild the extension")
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    msg = load().ttts_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")

@@ -1,0 +1,573 @@
+// Scaled dot-product attention (head_dim 64) forward + backward on fp32 MFMA, gfx950.
+//
+// All three uses of the path share these kernels: encoder self-attention (key-padding mask), decoder
+// masked self-attention (causal + key-padding) and encoder-decoder cross-attention (key-padding, per-head
+// post-dropout weights written out).  Masks are computed from `key_lens` in-kernel; no mask / score tensor
+// ever reaches HBM except the mandatory cross-attention weights.
+//
+// Orientation ("key on the accumulator rows, query on the lane"): scores are produced transposed,
+//   S^T[key][query] = K . (Q*scale)^T      (v_mfma_f32_32x32x2_f32, A = K tile from LDS, B = Q in registers)
+// so each lane owns ONE query column: its 16 accumulator registers are 16 keys of that query, the other
+// half-wave holds the other 16.  Row max / row sum are therefore lane-local plus one lane^32 exchange
+// (wavefront shuffle), and the probabilities are already in the B-operand layout of the next product
+//   O^T[d][query] += V^T[d][key] . P^T[key][query]
+// with no cross-lane movement at all.  The backward kernels use the same trick in both orientations.
+#include "ttts_common.h"
+
+namespace ttts {
+
+constexpr int HD = 64;            // head dim
+constexpr int KT_LD = HD + 1;     // LDS row stride (odd: conflict-free "row per lane" reads)
+constexpr int QB = 128;           // rows per workgroup (4 waves x 32)
+constexpr float NEG_INF = -__builtin_inff();
+
+struct AttnArgs {
+    const float* q; const float* k; const float* v;
+    float* o; float* lse; float* attn;
+    const float* dout; float* delta; float* dq; float* dk; float* dv;
+    const int64_t* key_lens;
+    int B, H, Tq, Tk;
+    int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    float drop_scale; uint32_t thr; uint64_t seed;
+};
+
+// ---- cooperative tile loaders (256 threads): 32 rows x 64 floats, rows beyond `nrows` read as zero
+__device__ __forceinline__ void load_tile_regs(const float* base, long row0, int nrows_total, int ld, int tid,
+                                               float4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int row = (tid >> 4) + 16 * i, c4 = tid & 15;
+        long gr = row0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < nrows_total) v = *reinterpret_cast<const float4*>(base + gr * ld + c4 * 4);
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void store_tile_lds(float* dst, int ldd, int tid, const float4 (&r)[2], float scale) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int row = (tid >> 4) + 16 * i, c4 = tid & 15;
+        float* d = dst + row * ldd + c4 * 4;
+        d[0] = r[i].x * scale; d[1] = r[i].y * scale; d[2] = r[i].z * scale; d[3] = r[i].w * scale;
+    }
+}
+// one wave stages its own 32 x 64 tile (rows beyond nrows_total -> 0) into `dst` (stride KT_LD)
+__device__ __forceinline__ void wave_stage_tile(const float* base, long row0, long nrows_total, int ld, int lane,
+                                                float* dst, float scale) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int row = (lane >> 4) + 4 * i, c4 = lane & 15;
+        long gr = row0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < nrows_total) v = *reinterpret_cast<const float4*>(base + gr * ld + c4 * 4);
+        float* d = dst + row * KT_LD + c4 * 4;
+        d[0] = v.x * scale; d[1] = v.y * scale; d[2] = v.z * scale; d[3] = v.w * scale;
+    }
+}
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS traffic of one wave: make the writes above visible to the reads below (same wave)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// write a 2 x (32x32) accumulator pair holding X^T[d][row] (row on the lane) as rows of 64 floats
+__device__ __forceinline__ void wave_store_rows(const f32x16 (&acc)[2], float* scratch, float* gbase, long row0,
+                                                long nrows_total, int ld, int lane, float scale) {
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scratch[l31 * KT_LD + blk * 32 + acc_row(r, half)] = acc[blk][r] * scale;
+    wave_lds_sync();
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+        float v = scratch[i * KT_LD + lane];
+        if (row0 + i < nrows_total) gbase[(row0 + i) * ld + lane] = v;
+    }
+    wave_lds_sync();
+}
+
+// =====================================================================================  forward
+template <bool CAUSAL, bool WRITE_A>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ks[32 * KT_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[32 * HD];
+    __shared__ __attribute__((aligned(16))) float scratch_all[4 * 32 * KT_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int qblk = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;   // heaviest causal blocks first
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = qblk * QB, qw0 = q0 + wave * 32;
+    const int qg = qw0 + l31;
+    float* scratch = scratch_all + wave * 32 * KT_LD;
+
+    int klen = (int)a.key_lens[b];
+    if (klen > a.Tk) klen = a.Tk;
+    if (klen < 0) klen = 0;
+    int kend = klen;
+    if (CAUSAL && kend > q0 + QB) kend = q0 + QB;
+    const int ntiles_live = (kend + 31) / 32;
+    const int ntiles = WRITE_A ? (a.Tk + 31) / 32 : ntiles_live;
+    int wave_kend = kend;
+    if (CAUSAL && wave_kend > qw0 + 32) wave_kend = qw0 + 32;
+
+    const float* qb_ = a.q + (long)b * a.Tq * a.ldq + h * HD;
+    const float* kb_ = a.k + (long)b * a.Tk * a.ldk + h * HD;
+    const float* vb_ = a.v + (long)b * a.Tk * a.ldv + h * HD;
+
+    // Q fragment: lane (query l31, half) holds Q[q][2j+half] * sqrt(1/64)
+    float qreg[32];
+    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 32; ++j) qreg[j] = scratch[l31 * KT_LD + 2 * j + half];
+    wave_lds_sync();
+
+    float m = NEG_INF, l = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+
+    const long arow = ((long)(b * a.H + h) * a.Tq);   // row base of the (B,H,Tq,*) outputs
+
+    auto scores = [&](f32x16& s) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            float kf = Ks[l31 * KT_LD + 2 * j + half];
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, qreg[j], s, 0, 0, 0);
+        }
+    };
+    auto alive = [&](int key_g) -> bool { return key_g < klen && (!CAUSAL || key_g <= qg); };
+
+    float4 rk[2], rv[2];
+    if (WRITE_A) {
+        // ---------------- pass 1: row max / row sum only
+        if (ntiles_live > 0) load_tile_regs(kb_, 0, a.Tk, a.ldk, tid, rk);
+        for (int t = 0; t < ntiles_live; ++t) {
+            __syncthreads();
+            store_tile_lds(Ks, KT_LD, tid, rk, 1.f);
+            __syncthreads();
+            if (t + 1 < ntiles_live) load_tile_regs(kb_, (long)(t + 1) * 32, a.Tk, a.ldk, tid, rk);
+            f32x16 s;
+            scores(s);
+            float mx = NEG_INF;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int key_g = t * 32 + acc_row(r, half);
+                s[r] = alive(key_g) ? s[r] : NEG_INF;
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float m_new = fmaxf(m, mx);
+            float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+            float alpha = __expf(m - m_use);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ps += __expf(s[r] - m_use);
+            l = l * alpha + ps;
+            m = m_new;
+        }
+        l = l + __shfl_xor(l, 32, 64);
+    }
+
+    const float m_fin = (m == NEG_INF) ? 0.f : m;
+    const float inv_l = (l > 0.f) ? 1.f / l : 0.f;
+
+    // ---------------- main pass
+    if (ntiles > 0) {
+        load_tile_regs(kb_, 0, a.Tk, a.ldk, tid, rk);
+        load_tile_regs(vb_, 0, a.Tk, a.ldv, tid, rv);
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        store_tile_lds(Ks, KT_LD, tid, rk, 1.f);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row = (tid >> 4) + 16 * i, c4 = tid & 15;
+            *reinterpret_cast<float4*>(Vs + row * HD + c4 * 4) = rv[i];
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            load_tile_regs(kb_, (long)(t + 1) * 32, a.Tk, a.ldk, tid, rk);
+            load_tile_regs(vb_, (long)(t + 1) * 32, a.Tk, a.ldv, tid, rv);
+        }
+        if (!WRITE_A && t * 32 >= wave_kend) continue;   // tile entirely above this wave's causal frontier
+
+        f32x16 s;
+        scores(s);
+        float p[16];
+        if (WRITE_A) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int key_g = t * 32 + acc_row(r, half);
+                p[r] = alive(key_g) ? __expf(s[r] - m_fin) * inv_l : 0.f;
+            }
+        } else {
+            float mx = NEG_INF;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int key_g = t * 32 + acc_row(r, half);
+                s[r] = alive(key_g) ? s[r] : NEG_INF;
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float m_new = fmaxf(m, mx);
+            float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+            float alpha = __expf(m - m_use);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = __expf(s[r] - m_use); ps += p[r]; }
+            l = l * alpha + ps;
+            m = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        }
+        if (a.thr != 0u) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int key_g = t * 32 + acc_row(r, half);
+                uint64_t idx = (uint64_t)(arow + qg) * (uint64_t)a.Tk + (uint64_t)key_g;
+                p[r] = keep_elem(a.seed, idx, a.thr) ? p[r] * a.drop_scale : 0.f;
+            }
+        }
+        if (WRITE_A) {
+            // transpose the 32(key) x 32(query) tile through LDS so each weight row is written as 128-B segments
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scratch[l31 * 33 + acc_row(r, half)] = p[r];
+            wave_lds_sync();
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                int qrow = 2 * i + half;
+                float v = scratch[qrow * 33 + l31];
+                int q_g = qw0 + qrow, key_g = t * 32 + l31;
+                if (q_g < a.Tq && key_g < a.Tk) a.attn[(arow + q_g) * a.Tk + key_g] = v;
+            }
+            wave_lds_sync();
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int krow = acc_row(r, half);
+            float v0 = Vs[krow * HD + l31];
+            float v1 = Vs[krow * HD + 32 + l31];
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, p[r], o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, p[r], o[1], 0, 0, 0);
+        }
+    }
+
+    float out_scale = 1.f;
+    float lse_v;
+    if (WRITE_A) {
+        lse_v = m_fin + __logf(l > 0.f ? l : 1.f);
+    } else {
+        float lt = l + __shfl_xor(l, 32, 64);
+        out_scale = (lt > 0.f) ? 1.f / lt : 0.f;
+        lse_v = ((m == NEG_INF) ? 0.f : m) + __logf(lt > 0.f ? lt : 1.f);
+    }
+    if (a.lse != nullptr && half == 0 && qg < a.Tq) a.lse[arow + qg] = lse_v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= out_scale; o[1][r] *= out_scale; }
+    __syncthreads();
+    wave_store_rows(o, scratch, a.o + (long)b * a.Tq * a.ldo + h * HD, qw0, a.Tq, a.ldo, lane, 1.f);
+}
+
+// =====================================================================================  backward: dQ (+ delta)
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ks[32 * KT_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[32 * KT_LD];
+    __shared__ __attribute__((aligned(16))) float scratch_all[4 * 32 * KT_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int qblk = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = qblk * QB, qw0 = q0 + wave * 32;
+    const int qg = qw0 + l31;
+    float* scratch = scratch_all + wave * 32 * KT_LD;
+
+    int klen = (int)a.key_lens[b];
+    if (klen > a.Tk) klen = a.Tk;
+    if (klen < 0) klen = 0;
+    int kend = klen;
+    if (CAUSAL && kend > q0 + QB) kend = q0 + QB;
+    const int ntiles = (kend + 31) / 32;
+    int wave_kend = kend;
+    if (CAUSAL && wave_kend > qw0 + 32) wave_kend = qw0 + 32;
+
+    const float* qb_ = a.q + (long)b * a.Tq * a.ldq + h * HD;
+    const float* kb_ = a.k + (long)b * a.Tk * a.ldk + h * HD;
+    const float* vb_ = a.v + (long)b * a.Tk * a.ldv + h * HD;
+    const float* ob_ = a.o + (long)b * a.Tq * a.ldo + h * HD;
+    const float* gb_ = a.dout + (long)b * a.Tq * a.ldo + h * HD;
+    const long arow = ((long)(b * a.H + h) * a.Tq);
+
+    float qreg[32], greg[32];
+    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 32; ++j) qreg[j] = scratch[l31 * KT_LD + 2 * j + half];
+    wave_lds_sync();
+    wave_stage_tile(gb_, qw0, a.Tq, a.ldo, lane, scratch, 1.f);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 32; ++j) greg[j] = scratch[l31 * KT_LD + 2 * j + half];
+    wave_lds_sync();
+    wave_stage_tile(ob_, qw0, a.Tq, a.ldo, lane, scratch, 1.f);
+    wave_lds_sync();
+    float delta = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) delta += greg[j] * scratch[l31 * KT_LD + 2 * j + half];
+    wave_lds_sync();
+    delta += __shfl_xor(delta, 32, 64);
+    if (half == 0 && qg < a.Tq) a.delta[arow + qg] = delta;
+    const float lse_q = (qg < a.Tq) ? a.lse[arow + qg] : 0.f;
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+
+    float4 rk[2], rv[2];
+    if (ntiles > 0) {
+        load_tile_regs(kb_, 0, a.Tk, a.ldk, tid, rk);
+        load_tile_regs(vb_, 0, a.Tk, a.ldv, tid, rv);
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        store_tile_lds(Ks, KT_LD, tid, rk, 1.f);
+        store_tile_lds(Vs, KT_LD, tid, rv, 1.f);
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            load_tile_regs(kb_, (long)(t + 1) * 32, a.Tk, a.ldk, tid, rk);
+            load_tile_regs(vb_, (long)(t + 1) * 32, a.Tk, a.ldv, tid, rv);
+        }
+        if (t * 32 >= wave_kend) continue;
+
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            float kf = Ks[l31 * KT_LD + 2 * j + half];
+            float vf = Vs[l31 * KT_LD + 2 * j + half];
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, qreg[j], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, greg[j], dp, 0, 0, 0);
+        }
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int key_g = t * 32 + acc_row(r, half);
+            bool live = key_g < klen && (!CAUSAL || key_g <= qg);
+            float p = live ? __expf(s[r] - lse_q) : 0.f;
+            float g = dp[r];
+            if (a.thr != 0u) {
+                uint64_t idx = (uint64_t)(arow + qg) * (uint64_t)a.Tk + (uint64_t)key_g;
+                g = keep_elem(a.seed, idx, a.thr) ? g * a.drop_scale : 0.f;
+            }
+            ds[r] = p * (g - delta);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int krow = acc_row(r, half);
+            float k0 = Ks[krow * KT_LD + l31];
+            float k1 = Ks[krow * KT_LD + 32 + l31];
+            dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0, ds[r], dq[0], 0, 0, 0);
+            dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1, ds[r], dq[1], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    wave_store_rows(dq, scratch, a.dq + (long)b * a.Tq * a.lddq + h * HD, qw0, a.Tq, a.lddq, lane, 0.125f);
+}
+
+// =====================================================================================  backward: dK, dV
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Qs[32 * KT_LD];
+    __shared__ __attribute__((aligned(16))) float Gs[32 * KT_LD];
+    __shared__ float lse_s[32], delta_s[32];
+    __shared__ __attribute__((aligned(16))) float scratch_all[4 * 32 * KT_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int kblk = blockIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int k0 = kblk * QB, kw0 = k0 + wave * 32;
+    const int kg = kw0 + l31;
+    float* scratch = scratch_all + wave * 32 * KT_LD;
+
+    int klen = (int)a.key_lens[b];
+    if (klen > a.Tk) klen = a.Tk;
+    if (klen < 0) klen = 0;
+
+    const float* qb_ = a.q + (long)b * a.Tq * a.ldq + h * HD;
+    const float* kb_ = a.k + (long)b * a.Tk * a.ldk + h * HD;
+    const float* vb_ = a.v + (long)b * a.Tk * a.ldv + h * HD;
+    const float* gb_ = a.dout + (long)b * a.Tq * a.ldo + h * HD;
+    const long arow = ((long)(b * a.H + h) * a.Tq);
+
+    float kreg[32], vreg[32];
+    wave_stage_tile(kb_, kw0, a.Tk, a.ldk, lane, scratch, 1.f);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 32; ++j) kreg[j] = scratch[l31 * KT_LD + 2 * j + half];
+    wave_lds_sync();
+    wave_stage_tile(vb_, kw0, a.Tk, a.ldv, lane, scratch, 1.f);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 32; ++j) vreg[j] = scratch[l31 * KT_LD + 2 * j + half];
+    wave_lds_sync();
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+
+    const int nqt = (a.Tq + 31) / 32;
+    int qt_begin = CAUSAL ? (k0 / 32) : 0;        // queries below the block's first key never see it
+    if (k0 >= klen) qt_begin = nqt;               // whole key block is padding: gradients are zero
+
+    float4 rq[2], rg[2];
+    if (qt_begin < nqt) {
+        load_tile_regs(qb_, (long)qt_begin * 32, a.Tq, a.ldq, tid, rq);
+        load_tile_regs(gb_, (long)qt_begin * 32, a.Tq, a.ldo, tid, rg);
+    }
+    for (int qt = qt_begin; qt < nqt; ++qt) {
+        __syncthreads();
+        store_tile_lds(Qs, KT_LD, tid, rq, 0.125f);
+        store_tile_lds(Gs, KT_LD, tid, rg, 1.f);
+        if (tid < 32) {
+            int q = qt * 32 + tid;
+            lse_s[tid] = (q < a.Tq) ? a.lse[arow + q] : 0.f;
+            delta_s[tid] = (q < a.Tq) ? a.delta[arow + q] : 0.f;
+        }
+        __syncthreads();
+        if (qt + 1 < nqt) {
+            load_tile_regs(qb_, (long)(qt + 1) * 32, a.Tq, a.ldq, tid, rq);
+            load_tile_regs(gb_, (long)(qt + 1) * 32, a.Tq, a.ldo, tid, rg);
+        }
+        if (CAUSAL && qt * 32 + 31 < kw0) continue;   // every query of the tile precedes this wave's keys
+
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            float qf = Qs[l31 * KT_LD + 2 * j + half];
+            float gf = Gs[l31 * KT_LD + 2 * j + half];
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf, kreg[j], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gf, vreg[j], dp, 0, 0, 0);
+        }
+        float pd[16], ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qrow = acc_row(r, half);
+            const int q_g = qt * 32 + qrow;
+            bool live = kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq;
+            float p = live ? __expf(s[r] - lse_s[qrow]) : 0.f;
+            float g = dp[r];
+            float pk = p;
+            if (a.thr != 0u) {
+                uint64_t idx = (uint64_t)(arow + q_g) * (uint64_t)a.Tk + (uint64_t)kg;
+                bool keep = keep_elem(a.seed, idx, a.thr);
+                g = keep ? g * a.drop_scale : 0.f;
+                pk = keep ? p * a.drop_scale : 0.f;
+            }
+            pd[r] = pk;
+            ds[r] = p * (g - delta_s[qrow]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qrow = acc_row(r, half);
+            float g0 = Gs[qrow * KT_LD + l31];
+            float g1 = Gs[qrow * KT_LD + 32 + l31];
+            float q0f = Qs[qrow * KT_LD + l31];
+            float q1f = Qs[qrow * KT_LD + 32 + l31];
+            dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, pd[r], dv[0], 0, 0, 0);
+            dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, pd[r], dv[1], 0, 0, 0);
+            dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0f, ds[r], dk[0], 0, 0, 0);
+            dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1f, ds[r], dk[1], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    wave_store_rows(dk, scratch, a.dk + (long)b * a.Tk * a.lddk + h * HD, kw0, a.Tk, a.lddk, lane, 1.f);
+    wave_store_rows(dv, scratch, a.dv + (long)b * a.Tk * a.lddv + h * HD, kw0, a.Tk, a.lddv, lane, 1.f);
+}
+
+static int check_common(const char* name, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, float drop_p) {
+    TTTS_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "%s: bad dims", name);
+    TTTS_REQUIRE(B <= 65535 && H <= 65535, "%s: B and H must be <= 65535", name);
+    TTTS_REQUIRE(ldq >= H * HD && ldk >= H * HD && ldv >= H * HD && ldo >= H * HD, "%s: row strides must be >= H*64", name);
+    TTTS_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "%s: row strides must be multiples of 4", name);
+    TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "%s: bad dropout p", name);
+    return TTTS_OK;
+}
+
+}  // namespace ttts
+
+using namespace ttts;
+
+extern "C" {
+
+int ttts_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
+                       const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
+                       int causal, float drop_p, uint64_t seed, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TTTS_REQUIRE(q && k && v && o && key_lens, "attention_fwd: null pointer");
+    int rc = check_common("attention_fwd", B, H, Tq, Tk, ldq, ldk, ldv, ldo, drop_p);
+    if (rc) return rc;
+    TTTS_REQUIRE(!(causal && attn), "attention_fwd: weights output is only provided for the non-causal (cross) form");
+    TTTS_REQUIRE(!causal || Tq == Tk, "attention_fwd: causal form needs Tq == Tk");
+    TTTS_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0, "attention_fwd: q/k/v must be 16-byte aligned");
+    AttnArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.attn = attn; a.key_lens = key_lens;
+    a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+    a.drop_scale = 1.f / (1.f - drop_p);
+    a.seed = seed;
+    dim3 grid(cdiv(Tq, QB), H, B);
+    if (causal)
+        hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), 0, stream, a);
+    else if (attn)
+        hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), 0, stream, a);
+    TTTS_LAUNCH_CHECK("attn_fwd_kernel");
+    return TTTS_OK;
+}
+
+int ttts_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* do_,
+                       const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
+                       int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                       int causal, float drop_p, uint64_t seed, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TTTS_REQUIRE(q && k && v && o && do_ && lse && delta && dq && dk && dv && key_lens, "attention_bwd: null pointer");
+    int rc = check_common("attention_bwd", B, H, Tq, Tk, ldq, ldk, ldv, ldo, drop_p);
+    if (rc) return rc;
+    TTTS_REQUIRE(lddq >= H * HD && lddk >= H * HD && lddv >= H * HD, "attention_bwd: gradient strides must be >= H*64");
+    TTTS_REQUIRE(!causal || Tq == Tk, "attention_bwd: causal form needs Tq == Tk");
+    TTTS_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)do_) & 15) == 0,
+                 "attention_bwd: q/k/v/o/do must be 16-byte aligned");
+    AttnArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.o = const_cast<float*>(o); a.dout = do_; a.lse = const_cast<float*>(lse);
+    a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv; a.key_lens = key_lens;
+    a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+    a.drop_scale = 1.f / (1.f - drop_p);
+    a.seed = seed;
+    dim3 gq(cdiv(Tq, QB), H, B), gk(cdiv(Tk, QB), H, B);
+    if (causal) {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), gq, dim3(256), 0, stream, a);
+        TTTS_LAUNCH_CHECK("attn_bwd_dq_kernel");
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), gk, dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), gq, dim3(256), 0, stream, a);
+        TTTS_LAUNCH_CHECK("attn_bwd_dq_kernel");
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), gk, dim3(256), 0, stream, a);
+    }
+    TTTS_LAUNCH_CHECK("attn_bwd_dkv_kernel");
+    return TTTS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,328 @@
+// Small row-wise / element-wise pieces of the path: embedding gather + scatter-add, scaled positional
+// encoding, dropout / relu backward masks, the 1-wide stop-token head.  All HBM-bound; float4 accesses,
+// grid-stride loops capped at 8 blocks per CU, fixed-order reductions.
+#include <stdarg.h>
+
+#include "ttts_common.h"
+
+namespace ttts {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline int ew_grid(long n_items) {
+    long g = (n_items + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------ embedding
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                            float* __restrict__ out, long n, int vocab, int d4) {
+    // one wave per output row, float4 per lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long row = (long)blockIdx.x * 4 + wave; row < n; row += (long)gridDim.x * 4) {
+        long id = ids[row];
+        if (id < 0) id = 0;
+        if (id >= vocab) id = vocab - 1;
+        const float4* src = reinterpret_cast<const float4*>(table) + id * d4;
+        float4* dst = reinterpret_cast<float4*>(out) + row * d4;
+        for (int c = lane; c < d4; c += 64) dst[c] = src[c];
+    }
+}
+
+// one workgroup per vocabulary row: scans all ids in order and sums the matching rows (deterministic)
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
+                                                            float* __restrict__ dtable, long n, int d) {
+    const int v = blockIdx.x;
+    constexpr int MAXPER = 4;   // d <= 1024
+    float acc[MAXPER] = {0.f, 0.f, 0.f, 0.f};
+    for (long i = 0; i < n; ++i) {
+        if (ids[i] == v) {
+#pragma unroll
+            for (int j = 0; j < MAXPER; ++j) {
+                int c = threadIdx.x + 256 * j;
+                if (c < d) acc[j] += dout[i * d + c];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXPER; ++j) {
+        int c = threadIdx.x + 256 * j;
+        if (c < d) dtable[(long)v * d + c] = acc[j];
+    }
+}
+
+// ------------------------------------------------------------------ positional encoding
+__global__ __launch_bounds__(256) void posenc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                                         const float* __restrict__ alpha, float* __restrict__ y, long n4,
+                                                         int T, int d, float drop_scale, uint32_t thr, uint64_t seed) {
+    const float a = alpha[0];
+    const long td = (long)T * d;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long e = i * 4;
+        const long pe_off = e % td;   // (t, c) offset inside the (T, d) table
+        float4 xv = *reinterpret_cast<const float4*>(x + e);
+        float4 pv = *reinterpret_cast<const float4*>(pe + pe_off);
+        float o[4] = {xv.x + a * pv.x, xv.y + a * pv.y, xv.z + a * pv.z, xv.w + a * pv.w};
+        if (thr != 0u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = keep_elem(seed, (uint64_t)(e + j), thr) ? o[j] * drop_scale : 0.f;
+        }
+        *reinterpret_cast<float4*>(y + e) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+constexpr int PE_BWD_BLOCKS = 1024;
+
+// dx = dy*keep/(1-p); block partial of sum(dx * pe) -> ws[block]
+__global__ __launch_bounds__(256) void posenc_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pe,
+                                                         float* __restrict__ dx, float* __restrict__ ws, long n4, int T,
+                                                         int d, float drop_scale, uint32_t thr, uint64_t seed) {
+    __shared__ float red[4];
+    const long td = (long)T * d;
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long e = i * 4;
+        float4 gv = *reinterpret_cast<const float4*>(dy + e);
+        float4 pv = *reinterpret_cast<const float4*>(pe + (e % td));
+        float g[4] = {gv.x, gv.y, gv.z, gv.w};
+        if (thr != 0u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = keep_elem(seed, (uint64_t)(e + j), thr) ? g[j] * drop_scale : 0.f;
+        }
+        s += g[0] * pv.x + g[1] * pv.y + g[2] * pv.z + g[3] * pv.w;
+        *reinterpret_cast<float4*>(dx + e) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void scalar_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int n) {
+    // single wave, fixed order
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += ws[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// ------------------------------------------------------------------ masks
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out,
+                                                               float* __restrict__ dx, long n4, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 g = reinterpret_cast<const float4*>(dy)[i];
+        float4 o = reinterpret_cast<const float4*>(out)[i];
+        float4 r;
+        r.x = o.x > 0.f ? g.x * scale : 0.f;
+        r.y = o.y > 0.f ? g.y * scale : 0.f;
+        r.z = o.z > 0.f ? g.z * scale : 0.f;
+        r.w = o.w > 0.f ? g.w * scale : 0.f;
+        reinterpret_cast<float4*>(dx)[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long n4,
+                                                          float scale, uint32_t thr, uint64_t seed) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long e = i * 4;
+        float4 g = reinterpret_cast<const float4*>(dy)[i];
+        float4 r;
+        r.x = keep_elem(seed, (uint64_t)e, thr) ? g.x * scale : 0.f;
+        r.y = keep_elem(seed, (uint64_t)(e + 1), thr) ? g.y * scale : 0.f;
+        r.z = keep_elem(seed, (uint64_t)(e + 2), thr) ? g.z * scale : 0.f;
+        r.w = keep_elem(seed, (uint64_t)(e + 3), thr) ? g.w * scale : 0.f;
+        reinterpret_cast<float4*>(dx)[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                  float* __restrict__ z, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(x)[i];
+        float4 b = reinterpret_cast<const float4*>(y)[i];
+        reinterpret_cast<float4*>(z)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+// ------------------------------------------------------------------ stop-token head (N = 1)
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ y, long M, int d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float bias = b ? b[0] : 0.f;
+    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+        const float* xr = x + row * d;
+        float s = 0.f;
+        for (int c = lane; c < d; c += 64) s += xr[c] * w[c];
+        s = wave_sum(s);
+        if (lane == 0) y[row] = s + bias;
+    }
+}
+
+constexpr int RD_BWD_BLOCKS = 512;
+
+// dx[m,:] += dy[m]*w ; per-block partials of dw[c] = sum_m dy[m]*x[m,c] and db = sum_m dy[m] -> ws[block][d+1]
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ w, float* __restrict__ dx,
+                                                         float* __restrict__ ws, long M, int d) {
+    __shared__ float red[4][1025];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int MAXPER = 16;
+    const int nper = d >> 6;
+    float acc[MAXPER], wv[MAXPER];
+    float accb = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) { acc[i] = 0.f; wv[i] = (i < nper) ? w[lane + 64 * i] : 0.f; }
+    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+        const float g = dy[row];
+        accb += g;
+#pragma unroll
+        for (int i = 0; i < MAXPER; ++i) {
+            if (i < nper) {
+                long e = row * d + lane + 64 * i;
+                acc[i] += g * x[e];
+                if (dx) dx[e] += g * wv[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i)
+        if (i < nper) red[wave][lane + 64 * i] = acc[i];
+    if (lane == 0) red[wave][1024] = accb;
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256)
+        ws[(long)blockIdx.x * (d + 1) + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (threadIdx.x == 0)
+        ws[(long)blockIdx.x * (d + 1) + d] = (red[0][1024] + red[1][1024]) + (red[2][1024] + red[3][1024]);
+}
+
+__global__ void rowdot_bwd_final_kernel(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db,
+                                        int nblk, int d) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > d) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += ws[(long)b * (d + 1) + c];
+    if (c < d) { if (dw) dw[c] = s; }
+    else if (db) db[0] = s;
+}
+
+}  // namespace ttts
+
+using namespace ttts;
+
+extern "C" {
+
+const char* ttts_last_error(void) { return ttts::g_err; }
+int ttts_abi_version(void) { return 1; }
+
+int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d, void* stream) {
+    TTTS_REQUIRE(ids && table && out, "embedding_fwd: null pointer");
+    TTTS_REQUIRE(n > 0 && vocab > 0 && d > 0 && d % 4 == 0, "embedding_fwd: d=%d must be a multiple of 4", d);
+    int grid = (int)((n + 3) / 4);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, table, out, (long)n, vocab,
+                       d / 4);
+    TTTS_LAUNCH_CHECK("embedding_fwd_kernel");
+    return TTTS_OK;
+}
+
+int ttts_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t n, int vocab, int d, void* stream) {
+    TTTS_REQUIRE(ids && dout && dtable, "embedding_bwd: null pointer");
+    TTTS_REQUIRE(n > 0 && vocab > 0 && d > 0 && d <= 1024, "embedding_bwd: d=%d must be <= 1024", d);
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(vocab), dim3(256), 0, (hipStream_t)stream, ids, dout, dtable, (long)n, d);
+    TTTS_LAUNCH_CHECK("embedding_bwd_kernel");
+    return TTTS_OK;
+}
+
+int ttts_posenc_fwd(const float* x, const float* pe, const float* alpha, float* y, int B, int T, int d, float drop_p,
+                    uint64_t seed, void* stream) {
+    TTTS_REQUIRE(x && pe && alpha && y, "posenc_fwd: null pointer");
+    TTTS_REQUIRE(B > 0 && T > 0 && d > 0 && d % 4 == 0, "posenc_fwd: d=%d must be a multiple of 4", d);
+    TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "posenc_fwd: bad dropout p");
+    long n4 = (long)B * T * d / 4;
+    uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+    hipLaunchKernelGGL(posenc_fwd_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, pe, alpha, y, n4, T, d,
+                       1.f / (1.f - drop_p), thr, seed);
+    TTTS_LAUNCH_CHECK("posenc_fwd_kernel");
+    return TTTS_OK;
+}
+
+size_t ttts_posenc_bwd_workspace_bytes(void) { return (size_t)PE_BWD_BLOCKS * sizeof(float); }
+
+int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, float* ws, size_t ws_bytes, int B, int T,
+                    int d, float drop_p, uint64_t seed, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TTTS_REQUIRE(dy && pe && dx && dalpha && ws, "posenc_bwd: null pointer");
+    TTTS_REQUIRE(B > 0 && T > 0 && d > 0 && d % 4 == 0, "posenc_bwd: bad dims");
+    TTTS_REQUIRE(ws_bytes >= ttts_posenc_bwd_workspace_bytes(), "posenc_bwd: workspace too small");
+    long n4 = (long)B * T * d / 4;
+    int grid = ew_grid(n4);
+    if (grid > PE_BWD_BLOCKS) grid = PE_BWD_BLOCKS;
+    uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+    hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid), dim3(256), 0, stream, dy, pe, dx, ws, n4, T, d, 1.f / (1.f - drop_p),
+                       thr, seed);
+    TTTS_LAUNCH_CHECK("posenc_bwd_kernel");
+    hipLaunchKernelGGL(scalar_reduce_kernel, dim3(1), dim3(64), 0, stream, ws, dalpha, grid);
+    TTTS_LAUNCH_CHECK("scalar_reduce_kernel");
+    return TTTS_OK;
+}
+
+int ttts_relu_dropout_bwd(const float* dy, const float* out, float* dx, int64_t n, float drop_p, void* stream) {
+    TTTS_REQUIRE(dy && out && dx && n > 0 && n % 4 == 0, "relu_dropout_bwd: bad arguments (n %% 4 must be 0)");
+    TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relu_dropout_bwd: bad dropout p");
+    hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, out, dx,
+                       (long)(n / 4), 1.f / (1.f - drop_p));
+    TTTS_LAUNCH_CHECK("relu_dropout_bwd_kernel");
+    return TTTS_OK;
+}
+
+int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, void* stream) {
+    TTTS_REQUIRE(dy && dx && n > 0 && n % 4 == 0, "dropout_bwd: bad arguments (n %% 4 must be 0)");
+    TTTS_REQUIRE(drop_p > 0.f && drop_p < 1.f, "dropout_bwd: p must be in (0,1)");
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, dx, (long)(n / 4),
+                       1.f / (1.f - drop_p), drop_threshold(drop_p), seed);
+    TTTS_LAUNCH_CHECK("dropout_bwd_kernel");
+    return TTTS_OK;
+}
+
+int ttts_add(const float* x, const float* y, float* z, int64_t n, void* stream) {
+    TTTS_REQUIRE(x && y && z && n > 0 && n % 4 == 0, "add: bad arguments (n %% 4 must be 0)");
+    hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y, z, (long)(n / 4));
+    TTTS_LAUNCH_CHECK("add_kernel");
+    return TTTS_OK;
+}
+
+int ttts_rowdot_fwd(const float* x, const float* w, const float* b, float* y, int64_t M, int d, void* stream) {
+    TTTS_REQUIRE(x && w && y && M > 0 && d > 0, "rowdot_fwd: bad arguments");
+    int grid = (int)((M + 3) / 4);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(rowdot_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, b, y, (long)M, d);
+    TTTS_LAUNCH_CHECK("rowdot_fwd_kernel");
+    return TTTS_OK;
+}
+
+size_t ttts_rowdot_bwd_workspace_bytes(int d) { return (size_t)RD_BWD_BLOCKS * (d + 1) * sizeof(float); }
+
+int ttts_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx_accum, float* dw, float* db, float* ws,
+                    size_t ws_bytes, int64_t M, int d, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TTTS_REQUIRE(dy && x && w && ws, "rowdot_bwd: null pointer");
+    TTTS_REQUIRE(M > 0 && d > 0 && d % 64 == 0 && d <= 1024, "rowdot_bwd: d=%d must be a multiple of 64, <= 1024", d);
+    TTTS_REQUIRE(ws_bytes >= ttts_rowdot_bwd_workspace_bytes(d), "rowdot_bwd: workspace too small");
+    int nblk = RD_BWD_BLOCKS;
+    if ((long)nblk * 4 > M) nblk = (int)((M + 3) / 4);
+    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dy, x, w, dx_accum, ws, (long)M, d);
+    TTTS_LAUNCH_CHECK("rowdot_bwd_kernel");
+    hipLaunchKernelGGL(rowdot_bwd_final_kernel, dim3(cdiv(d + 1, 256)), dim3(256), 0, stream, ws, dw, db, nblk, d);
+    TTTS_LAUNCH_CHECK("rowdot_bwd_final_kernel");
+    return TTTS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,528 @@
+// fp32 MFMA GEMM family for gfx950: linear / 1x1-conv FFN / k-tap Conv1d as implicit GEMM,
+// forward (x.W^T), data-gradient (dy.W) and weight-gradient (dy^T.x, split over rows).
+//
+// One workgroup = 4 waves (256 threads) computes a BM x BN tile with v_mfma_f32_32x32x2_f32
+// (exact fp32, k-ordered fma chain).  Operand tiles are staged global -> registers -> LDS
+// (double-buffered, one barrier per 16-deep k-tile); each wave owns a (BM/WM) x (BN/WN) sub-tile
+// made of 32x32 MFMA accumulators.
+//
+// Operand addressing modes (template flags):
+//   A_KC  : A is [M][K] row-major, K contiguous ("activation rows").  Supports an implicit
+//           im2col: K = taps*cin, k-tile -> (tap, channel block), source row = m + shift(tap),
+//           zero outside the utterance [0,T) the row belongs to.  This serves Conv1d forward,
+//           Conv1d data-gradient (flipped taps) and the decoder's go-frame shift (one tap, shift -1).
+//   !A_KC : A is stored [K][M] (reduction index is the row) -- dy^T for weight gradients.
+//   B_KC  : B is [N][K] row-major, K contiguous (nn.Linear weight layout, packed conv weight).
+//   !B_KC : B is stored [K][N] (reduction index is the row) -- W for data-gradients, x for weight
+//           gradients (with the same per-tap row shift / utterance clipping as above).
+#include "ttts_common.h"
+
+namespace ttts {
+
+constexpr int BK = 16;          // k-tile depth (floats)
+constexpr int KC_LD = BK + 1;   // LDS row stride for K-contiguous tiles (odd -> conflict-free b32 reads)
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    // implicit row shift (conv taps / go-frame): rows are (b*T + t)
+    int T;           // 0: no utterance clipping (shift must be 0)
+    int cin;         // A_KC: channels per tap (K = taps*cin)
+    int shift0, shift_step;
+    int ztaps;       // !B_KC: number of taps spread over blockIdx.z (z = split*ztaps + tap)
+    // split over the reduction dimension
+    int kt_per_split;
+    long c_zstride;  // C offset per z slice
+    // epilogue (applied only when kt range covers all of K, i.e. no split)
+    const float* bias;
+    int act;         // 0 none, 1 relu
+    float drop_scale;
+    uint32_t drop_thr;
+    uint64_t seed;
+    const float* residual;
+    long ldr;
+};
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
+    constexpr int A_ELEMS = A_KC ? BM * KC_LD : BK * BM;
+    constexpr int B_ELEMS = B_KC ? BN * KC_LD : BK * BN;
+    constexpr int NLA = (BM * 4 + 255) / 256;   // float4 loads per thread for the A tile
+    constexpr int NLB = (BN * 4 + 255) / 256;
+
+    __shared__ __attribute__((aligned(16))) float lds[2 * (A_ELEMS + B_ELEMS)];
+    constexpr int STAGE = A_ELEMS + B_ELEMS;   // stage `buf`: A at lds + buf*STAGE, B right behind it
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+    const int ztap = (g.ztaps > 1) ? (z % g.ztaps) : 0;
+    const int zsplit = (g.ztaps > 1) ? (z / g.ztaps) : z;
+
+    const int nkt = g.K / BK + ((g.K % BK) ? 1 : 0);
+    const int kt_begin = zsplit * g.kt_per_split;
+    int kt_end = kt_begin + g.kt_per_split;
+    if (kt_end > nkt) kt_end = nkt;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[NLA], rb[NLB];
+
+    // ---- per-thread static parts of the loaders
+    // K-contiguous tiles: thread -> (row = idx>>2, chunk = idx&3); natural tiles: (krow = idx / (X/4), col4)
+    int a_t[NLA];     // A_KC: t index of the row inside its utterance (for shift clipping)
+    bool a_ok[NLA];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        int idx = tid + i * 256;
+        if (A_KC) {
+            int row = idx >> 2;
+            int m = m0 + row;
+            a_ok[i] = (row < BM) && (m < g.M);
+            a_t[i] = (g.T > 0) ? (m % g.T) : 0;
+        } else {
+            a_ok[i] = idx < BK * (BM / 4);
+            a_t[i] = 0;
+        }
+    }
+
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK;
+        // ---------------- A
+        if (A_KC) {
+            const int tap = k0 / g.cin;
+            const int c0 = k0 - tap * g.cin;
+            const int shift = g.shift0 + tap * g.shift_step;
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) {
+                int idx = tid + i * 256;
+                int row = idx >> 2, ch = idx & 3;
+                bool ok = a_ok[i];
+                if (g.T > 0) ok = ok && ((unsigned)(a_t[i] + shift) < (unsigned)g.T);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) {
+                    const float* p = g.A + (long)(m0 + row + shift) * g.lda + c0 + ch * 4;
+                    v = *reinterpret_cast<const float4*>(p);
+                }
+                ra[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) {
+                int idx = tid + i * 256;
+                int kr = idx / (BM / 4), c4 = idx % (BM / 4);
+                int k = k0 + kr, m = m0 + c4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a_ok[i] && k < g.K && m < g.M) {   // M % 4 == 0 is required by the host wrapper
+                    v = *reinterpret_cast<const float4*>(g.A + (long)k * g.lda + m);
+                }
+                ra[i] = v;
+            }
+        }
+        // ---------------- B
+        if (B_KC) {
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) {
+                int idx = tid + i * 256;
+                int row = idx >> 2, ch = idx & 3;
+                int n = n0 + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < BN && n < g.N) v = *reinterpret_cast<const float4*>(g.B + (long)n * g.ldb + k0 + ch * 4);
+                rb[i] = v;
+            }
+        } else {
+            const int shift = g.shift0 + ztap * g.shift_step;
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) {
+                int idx = tid + i * 256;
+                int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+                int k = k0 + kr, n = n0 + c4 * 4;
+                bool ok = (idx < BK * (BN / 4)) && k < g.K && n < g.N;
+                if (g.T > 0) ok = ok && ((unsigned)((k % g.T) + shift) < (unsigned)g.T);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) v = *reinterpret_cast<const float4*>(g.B + (long)(k + shift) * g.ldb + n);
+                rb[i] = v;
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* as = lds + buf * STAGE;
+        float* bs = as + A_ELEMS;
+        if (A_KC) {
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) {
+                int idx = tid + i * 256;
+                int row = idx >> 2, ch = idx & 3;
+                if (row < BM) {
+                    float* d = as + row * KC_LD + ch * 4;
+                    d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) {
+                int idx = tid + i * 256;
+                if (idx < BK * (BM / 4)) {
+                    int kr = idx / (BM / 4), c4 = idx % (BM / 4);
+                    *reinterpret_cast<float4*>(as + kr * BM + c4 * 4) = ra[i];
+                }
+            }
+        }
+        if (B_KC) {
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) {
+                int idx = tid + i * 256;
+                int row = idx >> 2, ch = idx & 3;
+                if (row < BN) {
+                    float* d = bs + row * KC_LD + ch * 4;
+                    d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) {
+                int idx = tid + i * 256;
+                if (idx < BK * (BN / 4)) {
+                    int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+                    *reinterpret_cast<float4*>(bs + kr * BN + c4 * 4) = rb[i];
+                }
+            }
+        }
+    };
+
+    auto compute = [&](int buf) {
+        const float* as = lds + buf * STAGE;
+        const float* bs = as + A_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+            const int k = kk * 2 + half;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int m = wm * WTM + i * 32 + l31;
+                a[i] = A_KC ? as[m * KC_LD + k] : as[k * BM + m];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int n = wn * WTN + j * 32 + l31;
+                b[j] = B_KC ? bs[n * KC_LD + k] : bs[k * BN + n];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (kt_begin < kt_end) {
+        load_tiles(kt_begin);
+        store_tiles(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const bool more = (kt + 1) < kt_end;
+            if (more) load_tiles(kt + 1);
+            compute(buf);
+            if (more) store_tiles(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ---------------- epilogue
+    float* C = g.C + (long)z * g.c_zstride;
+    const bool do_drop = g.drop_thr != 0u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WTN + j * 32 + l31;
+            const float bv = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WTM + i * 32 + acc_row(r, half);
+                if (row < g.M && col < g.N) {
+                    float v = acc[i][j][r] + bv;
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    if (do_drop) {
+                        uint64_t idx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
+                        v = keep_elem(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
+                    }
+                    if (g.residual != nullptr) v += g.residual[(long)row * g.ldr + col];
+                    C[(long)row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// out[i] (+bias over rows) = sum_z ws[z][i]   -- deterministic second stage of the split weight gradients
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n, int nsplit) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += ws[(long)z * n + i];
+    out[i] = s;
+}
+
+// conv weight gradient: ws[split][tap][co][ci] -> dw[co][ci][tap]
+__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int cout, int cin,
+                                         int taps, int nsplit) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // index into [tap][co][ci]
+    long per = (long)cout * cin;
+    long n = per * taps;
+    if (i >= n) return;
+    int tap = (int)(i / per);
+    long rem = i - (long)tap * per;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += ws[(long)z * n + i];
+    dw[rem * taps + tap] = s;
+}
+
+// w[co][ci][tap] -> wp[co][tap][ci]  (forward: K-contiguous rows per output channel)
+//                -> wt[ci][tap][co]  (data gradient: K-contiguous rows per input channel)
+__global__ void conv_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wt,
+                                        int cout, int cin, int taps) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long n = (long)cout * cin * taps;
+    if (i >= n) return;
+    int tap = (int)(i % taps);
+    long r = i / taps;
+    int ci = (int)(r % cin);
+    int co = (int)(r / cin);
+    float v = w[i];
+    if (wp) wp[((long)co * taps + tap) * cin + ci] = v;
+    if (wt) wt[((long)ci * taps + tap) * cout + co] = v;
+}
+
+// column sums (bias gradients): out[c] = sum_r x[r][c]; two deterministic stages
+__global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long rows, int cols,
+                                      long ld, int rows_per_block) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += x[r * ld + c];
+    part[(long)blockIdx.y * cols + c] = s;
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t stream) {
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), zdim);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC>), grid, dim3(256), 0, stream, g);
+    TTTS_LAUNCH_CHECK("gemm_f32_kernel");
+    return TTTS_OK;
+}
+
+template <bool A_KC, bool B_KC>
+static int dispatch_gemm(const GemmArgs& g, int zdim, hipStream_t stream) {
+    // N <= 96: a 128x96 tile (4 waves stacked along M) wastes less than 128x128 on the 80-wide mel GEMMs
+    if (g.N <= 96) return launch_gemm<128, 96, 4, 1, A_KC, B_KC>(g, zdim, stream);
+    return launch_gemm<128, 128, 2, 2, A_KC, B_KC>(g, zdim, stream);
+}
+
+static GemmArgs base_args() {
+    GemmArgs g;
+    g.A = g.B = nullptr; g.C = nullptr;
+    g.M = g.N = g.K = 0; g.lda = g.ldb = g.ldc = 0;
+    g.T = 0; g.cin = 1; g.shift0 = 0; g.shift_step = 0; g.ztaps = 1;
+    g.kt_per_split = 1 << 30; g.c_zstride = 0;
+    g.bias = nullptr; g.act = 0; g.drop_scale = 1.f; g.drop_thr = 0; g.seed = 0;
+    g.residual = nullptr; g.ldr = 0;
+    return g;
+}
+
+static int aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace ttts
+
+using namespace ttts;
+
+extern "C" {
+
+int ttts_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, int64_t M,
+                    int N, int K, int act, float drop_p, uint64_t seed, int row_shift, int T, void* stream) {
+    TTTS_REQUIRE(x && w && y, "linear_fwd: null pointer");
+    TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_fwd: bad dims M=%lld N=%d K=%d", (long long)M, N, K);
+    TTTS_REQUIRE(K % BK == 0, "linear_fwd: K=%d must be a multiple of %d", K, BK);
+    TTTS_REQUIRE(aligned16(x) && aligned16(w), "linear_fwd: x/w must be 16-byte aligned");
+    TTTS_REQUIRE(act == 0 || act == 1, "linear_fwd: act must be 0 (none) or 1 (relu)");
+    TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "linear_fwd: dropout p=%f out of [0,1)", drop_p);
+    TTTS_REQUIRE(row_shift == 0 || (T > 0 && M % T == 0), "linear_fwd: row_shift needs T>0 and M %% T == 0");
+    GemmArgs g = base_args();
+    g.A = x; g.B = w; g.C = y; g.M = (int)M; g.N = N; g.K = K;
+    g.lda = K; g.ldb = K; g.ldc = N;
+    g.cin = K; g.shift0 = row_shift; g.T = (row_shift != 0) ? T : 0;
+    g.bias = bias; g.act = act;
+    if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; }
+    g.residual = residual; g.ldr = N;
+    return dispatch_gemm<true, true>(g, 1, (hipStream_t)stream);
+}
+
+int ttts_linear_bwd_data(const float* dy, const float* w, const float* residual, float* dx, int64_t M, int N, int K,
+                         void* stream) {
+    // dx[M,K] = dy[M,N] . w[N,K] (+ residual)   (reduction over N; w consumed in its natural [N][K] layout)
+    TTTS_REQUIRE(dy && w && dx, "linear_bwd_data: null pointer");
+    TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_bwd_data: bad dims");
+    TTTS_REQUIRE(N % BK == 0 && K % 4 == 0, "linear_bwd_data: N=%d must be a multiple of 16 and K=%d of 4", N, K);
+    TTTS_REQUIRE(aligned16(dy) && aligned16(w), "linear_bwd_data: dy/w must be 16-byte aligned");
+    GemmArgs g = base_args();
+    g.A = dy; g.B = w; g.C = dx; g.M = (int)M; g.N = K; g.K = N;
+    g.lda = N; g.ldb = K; g.ldc = K; g.cin = N;
+    g.residual = residual; g.ldr = K;
+    return dispatch_gemm<true, false>(g, 1, (hipStream_t)stream);
+}
+
+size_t ttts_wgrad_workspace_bytes(int64_t M, int N, int K, int taps) {
+    // split the row (reduction) dimension so that about 1024 workgroups exist
+    long tiles = (long)cdiv(N, 128) * cdiv(K, 128) * taps;
+    long nkt = (M + BK - 1) / BK;
+    long want = 1024 / tiles;
+    if (want < 1) want = 1;
+    if (want > nkt) want = nkt;
+    long per = (nkt + want - 1) / want;
+    long nsplit = (nkt + per - 1) / per;
+    return (size_t)nsplit * taps * N * K * sizeof(float) + (size_t)256 * (size_t)N * sizeof(float);
+}
+
+static int wgrad_common(const float* dy, const float* x, float* ws, int64_t M, int N, int K, int taps, int T, int shift0,
+                        int shift_step, int* nsplit_out, hipStream_t stream) {
+    long tiles = (long)cdiv(N, 128) * cdiv(K, 128) * taps;
+    long nkt = (M + BK - 1) / BK;
+    long want = 1024 / tiles;
+    if (want < 1) want = 1;
+    if (want > nkt) want = nkt;
+    long per = (nkt + want - 1) / want;
+    long nsplit = (nkt + per - 1) / per;
+    GemmArgs g = base_args();
+    // C[N][K] (per tap) = dy^T[N][M] . xshift[M][K]
+    g.A = dy; g.B = x; g.C = ws; g.M = N; g.N = K; g.K = (int)M;
+    g.lda = N; g.ldb = K; g.ldc = K;
+    g.T = T; g.shift0 = shift0; g.shift_step = shift_step; g.ztaps = taps;
+    g.kt_per_split = (int)per; g.c_zstride = (long)N * K;
+    *nsplit_out = (int)nsplit;
+    return dispatch_gemm<false, false>(g, (int)(nsplit * taps), stream);
+}
+
+int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
+                           int64_t M, int N, int K, int row_shift, int T, void* stream_) {
+    // dw[N,K] = dy[M,N]^T . x[M,K] ; dbias[N] = column sums of dy
+    hipStream_t stream = (hipStream_t)stream_;
+    TTTS_REQUIRE(dy && x && dw && ws, "linear_bwd_weight: null pointer");
+    TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_bwd_weight: bad dims");
+    TTTS_REQUIRE(N % 4 == 0 && K % 4 == 0, "linear_bwd_weight: N=%d and K=%d must be multiples of 4", N, K);
+    TTTS_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(ws), "linear_bwd_weight: pointers must be 16-byte aligned");
+    TTTS_REQUIRE(ws_bytes >= ttts_wgrad_workspace_bytes(M, N, K, 1), "linear_bwd_weight: workspace too small");
+    TTTS_REQUIRE(row_shift == 0 || (T > 0 && M % T == 0), "linear_bwd_weight: row_shift needs T>0 and M %% T == 0");
+    int nsplit = 1;
+    int rc = wgrad_common(dy, x, ws, M, N, K, 1, row_shift != 0 ? T : 0, row_shift, 0, &nsplit, stream);
+    if (rc) return rc;
+    long n = (long)N * K;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, ws, dw, n, nsplit);
+    TTTS_LAUNCH_CHECK("splitk_reduce_kernel");
+    if (dbias) {
+        float* part = ws + (size_t)nsplit * n;
+        int nb = 256;
+        int rpb = cdiv(M, nb);
+        nb = cdiv(M, rpb);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), nb), dim3(64), 0, stream, dy, part, (long)M, N,
+                           (long)N, rpb);
+        TTTS_LAUNCH_CHECK("colsum_partial_kernel");
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, part, dbias, (long)N, nb);
+        TTTS_LAUNCH_CHECK("splitk_reduce_kernel(bias)");
+    }
+    return TTTS_OK;
+}
+
+size_t ttts_conv1d_pack_bytes(int cout, int cin, int taps) { return (size_t)cout * cin * taps * sizeof(float); }
+
+int ttts_conv1d_pack_weight(const float* w, float* w_fwd, float* w_bwd, int cout, int cin, int taps, void* stream) {
+    TTTS_REQUIRE(w && (w_fwd || w_bwd), "conv1d_pack_weight: null pointer");
+    long n = (long)cout * cin * taps;
+    hipLaunchKernelGGL(conv_pack_weight_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, w_fwd, w_bwd,
+                       cout, cin, taps);
+    TTTS_LAUNCH_CHECK("conv_pack_weight_kernel");
+    return TTTS_OK;
+}
+
+int ttts_conv1d_fwd(const float* x, const float* w_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
+                    int taps, void* stream) {
+    // y[b,t,co] = bias[co] + sum_{tap,ci} x[b,t+tap-pad,ci] * w[co,ci,tap],  pad = (taps-1)/2, zero outside [0,T)
+    TTTS_REQUIRE(x && w_fwd && y, "conv1d_fwd: null pointer");
+    TTTS_REQUIRE(B > 0 && T > 0 && cin > 0 && cout > 0 && taps > 0 && (taps & 1), "conv1d_fwd: bad dims");
+    TTTS_REQUIRE(cin % BK == 0, "conv1d_fwd: cin=%d must be a multiple of %d", cin, BK);
+    TTTS_REQUIRE((long)B * T < (1L << 31), "conv1d_fwd: B*T too large");
+    TTTS_REQUIRE(aligned16(x) && aligned16(w_fwd), "conv1d_fwd: pointers must be 16-byte aligned");
+    GemmArgs g = base_args();
+    g.A = x; g.B = w_fwd; g.C = y; g.M = B * T; g.N = cout; g.K = taps * cin;
+    g.lda = cin; g.ldb = (long)taps * cin; g.ldc = cout;
+    g.T = T; g.cin = cin; g.shift0 = -((taps - 1) / 2); g.shift_step = 1;
+    g.bias = bias;
+    return dispatch_gemm<true, true>(g, 1, (hipStream_t)stream);
+}
+
+int ttts_conv1d_bwd_data(const float* dy, const float* w_bwd, float* dx, int B, int T, int cin, int cout, int taps,
+                         void* stream) {
+    // dx[b,t,ci] = sum_{tap,co} dy[b,t-tap+pad,co] * w[co,ci,tap]   (w_bwd = w packed as [ci][tap][co])
+    TTTS_REQUIRE(dy && w_bwd && dx, "conv1d_bwd_data: null pointer");
+    TTTS_REQUIRE(B > 0 && T > 0 && cin > 0 && cout > 0 && taps > 0 && (taps & 1), "conv1d_bwd_data: bad dims");
+    TTTS_REQUIRE(cout % BK == 0, "conv1d_bwd_data: cout=%d must be a multiple of %d", cout, BK);
+    TTTS_REQUIRE(aligned16(dy) && aligned16(w_bwd), "conv1d_bwd_data: pointers must be 16-byte aligned");
+    GemmArgs g = base_args();
+    g.A = dy; g.B = w_bwd; g.C = dx; g.M = B * T; g.N = cin; g.K = taps * cout;
+    g.lda = cout; g.ldb = (long)taps * cout; g.ldc = cin;
+    g.T = T; g.cin = cout; g.shift0 = (taps - 1) / 2; g.shift_step = -1;
+    return dispatch_gemm<true, true>(g, 1, (hipStream_t)stream);
+}
+
+int ttts_conv1d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
+                           int T, int cin, int cout, int taps, void* stream_) {
+    // dw[co,ci,tap] = sum_{b,t} dy[b,t,co] * x[b,t+tap-pad,ci] ; dbias[co] = sum dy
+    hipStream_t stream = (hipStream_t)stream_;
+    TTTS_REQUIRE(dy && x && dw && ws, "conv1d_bwd_weight: null pointer");
+    TTTS_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "conv1d_bwd_weight: channel counts must be multiples of 4");
+    TTTS_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(ws), "conv1d_bwd_weight: pointers must be 16-byte aligned");
+    int64_t M = (int64_t)B * T;
+    TTTS_REQUIRE(ws_bytes >= ttts_wgrad_workspace_bytes(M, cout, cin, taps), "conv1d_bwd_weight: workspace too small");
+    int nsplit = 1;
+    int rc = wgrad_common(dy, x, ws, M, cout, cin, taps, T, -((taps - 1) / 2), 1, &nsplit, stream);
+    if (rc) return rc;
+    long n = (long)cout * cin * taps;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, ws, dw, cout, cin, taps,
+                       nsplit);
+    TTTS_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
+    if (dbias) {
+        float* part = ws + (size_t)nsplit * n;
+        int nb = 256;
+        int rpb = cdiv(M, nb);
+        nb = cdiv(M, rpb);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cout, 64), nb), dim3(64), 0, stream, dy, part, (long)M, cout,
+                           (long)cout, rpb);
+        TTTS_LAUNCH_CHECK("colsum_partial_kernel");
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, stream, part, dbias, (long)cout, nb);
+        TTTS_LAUNCH_CHECK("splitk_reduce_kernel(bias)");
+    }
+    return TTTS_OK;
+}
+
+}  // extern "C"

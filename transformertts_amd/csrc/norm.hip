@@ -1,0 +1,402 @@
+// LayerNorm and BatchNorm1d (train / eval) forward + backward for (rows, channels) fp32 activations.
+// HBM-bound: every kernel streams rows with coalesced accesses across channels, reduces with
+// wave shuffles / fixed-order partials (bitwise reproducible, no atomics).
+#include "ttts_common.h"
+
+namespace ttts {
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// one wave per row; lane owns columns lane, lane+64, ... (coalesced 256-B segments per step)
+constexpr int LN_MAXPER = 16;   // d <= 1024
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            long M, int d, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const int nper = d >> 6;
+    const float* xr = x + row * d;
+    float v[LN_MAXPER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXPER; ++i) {
+        if (i < nper) { v[i] = xr[lane + 64 * i]; s += v[i]; }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXPER; ++i) {
+        if (i < nper) { float c = v[i] - mean; q += c * c; }
+    }
+    const float var = wave_sum(q) / (float)d;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float* yr = y + row * d;
+#pragma unroll
+    for (int i = 0; i < LN_MAXPER; ++i) {
+        if (i < nper) {
+            int c = lane + 64 * i;
+            yr[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        }
+    }
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+
+constexpr int LN_BWD_BLOCKS = 512;
+
+// dx per row; per-block partial column sums of dy*xhat (dgamma) and dy (dbeta) -> ws[block][2][d]
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, float* __restrict__ dx,
+                                                            float* __restrict__ ws, long M, int d) {
+    __shared__ float red[4][2][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nper = d >> 6;
+    float g[LN_MAXPER], accg[LN_MAXPER], accb[LN_MAXPER];
+#pragma unroll
+    for (int i = 0; i < LN_MAXPER; ++i) {
+        accg[i] = 0.f; accb[i] = 0.f;
+        g[i] = (i < nper) ? gamma[lane + 64 * i] : 0.f;
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const float* xr = x + row * d;
+        const float* dr = dy + row * d;
+        float xh[LN_MAXPER], gd[LN_MAXPER];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXPER; ++i) {
+            if (i < nper) {
+                int c = lane + 64 * i;
+                float dyv = dr[c];
+                xh[i] = (xr[c] - mu) * rs;
+                gd[i] = dyv * g[i];
+                s1 += gd[i];
+                s2 += gd[i] * xh[i];
+                accg[i] += dyv * xh[i];
+                accb[i] += dyv;
+            }
+        }
+        s1 = wave_sum(s1) / (float)d;
+        s2 = wave_sum(s2) / (float)d;
+        float* dxr = dx + row * d;
+#pragma unroll
+        for (int i = 0; i < LN_MAXPER; ++i) {
+            if (i < nper) dxr[lane + 64 * i] = rs * (gd[i] - s1 - xh[i] * s2);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXPER; ++i) {
+        if (i < nper) {
+            red[wave][0][lane + 64 * i] = accg[i];
+            red[wave][1][lane + 64 * i] = accb[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * d; c += 256) {
+        int which = c / d, col = c - which * d;
+        float s = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+        ws[((long)blockIdx.x * 2 + which) * d + col] = s;
+    }
+}
+
+// out0[c] = sum_b ws[b][0][c], out1[c] = sum_b ws[b][1][c]
+__global__ void pair_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out0, float* __restrict__ out1,
+                                   int nblk, int d) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * d) return;
+    int which = c / d, col = c - which * d;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += ws[((long)b * 2 + which) * d + col];
+    float* o = which ? out1 : out0;
+    if (o) o[col] = s;
+}
+
+// ------------------------------------------------------------------------------------------ BatchNorm
+constexpr int BN_MAXBLK = 256;
+
+// per (row-chunk, channel): count, mean, M2 (Welford), merged deterministically by bn_stats_final_kernel
+__global__ void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ ws, long M, int C,
+                                        int rows_per_block) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float mean = 0.f, m2 = 0.f;
+    float n = 0.f;
+    for (long r = r0; r < r1; ++r) {
+        float v = x[r * C + c];
+        n += 1.f;
+        float dlt = v - mean;
+        mean += dlt / n;
+        m2 += dlt * (v - mean);
+    }
+    float* w = ws + ((long)blockIdx.y * 3) * C;
+    w[c] = n;
+    w[C + c] = mean;
+    w[2 * C + c] = m2;
+}
+
+__global__ void bn_stats_final_kernel(const float* __restrict__ ws, float* __restrict__ mean_out,
+                                      float* __restrict__ invstd_out, float* __restrict__ running_mean,
+                                      float* __restrict__ running_var, int64_t* __restrict__ nbt, int nblk, int C,
+                                      float momentum, float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int b = 0; b < nblk; ++b) {
+            const float* w = ws + ((long)b * 3) * C;
+            float nb = w[c], mb = w[C + c], m2b = w[2 * C + c];
+            if (nb > 0.f) {
+                float nn = n + nb;
+                float dlt = mb - mean;
+                mean += dlt * (nb / nn);
+                m2 += m2b + dlt * dlt * (n * nb / nn);
+                n = nn;
+            }
+        }
+        float var = m2 / n;
+        mean_out[c] = mean;
+        invstd_out[c] = 1.0f / sqrtf(var + eps);
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        if (running_var) {
+            float unbiased = (n > 1.f) ? m2 / (n - 1.f) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+    }
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ mean,
+                                     float* __restrict__ invstd, int C, float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        mean[c] = rm[c];
+        invstd[c] = 1.0f / sqrtf(rv[c] + eps);
+    }
+}
+
+// z = drop(act(xhat*gamma + beta)); 4 channels per thread (C % 4 == 0)
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ z, long n4,
+                                                           int C, int act, float drop_scale, uint32_t thr, uint64_t seed) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long e = i * 4;
+        const int c = (int)(e % C);
+        float4 xv = *reinterpret_cast<const float4*>(x + e);
+        float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        float4 be = *reinterpret_cast<const float4*>(beta + c);
+        float o[4] = {(xv.x - mu.x) * is.x * ga.x + be.x, (xv.y - mu.y) * is.y * ga.y + be.y,
+                      (xv.z - mu.z) * is.z * ga.z + be.z, (xv.w - mu.w) * is.w * ga.w + be.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (act == TTTS_ACT_TANH) o[j] = tanhf(o[j]);
+            if (thr != 0u) o[j] = keep_elem(seed, (uint64_t)(e + j), thr) ? o[j] * drop_scale : 0.f;
+        }
+        *reinterpret_cast<float4*>(z + e) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// gradient w.r.t. the BN output (before act / dropout) for element e, channel c
+__device__ __forceinline__ float bn_dy_pre(float dz, float xhat, float gamma, float beta, int act, float drop_scale,
+                                           uint32_t thr, uint64_t seed, uint64_t e) {
+    float g = dz;
+    if (thr != 0u) g = keep_elem(seed, e, thr) ? g * drop_scale : 0.f;
+    if (act == TTTS_ACT_TANH) {
+        float t = tanhf(xhat * gamma + beta);
+        g *= (1.f - t * t);
+    }
+    return g;
+}
+
+// per (row-chunk, channel): sum dy, sum dy*xhat -> ws[blk][2][C]
+__global__ void bn_bwd_partial_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      float* __restrict__ ws, long M, int C, int rows_per_block, int act, float drop_scale,
+                                      uint32_t thr, uint64_t seed) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (long r = r0; r < r1; ++r) {
+        long e = r * C + c;
+        float xh = (x[e] - mu) * is;
+        float g = bn_dy_pre(dz[e], xh, ga, be, act, drop_scale, thr, seed, (uint64_t)e);
+        s1 += g;
+        s2 += g * xh;
+    }
+    ws[((long)blockIdx.y * 2) * C + c] = s1;
+    ws[((long)blockIdx.y * 2 + 1) * C + c] = s2;
+}
+
+// sums[0][c] = sum dy (= dbeta), sums[1][c] = sum dy*xhat (= dgamma)
+__global__ void bn_bwd_final_kernel(const float* __restrict__ ws, float* __restrict__ sums, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int nblk, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += ws[((long)b * 2) * C + c];
+        s2 += ws[((long)b * 2 + 1) * C + c];
+    }
+    sums[c] = s1;
+    sums[C + c] = s2;
+    if (dbeta) dbeta[c] = s1;
+    if (dgamma) dgamma[c] = s2;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ sums, float* __restrict__ dx, long n4,
+                                                           int C, float inv_m, int act, float drop_scale, uint32_t thr,
+                                                           uint64_t seed) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long e = i * 4;
+        const int c = (int)(e % C);
+        float4 xv = *reinterpret_cast<const float4*>(x + e);
+        float4 dv = *reinterpret_cast<const float4*>(dz + e);
+        float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float is = invstd[c + j], ga = gamma[c + j];
+            float xh = (xs[j] - mean[c + j]) * is;
+            float g = bn_dy_pre(ds[j], xh, ga, beta[c + j], act, drop_scale, thr, seed, (uint64_t)(e + j));
+            o[j] = ga * is * (g - sums[c + j] * inv_m - xh * sums[C + c + j] * inv_m);
+        }
+        *reinterpret_cast<float4*>(dx + e) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+static int bn_blocks(long M, int* rows_per_block) {
+    int nb = BN_MAXBLK;
+    int rpb = cdiv(M, nb);
+    if (rpb < 1) rpb = 1;
+    nb = cdiv(M, rpb);
+    *rows_per_block = rpb;
+    return nb;
+}
+
+}  // namespace ttts
+
+using namespace ttts;
+
+extern "C" {
+
+int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       int64_t M, int d, float eps, void* stream) {
+    TTTS_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
+    TTTS_REQUIRE(M > 0 && d > 0 && d % 64 == 0 && d <= 64 * LN_MAXPER, "layernorm_fwd: d=%d must be a multiple of 64, <= %d",
+                 d, 64 * LN_MAXPER);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
+                       rstd, (long)M, d, eps);
+    TTTS_LAUNCH_CHECK("layernorm_fwd_kernel");
+    return TTTS_OK;
+}
+
+size_t ttts_layernorm_bwd_workspace_bytes(int d) { return (size_t)LN_BWD_BLOCKS * 2 * d * sizeof(float); }
+
+int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
+                       void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TTTS_REQUIRE(dy && x && mean && rstd && gamma && dx && ws, "layernorm_bwd: null pointer");
+    TTTS_REQUIRE(M > 0 && d > 0 && d % 64 == 0 && d <= 64 * LN_MAXPER, "layernorm_bwd: bad d=%d", d);
+    TTTS_REQUIRE(ws_bytes >= ttts_layernorm_bwd_workspace_bytes(d), "layernorm_bwd: workspace too small");
+    int nblk = LN_BWD_BLOCKS;
+    if ((long)nblk * 4 > M) nblk = cdiv(M, 4);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M, d);
+    TTTS_LAUNCH_CHECK("layernorm_bwd_kernel");
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3(cdiv(2 * d, 256)), dim3(256), 0, stream, ws, dgamma, dbeta, nblk, d);
+    TTTS_LAUNCH_CHECK("pair_reduce_kernel");
+    return TTTS_OK;
+}
+
+size_t ttts_bn_workspace_bytes(int64_t M, int C) {
+    (void)M;
+    return ((size_t)BN_MAXBLK * 3 + 2) * (size_t)C * sizeof(float);
+}
+
+int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float* ws, size_t ws_bytes, int64_t M, int C, float momentum,
+                        float eps, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TTTS_REQUIRE(x && mean && invstd && ws, "bn_train_stats: null pointer");
+    TTTS_REQUIRE(M > 1 && C > 0, "bn_train_stats: need M > 1 rows (got %lld) and C > 0", (long long)M);
+    TTTS_REQUIRE(ws_bytes >= ttts_bn_workspace_bytes(M, C), "bn_train_stats: workspace too small");
+    int rpb;
+    int nb = bn_blocks(M, &rpb);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(cdiv(C, 64), nb), dim3(64), 0, stream, x, ws, (long)M, C, rpb);
+    TTTS_LAUNCH_CHECK("bn_stats_partial_kernel");
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, ws, mean, invstd, running_mean,
+                       running_var, num_batches_tracked, nb, C, momentum, eps);
+    TTTS_LAUNCH_CHECK("bn_stats_final_kernel");
+    return TTTS_OK;
+}
+
+int ttts_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C, float eps,
+                       void* stream) {
+    TTTS_REQUIRE(running_mean && running_var && mean && invstd && C > 0, "bn_eval_stats: bad arguments");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, running_mean,
+                       running_var, mean, invstd, C, eps);
+    TTTS_LAUNCH_CHECK("bn_eval_stats_kernel");
+    return TTTS_OK;
+}
+
+int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      float* z, int64_t M, int C, int act, float drop_p, uint64_t seed, void* stream) {
+    TTTS_REQUIRE(x && mean && invstd && gamma && beta && z, "bn_apply_fwd: null pointer");
+    TTTS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_apply_fwd: C=%d must be a multiple of 4", C);
+    TTTS_REQUIRE(act == TTTS_ACT_NONE || act == TTTS_ACT_TANH, "bn_apply_fwd: act must be none or tanh");
+    TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "bn_apply_fwd: bad dropout p");
+    long n4 = (long)M * C / 4;
+    int grid = (int)((n4 + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, z,
+                       n4, C, act, 1.f / (1.f - drop_p), thr, seed);
+    TTTS_LAUNCH_CHECK("bn_apply_fwd_kernel");
+    return TTTS_OK;
+}
+
+int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float* invstd, const float* gamma,
+                const float* beta, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int C,
+                int act, float drop_p, uint64_t seed, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TTTS_REQUIRE(dz && x && mean && invstd && gamma && beta && dx && ws, "bn_bwd: null pointer");
+    TTTS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd: C=%d must be a multiple of 4", C);
+    TTTS_REQUIRE(ws_bytes >= ttts_bn_workspace_bytes(M, C), "bn_bwd: workspace too small");
+    int rpb;
+    int nb = bn_blocks(M, &rpb);
+    uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+    float scale = 1.f / (1.f - drop_p);
+    float* sums = ws + (size_t)BN_MAXBLK * 3 * C;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(C, 64), nb), dim3(64), 0, stream, dz, x, mean, invstd, gamma, beta,
+                       ws, (long)M, C, rpb, act, scale, thr, seed);
+    TTTS_LAUNCH_CHECK("bn_bwd_partial_kernel");
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, ws, sums, dgamma, dbeta, nb, C);
+    TTTS_LAUNCH_CHECK("bn_bwd_final_kernel");
+    long n4 = (long)M * C / 4;
+    int grid = (int)((n4 + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, dz, x, mean, invstd, gamma, beta, sums, dx, n4,
+                       C, 1.0f / (float)M, act, scale, thr, seed);
+    TTTS_LAUNCH_CHECK("bn_bwd_apply_kernel");
+    return TTTS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+"""LightningModule counterpart: the `training_step()` surface of the reference (`lightning_module.py:23-204`)
+over the HIP-backed TransformerTTS.
+
+Subclasses `pytorch_lightning.LightningModule` when Lightning is installed (so it drops into the reference's
+`train.py`); otherwise a minimal stand-in base provides `device`, `current_epoch` and `log`, and `bench.py` /
+`train_dp.py` drive `training_step` directly.  PNG plotting and loguru logging of the reference are out of scope
+(SURVEY.md section 2); the per-step `.item()` of the reference (lightning_module.py:84) is kept behind
+`config['training']['sync_loss_every_step']` (default True, as the reference) so benchmarks can state which.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict
+
+import torch
+
+from .loss import TransformerTTSLoss
+from .model import TransformerTTS
+from .utils.util import apply_teacher_forcing, get_noam_scheduler, get_teacher_forcing_ratio, prepare_batch
+
+try:  # pragma: no cover - Lightning is absent from the build image
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    class _Base(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.current_epoch = 0
+            self._logged: Dict[str, float] = {}
+
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+        def log(self, name, value, **kwargs):
+            self._logged[name] = float(value)
+
+
+class LightningModule(_Base):
+    def __init__(self, config: Dict[str, Any], exp_dir: str = None):
+        super().__init__()
+        self.model = TransformerTTS(**config['model'])
+        self.criterion = TransformerTTSLoss(**config['loss'])
+        self.config = config
+        self.exp_dir = exp_dir
+        self.train_losses = []
+        self.valid_losses = []
+        self.example_batch = None
+        self.log_interval = config['training'].get('log_interval', 100)
+        self.sync_loss = config['training'].get('sync_loss_every_step', True)
+
+    def forward(self, phoneme, melspec, phoneme_lens, melspec_lens):
+        return self.model(phoneme, melspec, phoneme_lens, melspec_lens)
+
+    def training_step(self, batch, batch_idx):
+        phoneme, melspec, phoneme_lens, melspec_lens = prepare_batch(batch, self.device)
+        # forward #1 (no grad, train mode: dropout on, BN statistics updated) -> the model's own prediction
+        with torch.no_grad():
+            pred_melspec = self.forward(phoneme, melspec, phoneme_lens, melspec_lens)['pred_melspec']
+        p_tf = get_teacher_forcing_ratio(epoch=self.current_epoch + 1,
+                                         total_epochs=self.config['training']['num_epochs'],
+                                         mode=self.config['training']['teacher_forcing_mode'], cycles=1)
+        mel_mixed = apply_teacher_forcing(pred_melspec, melspec, melspec_lens, p_tf, self.device)
+        # forward #2 (with grad) on the mixed input, loss against the ground truth
+        output = self.forward(phoneme, mel_mixed, phoneme_lens, melspec_lens)
+        loss = self.criterion(output, melspec, melspec_lens)
+        if self.sync_loss:
+            self.train_losses.append(loss['total'].item())
+        else:
+            self.train_losses.append(loss['total'].detach())
+        return loss['total']
+
+    def on_train_epoch_end(self):
+        self.train_losses.clear()
+
+    def validation_step(self, batch, batch_idx):
+        if self.example_batch is None:
+            self.example_batch = batch
+        phoneme, melspec, phoneme_lens, melspec_lens = prepare_batch(batch, self.device)
+        output = self.forward(phoneme, melspec, phoneme_lens, melspec_lens)
+        loss = self.criterion(output, melspec, melspec_lens)
+        self.valid_losses.append(loss['total'].item())
+        return loss['total']
+
+    def on_validation_epoch_end(self):
+        if self.valid_losses:
+            self.log('val_loss', sum(self.valid_losses) / len(self.valid_losses), on_epoch=True)
+        self.valid_losses.clear()
+
+    def configure_optimizers(self):
+        optimizer = torch.optim.Adam(self.parameters(), lr=1.0, betas=(0.9, 0.98), eps=1e-9)
+        lr_lambda = get_noam_scheduler(d_model=self.config['model']['d_model'],
+                                       warmup_steps=self.config['training']['warmup_steps'])
+        scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lr_lambda)
+        return {'optimizer': optimizer, 'lr_scheduler': {'scheduler': scheduler, 'interval': 'step', 'frequency': 1}}

@@ -1,0 +1,199 @@
+"""Transformer encoder / decoder stacks on the HIP kernels.
+
+Class names, constructor signatures and parameter names follow the reference's
+`model/layers.py:7-111` and the torch classes it builds on (`nn.MultiheadAttention`,
+`nn.TransformerEncoderLayer`, `nn.TransformerEncoder`, torch/nn/modules/transformer.py), so
+`state_dict()` is key-for-key the reference's.  Differences by design (MI355X-first):
+  * masks never exist as tensors: the stacks take per-utterance lengths (`*_lens`, int64 on the
+    device) and the attention kernels derive key-padding and causal masks from them;
+    `*_key_padding_mask` / `tgt_mask` arguments are still accepted and converted (prefix masks only);
+  * post-norm only (`norm_first=False`, the reference's configuration), batch-first only, relu FFN;
+  * residual adds, biases, relu and dropout live in GEMM epilogues, not in separate ops.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import ops
+
+
+def _lens_from_kpm(kpm: Optional[Tensor], B: int, T: int, device) -> Tensor:
+    if kpm is None:
+        return torch.full((B,), T, dtype=torch.int64, device=device)
+    return (~kpm.bool()).sum(dim=1).to(torch.int64)
+
+
+class MultiheadAttention(nn.Module):
+    """Parameter layout of nn.MultiheadAttention (packed in-proj, `out_proj` sub-module); head_dim must be 64."""
+
+    def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0.0):
+        super().__init__()
+        if embed_dim != num_heads * 64:
+            raise ValueError("MultiheadAttention: the gfx950 attention kernels are specialised for head_dim 64")
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)     # torch MultiheadAttention._reset_parameters
+        nn.init.constant_(self.in_proj_bias, 0.0)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+    def _p(self) -> float:
+        return self.dropout if self.training else 0.0
+
+    def self_attention(self, x: Tensor, lens: Tensor, causal: bool, residual: Tensor, out_drop: float) -> Tensor:
+        """residual + drop(out_proj(attention(in_proj(x))))"""
+        qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias)
+        p = self._p()
+        ctx = ops.SelfAttentionFn.apply(qkv, lens, self.num_heads, causal, p, ops.seeds.next() if p > 0 else 0)
+        return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, drop_p=out_drop,
+                          seed=ops.seeds.next() if out_drop > 0 else 0)
+
+    def cross_attention(self, x: Tensor, mem: Tensor, mem_lens: Tensor, residual: Tensor, out_drop: float):
+        d = self.embed_dim
+        q = ops.linear(x, self.in_proj_weight[:d], self.in_proj_bias[:d])
+        kv = ops.linear(mem, self.in_proj_weight[d:], self.in_proj_bias[d:])
+        p = self._p()
+        ctx, attn = ops.CrossAttentionFn.apply(q, kv, mem_lens, self.num_heads, p, ops.seeds.next() if p > 0 else 0)
+        out = ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, drop_p=out_drop,
+                         seed=ops.seeds.next() if out_drop > 0 else 0)
+        return out, attn
+
+
+def _ffn_block(layer, x: Tensor, out_dropout: nn.Dropout) -> Tensor:
+    """x + drop_out(W2 . drop(relu(W1 x))): relu+dropout ride in the first GEMM's epilogue, dropout+residual in
+    the second's (torch `_ff_block`, torch/nn/modules/transformer.py:980-982,1197-1199)."""
+    p = layer.dropout.p if layer.training else 0.0
+    po = out_dropout.p if layer.training else 0.0
+    h = ops.linear(x, layer.linear1.weight, layer.linear1.bias, act=ops.ACT_RELU, drop_p=p,
+                   seed=ops.seeds.next() if p > 0 else 0)
+    return ops.linear(h, layer.linear2.weight, layer.linear2.bias, residual=x, drop_p=po,
+                      seed=ops.seeds.next() if po > 0 else 0)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model: int, nhead: int, dim_feedforward: int = 2048, dropout: float = 0.1,
+                 activation: str = 'relu', batch_first: bool = True, norm_first: bool = False):
+        super().__init__()
+        if activation != 'relu' or not batch_first or norm_first:
+            raise ValueError("TransformerEncoderLayer: relu, batch_first, post-norm only (the reference's configuration)")
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model, eps=1e-5)
+        self.norm2 = nn.LayerNorm(d_model, eps=1e-5)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+
+    def forward(self, src: Tensor, src_lens: Tensor) -> Tensor:
+        p1 = self.dropout1.p if self.training else 0.0
+        s = self.self_attn.self_attention(src, src_lens, False, residual=src, out_drop=p1)
+        x = ops.layer_norm(s, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = ops.layer_norm(_ffn_block(self, x, self.dropout2), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return x
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer: TransformerEncoderLayer, num_layers: int, norm=None):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm = norm
+
+    def forward(self, src: Tensor, mask=None, src_key_padding_mask: Optional[Tensor] = None,
+                src_lens: Optional[Tensor] = None) -> Tensor:
+        if mask is not None:
+            raise ValueError("TransformerEncoder: arbitrary attention masks are not supported, pass lengths")
+        if src_lens is None:
+            src_lens = _lens_from_kpm(src_key_padding_mask, src.size(0), src.size(1), src.device)
+        x = src
+        for layer in self.layers:
+            x = layer(x, src_lens)
+        if self.norm is not None:
+            x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x
+
+
+class TransformerDecoderLayer(nn.Module):
+    '''
+    Decoder layer which returns the per-head cross-attention weights (reference model/layers.py:7-74).
+    '''
+
+    def __init__(self, d_model: int, nhead: int, dim_feedforward: int = 2048, dropout: float = 0.1,
+                 norm_first: bool = False, batch_first: bool = True):
+        super().__init__()
+        if norm_first or not batch_first:
+            raise ValueError("TransformerDecoderLayer: batch_first, post-norm only (the reference's configuration)")
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm_first = norm_first
+        self.norm1 = nn.LayerNorm(d_model, eps=1e-5)
+        self.norm2 = nn.LayerNorm(d_model, eps=1e-5)
+        self.norm3 = nn.LayerNorm(d_model, eps=1e-5)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+
+    def forward(self, tgt: Tensor, memory: Tensor, tgt_mask: Optional[Tensor] = None,
+                memory_mask: Optional[Tensor] = None, tgt_key_padding_mask: Optional[Tensor] = None,
+                memory_key_padding_mask: Optional[Tensor] = None, tgt_is_causal: bool = True,
+                memory_is_causal: bool = False, tgt_lens: Optional[Tensor] = None,
+                memory_lens: Optional[Tensor] = None):
+        if memory_mask is not None or memory_is_causal:
+            raise ValueError("TransformerDecoderLayer: memory masks other than key padding are not supported")
+        B = tgt.size(0)
+        if tgt_lens is None:
+            tgt_lens = _lens_from_kpm(tgt_key_padding_mask, B, tgt.size(1), tgt.device)
+        if memory_lens is None:
+            memory_lens = _lens_from_kpm(memory_key_padding_mask, B, memory.size(1), tgt.device)
+        causal = bool(tgt_is_causal) or tgt_mask is not None
+        tr = self.training
+        s = self.self_attn.self_attention(tgt, tgt_lens, causal, residual=tgt, out_drop=self.dropout1.p if tr else 0.0)
+        x = ops.layer_norm(s, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        s, alignments = self.multihead_attn.cross_attention(x, memory, memory_lens, residual=x,
+                                                            out_drop=self.dropout2.p if tr else 0.0)
+        x = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x = ops.layer_norm(_ffn_block(self, x, self.dropout3), self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return x, alignments
+
+
+class TransformerDecoder(nn.Module):
+    '''
+    Decoder stack which returns the alignments of every layer (reference model/layers.py:77-111).
+    '''
+
+    def __init__(self, decoder_layer, num_layers, norm=None):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(decoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm = norm
+
+    def forward(self, tgt: Tensor, memory: Tensor, tgt_mask: Optional[Tensor] = None,
+                memory_mask: Optional[Tensor] = None, tgt_key_padding_mask: Optional[Tensor] = None,
+                memory_key_padding_mask: Optional[Tensor] = None, tgt_is_causal: Optional[bool] = None,
+                memory_is_causal: Optional[bool] = None, tgt_lens: Optional[Tensor] = None,
+                memory_lens: Optional[Tensor] = None):
+        B = tgt.size(0)
+        if tgt_lens is None:
+            tgt_lens = _lens_from_kpm(tgt_key_padding_mask, B, tgt.size(1), tgt.device)
+        if memory_lens is None:
+            memory_lens = _lens_from_kpm(memory_key_padding_mask, B, memory.size(1), tgt.device)
+        alignments = []
+        for layer in self.layers:
+            tgt, alignment = layer(tgt=tgt, memory=memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                                   tgt_is_causal=True if tgt_is_causal is None else tgt_is_causal,
+                                   memory_is_causal=bool(memory_is_causal), tgt_lens=tgt_lens,
+                                   memory_lens=memory_lens)
+            alignments.append(alignment)
+        if self.norm is not None:
+            tgt = ops.layer_norm(tgt, self.norm.weight, self.norm.bias, self.norm.eps)
+        return tgt, alignments

@@ -1,0 +1,436 @@
+"""torch.autograd.Function wrappers over the C ABI (include/ttts_hip.h).
+
+PyTorch is used here only as plumbing: it owns device memory (caching allocator), the current HIP
+stream and the autograd graph.  Every arithmetic step on the path is a hand-written gfx950 kernel
+called through `_lib`; nothing in this file computes with torch ops on the hot path, and there is
+no CPU / eager fallback -- non-CUDA tensors are rejected.
+"""
+from __future__ import annotations
+
+from ctypes import c_void_p
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA/HIP tensor (the HIP path has no CPU fallback), got {t.device}")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty((max(int(nbytes), 16) + 3) // 4, dtype=torch.float32, device=device)
+
+
+class _SeedStream:
+    """64-bit dropout seeds: one per dropout site per forward call (the kernels hash seed + element index)."""
+
+    def __init__(self, base: int = 0x5EED5EED):
+        self.base = base
+        self.counter = 0
+
+    def manual_seed(self, seed: int) -> None:
+        self.base = int(seed) & 0xFFFFFFFFFFFF
+        self.counter = 0
+
+    def next(self) -> int:
+        self.counter += 1
+        return ((self.base * 0x9E3779B97F4A7C15) ^ (self.counter * 0xD1B54A32D192ED03)) & 0xFFFFFFFFFFFFFFFF
+
+
+seeds = _SeedStream()
+
+
+# ----------------------------------------------------------------------------------------------- linear
+class LinearFn(torch.autograd.Function):
+    """y = drop(act(x @ w.T + b)) + residual, rows optionally shifted by `row_shift` inside each utterance."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, act, drop_p, seed, row_shift, T):
+        lib = _lib.load()
+        x = _chk(x, "linear.x")
+        w = _chk(w, "linear.weight")
+        N, K = w.shape
+        if x.shape[-1] != K:
+            raise ValueError(f"linear: x has {x.shape[-1]} features, weight expects {K}")
+        if act == ACT_RELU and residual is not None:
+            raise ValueError("linear: relu epilogue cannot be combined with a residual")
+        M = x.numel() // K
+        y = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
+        b_ = _chk(b, "linear.bias") if b is not None else None
+        r_ = _chk(residual, "linear.residual") if residual is not None else None
+        if r_ is not None and r_.shape != y.shape:
+            raise ValueError("linear: residual shape mismatch")
+        _lib.check(lib.ttts_linear_fwd(_p(x), _p(w), _p(b_), _p(r_), _p(y), M, N, K, act, float(drop_p), seed,
+                                       row_shift, T, _stream()), "ttts_linear_fwd")
+        ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
+        ctx.cfg = (act, float(drop_p), seed, row_shift, T, b is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, y = ctx.saved_tensors
+        act, drop_p, seed, row_shift, T, has_b, has_r = ctx.cfg
+        N, K = w.shape
+        M = x.numel() // K
+        dy = _chk(dy, "linear.dy")
+        if act == ACT_RELU:
+            dacc = torch.empty_like(dy)
+            _lib.check(lib.ttts_relu_dropout_bwd(_p(dy), _p(y), _p(dacc), dy.numel(), drop_p, _stream()),
+                       "ttts_relu_dropout_bwd")
+        elif drop_p > 0.0:
+            dacc = torch.empty_like(dy)
+            _lib.check(lib.ttts_dropout_bwd(_p(dy), _p(dacc), dy.numel(), drop_p, seed, _stream()), "ttts_dropout_bwd")
+        else:
+            dacc = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if row_shift != 0:
+                raise RuntimeError("linear: input gradient through a shifted loader is not needed on this path")
+            dx = torch.empty_like(x)
+            _lib.check(lib.ttts_linear_bwd_data(_p(dacc), _p(w), None, _p(dx), M, N, K, _stream()), "ttts_linear_bwd_data")
+        if ctx.needs_input_grad[1]:
+            nbytes = lib.ttts_wgrad_workspace_bytes(M, N, K, 1)
+            ws = _ws(nbytes, x.device)
+            dw = torch.empty_like(w)
+            db = torch.empty(N, dtype=torch.float32, device=x.device) if has_b else None
+            _lib.check(lib.ttts_linear_bwd_weight(_p(dacc), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K,
+                                                  row_shift, T, _stream()), "ttts_linear_bwd_weight")
+        return dx, dw, db, (dy if has_r else None), None, None, None, None, None
+
+
+def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_shift=0, T=0):
+    return LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T)
+
+
+# ----------------------------------------------------------------------------------------------- heads
+class HeadsFn(torch.autograd.Function):
+    """mel = x @ w_mel.T + b_mel  (B,T,n_mels);  stop = x @ w_stop.T + b_stop  (B,T)  -- one read of dx."""
+
+    @staticmethod
+    def forward(ctx, x, w_mel, b_mel, w_stop, b_stop):
+        lib = _lib.load()
+        x = _chk(x, "heads.x")
+        N, K = w_mel.shape
+        M = x.numel() // K
+        mel = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
+        stop = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+        _lib.check(lib.ttts_linear_fwd(_p(x), _p(_chk(w_mel, "w_mel")), _p(b_mel), None, _p(mel), M, N, K, ACT_NONE, 0.0,
+                                       0, 0, 0, _stream()), "ttts_linear_fwd")
+        _lib.check(lib.ttts_rowdot_fwd(_p(x), _p(_chk(w_stop, "w_stop")), _p(b_stop), _p(stop), M, K, _stream()),
+                   "ttts_rowdot_fwd")
+        ctx.save_for_backward(x, w_mel, w_stop)
+        return mel, stop
+
+    @staticmethod
+    def backward(ctx, dmel, dstop):
+        lib = _lib.load()
+        x, w_mel, w_stop = ctx.saved_tensors
+        N, K = w_mel.shape
+        M = x.numel() // K
+        dmel = _chk(dmel, "heads.dmel")
+        dstop = _chk(dstop, "heads.dstop")
+        dx = torch.empty_like(x)
+        _lib.check(lib.ttts_linear_bwd_data(_p(dmel), _p(w_mel), None, _p(dx), M, N, K, _stream()), "ttts_linear_bwd_data")
+        ws = _ws(lib.ttts_wgrad_workspace_bytes(M, N, K, 1), x.device)
+        dw_mel = torch.empty_like(w_mel)
+        db_mel = torch.empty(N, dtype=torch.float32, device=x.device)
+        _lib.check(lib.ttts_linear_bwd_weight(_p(dmel), _p(x), _p(dw_mel), _p(db_mel), _p(ws), ws.numel() * 4, M, N, K, 0,
+                                              0, _stream()), "ttts_linear_bwd_weight")
+        ws2 = _ws(lib.ttts_rowdot_bwd_workspace_bytes(K), x.device)
+        dw_stop = torch.empty_like(w_stop)
+        db_stop = torch.empty(1, dtype=torch.float32, device=x.device)
+        _lib.check(lib.ttts_rowdot_bwd(_p(dstop), _p(x), _p(w_stop), _p(dx), _p(dw_stop), _p(db_stop), _p(ws2),
+                                       ws2.numel() * 4, M, K, _stream()), "ttts_rowdot_bwd")
+        return dx, dw_mel, db_mel, dw_stop, db_stop
+
+
+# ----------------------------------------------------------------------------------------------- conv + BN
+class ConvBNFn(torch.autograd.Function):
+    """z = drop(act(BatchNorm1d(Conv1d_same(x)))) on (B,T,C); running stats updated in place when training."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act,
+                drop_p, seed):
+        lib = _lib.load()
+        x = _chk(x, "conv_bn.x")
+        B, T, cin = x.shape
+        cout, cin_w, taps = conv_w.shape
+        if cin != cin_w:
+            raise ValueError(f"conv_bn: x has {cin} channels, weight expects {cin_w}")
+        dev = x.device
+        conv_w = _chk(conv_w, "conv.weight")
+        w_fwd = torch.empty(cout * taps * cin, dtype=torch.float32, device=dev)
+        _lib.check(lib.ttts_conv1d_pack_weight(_p(conv_w), _p(w_fwd), None, cout, cin, taps, _stream()),
+                   "ttts_conv1d_pack_weight")
+        y = torch.empty(B, T, cout, dtype=torch.float32, device=dev)
+        _lib.check(lib.ttts_conv1d_fwd(_p(x), _p(w_fwd), _p(conv_b), _p(y), B, T, cin, cout, taps, _stream()),
+                   "ttts_conv1d_fwd")
+        mean = torch.empty(cout, dtype=torch.float32, device=dev)
+        invstd = torch.empty(cout, dtype=torch.float32, device=dev)
+        M = B * T
+        if training:
+            ws = _ws(lib.ttts_bn_workspace_bytes(M, cout), dev)
+            _lib.check(lib.ttts_bn_train_stats(_p(y), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(nbt),
+                                               _p(ws), ws.numel() * 4, M, cout, float(momentum), float(eps), _stream()),
+                       "ttts_bn_train_stats")
+        else:
+            _lib.check(lib.ttts_bn_eval_stats(_p(running_mean), _p(running_var), _p(mean), _p(invstd), cout, float(eps),
+                                              _stream()), "ttts_bn_eval_stats")
+        z = torch.empty_like(y)
+        _lib.check(lib.ttts_bn_apply_fwd(_p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(z), M, cout, act,
+                                         float(drop_p), seed, _stream()), "ttts_bn_apply_fwd")
+        ctx.save_for_backward(x, conv_w, y, mean, invstd, gamma, beta)
+        ctx.cfg = (training, act, float(drop_p), seed, conv_b is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        x, conv_w, y, mean, invstd, gamma, beta = ctx.saved_tensors
+        training, act, drop_p, seed, has_b = ctx.cfg
+        if not training:
+            raise RuntimeError("conv_bn: backward is implemented for train-mode BatchNorm only")
+        B, T, cin = x.shape
+        cout, _, taps = conv_w.shape
+        dev = x.device
+        M = B * T
+        dz = _chk(dz, "conv_bn.dz")
+        dy = torch.empty_like(y)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        ws = _ws(lib.ttts_bn_workspace_bytes(M, cout), dev)
+        _lib.check(lib.ttts_bn_bwd(_p(dz), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(dgamma), _p(dbeta),
+                                   _p(ws), ws.numel() * 4, M, cout, act, drop_p, seed, _stream()), "ttts_bn_bwd")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w_bwd = torch.empty(cin * taps * cout, dtype=torch.float32, device=dev)
+            _lib.check(lib.ttts_conv1d_pack_weight(_p(conv_w), None, _p(w_bwd), cout, cin, taps, _stream()),
+                       "ttts_conv1d_pack_weight")
+            dx = torch.empty_like(x)
+            _lib.check(lib.ttts_conv1d_bwd_data(_p(dy), _p(w_bwd), _p(dx), B, T, cin, cout, taps, _stream()),
+                       "ttts_conv1d_bwd_data")
+        ws2 = _ws(lib.ttts_wgrad_workspace_bytes(M, cout, cin, taps), dev)
+        dw = torch.empty_like(conv_w)
+        db = torch.empty(cout, dtype=torch.float32, device=dev) if has_b else None
+        _lib.check(lib.ttts_conv1d_bwd_weight(_p(dy), _p(x), _p(dw), _p(db), _p(ws2), ws2.numel() * 4, B, T, cin, cout,
+                                              taps, _stream()), "ttts_conv1d_bwd_weight")
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+def conv_bn(x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum=0.1, eps=1e-5,
+            act=ACT_NONE, drop_p=0.0, seed=0):
+    return ConvBNFn.apply(x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act,
+                          drop_p, seed)
+
+
+# ----------------------------------------------------------------------------------------------- layer norm
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        lib = _lib.load()
+        x = _chk(x, "layernorm.x")
+        d = x.shape[-1]
+        M = x.numel() // d
+        y = torch.empty_like(x)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        _lib.check(lib.ttts_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, d, float(eps),
+                                          _stream()), "ttts_layernorm_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma, mean, rstd = ctx.saved_tensors
+        d = x.shape[-1]
+        M = x.numel() // d
+        dy = _chk(dy, "layernorm.dy")
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        ws = _ws(lib.ttts_layernorm_bwd_workspace_bytes(d), x.device)
+        _lib.check(lib.ttts_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
+                                          _p(ws), ws.numel() * 4, M, d, _stream()), "ttts_layernorm_bwd")
+        return dx, dgamma, dbeta, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def _attn_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, lens, causal, drop_p, seed, need_weights):
+    lib = _lib.load()
+    dev = q.device
+    o = torch.empty(B, Tq, H * 64, dtype=torch.float32, device=dev)
+    lse = torch.empty(B, H, Tq, dtype=torch.float32, device=dev)
+    attn = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=dev) if need_weights else None
+    _lib.check(lib.ttts_attention_fwd(q, k, v, _p(o), _p(lse), _p(attn), _p(lens), B, H, Tq, Tk, ldq, ldk, ldv, H * 64,
+                                      1 if causal else 0, float(drop_p), seed, _stream()), "ttts_attention_fwd")
+    return o, lse, attn
+
+
+def _off(t: torch.Tensor, col: int):
+    return c_void_p(t.data_ptr() + 4 * col)
+
+
+class SelfAttentionFn(torch.autograd.Function):
+    """o = softmax(mask(q k^T / 8)) v over a packed in-proj output qkv (B,T,3d); heads of 64."""
+
+    @staticmethod
+    def forward(ctx, qkv, lens, n_head, causal, drop_p, seed):
+        qkv = _chk(qkv, "self_attention.qkv")
+        lens = _chk(lens, "self_attention.lens", torch.int64)
+        B, T, d3 = qkv.shape
+        d = d3 // 3
+        if d != n_head * 64:
+            raise ValueError(f"attention kernels need head_dim 64 (d_model {d}, heads {n_head})")
+        o, lse, _ = _attn_fwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), d3, d3, d3, B, n_head, T, T, lens, causal,
+                              drop_p, seed, False)
+        ctx.save_for_backward(qkv, o, lse, lens)
+        ctx.cfg = (n_head, causal, float(drop_p), seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        lib = _lib.load()
+        qkv, o, lse, lens = ctx.saved_tensors
+        n_head, causal, drop_p, seed = ctx.cfg
+        B, T, d3 = qkv.shape
+        d = d3 // 3
+        do = _chk(do, "self_attention.do")
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        _lib.check(lib.ttts_attention_bwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta),
+                                          _off(dqkv, 0), _off(dqkv, d), _off(dqkv, 2 * d), _p(lens), B, n_head, T, T, d3,
+                                          d3, d3, d, d3, d3, d3, 1 if causal else 0, drop_p, seed, _stream()),
+                   "ttts_attention_bwd")
+        return dqkv, None, None, None, None, None
+
+
+class CrossAttentionFn(torch.autograd.Function):
+    """Encoder-decoder attention: q (B,Tq,d), packed kv (B,Tk,2d) -> o (B,Tq,d), weights (B,H,Tq,Tk) post-dropout."""
+
+    @staticmethod
+    def forward(ctx, q, kv, lens, n_head, drop_p, seed):
+        q = _chk(q, "cross_attention.q")
+        kv = _chk(kv, "cross_attention.kv")
+        lens = _chk(lens, "cross_attention.lens", torch.int64)
+        B, Tq, d = q.shape
+        Tk = kv.shape[1]
+        if d != n_head * 64:
+            raise ValueError(f"attention kernels need head_dim 64 (d_model {d}, heads {n_head})")
+        o, lse, attn = _attn_fwd(_off(q, 0), _off(kv, 0), _off(kv, d), d, 2 * d, 2 * d, B, n_head, Tq, Tk, lens, False,
+                                 drop_p, seed, True)
+        ctx.save_for_backward(q, kv, o, lse, lens)
+        ctx.cfg = (n_head, float(drop_p), seed)
+        ctx.mark_non_differentiable(attn)
+        return o, attn
+
+    @staticmethod
+    def backward(ctx, do, _dattn):
+        lib = _lib.load()
+        q, kv, o, lse, lens = ctx.saved_tensors
+        n_head, drop_p, seed = ctx.cfg
+        B, Tq, d = q.shape
+        Tk = kv.shape[1]
+        do = _chk(do, "cross_attention.do")
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        delta = torch.empty_like(lse)
+        _lib.check(lib.ttts_attention_bwd(_off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
+                                          _off(dq, 0), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk, d, 2 * d,
+                                          2 * d, d, d, 2 * d, 2 * d, 0, drop_p, seed, _stream()), "ttts_attention_bwd")
+        return dq, dkv, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------- small pieces
+class EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, table):
+        lib = _lib.load()
+        ids = _chk(ids, "embedding.ids", torch.int64)
+        table = _chk(table, "embedding.weight")
+        vocab, d = table.shape
+        out = torch.empty(*ids.shape, d, dtype=torch.float32, device=table.device)
+        _lib.check(lib.ttts_embedding_fwd(_p(ids), _p(table), _p(out), ids.numel(), vocab, d, _stream()),
+                   "ttts_embedding_fwd")
+        ctx.save_for_backward(ids)
+        ctx.shape = (vocab, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        (ids,) = ctx.saved_tensors
+        vocab, d = ctx.shape
+        dout = _chk(dout, "embedding.dout")
+        dtable = torch.empty(vocab, d, dtype=torch.float32, device=dout.device)
+        _lib.check(lib.ttts_embedding_bwd(_p(ids), _p(dout), _p(dtable), ids.numel(), vocab, d, _stream()),
+                   "ttts_embedding_bwd")
+        return None, dtable
+
+
+class PosEncFn(torch.autograd.Function):
+    """y = drop(x + alpha * pe[:T])"""
+
+    @staticmethod
+    def forward(ctx, x, pe, alpha, drop_p, seed):
+        lib = _lib.load()
+        x = _chk(x, "posenc.x")
+        B, T, d = x.shape
+        if T > pe.shape[0] or d != pe.shape[1]:
+            raise ValueError("posenc: sequence longer than the table or width mismatch")
+        y = torch.empty_like(x)
+        _lib.check(lib.ttts_posenc_fwd(_p(x), _p(pe), _p(alpha), _p(y), B, T, d, float(drop_p), seed, _stream()),
+                   "ttts_posenc_fwd")
+        ctx.save_for_backward(pe)
+        ctx.cfg = (float(drop_p), seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (pe,) = ctx.saved_tensors
+        drop_p, seed = ctx.cfg
+        dy = _chk(dy, "posenc.dy")
+        B, T, d = dy.shape
+        dx = torch.empty_like(dy)
+        dalpha = torch.empty(1, dtype=torch.float32, device=dy.device)
+        ws = _ws(lib.ttts_posenc_bwd_workspace_bytes(), dy.device)
+        _lib.check(lib.ttts_posenc_bwd(_p(dy), _p(pe), _p(dx), _p(dalpha), _p(ws), ws.numel() * 4, B, T, d, drop_p, seed,
+                                       _stream()), "ttts_posenc_bwd")
+        return dx, None, dalpha, None, None
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        lib = _lib.load()
+        x = _chk(x, "add.x")
+        y = _chk(y, "add.y")
+        z = torch.empty_like(x)
+        _lib.check(lib.ttts_add(_p(x), _p(y), _p(z), x.numel(), _stream()), "ttts_add")
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        return dz, dz
