@@ -13,11 +13,16 @@ def pytest_configure(config):
 
 
 def rel_l2(a, b):
-    import torch
+    import inspect
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     den = b.norm().item()
-    return (a - b).norm().item() / (den if den > 0 else 1.0)
+    err = (a - b).norm().item() / (den if den > 0 else 1.0)
+    if os.environ.get("TTTS_ERRLOG"):      # development aid: log every measured error with its call site
+        fr = inspect.stack()[1]
+        with open(os.environ["TTTS_ERRLOG"], "a") as f:
+            f.write(f"{err:.3e} {os.path.basename(fr.filename)}:{fr.lineno} {fr.function} {(fr.code_context or [''])[0].strip()[:90]}\n")
+    return err
 
 
 @pytest.fixture(scope="session")

@@ -1,6 +1,6 @@
 """Per-kernel parity: every C-ABI entry point (called through transformertts_amd.ops) against a plain
 torch reference of the same op evaluated in fp64 on the CPU.  Tolerance 2e-5 rel-L2 unless stated
-(fp32 MFMA = exact fp32 fma chains; the end-to-end gate of north_star is 1e-4)."""
+(measured 5e-8 .. 8e-7: fp32 MFMA = exact fp32 fma chains; the end-to-end gate of north_star is 1e-4)."""
 import math
 
 import pytest
@@ -10,7 +10,7 @@ import torch.nn.functional as F
 from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
-TOL = 2e-5
+TOL = 5e-6
 
 
 def _dev():
@@ -101,10 +101,10 @@ def test_conv_bn_fwd_bwd(B, T, cin, cout, act, training):
         z.backward(dz.to(_dev()))
         assert int(nbt.item()) == 1
         assert rel_l2(rmg, rmd) < TOL and rel_l2(rvg, rvd) < TOL
-        assert rel_l2(xg.grad, xd.grad) < 5e-5
-        assert rel_l2(wg.grad, wd.grad) < 5e-5
-        assert rel_l2(gg.grad, gd.grad) < 5e-5
-        assert rel_l2(beg.grad, bed.grad) < 5e-5
+        assert rel_l2(xg.grad, xd.grad) < TOL
+        assert rel_l2(wg.grad, wd.grad) < TOL
+        assert rel_l2(gg.grad, gd.grad) < TOL
+        assert rel_l2(beg.grad, bed.grad) < TOL
         # conv bias in front of train-mode BN: analytically zero gradient
         assert bg.grad.abs().max().item() < 1e-3 * dz.abs().sum().item() / cout
     else:
@@ -157,7 +157,7 @@ def test_self_attention(B, H, T, causal, lens):
     out = ops.SelfAttentionFn.apply(qg, lens_t.to(_dev()), H, causal, 0.0, 0)
     out.backward(do.to(_dev()))
     assert rel_l2(out, ref) < TOL
-    assert rel_l2(qg.grad, qd.grad) < 5e-5
+    assert rel_l2(qg.grad, qd.grad) < TOL
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,lens", [(2, 2, 40, 12, [12, 5]), (2, 4, 300, 60, [60, 31]), (3, 4, 130, 100, [100, 64, 1]),
@@ -181,8 +181,8 @@ def test_cross_attention(B, H, Tq, Tk, lens):
     assert torch.all(attn.sum(-1).sub(1).abs() < 1e-5)
     for b, n in enumerate(lens):          # zero mass on padded keys
         assert float(attn[b, :, :, n:].abs().sum()) == 0.0
-    assert rel_l2(qg.grad, qd.grad) < 5e-5
-    assert rel_l2(kvg.grad, kvd.grad) < 5e-5
+    assert rel_l2(qg.grad, qd.grad) < TOL
+    assert rel_l2(kvg.grad, kvd.grad) < TOL
 
 
 def test_embedding_posenc_heads_add():

@@ -279,7 +279,7 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 # ----------------------------------------------------------------------------------------------- attention
 def _attn_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, lens, causal, drop_p, seed, need_weights):
     lib = _lib.load()
-    dev = q.device
+    dev = lens.device
     o = torch.empty(B, Tq, H * 64, dtype=torch.float32, device=dev)
     lse = torch.empty(B, H, Tq, dtype=torch.float32, device=dev)
     attn = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=dev) if need_weights else None
