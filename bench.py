@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py -- mel frames/sec of one teacher-forced Transformer-TTS training step on N MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = the arithmetic of the reference's `LightningModule.training_step` (lightning_module.py:45-86):
+no-grad forward (train mode) -> scheduled-sampling mix -> forward -> loss -> backward, followed by what the
+reference's Trainer does per optimizer step (train.py:38-51): gradient all-reduce (N > 1), global-norm clip 1.0,
+Adam + Noam LR.  Dropout is ON (p = 0.5 / 0.1 as config.yaml), BatchNorm in train mode, fp32 throughout.
+Workload at N = 1: BASELINE.json configs[2] -- batch 64, d_model 256, 3+3 layers, 4 heads, dense synthetic
+LJSpeech-shaped batch (100 phonemes, 870 frames x 80 mels per utterance, seed 1234); weak scaling (64 per GPU).
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def algorithmic_flops_forward(cfg, p: int, m: int) -> float:
+    """useful forward FLOPs of one utterance with p phonemes, m frames (causal half counted)."""
+    d, k = cfg["d_model"], cfg["encoder_prenet_kernel_size"]
+    n_mel, Le, Ld = cfg["n_mels"], cfg["encoder_n_layers"], cfg["decoder_n_layers"]
+    pre, post = cfg["encoder_prenet_n_layers"], cfg["postnet_n_layers"]
+    dffe, dffd = cfg["encoder_d_ffn"], cfg["decoder_d_ffn"]
+    E = pre * 2 * d * d * k + 2 * d * d + Le * (8 * d * d + 4 * d * dffe)
+    D = 2 * (n_mel * d + d * d) + Ld * (12 * d * d + 4 * d * dffd) + 2 * d * (n_mel + 1) \
+        + 2 * cfg["postnet_kernel_size"] * (2 * n_mel * d + (post - 2) * d * d)
+    return p * E + m * D + Le * 4 * p * p * d + Ld * 4 * p * d * d + Ld * 4 * m * p * d + Ld * 2 * m * (m + 1) * d
+
+
+class GemmProbe:
+    """HIP-event timing of every launch of the dominant kernel (the forward-type fp32 MFMA GEMM
+    gemm_f32_kernel<128,128,2,2,true,true>: nn.Linear forward, Conv1d forward and Conv1d data-gradient with N > 96)
+    on torch's current stream -- the stream the kernels are launched on."""
+
+    NAMES = ("ttts_linear_fwd", "ttts_conv1d_fwd", "ttts_conv1d_bwd_data")
+
+    def __init__(self, lib):
+        self.lib, self.records, self.orig = lib, [], {}
+
+    def _flops(self, name, a):
+        if name == "ttts_linear_fwd":
+            M, N, K = a[5], a[6], a[7]
+        elif name == "ttts_conv1d_fwd":          # (x, w, bias, y, B, T, cin, cout, taps, stream)
+            M, N, K = a[4] * a[5], a[7], a[6] * a[8]
+        else:                                    # bwd_data (dy, w, dx, B, T, cin, cout, taps, stream): N = cin, K = cout*taps
+            M, N, K = a[3] * a[4], a[5], a[6] * a[7]
+        return (2.0 * M * N * K, N)
+
+    def __enter__(self):
+        for n in self.NAMES:
+            fn = getattr(self.lib, n)
+            self.orig[n] = fn
+
+            def wrapped(*a, _fn=fn, _n=n):
+                fl, N = self._flops(_n, a)
+                if N <= 96:                      # 128x96 instantiation: not the dominant kernel
+                    return _fn(*a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _fn(*a)
+                e1.record()
+                self.records.append((e0, e1, fl))
+                return rc
+            setattr(self.lib, n, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for n, fn in self.orig.items():
+            setattr(self.lib, n, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = [e0.elapsed_time(e1) for e0, e1, _ in self.records]
+        fl = [f for _, _, f in self.records]
+        n = len(ms)
+        if n == 0:
+            return None
+        avg_ms, avg_fl = sum(ms) / n, sum(fl) / n
+        return {"launches": n, "avg_ms": avg_ms, "avg_flops": avg_fl, "tflops": avg_fl / (avg_ms * 1e-3) / 1e12}
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box exposes 256
+    logical CPUs but grants a 16-CPU share; oversubscribing the quota stalls the run)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(cfg, B: int, Tp: int, Tm: int, steps: int) -> dict:
+    """The oracle (CPU restatement, kind 'port') timed on this host's cores on a bounded sample of the same workload."""
+    from oracle import fill_state, synth_batch, oracle_training_step
+    torch.set_num_threads(usable_cores())
+    sd = fill_state(cfg, 42)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and k != "pe.pe":
+            v.requires_grad_(True)
+    batch = synth_batch(B, Tp, Tm, cfg["n_mels"], cfg["n_phon"], ragged=False, seed=1234)
+    times = []
+    for i in range(steps + 1):
+        for v in sd.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        loss, _, _ = oracle_training_step(sd, cfg, batch, epoch=0, dropout=True)
+        loss["total"].backward()
+        dt = time.perf_counter() - t0
+        if i > 0:
+            times.append(dt)
+    med = statistics.median(times)
+    return {"value": B * Tm / med, "unit": "mel frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle training step (2 fwd + bwd, fp32, dropout on), dense batch {B} x {Tm} frames x {Tp} phonemes, "
+                      f"median of {len(times)} steps after 1 warm-up, {med:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--tp", type=int, default=100)
+    ap.add_argument("--tm", type=int, default=870)
+    ap.add_argument("--config", default="base")
+    ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-probe", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from oracle.spec import model_config
+    from oracle.synth import synth_batch
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.lightning_module import LightningModule
+    from transformertts_amd.parallel import FlatGradBucket, broadcast_module_state
+
+    cfg = model_config(args.config)
+    config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
+              "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,
+                           "sync_loss_every_step": False, "max_grad_norm": 1.0}}
+    torch.manual_seed(42)
+    ops.seeds.manual_seed(42 + rank)
+    lm = LightningModule(config).to(dev)
+    lm.train()
+    broadcast_module_state(lm)
+    bucket = FlatGradBucket(lm.parameters())
+    opt_cfg = lm.configure_optimizers()
+    optimizer, scheduler = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
+
+    # per-rank shard of the global synthetic batch (weak scaling: args.batch utterances per GPU)
+    batch = synth_batch(args.batch, args.tp, args.tm, cfg["n_mels"], cfg["n_phon"], ragged=args.ragged, seed=1234 + rank)
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    frames_rank = int(batch["melspec_lens"].sum().item())
+    flops_rank = 4.0 * sum(algorithmic_flops_forward(cfg, int(p), int(m))
+                           for p, m in zip(batch["phoneme_lens"].tolist(), batch["melspec_lens"].tolist()))
+
+    def step(i):
+        bucket.zero()
+        loss = lm.training_step(batch, i)
+        loss.backward()
+        bucket.allreduce_mean()
+        bucket.clip_grad_norm_(config["training"]["max_grad_norm"])
+        optimizer.step()
+        scheduler.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_start = time.perf_counter()
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.2f}s] {msg}", file=sys.stderr, flush=True)
+
+    note(f"model and batch on device ({frames_rank} frames/rank)")
+    for i in range(args.warmup):
+        step(i)
+        torch.cuda.synchronize()
+        note(f"warm-up step {i} done")
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    note(f"{args.steps} timed steps: {elapsed / args.steps * 1e3:.2f} ms/step")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(frames_rank), flops_rank], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    frames_all, flops_all = float(tot[0].item()), float(tot[1].item())
+    final_loss = float(loss.item())
+
+    probe = None
+    if rank == 0 and not args.no_probe:
+        with GemmProbe(_lib.load()) as gp:     # one extra, untimed, instrumented step
+            step(args.warmup + args.steps)
+        probe = gp.summary()
+        note("instrumented step done")
+    fence()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "mel frames/sec teacher-forced step, LJSpeech-shape batch, 1/2/4/8 MI355X",
+            "value": frames_all * args.steps / elapsed, "unit": "mel frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: training step (no-grad fwd + fwd + loss + bwd + clip + Adam), "
+                                   f"batch {args.batch}/GPU x {args.tm} frames x {args.tp} phonemes "
+                                   f"({'ragged' if args.ragged else 'dense'}), {args.config} config d_model {cfg['d_model']}, "
+                                   f"{cfg['encoder_n_layers']}+{cfg['decoder_n_layers']} layers, dropout on, fp32",
+                       "global_batch": args.batch * world, "frames_per_step": frames_all, "parallelism": f"dp{world}",
+                       "final_loss": final_loss, "per_step_loss_item_sync": False},
+            "step_algorithmic_tflops": flops_all / 1e12,
+            "step_achieved_tflops_per_gpu": flops_all / world / (elapsed / args.steps) / 1e12,
+        }
+        if probe is not None:
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,2,2,true,true>",
+                               "achieved": probe["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": probe["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "launches_per_step": probe["launches"], "avg_launch_ms": probe["avg_ms"],
+                               "avg_launch_gflop": probe["avg_flops"] / 1e9}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, args.tp, args.tm, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
