@@ -50,10 +50,12 @@ int ttts_linear_fwd(const float* x, const float* w, const float* bias, const flo
 /* dx[M,K] = dy[M,N] . w[N,K] (+ residual[M,K])                      N % 16 == 0, K % 4 == 0 */
 int ttts_linear_bwd_data(const float* dy, const float* w, const float* residual, float* dx, int64_t M, int N, int K,
                          void* stream);
-/* dw[N,K] = dy[M,N]^T . x[M,K] (x rows shifted as in forward); dbias[N] = column sums of dy (optional) */
+/* dw[N,K] = dy[M,N]^T . x[M,K] (x rows shifted as in forward); dbias[N] = column sums of dy (optional).
+ * Every parameter-gradient output in this header takes `accumulate`: 0 stores, 1 adds to what is there, so that
+ * gradients can land directly in slices of one flat, pre-zeroed gradient buffer (the data-parallel bucket). */
 size_t ttts_wgrad_workspace_bytes(int64_t M, int N, int K, int taps);
 int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
-                           int64_t M, int N, int K, int row_shift, int T, void* stream);
+                           int64_t M, int N, int K, int row_shift, int T, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ Conv1d (k taps, same padding) on (B,T,C)
  * Replaces ConvNormBN's permute -> nn.Conv1d(pad=(k-1)//2) -> permute (model/module.py:28-33) as an
@@ -66,7 +68,7 @@ int ttts_conv1d_fwd(const float* x, const float* w_fwd, const float* bias, float
 int ttts_conv1d_bwd_data(const float* dy, const float* w_bwd, float* dx, int B, int T, int cin, int cout, int taps,
                          void* stream);
 int ttts_conv1d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
-                           int T, int cin, int cout, int taps, void* stream);
+                           int T, int cin, int cout, int taps, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm1d over (M = B*T rows, C channels)
  * Replaces nn.BatchNorm1d inside ConvNormBN (model/module.py:19,31) plus the Tanh / Dropout entries that
@@ -85,7 +87,7 @@ int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, co
 /* train-mode backward through drop/act/BN: dx, dgamma, dbeta from dz and the saved x, mean, invstd */
 int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float* invstd, const float* gamma,
                 const float* beta, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int C,
-                int act, float drop_p, uint64_t seed, void* stream);
+                int act, float drop_p, uint64_t seed, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm over the last dim (d % 64 == 0, d <= 1024)
  * Replaces nn.LayerNorm norm1/2/3 of the encoder/decoder layers (torch/nn/modules/transformer.py:951-956,
@@ -95,7 +97,7 @@ int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 size_t ttts_layernorm_bwd_workspace_bytes(int d);
 int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
-                       void* stream);
+                       int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ attention (head_dim = 64)
  * Scaled dot-product attention with masks computed from lengths in-kernel (no mask tensors):
@@ -119,13 +121,14 @@ int ttts_attention_bwd(const float* q, const float* k, const float* v, const flo
 /* ------------------------------------------------------------------ small row / element-wise pieces
  * nn.Embedding gather / scatter-add (model/model.py:168,288; no padding_idx) */
 int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d, void* stream);
-int ttts_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t n, int vocab, int d, void* stream);
+int ttts_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t n, int vocab, int d, int accumulate,
+                       void* stream);
 /* PositionalEncoding.forward (model/model.py:91-97): y = drop(x + alpha * pe[t]) */
 int ttts_posenc_fwd(const float* x, const float* pe, const float* alpha, float* y, int B, int T, int d, float drop_p,
                     uint64_t seed, void* stream);
 size_t ttts_posenc_bwd_workspace_bytes(void);
 int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, float* ws, size_t ws_bytes, int B, int T,
-                    int d, float drop_p, uint64_t seed, void* stream);
+                    int d, float drop_p, uint64_t seed, int accumulate, void* stream);
 /* dx = dy * 1[out > 0] / (1-p): backward of drop(relu(.)) given the forward output */
 int ttts_relu_dropout_bwd(const float* dy, const float* out, float* dx, int64_t n, float drop_p, void* stream);
 /* dx = dy * keep(seed, i) / (1-p) */
@@ -136,7 +139,7 @@ int ttts_add(const float* x, const float* y, float* z, int64_t n, void* stream);
 int ttts_rowdot_fwd(const float* x, const float* w, const float* b, float* y, int64_t M, int d, void* stream);
 size_t ttts_rowdot_bwd_workspace_bytes(int d);
 int ttts_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx_accum, float* dw, float* db, float* ws,
-                    size_t ws_bytes, int64_t M, int d, void* stream);
+                    size_t ws_bytes, int64_t M, int d, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,8 @@ def _g(t):
 
 @pytest.mark.parametrize("M,N,K,act,res", [(300, 256, 256, 0, False), (1000, 80, 256, 0, True), (777, 1024, 256, 1, False),
                                             (513, 256, 1024, 0, True), (64, 256, 80, 1, False), (4099, 768, 256, 0, False),
-                                            (130, 16, 128, 0, False)])
+                                            (130, 16, 128, 0, False), (24577, 512, 256, 1, False),
+                                            (26001, 256, 1024, 0, True), (50003, 80, 256, 0, False)])
 def test_linear_fwd_bwd(M, N, K, act, res):
     from transformertts_amd import ops
     x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3, scale=0.1)
@@ -74,7 +75,8 @@ def test_linear_go_frame_shift():
 
 @pytest.mark.parametrize("B,T,cin,cout,act,training", [(3, 37, 128, 128, 0, True), (2, 300, 80, 256, 2, True),
                                                         (2, 131, 256, 80, 0, True), (4, 50, 256, 256, 2, True),
-                                                        (2, 64, 256, 256, 2, False), (5, 1, 16, 128, 2, True)])
+                                                        (2, 64, 256, 256, 2, False), (5, 1, 16, 128, 2, True),
+                                                        (31, 870, 256, 256, 2, True), (61, 433, 80, 256, 0, True)])
 def test_conv_bn_fwd_bwd(B, T, cin, cout, act, training):
     from transformertts_amd import ops
     k = 5

@@ -21,33 +21,33 @@ SIGNATURES = {
     "ttts_linear_fwd": (I, [P, P, P, P, P, L, I, I, I, F, U, I, I, P]),
     "ttts_linear_bwd_data": (I, [P, P, P, P, L, I, I, P]),
     "ttts_wgrad_workspace_bytes": (Z, [L, I, I, I]),
-    "ttts_linear_bwd_weight": (I, [P, P, P, P, P, Z, L, I, I, I, I, P]),
+    "ttts_linear_bwd_weight": (I, [P, P, P, P, P, Z, L, I, I, I, I, I, P]),
     "ttts_conv1d_pack_bytes": (Z, [I, I, I]),
     "ttts_conv1d_pack_weight": (I, [P, P, P, I, I, I, P]),
     "ttts_conv1d_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "ttts_conv1d_bwd_data": (I, [P, P, P, I, I, I, I, I, P]),
-    "ttts_conv1d_bwd_weight": (I, [P, P, P, P, P, Z, I, I, I, I, I, P]),
+    "ttts_conv1d_bwd_weight": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, P]),
     "ttts_bn_workspace_bytes": (Z, [L, I]),
     "ttts_bn_train_stats": (I, [P, P, P, P, P, P, P, Z, L, I, F, F, P]),
     "ttts_bn_eval_stats": (I, [P, P, P, P, I, F, P]),
     "ttts_bn_apply_fwd": (I, [P, P, P, P, P, P, L, I, I, F, U, P]),
-    "ttts_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, Z, L, I, I, F, U, P]),
+    "ttts_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, Z, L, I, I, F, U, I, P]),
     "ttts_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
     "ttts_layernorm_bwd_workspace_bytes": (Z, [I]),
-    "ttts_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, P]),
+    "ttts_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P]),
     "ttts_attention_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P]),
     "ttts_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P]),
     "ttts_embedding_fwd": (I, [P, P, P, L, I, I, P]),
-    "ttts_embedding_bwd": (I, [P, P, P, L, I, I, P]),
+    "ttts_embedding_bwd": (I, [P, P, P, L, I, I, I, P]),
     "ttts_posenc_fwd": (I, [P, P, P, P, I, I, I, F, U, P]),
     "ttts_posenc_bwd_workspace_bytes": (Z, []),
-    "ttts_posenc_bwd": (I, [P, P, P, P, P, Z, I, I, I, F, U, P]),
+    "ttts_posenc_bwd": (I, [P, P, P, P, P, Z, I, I, I, F, U, I, P]),
     "ttts_relu_dropout_bwd": (I, [P, P, P, L, F, P]),
     "ttts_dropout_bwd": (I, [P, P, L, F, U, P]),
     "ttts_add": (I, [P, P, P, L, P]),
     "ttts_rowdot_fwd": (I, [P, P, P, P, L, I, P]),
     "ttts_rowdot_bwd_workspace_bytes": (Z, [I]),
-    "ttts_rowdot_bwd": (I, [P, P, P, P, P, P, P, Z, L, I, P]),
+    "ttts_rowdot_bwd": (I, [P, P, P, P, P, P, P, Z, L, I, I, P]),
 }
 
 _lib = None

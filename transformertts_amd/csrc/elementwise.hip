@@ -37,25 +37,44 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __res
     }
 }
 
-// one workgroup per vocabulary row: scans all ids in order and sums the matching rows (deterministic)
+// one workgroup per vocabulary row.  Positions holding this id are compacted IN ORDER into LDS, 256 ids per step
+// (wave ballots + prefix counts), then the matching gradient rows are summed in that fixed order: deterministic.
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
-                                                            float* __restrict__ dtable, long n, int d) {
+                                                            float* __restrict__ dtable, long n, int d, int accumulate) {
+    __shared__ int list[256];
+    __shared__ int wcount[4];
     const int v = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int MAXPER = 4;   // d <= 1024
     float acc[MAXPER] = {0.f, 0.f, 0.f, 0.f};
-    for (long i = 0; i < n; ++i) {
-        if (ids[i] == v) {
+    for (long base = 0; base < n; base += 256) {
+        const long i = base + tid;
+        const bool hit = (i < n) && (ids[i] == v);
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wcount[wave] = __popcll(m);
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += wcount[w];
+        const int total = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)(i - base);
+        __syncthreads();
+        for (int k = 0; k < total; ++k) {
+            const long row = base + list[k];
 #pragma unroll
             for (int j = 0; j < MAXPER; ++j) {
-                int c = threadIdx.x + 256 * j;
-                if (c < d) acc[j] += dout[i * d + c];
+                int c = tid + 256 * j;
+                if (c < d) acc[j] += dout[row * d + c];
             }
         }
+        __syncthreads();
     }
 #pragma unroll
     for (int j = 0; j < MAXPER; ++j) {
-        int c = threadIdx.x + 256 * j;
-        if (c < d) dtable[(long)v * d + c] = acc[j];
+        int c = tid + 256 * j;
+        if (c < d) {
+            long o = (long)v * d + c;
+            dtable[o] = accumulate ? dtable[o] + acc[j] : acc[j];
+        }
     }
 }
 
@@ -106,12 +125,12 @@ __global__ __launch_bounds__(256) void posenc_bwd_kernel(const float* __restrict
     if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void scalar_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int n) {
+__global__ void scalar_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int n, int accumulate) {
     // single wave, fixed order
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 64) s += ws[i];
     s = wave_sum(s);
-    if (threadIdx.x == 0) out[0] = s;
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
 }
 
 // ------------------------------------------------------------------ masks
@@ -166,7 +185,7 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict
     }
 }
 
-constexpr int RD_BWD_BLOCKS = 512;
+constexpr int RD_BWD_BLOCKS = 256;
 
 // dx[m,:] += dy[m]*w ; per-block partials of dw[c] = sum_m dy[m]*x[m,c] and db = sum_m dy[m] -> ws[block][d+1]
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -203,16 +222,6 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
         ws[(long)blockIdx.x * (d + 1) + d] = (red[0][1024] + red[1][1024]) + (red[2][1024] + red[3][1024]);
 }
 
-__global__ void rowdot_bwd_final_kernel(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db,
-                                        int nblk, int d) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > d) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += ws[(long)b * (d + 1) + c];
-    if (c < d) { if (dw) dw[c] = s; }
-    else if (db) db[0] = s;
-}
-
 }  // namespace ttts
 
 using namespace ttts;
@@ -220,7 +229,7 @@ using namespace ttts;
 extern "C" {
 
 const char* ttts_last_error(void) { return ttts::g_err; }
-int ttts_abi_version(void) { return 1; }
+int ttts_abi_version(void) { return 2; }
 
 int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d, void* stream) {
     TTTS_REQUIRE(ids && table && out, "embedding_fwd: null pointer");
@@ -233,10 +242,12 @@ int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64
     return TTTS_OK;
 }
 
-int ttts_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t n, int vocab, int d, void* stream) {
+int ttts_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t n, int vocab, int d, int accumulate,
+                       void* stream) {
     TTTS_REQUIRE(ids && dout && dtable, "embedding_bwd: null pointer");
     TTTS_REQUIRE(n > 0 && vocab > 0 && d > 0 && d <= 1024, "embedding_bwd: d=%d must be <= 1024", d);
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(vocab), dim3(256), 0, (hipStream_t)stream, ids, dout, dtable, (long)n, d);
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(vocab), dim3(256), 0, (hipStream_t)stream, ids, dout, dtable, (long)n, d,
+                       accumulate);
     TTTS_LAUNCH_CHECK("embedding_bwd_kernel");
     return TTTS_OK;
 }
@@ -257,7 +268,7 @@ int ttts_posenc_fwd(const float* x, const float* pe, const float* alpha, float* 
 size_t ttts_posenc_bwd_workspace_bytes(void) { return (size_t)PE_BWD_BLOCKS * sizeof(float); }
 
 int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, float* ws, size_t ws_bytes, int B, int T,
-                    int d, float drop_p, uint64_t seed, void* stream_) {
+                    int d, float drop_p, uint64_t seed, int accumulate, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && pe && dx && dalpha && ws, "posenc_bwd: null pointer");
     TTTS_REQUIRE(B > 0 && T > 0 && d > 0 && d % 4 == 0, "posenc_bwd: bad dims");
@@ -269,7 +280,7 @@ int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, 
     hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid), dim3(256), 0, stream, dy, pe, dx, ws, n4, T, d, 1.f / (1.f - drop_p),
                        thr, seed);
     TTTS_LAUNCH_CHECK("posenc_bwd_kernel");
-    hipLaunchKernelGGL(scalar_reduce_kernel, dim3(1), dim3(64), 0, stream, ws, dalpha, grid);
+    hipLaunchKernelGGL(scalar_reduce_kernel, dim3(1), dim3(64), 0, stream, ws, dalpha, grid, accumulate);
     TTTS_LAUNCH_CHECK("scalar_reduce_kernel");
     return TTTS_OK;
 }
@@ -311,7 +322,7 @@ int ttts_rowdot_fwd(const float* x, const float* w, const float* b, float* y, in
 size_t ttts_rowdot_bwd_workspace_bytes(int d) { return (size_t)RD_BWD_BLOCKS * (d + 1) * sizeof(float); }
 
 int ttts_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx_accum, float* dw, float* db, float* ws,
-                    size_t ws_bytes, int64_t M, int d, void* stream_) {
+                    size_t ws_bytes, int64_t M, int d, int accumulate, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && x && w && ws, "rowdot_bwd: null pointer");
     TTTS_REQUIRE(M > 0 && d > 0 && d % 64 == 0 && d <= 1024, "rowdot_bwd: d=%d must be a multiple of 64, <= 1024", d);
@@ -320,9 +331,7 @@ int ttts_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx_a
     if ((long)nblk * 4 > M) nblk = (int)((M + 3) / 4);
     hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dy, x, w, dx_accum, ws, (long)M, d);
     TTTS_LAUNCH_CHECK("rowdot_bwd_kernel");
-    hipLaunchKernelGGL(rowdot_bwd_final_kernel, dim3(cdiv(d + 1, 256)), dim3(256), 0, stream, ws, dw, db, nblk, d);
-    TTTS_LAUNCH_CHECK("rowdot_bwd_final_kernel");
-    return TTTS_OK;
+    return launch_reduce_rows(ws, d + 1, nblk, d + 1, dw, d, db, accumulate, stream);
 }
 
 }  // extern "C"

@@ -44,6 +44,8 @@ struct GemmArgs {
     uint64_t seed;
     const float* residual;
     long ldr;
+    // weight-gradient form only: per-split column sums of A (= bias gradient partials), [zsplit][M]
+    float* colsum;
 };
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
@@ -83,6 +85,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[NLA], rb[NLB];
+    float4 csum[NLA];   // running sum of this thread's A elements over the k-tiles (bias gradient, !A_KC form)
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) csum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // ---- per-thread static parts of the loaders
     // K-contiguous tiles: thread -> (row = idx>>2, chunk = idx&3); natural tiles: (krow = idx / (X/4), col4)
@@ -133,6 +138,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                     v = *reinterpret_cast<const float4*>(g.A + (long)k * g.lda + m);
                 }
                 ra[i] = v;
+                csum[i].x += v.x; csum[i].y += v.y; csum[i].z += v.z; csum[i].w += v.w;
             }
         }
         // ---------------- B
@@ -247,6 +253,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
     }
 
+    if constexpr (!A_KC && !B_KC) {
+        // bias-gradient partials: sum over this split's rows of dy for the BM output channels of the tile
+        if (g.colsum != nullptr && blockIdx.x == 0 && ztap == 0) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) {
+                int idx = tid + i * 256;
+                if (idx < BK * (BM / 4)) {
+                    int kr = idx / (BM / 4), c4 = idx % (BM / 4);
+                    *reinterpret_cast<float4*>(lds + kr * BM + c4 * 4) = csum[i];
+                }
+            }
+            __syncthreads();
+            if (tid < BM && m0 + tid < g.M) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int kr = 0; kr < BK; ++kr) sacc += lds[kr * BM + tid];
+                g.colsum[(long)zsplit * g.M + m0 + tid] = sacc;
+            }
+        }
+    }
+
     // ---------------- epilogue
     float* C = g.C + (long)z * g.c_zstride;
     const bool do_drop = g.drop_thr != 0u;
@@ -274,27 +302,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-// out[i] (+bias over rows) = sum_z ws[z][i]   -- deterministic second stage of the split weight gradients
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n, int nsplit) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += ws[(long)z * n + i];
-    out[i] = s;
-}
-
-// conv weight gradient: ws[split][tap][co][ci] -> dw[co][ci][tap]
-__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int cout, int cin,
-                                         int taps, int nsplit) {
+// conv weight gradient: ws[split][tap][co][ci] -> dw[co][ci][tap] (+= when accumulate)
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                int cout, int cin, int taps, int nsplit, int accumulate) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // index into [tap][co][ci]
     long per = (long)cout * cin;
     long n = per * taps;
     if (i >= n) return;
     int tap = (int)(i / per);
     long rem = i - (long)tap * per;
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += ws[(long)z * n + i];
-    dw[rem * taps + tap] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 4 <= nsplit; z += 4) {
+        s0 += ws[(long)z * n + i];
+        s1 += ws[(long)(z + 1) * n + i];
+        s2 += ws[(long)(z + 2) * n + i];
+        s3 += ws[(long)(z + 3) * n + i];
+    }
+    for (; z < nsplit; ++z) s0 += ws[(long)z * n + i];
+    float s = (s0 + s1) + (s2 + s3);
+    long o = rem * taps + tap;
+    dw[o] = accumulate ? dw[o] + s : s;
 }
 
 // w[co][ci][tap] -> wp[co][tap][ci]  (forward: K-contiguous rows per output channel)
@@ -313,19 +341,6 @@ __global__ void conv_pack_weight_kernel(const float* __restrict__ w, float* __re
     if (wt) wt[((long)ci * taps + tap) * cout + co] = v;
 }
 
-// column sums (bias gradients): out[c] = sum_r x[r][c]; two deterministic stages
-__global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long rows, int cols,
-                                      long ld, int rows_per_block) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    long r0 = (long)blockIdx.y * rows_per_block;
-    long r1 = r0 + rows_per_block;
-    if (r1 > rows) r1 = rows;
-    float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += x[r * ld + c];
-    part[(long)blockIdx.y * cols + c] = s;
-}
-
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
 static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t stream) {
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), zdim);
@@ -334,8 +349,13 @@ static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t stream) {
     return TTTS_OK;
 }
 
+enum { TILE_AUTO = 0, TILE_64 = 1 };
+
 template <bool A_KC, bool B_KC>
-static int dispatch_gemm(const GemmArgs& g, int zdim, hipStream_t stream) {
+static int dispatch_gemm(const GemmArgs& g, int zdim, int tile, hipStream_t stream) {
+    // 64x64 tiles when 128x128 tiles would leave most of the 256 CUs idle (encoder-side GEMMs, small weight gradients)
+    if (tile == TILE_AUTO && (long)cdiv(g.M, 128) * cdiv(g.N, 128) * zdim < 384) tile = TILE_64;
+    if (tile == TILE_64) return launch_gemm<64, 64, 2, 2, A_KC, B_KC>(g, zdim, stream);
     // N <= 96: a 128x96 tile (4 waves stacked along M) wastes less than 128x128 on the 80-wide mel GEMMs
     if (g.N <= 96) return launch_gemm<128, 96, 4, 1, A_KC, B_KC>(g, zdim, stream);
     return launch_gemm<128, 128, 2, 2, A_KC, B_KC>(g, zdim, stream);
@@ -348,11 +368,29 @@ static GemmArgs base_args() {
     g.T = 0; g.cin = 1; g.shift0 = 0; g.shift_step = 0; g.ztaps = 1;
     g.kt_per_split = 1 << 30; g.c_zstride = 0;
     g.bias = nullptr; g.act = 0; g.drop_scale = 1.f; g.drop_thr = 0; g.seed = 0;
-    g.residual = nullptr; g.ldr = 0;
+    g.residual = nullptr; g.ldr = 0; g.colsum = nullptr;
     return g;
 }
 
 static int aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// how the row (reduction) dimension of a weight gradient is split: about 768 workgroups (3 per CU) in flight
+struct WgradPlan { int tile; int nsplit; int kt_per_split; };
+static WgradPlan plan_wgrad(int64_t M, int N, int K, int taps) {
+    WgradPlan p;
+    long tiles = (long)cdiv(N, 128) * cdiv(K, 128) * taps;
+    p.tile = TILE_AUTO;
+    if (tiles < 16) { p.tile = TILE_64; tiles = (long)cdiv(N, 64) * cdiv(K, 64) * taps; }
+    long nkt = (M + BK - 1) / BK;
+    long want = 768 / tiles;
+    if (want < 1) want = 1;
+    if (want > nkt) want = nkt;
+    long per = (nkt + want - 1) / want;
+    if (per < 8 && nkt >= 8) per = 8;
+    p.kt_per_split = (int)per;
+    p.nsplit = (int)((nkt + per - 1) / per);
+    return p;
+}
 
 }  // namespace ttts
 
@@ -376,7 +414,7 @@ int ttts_linear_fwd(const float* x, const float* w, const float* bias, const flo
     g.bias = bias; g.act = act;
     if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; }
     g.residual = residual; g.ldr = N;
-    return dispatch_gemm<true, true>(g, 1, (hipStream_t)stream);
+    return dispatch_gemm<true, true>(g, 1, TILE_AUTO, (hipStream_t)stream);
 }
 
 int ttts_linear_bwd_data(const float* dy, const float* w, const float* residual, float* dx, int64_t M, int N, int K,
@@ -390,43 +428,31 @@ int ttts_linear_bwd_data(const float* dy, const float* w, const float* residual,
     g.A = dy; g.B = w; g.C = dx; g.M = (int)M; g.N = K; g.K = N;
     g.lda = N; g.ldb = K; g.ldc = K; g.cin = N;
     g.residual = residual; g.ldr = K;
-    return dispatch_gemm<true, false>(g, 1, (hipStream_t)stream);
+    return dispatch_gemm<true, false>(g, 1, TILE_AUTO, (hipStream_t)stream);
 }
 
 size_t ttts_wgrad_workspace_bytes(int64_t M, int N, int K, int taps) {
-    // split the row (reduction) dimension so that about 1024 workgroups exist
-    long tiles = (long)cdiv(N, 128) * cdiv(K, 128) * taps;
-    long nkt = (M + BK - 1) / BK;
-    long want = 1024 / tiles;
-    if (want < 1) want = 1;
-    if (want > nkt) want = nkt;
-    long per = (nkt + want - 1) / want;
-    long nsplit = (nkt + per - 1) / per;
-    return (size_t)nsplit * taps * N * K * sizeof(float) + (size_t)256 * (size_t)N * sizeof(float);
+    WgradPlan p = plan_wgrad(M, N, K, taps);
+    return ((size_t)p.nsplit * taps * N * K + (size_t)p.nsplit * N) * sizeof(float);
 }
 
-static int wgrad_common(const float* dy, const float* x, float* ws, int64_t M, int N, int K, int taps, int T, int shift0,
-                        int shift_step, int* nsplit_out, hipStream_t stream) {
-    long tiles = (long)cdiv(N, 128) * cdiv(K, 128) * taps;
-    long nkt = (M + BK - 1) / BK;
-    long want = 1024 / tiles;
-    if (want < 1) want = 1;
-    if (want > nkt) want = nkt;
-    long per = (nkt + want - 1) / want;
-    long nsplit = (nkt + per - 1) / per;
+static int wgrad_common(const float* dy, const float* x, float* ws, float* colsum_ws, int64_t M, int N, int K, int taps,
+                        int T, int shift0, int shift_step, WgradPlan* plan_out, hipStream_t stream) {
+    WgradPlan p = plan_wgrad(M, N, K, taps);
     GemmArgs g = base_args();
     // C[N][K] (per tap) = dy^T[N][M] . xshift[M][K]
     g.A = dy; g.B = x; g.C = ws; g.M = N; g.N = K; g.K = (int)M;
     g.lda = N; g.ldb = K; g.ldc = K;
     g.T = T; g.shift0 = shift0; g.shift_step = shift_step; g.ztaps = taps;
-    g.kt_per_split = (int)per; g.c_zstride = (long)N * K;
-    *nsplit_out = (int)nsplit;
-    return dispatch_gemm<false, false>(g, (int)(nsplit * taps), stream);
+    g.kt_per_split = p.kt_per_split; g.c_zstride = (long)N * K;
+    g.colsum = colsum_ws;
+    *plan_out = p;
+    return dispatch_gemm<false, false>(g, p.nsplit * taps, p.tile, stream);
 }
 
 int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
-                           int64_t M, int N, int K, int row_shift, int T, void* stream_) {
-    // dw[N,K] = dy[M,N]^T . x[M,K] ; dbias[N] = column sums of dy
+                           int64_t M, int N, int K, int row_shift, int T, int accumulate, void* stream_) {
+    // dw[N,K] (+)= dy[M,N]^T . x[M,K] ; dbias[N] (+)= column sums of dy
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && x && dw && ws, "linear_bwd_weight: null pointer");
     TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_bwd_weight: bad dims");
@@ -434,24 +460,15 @@ int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db
     TTTS_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(ws), "linear_bwd_weight: pointers must be 16-byte aligned");
     TTTS_REQUIRE(ws_bytes >= ttts_wgrad_workspace_bytes(M, N, K, 1), "linear_bwd_weight: workspace too small");
     TTTS_REQUIRE(row_shift == 0 || (T > 0 && M % T == 0), "linear_bwd_weight: row_shift needs T>0 and M %% T == 0");
-    int nsplit = 1;
-    int rc = wgrad_common(dy, x, ws, M, N, K, 1, row_shift != 0 ? T : 0, row_shift, 0, &nsplit, stream);
-    if (rc) return rc;
+    WgradPlan p;
     long n = (long)N * K;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, ws, dw, n, nsplit);
-    TTTS_LAUNCH_CHECK("splitk_reduce_kernel");
-    if (dbias) {
-        float* part = ws + (size_t)nsplit * n;
-        int nb = 256;
-        int rpb = cdiv(M, nb);
-        nb = cdiv(M, rpb);
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), nb), dim3(64), 0, stream, dy, part, (long)M, N,
-                           (long)N, rpb);
-        TTTS_LAUNCH_CHECK("colsum_partial_kernel");
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, part, dbias, (long)N, nb);
-        TTTS_LAUNCH_CHECK("splitk_reduce_kernel(bias)");
-    }
-    return TTTS_OK;
+    float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, N, K, 1).nsplit * n : nullptr;
+    int rc = wgrad_common(dy, x, ws, colsum_ws, M, N, K, 1, row_shift != 0 ? T : 0, row_shift, 0, &p, stream);
+    if (rc) return rc;
+    rc = launch_reduce_rows(ws, n, p.nsplit, n, dw, n, nullptr, accumulate, stream);
+    if (rc) return rc;
+    if (dbias) rc = launch_reduce_rows(colsum_ws, N, p.nsplit, N, dbias, N, nullptr, accumulate, stream);
+    return rc;
 }
 
 size_t ttts_conv1d_pack_bytes(int cout, int cin, int taps) { return (size_t)cout * cin * taps * sizeof(float); }
@@ -478,7 +495,7 @@ int ttts_conv1d_fwd(const float* x, const float* w_fwd, const float* bias, float
     g.lda = cin; g.ldb = (long)taps * cin; g.ldc = cout;
     g.T = T; g.cin = cin; g.shift0 = -((taps - 1) / 2); g.shift_step = 1;
     g.bias = bias;
-    return dispatch_gemm<true, true>(g, 1, (hipStream_t)stream);
+    return dispatch_gemm<true, true>(g, 1, TILE_AUTO, (hipStream_t)stream);
 }
 
 int ttts_conv1d_bwd_data(const float* dy, const float* w_bwd, float* dx, int B, int T, int cin, int cout, int taps,
@@ -492,37 +509,28 @@ int ttts_conv1d_bwd_data(const float* dy, const float* w_bwd, float* dx, int B, 
     g.A = dy; g.B = w_bwd; g.C = dx; g.M = B * T; g.N = cin; g.K = taps * cout;
     g.lda = cout; g.ldb = (long)taps * cout; g.ldc = cin;
     g.T = T; g.cin = cout; g.shift0 = (taps - 1) / 2; g.shift_step = -1;
-    return dispatch_gemm<true, true>(g, 1, (hipStream_t)stream);
+    return dispatch_gemm<true, true>(g, 1, TILE_AUTO, (hipStream_t)stream);
 }
 
 int ttts_conv1d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
-                           int T, int cin, int cout, int taps, void* stream_) {
-    // dw[co,ci,tap] = sum_{b,t} dy[b,t,co] * x[b,t+tap-pad,ci] ; dbias[co] = sum dy
+                           int T, int cin, int cout, int taps, int accumulate, void* stream_) {
+    // dw[co,ci,tap] (+)= sum_{b,t} dy[b,t,co] * x[b,t+tap-pad,ci] ; dbias[co] (+)= sum dy
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && x && dw && ws, "conv1d_bwd_weight: null pointer");
     TTTS_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "conv1d_bwd_weight: channel counts must be multiples of 4");
     TTTS_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(ws), "conv1d_bwd_weight: pointers must be 16-byte aligned");
     int64_t M = (int64_t)B * T;
     TTTS_REQUIRE(ws_bytes >= ttts_wgrad_workspace_bytes(M, cout, cin, taps), "conv1d_bwd_weight: workspace too small");
-    int nsplit = 1;
-    int rc = wgrad_common(dy, x, ws, M, cout, cin, taps, T, -((taps - 1) / 2), 1, &nsplit, stream);
-    if (rc) return rc;
+    WgradPlan p;
     long n = (long)cout * cin * taps;
+    float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, cout, cin, taps).nsplit * n : nullptr;
+    int rc = wgrad_common(dy, x, ws, colsum_ws, M, cout, cin, taps, T, -((taps - 1) / 2), 1, &p, stream);
+    if (rc) return rc;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, ws, dw, cout, cin, taps,
-                       nsplit);
+                       p.nsplit, accumulate);
     TTTS_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
-    if (dbias) {
-        float* part = ws + (size_t)nsplit * n;
-        int nb = 256;
-        int rpb = cdiv(M, nb);
-        nb = cdiv(M, rpb);
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cout, 64), nb), dim3(64), 0, stream, dy, part, (long)M, cout,
-                           (long)cout, rpb);
-        TTTS_LAUNCH_CHECK("colsum_partial_kernel");
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, stream, part, dbias, (long)cout, nb);
-        TTTS_LAUNCH_CHECK("splitk_reduce_kernel(bias)");
-    }
-    return TTTS_OK;
+    if (dbias) rc = launch_reduce_rows(colsum_ws, cout, p.nsplit, cout, dbias, cout, nullptr, accumulate, stream);
+    return rc;
 }
 
 }  // extern "C"

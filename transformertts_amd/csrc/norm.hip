@@ -46,100 +46,101 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
-constexpr int LN_BWD_BLOCKS = 512;
+constexpr int LN_BWD_BLOCKS = 256;
 
 // dx per row; per-block partial column sums of dy*xhat (dgamma) and dy (dbeta) -> ws[block][2][d]
+template <int NPER>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
-                                                            float* __restrict__ ws, long M, int d) {
-    __shared__ float red[4][2][1024];
+                                                            float* __restrict__ ws, long M) {
+    constexpr int d = NPER * 64;
+    __shared__ float red[4][2][d];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nper = d >> 6;
-    float g[LN_MAXPER], accg[LN_MAXPER], accb[LN_MAXPER];
+    float g[NPER], accg[NPER], accb[NPER];
 #pragma unroll
-    for (int i = 0; i < LN_MAXPER; ++i) {
+    for (int i = 0; i < NPER; ++i) {
         accg[i] = 0.f; accb[i] = 0.f;
-        g[i] = (i < nper) ? gamma[lane + 64 * i] : 0.f;
+        g[i] = gamma[lane + 64 * i];
     }
     for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
         const float* xr = x + row * d;
         const float* dr = dy + row * d;
-        float xh[LN_MAXPER], gd[LN_MAXPER];
+        float xh[NPER], gd[NPER];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXPER; ++i) {
-            if (i < nper) {
-                int c = lane + 64 * i;
-                float dyv = dr[c];
-                xh[i] = (xr[c] - mu) * rs;
-                gd[i] = dyv * g[i];
-                s1 += gd[i];
-                s2 += gd[i] * xh[i];
-                accg[i] += dyv * xh[i];
-                accb[i] += dyv;
-            }
+        for (int i = 0; i < NPER; ++i) {
+            int c = lane + 64 * i;
+            float dyv = dr[c];
+            xh[i] = (xr[c] - mu) * rs;
+            gd[i] = dyv * g[i];
+            s1 += gd[i];
+            s2 += gd[i] * xh[i];
+            accg[i] += dyv * xh[i];
+            accb[i] += dyv;
         }
         s1 = wave_sum(s1) / (float)d;
         s2 = wave_sum(s2) / (float)d;
         float* dxr = dx + row * d;
 #pragma unroll
-        for (int i = 0; i < LN_MAXPER; ++i) {
-            if (i < nper) dxr[lane + 64 * i] = rs * (gd[i] - s1 - xh[i] * s2);
-        }
+        for (int i = 0; i < NPER; ++i) dxr[lane + 64 * i] = rs * (gd[i] - s1 - xh[i] * s2);
     }
 #pragma unroll
-    for (int i = 0; i < LN_MAXPER; ++i) {
-        if (i < nper) {
-            red[wave][0][lane + 64 * i] = accg[i];
-            red[wave][1][lane + 64 * i] = accb[i];
-        }
+    for (int i = 0; i < NPER; ++i) {
+        red[wave][0][lane + 64 * i] = accg[i];
+        red[wave][1][lane + 64 * i] = accb[i];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < 2 * d; c += 256) {
         int which = c / d, col = c - which * d;
-        float s = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
-        ws[((long)blockIdx.x * 2 + which) * d + col] = s;
+        float sum = (red[0][which][col] + red[1][which][col]) + (red[2][which][col] + red[3][which][col]);
+        ws[((long)blockIdx.x * 2 + which) * d + col] = sum;
     }
-}
-
-// out0[c] = sum_b ws[b][0][c], out1[c] = sum_b ws[b][1][c]
-__global__ void pair_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out0, float* __restrict__ out1,
-                                   int nblk, int d) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * d) return;
-    int which = c / d, col = c - which * d;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += ws[((long)b * 2 + which) * d + col];
-    float* o = which ? out1 : out0;
-    if (o) o[col] = s;
 }
 
 // ------------------------------------------------------------------------------------------ BatchNorm
-constexpr int BN_MAXBLK = 256;
+constexpr int BN_MAXBLK = 128;
 
-// per (row-chunk, channel): count, mean, M2 (Welford), merged deterministically by bn_stats_final_kernel
-__global__ void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ ws, long M, int C,
-                                        int rows_per_block) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// per (row-chunk, channel): count, mean, M2 = sum (x - mean)^2.  Block = 64 channels x 4 row-lanes; two passes over the
+// chunk (the second one hits L2) so no division sits in the streaming loops; merged deterministically afterwards.
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ ws, long M,
+                                                               int C, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool ok = c < C;
     long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    float mean = 0.f, m2 = 0.f;
-    float n = 0.f;
-    for (long r = r0; r < r1; ++r) {
-        float v = x[r * C + c];
-        n += 1.f;
-        float dlt = v - mean;
-        mean += dlt / n;
-        m2 += dlt * (v - mean);
+    const float n = (float)(r1 - r0);
+    float s0 = 0.f, s1 = 0.f;
+    if (ok) {
+        long r = r0 + rl;
+        for (; r + 4 < r1; r += 8) { s0 += x[r * C + c]; s1 += x[(r + 4) * C + c]; }
+        if (r < r1) s0 += x[r * C + c];
     }
-    float* w = ws + ((long)blockIdx.y * 3) * C;
-    w[c] = n;
-    w[C + c] = mean;
-    w[2 * C + c] = m2;
+    red[rl][cl] = s0 + s1;
+    __syncthreads();
+    const float mean = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / n;
+    __syncthreads();
+    float q0 = 0.f, q1 = 0.f;
+    if (ok) {
+        long r = r0 + rl;
+        for (; r + 4 < r1; r += 8) {
+            float a = x[r * C + c] - mean, b = x[(r + 4) * C + c] - mean;
+            q0 += a * a; q1 += b * b;
+        }
+        if (r < r1) { float a = x[r * C + c] - mean; q0 += a * a; }
+    }
+    red[rl][cl] = q0 + q1;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        float* w = ws + ((long)blockIdx.y * 3) * C;
+        w[c] = n;
+        w[C + c] = mean;
+        w[2 * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    }
 }
 
 __global__ void bn_stats_final_kernel(const float* __restrict__ ws, float* __restrict__ mean_out,
@@ -217,44 +218,46 @@ __device__ __forceinline__ float bn_dy_pre(float dz, float xhat, float gamma, fl
     return g;
 }
 
-// per (row-chunk, channel): sum dy, sum dy*xhat -> ws[blk][2][C]
-__global__ void bn_bwd_partial_kernel(const float* __restrict__ dz, const float* __restrict__ x,
-                                      const float* __restrict__ mean, const float* __restrict__ invstd,
-                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                      float* __restrict__ ws, long M, int C, int rows_per_block, int act, float drop_scale,
-                                      uint32_t thr, uint64_t seed) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// per (row-chunk, channel): sum dy, sum dy*xhat -> ws[blk][2C]  (block = 64 channels x 4 row-lanes)
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ ws, long M, int C, int rows_per_block,
+                                                             int act, float drop_scale, uint32_t thr, uint64_t seed) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool ok = c < C;
     long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
     float s1 = 0.f, s2 = 0.f;
-    for (long r = r0; r < r1; ++r) {
-        long e = r * C + c;
-        float xh = (x[e] - mu) * is;
-        float g = bn_dy_pre(dz[e], xh, ga, be, act, drop_scale, thr, seed, (uint64_t)e);
-        s1 += g;
-        s2 += g * xh;
+    if (ok) {
+        const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+        for (long r = r0 + rl; r < r1; r += 4) {
+            long e = r * C + c;
+            float xh = (x[e] - mu) * is;
+            float g = bn_dy_pre(dz[e], xh, ga, be, act, drop_scale, thr, seed, (uint64_t)e);
+            s1 += g;
+            s2 += g * xh;
+        }
     }
-    ws[((long)blockIdx.y * 2) * C + c] = s1;
-    ws[((long)blockIdx.y * 2 + 1) * C + c] = s2;
+    red[0][rl][cl] = s1;
+    red[1][rl][cl] = s2;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        ws[((long)blockIdx.y * 2) * C + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        ws[((long)blockIdx.y * 2 + 1) * C + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
 }
 
-// sums[0][c] = sum dy (= dbeta), sums[1][c] = sum dy*xhat (= dgamma)
-__global__ void bn_bwd_final_kernel(const float* __restrict__ ws, float* __restrict__ sums, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, int nblk, int C) {
+// dgamma / dbeta (+)= the reduced sums
+__global__ void bn_param_grad_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     int C, int accumulate) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += ws[((long)b * 2) * C + c];
-        s2 += ws[((long)b * 2 + 1) * C + c];
-    }
-    sums[c] = s1;
-    sums[C + c] = s2;
-    if (dbeta) dbeta[c] = s1;
-    if (dgamma) dgamma[c] = s2;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sums[c] : sums[c];
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sums[C + c] : sums[C + c];
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ x,
@@ -312,18 +315,27 @@ size_t ttts_layernorm_bwd_workspace_bytes(int d) { return (size_t)LN_BWD_BLOCKS 
 
 int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
-                       void* stream_) {
+                       int accumulate, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && x && mean && rstd && gamma && dx && ws, "layernorm_bwd: null pointer");
     TTTS_REQUIRE(M > 0 && d > 0 && d % 64 == 0 && d <= 64 * LN_MAXPER, "layernorm_bwd: bad d=%d", d);
     TTTS_REQUIRE(ws_bytes >= ttts_layernorm_bwd_workspace_bytes(d), "layernorm_bwd: workspace too small");
     int nblk = LN_BWD_BLOCKS;
     if ((long)nblk * 4 > M) nblk = cdiv(M, 4);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M, d);
+#define TTTS_LN_BWD(NPER)                                                                                         \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<NPER>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, \
+                       (long)M)
+    switch (d / 64) {
+        case 1: TTTS_LN_BWD(1); break;
+        case 2: TTTS_LN_BWD(2); break;
+        case 4: TTTS_LN_BWD(4); break;
+        case 8: TTTS_LN_BWD(8); break;
+        case 16: TTTS_LN_BWD(16); break;
+        default: TTTS_REQUIRE(false, "layernorm_bwd: d=%d must be 64, 128, 256, 512 or 1024", d);
+    }
+#undef TTTS_LN_BWD
     TTTS_LAUNCH_CHECK("layernorm_bwd_kernel");
-    hipLaunchKernelGGL(pair_reduce_kernel, dim3(cdiv(2 * d, 256)), dim3(256), 0, stream, ws, dgamma, dbeta, nblk, d);
-    TTTS_LAUNCH_CHECK("pair_reduce_kernel");
-    return TTTS_OK;
+    return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate, stream);
 }
 
 size_t ttts_bn_workspace_bytes(int64_t M, int C) {
@@ -340,7 +352,7 @@ int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* runni
     TTTS_REQUIRE(ws_bytes >= ttts_bn_workspace_bytes(M, C), "bn_train_stats: workspace too small");
     int rpb;
     int nb = bn_blocks(M, &rpb);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(cdiv(C, 64), nb), dim3(64), 0, stream, x, ws, (long)M, C, rpb);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(cdiv(C, 64), nb), dim3(256), 0, stream, x, ws, (long)M, C, rpb);
     TTTS_LAUNCH_CHECK("bn_stats_partial_kernel");
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, ws, mean, invstd, running_mean,
                        running_var, num_batches_tracked, nb, C, momentum, eps);
@@ -375,7 +387,7 @@ int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, co
 
 int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float* invstd, const float* gamma,
                 const float* beta, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int C,
-                int act, float drop_p, uint64_t seed, void* stream_) {
+                int act, float drop_p, uint64_t seed, int accumulate, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dz && x && mean && invstd && gamma && beta && dx && ws, "bn_bwd: null pointer");
     TTTS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd: C=%d must be a multiple of 4", C);
@@ -385,11 +397,13 @@ int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float*
     uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     float scale = 1.f / (1.f - drop_p);
     float* sums = ws + (size_t)BN_MAXBLK * 3 * C;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(C, 64), nb), dim3(64), 0, stream, dz, x, mean, invstd, gamma, beta,
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(C, 64), nb), dim3(256), 0, stream, dz, x, mean, invstd, gamma, beta,
                        ws, (long)M, C, rpb, act, scale, thr, seed);
     TTTS_LAUNCH_CHECK("bn_bwd_partial_kernel");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, ws, sums, dgamma, dbeta, nb, C);
-    TTTS_LAUNCH_CHECK("bn_bwd_final_kernel");
+    int rc = launch_reduce_rows(ws, 2 * C, nb, 2 * C, sums, 2 * C, nullptr, 0, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, sums, dgamma, dbeta, C, accumulate);
+    TTTS_LAUNCH_CHECK("bn_param_grad_kernel");
     long n4 = (long)M * C / 4;
     int grid = (int)((n4 + 255) / 256);
     if (grid > 4096) grid = 4096;

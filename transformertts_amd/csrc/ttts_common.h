@@ -30,6 +30,10 @@ void set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// out0[c] (+)= sum_r ws[r*ld + c] for c < n0, out1[c - n0] for the rest (reduce.hip); fixed summation order
+int launch_reduce_rows(const float* ws, long ld, int nrows, long ncols, float* out0, long n0, float* out1, int accumulate,
+                       hipStream_t stream);
+
 // ---------------------------------------------------------------- counter-based dropout RNG
 // keep(seed, idx) is a pure function of the 64-bit site seed and the flat element index, so the
 // backward kernels regenerate exactly the forward mask without storing it.

@@ -56,6 +56,22 @@ class _SeedStream:
 seeds = _SeedStream()
 
 
+def _sink(t: Optional[torch.Tensor]):
+    """Gradient sink of a parameter: a slice of the flat data-parallel gradient bucket (parallel.FlatGradBucket).
+    When every parameter of an op has one, the backward kernels ADD their result straight into it
+    (`accumulate=1`) and autograd gets None -- no per-tensor accumulation kernels, no flatten copy."""
+    return None if t is None else getattr(t, "_ttts_grad_sink", None)
+
+
+def _sinks(*params):
+    """(list of destinations or None, accumulate flag): sinks are used only if all given parameters have one."""
+    live = [p for p in params if p is not None]
+    sk = [_sink(p) for p in live]
+    if live and all(x is not None for x in sk):
+        return [(_sink(p) if p is not None else None) for p in params], 1
+    return None, 0
+
+
 # ----------------------------------------------------------------------------------------------- linear
 class LinearFn(torch.autograd.Function):
     """y = drop(act(x @ w.T + b)) + residual, rows optionally shifted by `row_shift` inside each utterance."""
@@ -80,6 +96,7 @@ class LinearFn(torch.autograd.Function):
                                        row_shift, T, _stream()), "ttts_linear_fwd")
         ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
         ctx.cfg = (act, float(drop_p), seed, row_shift, T, b is not None, residual is not None)
+        ctx.sinks = _sinks(w, b)
         return y
 
     @staticmethod
@@ -108,10 +125,14 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             nbytes = lib.ttts_wgrad_workspace_bytes(M, N, K, 1)
             ws = _ws(nbytes, x.device)
-            dw = torch.empty_like(w)
-            db = torch.empty(N, dtype=torch.float32, device=x.device) if has_b else None
-            _lib.check(lib.ttts_linear_bwd_weight(_p(dacc), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K,
-                                                  row_shift, T, _stream()), "ttts_linear_bwd_weight")
+            sk, acc = ctx.sinks
+            if sk is not None:
+                dw_t, db_t = sk
+            else:
+                dw_t = dw = torch.empty_like(w)
+                db_t = db = torch.empty(N, dtype=torch.float32, device=x.device) if has_b else None
+            _lib.check(lib.ttts_linear_bwd_weight(_p(dacc), _p(x), _p(dw_t), _p(db_t), _p(ws), ws.numel() * 4, M, N, K,
+                                                  row_shift, T, acc, _stream()), "ttts_linear_bwd_weight")
         return dx, dw, db, (dy if has_r else None), None, None, None, None, None
 
 
@@ -136,6 +157,7 @@ class HeadsFn(torch.autograd.Function):
         _lib.check(lib.ttts_rowdot_fwd(_p(x), _p(_chk(w_stop, "w_stop")), _p(b_stop), _p(stop), M, K, _stream()),
                    "ttts_rowdot_fwd")
         ctx.save_for_backward(x, w_mel, w_stop)
+        ctx.sinks = _sinks(w_mel, b_mel, w_stop, b_stop)
         return mel, stop
 
     @staticmethod
@@ -149,15 +171,20 @@ class HeadsFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         _lib.check(lib.ttts_linear_bwd_data(_p(dmel), _p(w_mel), None, _p(dx), M, N, K, _stream()), "ttts_linear_bwd_data")
         ws = _ws(lib.ttts_wgrad_workspace_bytes(M, N, K, 1), x.device)
-        dw_mel = torch.empty_like(w_mel)
-        db_mel = torch.empty(N, dtype=torch.float32, device=x.device)
-        _lib.check(lib.ttts_linear_bwd_weight(_p(dmel), _p(x), _p(dw_mel), _p(db_mel), _p(ws), ws.numel() * 4, M, N, K, 0,
-                                              0, _stream()), "ttts_linear_bwd_weight")
+        sk, acc = ctx.sinks
+        if sk is not None:
+            t_wm, t_bm, t_ws, t_bs = sk
+            dw_mel = db_mel = dw_stop = db_stop = None
+        else:
+            t_wm = dw_mel = torch.empty_like(w_mel)
+            t_bm = db_mel = torch.empty(N, dtype=torch.float32, device=x.device)
+            t_ws = dw_stop = torch.empty_like(w_stop)
+            t_bs = db_stop = torch.empty(1, dtype=torch.float32, device=x.device)
+        _lib.check(lib.ttts_linear_bwd_weight(_p(dmel), _p(x), _p(t_wm), _p(t_bm), _p(ws), ws.numel() * 4, M, N, K, 0,
+                                              0, acc, _stream()), "ttts_linear_bwd_weight")
         ws2 = _ws(lib.ttts_rowdot_bwd_workspace_bytes(K), x.device)
-        dw_stop = torch.empty_like(w_stop)
-        db_stop = torch.empty(1, dtype=torch.float32, device=x.device)
-        _lib.check(lib.ttts_rowdot_bwd(_p(dstop), _p(x), _p(w_stop), _p(dx), _p(dw_stop), _p(db_stop), _p(ws2),
-                                       ws2.numel() * 4, M, K, _stream()), "ttts_rowdot_bwd")
+        _lib.check(lib.ttts_rowdot_bwd(_p(dstop), _p(x), _p(w_stop), _p(dx), _p(t_ws), _p(t_bs), _p(ws2),
+                                       ws2.numel() * 4, M, K, acc, _stream()), "ttts_rowdot_bwd")
         return dx, dw_mel, db_mel, dw_stop, db_stop
 
 
@@ -198,6 +225,7 @@ class ConvBNFn(torch.autograd.Function):
                                          float(drop_p), seed, _stream()), "ttts_bn_apply_fwd")
         ctx.save_for_backward(x, conv_w, y, mean, invstd, gamma, beta)
         ctx.cfg = (training, act, float(drop_p), seed, conv_b is not None)
+        ctx.sinks = _sinks(conv_w, conv_b, gamma, beta)
         return z
 
     @staticmethod
@@ -213,11 +241,18 @@ class ConvBNFn(torch.autograd.Function):
         M = B * T
         dz = _chk(dz, "conv_bn.dz")
         dy = torch.empty_like(y)
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(beta)
+        sk, acc = ctx.sinks
+        dw = db = dgamma = dbeta = None
+        if sk is not None:
+            t_w, t_b, t_g, t_be = sk
+        else:
+            t_w = dw = torch.empty_like(conv_w)
+            t_b = db = torch.empty(cout, dtype=torch.float32, device=dev) if has_b else None
+            t_g = dgamma = torch.empty_like(gamma)
+            t_be = dbeta = torch.empty_like(beta)
         ws = _ws(lib.ttts_bn_workspace_bytes(M, cout), dev)
-        _lib.check(lib.ttts_bn_bwd(_p(dz), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(dgamma), _p(dbeta),
-                                   _p(ws), ws.numel() * 4, M, cout, act, drop_p, seed, _stream()), "ttts_bn_bwd")
+        _lib.check(lib.ttts_bn_bwd(_p(dz), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(t_g), _p(t_be),
+                                   _p(ws), ws.numel() * 4, M, cout, act, drop_p, seed, acc, _stream()), "ttts_bn_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
             w_bwd = torch.empty(cin * taps * cout, dtype=torch.float32, device=dev)
@@ -227,10 +262,8 @@ class ConvBNFn(torch.autograd.Function):
             _lib.check(lib.ttts_conv1d_bwd_data(_p(dy), _p(w_bwd), _p(dx), B, T, cin, cout, taps, _stream()),
                        "ttts_conv1d_bwd_data")
         ws2 = _ws(lib.ttts_wgrad_workspace_bytes(M, cout, cin, taps), dev)
-        dw = torch.empty_like(conv_w)
-        db = torch.empty(cout, dtype=torch.float32, device=dev) if has_b else None
-        _lib.check(lib.ttts_conv1d_bwd_weight(_p(dy), _p(x), _p(dw), _p(db), _p(ws2), ws2.numel() * 4, B, T, cin, cout,
-                                              taps, _stream()), "ttts_conv1d_bwd_weight")
+        _lib.check(lib.ttts_conv1d_bwd_weight(_p(dy), _p(x), _p(t_w), _p(t_b), _p(ws2), ws2.numel() * 4, B, T, cin, cout,
+                                              taps, acc, _stream()), "ttts_conv1d_bwd_weight")
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
@@ -254,6 +287,7 @@ class LayerNormFn(torch.autograd.Function):
         _lib.check(lib.ttts_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, d, float(eps),
                                           _stream()), "ttts_layernorm_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.sinks = _sinks(gamma, beta)
         return y
 
     @staticmethod
@@ -264,11 +298,16 @@ class LayerNormFn(torch.autograd.Function):
         M = x.numel() // d
         dy = _chk(dy, "layernorm.dy")
         dx = torch.empty_like(x)
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(gamma)
+        sk, acc = ctx.sinks
+        dgamma = dbeta = None
+        if sk is not None:
+            t_g, t_b = sk
+        else:
+            t_g = dgamma = torch.empty_like(gamma)
+            t_b = dbeta = torch.empty_like(gamma)
         ws = _ws(lib.ttts_layernorm_bwd_workspace_bytes(d), x.device)
-        _lib.check(lib.ttts_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
-                                          _p(ws), ws.numel() * 4, M, d, _stream()), "ttts_layernorm_bwd")
+        _lib.check(lib.ttts_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(t_g), _p(t_b),
+                                          _p(ws), ws.numel() * 4, M, d, acc, _stream()), "ttts_layernorm_bwd")
         return dx, dgamma, dbeta, None
 
 
@@ -375,6 +414,7 @@ class EmbeddingFn(torch.autograd.Function):
                    "ttts_embedding_fwd")
         ctx.save_for_backward(ids)
         ctx.shape = (vocab, d)
+        ctx.sinks = _sinks(table)
         return out
 
     @staticmethod
@@ -383,8 +423,13 @@ class EmbeddingFn(torch.autograd.Function):
         (ids,) = ctx.saved_tensors
         vocab, d = ctx.shape
         dout = _chk(dout, "embedding.dout")
-        dtable = torch.empty(vocab, d, dtype=torch.float32, device=dout.device)
-        _lib.check(lib.ttts_embedding_bwd(_p(ids), _p(dout), _p(dtable), ids.numel(), vocab, d, _stream()),
+        sk, acc = ctx.sinks
+        dtable = None
+        if sk is not None:
+            t = sk[0]
+        else:
+            t = dtable = torch.empty(vocab, d, dtype=torch.float32, device=dout.device)
+        _lib.check(lib.ttts_embedding_bwd(_p(ids), _p(dout), _p(t), ids.numel(), vocab, d, acc, _stream()),
                    "ttts_embedding_bwd")
         return None, dtable
 
@@ -404,6 +449,7 @@ class PosEncFn(torch.autograd.Function):
                    "ttts_posenc_fwd")
         ctx.save_for_backward(pe)
         ctx.cfg = (float(drop_p), seed)
+        ctx.sinks = _sinks(alpha)
         return y
 
     @staticmethod
@@ -414,9 +460,14 @@ class PosEncFn(torch.autograd.Function):
         dy = _chk(dy, "posenc.dy")
         B, T, d = dy.shape
         dx = torch.empty_like(dy)
-        dalpha = torch.empty(1, dtype=torch.float32, device=dy.device)
+        sk, acc = ctx.sinks
+        dalpha = None
+        if sk is not None:
+            t = sk[0]
+        else:
+            t = dalpha = torch.empty(1, dtype=torch.float32, device=dy.device)
         ws = _ws(lib.ttts_posenc_bwd_workspace_bytes(), dy.device)
-        _lib.check(lib.ttts_posenc_bwd(_p(dy), _p(pe), _p(dx), _p(dalpha), _p(ws), ws.numel() * 4, B, T, d, drop_p, seed,
+        _lib.check(lib.ttts_posenc_bwd(_p(dy), _p(pe), _p(dx), _p(t), _p(ws), ws.numel() * 4, B, T, d, drop_p, seed, acc,
                                        _stream()), "ttts_posenc_bwd")
         return dx, None, dalpha, None, None
 

@@ -32,9 +32,12 @@ class FlatGradBucket:
         self.attach()
 
     def attach(self) -> None:
-        """Point every .grad at its slice of the flat buffer (autograd then accumulates in place)."""
+        """Point every .grad at its slice of the flat buffer and register the slice as the parameter's gradient
+        sink: the HIP backward kernels then add their results straight into the bucket (ops._sink); anything that
+        still flows through autograd accumulates in place into the same memory."""
         for p, v in zip(self.params, self.views):
             p.grad = v
+            p._ttts_grad_sink = v
 
     def zero(self) -> None:
         self.flat.zero_()
