@@ -44,7 +44,7 @@ def gemm_wgrad(M, N, K):
     dy = torch.randn(M, N, device=dev); x = torch.randn(M, K, device=dev); dw = torch.empty(N, K, device=dev)
     db = torch.empty(N, device=dev)
     ws = _ws(lib.ttts_wgrad_workspace_bytes(M, N, K, 1), dev)
-    us = timeit(lambda: lib.ttts_linear_bwd_weight(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, _stream()))
+    us = timeit(lambda: lib.ttts_linear_bwd_weight(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 0, _stream()))
     print(f"linear_wgrad M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s (incl. reduce + bias)")
 
 
@@ -59,7 +59,7 @@ def conv(B, T, cin, cout):
     us = timeit(lambda: lib.ttts_conv1d_bwd_data(_p(y), _p(wb), _p(dx), B, T, cin, cout, 5, _stream()))
     print(f"conv_dgrad {cin:4d}->{cout:4d} M={B*T}: {us:8.1f} us {fl/us/1e6:7.1f} TF/s")
     ws = _ws(lib.ttts_wgrad_workspace_bytes(B * T, cout, cin, 5), dev)
-    us = timeit(lambda: lib.ttts_conv1d_bwd_weight(_p(y), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, B, T, cin, cout, 5, _stream()))
+    us = timeit(lambda: lib.ttts_conv1d_bwd_weight(_p(y), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, B, T, cin, cout, 5, 0, _stream()))
     print(f"conv_wgrad {cin:4d}->{cout:4d} M={B*T}: {us:8.1f} us {fl/us/1e6:7.1f} TF/s (incl. reduce + bias)")
 
 

@@ -10,7 +10,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libttts_hip.so")
+LIB_PATH = os.environ.get("TTTS_LIB", os.path.join(_HERE, "libttts_hip.so"))   # TTTS_LIB: development A/B builds
 
 P, I, L, F, U, Z = c_void_p, c_int, c_int64, c_float, c_uint64, c_size_t
 

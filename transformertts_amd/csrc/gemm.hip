@@ -19,7 +19,13 @@
 
 namespace ttts {
 
-constexpr int BK = 16;          // k-tile depth (floats)
+#ifndef TTTS_GEMM_BK
+#define TTTS_GEMM_BK 16
+#endif
+#ifndef TTTS_GEMM_MINWAVES
+#define TTTS_GEMM_MINWAVES 1
+#endif
+constexpr int BK = TTTS_GEMM_BK;          // k-tile depth (floats)
 constexpr int KC_LD = BK + 1;   // LDS row stride for K-contiguous tiles (odd -> conflict-free b32 reads)
 
 struct GemmArgs {
@@ -49,7 +55,7 @@ struct GemmArgs {
 };
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_f32_kernel(GemmArgs g) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
