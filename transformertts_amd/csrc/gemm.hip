@@ -52,7 +52,17 @@ struct GemmArgs {
     long ldr;
     // weight-gradient form only: per-split column sums of A (= bias gradient partials), [zsplit][M]
     float* colsum;
+    // operand extents in bytes (< 4 GiB): loads go through raw buffer descriptors, so an out-of-range offset returns
+    // zeros in hardware -- row / column / tap clipping costs a select on the offset instead of a branch around the load
+    uint32_t a_bytes, b_bytes;
 };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t OOB = 0xFFFFFFFFu;
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_f32_kernel(GemmArgs g) {
@@ -90,26 +100,45 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_f32_kernel(GemmA
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
+
     float4 ra[NLA], rb[NLB];
     float4 csum[NLA];   // running sum of this thread's A elements over the k-tiles (bias gradient, !A_KC form)
 #pragma unroll
     for (int i = 0; i < NLA; ++i) csum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // ---- per-thread static parts of the loaders
+    // ---- per-thread static parts of the loaders: byte offsets of this thread's float4s at k-tile 0
     // K-contiguous tiles: thread -> (row = idx>>2, chunk = idx&3); natural tiles: (krow = idx / (X/4), col4)
-    int a_t[NLA];     // A_KC: t index of the row inside its utterance (for shift clipping)
-    bool a_ok[NLA];
+    int a_t[NLA];          // A_KC: t index of the row inside its utterance (for shift clipping)
+    uint32_t a_off[NLA];   // OOB when the row / column is outside the matrix
+    uint32_t b_off[NLB];
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
         int idx = tid + i * 256;
         if (A_KC) {
-            int row = idx >> 2;
+            int row = idx >> 2, ch = idx & 3;
             int m = m0 + row;
-            a_ok[i] = (row < BM) && (m < g.M);
+            a_off[i] = (row < BM && m < g.M) ? (uint32_t)(((long)m * g.lda + ch * 4) * 4) : OOB;
             a_t[i] = (g.T > 0) ? (m % g.T) : 0;
         } else {
-            a_ok[i] = idx < BK * (BM / 4);
-            a_t[i] = 0;
+            int kr = idx / (BM / 4), c4 = idx % (BM / 4);
+            int m = m0 + c4 * 4;
+            a_off[i] = (idx < BK * (BM / 4) && m < g.M) ? (uint32_t)(((long)kr * g.lda + m) * 4) : OOB;
+            a_t[i] = kr;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        int idx = tid + i * 256;
+        if (B_KC) {
+            int row = idx >> 2, ch = idx & 3;
+            int n = n0 + row;
+            b_off[i] = (row < BN && n < g.N) ? (uint32_t)(((long)n * g.ldb + ch * 4) * 4) : OOB;
+        } else {
+            int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+            int n = n0 + c4 * 4;
+            b_off[i] = (idx < BK * (BN / 4) && n < g.N) ? (uint32_t)(((long)kr * g.ldb + n) * 4) : OOB;
         }
     }
 
@@ -120,56 +149,37 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_f32_kernel(GemmA
             const int tap = k0 / g.cin;
             const int c0 = k0 - tap * g.cin;
             const int shift = g.shift0 + tap * g.shift_step;
+            const uint32_t koff = (uint32_t)(((long)shift * g.lda + c0) * 4);
 #pragma unroll
             for (int i = 0; i < NLA; ++i) {
-                int idx = tid + i * 256;
-                int row = idx >> 2, ch = idx & 3;
-                bool ok = a_ok[i];
+                bool ok = a_off[i] != OOB;
                 if (g.T > 0) ok = ok && ((unsigned)(a_t[i] + shift) < (unsigned)g.T);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) {
-                    const float* p = g.A + (long)(m0 + row + shift) * g.lda + c0 + ch * 4;
-                    v = *reinterpret_cast<const float4*>(p);
-                }
-                ra[i] = v;
+                ra[i] = buf_load4(rsrcA, ok ? a_off[i] + koff : OOB);
             }
         } else {
+            const uint32_t koff = (uint32_t)((long)k0 * g.lda * 4);
 #pragma unroll
             for (int i = 0; i < NLA; ++i) {
-                int idx = tid + i * 256;
-                int kr = idx / (BM / 4), c4 = idx % (BM / 4);
-                int k = k0 + kr, m = m0 + c4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a_ok[i] && k < g.K && m < g.M) {   // M % 4 == 0 is required by the host wrapper
-                    v = *reinterpret_cast<const float4*>(g.A + (long)k * g.lda + m);
-                }
-                ra[i] = v;
-                csum[i].x += v.x; csum[i].y += v.y; csum[i].z += v.z; csum[i].w += v.w;
+                bool ok = a_off[i] != OOB && (k0 + a_t[i]) < g.K;
+                ra[i] = buf_load4(rsrcA, ok ? a_off[i] + koff : OOB);
+                csum[i].x += ra[i].x; csum[i].y += ra[i].y; csum[i].z += ra[i].z; csum[i].w += ra[i].w;
             }
         }
         // ---------------- B
         if (B_KC) {
+            const uint32_t koff = (uint32_t)(k0 * 4);
 #pragma unroll
-            for (int i = 0; i < NLB; ++i) {
-                int idx = tid + i * 256;
-                int row = idx >> 2, ch = idx & 3;
-                int n = n0 + row;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < BN && n < g.N) v = *reinterpret_cast<const float4*>(g.B + (long)n * g.ldb + k0 + ch * 4);
-                rb[i] = v;
-            }
+            for (int i = 0; i < NLB; ++i) rb[i] = buf_load4(rsrcB, b_off[i] != OOB ? b_off[i] + koff : OOB);
         } else {
             const int shift = g.shift0 + ztap * g.shift_step;
+            const uint32_t koff = (uint32_t)((long)(k0 + shift) * g.ldb * 4);
 #pragma unroll
             for (int i = 0; i < NLB; ++i) {
                 int idx = tid + i * 256;
-                int kr = idx / (BN / 4), c4 = idx % (BN / 4);
-                int k = k0 + kr, n = n0 + c4 * 4;
-                bool ok = (idx < BK * (BN / 4)) && k < g.K && n < g.N;
+                int k = k0 + idx / (BN / 4);
+                bool ok = b_off[i] != OOB && k < g.K;
                 if (g.T > 0) ok = ok && ((unsigned)((k % g.T) + shift) < (unsigned)g.T);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) v = *reinterpret_cast<const float4*>(g.B + (long)(k + shift) * g.ldb + n);
-                rb[i] = v;
+                rb[i] = buf_load4(rsrcB, ok ? b_off[i] + koff : OOB);
             }
         }
     };
@@ -374,7 +384,7 @@ static GemmArgs base_args() {
     g.T = 0; g.cin = 1; g.shift0 = 0; g.shift_step = 0; g.ztaps = 1;
     g.kt_per_split = 1 << 30; g.c_zstride = 0;
     g.bias = nullptr; g.act = 0; g.drop_scale = 1.f; g.drop_thr = 0; g.seed = 0;
-    g.residual = nullptr; g.ldr = 0; g.colsum = nullptr;
+    g.residual = nullptr; g.ldr = 0; g.colsum = nullptr; g.a_bytes = 0; g.b_bytes = 0;
     return g;
 }
 
@@ -416,6 +426,8 @@ int ttts_linear_fwd(const float* x, const float* w, const float* bias, const flo
     GemmArgs g = base_args();
     g.A = x; g.B = w; g.C = y; g.M = (int)M; g.N = N; g.K = K;
     g.lda = K; g.ldb = K; g.ldc = N;
+    TTTS_REQUIRE((uint64_t)M * K * 4 < (1ull << 32) && (uint64_t)N * K * 4 < (1ull << 32), "linear_fwd: operand larger than 4 GiB");
+    g.a_bytes = (uint32_t)((uint64_t)M * K * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 4);
     g.cin = K; g.shift0 = row_shift; g.T = (row_shift != 0) ? T : 0;
     g.bias = bias; g.act = act;
     if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; }
@@ -433,6 +445,8 @@ int ttts_linear_bwd_data(const float* dy, const float* w, const float* residual,
     GemmArgs g = base_args();
     g.A = dy; g.B = w; g.C = dx; g.M = (int)M; g.N = K; g.K = N;
     g.lda = N; g.ldb = K; g.ldc = K; g.cin = N;
+    TTTS_REQUIRE((uint64_t)M * N * 4 < (1ull << 32) && (uint64_t)N * K * 4 < (1ull << 32), "linear_bwd_data: operand larger than 4 GiB");
+    g.a_bytes = (uint32_t)((uint64_t)M * N * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 4);
     g.residual = residual; g.ldr = K;
     return dispatch_gemm<true, false>(g, 1, TILE_AUTO, (hipStream_t)stream);
 }
@@ -449,6 +463,11 @@ static int wgrad_common(const float* dy, const float* x, float* ws, float* colsu
     // C[N][K] (per tap) = dy^T[N][M] . xshift[M][K]
     g.A = dy; g.B = x; g.C = ws; g.M = N; g.N = K; g.K = (int)M;
     g.lda = N; g.ldb = K; g.ldc = K;
+    if (!((uint64_t)M * N * 4 < (1ull << 32) && (uint64_t)M * K * 4 < (1ull << 32))) {
+        set_error("weight gradient: operand larger than 4 GiB");
+        return TTTS_ERR_INVALID;
+    }
+    g.a_bytes = (uint32_t)((uint64_t)M * N * 4); g.b_bytes = (uint32_t)((uint64_t)M * K * 4);
     g.T = T; g.shift0 = shift0; g.shift_step = shift_step; g.ztaps = taps;
     g.kt_per_split = p.kt_per_split; g.c_zstride = (long)N * K;
     g.colsum = colsum_ws;
@@ -499,6 +518,8 @@ int ttts_conv1d_fwd(const float* x, const float* w_fwd, const float* bias, float
     GemmArgs g = base_args();
     g.A = x; g.B = w_fwd; g.C = y; g.M = B * T; g.N = cout; g.K = taps * cin;
     g.lda = cin; g.ldb = (long)taps * cin; g.ldc = cout;
+    TTTS_REQUIRE((uint64_t)B * T * cin * 4 < (1ull << 32), "conv1d_fwd: activation larger than 4 GiB");
+    g.a_bytes = (uint32_t)((uint64_t)B * T * cin * 4); g.b_bytes = (uint32_t)((uint64_t)cout * taps * cin * 4);
     g.T = T; g.cin = cin; g.shift0 = -((taps - 1) / 2); g.shift_step = 1;
     g.bias = bias;
     return dispatch_gemm<true, true>(g, 1, TILE_AUTO, (hipStream_t)stream);
@@ -514,6 +535,8 @@ int ttts_conv1d_bwd_data(const float* dy, const float* w_bwd, float* dx, int B, 
     GemmArgs g = base_args();
     g.A = dy; g.B = w_bwd; g.C = dx; g.M = B * T; g.N = cin; g.K = taps * cout;
     g.lda = cout; g.ldb = (long)taps * cout; g.ldc = cin;
+    TTTS_REQUIRE((uint64_t)B * T * cout * 4 < (1ull << 32), "conv1d_bwd_data: activation larger than 4 GiB");
+    g.a_bytes = (uint32_t)((uint64_t)B * T * cout * 4); g.b_bytes = (uint32_t)((uint64_t)cin * taps * cout * 4);
     g.T = T; g.cin = cout; g.shift0 = (taps - 1) / 2; g.shift_step = -1;
     return dispatch_gemm<true, true>(g, 1, TILE_AUTO, (hipStream_t)stream);
 }
