@@ -15,6 +15,8 @@
 //   B_KC  : B is [N][K] row-major, K contiguous (nn.Linear weight layout, packed conv weight).
 //   !B_KC : B is stored [K][N] (reduction index is the row) -- W for data-gradients, x for weight
 //           gradients (with the same per-tap row shift / utterance clipping as above).
+#include <stdlib.h>
+
 #include "ttts_common.h"
 
 namespace ttts {
@@ -299,20 +301,32 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_f32_kernel(GemmA
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * WTN + j * 32 + l31;
-            const float bv = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
+            const bool col_ok = col < g.N;
+            const float bv = (g.bias != nullptr && col_ok) ? g.bias[col] : 0.f;
+            const int row0 = m0 + wm * WTM + i * 32;
+            float res[16];
+            // all residual loads of the sub-tile are issued before the first store (one wait, not sixteen)
+            if (g.residual != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + acc_row(r, half);
+                    res[r] = (row < g.M && col_ok) ? g.residual[(long)row * g.ldr + col] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) res[r] = 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WTM + i * 32 + acc_row(r, half);
-                if (row < g.M && col < g.N) {
-                    float v = acc[i][j][r] + bv;
-                    if (g.act == 1) v = fmaxf(v, 0.f);
-                    if (do_drop) {
-                        uint64_t idx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
-                        v = keep_elem(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
-                    }
-                    if (g.residual != nullptr) v += g.residual[(long)row * g.ldr + col];
-                    C[(long)row * g.ldc + col] = v;
+                const int row = row0 + acc_row(r, half);
+                float v = acc[i][j][r] + bv;
+                if (g.act == 1) v = fmaxf(v, 0.f);
+                if (do_drop) {
+                    uint64_t idx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
+                    v = keep_elem(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
                 }
+                v += res[r];
+                if (row < g.M && col_ok) C[(long)row * g.ldc + col] = v;
             }
         }
     }
@@ -365,16 +379,44 @@ static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t stream) {
     return TTTS_OK;
 }
 
-enum { TILE_AUTO = 0, TILE_64 = 1 };
+enum { TILE_AUTO = 0, TILE_64 = 1, TILE_128 = 2, TILE_64x128 = 3, TILE_128x96 = 4 };
+
+// Pick the tile that minimises (rounds of workgroups over the chip) x (work per workgroup), i.e. the launch's
+// quantisation loss: e.g. M = 55 680, N = 256 is 870 tiles of 128x128 = 1.13 rounds of 768 resident workgroups
+// (the second round runs a mostly empty chip), but 1 740 tiles of 64x128 = 1.7 rounds of 1 024.
+static int choose_tile(long M, long N, long zdim) {
+    static int forced = -1;                       // development aid: TTTS_GEMM_TILE=1..4 forces a tile shape
+    if (forced < 0) { const char* e = getenv("TTTS_GEMM_TILE"); forced = e ? atoi(e) : 0; }
+    if (forced > 0) return forced;
+    struct Cand { int tile, bm, bn, per_cu; float eff; };
+    const Cand cands[] = {{TILE_128, 128, 128, 3, 1.00f}, {TILE_64x128, 64, 128, 4, 0.93f}, {TILE_64, 64, 64, 6, 0.80f}};
+    int best = TILE_128;
+    float best_cost = 1e30f;
+    for (const Cand& c : cands) {
+        long tiles = (long)cdiv(M, c.bm) * cdiv(N, c.bn) * zdim;
+        long slots = 256L * c.per_cu;
+        long full = tiles / slots;
+        float tail = (float)(tiles - full * slots) / (float)slots;   // fraction of the chip the last round fills
+        // a partially filled round still costs: its workgroups run at most ~2.2x faster on an emptier CU
+        float rounds = (float)full + (tail > 0.f ? (tail < 0.45f ? 0.45f : tail) : 0.f);
+        float cost = rounds * (float)slots * (float)(c.bm * c.bn) / c.eff;
+        if (cost < best_cost) { best_cost = cost; best = c.tile; }
+    }
+    return best;
+}
 
 template <bool A_KC, bool B_KC>
 static int dispatch_gemm(const GemmArgs& g, int zdim, int tile, hipStream_t stream) {
-    // 64x64 tiles when 128x128 tiles would leave most of the 256 CUs idle (encoder-side GEMMs, small weight gradients)
-    if (tile == TILE_AUTO && (long)cdiv(g.M, 128) * cdiv(g.N, 128) * zdim < 384) tile = TILE_64;
-    if (tile == TILE_64) return launch_gemm<64, 64, 2, 2, A_KC, B_KC>(g, zdim, stream);
-    // N <= 96: a 128x96 tile (4 waves stacked along M) wastes less than 128x128 on the 80-wide mel GEMMs
-    if (g.N <= 96) return launch_gemm<128, 96, 4, 1, A_KC, B_KC>(g, zdim, stream);
-    return launch_gemm<128, 128, 2, 2, A_KC, B_KC>(g, zdim, stream);
+    if (tile == TILE_AUTO) {
+        if (g.N <= 96 && (long)cdiv(g.M, 128) * zdim >= 384) tile = TILE_128x96;   // 80-wide mel GEMMs
+        else tile = choose_tile(g.M, g.N, zdim);
+    }
+    switch (tile) {
+        case TILE_64: return launch_gemm<64, 64, 2, 2, A_KC, B_KC>(g, zdim, stream);
+        case TILE_64x128: return launch_gemm<64, 128, 2, 2, A_KC, B_KC>(g, zdim, stream);
+        case TILE_128x96: return launch_gemm<128, 96, 4, 1, A_KC, B_KC>(g, zdim, stream);
+        default: return launch_gemm<128, 128, 2, 2, A_KC, B_KC>(g, zdim, stream);
+    }
 }
 
 static GemmArgs base_args() {
@@ -395,7 +437,7 @@ struct WgradPlan { int tile; int nsplit; int kt_per_split; };
 static WgradPlan plan_wgrad(int64_t M, int N, int K, int taps) {
     WgradPlan p;
     long tiles = (long)cdiv(N, 128) * cdiv(K, 128) * taps;
-    p.tile = TILE_AUTO;
+    p.tile = (K <= 96) ? TILE_128x96 : TILE_128;
     if (tiles < 16) { p.tile = TILE_64; tiles = (long)cdiv(N, 64) * cdiv(K, 64) * taps; }
     long nkt = (M + BK - 1) / BK;
     long want = 768 / tiles;
