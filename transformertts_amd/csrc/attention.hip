@@ -16,6 +16,17 @@
 
 namespace ttts {
 
+// minimum waves per SIMD the register allocator must leave room for (launch bounds), per kernel
+#ifndef TTTS_DKV_W
+#define TTTS_DKV_W 2
+#endif
+#ifndef TTTS_DQ_W
+#define TTTS_DQ_W 2
+#endif
+#ifndef TTTS_FWD_W
+#define TTTS_FWD_W 3
+#endif
+
 constexpr int HD = 64;            // head dim
 constexpr int KT_LD = HD + 1;     // LDS row stride (odd: conflict-free "row per lane" reads)
 constexpr int QB = 128;           // rows per workgroup (4 waves x 32)
@@ -31,24 +42,31 @@ struct AttnArgs {
     float drop_scale; uint32_t thr; uint64_t seed;
 };
 
-// ---- cooperative tile loaders (256 threads): 32 rows x 64 floats, rows beyond `nrows` read as zero
-__device__ __forceinline__ void load_tile_regs(const float* base, long row0, int nrows_total, int ld, int tid,
-                                               float4 (&r)[2]) {
+// ---- cooperative staging (256 threads): KB rows x 64 floats from global straight into LDS; rows beyond
+// `nrows_total` are zero.  No register prefetch across the compute phase: with 3-4 workgroups per CU the other
+// workgroups cover the load latency, and the registers are worth more as occupancy.
+constexpr int KB = 64;   // rows staged per barrier pair (two 32-row MFMA sub-tiles)
+template <bool PADDED>
+__device__ __forceinline__ void stage_rows(const float* base, long row0, long nrows_total, int ld, int tid, float* dst,
+                                           float scale) {
+    constexpr int LDD = PADDED ? KT_LD : HD;
+    float4 v[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
         int row = (tid >> 4) + 16 * i, c4 = tid & 15;
         long gr = row0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr < nrows_total) v = *reinterpret_cast<const float4*>(base + gr * ld + c4 * 4);
-        r[i] = v;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < nrows_total) v[i] = *reinterpret_cast<const float4*>(base + gr * ld + c4 * 4);
     }
-}
-__device__ __forceinline__ void store_tile_lds(float* dst, int ldd, int tid, const float4 (&r)[2], float scale) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
         int row = (tid >> 4) + 16 * i, c4 = tid & 15;
-        float* d = dst + row * ldd + c4 * 4;
-        d[0] = r[i].x * scale; d[1] = r[i].y * scale; d[2] = r[i].z * scale; d[3] = r[i].w * scale;
+        float* d = dst + row * LDD + c4 * 4;
+        if (PADDED) {
+            d[0] = v[i].x * scale; d[1] = v[i].y * scale; d[2] = v[i].z * scale; d[3] = v[i].w * scale;
+        } else {
+            *reinterpret_cast<float4*>(d) = make_float4(v[i].x * scale, v[i].y * scale, v[i].z * scale, v[i].w * scale);
+        }
     }
 }
 // one wave stages its own 32 x 64 tile (rows beyond nrows_total -> 0) into `dst` (stride KT_LD)
@@ -87,29 +105,36 @@ __device__ __forceinline__ void wave_store_rows(const f32x16 (&acc)[2], float* s
     wave_lds_sync();
 }
 
+// LDS budget shared by the three kernels: two staged 64-row tiles, re-used as per-wave 32x65 scratch in the
+// prologue / epilogue (4 waves x 8320 B = 33280 B)
+constexpr int SMEM_FLOATS = 4 * 32 * KT_LD;
+static_assert(2 * KB * KT_LD <= SMEM_FLOATS, "staging buffers must fit the shared scratch");
+
 // =====================================================================================  forward
 template <bool CAUSAL, bool WRITE_A>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) float Ks[32 * KT_LD];
-    __shared__ __attribute__((aligned(16))) float Vs[32 * HD];
-    __shared__ __attribute__((aligned(16))) float scratch_all[4 * 32 * KT_LD];
+__global__ __launch_bounds__(256, TTTS_FWD_W) void attn_fwd_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    __shared__ float ptile_all[WRITE_A ? 4 * 32 * 33 : 1];
+    float* Ks = smem;                  // [KB][65]
+    float* Vs = smem + KB * KT_LD;     // [KB][64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
+    float* ptile = ptile_all + (WRITE_A ? wave * 32 * 33 : 0);
     const int qblk = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;   // heaviest causal blocks first
     const int h = blockIdx.y, b = blockIdx.z;
     const int q0 = qblk * QB, qw0 = q0 + wave * 32;
     const int qg = qw0 + l31;
-    float* scratch = scratch_all + wave * 32 * KT_LD;
+    float* scratch = smem + wave * 32 * KT_LD;
 
     int klen = (int)a.key_lens[b];
     if (klen > a.Tk) klen = a.Tk;
     if (klen < 0) klen = 0;
     int kend = klen;
     if (CAUSAL && kend > q0 + QB) kend = q0 + QB;
-    const int ntiles_live = (kend + 31) / 32;
-    const int ntiles = WRITE_A ? (a.Tk + 31) / 32 : ntiles_live;
-    int wave_kend = kend;
+    const int nst_live = (kend + KB - 1) / KB;
+    const int nst = WRITE_A ? (a.Tk + KB - 1) / KB : nst_live;
+    int wave_kend = WRITE_A ? a.Tk : kend;
     if (CAUSAL && wave_kend > qw0 + 32) wave_kend = qw0 + 32;
 
     const float* qb_ = a.q + (long)b * a.Tq * a.ldq + h * HD;
@@ -122,7 +147,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < 32; ++j) qreg[j] = scratch[l31 * KT_LD + 2 * j + half];
-    wave_lds_sync();
 
     float m = NEG_INF, l = 0.f;
     f32x16 o[2];
@@ -130,45 +154,57 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
 
     const long arow = ((long)(b * a.H + h) * a.Tq);   // row base of the (B,H,Tq,*) outputs
+    const uint32_t rowid = (uint32_t)(arow + qg);
 
-    auto scores = [&](f32x16& s) {
+    auto scores = [&](const float* ks, f32x16& s) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-            float kf = Ks[l31 * KT_LD + 2 * j + half];
+            float kf = ks[l31 * KT_LD + 2 * j + half];
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, qreg[j], s, 0, 0, 0);
         }
     };
     auto alive = [&](int key_g) -> bool { return key_g < klen && (!CAUSAL || key_g <= qg); };
+    // dropout on the 16 weights of this lane: keys (r, r+1) with r even are neighbours and share one hash
+    auto drop16 = [&](float (&p)[16], int key0) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const int key_g = key0 + acc_row(r, half);
+            const uint32_t hsh = attn_hash(a.seed, rowid, (uint32_t)key_g >> 1);
+            p[r] = keep_from_hash(hsh, 0u, a.thr) ? p[r] * a.drop_scale : 0.f;
+            p[r + 1] = keep_from_hash(hsh, 1u, a.thr) ? p[r + 1] * a.drop_scale : 0.f;
+        }
+    };
 
-    float4 rk[2], rv[2];
     if (WRITE_A) {
         // ---------------- pass 1: row max / row sum only
-        if (ntiles_live > 0) load_tile_regs(kb_, 0, a.Tk, a.ldk, tid, rk);
-        for (int t = 0; t < ntiles_live; ++t) {
+        for (int t = 0; t < nst_live; ++t) {
             __syncthreads();
-            store_tile_lds(Ks, KT_LD, tid, rk, 1.f);
+            stage_rows<true>(kb_, (long)t * KB, a.Tk, a.ldk, tid, Ks, 1.f);
             __syncthreads();
-            if (t + 1 < ntiles_live) load_tile_regs(kb_, (long)(t + 1) * 32, a.Tk, a.ldk, tid, rk);
-            f32x16 s;
-            scores(s);
-            float mx = NEG_INF;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int key_g = t * 32 + acc_row(r, half);
-                s[r] = alive(key_g) ? s[r] : NEG_INF;
-                mx = fmaxf(mx, s[r]);
+            for (int sub = 0; sub < 2; ++sub) {
+                const int key0 = t * KB + sub * 32;
+                if (key0 >= kend) break;
+                f32x16 s;
+                scores(Ks + sub * 32 * KT_LD, s);
+                float mx = NEG_INF;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[r] = alive(key0 + acc_row(r, half)) ? s[r] : NEG_INF;
+                    mx = fmaxf(mx, s[r]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float m_new = fmaxf(m, mx);
+                float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+                float alpha = __expf(m - m_use);
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ps += __expf(s[r] - m_use);
+                l = l * alpha + ps;
+                m = m_new;
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float m_new = fmaxf(m, mx);
-            float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-            float alpha = __expf(m - m_use);
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ps += __expf(s[r] - m_use);
-            l = l * alpha + ps;
-            m = m_new;
         }
         l = l + __shfl_xor(l, 32, 64);
     }
@@ -177,83 +213,66 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const float inv_l = (l > 0.f) ? 1.f / l : 0.f;
 
     // ---------------- main pass
-    if (ntiles > 0) {
-        load_tile_regs(kb_, 0, a.Tk, a.ldk, tid, rk);
-        load_tile_regs(vb_, 0, a.Tk, a.ldv, tid, rv);
-    }
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = 0; t < nst; ++t) {
         __syncthreads();
-        store_tile_lds(Ks, KT_LD, tid, rk, 1.f);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int row = (tid >> 4) + 16 * i, c4 = tid & 15;
-            *reinterpret_cast<float4*>(Vs + row * HD + c4 * 4) = rv[i];
-        }
+        stage_rows<true>(kb_, (long)t * KB, a.Tk, a.ldk, tid, Ks, 1.f);
+        stage_rows<false>(vb_, (long)t * KB, a.Tk, a.ldv, tid, Vs, 1.f);
         __syncthreads();
-        if (t + 1 < ntiles) {
-            load_tile_regs(kb_, (long)(t + 1) * 32, a.Tk, a.ldk, tid, rk);
-            load_tile_regs(vb_, (long)(t + 1) * 32, a.Tk, a.ldv, tid, rv);
-        }
-        if (!WRITE_A && t * 32 >= wave_kend) continue;   // tile entirely above this wave's causal frontier
-
-        f32x16 s;
-        scores(s);
-        float p[16];
-        if (WRITE_A) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int key_g = t * 32 + acc_row(r, half);
-                p[r] = alive(key_g) ? __expf(s[r] - m_fin) * inv_l : 0.f;
+        for (int sub = 0; sub < 2; ++sub) {
+            const int key0 = t * KB + sub * 32;
+            if (key0 >= wave_kend) break;      // sub-tile entirely above this wave's causal frontier / past the keys
+            const float* ks = Ks + sub * 32 * KT_LD;
+            const float* vs = Vs + sub * 32 * HD;
+            f32x16 s;
+            scores(ks, s);
+            float p[16];
+            if (WRITE_A) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] = alive(key0 + acc_row(r, half)) ? __expf(s[r] - m_fin) * inv_l : 0.f;
+            } else {
+                float mx = NEG_INF;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[r] = alive(key0 + acc_row(r, half)) ? s[r] : NEG_INF;
+                    mx = fmaxf(mx, s[r]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float m_new = fmaxf(m, mx);
+                float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+                float alpha = __expf(m - m_use);
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { p[r] = __expf(s[r] - m_use); ps += p[r]; }
+                l = l * alpha + ps;
+                m = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
             }
-        } else {
-            float mx = NEG_INF;
+            if (a.thr != 0u) drop16(p, key0);
+            if (WRITE_A) {
+                // transpose the 32(key) x 32(query) tile through a small per-wave LDS buffer so every weight row leaves
+                // as a 128-B segment
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int key_g = t * 32 + acc_row(r, half);
-                s[r] = alive(key_g) ? s[r] : NEG_INF;
-                mx = fmaxf(mx, s[r]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float m_new = fmaxf(m, mx);
-            float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-            float alpha = __expf(m - m_use);
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { p[r] = __expf(s[r] - m_use); ps += p[r]; }
-            l = l * alpha + ps;
-            m = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-        }
-        if (a.thr != 0u) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int key_g = t * 32 + acc_row(r, half);
-                uint64_t idx = (uint64_t)(arow + qg) * (uint64_t)a.Tk + (uint64_t)key_g;
-                p[r] = keep_elem(a.seed, idx, a.thr) ? p[r] * a.drop_scale : 0.f;
-            }
-        }
-        if (WRITE_A) {
-            // transpose the 32(key) x 32(query) tile through LDS so each weight row is written as 128-B segments
-#pragma unroll
-            for (int r = 0; r < 16; ++r) scratch[l31 * 33 + acc_row(r, half)] = p[r];
-            wave_lds_sync();
+                for (int r = 0; r < 16; ++r) ptile[l31 * 33 + acc_row(r, half)] = p[r];
+                wave_lds_sync();
 #pragma unroll 4
-            for (int i = 0; i < 16; ++i) {
-                int qrow = 2 * i + half;
-                float v = scratch[qrow * 33 + l31];
-                int q_g = qw0 + qrow, key_g = t * 32 + l31;
-                if (q_g < a.Tq && key_g < a.Tk) a.attn[(arow + q_g) * a.Tk + key_g] = v;
+                for (int i = 0; i < 16; ++i) {
+                    const int qrow = 2 * i + half;
+                    const float v = ptile[qrow * 33 + l31];
+                    const int q_g = qw0 + qrow, key_g = key0 + l31;
+                    if (q_g < a.Tq && key_g < a.Tk) a.attn[(arow + q_g) * a.Tk + key_g] = v;
+                }
+                wave_lds_sync();
             }
-            wave_lds_sync();
-        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int krow = acc_row(r, half);
-            float v0 = Vs[krow * HD + l31];
-            float v1 = Vs[krow * HD + 32 + l31];
-            o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, p[r], o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, p[r], o[1], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) {
+                const int krow = acc_row(r, half);
+                float v0 = vs[krow * HD + l31];
+                float v1 = vs[krow * HD + 32 + l31];
+                o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, p[r], o[0], 0, 0, 0);
+                o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, p[r], o[1], 0, 0, 0);
+            }
         }
     }
 
@@ -275,10 +294,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
 // =====================================================================================  backward: dQ (+ delta)
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) float Ks[32 * KT_LD];
-    __shared__ __attribute__((aligned(16))) float Vs[32 * KT_LD];
-    __shared__ __attribute__((aligned(16))) float scratch_all[4 * 32 * KT_LD];
+__global__ __launch_bounds__(256, TTTS_DQ_W) void attn_bwd_dq_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    float* Ks = smem;                  // [KB][65]
+    float* Vs = smem + KB * KT_LD;     // [KB][65]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -286,14 +305,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const int h = blockIdx.y, b = blockIdx.z;
     const int q0 = qblk * QB, qw0 = q0 + wave * 32;
     const int qg = qw0 + l31;
-    float* scratch = scratch_all + wave * 32 * KT_LD;
+    float* scratch = smem + wave * 32 * KT_LD;
 
     int klen = (int)a.key_lens[b];
     if (klen > a.Tk) klen = a.Tk;
     if (klen < 0) klen = 0;
     int kend = klen;
     if (CAUSAL && kend > q0 + QB) kend = q0 + QB;
-    const int ntiles = (kend + 31) / 32;
+    const int nst = (kend + KB - 1) / KB;
     int wave_kend = kend;
     if (CAUSAL && wave_kend > qw0 + 32) wave_kend = qw0 + 32;
 
@@ -303,6 +322,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const float* ob_ = a.o + (long)b * a.Tq * a.ldo + h * HD;
     const float* gb_ = a.dout + (long)b * a.Tq * a.ldo + h * HD;
     const long arow = ((long)(b * a.H + h) * a.Tq);
+    const uint32_t rowid = (uint32_t)(arow + qg);
 
     float qreg[32], greg[32];
     wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
@@ -320,7 +340,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     float delta = 0.f;
 #pragma unroll
     for (int j = 0; j < 32; ++j) delta += greg[j] * scratch[l31 * KT_LD + 2 * j + half];
-    wave_lds_sync();
     delta += __shfl_xor(delta, 32, 64);
     if (half == 0 && qg < a.Tq) a.delta[arow + qg] = delta;
     const float lse_q = (qg < a.Tq) ? a.lse[arow + qg] : 0.f;
@@ -329,52 +348,51 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
 
-    float4 rk[2], rv[2];
-    if (ntiles > 0) {
-        load_tile_regs(kb_, 0, a.Tk, a.ldk, tid, rk);
-        load_tile_regs(vb_, 0, a.Tk, a.ldv, tid, rv);
-    }
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = 0; t < nst; ++t) {
         __syncthreads();
-        store_tile_lds(Ks, KT_LD, tid, rk, 1.f);
-        store_tile_lds(Vs, KT_LD, tid, rv, 1.f);
+        stage_rows<true>(kb_, (long)t * KB, a.Tk, a.ldk, tid, Ks, 1.f);
+        stage_rows<true>(vb_, (long)t * KB, a.Tk, a.ldv, tid, Vs, 1.f);
         __syncthreads();
-        if (t + 1 < ntiles) {
-            load_tile_regs(kb_, (long)(t + 1) * 32, a.Tk, a.ldk, tid, rk);
-            load_tile_regs(vb_, (long)(t + 1) * 32, a.Tk, a.ldv, tid, rv);
-        }
-        if (t * 32 >= wave_kend) continue;
-
-        f32x16 s, dp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        for (int sub = 0; sub < 2; ++sub) {
+            const int key0 = t * KB + sub * 32;
+            if (key0 >= wave_kend) break;
+            const float* ks = Ks + sub * 32 * KT_LD;
+            const float* vs = Vs + sub * 32 * KT_LD;
+            f32x16 s, dp;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            float kf = Ks[l31 * KT_LD + 2 * j + half];
-            float vf = Vs[l31 * KT_LD + 2 * j + half];
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, qreg[j], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, greg[j], dp, 0, 0, 0);
-        }
-        float ds[16];
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int key_g = t * 32 + acc_row(r, half);
-            bool live = key_g < klen && (!CAUSAL || key_g <= qg);
-            float p = live ? __expf(s[r] - lse_q) : 0.f;
-            float g = dp[r];
-            if (a.thr != 0u) {
-                uint64_t idx = (uint64_t)(arow + qg) * (uint64_t)a.Tk + (uint64_t)key_g;
-                g = keep_elem(a.seed, idx, a.thr) ? g * a.drop_scale : 0.f;
+            for (int j = 0; j < 32; ++j) {
+                float kf = ks[l31 * KT_LD + 2 * j + half];
+                float vf = vs[l31 * KT_LD + 2 * j + half];
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, qreg[j], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, greg[j], dp, 0, 0, 0);
             }
-            ds[r] = p * (g - delta);
-        }
+            float ds[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int krow = acc_row(r, half);
-            float k0 = Ks[krow * KT_LD + l31];
-            float k1 = Ks[krow * KT_LD + 32 + l31];
-            dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0, ds[r], dq[0], 0, 0, 0);
-            dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1, ds[r], dq[1], 0, 0, 0);
+            for (int r = 0; r < 16; r += 2) {
+                const int key_g = key0 + acc_row(r, half);
+                uint32_t hsh = 0;
+                if (a.thr != 0u) hsh = attn_hash(a.seed, rowid, (uint32_t)key_g >> 1);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int kg = key_g + e;
+                    bool live = kg < klen && (!CAUSAL || kg <= qg);
+                    float p = live ? __expf(s[r + e] - lse_q) : 0.f;
+                    float g = dp[r + e];
+                    if (a.thr != 0u) g = keep_from_hash(hsh, (uint32_t)e, a.thr) ? g * a.drop_scale : 0.f;
+                    ds[r + e] = p * (g - delta);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int krow = acc_row(r, half);
+                float k0 = ks[krow * KT_LD + l31];
+                float k1 = ks[krow * KT_LD + 32 + l31];
+                dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0, ds[r], dq[0], 0, 0, 0);
+                dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1, ds[r], dq[1], 0, 0, 0);
+            }
         }
     }
     __syncthreads();
@@ -383,11 +401,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // =====================================================================================  backward: dK, dV
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) float Qs[32 * KT_LD];
-    __shared__ __attribute__((aligned(16))) float Gs[32 * KT_LD];
-    __shared__ float lse_s[32], delta_s[32];
-    __shared__ __attribute__((aligned(16))) float scratch_all[4 * 32 * KT_LD];
+__global__ __launch_bounds__(256, TTTS_DKV_W) void attn_bwd_dkv_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    __shared__ float lse_s[KB], delta_s[KB];
+    float* Qs = smem;                  // [KB][65]
+    float* Gs = smem + KB * KT_LD;     // [KB][65]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -395,7 +413,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int h = blockIdx.y, b = blockIdx.z;
     const int k0 = kblk * QB, kw0 = k0 + wave * 32;
     const int kg = kw0 + l31;
-    float* scratch = scratch_all + wave * 32 * KT_LD;
+    float* scratch = smem + wave * 32 * KT_LD;
 
     int klen = (int)a.key_lens[b];
     if (klen > a.Tk) klen = a.Tk;
@@ -417,76 +435,72 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < 32; ++j) vreg[j] = scratch[l31 * KT_LD + 2 * j + half];
-    wave_lds_sync();
 
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
 
-    const int nqt = (a.Tq + 31) / 32;
-    int qt_begin = CAUSAL ? (k0 / 32) : 0;        // queries below the block's first key never see it
-    if (k0 >= klen) qt_begin = nqt;               // whole key block is padding: gradients are zero
+    const int nqs = (a.Tq + KB - 1) / KB;
+    int qs_begin = CAUSAL ? (k0 / KB) : 0;        // queries below the block's first key never see it
+    if (k0 >= klen) qs_begin = nqs;               // whole key block is padding: gradients are zero
 
-    float4 rq[2], rg[2];
-    if (qt_begin < nqt) {
-        load_tile_regs(qb_, (long)qt_begin * 32, a.Tq, a.ldq, tid, rq);
-        load_tile_regs(gb_, (long)qt_begin * 32, a.Tq, a.ldo, tid, rg);
-    }
-    for (int qt = qt_begin; qt < nqt; ++qt) {
+    for (int qs = qs_begin; qs < nqs; ++qs) {
         __syncthreads();
-        store_tile_lds(Qs, KT_LD, tid, rq, 0.125f);
-        store_tile_lds(Gs, KT_LD, tid, rg, 1.f);
-        if (tid < 32) {
-            int q = qt * 32 + tid;
+        stage_rows<true>(qb_, (long)qs * KB, a.Tq, a.ldq, tid, Qs, 0.125f);
+        stage_rows<true>(gb_, (long)qs * KB, a.Tq, a.ldo, tid, Gs, 1.f);
+        if (tid < KB) {
+            int q = qs * KB + tid;
             lse_s[tid] = (q < a.Tq) ? a.lse[arow + q] : 0.f;
             delta_s[tid] = (q < a.Tq) ? a.delta[arow + q] : 0.f;
         }
         __syncthreads();
-        if (qt + 1 < nqt) {
-            load_tile_regs(qb_, (long)(qt + 1) * 32, a.Tq, a.ldq, tid, rq);
-            load_tile_regs(gb_, (long)(qt + 1) * 32, a.Tq, a.ldo, tid, rg);
-        }
-        if (CAUSAL && qt * 32 + 31 < kw0) continue;   // every query of the tile precedes this wave's keys
-
-        f32x16 s, dp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        for (int sub = 0; sub < 2; ++sub) {
+            const int qt0 = qs * KB + sub * 32;
+            if (qt0 >= a.Tq) break;
+            if (CAUSAL && qt0 + 31 < kw0) continue;   // every query of the sub-tile precedes this wave's keys
+            const float* qsub = Qs + sub * 32 * KT_LD;
+            const float* gsub = Gs + sub * 32 * KT_LD;
+            f32x16 s, dp;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            float qf = Qs[l31 * KT_LD + 2 * j + half];
-            float gf = Gs[l31 * KT_LD + 2 * j + half];
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf, kreg[j], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gf, vreg[j], dp, 0, 0, 0);
-        }
-        float pd[16], ds[16];
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qrow = acc_row(r, half);
-            const int q_g = qt * 32 + qrow;
-            bool live = kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq;
-            float p = live ? __expf(s[r] - lse_s[qrow]) : 0.f;
-            float g = dp[r];
-            float pk = p;
-            if (a.thr != 0u) {
-                uint64_t idx = (uint64_t)(arow + q_g) * (uint64_t)a.Tk + (uint64_t)kg;
-                bool keep = keep_elem(a.seed, idx, a.thr);
-                g = keep ? g * a.drop_scale : 0.f;
-                pk = keep ? p * a.drop_scale : 0.f;
+            for (int j = 0; j < 32; ++j) {
+                float qf = qsub[l31 * KT_LD + 2 * j + half];
+                float gf = gsub[l31 * KT_LD + 2 * j + half];
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf, kreg[j], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gf, vreg[j], dp, 0, 0, 0);
             }
-            pd[r] = pk;
-            ds[r] = p * (g - delta_s[qrow]);
-        }
+            float pd[16], ds[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qrow = acc_row(r, half);
-            float g0 = Gs[qrow * KT_LD + l31];
-            float g1 = Gs[qrow * KT_LD + 32 + l31];
-            float q0f = Qs[qrow * KT_LD + l31];
-            float q1f = Qs[qrow * KT_LD + 32 + l31];
-            dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, pd[r], dv[0], 0, 0, 0);
-            dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, pd[r], dv[1], 0, 0, 0);
-            dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0f, ds[r], dk[0], 0, 0, 0);
-            dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1f, ds[r], dk[1], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) {
+                const int qrow = acc_row(r, half);
+                const int q_g = qt0 + qrow;
+                bool live = kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq;
+                float p = live ? __expf(s[r] - lse_s[sub * 32 + qrow]) : 0.f;
+                float g = dp[r];
+                float pk = p;
+                if (a.thr != 0u) {
+                    const uint32_t hsh = attn_hash(a.seed, (uint32_t)(arow + q_g), (uint32_t)kg >> 1);
+                    bool keep = keep_from_hash(hsh, (uint32_t)kg & 1u, a.thr);
+                    g = keep ? g * a.drop_scale : 0.f;
+                    pk = keep ? p * a.drop_scale : 0.f;
+                }
+                pd[r] = pk;
+                ds[r] = p * (g - delta_s[sub * 32 + qrow]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qrow = acc_row(r, half);
+                float g0 = gsub[qrow * KT_LD + l31];
+                float g1 = gsub[qrow * KT_LD + 32 + l31];
+                float q0f = qsub[qrow * KT_LD + l31];
+                float q1f = qsub[qrow * KT_LD + 32 + l31];
+                dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, pd[r], dv[0], 0, 0, 0);
+                dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, pd[r], dv[1], 0, 0, 0);
+                dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0f, ds[r], dk[0], 0, 0, 0);
+                dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1f, ds[r], dk[1], 0, 0, 0);
+            }
         }
     }
     __syncthreads();

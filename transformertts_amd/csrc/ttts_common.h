@@ -35,27 +35,30 @@ int launch_reduce_rows(const float* ws, long ld, int nrows, long ncols, float* o
                        hipStream_t stream);
 
 // ---------------------------------------------------------------- counter-based dropout RNG
-// keep(seed, idx) is a pure function of the 64-bit site seed and the flat element index, so the
-// backward kernels regenerate exactly the forward mask without storing it.
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+// keep(seed, idx) is a pure function of the 64-bit site seed and the element index, so the backward kernels
+// regenerate exactly the forward mask without storing it.  One 32-bit hash serves TWO neighbouring elements
+// (16 random bits each): the keep test is `r16 >= round(p * 65536)`, i.e. p is honoured to 1.5e-5.
+__device__ __forceinline__ uint32_t hash_pair(uint64_t seed, uint32_t a, uint32_t b) {
+    uint32_t x = (a * 0x9E3779B1u) ^ (b * 0x85EBCA77u) ^ (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0xC2B2AE3Du);
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ uint32_t rand_u32(uint64_t seed, uint64_t idx) {
-    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-    uint32_t x = mix32(lo ^ (uint32_t)seed);
-    x = mix32(x + hi * 0x9E3779B1u + (uint32_t)(seed >> 32));
-    return x;
-}
-// threshold = round(p * 2^32) clipped; keep iff u32 >= threshold  (P[keep] = 1-p)
 __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
-    double t = (double)p * 4294967296.0;
+    double t = (double)p * 65536.0 + 0.5;
     if (t < 0.0) t = 0.0;
-    if (t > 4294967295.0) t = 4294967295.0;
+    if (t > 65535.0) t = 65535.0;
     return (uint32_t)t;
 }
+__device__ __forceinline__ bool keep_from_hash(uint32_t h, uint32_t odd, uint32_t thr) {
+    return (odd ? (h >> 16) : (h & 0xFFFFu)) >= thr;
+}
+// flat-index form (GEMM epilogues, element-wise kernels): elements 2i and 2i+1 share a hash
 __device__ __forceinline__ bool keep_elem(uint64_t seed, uint64_t idx, uint32_t thr) {
-    return rand_u32(seed, idx) >= thr;
+    return keep_from_hash(hash_pair(seed, (uint32_t)(idx >> 1), (uint32_t)(idx >> 33)), (uint32_t)idx & 1u, thr);
+}
+// attention-weight form: element (row, key) of the (B*H*Tq, Tk) weight matrix; keys 2j and 2j+1 share a hash
+__device__ __forceinline__ uint32_t attn_hash(uint64_t seed, uint32_t row, uint32_t key_pair) {
+    return hash_pair(seed, row, key_pair + 0x632BE5ABu);
 }
 
 // ---------------------------------------------------------------- wave helpers (wave = 64 lanes)
