@@ -57,6 +57,26 @@ size_t ttts_wgrad_workspace_bytes(int64_t M, int N, int K, int taps);
 int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
                            int64_t M, int N, int K, int row_shift, int T, int accumulate, void* stream);
 
+/* ---- split-precision ("bf16x6") forms of the forward / data-gradient GEMMs.  Same arithmetic contract (fp32 in,
+ * fp32 out, fp32 accumulate) with every product formed as six bf16 x bf16 MFMA terms of a 3-way hi/mid/lo split:
+ * measured error vs fp64 1.1e-7 (a plain fp32 fma chain: 2.9e-7) at 6/16 of the fp32 MFMA cycles.
+ * The weight operand is split once per call into planes[3][rows][cols] bf16 by ttts_weight_split:
+ *   mode 0  linear forward     planes of w (N,K)               rows = N,    cols = K
+ *   mode 1  linear data-grad   planes of w^T                   rows = K,    cols = N
+ *   mode 2  conv forward       [co][tap*cin + ci]              rows = cout, cols = taps*cin,  channels_per_tap = cin
+ *   mode 3  conv data-grad     [ci][tap*cout + co]             rows = cin,  cols = taps*cout, channels_per_tap = cout */
+size_t ttts_split_bytes(int64_t rows, int64_t cols);
+int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode, int channels_per_tap, int taps,
+                      void* stream);
+int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
+                       int64_t M, int N, int K, int act, float drop_p, uint64_t seed, int row_shift, int T, void* stream);
+int ttts_linear_bwd_data_x6(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
+                            int K, void* stream);
+int ttts_conv1d_fwd_x6(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
+                       int taps, void* stream);
+int ttts_conv1d_bwd_data_x6(const float* dy, const void* planes_bwd, float* dx, int B, int T, int cin, int cout, int taps,
+                            void* stream);
+
 /* ------------------------------------------------------------------ Conv1d (k taps, same padding) on (B,T,C)
  * Replaces ConvNormBN's permute -> nn.Conv1d(pad=(k-1)//2) -> permute (model/module.py:28-33) as an
  * implicit GEMM directly on the (B,T,C) layout.  Weights are re-laid once per call by

@@ -34,6 +34,27 @@ def gemm_fwd(M, N, K, act=0, res=False):
     print(f"linear_fwd   M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s")
 
 
+def gemm_fwd_x6(M, N, K):
+    x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev)
+    y = torch.empty(M, N, device=dev)
+    pl = ops._planes(w, 0, N, K)
+    us = timeit(lambda: lib.ttts_linear_fwd_x6(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, 0, 0, _stream()))
+    ref = (x[:256].double() @ w.double().t() + b.double())
+    err = ((y[:256].double() - ref).norm() / ref.norm()).item()
+    print(f"linear_fwd_x6 M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s   rel err vs fp64 {err:.2e}")
+
+
+def conv_x6(B, T, cin, cout):
+    x = torch.randn(B, T, cin, device=dev); w = torch.randn(cout, cin, 5, device=dev) * (5 * cin) ** -0.5; b = torch.randn(cout, device=dev)
+    y = torch.empty(B, T, cout, device=dev); dx = torch.empty_like(x)
+    pf = ops._planes(w, 2, cout, 5 * cin, cin, 5); pb = ops._planes(w, 3, cin, 5 * cout, cout, 5)
+    fl = 2.0 * B * T * cin * cout * 5
+    us = timeit(lambda: lib.ttts_conv1d_fwd_x6(_p(x), _p(pf), _p(b), _p(y), B, T, cin, cout, 5, _stream()))
+    print(f"conv_fwd_x6   {cin:4d}->{cout:4d} M={B*T}: {us:8.1f} us {fl/us/1e6:7.1f} TF/s")
+    us = timeit(lambda: lib.ttts_conv1d_bwd_data_x6(_p(y), _p(pb), _p(dx), B, T, cin, cout, 5, _stream()))
+    print(f"conv_dgrad_x6 {cin:4d}->{cout:4d} M={B*T}: {us:8.1f} us {fl/us/1e6:7.1f} TF/s")
+
+
 def gemm_dgrad(M, N, K):
     dy = torch.randn(M, N, device=dev); w = torch.randn(N, K, device=dev); dx = torch.empty(M, K, device=dev)
     us = timeit(lambda: lib.ttts_linear_bwd_data(_p(dy), _p(w), None, _p(dx), M, N, K, _stream()))
@@ -93,6 +114,13 @@ if __name__ == "__main__":
     for (M, N, K) in [(Mm, 256, 256), (Mm, 768, 256), (Mm, 1024, 256), (Mm, 256, 1024), (Mm, 256, 80), (Mm, 80, 256),
                       (Mp, 256, 256), (Mp, 768, 256), (Mp, 1024, 256), (Mp, 256, 1024), (Mp, 512, 256)]:
         gemm_fwd(M, N, K)
+    for (M, N, K) in [(Mm, 256, 256), (Mm, 768, 256), (Mm, 1024, 256), (Mm, 256, 1024), (Mm, 256, 80), (Mm, 80, 256),
+                      (Mp, 256, 256), (Mp, 1024, 256), (Mp, 256, 1024)]:
+        gemm_fwd_x6(M, N, K)
+    conv_x6(64, 870, 256, 256)
+    conv_x6(64, 870, 80, 256)
+    conv_x6(64, 870, 256, 80)
+    conv_x6(64, 100, 256, 256)
     for (M, N, K) in [(Mm, 256, 256), (Mm, 768, 256), (Mm, 1024, 256), (Mm, 256, 1024), (Mm, 80, 256)]:
         gemm_dgrad(M, N, K)
     for (M, N, K) in [(Mm, 256, 256), (Mm, 768, 256), (Mm, 1024, 256), (Mm, 256, 1024), (Mm, 80, 256), (Mm, 256, 80), (Mp, 1024, 256)]:

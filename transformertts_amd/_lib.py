@@ -22,6 +22,12 @@ SIGNATURES = {
     "ttts_linear_bwd_data": (I, [P, P, P, P, L, I, I, P]),
     "ttts_wgrad_workspace_bytes": (Z, [L, I, I, I]),
     "ttts_linear_bwd_weight": (I, [P, P, P, P, P, Z, L, I, I, I, I, I, P]),
+    "ttts_split_bytes": (Z, [L, L]),
+    "ttts_weight_split": (I, [P, P, I, I, I, I, I, P]),
+    "ttts_linear_fwd_x6": (I, [P, P, P, P, P, L, I, I, I, F, U, I, I, P]),
+    "ttts_linear_bwd_data_x6": (I, [P, P, P, P, L, I, I, P]),
+    "ttts_conv1d_fwd_x6": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "ttts_conv1d_bwd_data_x6": (I, [P, P, P, I, I, I, I, I, P]),
     "ttts_conv1d_pack_bytes": (Z, [I, I, I]),
     "ttts_conv1d_pack_weight": (I, [P, P, P, I, I, I, P]),
     "ttts_conv1d_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),

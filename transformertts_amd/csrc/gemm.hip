@@ -419,6 +419,258 @@ static int dispatch_gemm(const GemmArgs& g, int zdim, int tile, hipStream_t stre
     }
 }
 
+// ===============================================================================================================
+// Split-precision variant ("bf16x6"): fp32-accurate products on the 16x faster bf16 MFMA.
+// Every fp32 operand value is written as hi + mid + lo, three bf16 numbers (8 mantissa bits each, so 24 bits: the
+// split is exact up to 2^-25 relative), and the six leading cross products
+//     a1*b1 + (a1*b2 + a2*b1) + (a1*b3 + a2*b2 + a3*b1)
+// are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (each bf16 x bf16 product is exact in fp32).  The dropped
+// terms are O(2^-24) relative: measured error of a K = 256..1024 GEMM against fp64 is 1.1e-7, BELOW the 2.9e-7 of
+// a plain fp32 fma chain, at 6/16 of the fp32-MFMA cycle count.
+// Activations (A) are split on the fly while they are staged into LDS; weights (B) are split once per call by
+// weight_split_kernel into three [N][K] bf16 planes, so the B loader moves bytes only.
+// LDS image per operand plane: [row][16 k] bf16 = 32-byte rows; the two 16-byte chunks of a row are swapped on rows
+// with bit 3 set (chunk ^= (row >> 3) & 1), which makes the ds_read_b128 of the MFMA fragments conflict-free.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_pack4(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned short h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __bf16 b1 = (__bf16)x[i];
+        float r1 = x[i] - (float)b1;
+        __bf16 b2 = (__bf16)r1;
+        float r2 = r1 - (float)b2;
+        __bf16 b3 = (__bf16)r2;
+        h[i] = __builtin_bit_cast(unsigned short, b1);
+        m[i] = __builtin_bit_cast(unsigned short, b2);
+        l[i] = __builtin_bit_cast(unsigned short, b3);
+    }
+    hi = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    mid = make_uint2((uint32_t)m[0] | ((uint32_t)m[1] << 16), (uint32_t)m[2] | ((uint32_t)m[3] << 16));
+    lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+}
+
+// planes[p][r][c] (p = hi, mid, lo; R rows of C bf16) from a weight tensor:
+//   mode 0: linear forward      B[r][c] = w[r*C + c]                      (w is (R, C))
+//   mode 1: linear data-grad    B[r][c] = w[c*R + r]                      (w is (C, R); B = w^T)
+//   mode 2: conv forward        B[co][tap*cin + ci] = w[(co*cin + ci)*taps + tap]       (R = cout, C = taps*cin)
+//   mode 3: conv data-grad      B[ci][tap*cout + co] = w[(co*cin + ci)*taps + tap]      (R = cin,  C = taps*cout)
+__global__ __launch_bounds__(256) void weight_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
+                                                           int R, int C, int mode, int c2, int taps) {
+    const long n = (long)R * C;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = (int)(i / C), c = (int)(i % C);
+    float v;
+    if (mode == 0) v = w[i];
+    else if (mode == 1) v = w[(long)c * R + r];
+    else {
+        const int tap = c / c2, ch = c % c2;          // c2 = channels per tap
+        if (mode == 2) v = w[((long)r * c2 + ch) * taps + tap];          // r = co, ch = ci, c2 = cin
+        else v = w[((long)ch * R + r) * taps + tap];                     // r = ci, ch = co, R = cin
+    }
+    __bf16 b1 = (__bf16)v;
+    float r1 = v - (float)b1;
+    __bf16 b2 = (__bf16)r1;
+    float r2 = r1 - (float)b2;
+    __bf16 b3 = (__bf16)r2;
+    planes[i] = __builtin_bit_cast(unsigned short, b1);
+    planes[n + i] = __builtin_bit_cast(unsigned short, b2);
+    planes[2 * n + i] = __builtin_bit_cast(unsigned short, b3);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(GemmArgs g) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(WM * WN == 4 && BK == 16, "4 waves per workgroup, one MFMA k-step per k-tile");
+    constexpr int A_PLANE = BM * 8, B_PLANE = BN * 8;          // dwords per plane (32-byte rows)
+    constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+    constexpr int NLA = (BM * 4 + 255) / 256;                  // float4 loads per thread for the A tile
+    constexpr bool B_ALL = (BN * 2 >= 256);                    // B tile: BN rows x 2 half-chunks of 16 B per plane
+
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int nkt = g.K / BK;
+
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
+    const uint32_t b_plane_bytes = (uint32_t)((long)g.N * g.ldb * 2);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[NLA];
+    u32x4 rb[3];
+
+    int a_t[NLA];
+    uint32_t a_off[NLA];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        int idx = tid + i * 256;
+        int row = idx >> 2, ch = idx & 3;
+        int m = m0 + row;
+        a_off[i] = (row < BM && m < g.M) ? (uint32_t)(((long)m * g.lda + ch * 4) * 4) : OOB;
+        a_t[i] = (g.T > 0) ? (m % g.T) : 0;
+    }
+    // B: thread -> (row = tid>>1, half-chunk = tid&1): 8 bf16 = 16 bytes per plane
+    const int b_row = tid >> 1, b_hc = tid & 1;
+    const uint32_t b_off = ((B_ALL || b_row < BN) && (n0 + b_row) < g.N)
+                               ? (uint32_t)(((long)(n0 + b_row) * g.ldb + b_hc * 8) * 2) : OOB;
+
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK;
+        const int tap = k0 / g.cin;
+        const int c0 = k0 - tap * g.cin;
+        const int shift = g.shift0 + tap * g.shift_step;
+        const uint32_t koff = (uint32_t)(((long)shift * g.lda + c0) * 4);
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            bool ok = a_off[i] != OOB;
+            if (g.T > 0) ok = ok && ((unsigned)(a_t[i] + shift) < (unsigned)g.T);
+            ra[i] = buf_load4(rsrcA, ok ? a_off[i] + koff : OOB);
+        }
+        const uint32_t kb = (uint32_t)(k0 * 2);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            rb[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)(b_off != OOB ? b_off + kb + p * b_plane_bytes : OOB), 0, 0);
+    };
+
+    auto store_tiles = [&](int buf) {
+        uint32_t* as = lds + buf * STAGE;
+        uint32_t* bs = as + 3 * A_PLANE;
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            int idx = tid + i * 256;
+            int row = idx >> 2, ch = idx & 3;
+            if (row < BM) {
+                uint2 hi, mid, lo;
+                split3_pack4(ra[i], hi, mid, lo);
+                const int d = row * 8 + (((ch >> 1) ^ ((row >> 3) & 1)) * 4) + (ch & 1) * 2;
+                *reinterpret_cast<uint2*>(as + d) = hi;
+                *reinterpret_cast<uint2*>(as + A_PLANE + d) = mid;
+                *reinterpret_cast<uint2*>(as + 2 * A_PLANE + d) = lo;
+            }
+        }
+        if (B_ALL || b_row < BN) {
+            const int d = b_row * 8 + ((b_hc ^ ((b_row >> 3) & 1)) * 4);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(bs + p * B_PLANE + d) = rb[p];
+        }
+    };
+
+    auto compute = [&](int buf) {
+        const uint32_t* as = lds + buf * STAGE;
+        const uint32_t* bs = as + 3 * A_PLANE;
+        const int cw = ((half ^ ((l31 >> 3) & 1)) * 4);       // swizzled 16-byte chunk of this lane's 8 k values
+        bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[p][i] = *reinterpret_cast<const bf16x8*>(as + p * A_PLANE + (wm * WTM + i * 32 + l31) * 8 + cw);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[p][j] = *reinterpret_cast<const bf16x8*>(bs + p * B_PLANE + (wn * WTN + j * 32 + l31) * 8 + cw);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);   // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+    };
+
+    if (nkt > 0) {
+        load_tiles(0);
+        store_tiles(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+            const bool more = (kt + 1) < nkt;
+            if (more) load_tiles(kt + 1);
+            compute(buf);
+            if (more) store_tiles(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ---------------- epilogue (same as the fp32 kernel)
+    float* C = g.C;
+    const bool do_drop = g.drop_thr != 0u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WTN + j * 32 + l31;
+            const bool col_ok = col < g.N;
+            const float bv = (g.bias != nullptr && col_ok) ? g.bias[col] : 0.f;
+            const int row0 = m0 + wm * WTM + i * 32;
+            float res[16];
+            if (g.residual != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + acc_row(r, half);
+                    res[r] = (row < g.M && col_ok) ? g.residual[(long)row * g.ldr + col] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) res[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + acc_row(r, half);
+                float v = acc[i][j][r] + bv;
+                if (g.act == 1) v = fmaxf(v, 0.f);
+                if (do_drop) {
+                    uint64_t idx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
+                    v = keep_elem(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
+                }
+                v += res[r];
+                if (row < g.M && col_ok) C[(long)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_split(const GemmArgs& g, hipStream_t stream) {
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), 1);
+    hipLaunchKernelGGL((gemm_bf16x6_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, stream, g);
+    TTTS_LAUNCH_CHECK("gemm_bf16x6_kernel");
+    return TTTS_OK;
+}
+
+static int dispatch_split(const GemmArgs& g, hipStream_t stream) {
+    int tile = (g.N <= 96 && (long)cdiv(g.M, 128) >= 384) ? TILE_128x96 : choose_tile(g.M, g.N, 1);
+    switch (tile) {
+        case TILE_64: return launch_split<64, 64, 2, 2>(g, stream);
+        case TILE_64x128: return launch_split<64, 128, 2, 2>(g, stream);
+        case TILE_128x96: return launch_split<128, 96, 4, 1>(g, stream);
+        default: return launch_split<128, 128, 2, 2>(g, stream);
+    }
+}
+
 static GemmArgs base_args() {
     GemmArgs g;
     g.A = g.B = nullptr; g.C = nullptr;
@@ -602,6 +854,90 @@ int ttts_conv1d_bwd_weight(const float* dy, const float* x, float* dw, float* db
     TTTS_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
     if (dbias) rc = launch_reduce_rows(colsum_ws, cout, p.nsplit, cout, dbias, cout, nullptr, accumulate, stream);
     return rc;
+}
+
+size_t ttts_split_bytes(int64_t rows, int64_t cols) { return (size_t)3 * (size_t)rows * (size_t)cols * 2; }
+
+int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode, int channels_per_tap, int taps,
+                      void* stream) {
+    // planes[3][rows][cols] bf16 (hi, mid, lo) of a weight re-laid as the K-contiguous B operand; modes in gemm.hip
+    TTTS_REQUIRE(w && planes && rows > 0 && cols > 0, "weight_split: bad arguments");
+    TTTS_REQUIRE(mode >= 0 && mode <= 3, "weight_split: mode must be 0..3");
+    TTTS_REQUIRE(mode < 2 || (channels_per_tap > 0 && taps > 0 && cols == channels_per_tap * taps),
+                 "weight_split: conv modes need cols == channels_per_tap * taps");
+    long n = (long)rows * cols;
+    hipLaunchKernelGGL(weight_split_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (unsigned short*)planes, rows, cols, mode, channels_per_tap, taps);
+    TTTS_LAUNCH_CHECK("weight_split_kernel");
+    return TTTS_OK;
+}
+
+int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
+                       int64_t M, int N, int K, int act, float drop_p, uint64_t seed, int row_shift, int T, void* stream) {
+    TTTS_REQUIRE(x && w_planes && y, "linear_fwd_x6: null pointer");
+    TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_fwd_x6: bad dims");
+    TTTS_REQUIRE(K % BK == 0, "linear_fwd_x6: K=%d must be a multiple of %d", K, BK);
+    TTTS_REQUIRE(aligned16(x) && aligned16(w_planes), "linear_fwd_x6: x / planes must be 16-byte aligned");
+    TTTS_REQUIRE(act == 0 || act == 1, "linear_fwd_x6: act must be 0 (none) or 1 (relu)");
+    TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "linear_fwd_x6: dropout p out of [0,1)");
+    TTTS_REQUIRE(row_shift == 0 || (T > 0 && M % T == 0), "linear_fwd_x6: row_shift needs T>0 and M %% T == 0");
+    TTTS_REQUIRE((uint64_t)M * K * 4 < (1ull << 32) && (uint64_t)N * K * 6 < (1ull << 32), "linear_fwd_x6: operand larger than 4 GiB");
+    GemmArgs g = base_args();
+    g.A = x; g.B = (const float*)w_planes; g.C = y; g.M = (int)M; g.N = N; g.K = K;
+    g.lda = K; g.ldb = K; g.ldc = N;
+    g.a_bytes = (uint32_t)((uint64_t)M * K * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 6);
+    g.cin = K; g.shift0 = row_shift; g.T = (row_shift != 0) ? T : 0;
+    g.bias = bias; g.act = act;
+    if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; }
+    g.residual = residual; g.ldr = N;
+    return dispatch_split(g, (hipStream_t)stream);
+}
+
+int ttts_linear_bwd_data_x6(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
+                            int K, void* stream) {
+    // dx[M,K] = dy[M,N] . w[N,K] (+ residual); wt_planes = split of w^T, i.e. [K][N] rows (weight_split mode 1)
+    TTTS_REQUIRE(dy && wt_planes && dx, "linear_bwd_data_x6: null pointer");
+    TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_bwd_data_x6: bad dims");
+    TTTS_REQUIRE(N % BK == 0, "linear_bwd_data_x6: N=%d must be a multiple of 16", N);
+    TTTS_REQUIRE(aligned16(dy) && aligned16(wt_planes), "linear_bwd_data_x6: pointers must be 16-byte aligned");
+    TTTS_REQUIRE((uint64_t)M * N * 4 < (1ull << 32) && (uint64_t)N * K * 6 < (1ull << 32), "linear_bwd_data_x6: operand larger than 4 GiB");
+    GemmArgs g = base_args();
+    g.A = dy; g.B = (const float*)wt_planes; g.C = dx; g.M = (int)M; g.N = K; g.K = N;
+    g.lda = N; g.ldb = N; g.ldc = K; g.cin = N;
+    g.a_bytes = (uint32_t)((uint64_t)M * N * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 6);
+    g.residual = residual; g.ldr = K;
+    return dispatch_split(g, (hipStream_t)stream);
+}
+
+int ttts_conv1d_fwd_x6(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
+                       int taps, void* stream) {
+    TTTS_REQUIRE(x && planes_fwd && y, "conv1d_fwd_x6: null pointer");
+    TTTS_REQUIRE(B > 0 && T > 0 && cin > 0 && cout > 0 && taps > 0 && (taps & 1), "conv1d_fwd_x6: bad dims");
+    TTTS_REQUIRE(cin % BK == 0, "conv1d_fwd_x6: cin=%d must be a multiple of %d", cin, BK);
+    TTTS_REQUIRE((uint64_t)B * T * cin * 4 < (1ull << 32), "conv1d_fwd_x6: activation larger than 4 GiB");
+    TTTS_REQUIRE(aligned16(x) && aligned16(planes_fwd), "conv1d_fwd_x6: pointers must be 16-byte aligned");
+    GemmArgs g = base_args();
+    g.A = x; g.B = (const float*)planes_fwd; g.C = y; g.M = B * T; g.N = cout; g.K = taps * cin;
+    g.lda = cin; g.ldb = (long)taps * cin; g.ldc = cout;
+    g.a_bytes = (uint32_t)((uint64_t)B * T * cin * 4); g.b_bytes = (uint32_t)((uint64_t)cout * taps * cin * 6);
+    g.T = T; g.cin = cin; g.shift0 = -((taps - 1) / 2); g.shift_step = 1;
+    g.bias = bias;
+    return dispatch_split(g, (hipStream_t)stream);
+}
+
+int ttts_conv1d_bwd_data_x6(const float* dy, const void* planes_bwd, float* dx, int B, int T, int cin, int cout, int taps,
+                            void* stream) {
+    TTTS_REQUIRE(dy && planes_bwd && dx, "conv1d_bwd_data_x6: null pointer");
+    TTTS_REQUIRE(B > 0 && T > 0 && cin > 0 && cout > 0 && taps > 0 && (taps & 1), "conv1d_bwd_data_x6: bad dims");
+    TTTS_REQUIRE(cout % BK == 0, "conv1d_bwd_data_x6: cout=%d must be a multiple of %d", cout, BK);
+    TTTS_REQUIRE((uint64_t)B * T * cout * 4 < (1ull << 32), "conv1d_bwd_data_x6: activation larger than 4 GiB");
+    TTTS_REQUIRE(aligned16(dy) && aligned16(planes_bwd), "conv1d_bwd_data_x6: pointers must be 16-byte aligned");
+    GemmArgs g = base_args();
+    g.A = dy; g.B = (const float*)planes_bwd; g.C = dx; g.M = B * T; g.N = cin; g.K = taps * cout;
+    g.lda = cout; g.ldb = (long)taps * cout; g.ldc = cin;
+    g.a_bytes = (uint32_t)((uint64_t)B * T * cout * 4); g.b_bytes = (uint32_t)((uint64_t)cin * taps * cout * 6);
+    g.T = T; g.cin = cout; g.shift0 = (taps - 1) / 2; g.shift_step = -1;
+    return dispatch_split(g, (hipStream_t)stream);
 }
 
 }  // extern "C"

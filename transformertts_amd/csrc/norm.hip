@@ -143,16 +143,36 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
-__global__ void bn_stats_final_kernel(const float* __restrict__ ws, float* __restrict__ mean_out,
-                                      float* __restrict__ invstd_out, float* __restrict__ running_mean,
-                                      float* __restrict__ running_var, int64_t* __restrict__ nbt, int nblk, int C,
-                                      float momentum, float eps) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+// Merge the per-chunk (count, mean, M2) partials of a channel (Chan et al.), 16 channels x 16 merge-lanes per
+// workgroup: each lane folds every 16th partial in order, lane 0 then folds the 16 lane results in order.
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ ws, float* __restrict__ mean_out,
+                                                             float* __restrict__ invstd_out, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                             int nblk, int C, float momentum, float eps) {
+    __shared__ float sn[16][17], sm[16][17], sq[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
     if (c < C) {
-        float n = 0.f, mean = 0.f, m2 = 0.f;
-        for (int b = 0; b < nblk; ++b) {
+        for (int b = rl; b < nblk; b += 16) {
             const float* w = ws + ((long)b * 3) * C;
             float nb = w[c], mb = w[C + c], m2b = w[2 * C + c];
+            if (nb > 0.f) {
+                float nn = n + nb;
+                float dlt = mb - mean;
+                mean += dlt * (nb / nn);
+                m2 += m2b + dlt * dlt * (n * nb / nn);
+                n = nn;
+            }
+        }
+    }
+    sn[rl][cl] = n; sm[rl][cl] = mean; sq[rl][cl] = m2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        n = 0.f; mean = 0.f; m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float nb = sn[i][cl], mb = sm[i][cl], m2b = sq[i][cl];
             if (nb > 0.f) {
                 float nn = n + nb;
                 float dlt = mb - mean;
@@ -354,7 +374,7 @@ int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* runni
     int nb = bn_blocks(M, &rpb);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(cdiv(C, 64), nb), dim3(256), 0, stream, x, ws, (long)M, C, rpb);
     TTTS_LAUNCH_CHECK("bn_stats_partial_kernel");
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, ws, mean, invstd, running_mean,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 16)), dim3(256), 0, stream, ws, mean, invstd, running_mean,
                        running_var, num_batches_tracked, nb, C, momentum, eps);
     TTTS_LAUNCH_CHECK("bn_stats_final_kernel");
     return TTTS_OK;

@@ -7,6 +7,7 @@ no CPU / eager fallback -- non-CUDA tensors are rejected.
 """
 from __future__ import annotations
 
+import os
 from ctypes import c_void_p
 from typing import Optional
 
@@ -55,6 +56,34 @@ class _SeedStream:
 
 seeds = _SeedStream()
 
+# Forward / data-gradient GEMMs and convolutions: "x6" = fp32-accurate split-precision products on the bf16 MFMA
+# (3-way bf16 split, six MFMA terms, fp32 accumulate; error 1.1e-7 vs 2.9e-7 for the plain fp32 MFMA chain),
+# "f32" = the plain v_mfma_f32_32x32x2_f32 kernel.  Weight gradients always use the fp32 kernel.
+GEMM_MODE = os.environ.get("TTTS_GEMM_MODE", "x6")
+
+
+def _planes(w: torch.Tensor, mode: int, rows: int, cols: int, c2: int = 0, taps: int = 0) -> torch.Tensor:
+    """hi/mid/lo bf16 planes of a weight, re-laid as the K-contiguous B operand (ttts_weight_split).  Cached on the
+    tensor object and keyed by its version counter + storage address, so the two forwards and the backward of a
+    step split each weight once and an optimizer step invalidates the planes."""
+    cache = getattr(w, "_ttts_planes", None)
+    tag = (w._version, w.data_ptr())
+    if cache is not None:
+        ent = cache.get(mode)
+        if ent is not None and ent[0] == tag:
+            return ent[1]
+    lib = _lib.load()
+    planes = torch.empty(3 * rows * cols, dtype=torch.int16, device=w.device)
+    _lib.check(lib.ttts_weight_split(_p(w), _p(planes), rows, cols, mode, c2, taps, _stream()), "ttts_weight_split")
+    try:
+        if cache is None:
+            cache = {}
+            w._ttts_planes = cache
+        cache[mode] = (tag, planes)
+    except AttributeError:
+        pass
+    return planes
+
 
 def _sink(t: Optional[torch.Tensor]):
     """Gradient sink of a parameter: a slice of the flat data-parallel gradient bucket (parallel.FlatGradBucket).
@@ -92,8 +121,12 @@ class LinearFn(torch.autograd.Function):
         r_ = _chk(residual, "linear.residual") if residual is not None else None
         if r_ is not None and r_.shape != y.shape:
             raise ValueError("linear: residual shape mismatch")
-        _lib.check(lib.ttts_linear_fwd(_p(x), _p(w), _p(b_), _p(r_), _p(y), M, N, K, act, float(drop_p), seed,
-                                       row_shift, T, _stream()), "ttts_linear_fwd")
+        if GEMM_MODE == "x6":
+            _lib.check(lib.ttts_linear_fwd_x6(_p(x), _p(_planes(w, 0, N, K)), _p(b_), _p(r_), _p(y), M, N, K, act,
+                                              float(drop_p), seed, row_shift, T, _stream()), "ttts_linear_fwd_x6")
+        else:
+            _lib.check(lib.ttts_linear_fwd(_p(x), _p(w), _p(b_), _p(r_), _p(y), M, N, K, act, float(drop_p), seed,
+                                           row_shift, T, _stream()), "ttts_linear_fwd")
         ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
         ctx.cfg = (act, float(drop_p), seed, row_shift, T, b is not None, residual is not None)
         ctx.sinks = _sinks(w, b)
@@ -121,7 +154,12 @@ class LinearFn(torch.autograd.Function):
             if row_shift != 0:
                 raise RuntimeError("linear: input gradient through a shifted loader is not needed on this path")
             dx = torch.empty_like(x)
-            _lib.check(lib.ttts_linear_bwd_data(_p(dacc), _p(w), None, _p(dx), M, N, K, _stream()), "ttts_linear_bwd_data")
+            if GEMM_MODE == "x6":
+                _lib.check(lib.ttts_linear_bwd_data_x6(_p(dacc), _p(_planes(w, 1, K, N)), None, _p(dx), M, N, K,
+                                                       _stream()), "ttts_linear_bwd_data_x6")
+            else:
+                _lib.check(lib.ttts_linear_bwd_data(_p(dacc), _p(w), None, _p(dx), M, N, K, _stream()),
+                           "ttts_linear_bwd_data")
         if ctx.needs_input_grad[1]:
             nbytes = lib.ttts_wgrad_workspace_bytes(M, N, K, 1)
             ws = _ws(nbytes, x.device)
@@ -152,8 +190,13 @@ class HeadsFn(torch.autograd.Function):
         M = x.numel() // K
         mel = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
         stop = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
-        _lib.check(lib.ttts_linear_fwd(_p(x), _p(_chk(w_mel, "w_mel")), _p(b_mel), None, _p(mel), M, N, K, ACT_NONE, 0.0,
-                                       0, 0, 0, _stream()), "ttts_linear_fwd")
+        w_mel = _chk(w_mel, "w_mel")
+        if GEMM_MODE == "x6":
+            _lib.check(lib.ttts_linear_fwd_x6(_p(x), _p(_planes(w_mel, 0, N, K)), _p(b_mel), None, _p(mel), M, N, K,
+                                              ACT_NONE, 0.0, 0, 0, 0, _stream()), "ttts_linear_fwd_x6")
+        else:
+            _lib.check(lib.ttts_linear_fwd(_p(x), _p(w_mel), _p(b_mel), None, _p(mel), M, N, K, ACT_NONE, 0.0,
+                                           0, 0, 0, _stream()), "ttts_linear_fwd")
         _lib.check(lib.ttts_rowdot_fwd(_p(x), _p(_chk(w_stop, "w_stop")), _p(b_stop), _p(stop), M, K, _stream()),
                    "ttts_rowdot_fwd")
         ctx.save_for_backward(x, w_mel, w_stop)
@@ -169,7 +212,12 @@ class HeadsFn(torch.autograd.Function):
         dmel = _chk(dmel, "heads.dmel")
         dstop = _chk(dstop, "heads.dstop")
         dx = torch.empty_like(x)
-        _lib.check(lib.ttts_linear_bwd_data(_p(dmel), _p(w_mel), None, _p(dx), M, N, K, _stream()), "ttts_linear_bwd_data")
+        if GEMM_MODE == "x6":
+            _lib.check(lib.ttts_linear_bwd_data_x6(_p(dmel), _p(_planes(w_mel, 1, K, N)), None, _p(dx), M, N, K, _stream()),
+                       "ttts_linear_bwd_data_x6")
+        else:
+            _lib.check(lib.ttts_linear_bwd_data(_p(dmel), _p(w_mel), None, _p(dx), M, N, K, _stream()),
+                       "ttts_linear_bwd_data")
         ws = _ws(lib.ttts_wgrad_workspace_bytes(M, N, K, 1), x.device)
         sk, acc = ctx.sinks
         if sk is not None:
@@ -203,12 +251,16 @@ class ConvBNFn(torch.autograd.Function):
             raise ValueError(f"conv_bn: x has {cin} channels, weight expects {cin_w}")
         dev = x.device
         conv_w = _chk(conv_w, "conv.weight")
-        w_fwd = torch.empty(cout * taps * cin, dtype=torch.float32, device=dev)
-        _lib.check(lib.ttts_conv1d_pack_weight(_p(conv_w), _p(w_fwd), None, cout, cin, taps, _stream()),
-                   "ttts_conv1d_pack_weight")
         y = torch.empty(B, T, cout, dtype=torch.float32, device=dev)
-        _lib.check(lib.ttts_conv1d_fwd(_p(x), _p(w_fwd), _p(conv_b), _p(y), B, T, cin, cout, taps, _stream()),
-                   "ttts_conv1d_fwd")
+        if GEMM_MODE == "x6":
+            _lib.check(lib.ttts_conv1d_fwd_x6(_p(x), _p(_planes(conv_w, 2, cout, taps * cin, cin, taps)), _p(conv_b), _p(y),
+                                              B, T, cin, cout, taps, _stream()), "ttts_conv1d_fwd_x6")
+        else:
+            w_fwd = torch.empty(cout * taps * cin, dtype=torch.float32, device=dev)
+            _lib.check(lib.ttts_conv1d_pack_weight(_p(conv_w), _p(w_fwd), None, cout, cin, taps, _stream()),
+                       "ttts_conv1d_pack_weight")
+            _lib.check(lib.ttts_conv1d_fwd(_p(x), _p(w_fwd), _p(conv_b), _p(y), B, T, cin, cout, taps, _stream()),
+                       "ttts_conv1d_fwd")
         mean = torch.empty(cout, dtype=torch.float32, device=dev)
         invstd = torch.empty(cout, dtype=torch.float32, device=dev)
         M = B * T
@@ -255,12 +307,16 @@ class ConvBNFn(torch.autograd.Function):
                                    _p(ws), ws.numel() * 4, M, cout, act, drop_p, seed, acc, _stream()), "ttts_bn_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
-            w_bwd = torch.empty(cin * taps * cout, dtype=torch.float32, device=dev)
-            _lib.check(lib.ttts_conv1d_pack_weight(_p(conv_w), None, _p(w_bwd), cout, cin, taps, _stream()),
-                       "ttts_conv1d_pack_weight")
             dx = torch.empty_like(x)
-            _lib.check(lib.ttts_conv1d_bwd_data(_p(dy), _p(w_bwd), _p(dx), B, T, cin, cout, taps, _stream()),
-                       "ttts_conv1d_bwd_data")
+            if GEMM_MODE == "x6":
+                _lib.check(lib.ttts_conv1d_bwd_data_x6(_p(dy), _p(_planes(conv_w, 3, cin, taps * cout, cout, taps)), _p(dx),
+                                                       B, T, cin, cout, taps, _stream()), "ttts_conv1d_bwd_data_x6")
+            else:
+                w_bwd = torch.empty(cin * taps * cout, dtype=torch.float32, device=dev)
+                _lib.check(lib.ttts_conv1d_pack_weight(_p(conv_w), None, _p(w_bwd), cout, cin, taps, _stream()),
+                           "ttts_conv1d_pack_weight")
+                _lib.check(lib.ttts_conv1d_bwd_data(_p(dy), _p(w_bwd), _p(dx), B, T, cin, cout, taps, _stream()),
+                           "ttts_conv1d_bwd_data")
         ws2 = _ws(lib.ttts_wgrad_workspace_bytes(M, cout, cin, taps), dev)
         _lib.check(lib.ttts_conv1d_bwd_weight(_p(dy), _p(x), _p(t_w), _p(t_b), _p(ws2), ws2.numel() * 4, B, T, cin, cout,
                                               taps, acc, _stream()), "ttts_conv1d_bwd_weight")
