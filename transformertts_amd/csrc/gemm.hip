@@ -381,25 +381,21 @@ static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t stream) {
 
 enum { TILE_AUTO = 0, TILE_64 = 1, TILE_128 = 2, TILE_64x128 = 3, TILE_128x96 = 4 };
 
-// Pick the tile that minimises (rounds of workgroups over the chip) x (work per workgroup), i.e. the launch's
-// quantisation loss: e.g. M = 55 680, N = 256 is 870 tiles of 128x128 = 1.13 rounds of 768 resident workgroups
-// (the second round runs a mostly empty chip), but 1 740 tiles of 64x128 = 1.7 rounds of 1 024.
-static int choose_tile(long M, long N, long zdim) {
+// Pick the tile that minimises the busiest CU's work: ceil(tiles / 256 CUs) workgroups in sequence, each costing
+// its area divided by how efficiently that tile shape runs.  E.g. M = 55 680, N = 256 in fp32: 870 tiles of 128x128
+// are 4 deep on some CUs (65 536), 1 740 tiles of 64x128 are 7 deep at 0.93 efficiency (61 660) -> 64x128.
+// The split-precision kernel is latency / traffic bound, so small tiles cost it more (second efficiency table).
+static int choose_tile(long M, long N, long zdim, bool x6 = false) {
     static int forced = -1;                       // development aid: TTTS_GEMM_TILE=1..4 forces a tile shape
     if (forced < 0) { const char* e = getenv("TTTS_GEMM_TILE"); forced = e ? atoi(e) : 0; }
     if (forced > 0) return forced;
-    struct Cand { int tile, bm, bn, per_cu; float eff; };
-    const Cand cands[] = {{TILE_128, 128, 128, 3, 1.00f}, {TILE_64x128, 64, 128, 4, 0.93f}, {TILE_64, 64, 64, 6, 0.80f}};
+    struct Cand { int tile, bm, bn; float eff_f32, eff_x6; };
+    const Cand cands[] = {{TILE_128, 128, 128, 1.00f, 1.00f}, {TILE_64x128, 64, 128, 0.93f, 0.75f}, {TILE_64, 64, 64, 0.80f, 0.60f}};
     int best = TILE_128;
     float best_cost = 1e30f;
     for (const Cand& c : cands) {
         long tiles = (long)cdiv(M, c.bm) * cdiv(N, c.bn) * zdim;
-        long slots = 256L * c.per_cu;
-        long full = tiles / slots;
-        float tail = (float)(tiles - full * slots) / (float)slots;   // fraction of the chip the last round fills
-        // a partially filled round still costs: its workgroups run at most ~2.2x faster on an emptier CU
-        float rounds = (float)full + (tail > 0.f ? (tail < 0.45f ? 0.45f : tail) : 0.f);
-        float cost = rounds * (float)slots * (float)(c.bm * c.bn) / c.eff;
+        float cost = (float)((tiles + 255) / 256) * (float)(c.bm * c.bn) / (x6 ? c.eff_x6 : c.eff_f32);
         if (cost < best_cost) { best_cost = cost; best = c.tile; }
     }
     return best;
@@ -662,7 +658,7 @@ static int launch_split(const GemmArgs& g, hipStream_t stream) {
 }
 
 static int dispatch_split(const GemmArgs& g, hipStream_t stream) {
-    int tile = (g.N <= 96 && (long)cdiv(g.M, 128) >= 384) ? TILE_128x96 : choose_tile(g.M, g.N, 1);
+    int tile = (g.N <= 96 && (long)cdiv(g.M, 128) >= 384) ? TILE_128x96 : choose_tile(g.M, g.N, 1, true);
     switch (tile) {
         case TILE_64: return launch_split<64, 64, 2, 2>(g, stream);
         case TILE_64x128: return launch_split<64, 128, 2, 2>(g, stream);
