@@ -30,6 +30,19 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense
+
+
+def measured_traffic(kernel: str):
+    """HBM bytes per launch of the dominant kernel from the committed PMC collection (separate rocprofv3 --pmc passes
+    of this same command, FETCH_SIZE doubled per the gfx950 note; profiles/r01_traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)
+        ent = t.get(kernel)
+        return ent["hbm_bytes_per_launch"] if ent else None
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def algorithmic_flops_forward(cfg, p: int, m: int) -> float:
@@ -45,38 +58,40 @@ def algorithmic_flops_forward(cfg, p: int, m: int) -> float:
 
 
 class GemmProbe:
-    """HIP-event timing of every launch of the dominant kernel (the forward-type fp32 MFMA GEMM
-    gemm_f32_kernel<128,128,2,2,true,true>: nn.Linear forward, Conv1d forward and Conv1d data-gradient with N > 96)
-    on torch's current stream -- the stream the kernels are launched on."""
+    """HIP-event timing of every forward-type GEMM launch (nn.Linear forward / data-gradient, Conv1d forward /
+    data-gradient) on torch's current stream -- the stream the kernels are launched on.  Each launch is attributed to
+    the kernel instantiation the library dispatches it to (ttts_gemm_tile_choice); `summary()` reports the
+    instantiation with the largest total time = the dominant kernel of the step."""
 
-    NAMES = ("ttts_linear_fwd", "ttts_conv1d_fwd", "ttts_conv1d_bwd_data")
+    TILES = {1: "64,64,2,2", 2: "128,128,2,2", 3: "64,128,2,2", 4: "128,96,4,1"}
+    # name -> (x6?, extractor of (M, N, K) from the C-ABI argument tuple)
+    CALLS = {
+        "ttts_linear_fwd": (0, lambda a: (a[5], a[6], a[7])),
+        "ttts_linear_fwd_x6": (1, lambda a: (a[5], a[6], a[7])),
+        "ttts_linear_bwd_data": (0, lambda a: (a[4], a[6], a[5])),        # (dy, w, res, dx, M, N, K): out N_gemm = K, red = N
+        "ttts_linear_bwd_data_x6": (1, lambda a: (a[4], a[6], a[5])),
+        "ttts_conv1d_fwd": (0, lambda a: (a[4] * a[5], a[7], a[6] * a[8])),
+        "ttts_conv1d_fwd_x6": (1, lambda a: (a[4] * a[5], a[7], a[6] * a[8])),
+        "ttts_conv1d_bwd_data": (0, lambda a: (a[3] * a[4], a[5], a[6] * a[7])),
+        "ttts_conv1d_bwd_data_x6": (1, lambda a: (a[3] * a[4], a[5], a[6] * a[7])),
+    }
 
     def __init__(self, lib):
         self.lib, self.records, self.orig = lib, [], {}
 
-    def _flops(self, name, a):
-        if name == "ttts_linear_fwd":
-            M, N, K = a[5], a[6], a[7]
-        elif name == "ttts_conv1d_fwd":          # (x, w, bias, y, B, T, cin, cout, taps, stream)
-            M, N, K = a[4] * a[5], a[7], a[6] * a[8]
-        else:                                    # bwd_data (dy, w, dx, B, T, cin, cout, taps, stream): N = cin, K = cout*taps
-            M, N, K = a[3] * a[4], a[5], a[6] * a[7]
-        return (2.0 * M * N * K, N)
-
     def __enter__(self):
-        for n in self.NAMES:
+        for n, (x6, dims) in self.CALLS.items():
             fn = getattr(self.lib, n)
             self.orig[n] = fn
 
-            def wrapped(*a, _fn=fn, _n=n):
-                fl, N = self._flops(_n, a)
-                if N <= 96:                      # 128x96 instantiation: not the dominant kernel
-                    return _fn(*a)
+            def wrapped(*a, _fn=fn, _x6=x6, _dims=dims):
+                M, N, K = _dims(a)
+                tile = self.lib.ttts_gemm_tile_choice(M, N, _x6)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = _fn(*a)
                 e1.record()
-                self.records.append((e0, e1, fl))
+                self.records.append((e0, e1, 2.0 * M * N * K, (_x6, tile)))
                 return rc
             setattr(self.lib, n, wrapped)
         return self
@@ -87,13 +102,20 @@ class GemmProbe:
 
     def summary(self):
         torch.cuda.synchronize()
-        ms = [e0.elapsed_time(e1) for e0, e1, _ in self.records]
-        fl = [f for _, _, f in self.records]
-        n = len(ms)
-        if n == 0:
+        groups = {}
+        for e0, e1, fl, key in self.records:
+            g = groups.setdefault(key, [0, 0.0, 0.0])
+            g[0] += 1
+            g[1] += e0.elapsed_time(e1)
+            g[2] += fl
+        if not groups:
             return None
-        avg_ms, avg_fl = sum(ms) / n, sum(fl) / n
-        return {"launches": n, "avg_ms": avg_ms, "avg_flops": avg_fl, "tflops": avg_fl / (avg_ms * 1e-3) / 1e12}
+        key = max(groups, key=lambda k: groups[k][1])
+        n, ms, fl = groups[key]
+        x6, tile = key
+        name = (f"gemm_bf16x6_kernel<{self.TILES[tile]}>" if x6 else f"gemm_f32_kernel<{self.TILES[tile]},true,*>")
+        return {"kernel": name, "x6": bool(x6), "launches": n, "avg_ms": ms / n, "avg_flops": fl / n,
+                "tflops": fl / (ms * 1e-3) / 1e12, "total_ms": ms}
 
 
 def usable_cores() -> int:
@@ -256,11 +278,17 @@ def main():
             "step_achieved_tflops_per_gpu": flops_all / world / (elapsed / args.steps) / 1e12,
         }
         if probe is not None:
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,2,2,true,true>",
+            # fp32 in / fp32 out / fp32-accurate products: priced against the fp32 MFMA peak of the dtype.  The
+            # split-precision kernel executes 6 bf16 MFMA flops per algorithmic flop; that rate and its fraction of the
+            # 2.5 PFLOP/s bf16 peak are reported next to it.
+            out["roofline"] = {"bound": "mfma", "kernel": probe["kernel"],
                                "achieved": probe["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": probe["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "frac": probe["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": measured_traffic(probe["kernel"]),
                                "launches_per_step": probe["launches"], "avg_launch_ms": probe["avg_ms"],
-                               "avg_launch_gflop": probe["avg_flops"] / 1e9}
+                               "avg_launch_gflop": probe["avg_flops"] / 1e9, "step_share_ms": probe["total_ms"]}
+            if probe["x6"]:
+                out["roofline"]["executed_bf16_tflops"] = 6.0 * probe["tflops"]
+                out["roofline"]["frac_of_bf16_peak"] = 6.0 * probe["tflops"] / PEAK_BF16_MFMA_TFLOPS
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, args.tp, args.tm, args.cpu_steps)
         print(json.dumps(out), flush=True)

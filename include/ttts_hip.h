@@ -66,6 +66,8 @@ int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db
  *   mode 2  conv forward       [co][tap*cin + ci]              rows = cout, cols = taps*cin,  channels_per_tap = cin
  *   mode 3  conv data-grad     [ci][tap*cout + co]             rows = cin,  cols = taps*cout, channels_per_tap = cout */
 size_t ttts_split_bytes(int64_t rows, int64_t cols);
+/* tile shape the forward / data-gradient dispatch uses for an M x N output (1: 64x64, 2: 128x128, 3: 64x128, 4: 128x96) */
+int ttts_gemm_tile_choice(int64_t M, int N, int x6);
 int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode, int channels_per_tap, int taps,
                       void* stream);
 int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,

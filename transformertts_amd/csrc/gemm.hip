@@ -852,6 +852,13 @@ int ttts_conv1d_bwd_weight(const float* dy, const float* x, float* dw, float* db
     return rc;
 }
 
+int ttts_gemm_tile_choice(int64_t M, int N, int x6) {
+    // which tile the forward / data-gradient dispatch picks for an M x N output: 1 = 64x64, 2 = 128x128, 3 = 64x128,
+    // 4 = 128x96 (profiling aid: lets a host-side probe attribute a launch to its kernel instantiation)
+    if (N <= 96 && (long)cdiv(M, 128) >= 384) return TILE_128x96;
+    return choose_tile(M, N, 1, x6 != 0);
+}
+
 size_t ttts_split_bytes(int64_t rows, int64_t cols) { return (size_t)3 * (size_t)rows * (size_t)cols * 2; }
 
 int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode, int channels_per_tap, int taps,
