@@ -179,11 +179,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal mode for a one-GPU box (TTTS_BENCH_REHEARSAL=1): every rank uses cuda:0 and the collectives run over
+    # gloo on host copies, so the launcher protocol (env parsing, barriers, MAX-over-ranks timing, rank-0 JSON) can be
+    # exercised without N GPUs.  The real path is one rank per GPU over RCCL ("nccl" on ROCm).
+    rehearsal = os.environ.get("TTTS_BENCH_REHEARSAL", "0") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from oracle.spec import model_config
     from oracle.synth import synth_batch
@@ -244,8 +252,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     note(f"{args.steps} timed steps: {elapsed / args.steps * 1e3:.2f} ms/step")
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(frames_rank), flops_rank], dtype=torch.float64, device=dev)
+    red_dev = torch.device("cpu") if rehearsal else dev
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(frames_rank), flops_rank], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -254,11 +263,15 @@ def main():
     final_loss = float(loss.item())
 
     probe = None
-    if rank == 0 and not args.no_probe:
-        with GemmProbe(_lib.load()) as gp:     # one extra, untimed, instrumented step
+    if not args.no_probe:
+        # one extra, untimed step on EVERY rank (it contains the gradient all-reduce); rank 0 instruments it
+        if rank == 0:
+            with GemmProbe(_lib.load()) as gp:
+                step(args.warmup + args.steps)
+            probe = gp.summary()
+            note("instrumented step done")
+        else:
             step(args.warmup + args.steps)
-        probe = gp.summary()
-        note("instrumented step done")
     fence()
 
     if rank == 0:

@@ -46,7 +46,12 @@ class FlatGradBucket:
     def allreduce_mean(self, group: Optional[dist.ProcessGroup] = None, async_op: bool = False):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return None
-        if dist.get_backend(group) == "gloo":   # gloo has no AVG
+        if dist.get_backend(group) == "gloo":   # gloo has no AVG; device buffers are staged through the host
+            if self.flat.is_cuda:
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                self.flat.copy_(host.div_(dist.get_world_size(group)))
+                return None
             work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
             if async_op:
                 return work
@@ -66,8 +71,14 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) ->
     """Make every replica start from rank `src`'s parameters and buffers."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
+    stage = dist.get_backend(group) == "gloo"
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        if stage and t.is_cuda:                 # gloo rehearsal on a GPU box: broadcast a host copy
+            host = t.data.cpu()
+            dist.broadcast(host, src=src, group=group)
+            t.data.copy_(host)
+        else:
+            dist.broadcast(t.data, src=src, group=group)
 
 
 def shard_batch(batch: dict, rank: int, world: int) -> dict:
