@@ -249,9 +249,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+    host_elapsed = time.perf_counter() - t0     # time to ENQUEUE the steps (host side); the GPU may still be running
     fence()
     elapsed = time.perf_counter() - t0
-    note(f"{args.steps} timed steps: {elapsed / args.steps * 1e3:.2f} ms/step")
+    note(f"{args.steps} timed steps: {elapsed / args.steps * 1e3:.2f} ms/step (host enqueue {host_elapsed / args.steps * 1e3:.2f} ms/step)")
     red_dev = torch.device("cpu") if rehearsal else dev
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     tot = torch.tensor([float(frames_rank), flops_rank], dtype=torch.float64, device=red_dev)
@@ -287,6 +288,7 @@ def main():
                                    f"{cfg['encoder_n_layers']}+{cfg['decoder_n_layers']} layers, dropout on, fp32",
                        "global_batch": args.batch * world, "frames_per_step": frames_all, "parallelism": f"dp{world}",
                        "final_loss": final_loss, "per_step_loss_item_sync": False},
+            "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "step_algorithmic_tflops": flops_all / 1e12,
             "step_achieved_tflops_per_gpu": flops_all / world / (elapsed / args.steps) / 1e12,
         }

@@ -163,6 +163,23 @@ size_t ttts_rowdot_bwd_workspace_bytes(int d);
 int ttts_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx_accum, float* dw, float* db, float* ws,
                     size_t ws_bytes, int64_t M, int d, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------ loss and scheduled-sampling mix
+ * TransformerTTSLoss.forward (loss.py:15-55): out4 = [total, pred_mel, post_mel, stop]; masked MSE over frames
+ * t < lens[b] (x2, post weighted 0.5 in the total) + BCE-with-logits on the stop gate (1 at t = lens[b]-1) with
+ * pos_weight, mean over valid frames.  ws keeps the normalisers for ttts_loss_bwd, which takes the upstream gradient
+ * of the four outputs (grad4) and writes the gradients of pred / post / stop. */
+size_t ttts_loss_workspace_bytes(void);
+int ttts_loss_fwd(const float* pred, const float* post, const float* stop, const float* mel, const int64_t* lens,
+                  float* out4, float* ws, size_t ws_bytes, int B, int T, int C, float pos_weight, void* stream);
+int ttts_loss_bwd(const float* pred, const float* post, const float* stop, const float* mel, const int64_t* lens,
+                  const float* ws, const float* grad4, float* dpred, float* dpost, float* dstop, int B, int T, int C,
+                  float pos_weight, void* stream);
+/* block_mask + apply_teacher_forcing (utils/util.py:103-120): u is the (B,T) uniform draw; frame t takes the model's
+ * prediction when any u[t-l_bar/2 .. t-l_bar/2+l_bar-1] < 1-p_tf (max_pool1d(k=l_bar, s=1, pad=l_bar/2)[:T]), the
+ * ground truth otherwise, and zero beyond lens[b]. */
+int ttts_sched_sampling_mix(const float* pred, const float* mel, const float* u, const int64_t* lens, float* out, int B,
+                            int T, int C, float p_tf, int l_bar, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,6 +185,12 @@ def test_cross_attention(B, H, Tq, Tk, lens):
         assert float(attn[b, :, :, n:].abs().sum()) == 0.0
     assert rel_l2(qg.grad, qd.grad) < TOL
     assert rel_l2(kvg.grad, kvd.grad) < TOL
+    # the same attention without the weights output (single-pass online softmax path)
+    q2, kv2 = _g(q_), _g(kv_)
+    out2, none_w = ops.CrossAttentionFn.apply(q2, kv2, lens_t.to(_dev()), H, 0.0, 0, False)
+    out2.backward(do.to(_dev()))
+    assert none_w.numel() == 0
+    assert rel_l2(out2, ref) < TOL and rel_l2(q2.grad, qd.grad) < TOL and rel_l2(kv2.grad, kvd.grad) < TOL
 
 
 def test_embedding_posenc_heads_add():
@@ -269,3 +275,39 @@ def test_dropout_masks_are_consistent_and_calibrated():
     (gkv,) = torch.autograd.grad(o1, kvg, do)
     v_grad_ref = torch.einsum("bhqk,bqhd->bkhd", a1, do.view(B, Tq, H, 64)).reshape(B, Tk, 128)
     assert rel_l2(gkv[:, :, 128:], v_grad_ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,T,C,lens", [(3, 37, 16, [37, 20, 9]), (4, 300, 80, [300, 211, 95, 1])])
+def test_loss_kernels(B, T, C, lens):
+    from oracle import oracle_loss
+    from transformertts_amd.loss import TransformerTTSLoss
+    pred, post, stop, mel = _rand(B, T, C, seed=1), _rand(B, T, C, seed=2), _rand(B, T, seed=3, scale=2.0), _rand(B, T, C, seed=4)
+    lens_t = torch.tensor(lens, dtype=torch.int64)
+    pd, qd, sd = [t.double().requires_grad_() for t in (pred, post, stop)]
+    ref = oracle_loss({"pred_melspec": pd, "post_melspec": qd, "pred_stop": sd}, mel.double(), lens_t)
+    w = torch.tensor([1.0, 0.3, -0.7, 2.0], dtype=torch.float64)       # exercise all four upstream gradients
+    (w[0] * ref["total"] + w[1] * ref["pred_mel"] + w[2] * ref["post_mel"] + w[3] * ref["stop"]).backward()
+    pg, qg, sg = _g(pred), _g(post), _g(stop)
+    out = TransformerTTSLoss(8.0).to(_dev())({"pred_melspec": pg, "post_melspec": qg, "pred_stop": sg}, mel.to(_dev()),
+                                             lens_t.to(_dev()))
+    for k in ("total", "pred_mel", "post_mel", "stop"):
+        assert abs(out[k].item() - ref[k].item()) < 2e-6 * max(1.0, abs(ref[k].item())), k
+    wd = w.float().to(_dev())
+    (wd[0] * out["total"] + wd[1] * out["pred_mel"] + wd[2] * out["post_mel"] + wd[3] * out["stop"]).backward()
+    assert rel_l2(pg.grad, pd.grad) < TOL and rel_l2(qg.grad, qd.grad) < TOL and rel_l2(sg.grad, sd.grad) < TOL
+    for b, n in enumerate(lens):           # padded frames get exactly zero gradient
+        assert float(pg.grad[b, n:].abs().sum()) == 0.0 and float(sg.grad[b, n:].abs().sum()) == 0.0
+
+
+def test_scheduled_sampling_mix_kernel(golden_dir):
+    """Bit-exact against the reference's own mixed tensors (tests/golden/helpers.npz) for the injected uniform draw."""
+    import os
+    import numpy as np
+    from transformertts_amd import ops
+    g = np.load(os.path.join(golden_dir, "helpers.npz"))
+    pred, mel, lens = (torch.from_numpy(g["ss/pred"]), torch.from_numpy(g["ss/mel"]), torch.from_numpy(g["ss/lens"]))
+    dev = _dev()
+    for p_tf in (1.0, 0.7, 0.05):
+        u = torch.from_numpy(g[f"ss/u_{p_tf}"]).view(pred.shape[0], -1)
+        out = ops.sched_sampling_mix(pred.to(dev), mel.to(dev), u.to(dev), lens.to(dev), p_tf, 8)
+        assert torch.equal(out.cpu(), torch.from_numpy(g[f"ss/mixed_{p_tf}"])), p_tf

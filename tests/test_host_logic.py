@@ -63,8 +63,9 @@ def test_state_dict_contract_and_ctor_signature():
                       "encoder_d_ffn", "encoder_dropout", "decoder_n_layers", "decoder_n_head", "decoder_d_ffn",
                       "decoder_dropout", "postnet_n_layers", "postnet_kernel_size", "postnet_dropout", "d_model",
                       "n_phon", "n_mels", "device"]
-    assert list(inspect.signature(TransformerTTS.forward).parameters)[1:] == ["phoneme", "melspec", "phoneme_lens",
-                                                                              "melspec_lens"]
+    fwd = inspect.signature(TransformerTTS.forward).parameters
+    assert list(fwd)[1:5] == ["phoneme", "melspec", "phoneme_lens", "melspec_lens"]
+    assert all(p.default is not inspect.Parameter.empty for p in list(fwd.values())[5:])   # extensions are optional
     # encoder layers start as identical deep copies (torch nn.TransformerEncoder semantics)
     assert torch.equal(base.encoder.layers[0].linear1.weight, base.encoder.layers[2].linear1.weight)
 

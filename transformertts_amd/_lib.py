@@ -52,6 +52,10 @@ SIGNATURES = {
     "ttts_relu_dropout_bwd": (I, [P, P, P, L, F, P]),
     "ttts_dropout_bwd": (I, [P, P, L, F, U, P]),
     "ttts_add": (I, [P, P, P, L, P]),
+    "ttts_loss_workspace_bytes": (Z, []),
+    "ttts_loss_fwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, F, P]),
+    "ttts_loss_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, F, P]),
+    "ttts_sched_sampling_mix": (I, [P, P, P, P, P, I, I, I, F, I, P]),
     "ttts_rowdot_fwd": (I, [P, P, P, P, L, I, P]),
     "ttts_rowdot_bwd_workspace_bytes": (Z, [I]),
     "ttts_rowdot_bwd": (I, [P, P, P, P, P, P, P, Z, L, I, I, P]),

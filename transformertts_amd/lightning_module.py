@@ -48,14 +48,15 @@ class LightningModule(_Base):
         self.log_interval = config['training'].get('log_interval', 100)
         self.sync_loss = config['training'].get('sync_loss_every_step', True)
 
-    def forward(self, phoneme, melspec, phoneme_lens, melspec_lens):
-        return self.model(phoneme, melspec, phoneme_lens, melspec_lens)
+    def forward(self, phoneme, melspec, phoneme_lens, melspec_lens, **kwargs):
+        return self.model(phoneme, melspec, phoneme_lens, melspec_lens, **kwargs)
 
     def training_step(self, batch, batch_idx):
         phoneme, melspec, phoneme_lens, melspec_lens = prepare_batch(batch, self.device)
         # forward #1 (no grad, train mode: dropout on, BN statistics updated) -> the model's own prediction
-        with torch.no_grad():
-            pred_melspec = self.forward(phoneme, melspec, phoneme_lens, melspec_lens)['pred_melspec']
+        with torch.no_grad():   # only pred_melspec is used: do not materialise the attention maps
+            pred_melspec = self.forward(phoneme, melspec, phoneme_lens, melspec_lens,
+                                        need_alignments=False)['pred_melspec']
         p_tf = get_teacher_forcing_ratio(epoch=self.current_epoch + 1,
                                          total_epochs=self.config['training']['num_epochs'],
                                          mode=self.config['training']['teacher_forcing_mode'], cycles=1)

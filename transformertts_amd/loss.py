@@ -1,11 +1,10 @@
 """TransformerTTSLoss -- masked MSE (pred + 0.5 * post) + stop-gate BCE-with-logits (pos_weight).
 
 Same constructor, call signature, returned dict and `pos_weight` buffer as the reference's `loss.py:8-55`.
-Restated without boolean-index gathers (`mel[mask]`, loss.py:34-36,44), which allocate data-dependent
-shapes and force a device->host sync every step: the masked means are computed as masked sums over the
-padded tensors, which is the same arithmetic up to fp32 summation order.
-SURVEY.md section 8f ranks a fused HIP kernel for this as the first "next" item; until then these are
-stock torch element-wise ops on the device (they sit outside the model hot path).
+On HIP tensors the whole loss (and its backward) runs in the fused kernels of csrc/loss.hip (SURVEY.md
+section 8f, row 1): one streaming masked reduction instead of the reference's boolean-index gathers
+(`mel[mask]`, loss.py:34-36,44), which allocate data-dependent shapes and force a device->host sync.
+On CPU tensors (host-side checks only) the same arithmetic is evaluated with masked sums in torch.
 """
 from __future__ import annotations
 
@@ -21,9 +20,19 @@ class TransformerTTSLoss(nn.Module):
     def __init__(self, stop_weight: float = 8.0):
         super().__init__()
         self.register_buffer("pos_weight", torch.tensor(stop_weight))
+        self._pos_weight_host = float(stop_weight)   # host copy: reading the device buffer every step would synchronise
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        if prefix + "pos_weight" in state_dict:
+            self._pos_weight_host = float(state_dict[prefix + "pos_weight"])
 
     def forward(self, outputs: Dict[str, Tensor], mel: Tensor, lengths: Tensor) -> Dict[str, Tensor]:
         pred, post, stop = outputs["pred_melspec"], outputs["post_melspec"], outputs["pred_stop"]
+        if pred.is_cuda:
+            from . import ops
+            out = ops.TTSLossFn.apply(pred, post, stop, mel, lengths.to(torch.int64), self._pos_weight_host)
+            return {"total": out[0], "pred_mel": out[1], "post_mel": out[2], "stop": out[3]}
         B, T, C = pred.shape
         pos = torch.arange(T, device=pred.device).unsqueeze(0)
         valid = (pos < lengths.unsqueeze(1)).to(pred.dtype)                 # (B,T)

@@ -54,12 +54,16 @@ class MultiheadAttention(nn.Module):
         return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, drop_p=out_drop,
                           seed=ops.seeds.next() if out_drop > 0 else 0)
 
-    def cross_attention(self, x: Tensor, mem: Tensor, mem_lens: Tensor, residual: Tensor, out_drop: float):
+    def cross_attention(self, x: Tensor, mem: Tensor, mem_lens: Tensor, residual: Tensor, out_drop: float,
+                        need_weights: bool = True):
         d = self.embed_dim
         q = ops.linear(x, self.in_proj_weight[:d], self.in_proj_bias[:d])
         kv = ops.linear(mem, self.in_proj_weight[d:], self.in_proj_bias[d:])
         p = self._p()
-        ctx, attn = ops.CrossAttentionFn.apply(q, kv, mem_lens, self.num_heads, p, ops.seeds.next() if p > 0 else 0)
+        ctx, attn = ops.CrossAttentionFn.apply(q, kv, mem_lens, self.num_heads, p, ops.seeds.next() if p > 0 else 0,
+                                               need_weights)
+        if not need_weights:
+            attn = None
         out = ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, drop_p=out_drop,
                          seed=ops.seeds.next() if out_drop > 0 else 0)
         return out, attn
@@ -147,7 +151,7 @@ class TransformerDecoderLayer(nn.Module):
                 memory_mask: Optional[Tensor] = None, tgt_key_padding_mask: Optional[Tensor] = None,
                 memory_key_padding_mask: Optional[Tensor] = None, tgt_is_causal: bool = True,
                 memory_is_causal: bool = False, tgt_lens: Optional[Tensor] = None,
-                memory_lens: Optional[Tensor] = None):
+                memory_lens: Optional[Tensor] = None, need_alignments: bool = True):
         if memory_mask is not None or memory_is_causal:
             raise ValueError("TransformerDecoderLayer: memory masks other than key padding are not supported")
         B = tgt.size(0)
@@ -160,7 +164,8 @@ class TransformerDecoderLayer(nn.Module):
         s = self.self_attn.self_attention(tgt, tgt_lens, causal, residual=tgt, out_drop=self.dropout1.p if tr else 0.0)
         x = ops.layer_norm(s, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         s, alignments = self.multihead_attn.cross_attention(x, memory, memory_lens, residual=x,
-                                                            out_drop=self.dropout2.p if tr else 0.0)
+                                                            out_drop=self.dropout2.p if tr else 0.0,
+                                                            need_weights=need_alignments)
         x = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         x = ops.layer_norm(_ffn_block(self, x, self.dropout3), self.norm3.weight, self.norm3.bias, self.norm3.eps)
         return x, alignments
@@ -181,7 +186,7 @@ class TransformerDecoder(nn.Module):
                 memory_mask: Optional[Tensor] = None, tgt_key_padding_mask: Optional[Tensor] = None,
                 memory_key_padding_mask: Optional[Tensor] = None, tgt_is_causal: Optional[bool] = None,
                 memory_is_causal: Optional[bool] = None, tgt_lens: Optional[Tensor] = None,
-                memory_lens: Optional[Tensor] = None):
+                memory_lens: Optional[Tensor] = None, need_alignments: bool = True):
         B = tgt.size(0)
         if tgt_lens is None:
             tgt_lens = _lens_from_kpm(tgt_key_padding_mask, B, tgt.size(1), tgt.device)
@@ -192,7 +197,7 @@ class TransformerDecoder(nn.Module):
             tgt, alignment = layer(tgt=tgt, memory=memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
                                    tgt_is_causal=True if tgt_is_causal is None else tgt_is_causal,
                                    memory_is_causal=bool(memory_is_causal), tgt_lens=tgt_lens,
-                                   memory_lens=memory_lens)
+                                   memory_lens=memory_lens, need_alignments=need_alignments)
             alignments.append(alignment)
         if self.norm is not None:
             tgt = ops.layer_norm(tgt, self.norm.weight, self.norm.bias, self.norm.eps)

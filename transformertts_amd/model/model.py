@@ -178,8 +178,13 @@ class TransformerTTS(nn.Module):
         x = self.pe(self.enc_prenet(x))
         return self.encoder(x, src_lens=phoneme_lens)
 
-    def forward(self, phoneme: Tensor, melspec: Tensor, phoneme_lens: Tensor, melspec_lens: Tensor) -> dict:
+    def forward(self, phoneme: Tensor, melspec: Tensor, phoneme_lens: Tensor, melspec_lens: Tensor,
+                need_alignments: bool = True) -> dict:
         """
+        `need_alignments=False` (an extension; the reference always returns them) skips writing the per-head
+        cross-attention maps -- 267 MB per forward at batch 64 -- for callers that only want the mels, e.g. the
+        no-grad first forward of `training_step`.  `alignments` is then a list of None.
+
         Args:
           - phoneme (B, T_phon) int64, melspec (B, T_mel, n_mels) fp32, phoneme_lens / melspec_lens (B,) int64,
             all on the HIP device.
@@ -195,7 +200,8 @@ class TransformerTTS(nn.Module):
         memory = self.encode(phoneme, phoneme_lens)
         tgt = self.pe(self.dec_prenet(melspec, shift_right=True))
         tgt_out, alignments = self.decoder(tgt=tgt, memory=memory, tgt_is_causal=True, memory_is_causal=False,
-                                           tgt_lens=melspec_lens, memory_lens=phoneme_lens)
+                                           tgt_lens=melspec_lens, memory_lens=phoneme_lens,
+                                           need_alignments=need_alignments)
         pred_melspec, pred_stop = ops.HeadsFn.apply(tgt_out, self.linear1.linear.weight, self.linear1.linear.bias,
                                                     self.linear2.linear.weight, self.linear2.linear.bias)
         post_melspec = ops.AddFn.apply(self.postnet(pred_melspec), pred_melspec)
@@ -225,7 +231,7 @@ class TransformerTTS(nn.Module):
             tgt = self.pe(self.dec_prenet(cur))
             lens_t = torch.full((B,), t, dtype=torch.int64, device=dev)
             out, _ = self.decoder(tgt=tgt, memory=memory, tgt_is_causal=True, tgt_lens=lens_t,
-                                  memory_lens=phoneme_lens)
+                                  memory_lens=phoneme_lens, need_alignments=False)
             last = out[:, -1:, :].contiguous()
             mel, stop = ops.HeadsFn.apply(last, self.linear1.linear.weight, self.linear1.linear.bias,
                                           self.linear2.linear.weight, self.linear2.linear.bias)

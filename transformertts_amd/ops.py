@@ -22,7 +22,15 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() costs ~100 us per
+    call here (it re-reads os.environ through is_available()), i.e. 25 ms per training step over ~700 launches; the raw
+    accessor is the same one torch's own launchers use."""
+    if _raw_stream is not None:
+        return c_void_p(_raw_stream(torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -425,7 +433,7 @@ class CrossAttentionFn(torch.autograd.Function):
     """Encoder-decoder attention: q (B,Tq,d), packed kv (B,Tk,2d) -> o (B,Tq,d), weights (B,H,Tq,Tk) post-dropout."""
 
     @staticmethod
-    def forward(ctx, q, kv, lens, n_head, drop_p, seed):
+    def forward(ctx, q, kv, lens, n_head, drop_p, seed, need_weights=True):
         q = _chk(q, "cross_attention.q")
         kv = _chk(kv, "cross_attention.kv")
         lens = _chk(lens, "cross_attention.lens", torch.int64)
@@ -434,9 +442,11 @@ class CrossAttentionFn(torch.autograd.Function):
         if d != n_head * 64:
             raise ValueError(f"attention kernels need head_dim 64 (d_model {d}, heads {n_head})")
         o, lse, attn = _attn_fwd(_off(q, 0), _off(kv, 0), _off(kv, d), d, 2 * d, 2 * d, B, n_head, Tq, Tk, lens, False,
-                                 drop_p, seed, True)
+                                 drop_p, seed, need_weights)
         ctx.save_for_backward(q, kv, o, lse, lens)
         ctx.cfg = (n_head, float(drop_p), seed)
+        if attn is None:       # weights not requested: single-pass online softmax, nothing written
+            attn = torch.empty(0, dtype=torch.float32, device=q.device)
         ctx.mark_non_differentiable(attn)
         return o, attn
 
@@ -454,7 +464,7 @@ class CrossAttentionFn(torch.autograd.Function):
         _lib.check(lib.ttts_attention_bwd(_off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
                                           _off(dq, 0), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk, d, 2 * d,
                                           2 * d, d, d, 2 * d, 2 * d, 0, drop_p, seed, _stream()), "ttts_attention_bwd")
-        return dq, dkv, None, None, None, None
+        return dq, dkv, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------- small pieces
@@ -541,3 +551,48 @@ class AddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         return dz, dz
+
+
+# ----------------------------------------------------------------------------------------------- loss / mix
+class TTSLossFn(torch.autograd.Function):
+    """[total, pred_mel, post_mel, stop] of TransformerTTSLoss in one streaming reduction (no boolean-index gathers)."""
+
+    @staticmethod
+    def forward(ctx, pred, post, stop, mel, lens, pos_weight):
+        lib = _lib.load()
+        pred, post, stop, mel = (_chk(pred, "loss.pred"), _chk(post, "loss.post"), _chk(stop, "loss.stop"),
+                                 _chk(mel, "loss.mel"))
+        lens = _chk(lens, "loss.lengths", torch.int64)
+        B, T, C = pred.shape
+        if post.shape != pred.shape or mel.shape != pred.shape or stop.shape != (B, T):
+            raise ValueError("loss: shape mismatch between pred / post / mel / stop")
+        out = torch.empty(4, dtype=torch.float32, device=pred.device)
+        ws = _ws(lib.ttts_loss_workspace_bytes(), pred.device)
+        _lib.check(lib.ttts_loss_fwd(_p(pred), _p(post), _p(stop), _p(mel), _p(lens), _p(out), _p(ws), ws.numel() * 4, B, T, C,
+                                     float(pos_weight), _stream()), "ttts_loss_fwd")
+        ctx.save_for_backward(pred, post, stop, mel, lens, ws)
+        ctx.pos_weight = float(pos_weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        pred, post, stop, mel, lens, ws = ctx.saved_tensors
+        B, T, C = pred.shape
+        g = _chk(g, "loss.grad")
+        dpred, dpost, dstop = torch.empty_like(pred), torch.empty_like(post), torch.empty_like(stop)
+        _lib.check(lib.ttts_loss_bwd(_p(pred), _p(post), _p(stop), _p(mel), _p(lens), _p(ws), _p(g), _p(dpred), _p(dpost),
+                                     _p(dstop), B, T, C, ctx.pos_weight, _stream()), "ttts_loss_bwd")
+        return dpred, dpost, dstop, None, None, None
+
+
+def sched_sampling_mix(pred, mel, u, lens, p_tf: float, l_bar: int = 8):
+    """Block-wise scheduled-sampling mix on the device; `u` is the (B,T) uniform draw."""
+    lib = _lib.load()
+    pred, mel, u = _chk(pred, "mix.pred"), _chk(mel, "mix.mel"), _chk(u, "mix.u")
+    lens = _chk(lens, "mix.lens", torch.int64)
+    B, T, C = pred.shape
+    out = torch.empty_like(mel)
+    _lib.check(lib.ttts_sched_sampling_mix(_p(pred), _p(mel), _p(u), _p(lens), _p(out), B, T, C, float(p_tf), l_bar,
+                                           _stream()), "ttts_sched_sampling_mix")
+    return out

@@ -55,6 +55,11 @@ def block_mask(mel: Tensor, p_tf: float, L_bar: int) -> Tensor:
 
 
 def apply_teacher_forcing(pred_melspec: Tensor, melspec: Tensor, melspec_lens: Tensor, p_tf: float, device=None) -> Tensor:
+    if pred_melspec.is_cuda:   # fused HIP kernel; the uniform draw stays torch.rand on the device, as in the reference
+        from .. import ops
+        B, T, _ = pred_melspec.shape
+        u = torch.rand(B, 1, T, device=pred_melspec.device)
+        return ops.sched_sampling_mix(pred_melspec.detach(), melspec, u.view(B, T), melspec_lens.to(torch.int64), p_tf, 8)
     mask = block_mask(pred_melspec, p_tf, L_bar=8)
     mel_mixed = torch.where(mask, pred_melspec.detach(), melspec)
     valid = torch.arange(pred_melspec.size(1), device=pred_melspec.device).unsqueeze(0) < melspec_lens.unsqueeze(1)
