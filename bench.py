@@ -202,15 +202,15 @@ def main():
     cfg = model_config(args.config)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
               "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,
-                           "sync_loss_every_step": False, "max_grad_norm": 1.0}}
+                           "sync_loss_every_step": False, "fused_clip_norm": 1.0}}
     torch.manual_seed(42)
     ops.seeds.manual_seed(42 + rank)
     lm = LightningModule(config).to(dev)
     lm.train()
     broadcast_module_state(lm)
-    bucket = FlatGradBucket(lm.parameters())
-    opt_cfg = lm.configure_optimizers()
+    opt_cfg = lm.configure_optimizers()          # FlatAdam: flat parameters / gradients / moments, clip folded in
     optimizer, scheduler = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
+    bucket = optimizer.bucket
 
     # per-rank shard of the global synthetic batch (weak scaling: args.batch utterances per GPU)
     batch = synth_batch(args.batch, args.tp, args.tm, cfg["n_mels"], cfg["n_phon"], ragged=args.ragged, seed=1234 + rank)
@@ -220,12 +220,11 @@ def main():
                            for p, m in zip(batch["phoneme_lens"].tolist(), batch["melspec_lens"].tolist()))
 
     def step(i):
-        bucket.zero()
+        optimizer.zero_grad()
         loss = lm.training_step(batch, i)
         loss.backward()
         bucket.allreduce_mean()
-        bucket.clip_grad_norm_(config["training"]["max_grad_norm"])
-        optimizer.step()
+        optimizer.step()                         # global-norm clip (1.0) + Adam, two kernels over the flat bucket
         scheduler.step()
         return loss
 

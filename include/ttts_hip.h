@@ -180,6 +180,15 @@ int ttts_loss_bwd(const float* pred, const float* post, const float* stop, const
 int ttts_sched_sampling_mix(const float* pred, const float* mel, const float* u, const int64_t* lens, float* out, int B,
                             int T, int C, float p_tf, int l_bar, void* stream);
 
+/* ------------------------------------------------------------------ optimizer over flat buffers
+ * Global L2 norm of the flat gradient bucket (clip_grad_norm_, train.py:41) and one torch.optim.Adam step
+ * (lightning_module.py:160-163: betas (0.9, 0.98), eps 1e-9, lr = Noam factor set by the host) on flat parameter /
+ * gradient / moment buffers; the clip factor min(1, max_grad_norm / (norm + 1e-6)) is applied inside the step. */
+size_t ttts_grad_norm_workspace_bytes(void);
+int ttts_grad_norm(const float* g, float* norm_out, float* ws, size_t ws_bytes, int64_t n, void* stream);
+int ttts_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, const float* grad_norm, int64_t n, float lr,
+                   float beta1, float beta2, float eps, int64_t step, float max_grad_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -311,3 +311,29 @@ def test_scheduled_sampling_mix_kernel(golden_dir):
         u = torch.from_numpy(g[f"ss/u_{p_tf}"]).view(pred.shape[0], -1)
         out = ops.sched_sampling_mix(pred.to(dev), mel.to(dev), u.to(dev), lens.to(dev), p_tf, 8)
         assert torch.equal(out.cpu(), torch.from_numpy(g[f"ss/mixed_{p_tf}"])), p_tf
+
+
+def test_flat_adam_matches_torch_adam():
+    """FlatAdam (fused clip + Adam over flat buffers) against torch.optim.Adam + clip_grad_norm_ in fp64 on CPU."""
+    from transformertts_amd.optim import FlatAdam
+    from transformertts_amd.utils.util import get_noam_scheduler
+    dev = _dev()
+    shapes = [(100, 256), (768,), (256, 80, 5), (1,), (33, 7)]
+    ps = [torch.nn.Parameter(_rand(*s, seed=10 + i).to(dev)) for i, s in enumerate(shapes)]
+    ref = [torch.nn.Parameter(p.detach().cpu().double()) for p in ps]
+    opt = FlatAdam(ps, lr=1.0, betas=(0.9, 0.98), eps=1e-9, max_grad_norm=1.0)
+    ropt = torch.optim.Adam(ref, lr=1.0, betas=(0.9, 0.98), eps=1e-9)
+    lam = get_noam_scheduler(256, 4000)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lam)
+    rsch = torch.optim.lr_scheduler.LambdaLR(ropt, lam)
+    for step in range(4):
+        opt.zero_grad()
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            g = _rand(*p.shape, seed=100 * step + i, scale=(3.0 if step % 2 else 0.01))   # clipped and unclipped steps
+            p.grad.copy_(g.to(dev))
+            r.grad = g.double()
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        opt.step(); ropt.step(); sch.step(); rsch.step()
+    for p, r in zip(ps, ref):
+        assert p.data_ptr() >= opt.flat_params.data_ptr()       # still a view of the flat buffer
+        assert rel_l2(p, r) < 1e-5

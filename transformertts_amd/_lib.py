@@ -56,6 +56,9 @@ SIGNATURES = {
     "ttts_loss_fwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, F, P]),
     "ttts_loss_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, F, P]),
     "ttts_sched_sampling_mix": (I, [P, P, P, P, P, I, I, I, F, I, P]),
+    "ttts_grad_norm_workspace_bytes": (Z, []),
+    "ttts_grad_norm": (I, [P, P, P, Z, L, P]),
+    "ttts_adam_step": (I, [P, P, P, P, P, L, F, F, F, F, L, F, P]),
     "ttts_rowdot_fwd": (I, [P, P, P, P, L, I, P]),
     "ttts_rowdot_bwd_workspace_bytes": (Z, [I]),
     "ttts_rowdot_bwd": (I, [P, P, P, P, P, P, P, Z, L, I, I, P]),

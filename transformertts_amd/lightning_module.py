@@ -88,7 +88,14 @@ class LightningModule(_Base):
         self.valid_losses.clear()
 
     def configure_optimizers(self):
-        optimizer = torch.optim.Adam(self.parameters(), lr=1.0, betas=(0.9, 0.98), eps=1e-9)
+        if next(self.parameters()).is_cuda:
+            # same Adam arithmetic as the reference, fused over flat buffers; `fused_clip_norm` (> 0) folds the
+            # Trainer's gradient_clip_val (train.py:41) into the step for loops that do not clip themselves
+            from .optim import FlatAdam
+            optimizer = FlatAdam(self.parameters(), lr=1.0, betas=(0.9, 0.98), eps=1e-9,
+                                 max_grad_norm=float(self.config['training'].get('fused_clip_norm', 0.0)))
+        else:
+            optimizer = torch.optim.Adam(self.parameters(), lr=1.0, betas=(0.9, 0.98), eps=1e-9)
         lr_lambda = get_noam_scheduler(d_model=self.config['model']['d_model'],
                                        warmup_steps=self.config['training']['warmup_steps'])
         scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lr_lambda)

@@ -70,12 +70,22 @@ seeds = _SeedStream()
 GEMM_MODE = os.environ.get("TTTS_GEMM_MODE", "x6")
 
 
+_param_epoch = 0
+
+
+def bump_param_epoch() -> None:
+    """Invalidate every cached weight split.  Called by optimizers that update parameters through raw pointers
+    (optim.FlatAdam), which autograd's per-tensor version counters cannot see."""
+    global _param_epoch
+    _param_epoch += 1
+
+
 def _planes(w: torch.Tensor, mode: int, rows: int, cols: int, c2: int = 0, taps: int = 0) -> torch.Tensor:
     """hi/mid/lo bf16 planes of a weight, re-laid as the K-contiguous B operand (ttts_weight_split).  Cached on the
     tensor object and keyed by its version counter + storage address, so the two forwards and the backward of a
     step split each weight once and an optimizer step invalidates the planes."""
     cache = getattr(w, "_ttts_planes", None)
-    tag = (w._version, w.data_ptr())
+    tag = (w._version, w.data_ptr(), _param_epoch)
     if cache is not None:
         ent = cache.get(mode)
         if ent is not None and ent[0] == tag:
