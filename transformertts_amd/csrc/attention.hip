@@ -121,8 +121,10 @@ __global__ __launch_bounds__(256, TTTS_FWD_W) void attn_fwd_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     float* ptile = ptile_all + (WRITE_A ? wave * 32 * 33 : 0);
-    const int qblk = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;   // heaviest causal blocks first
-    const int h = blockIdx.y, b = blockIdx.z;
+    // grid = (B*H, query blocks): x (fastest in dispatch order) walks the (batch, head) pairs, y the query blocks, so the
+    // whole launch runs heaviest-first for the causal form (last query block = longest key range)
+    const int qblk = CAUSAL ? (gridDim.y - 1 - blockIdx.y) : blockIdx.y;
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
     const int q0 = qblk * QB, qw0 = q0 + wave * 32;
     const int qg = qw0 + l31;
     float* scratch = smem + wave * 32 * KT_LD;
@@ -301,8 +303,8 @@ __global__ __launch_bounds__(256, TTTS_DQ_W) void attn_bwd_dq_kernel(AttnArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int qblk = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int qblk = CAUSAL ? (gridDim.y - 1 - blockIdx.y) : blockIdx.y;
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
     const int q0 = qblk * QB, qw0 = q0 + wave * 32;
     const int qg = qw0 + l31;
     float* scratch = smem + wave * 32 * KT_LD;
@@ -409,8 +411,8 @@ __global__ __launch_bounds__(256, TTTS_DKV_W) void attn_bwd_dkv_kernel(AttnArgs 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int kblk = blockIdx.x;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int kblk = blockIdx.y;          // ascending = heaviest first for the causal form (key block 0 meets every query)
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
     const int k0 = kblk * QB, kw0 = k0 + wave * 32;
     const int kg = kw0 + l31;
     float* scratch = smem + wave * 32 * KT_LD;
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(256, TTTS_DKV_W) void attn_bwd_dkv_kernel(AttnArgs 
 
 static int check_common(const char* name, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, float drop_p) {
     TTTS_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "%s: bad dims", name);
-    TTTS_REQUIRE(B <= 65535 && H <= 65535, "%s: B and H must be <= 65535", name);
+    TTTS_REQUIRE((long)B * H < (1L << 31) && cdiv(Tq, QB) <= 65535 && cdiv(Tk, QB) <= 65535, "%s: grid too large", name);
     TTTS_REQUIRE(ldq >= H * HD && ldk >= H * HD && ldv >= H * HD && ldo >= H * HD, "%s: row strides must be >= H*64", name);
     TTTS_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "%s: row strides must be multiples of 4", name);
     TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "%s: bad dropout p", name);
@@ -539,7 +541,7 @@ int ttts_attention_fwd(const float* q, const float* k, const float* v, float* o,
     a.thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     a.drop_scale = 1.f / (1.f - drop_p);
     a.seed = seed;
-    dim3 grid(cdiv(Tq, QB), H, B);
+    dim3 grid(B * H, cdiv(Tq, QB), 1);
     if (causal)
         hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), 0, stream, a);
     else if (attn)
@@ -570,7 +572,7 @@ int ttts_attention_bwd(const float* q, const float* k, const float* v, const flo
     a.thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     a.drop_scale = 1.f / (1.f - drop_p);
     a.seed = seed;
-    dim3 gq(cdiv(Tq, QB), H, B), gk(cdiv(Tk, QB), H, B);
+    dim3 gq(B * H, cdiv(Tq, QB), 1), gk(B * H, cdiv(Tk, QB), 1);
     if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), gq, dim3(256), 0, stream, a);
         TTTS_LAUNCH_CHECK("attn_bwd_dq_kernel");
