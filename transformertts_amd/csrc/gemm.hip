@@ -25,7 +25,7 @@ namespace ttts {
 #define TTTS_GEMM_BK 16
 #endif
 #ifndef TTTS_GEMM_MINWAVES
-#define TTTS_GEMM_MINWAVES 1
+#define TTTS_GEMM_MINWAVES 3
 #endif
 constexpr int BK = TTTS_GEMM_BK;          // k-tile depth (floats)
 constexpr int KC_LD = BK + 1;   // LDS row stride for K-contiguous tiles (odd -> conflict-free b32 reads)
