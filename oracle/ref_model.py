@@ -228,3 +228,47 @@ def oracle_training_step(sd, cfg, batch, epoch: int = 0, num_epochs: int = 300,
     out = oracle_forward(sd, cfg, ph, mixed, pl, ml, training=True, dropout=dropout)
     loss = oracle_loss(out, mel, ml, stop_weight)
     return loss, out, mixed
+
+
+@torch.no_grad()
+def oracle_inference(sd, cfg, phoneme, phoneme_lens, max_len: int = 1500, stop_threshold: float = 0.5):
+    """TransformerTTS.inference, model/model.py:323-394: eval mode; the encoder is called WITHOUT a padding mask
+    (:346-348), each step re-runs pre-net + PE + the whole decoder over the frames so far (:354-374) with the causal +
+    length masks of _get_mask and the memory key-padding mask; stops when sigmoid(stop) >= threshold for all items."""
+    B = phoneme.size(0)
+    dt = sd["emb.weight"].dtype
+    x = F.embedding(phoneme, sd["emb.weight"])
+    for i in range(cfg["encoder_prenet_n_layers"]):
+        x = conv_norm_bn(sd, f"enc_prenet.layers.{2 * i}", x, False, False)
+    x = F.linear(x, sd["enc_prenet.linear.linear.weight"], sd["enc_prenet.linear.linear.bias"])
+    x = positional_encoding(sd, x, 0.1, False)
+    full = torch.full((B,), phoneme.size(1), dtype=torch.long)
+    for i in range(cfg["encoder_n_layers"]):
+        x = encoder_layer(sd, f"encoder.layers.{i}", x, cfg["encoder_n_head"], full, cfg["encoder_dropout"], False)
+    memory = x
+    ys = [torch.zeros(B, 1, cfg["n_mels"], dtype=dt)]
+    stops = []
+    for t in range(1, max_len):
+        y = torch.cat(ys, dim=1)
+        y = F.relu(F.linear(y, sd["dec_prenet.linear1.linear.weight"], sd["dec_prenet.linear1.linear.bias"]))
+        y = F.relu(F.linear(y, sd["dec_prenet.linear2.linear.weight"], sd["dec_prenet.linear2.linear.bias"]))
+        y = positional_encoding(sd, y, 0.1, False)
+        lens_t = torch.full((B,), t, dtype=torch.long)
+        for i in range(cfg["decoder_n_layers"]):
+            y, _ = decoder_layer(sd, f"decoder.layers.{i}", y, memory, cfg["decoder_n_head"], lens_t, phoneme_lens,
+                                 cfg["decoder_dropout"], False)
+        cur = y[:, -1:, :]
+        mel = F.linear(cur, sd["linear1.linear.weight"], sd["linear1.linear.bias"])
+        stop = F.linear(cur, sd["linear2.linear.weight"], sd["linear2.linear.bias"]).squeeze(-1)
+        ys.append(mel)
+        stops.append(stop)
+        if bool((torch.sigmoid(stop) >= stop_threshold).all()):
+            break
+    pred = torch.cat(ys[1:], dim=1)
+    z = pred
+    n_post = cfg["postnet_n_layers"]
+    for i in range(n_post):
+        z = conv_norm_bn(sd, f"postnet.layers.{3 * i}", z, False, False)
+        if i < n_post - 1:
+            z = torch.tanh(z)
+    return {"pred_melspec": pred, "post_melspec": z + pred, "pred_stop": torch.stack(stops, dim=1)}

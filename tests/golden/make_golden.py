@@ -182,6 +182,19 @@ def golden_step(name, cfg_name, B, Tp, Tm, w_seed, b_seed, epoch):
     print(name, "written; loss", float(loss))
 
 
+def golden_inference(name, cfg_name, B, Tp, w_seed, b_seed, max_len):
+    """The real TransformerTTS.inference (model/model.py:323-394), stop threshold out of reach -> max_len-1 steps."""
+    cfg = model_config(cfg_name)
+    m = _ref_model(cfg, w_seed)
+    batch = synth_batch(B, Tp, 40, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=b_seed)
+    out = m.inference(batch["phoneme"], batch["phoneme_lens"], max_len=max_len, stop_threshold=2.0)
+    rec = {"meta/cfg_name": cfg_name, "meta/B": B, "meta/Tp": Tp, "meta/w_seed": w_seed, "meta/b_seed": b_seed,
+           "meta/max_len": max_len, "pred_melspec": _np(out["pred_melspec"]), "post_melspec": _np(out["post_melspec"]),
+           "pred_stop": _np(out["pred_stop"])}
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+    print(name, "written;", tuple(out["pred_melspec"].shape))
+
+
 def golden_helpers(name):
     _install_stubs()
     sys.path.insert(0, REF)
@@ -229,3 +242,4 @@ if __name__ == "__main__":
     golden_model("tiny_model", "tiny", B=3, Tp=12, Tm=40, w_seed=11, b_seed=21, align_stride=1)
     golden_model("base_model", "base", B=2, Tp=60, Tm=300, w_seed=12, b_seed=22, align_stride=8)
     golden_step("tiny_step", "tiny", B=3, Tp=12, Tm=40, w_seed=11, b_seed=21, epoch=120)
+    golden_inference("tiny_inference", "tiny", B=3, Tp=12, w_seed=11, b_seed=21, max_len=14)

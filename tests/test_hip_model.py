@@ -200,3 +200,27 @@ def test_grad_sinks_match_autograd():
     crit(m2(*args), args[1], args[3])["total"].backward()
     expect = g1 + torch.cat([torch.nn.functional.pad(p.grad.flatten(), (0, (-p.numel()) % 64)) for p in m4.parameters()])
     assert rel_l2(bucket.flat, expect) < 1e-6
+
+
+def test_inference_kv_cache_vs_recompute_vs_oracle(golden_dir):
+    """Incremental decoding with K/V caches == the reference-style full recomputation == the oracle loop (fp64) ==
+    the reference's own inference output (golden)."""
+    from oracle import synth_batch, oracle_inference
+    g = np.load(os.path.join(golden_dir, "tiny_inference.npz"))
+    cfg, m = _build(str(g["meta/cfg_name"]), int(g["meta/w_seed"]))
+    batch = synth_batch(int(g["meta/B"]), int(g["meta/Tp"]), 40, cfg["n_mels"], cfg["n_phon"], ragged=True,
+                        seed=int(g["meta/b_seed"]))
+    ph, pl = batch["phoneme"].to("cuda"), batch["phoneme_lens"].to("cuda")
+    L = int(g["meta/max_len"])
+    fast = m.inference(ph, pl, max_len=L, stop_threshold=2.0, use_kv_cache=True)
+    slow = m.inference(ph, pl, max_len=L, stop_threshold=2.0, use_kv_cache=False)
+    ref = oracle_inference(_oracle64(cfg, int(g["meta/w_seed"])), cfg, batch["phoneme"], batch["phoneme_lens"], max_len=L,
+                           stop_threshold=2.0)
+    for k in ("pred_melspec", "post_melspec", "pred_stop"):
+        assert fast[k].shape == slow[k].shape == tuple(g[k].shape), k
+        assert rel_l2(fast[k], slow[k]) < 1e-5, (k, rel_l2(fast[k], slow[k]))
+        assert rel_l2(fast[k], ref[k]) < GATE, (k, rel_l2(fast[k], ref[k]))
+        assert rel_l2(fast[k], torch.from_numpy(g[k])) < GATE, k
+    # early stop: a threshold every item passes at once ends the loop after the first frame
+    one = m.inference(ph, pl, max_len=L, stop_threshold=0.0)
+    assert one["pred_melspec"].shape[1] == 1 and one["pred_stop"].shape[1] == 1

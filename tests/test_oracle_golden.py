@@ -10,7 +10,8 @@ import pytest
 import torch
 
 from conftest import rel_l2
-from oracle import model_config, fill_state, synth_batch, oracle_forward, oracle_loss, oracle_training_step
+from oracle import (model_config, fill_state, synth_batch, oracle_forward, oracle_loss, oracle_training_step,
+                    oracle_inference)
 from oracle.ref_model import teacher_forcing_ratio, noam_lambda, scheduled_sampling_mix
 
 OUT_TOL = 1e-5
@@ -130,3 +131,17 @@ def test_helpers(golden_dir):
     ls = oracle_loss(outs, mel, lens)
     for k in ("total", "pred_mel", "post_mel", "stop"):
         assert abs(ls[k].item() - float(g[f"loss/{k}"])) < 2e-6 * max(1.0, abs(float(g[f"loss/{k}"])))
+
+
+def test_inference(golden_dir):
+    """The restated autoregressive loop against the reference's own `inference()` (13 forced steps, tiny config)."""
+    g = _load(golden_dir, "tiny_inference")
+    cfg = model_config(str(g["meta/cfg_name"]))
+    sd = fill_state(cfg, int(g["meta/w_seed"]))
+    batch = synth_batch(int(g["meta/B"]), int(g["meta/Tp"]), 40, cfg["n_mels"], cfg["n_phon"], ragged=True,
+                        seed=int(g["meta/b_seed"]))
+    out = oracle_inference(sd, cfg, batch["phoneme"], batch["phoneme_lens"], max_len=int(g["meta/max_len"]),
+                           stop_threshold=2.0)
+    for k in ("pred_melspec", "post_melspec", "pred_stop"):
+        assert out[k].shape == tuple(g[k].shape), k
+        assert rel_l2(out[k], torch.from_numpy(g[k])) < 2e-5, (k, rel_l2(out[k], torch.from_numpy(g[k])))

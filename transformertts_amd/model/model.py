@@ -213,10 +213,17 @@ class TransformerTTS(nn.Module):
         }
 
     @torch.no_grad()
-    def inference(self, phoneme: Tensor, phoneme_lens: Tensor, max_len: int = 1500, stop_threshold: float = 0.5) -> dict:
+    def inference(self, phoneme: Tensor, phoneme_lens: Tensor, max_len: int = 1500, stop_threshold: float = 0.5,
+                  use_kv_cache: bool = True) -> dict:
         """Greedy autoregressive decoding with the reference's semantics (model/model.py:323-394): eval mode, the
-        encoder runs WITHOUT a padding mask, every step re-runs the decoder over the frames so far, stop when
-        sigmoid(stop) >= threshold for every item."""
+        encoder runs WITHOUT a padding mask, cross-attention masks padded phonemes, stop when sigmoid(stop) >= threshold
+        for every item, post-net once at the end.
+
+        The reference re-runs pre-net + the whole decoder over all frames so far at every step (O(T^3) overall).
+        `use_kv_cache=True` (default) computes the same values incrementally: each step
+        projects only the newest frame, appends its self-attention K/V to per-layer caches and attends with one query
+        row; the cross-attention K/V of the encoder memory are projected once.  `use_kv_cache=False` keeps the
+        reference's recomputation (used as a cross-check in the tests)."""
         B = phoneme.size(0)
         self.eval()
         dev = phoneme.device
@@ -226,20 +233,56 @@ class TransformerTTS(nn.Module):
         ys = torch.zeros(B, max_len, self.n_mels, device=dev)     # ys[:, t] = frame fed at step t (frame 0 = go)
         stops = []
         n = 0
-        for t in range(1, max_len):
-            cur = ys[:, :t].contiguous()
-            tgt = self.pe(self.dec_prenet(cur))
-            lens_t = torch.full((B,), t, dtype=torch.int64, device=dev)
-            out, _ = self.decoder(tgt=tgt, memory=memory, tgt_is_causal=True, tgt_lens=lens_t,
-                                  memory_lens=phoneme_lens, need_alignments=False)
-            last = out[:, -1:, :].contiguous()
-            mel, stop = ops.HeadsFn.apply(last, self.linear1.linear.weight, self.linear1.linear.bias,
-                                          self.linear2.linear.weight, self.linear2.linear.bias)
-            ys[:, t] = mel[:, 0]
-            stops.append(stop)
-            n = t
-            if bool((torch.sigmoid(stop) >= stop_threshold).all()):
-                break
+        heads = (self.linear1.linear.weight, self.linear1.linear.bias, self.linear2.linear.weight, self.linear2.linear.bias)
+        if use_kv_cache:
+            d = memory.size(-1)
+            layers = list(self.decoder.layers)
+            H = layers[0].self_attn.num_heads
+            # encoder memory K/V per layer, once; self-attention K/V caches (B, max_len, 2d) filled one row per step
+            mem_kv = [ops.linear(memory, l.multihead_attn.in_proj_weight[d:], l.multihead_attn.in_proj_bias[d:]) for l in layers]
+            cache = [torch.zeros(B, max_len, 2 * d, device=dev) for _ in layers]
+            Tp = memory.size(1)
+            for t in range(1, max_len):
+                x = self.dec_prenet(ys[:, t - 1:t].contiguous())
+                x = ops.PosEncFn.apply(x, self.pe.pe[t - 1:t], self.pe.alpha, 0.0, 0)
+                lens_t = torch.full((B,), t, dtype=torch.int64, device=dev)
+                for l, kvc, mkv in zip(layers, cache, mem_kv):
+                    sa = l.self_attn
+                    qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)                    # (B,1,3d)
+                    kvc[:, t - 1] = qkv[:, 0, d:]
+                    ctx, _, _ = ops._attn_fwd(ops._off(qkv, 0), ops._off(kvc, 0), ops._off(kvc, d), 3 * d, 2 * d, 2 * d, B, H,
+                                              1, max_len, lens_t, False, 0.0, 0, False)
+                    x = ops.layer_norm(ops.linear(ctx, sa.out_proj.weight, sa.out_proj.bias, residual=x),
+                                       l.norm1.weight, l.norm1.bias, l.norm1.eps)
+                    ca = l.multihead_attn
+                    q = ops.linear(x, ca.in_proj_weight[:d], ca.in_proj_bias[:d])
+                    ctx, _, _ = ops._attn_fwd(ops._off(q, 0), ops._off(mkv, 0), ops._off(mkv, d), d, 2 * d, 2 * d, B, H, 1, Tp,
+                                              phoneme_lens, False, 0.0, 0, False)
+                    x = ops.layer_norm(ops.linear(ctx, ca.out_proj.weight, ca.out_proj.bias, residual=x),
+                                       l.norm2.weight, l.norm2.bias, l.norm2.eps)
+                    hdn = ops.linear(x, l.linear1.weight, l.linear1.bias, act=ops.ACT_RELU)
+                    x = ops.layer_norm(ops.linear(hdn, l.linear2.weight, l.linear2.bias, residual=x),
+                                       l.norm3.weight, l.norm3.bias, l.norm3.eps)
+                mel, stop = ops.HeadsFn.apply(x, *heads)
+                ys[:, t] = mel[:, 0]
+                stops.append(stop)
+                n = t
+                if bool((torch.sigmoid(stop) >= stop_threshold).all()):
+                    break
+        else:
+            for t in range(1, max_len):
+                cur = ys[:, :t].contiguous()
+                tgt = self.pe(self.dec_prenet(cur))
+                lens_t = torch.full((B,), t, dtype=torch.int64, device=dev)
+                out, _ = self.decoder(tgt=tgt, memory=memory, tgt_is_causal=True, tgt_lens=lens_t,
+                                      memory_lens=phoneme_lens, need_alignments=False)
+                last = out[:, -1:, :].contiguous()
+                mel, stop = ops.HeadsFn.apply(last, *heads)
+                ys[:, t] = mel[:, 0]
+                stops.append(stop)
+                n = t
+                if bool((torch.sigmoid(stop) >= stop_threshold).all()):
+                    break
         pred_melspec = ys[:, 1:n + 1].contiguous()
         post_melspec = ops.AddFn.apply(self.postnet(pred_melspec), pred_melspec)
         return {'pred_melspec': pred_melspec, 'post_melspec': post_melspec, 'pred_stop': torch.stack(stops, dim=1)}
