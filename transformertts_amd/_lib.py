@@ -9,6 +9,10 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
+import torch  # noqa: F401  -- MUST precede the dlopen below: PyTorch-ROCm ships its own libamdhip64; if ours pulled the
+#                system copy in first, the process would hold two HIP runtimes and every launch fails with
+#                "no ROCm-capable device is detected"
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTTS_LIB", os.path.join(_HERE, "libttts_hip.so"))   # TTTS_LIB: development A/B builds
 
