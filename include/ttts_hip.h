@@ -157,6 +157,16 @@ int ttts_relu_dropout_bwd(const float* dy, const float* out, float* dx, int64_t 
 int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, void* stream);
 /* z = x + y */
 int ttts_add(const float* x, const float* y, float* z, int64_t n, void* stream);
+/* ---- input side: device-side padding of a ragged batch --------------------------------------
+ * Replaces the host loop of collate_fn (dataset.py:76-91) and the per-sample transpose of __getitem__
+ * (dataset.py:64).  `ragged` holds the B utterances back to back, each in its on-disk (n_mels, len_b) row-major
+ * layout (preprocess.py:36-42); frame_offsets (B+1, int64, device) are prefix sums of the lengths in frames.
+ * out (B, Tmax, n_mels) fp32 is fully written (frames >= len_b are zero).  1 <= n_mels <= 128. */
+int ttts_collate_melspec(const float* ragged, const int64_t* frame_offsets, float* out, int B, int Tmax, int n_mels,
+                         void* stream);
+/* phoneme ids: ragged int64 ids back to back, offsets (B+1); out (B, Pmax) int64, padded with 0 (dataset.py:79,88) */
+int ttts_collate_phoneme(const int64_t* ragged, const int64_t* offsets, int64_t* out, int B, int Pmax, void* stream);
+
 /* stop-token head, LinearNorm(d_model, 1) (model/model.py:226,313): y[m] = x[m,:].w + b, and its backward */
 int ttts_rowdot_fwd(const float* x, const float* w, const float* b, float* y, int64_t M, int d, void* stream);
 size_t ttts_rowdot_bwd_workspace_bytes(int d);

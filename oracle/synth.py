@@ -35,3 +35,21 @@ def synth_batch(B: int, Tp: int = 100, Tm: int = 870, n_mels: int = 80, n_phon: 
     mel = mel * (torch.arange(Tm_).unsqueeze(0) < ml.unsqueeze(1)).unsqueeze(-1)
     return {"phoneme": ph.contiguous(), "melspec": mel.contiguous(),
             "phoneme_lens": pl.contiguous(), "melspec_lens": ml.contiguous()}
+
+
+def synth_samples(n: int, n_mels: int = 80, n_phon: int = 100, max_frames: int = 200, seed: int = 77):
+    """`n` utterances as the reference's preprocess step stores them (preprocess.py:36-42): `melspec` fp32
+    (n_mels, T), `sequence` int64 ids, `transcript` str.  Phoneme lengths repeat on purpose (ties in the sort of
+    dataset.py:65), one utterance is the longest in frames but not in phonemes."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        T = int(rng.integers(5, max_frames + 1))
+        P = int(rng.integers(3, 12)) if i % 3 else 7
+        if i == 1:
+            T = max_frames + 3
+        out.append({"melspec": rng.standard_normal((n_mels, T)).astype(np.float32),
+                    "sequence": rng.integers(1, n_phon, size=P).astype(np.int64),
+                    "transcript": f"utterance {i}"})
+    return out

@@ -236,10 +236,36 @@ def golden_helpers(name):
     print(name, "written")
 
 
+def golden_collate(name):
+    """The reference's own Dataset.__getitem__ + collate_fn on files written in preprocess.py's format."""
+    import tempfile
+    _install_stubs()
+    from oracle.synth import synth_samples
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import dataset as ref_dataset                      # the real reference
+    out = {}
+    for tag, (n, n_mels) in {"a": (7, 80), "b": (5, 16), "c": (1, 80)}.items():
+        samples = synth_samples(n, n_mels=n_mels, seed=77 + n)
+        with tempfile.TemporaryDirectory() as d:
+            for i, s in enumerate(samples):
+                np.savez(os.path.join(d, f"LJ0{10 + i}-0001.npz"), melspec=s["melspec"], transcript=s["transcript"],
+                         phoneme=np.array(["x"]), sequence=s["sequence"])
+            ds = ref_dataset.TransformerTTSDataset({"path": {"preprocessed": d}}, mode="train")
+            items = [ds[i] for i in range(len(ds))]
+        b = ref_dataset.collate_fn(items)
+        for k in ("phoneme", "melspec", "phoneme_lens", "melspec_lens"):
+            out[f"{tag}_{k}"] = _np(b[k])
+        out[f"{tag}_transcript"] = np.array(b["transcript"])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "written")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_helpers("helpers")
     golden_model("tiny_model", "tiny", B=3, Tp=12, Tm=40, w_seed=11, b_seed=21, align_stride=1)
     golden_model("base_model", "base", B=2, Tp=60, Tm=300, w_seed=12, b_seed=22, align_stride=8)
     golden_step("tiny_step", "tiny", B=3, Tp=12, Tm=40, w_seed=11, b_seed=21, epoch=120)
+    golden_collate("collate")
     golden_inference("tiny_inference", "tiny", B=3, Tp=12, w_seed=11, b_seed=21, max_len=14)

@@ -56,6 +56,8 @@ SIGNATURES = {
     "ttts_relu_dropout_bwd": (I, [P, P, P, L, F, P]),
     "ttts_dropout_bwd": (I, [P, P, L, F, U, P]),
     "ttts_add": (I, [P, P, P, L, P]),
+    "ttts_collate_melspec": (I, [P, P, P, I, I, I, P]),
+    "ttts_collate_phoneme": (I, [P, P, P, I, I, P]),
     "ttts_loss_workspace_bytes": (Z, []),
     "ttts_loss_fwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, F, P]),
     "ttts_loss_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, F, P]),
