@@ -60,7 +60,8 @@ int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db
 /* ---- split-precision ("bf16x6") forms of the forward / data-gradient GEMMs.  Same arithmetic contract (fp32 in,
  * fp32 out, fp32 accumulate) with every product formed as six bf16 x bf16 MFMA terms of a 3-way hi/mid/lo split:
  * measured error vs fp64 1.1e-7 (a plain fp32 fma chain: 2.9e-7) at 6/16 of the fp32 MFMA cycles.
- * The weight operand is split once per call into planes[3][rows][cols] bf16 by ttts_weight_split:
+ * The weight operand is split once per call by ttts_weight_split into three bf16 planes (hi, mid, lo) of a rows x cols
+ * matrix, stored k-tile-major as [cols/16][plane][rows][16] (cols must be a multiple of 16):
  *   mode 0  linear forward     planes of w (N,K)               rows = N,    cols = K
  *   mode 1  linear data-grad   planes of w^T                   rows = K,    cols = N
  *   mode 2  conv forward       [co][tap*cin + ci]              rows = cout, cols = taps*cin,  channels_per_tap = cin
@@ -78,6 +79,12 @@ int ttts_conv1d_fwd_x6(const float* x, const void* planes_fwd, const float* bias
                        int taps, void* stream);
 int ttts_conv1d_bwd_data_x6(const float* dy, const void* planes_bwd, float* dx, int B, int T, int cin, int cout, int taps,
                             void* stream);
+/* Weight gradients in the same split-precision form (both operands are activations, split while they are staged);
+ * arguments, workspace (ttts_wgrad_workspace_bytes) and results as ttts_linear_bwd_weight / ttts_conv1d_bwd_weight. */
+int ttts_linear_bwd_weight_x6(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
+                              int64_t M, int N, int K, int row_shift, int T, int accumulate, void* stream);
+int ttts_conv1d_bwd_weight_x6(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
+                              int T, int cin, int cout, int taps, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ Conv1d (k taps, same padding) on (B,T,C)
  * Replaces ConvNormBN's permute -> nn.Conv1d(pad=(k-1)//2) -> permute (model/module.py:28-33) as an

@@ -24,6 +24,9 @@ namespace ttts {
 #ifndef TTTS_GEMM_BK
 #define TTTS_GEMM_BK 16
 #endif
+#ifndef TTTS_X6_XCD
+#define TTTS_X6_XCD 1
+#endif
 #ifndef TTTS_GEMM_MINWAVES
 #define TTTS_GEMM_MINWAVES 3
 #endif
@@ -424,31 +427,32 @@ static int dispatch_gemm(const GemmArgs& g, int zdim, int tile, hipStream_t stre
 // terms are O(2^-24) relative: measured error of a K = 256..1024 GEMM against fp64 is 1.1e-7, BELOW the 2.9e-7 of
 // a plain fp32 fma chain, at 6/16 of the fp32-MFMA cycle count.
 // Activations (A) are split on the fly while they are staged into LDS; weights (B) are split once per call by
-// weight_split_kernel into three [N][K] bf16 planes, so the B loader moves bytes only.
+// weight_split_kernel into bf16 planes laid k-tile-major ([K/16][plane][N][16]), so the B loader moves whole lines.
 // LDS image per operand plane: [row][16 k] bf16 = 32-byte rows; the two 16-byte chunks of a row are swapped on rows
 // with bit 3 set (chunk ^= (row >> 3) & 1), which makes the ds_read_b128 of the MFMA fragments conflict-free.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void split3_pack4(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    unsigned short h[4], m[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        __bf16 b1 = (__bf16)x[i];
-        float r1 = x[i] - (float)b1;
-        __bf16 b2 = (__bf16)r1;
-        float r2 = r1 - (float)b2;
-        __bf16 b3 = (__bf16)r2;
-        h[i] = __builtin_bit_cast(unsigned short, b1);
-        m[i] = __builtin_bit_cast(unsigned short, b2);
-        l[i] = __builtin_bit_cast(unsigned short, b3);
-    }
-    hi = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-    mid = make_uint2((uint32_t)m[0] | ((uint32_t)m[1] << 16), (uint32_t)m[2] | ((uint32_t)m[3] << 16));
-    lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 -> (hi, mid, lo) bf16 pairs, each packed in one dword (element 0 in the low half).  Written on vector
+// types so that the compiler emits v_cvt_pk_bf16_f32 / v_pk_add_f32: 9 VALU operations per pair.
+__device__ __forceinline__ void split3_pair(f32x2 x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+    f32x2 f = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    const f32x2 r1 = x - f;
+    mid = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+    f = f32x2{__uint_as_float(mid << 16), __uint_as_float(mid & 0xffff0000u)};
+    const f32x2 r2 = r1 - f;
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
 }
 
-// planes[p][r][c] (p = hi, mid, lo; R rows of C bf16) from a weight tensor:
+__device__ __forceinline__ void split3_pack4(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
+    split3_pair(f32x2{v.x, v.y}, hi.x, mid.x, lo.x);
+    split3_pair(f32x2{v.z, v.w}, hi.y, mid.y, lo.y);
+}
+
+// B[r][c] (R rows of C bf16 per plane p = hi, mid, lo; stored as [c/16][p][r][c%16]) from a weight tensor:
 //   mode 0: linear forward      B[r][c] = w[r*C + c]                      (w is (R, C))
 //   mode 1: linear data-grad    B[r][c] = w[c*R + r]                      (w is (C, R); B = w^T)
 //   mode 2: conv forward        B[co][tap*cin + ci] = w[(co*cin + ci)*taps + tap]       (R = cout, C = taps*cin)
@@ -472,9 +476,13 @@ __global__ __launch_bounds__(256) void weight_split_kernel(const float* __restri
     __bf16 b2 = (__bf16)r1;
     float r2 = r1 - (float)b2;
     __bf16 b3 = (__bf16)r2;
-    planes[i] = __builtin_bit_cast(unsigned short, b1);
-    planes[n + i] = __builtin_bit_cast(unsigned short, b2);
-    planes[2 * n + i] = __builtin_bit_cast(unsigned short, b3);
+    // k-tile-major image: [c / 16][plane][r][c % 16], so the BN x 16 block a workgroup stages per k-step and plane is
+    // one contiguous run (whole 128-byte lines; a [r][c] image gave 32-byte row pieces and 4x the L2->L1 traffic)
+    const long o = ((long)(c >> 4) * 3 * R + r) * 16 + (c & 15);
+    const long ps = (long)R * 16;
+    planes[o] = __builtin_bit_cast(unsigned short, b1);
+    planes[o + ps] = __builtin_bit_cast(unsigned short, b2);
+    planes[o + 2 * ps] = __builtin_bit_cast(unsigned short, b3);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -493,12 +501,27 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+#if TTTS_X6_XCD
+    // Workgroups are dispatched x-fastest and dealt round-robin to the 8 XCDs, each with its own L2.  Renumber so
+    // that XCD e works on one contiguous run of tiles (column blocks of a row panel first): the nx workgroups that
+    // read the same A rows then share an L2 (1 miss + nx-1 hits instead of nx fetches from the Infinity Cache / HBM,
+    // whose per-CU rate -- 10-14 B/clk -- is what bounds this kernel otherwise).
+    const int nx = gridDim.x;
+    const int ntiles = nx * gridDim.y;
+    const int bid = blockIdx.y * nx + blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int per = ntiles >> 3, rem = ntiles & 7;
+    const int t = xcd * per + min(xcd, rem) + slot;
+    const int ty = t / nx, tx = t - ty * nx;
+    const int m0 = ty * BM, n0 = tx * BN;
+#else
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+#endif
     const int nkt = g.K / BK;
 
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
-    const uint32_t b_plane_bytes = (uint32_t)((long)g.N * g.ldb * 2);
+    const uint32_t b_plane_bytes = (uint32_t)g.N * 32u;           // one plane of one k-tile: N rows of 16 bf16
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -524,9 +547,9 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
     // B: thread -> (row = tid>>1, half-chunk = tid&1): 8 bf16 = 16 bytes per plane
     const int b_row = tid >> 1, b_hc = tid & 1;
     const uint32_t b_off = ((B_ALL || b_row < BN) && (n0 + b_row) < g.N)
-                               ? (uint32_t)(((long)(n0 + b_row) * g.ldb + b_hc * 8) * 2) : OOB;
+                               ? (uint32_t)((n0 + b_row) * 32 + b_hc * 16) : OOB;
 
-    auto load_tiles = [&](int kt) {
+    auto load_a = [&](int kt) {
         const int k0 = kt * BK;
         const int tap = k0 / g.cin;
         const int c0 = k0 - tap * g.cin;
@@ -538,28 +561,29 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
             if (g.T > 0) ok = ok && ((unsigned)(a_t[i] + shift) < (unsigned)g.T);
             ra[i] = buf_load4(rsrcA, ok ? a_off[i] + koff : OOB);
         }
-        const uint32_t kb = (uint32_t)(k0 * 2);
+    };
+    auto load_b = [&](int kt) {
+        const uint32_t kb = (uint32_t)kt * 3u * b_plane_bytes;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             rb[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)(b_off != OOB ? b_off + kb + p * b_plane_bytes : OOB), 0, 0);
     };
 
-    auto store_tiles = [&](int buf) {
+    auto store_a = [&](int buf, int i) {
         uint32_t* as = lds + buf * STAGE;
-        uint32_t* bs = as + 3 * A_PLANE;
-#pragma unroll
-        for (int i = 0; i < NLA; ++i) {
-            int idx = tid + i * 256;
-            int row = idx >> 2, ch = idx & 3;
-            if (row < BM) {
-                uint2 hi, mid, lo;
-                split3_pack4(ra[i], hi, mid, lo);
-                const int d = row * 8 + (((ch >> 1) ^ ((row >> 3) & 1)) * 4) + (ch & 1) * 2;
-                *reinterpret_cast<uint2*>(as + d) = hi;
-                *reinterpret_cast<uint2*>(as + A_PLANE + d) = mid;
-                *reinterpret_cast<uint2*>(as + 2 * A_PLANE + d) = lo;
-            }
+        int idx = tid + i * 256;
+        int row = idx >> 2, ch = idx & 3;
+        if ((BM * 4) % 256 == 0 || row < BM) {
+            uint2 hi, mid, lo;
+            split3_pack4(ra[i], hi, mid, lo);
+            const int d = row * 8 + (((ch >> 1) ^ ((row >> 3) & 1)) * 4) + (ch & 1) * 2;
+            *reinterpret_cast<uint2*>(as + d) = hi;
+            *reinterpret_cast<uint2*>(as + A_PLANE + d) = mid;
+            *reinterpret_cast<uint2*>(as + 2 * A_PLANE + d) = lo;
         }
+    };
+    auto store_b = [&](int buf) {
+        uint32_t* bs = lds + buf * STAGE + 3 * A_PLANE;
         if (B_ALL || b_row < BN) {
             const int d = b_row * 8 + ((b_hc ^ ((b_row >> 3) & 1)) * 4);
 #pragma unroll
@@ -595,15 +619,23 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
                 acc[i][j] = c;
             }
     };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) store_a(buf, i);
+        store_b(buf);
+    };
 
+    // Tried and dropped: fetching activations two k-steps ahead into a second register set and splitting / writing them
+    // between the MFMAs.  It needs 206 VGPRs (2 waves per SIMD: 4 % slower than this loop at 3; capped at 168 it spills).
     if (nkt > 0) {
-        load_tiles(0);
+        load_a(0);
+        load_b(0);
         store_tiles(0);
         __syncthreads();
         int buf = 0;
         for (int kt = 0; kt < nkt; ++kt) {
             const bool more = (kt + 1) < nkt;
-            if (more) load_tiles(kt + 1);
+            if (more) { load_a(kt + 1); load_b(kt + 1); }
             compute(buf);
             if (more) store_tiles(buf ^ 1);
             __syncthreads();
@@ -667,6 +699,208 @@ static int dispatch_split(const GemmArgs& g, hipStream_t stream) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients in the split-precision form: C[n][k] (per tap, per row split) = sum_m dy[m][n] * x[m + shift][k].
+// Both operands are activations whose REDUCTION index (the row m) is the slow one in memory, so the MFMA fragments
+// (8 consecutive reduction indices per lane) are columns of the stored matrices.  The loader turns them: a thread
+// fetches 8 consecutive rows of ONE column with 8 dword loads (a wave covers 64 adjacent columns: 256-byte runs),
+// splits the 8 values into hi / mid / lo and writes three 16-byte pieces -- exactly the [row = column][16 k] LDS
+// image of the kernel above, so fragments, MFMA order and bank behaviour are shared with it.
+// Same GemmArgs meaning as gemm_f32_kernel<.., false, false>: A = dy (K x M), B = x (K x N), K = rows, z = split * ztaps
+// + tap, colsum = per-split column sums of dy (bias gradient).
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void wgrad_bf16x6_kernel(GemmArgs g) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(WM * WN == 4 && BK == 16 && BM <= 128 && BN <= 128, "4 waves, 16 rows per step, <= 128 columns per operand");
+    constexpr int A_PLANE = BM * 8, B_PLANE = BN * 8;          // dwords per plane (32-byte rows)
+    constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+    const int ztap = (g.ztaps > 1) ? (z % g.ztaps) : 0;
+    const int zsplit = (g.ztaps > 1) ? (z / g.ztaps) : z;
+    const int nkt = (g.K + BK - 1) / BK;
+    const int kt_begin = zsplit * g.kt_per_split;
+    int kt_end = kt_begin + g.kt_per_split;
+    if (kt_end > nkt) kt_end = nkt;
+    const int shift = g.shift0 + ztap * g.shift_step;
+
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // loader roles: thread -> (column, which 8 of the 16 rows).  2*BM (2*BN) threads take part.
+    //               When both operands fit side by side (64x64 tile) A and B slots go to different waves.
+    constexpr int B_T0 = (2 * BM + 2 * BN <= 256) ? 2 * BM : 0;
+    const int tb = tid - B_T0;
+    const bool a_slot = tid < 2 * BM, b_slot = tb >= 0 && tb < 2 * BN;
+    const int a_col = tid % BM, a_rh = (tid / BM) & 1;
+    const int b_col = (tb & 0xffff) % BN, b_rh = ((tb & 0xffff) / BN) & 1;
+    const bool a_on = a_slot && (m0 + a_col) < g.M;
+    const bool b_on = b_slot && (n0 + b_col) < g.N;
+    const uint32_t a_base = a_on ? (uint32_t)(((long)(a_rh * 8) * g.lda + m0 + a_col) * 4) : OOB;
+    const uint32_t b_base = b_on ? (uint32_t)(((long)(b_rh * 8 + shift) * g.ldb + n0 + b_col) * 4) : OOB;
+    const uint32_t a_row = (uint32_t)(g.lda * 4), b_row = (uint32_t)(g.ldb * 4);
+    // position of this thread's first B row inside its utterance (clipping of shifted rows), kept incrementally
+    int b_t = (g.T > 0) ? (int)(((long)kt_begin * BK + b_rh * 8) % g.T) : 0;
+
+    float av[8], bv[8];
+    float csum = 0.f;   // bias gradient: running sum of this thread's dy values
+
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK;
+        const uint32_t ka = (uint32_t)k0 * a_row, kb = (uint32_t)k0 * b_row;
+        const int ra0 = k0 + a_rh * 8, rb0 = k0 + b_rh * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = a_on && (ra0 + j) < g.K;
+            av[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcA, (int)(ok ? a_base + ka + j * a_row : OOB), 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bool ok = b_on && (rb0 + j) < g.K;
+            if (g.T > 0) {
+                int t = b_t + j;
+                if (g.T >= BK) { if (t >= g.T) t -= g.T; } else t %= g.T;
+                ok = ok && ((unsigned)(t + shift) < (unsigned)g.T);
+            }
+            bv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcB, (int)(ok ? b_base + kb + j * b_row : OOB), 0, 0));
+        }
+        if (g.T > 0) {   // utterances shorter than a k-step wrap more than once
+            b_t += BK;
+            if (g.T >= BK) { if (b_t >= g.T) b_t -= g.T; } else b_t %= g.T;
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        uint32_t* as = lds + buf * STAGE;
+        uint32_t* bs = as + 3 * A_PLANE;
+        if (a_slot) {
+            u32x4 hi, mid, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t h, m, l;
+                split3_pair(f32x2{av[2 * q], av[2 * q + 1]}, h, m, l);
+                hi[q] = h; mid[q] = m; lo[q] = l;
+            }
+            csum += ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
+            const int d = a_col * 8 + ((a_rh ^ ((a_col >> 3) & 1)) * 4);
+            *reinterpret_cast<u32x4*>(as + d) = hi;
+            *reinterpret_cast<u32x4*>(as + A_PLANE + d) = mid;
+            *reinterpret_cast<u32x4*>(as + 2 * A_PLANE + d) = lo;
+        }
+        if (b_slot) {
+            u32x4 hi, mid, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t h, m, l;
+                split3_pair(f32x2{bv[2 * q], bv[2 * q + 1]}, h, m, l);
+                hi[q] = h; mid[q] = m; lo[q] = l;
+            }
+            const int d = b_col * 8 + ((b_rh ^ ((b_col >> 3) & 1)) * 4);
+            *reinterpret_cast<u32x4*>(bs + d) = hi;
+            *reinterpret_cast<u32x4*>(bs + B_PLANE + d) = mid;
+            *reinterpret_cast<u32x4*>(bs + 2 * B_PLANE + d) = lo;
+        }
+    };
+
+    auto compute = [&](int buf) {
+        const uint32_t* as = lds + buf * STAGE;
+        const uint32_t* bs = as + 3 * A_PLANE;
+        const int cw = ((half ^ ((l31 >> 3) & 1)) * 4);
+        bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[p][i] = *reinterpret_cast<const bf16x8*>(as + p * A_PLANE + (wm * WTM + i * 32 + l31) * 8 + cw);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[p][j] = *reinterpret_cast<const bf16x8*>(bs + p * B_PLANE + (wn * WTN + j * 32 + l31) * 8 + cw);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+    };
+
+    if (kt_begin < kt_end) {
+        load_tiles(kt_begin);
+        store_tiles(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const bool more = (kt + 1) < kt_end;
+            if (more) load_tiles(kt + 1);
+            compute(buf);
+            if (more) store_tiles(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    if (g.colsum != nullptr && blockIdx.x == 0 && ztap == 0) {
+        float* fs = reinterpret_cast<float*>(lds);
+        __syncthreads();
+        if (a_slot) fs[a_rh * BM + a_col] = csum;
+        __syncthreads();
+        if (tid < BM && m0 + tid < g.M) g.colsum[(long)zsplit * g.M + m0 + tid] = fs[tid] + fs[BM + tid];
+    }
+
+    float* C = g.C + (long)z * g.c_zstride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WTN + j * 32 + l31;
+            const int row0 = m0 + wm * WTM + i * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + acc_row(r, half);
+                if (row < g.M && col < g.N) C[(long)row * g.ldc + col] = acc[i][j][r];
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_wgrad_split(const GemmArgs& g, int zdim, hipStream_t stream) {
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), zdim);
+    hipLaunchKernelGGL((wgrad_bf16x6_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, stream, g);
+    TTTS_LAUNCH_CHECK("wgrad_bf16x6_kernel");
+    return TTTS_OK;
+}
+
+static int dispatch_wgrad_split(const GemmArgs& g, int zdim, int tile, hipStream_t stream) {
+    switch (tile) {
+        case TILE_64: return launch_wgrad_split<64, 64, 2, 2>(g, zdim, stream);
+        case TILE_128x96: return launch_wgrad_split<128, 96, 4, 1>(g, zdim, stream);
+        default: return launch_wgrad_split<128, 128, 2, 2>(g, zdim, stream);
+    }
+}
+
 static GemmArgs base_args() {
     GemmArgs g;
     g.A = g.B = nullptr; g.C = nullptr;
@@ -682,14 +916,21 @@ static int aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // how the row (reduction) dimension of a weight gradient is split: about 768 workgroups (3 per CU) in flight
 struct WgradPlan { int tile; int nsplit; int kt_per_split; };
-static WgradPlan plan_wgrad(int64_t M, int N, int K, int taps) {
+static WgradPlan plan_wgrad(int64_t M, int N, int K, int taps, bool x6 = false) {
     WgradPlan p;
     long tiles = (long)cdiv(N, 128) * cdiv(K, 128) * taps;
     p.tile = (K <= 96) ? TILE_128x96 : TILE_128;
-    if (tiles < 16) { p.tile = TILE_64; tiles = (long)cdiv(N, 64) * cdiv(K, 64) * taps; }
     long nkt = (M + BK - 1) / BK;
+    if (x6) {
+        // the split-precision kernel wants the large tile (its per-thread staging work is fixed per k-step); small
+        // outputs get more row splits instead, capped so that the partial sums stay a few tens of MB
+        if (N <= 64 && K <= 64) { p.tile = TILE_64; tiles = (long)cdiv(N, 64) * cdiv(K, 64) * taps; }
+    } else if (tiles < 16) {
+        p.tile = TILE_64; tiles = (long)cdiv(N, 64) * cdiv(K, 64) * taps;
+    }
     long want = 768 / tiles;
     if (want < 1) want = 1;
+    if (x6 && want > 128) want = 128;
     if (want > nkt) want = nkt;
     long per = (nkt + want - 1) / want;
     if (per < 8 && nkt >= 8) per = 8;
@@ -697,6 +938,9 @@ static WgradPlan plan_wgrad(int64_t M, int N, int K, int taps) {
     p.nsplit = (int)((nkt + per - 1) / per);
     return p;
 }
+
+// the split-precision weight-gradient kernel pays off when both output dimensions fill its 128-wide tiles
+static bool wgrad_use_x6(int N, int K) { return N >= 128 && K >= 128; }
 
 }  // namespace ttts
 
@@ -742,13 +986,15 @@ int ttts_linear_bwd_data(const float* dy, const float* w, const float* residual,
 }
 
 size_t ttts_wgrad_workspace_bytes(int64_t M, int N, int K, int taps) {
-    WgradPlan p = plan_wgrad(M, N, K, taps);
-    return ((size_t)p.nsplit * taps * N * K + (size_t)p.nsplit * N) * sizeof(float);
+    // covers both kernel forms (their row-split counts differ)
+    WgradPlan p = plan_wgrad(M, N, K, taps, false), q = plan_wgrad(M, N, K, taps, true);
+    size_t ns = (size_t)(p.nsplit > q.nsplit ? p.nsplit : q.nsplit);
+    return (ns * taps * N * K + ns * N) * sizeof(float);
 }
 
 static int wgrad_common(const float* dy, const float* x, float* ws, float* colsum_ws, int64_t M, int N, int K, int taps,
-                        int T, int shift0, int shift_step, WgradPlan* plan_out, hipStream_t stream) {
-    WgradPlan p = plan_wgrad(M, N, K, taps);
+                        int T, int shift0, int shift_step, WgradPlan* plan_out, bool x6, hipStream_t stream) {
+    WgradPlan p = plan_wgrad(M, N, K, taps, x6);
     GemmArgs g = base_args();
     // C[N][K] (per tap) = dy^T[N][M] . xshift[M][K]
     g.A = dy; g.B = x; g.C = ws; g.M = N; g.N = K; g.K = (int)M;
@@ -762,11 +1008,12 @@ static int wgrad_common(const float* dy, const float* x, float* ws, float* colsu
     g.kt_per_split = p.kt_per_split; g.c_zstride = (long)N * K;
     g.colsum = colsum_ws;
     *plan_out = p;
+    if (x6) return dispatch_wgrad_split(g, p.nsplit * taps, p.tile, stream);
     return dispatch_gemm<false, false>(g, p.nsplit * taps, p.tile, stream);
 }
 
-int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
-                           int64_t M, int N, int K, int row_shift, int T, int accumulate, void* stream_) {
+static int linear_bwd_weight_impl(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
+                                  int64_t M, int N, int K, int row_shift, int T, int accumulate, bool x6, void* stream_) {
     // dw[N,K] (+)= dy[M,N]^T . x[M,K] ; dbias[N] (+)= column sums of dy
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && x && dw && ws, "linear_bwd_weight: null pointer");
@@ -777,13 +1024,23 @@ int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db
     TTTS_REQUIRE(row_shift == 0 || (T > 0 && M % T == 0), "linear_bwd_weight: row_shift needs T>0 and M %% T == 0");
     WgradPlan p;
     long n = (long)N * K;
-    float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, N, K, 1).nsplit * n : nullptr;
-    int rc = wgrad_common(dy, x, ws, colsum_ws, M, N, K, 1, row_shift != 0 ? T : 0, row_shift, 0, &p, stream);
+    x6 = x6 && wgrad_use_x6(N, K);
+    float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, N, K, 1, x6).nsplit * n : nullptr;
+    int rc = wgrad_common(dy, x, ws, colsum_ws, M, N, K, 1, row_shift != 0 ? T : 0, row_shift, 0, &p, x6, stream);
     if (rc) return rc;
     rc = launch_reduce_rows(ws, n, p.nsplit, n, dw, n, nullptr, accumulate, stream);
     if (rc) return rc;
     if (dbias) rc = launch_reduce_rows(colsum_ws, N, p.nsplit, N, dbias, N, nullptr, accumulate, stream);
     return rc;
+}
+
+int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
+                           int64_t M, int N, int K, int row_shift, int T, int accumulate, void* stream) {
+    return linear_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, M, N, K, row_shift, T, accumulate, false, stream);
+}
+int ttts_linear_bwd_weight_x6(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
+                              int64_t M, int N, int K, int row_shift, int T, int accumulate, void* stream) {
+    return linear_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, M, N, K, row_shift, T, accumulate, true, stream);
 }
 
 size_t ttts_conv1d_pack_bytes(int cout, int cin, int taps) { return (size_t)cout * cin * taps * sizeof(float); }
@@ -831,8 +1088,8 @@ int ttts_conv1d_bwd_data(const float* dy, const float* w_bwd, float* dx, int B, 
     return dispatch_gemm<true, true>(g, 1, TILE_AUTO, (hipStream_t)stream);
 }
 
-int ttts_conv1d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
-                           int T, int cin, int cout, int taps, int accumulate, void* stream_) {
+static int conv1d_bwd_weight_impl(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
+                                  int T, int cin, int cout, int taps, int accumulate, bool x6, void* stream_) {
     // dw[co,ci,tap] (+)= sum_{b,t} dy[b,t,co] * x[b,t+tap-pad,ci] ; dbias[co] (+)= sum dy
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && x && dw && ws, "conv1d_bwd_weight: null pointer");
@@ -842,14 +1099,24 @@ int ttts_conv1d_bwd_weight(const float* dy, const float* x, float* dw, float* db
     TTTS_REQUIRE(ws_bytes >= ttts_wgrad_workspace_bytes(M, cout, cin, taps), "conv1d_bwd_weight: workspace too small");
     WgradPlan p;
     long n = (long)cout * cin * taps;
-    float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, cout, cin, taps).nsplit * n : nullptr;
-    int rc = wgrad_common(dy, x, ws, colsum_ws, M, cout, cin, taps, T, -((taps - 1) / 2), 1, &p, stream);
+    x6 = x6 && wgrad_use_x6(cout, cin);
+    float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, cout, cin, taps, x6).nsplit * n : nullptr;
+    int rc = wgrad_common(dy, x, ws, colsum_ws, M, cout, cin, taps, T, -((taps - 1) / 2), 1, &p, x6, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, ws, dw, cout, cin, taps,
                        p.nsplit, accumulate);
     TTTS_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
     if (dbias) rc = launch_reduce_rows(colsum_ws, cout, p.nsplit, cout, dbias, cout, nullptr, accumulate, stream);
     return rc;
+}
+
+int ttts_conv1d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
+                           int T, int cin, int cout, int taps, int accumulate, void* stream) {
+    return conv1d_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, B, T, cin, cout, taps, accumulate, false, stream);
+}
+int ttts_conv1d_bwd_weight_x6(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
+                              int T, int cin, int cout, int taps, int accumulate, void* stream) {
+    return conv1d_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, B, T, cin, cout, taps, accumulate, true, stream);
 }
 
 int ttts_gemm_tile_choice(int64_t M, int N, int x6) {
@@ -866,6 +1133,7 @@ int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode
     // planes[3][rows][cols] bf16 (hi, mid, lo) of a weight re-laid as the K-contiguous B operand; modes in gemm.hip
     TTTS_REQUIRE(w && planes && rows > 0 && cols > 0, "weight_split: bad arguments");
     TTTS_REQUIRE(mode >= 0 && mode <= 3, "weight_split: mode must be 0..3");
+    TTTS_REQUIRE(cols % BK == 0, "weight_split: cols=%d must be a multiple of %d", cols, BK);
     TTTS_REQUIRE(mode < 2 || (channels_per_tap > 0 && taps > 0 && cols == channels_per_tap * taps),
                  "weight_split: conv modes need cols == channels_per_tap * taps");
     long n = (long)rows * cols;

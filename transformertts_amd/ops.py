@@ -68,6 +68,11 @@ seeds = _SeedStream()
 # (3-way bf16 split, six MFMA terms, fp32 accumulate; error 1.1e-7 vs 2.9e-7 for the plain fp32 MFMA chain),
 # "f32" = the plain v_mfma_f32_32x32x2_f32 kernel.  Weight gradients always use the fp32 kernel.
 GEMM_MODE = os.environ.get("TTTS_GEMM_MODE", "x6")
+WGRAD_MODE = os.environ.get("TTTS_WGRAD_MODE", GEMM_MODE)    # weight gradients: "x6" (split-precision MFMA) or "f32"
+
+
+def _wgrad_fn(lib, name: str):
+    return getattr(lib, name + "_x6") if WGRAD_MODE == "x6" else getattr(lib, name)
 
 
 _param_epoch = 0
@@ -187,8 +192,9 @@ class LinearFn(torch.autograd.Function):
             else:
                 dw_t = dw = torch.empty_like(w)
                 db_t = db = torch.empty(N, dtype=torch.float32, device=x.device) if has_b else None
-            _lib.check(lib.ttts_linear_bwd_weight(_p(dacc), _p(x), _p(dw_t), _p(db_t), _p(ws), ws.numel() * 4, M, N, K,
-                                                  row_shift, T, acc, _stream()), "ttts_linear_bwd_weight")
+            _lib.check(_wgrad_fn(lib, "ttts_linear_bwd_weight")(_p(dacc), _p(x), _p(dw_t), _p(db_t), _p(ws), ws.numel() * 4,
+                                                                 M, N, K, row_shift, T, acc, _stream()),
+                       "ttts_linear_bwd_weight")
         return dx, dw, db, (dy if has_r else None), None, None, None, None, None
 
 
@@ -246,8 +252,8 @@ class HeadsFn(torch.autograd.Function):
             t_bm = db_mel = torch.empty(N, dtype=torch.float32, device=x.device)
             t_ws = dw_stop = torch.empty_like(w_stop)
             t_bs = db_stop = torch.empty(1, dtype=torch.float32, device=x.device)
-        _lib.check(lib.ttts_linear_bwd_weight(_p(dmel), _p(x), _p(t_wm), _p(t_bm), _p(ws), ws.numel() * 4, M, N, K, 0,
-                                              0, acc, _stream()), "ttts_linear_bwd_weight")
+        _lib.check(_wgrad_fn(lib, "ttts_linear_bwd_weight")(_p(dmel), _p(x), _p(t_wm), _p(t_bm), _p(ws), ws.numel() * 4, M, N,
+                                                             K, 0, 0, acc, _stream()), "ttts_linear_bwd_weight")
         ws2 = _ws(lib.ttts_rowdot_bwd_workspace_bytes(K), x.device)
         _lib.check(lib.ttts_rowdot_bwd(_p(dstop), _p(x), _p(w_stop), _p(dx), _p(t_ws), _p(t_bs), _p(ws2),
                                        ws2.numel() * 4, M, K, acc, _stream()), "ttts_rowdot_bwd")
@@ -336,8 +342,8 @@ class ConvBNFn(torch.autograd.Function):
                 _lib.check(lib.ttts_conv1d_bwd_data(_p(dy), _p(w_bwd), _p(dx), B, T, cin, cout, taps, _stream()),
                            "ttts_conv1d_bwd_data")
         ws2 = _ws(lib.ttts_wgrad_workspace_bytes(M, cout, cin, taps), dev)
-        _lib.check(lib.ttts_conv1d_bwd_weight(_p(dy), _p(x), _p(t_w), _p(t_b), _p(ws2), ws2.numel() * 4, B, T, cin, cout,
-                                              taps, acc, _stream()), "ttts_conv1d_bwd_weight")
+        _lib.check(_wgrad_fn(lib, "ttts_conv1d_bwd_weight")(_p(dy), _p(x), _p(t_w), _p(t_b), _p(ws2), ws2.numel() * 4, B, T,
+                                                             cin, cout, taps, acc, _stream()), "ttts_conv1d_bwd_weight")
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
