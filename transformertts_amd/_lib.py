@@ -49,6 +49,7 @@ SIGNATURES = {
     "ttts_layernorm_bwd_workspace_bytes": (Z, [I]),
     "ttts_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P]),
     "ttts_attention_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P]),
+    "ttts_attention_fwd_x6": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P]),
     "ttts_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P]),
     "ttts_embedding_fwd": (I, [P, P, P, L, I, I, P]),
     "ttts_embedding_bwd": (I, [P, P, P, L, I, I, I, P]),

@@ -31,6 +31,7 @@ constexpr int HD = 64;            // head dim
 constexpr int KT_LD = HD + 1;     // LDS row stride (odd: conflict-free "row per lane" reads)
 constexpr int QB = 128;           // rows per workgroup (4 waves x 32)
 constexpr float NEG_INF = -__builtin_inff();
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
 struct AttnArgs {
     const float* q; const float* k; const float* v;
@@ -510,6 +511,305 @@ __global__ __launch_bounds__(256, TTTS_DKV_W) void attn_bwd_dkv_kernel(AttnArgs 
     wave_store_rows(dv, scratch, a.dv + (long)b * a.Tk * a.lddv + h * HD, kw0, a.Tk, a.lddv, lane, 1.f);
 }
 
+// =====================================================================================================================
+// Split-precision forms ("bf16x6", see gemm.hip): the same algorithm with every product formed on
+// v_mfma_f32_32x32x16_bf16 from hi/mid/lo bf16 splits of the fp32 operands (six products, fp32-grade accuracy at 6/16 of
+// the fp32-MFMA cycles).  What changes is data movement:
+//  * K is split while it is staged: three 64 x 64 bf16 planes, 128-byte rows, 16-byte chunks XOR-swizzled with
+//    (row >> 1) & 7 so that the fragment reads (ds_read_b128, 16 lanes per clock) are conflict-free.
+//  * V is staged TRANSPOSED ([d][key]) because it is the A operand of O^T += V^T P^T and its contraction index (key)
+//    must be the fast one.  The probabilities come out of the S^T accumulator with a lane holding keys
+//    4*half + (r & 3) + 8*(r >> 2); a 16-deep MFMA step takes registers 8t..8t+7, i.e. keys 16t + {0..3, 8..11} + 4*half.
+//    The contraction order is free, so V^T is stored in exactly that key order and P needs no cross-lane movement.
+//  * Q (B operand, per lane its query's 64 values) is split once into registers.
+constexpr int XP = 64 * 32;     // dwords per 64 x 64 bf16 plane
+__device__ __forceinline__ int xsw(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+// 64 rows x 64 floats (row-major, d fast) -> planes[3][64][64]; rows beyond nrows_total are zero
+__device__ __forceinline__ void stage_split_rows(const float* base, long row0, long nrows_total, int ld, int tid,
+                                                 uint32_t* dst) {
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 4) + 16 * i, c4 = tid & 15;
+        const long gr = row0 + row;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < nrows_total) v[i] = *reinterpret_cast<const float4*>(base + gr * ld + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 4) + 16 * i, c4 = tid & 15;
+        uint2 hi, mid, lo;
+        split3_pack4(v[i], hi, mid, lo);
+        const int d = xsw(row, c4 >> 1) + (c4 & 1) * 2;
+        *reinterpret_cast<uint2*>(dst + d) = hi;
+        *reinterpret_cast<uint2*>(dst + XP + d) = mid;
+        *reinterpret_cast<uint2*>(dst + 2 * XP + d) = lo;
+    }
+}
+// 64 rows (keys) x 64 floats -> TRANSPOSED planes[3][64 d][64 key positions], key order as described above
+__device__ __forceinline__ void stage_split_cols(const float* base, long row0, long nrows_total, int ld, int tid,
+                                                 uint32_t* dst) {
+    const int dq = tid & 15, kq = tid >> 4;
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long gr = row0 + 4 * kq + i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < nrows_total) v[i] = *reinterpret_cast<const float4*>(base + gr * ld + dq * 4);
+    }
+    // keys 4kq..4kq+3 sit at positions pos..pos+3 of their row
+    const int pos = (kq >> 3) * 32 + ((kq >> 2) & 1) * 16 + (kq & 1) * 8 + ((kq >> 1) & 1) * 4;
+    const float x[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x}, {v[0].y, v[1].y, v[2].y, v[3].y},
+                           {v[0].z, v[1].z, v[2].z, v[3].z}, {v[0].w, v[1].w, v[2].w, v[3].w}};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int d = 4 * dq + c;
+        uint2 hi, mid, lo;
+        split3_pair(f32x2{x[c][0], x[c][1]}, hi.x, mid.x, lo.x);
+        split3_pair(f32x2{x[c][2], x[c][3]}, hi.y, mid.y, lo.y);
+        const int dd = xsw(d, pos >> 3) + ((pos >> 2) & 1) * 2;
+        *reinterpret_cast<uint2*>(dst + dd) = hi;
+        *reinterpret_cast<uint2*>(dst + XP + dd) = mid;
+        *reinterpret_cast<uint2*>(dst + 2 * XP + dd) = lo;
+    }
+}
+// 8 fp32 -> three bf16x8 fragments
+__device__ __forceinline__ void split_frag8(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    u32x4v h, m, l;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        uint32_t a, b, c;
+        split3_pair(f32x2{x[2 * u], x[2 * u + 1]}, a, b, c);
+        h[u] = a; m[u] = b; l[u] = c;
+    }
+    hi = __builtin_bit_cast(bf16x8, h);
+    mid = __builtin_bit_cast(bf16x8, m);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+// c += a (hi,mid,lo) x b (hi,mid,lo), six products, smallest terms first
+__device__ __forceinline__ void mfma_x6(f32x16& c, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+}
+
+#ifndef TTTS_FWDX_W
+#define TTTS_FWDX_W 2
+#endif
+constexpr int XSMEM = 6 * XP;   // dwords: K planes + V^T planes of one 64-key stage (48 KB)
+static_assert(XSMEM >= SMEM_FLOATS, "per-wave fp32 scratch must fit the stage buffers");
+
+template <bool CAUSAL, bool WRITE_A>
+__global__ __launch_bounds__(256, TTTS_FWDX_W) void attn_fwd_x6_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t xs[XSMEM];
+    __shared__ float ptile_all[WRITE_A ? 4 * 32 * 17 : 1];   // per wave: 32 queries x 16 keys (+1 pad)
+    uint32_t* Kp = xs;              // [3][64 keys][64 d]
+    uint32_t* Vt = xs + 3 * XP;     // [3][64 d][64 key positions]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    float* ptile = ptile_all + (WRITE_A ? wave * 32 * 17 : 0);
+    const int qblk = CAUSAL ? (gridDim.y - 1 - blockIdx.y) : blockIdx.y;
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+    const int q0 = qblk * QB, qw0 = q0 + wave * 32;
+    const int qg = qw0 + l31;
+    float* scratch = reinterpret_cast<float*>(xs) + wave * 32 * KT_LD;
+
+    int klen = (int)a.key_lens[b];
+    if (klen > a.Tk) klen = a.Tk;
+    if (klen < 0) klen = 0;
+    int kend = klen;
+    if (CAUSAL && kend > q0 + QB) kend = q0 + QB;
+    const int nst_live = (kend + KB - 1) / KB;
+    const int nst = WRITE_A ? (a.Tk + KB - 1) / KB : nst_live;
+    int wave_kend = WRITE_A ? a.Tk : kend;
+    if (CAUSAL && wave_kend > qw0 + 32) wave_kend = qw0 + 32;
+
+    const float* qb_ = a.q + (long)b * a.Tq * a.ldq + h * HD;
+    const float* kb_ = a.k + (long)b * a.Tk * a.ldk + h * HD;
+    const float* vb_ = a.v + (long)b * a.Tk * a.ldv + h * HD;
+
+    // Q fragments: lane (query l31, half) holds Q[q][16 s + 8 half + 0..7] / 8 for the four d-steps s, split in three
+    bf16x8 qf[4][3];
+    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
+    wave_lds_sync();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = scratch[l31 * KT_LD + 16 * s + 8 * half + e];
+        split_frag8(x, qf[s][0], qf[s][1], qf[s][2]);
+    }
+
+    float m = NEG_INF, l = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+
+    const long arow = ((long)(b * a.H + h) * a.Tq);
+    const uint32_t rowid = (uint32_t)(arow + qg);
+
+    auto scores = [&](int sub, f32x16& s) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            bf16x8 kf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                kf[p] = *reinterpret_cast<const bf16x8*>(Kp + p * XP + xsw(sub * 32 + l31, 2 * st + half));
+            mfma_x6(s, kf, qf[st]);
+        }
+    };
+    auto alive = [&](int key_g) -> bool { return key_g < klen && (!CAUSAL || key_g <= qg); };
+    auto drop16 = [&](float (&p)[16], int key0) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const int key_g = key0 + acc_row(r, half);
+            const uint32_t hsh = attn_hash(a.seed, rowid, (uint32_t)key_g >> 1);
+            p[r] = keep_from_hash(hsh, 0u, a.thr) ? p[r] * a.drop_scale : 0.f;
+            p[r + 1] = keep_from_hash(hsh, 1u, a.thr) ? p[r + 1] * a.drop_scale : 0.f;
+        }
+    };
+
+    if (WRITE_A) {
+        // ---------------- pass 1: row max / row sum only
+        for (int t = 0; t < nst_live; ++t) {
+            __syncthreads();
+            stage_split_rows(kb_, (long)t * KB, a.Tk, a.ldk, tid, Kp);
+            __syncthreads();
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int key0 = t * KB + sub * 32;
+                if (key0 >= kend) break;
+                f32x16 s;
+                scores(sub, s);
+                float mx = NEG_INF;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[r] = alive(key0 + acc_row(r, half)) ? s[r] : NEG_INF;
+                    mx = fmaxf(mx, s[r]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float m_new = fmaxf(m, mx);
+                float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+                float alpha = __expf(m - m_use);
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ps += __expf(s[r] - m_use);
+                l = l * alpha + ps;
+                m = m_new;
+            }
+        }
+        l = l + __shfl_xor(l, 32, 64);
+    }
+
+    const float m_fin = (m == NEG_INF) ? 0.f : m;
+    const float inv_l = (l > 0.f) ? 1.f / l : 0.f;
+
+    // ---------------- main pass
+    for (int t = 0; t < nst; ++t) {
+        __syncthreads();
+        stage_split_rows(kb_, (long)t * KB, a.Tk, a.ldk, tid, Kp);
+        stage_split_cols(vb_, (long)t * KB, a.Tk, a.ldv, tid, Vt);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int key0 = t * KB + sub * 32;
+            if (key0 >= wave_kend) break;
+            f32x16 s;
+            scores(sub, s);
+            float p[16];
+            // a tile every lane sees in full needs no mask arithmetic (wave-uniform test)
+            const bool full = (key0 + 32 <= klen) && (!CAUSAL || key0 + 31 <= qw0);
+            if (WRITE_A) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] = alive(key0 + acc_row(r, half)) ? __expf(s[r] - m_fin) * inv_l : 0.f;
+            } else {
+                float mx = NEG_INF;
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        s[r] = alive(key0 + acc_row(r, half)) ? s[r] : NEG_INF;
+                        mx = fmaxf(mx, s[r]);
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float m_new = fmaxf(m, mx);
+                float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+                float alpha = __expf(m - m_use);
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { p[r] = __expf(s[r] - m_use); ps += p[r]; }
+                l = l * alpha + ps;
+                m = m_new;
+                if (__any(alpha != 1.f)) {   // the running maximum rarely moves after the first tiles
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+                }
+            }
+            if (a.thr != 0u) drop16(p, key0);
+            if (WRITE_A) {
+                // transpose through LDS in two halves of 16 keys (registers 8g..8g+7 are keys 16g..16g+15) so that the
+                // weights leave as 64-byte row segments
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ptile[l31 * 17 + (acc_row(8 * g2 + e, half) & 15)] = p[8 * g2 + e];
+                    wave_lds_sync();
+#pragma unroll 4
+                    for (int i = 0; i < 8; ++i) {
+                        const int qrow = 4 * i + (lane >> 4), kc = lane & 15;
+                        const float v = ptile[qrow * 17 + kc];
+                        const int q_g = qw0 + qrow, key_g = key0 + 16 * g2 + kc;
+                        if (q_g < a.Tq && key_g < a.Tk) a.attn[(arow + q_g) * a.Tk + key_g] = v;
+                    }
+                    wave_lds_sync();
+                }
+            }
+            // O^T[d][q] += V^T[d][key] P^T[key][q]: two 16-key steps, registers 8t..8t+7 of the lane are its B fragment
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = p[8 * t2 + e];
+                bf16x8 pf[3];
+                split_frag8(x, pf[0], pf[1], pf[2]);
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    bf16x8 vf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        vf[pl] = *reinterpret_cast<const bf16x8*>(Vt + pl * XP + xsw(32 * i2 + l31, 4 * sub + 2 * t2 + half));
+                    mfma_x6(o[i2], vf, pf);
+                }
+            }
+        }
+    }
+
+    float out_scale = 1.f;
+    float lse_v;
+    if (WRITE_A) {
+        lse_v = m_fin + __logf(l > 0.f ? l : 1.f);
+    } else {
+        float lt = l + __shfl_xor(l, 32, 64);
+        out_scale = (lt > 0.f) ? 1.f / lt : 0.f;
+        lse_v = ((m == NEG_INF) ? 0.f : m) + __logf(lt > 0.f ? lt : 1.f);
+    }
+    if (a.lse != nullptr && half == 0 && qg < a.Tq) a.lse[arow + qg] = lse_v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= out_scale; o[1][r] *= out_scale; }
+    __syncthreads();
+    wave_store_rows(o, scratch, a.o + (long)b * a.Tq * a.ldo + h * HD, qw0, a.Tq, a.ldo, lane, 1.f);
+}
+
 static int check_common(const char* name, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, float drop_p) {
     TTTS_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "%s: bad dims", name);
     TTTS_REQUIRE((long)B * H < (1L << 31) && cdiv(Tq, QB) <= 65535 && cdiv(Tk, QB) <= 65535, "%s: grid too large", name);
@@ -525,9 +825,9 @@ using namespace ttts;
 
 extern "C" {
 
-int ttts_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
-                       const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                       int causal, float drop_p, uint64_t seed, void* stream_) {
+static int attention_fwd_impl(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
+                              const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
+                              int causal, float drop_p, uint64_t seed, bool x6, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(q && k && v && o && key_lens, "attention_fwd: null pointer");
     int rc = check_common("attention_fwd", B, H, Tq, Tk, ldq, ldk, ldv, ldo, drop_p);
@@ -542,6 +842,16 @@ int ttts_attention_fwd(const float* q, const float* k, const float* v, float* o,
     a.drop_scale = 1.f / (1.f - drop_p);
     a.seed = seed;
     dim3 grid(B * H, cdiv(Tq, QB), 1);
+    if (x6) {
+        if (causal)
+            hipLaunchKernelGGL((attn_fwd_x6_kernel<true, false>), grid, dim3(256), 0, stream, a);
+        else if (attn)
+            hipLaunchKernelGGL((attn_fwd_x6_kernel<false, true>), grid, dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((attn_fwd_x6_kernel<false, false>), grid, dim3(256), 0, stream, a);
+        TTTS_LAUNCH_CHECK("attn_fwd_x6_kernel");
+        return TTTS_OK;
+    }
     if (causal)
         hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), 0, stream, a);
     else if (attn)
@@ -550,6 +860,19 @@ int ttts_attention_fwd(const float* q, const float* k, const float* v, float* o,
         hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), 0, stream, a);
     TTTS_LAUNCH_CHECK("attn_fwd_kernel");
     return TTTS_OK;
+}
+
+int ttts_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
+                       const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
+                       int causal, float drop_p, uint64_t seed, void* stream) {
+    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, false,
+                              stream);
+}
+int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
+                          const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
+                          int causal, float drop_p, uint64_t seed, void* stream) {
+    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, true,
+                              stream);
 }
 
 int ttts_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* do_,

@@ -430,27 +430,6 @@ static int dispatch_gemm(const GemmArgs& g, int zdim, int tile, hipStream_t stre
 // weight_split_kernel into bf16 planes laid k-tile-major ([K/16][plane][N][16]), so the B loader moves whole lines.
 // LDS image per operand plane: [row][16 k] bf16 = 32-byte rows; the two 16-byte chunks of a row are swapped on rows
 // with bit 3 set (chunk ^= (row >> 3) & 1), which makes the ds_read_b128 of the MFMA fragments conflict-free.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-// two fp32 -> (hi, mid, lo) bf16 pairs, each packed in one dword (element 0 in the low half).  Written on vector
-// types so that the compiler emits v_cvt_pk_bf16_f32 / v_pk_add_f32: 9 VALU operations per pair.
-__device__ __forceinline__ void split3_pair(f32x2 x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
-    f32x2 f = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
-    const f32x2 r1 = x - f;
-    mid = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
-    f = f32x2{__uint_as_float(mid << 16), __uint_as_float(mid & 0xffff0000u)};
-    const f32x2 r2 = r1 - f;
-    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
-}
-
-__device__ __forceinline__ void split3_pack4(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
-    split3_pair(f32x2{v.x, v.y}, hi.x, mid.x, lo.x);
-    split3_pair(f32x2{v.z, v.w}, hi.y, mid.y, lo.y);
-}
 
 // B[r][c] (R rows of C bf16 per plane p = hi, mid, lo; stored as [c/16][p][r][c%16]) from a weight tensor:
 //   mode 0: linear forward      B[r][c] = w[r*C + c]                      (w is (R, C))
@@ -591,7 +570,11 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
         }
     };
 
-    auto compute = [&](int buf) {
+    // One k-step.  LDS[buf] holds tile kt, the staging registers hold tile kt+1 (requested in the middle of the previous
+    // step).  After the first accumulator tile's MFMAs the registers are split / written to LDS[buf^1] and immediately
+    // re-used to request tile kt+2: every load has a whole k-step to land and the staging VALU / LDS work sits in the
+    // shadow of the remaining MFMAs, on ONE register set.
+    auto step = [&](int buf, int kt_next2, bool stage, bool fetch) {
         const uint32_t* as = lds + buf * STAGE;
         const uint32_t* bs = as + 3 * A_PLANE;
         const int cw = ((half ^ ((l31 >> 3) & 1)) * 4);       // swizzled 16-byte chunk of this lane's 8 k values
@@ -617,27 +600,28 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
                 acc[i][j] = c;
+                if (i == 0 && j == 0) {
+                    if (stage) {
+#pragma unroll
+                        for (int q = 0; q < NLA; ++q) store_a(buf ^ 1, q);
+                        store_b(buf ^ 1);
+                    }
+                    if (fetch) { load_a(kt_next2); load_b(kt_next2); }
+                }
             }
     };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NLA; ++i) store_a(buf, i);
-        store_b(buf);
-    };
 
-    // Tried and dropped: fetching activations two k-steps ahead into a second register set and splitting / writing them
-    // between the MFMAs.  It needs 206 VGPRs (2 waves per SIMD: 4 % slower than this loop at 3; capped at 168 it spills).
     if (nkt > 0) {
         load_a(0);
         load_b(0);
-        store_tiles(0);
+#pragma unroll
+        for (int q = 0; q < NLA; ++q) store_a(0, q);
+        store_b(0);
+        if (nkt > 1) { load_a(1); load_b(1); }
         __syncthreads();
         int buf = 0;
         for (int kt = 0; kt < nkt; ++kt) {
-            const bool more = (kt + 1) < nkt;
-            if (more) { load_a(kt + 1); load_b(kt + 1); }
-            compute(buf);
-            if (more) store_tiles(buf ^ 1);
+            step(buf, kt + 2, kt + 1 < nkt, kt + 2 < nkt);
             __syncthreads();
             buf ^= 1;
         }

@@ -76,6 +76,28 @@ __device__ __forceinline__ float wave_max(float v) {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---------------------------------------------------------------- split precision (bf16 x 3)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 -> (hi, mid, lo) bf16 pairs, each packed in one dword (element 0 in the low half).  Written on vector
+// types so that the compiler emits v_cvt_pk_bf16_f32 / v_pk_add_f32: 9 VALU operations per pair.
+__device__ __forceinline__ void split3_pair(f32x2 x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+    f32x2 f = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    const f32x2 r1 = x - f;
+    mid = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+    f = f32x2{__uint_as_float(mid << 16), __uint_as_float(mid & 0xffff0000u)};
+    const f32x2 r2 = r1 - f;
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
+}
+
+__device__ __forceinline__ void split3_pack4(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
+    split3_pair(f32x2{v.x, v.y}, hi.x, mid.x, lo.x);
+    split3_pair(f32x2{v.z, v.w}, hi.y, mid.y, lo.y);
+}
+
 // row index inside a 32x32 MFMA accumulator tile held by (lane, reg)
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 

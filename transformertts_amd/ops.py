@@ -68,6 +68,7 @@ seeds = _SeedStream()
 # (3-way bf16 split, six MFMA terms, fp32 accumulate; error 1.1e-7 vs 2.9e-7 for the plain fp32 MFMA chain),
 # "f32" = the plain v_mfma_f32_32x32x2_f32 kernel.  Weight gradients always use the fp32 kernel.
 GEMM_MODE = os.environ.get("TTTS_GEMM_MODE", "x6")
+ATTN_MODE = os.environ.get("TTTS_ATTN_MODE", GEMM_MODE)       # attention products: "x6" or "f32"
 WGRAD_MODE = os.environ.get("TTTS_WGRAD_MODE", GEMM_MODE)    # weight gradients: "x6" (split-precision MFMA) or "f32"
 
 
@@ -402,8 +403,9 @@ def _attn_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, lens, causal, drop_p, seed, 
     o = torch.empty(B, Tq, H * 64, dtype=torch.float32, device=dev)
     lse = torch.empty(B, H, Tq, dtype=torch.float32, device=dev)
     attn = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=dev) if need_weights else None
-    _lib.check(lib.ttts_attention_fwd(q, k, v, _p(o), _p(lse), _p(attn), _p(lens), B, H, Tq, Tk, ldq, ldk, ldv, H * 64,
-                                      1 if causal else 0, float(drop_p), seed, _stream()), "ttts_attention_fwd")
+    fwd = lib.ttts_attention_fwd_x6 if ATTN_MODE == "x6" else lib.ttts_attention_fwd
+    _lib.check(fwd(q, k, v, _p(o), _p(lse), _p(attn), _p(lens), B, H, Tq, Tk, ldq, ldk, ldv, H * 64,
+                   1 if causal else 0, float(drop_p), seed, _stream()), "ttts_attention_fwd")
     return o, lse, attn
 
 
