@@ -150,6 +150,10 @@ int ttts_attention_bwd(const float* q, const float* k, const float* v, const flo
 int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                           int causal, float drop_p, uint64_t seed, void* stream);
+int ttts_attention_bwd_x6(const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                          const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
+                          int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                          int causal, float drop_p, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------ small row / element-wise pieces
  * nn.Embedding gather / scatter-add (model/model.py:168,288; no padding_idx) */

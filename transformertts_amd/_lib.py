@@ -51,6 +51,7 @@ SIGNATURES = {
     "ttts_attention_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P]),
     "ttts_attention_fwd_x6": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P]),
     "ttts_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P]),
+    "ttts_attention_bwd_x6": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P]),
     "ttts_embedding_fwd": (I, [P, P, P, L, I, I, P]),
     "ttts_embedding_bwd": (I, [P, P, P, L, I, I, I, P]),
     "ttts_posenc_fwd": (I, [P, P, P, P, I, I, I, F, U, P]),

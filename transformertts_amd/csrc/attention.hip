@@ -810,6 +810,362 @@ __global__ __launch_bounds__(256, TTTS_FWDX_W) void attn_fwd_x6_kernel(AttnArgs 
     wave_store_rows(o, scratch, a.o + (long)b * a.Tq * a.ldo + h * HD, qw0, a.Tq, a.ldo, lane, 1.f);
 }
 
+// ---- backward, split-precision.  Both kernels need one streamed operand in BOTH orientations (row-major for the score
+// products, transposed for the gradient products), so a thread stages a 4 x 4 patch: split once, packed twice (the
+// transposed pairs are re-packed from the row-major ones with v_perm_b32 instead of being split again).
+__device__ __forceinline__ void patch_load(const float* base, long row0, long nrows_total, int ld, int rq, int dq,
+                                           float scale, float4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long gr = row0 + 4 * rq + i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < nrows_total) {
+            v[i] = *reinterpret_cast<const float4*>(base + gr * ld + dq * 4);
+            v[i].x *= scale; v[i].y *= scale; v[i].z *= scale; v[i].w *= scale;
+        }
+    }
+}
+// rows 4rq..4rq+3, columns 4dq..4dq+3 -> row-major planes `rows` (stride XPR dwords per plane, 128-byte rows) and, when
+// TR, transposed planes `cols` ([64 d][NPOS positions], plane stride XPC; `pos` = position of row 4rq in the permuted
+// order; chunk swizzle for 128-byte rows: xsw, for 64-byte rows: xsw4)
+__device__ __forceinline__ int xsw4(int row, int chunk) { return row * 16 + ((chunk ^ ((row >> 2) & 3)) << 2); }
+template <bool TR, int NPOS>
+__device__ __forceinline__ void patch_split_store(const float4 (&v)[4], int rq, int dq, int pos, uint32_t* rows, int XPR,
+                                                  uint32_t* cols, int XPC) {
+    uint2 hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        split3_pack4(v[i], hi[i], mid[i], lo[i]);
+        const int d = xsw(4 * rq + i, dq >> 1) + (dq & 1) * 2;
+        *reinterpret_cast<uint2*>(rows + d) = hi[i];
+        *reinterpret_cast<uint2*>(rows + XPR + d) = mid[i];
+        *reinterpret_cast<uint2*>(rows + 2 * XPR + d) = lo[i];
+    }
+    if (TR) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t sel = (c & 1) ? 0x07060302u : 0x05040100u;   // high / low halves of the two source dwords
+            uint2 th, tm, tl;
+            if (c < 2) {
+                th.x = __builtin_amdgcn_perm(hi[1].x, hi[0].x, sel); th.y = __builtin_amdgcn_perm(hi[3].x, hi[2].x, sel);
+                tm.x = __builtin_amdgcn_perm(mid[1].x, mid[0].x, sel); tm.y = __builtin_amdgcn_perm(mid[3].x, mid[2].x, sel);
+                tl.x = __builtin_amdgcn_perm(lo[1].x, lo[0].x, sel); tl.y = __builtin_amdgcn_perm(lo[3].x, lo[2].x, sel);
+            } else {
+                th.x = __builtin_amdgcn_perm(hi[1].y, hi[0].y, sel); th.y = __builtin_amdgcn_perm(hi[3].y, hi[2].y, sel);
+                tm.x = __builtin_amdgcn_perm(mid[1].y, mid[0].y, sel); tm.y = __builtin_amdgcn_perm(mid[3].y, mid[2].y, sel);
+                tl.x = __builtin_amdgcn_perm(lo[1].y, lo[0].y, sel); tl.y = __builtin_amdgcn_perm(lo[3].y, lo[2].y, sel);
+            }
+            const int d = 4 * dq + c;
+            const int dd = (NPOS == 64 ? xsw(d, pos >> 3) : xsw4(d, pos >> 3)) + ((pos >> 2) & 1) * 2;
+            *reinterpret_cast<uint2*>(cols + dd) = th;
+            *reinterpret_cast<uint2*>(cols + XPC + dd) = tm;
+            *reinterpret_cast<uint2*>(cols + 2 * XPC + dd) = tl;
+        }
+    }
+}
+// position (in the permuted contraction order) of row 4*rq within its 32-row group: 16 t + 8 h + 4 (e >> 2), see above
+__device__ __forceinline__ int perm_pos(int rq) { return ((rq >> 2) & 1) * 16 + (rq & 1) * 8 + ((rq >> 1) & 1) * 4; }
+
+// lane-resident B operand: the 64 values of this lane's row (query or key), split, for the four 16-deep steps
+__device__ __forceinline__ void load_lane_frags(const float* scratch, int l31, int half, bf16x8 (&f)[4][3]) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = scratch[l31 * KT_LD + 16 * st + 8 * half + e];
+        split_frag8(x, f[st][0], f[st][1], f[st][2]);
+    }
+}
+
+#ifndef TTTS_DQX_W
+#define TTTS_DQX_W 2
+#endif
+#ifndef TTTS_DKVX_W
+#define TTTS_DKVX_W 2
+#endif
+constexpr int DQX_SMEM = 9 * XP * 4;   // bytes: K rows, V rows, K^T of one 64-key stage (72 KB, dynamic)
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, TTTS_DQX_W) void attn_bwd_dq_x6_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t xsd[];
+    uint32_t* Kr = xsd;              // [3][64 keys][64 d]
+    uint32_t* Vr = xsd + 3 * XP;     // [3][64 keys][64 d]
+    uint32_t* Kt = xsd + 6 * XP;     // [3][64 d][64 key positions]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int qblk = CAUSAL ? (gridDim.y - 1 - blockIdx.y) : blockIdx.y;
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+    const int q0 = qblk * QB, qw0 = q0 + wave * 32;
+    const int qg = qw0 + l31;
+    float* scratch = reinterpret_cast<float*>(xsd) + wave * 32 * KT_LD;
+
+    int klen = (int)a.key_lens[b];
+    if (klen > a.Tk) klen = a.Tk;
+    if (klen < 0) klen = 0;
+    int kend = klen;
+    if (CAUSAL && kend > q0 + QB) kend = q0 + QB;
+    const int nst = (kend + KB - 1) / KB;
+    int wave_kend = kend;
+    if (CAUSAL && wave_kend > qw0 + 32) wave_kend = qw0 + 32;
+
+    const float* qb_ = a.q + (long)b * a.Tq * a.ldq + h * HD;
+    const float* kb_ = a.k + (long)b * a.Tk * a.ldk + h * HD;
+    const float* vb_ = a.v + (long)b * a.Tk * a.ldv + h * HD;
+    const float* ob_ = a.o + (long)b * a.Tq * a.ldo + h * HD;
+    const float* gb_ = a.dout + (long)b * a.Tq * a.ldo + h * HD;
+    const long arow = ((long)(b * a.H + h) * a.Tq);
+    const uint32_t rowid = (uint32_t)(arow + qg);
+
+    bf16x8 qf[4][3], gf[4][3];
+    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
+    wave_lds_sync();
+    load_lane_frags(scratch, l31, half, qf);
+    wave_lds_sync();
+    wave_stage_tile(ob_, qw0, a.Tq, a.ldo, lane, scratch, 1.f);
+    wave_lds_sync();
+    float orow[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) orow[j] = scratch[l31 * KT_LD + 2 * j + half];
+    wave_lds_sync();
+    wave_stage_tile(gb_, qw0, a.Tq, a.ldo, lane, scratch, 1.f);
+    wave_lds_sync();
+    float delta = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) delta += scratch[l31 * KT_LD + 2 * j + half] * orow[j];
+    delta += __shfl_xor(delta, 32, 64);
+    load_lane_frags(scratch, l31, half, gf);
+    if (half == 0 && qg < a.Tq) a.delta[arow + qg] = delta;
+    const float lse_q = (qg < a.Tq) ? a.lse[arow + qg] : 0.f;
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+
+    const int rq = tid >> 4, dqd = tid & 15;
+    const int kpos = (rq >> 3) * 32 + perm_pos(rq);
+    for (int t = 0; t < nst; ++t) {
+        __syncthreads();
+        {
+            float4 v[4];
+            patch_load(kb_, (long)t * KB, a.Tk, a.ldk, rq, dqd, 1.f, v);
+            patch_split_store<true, 64>(v, rq, dqd, kpos, Kr, XP, Kt, XP);
+            patch_load(vb_, (long)t * KB, a.Tk, a.ldv, rq, dqd, 1.f, v);
+            patch_split_store<false, 64>(v, rq, dqd, 0, Vr, XP, nullptr, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int key0 = t * KB + sub * 32;
+            if (key0 >= wave_kend) break;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                bf16x8 kf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    kf[p] = *reinterpret_cast<const bf16x8*>(Kr + p * XP + xsw(sub * 32 + l31, 2 * st + half));
+                mfma_x6(s, kf, qf[st]);
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                bf16x8 vf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    vf[p] = *reinterpret_cast<const bf16x8*>(Vr + p * XP + xsw(sub * 32 + l31, 2 * st + half));
+                mfma_x6(dp, vf, gf[st]);
+            }
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int key_g = key0 + acc_row(r, half);
+                uint32_t hsh = 0;
+                if (a.thr != 0u) hsh = attn_hash(a.seed, rowid, (uint32_t)key_g >> 1);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int kg = key_g + e;
+                    bool live = kg < klen && (!CAUSAL || kg <= qg);
+                    float p = live ? __expf(s[r + e] - lse_q) : 0.f;
+                    float g = dp[r + e];
+                    if (a.thr != 0u) g = keep_from_hash(hsh, (uint32_t)e, a.thr) ? g * a.drop_scale : 0.f;
+                    ds[r + e] = p * (g - delta);
+                }
+            }
+            // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = ds[8 * t2 + e];
+                bf16x8 dsf[3];
+                split_frag8(x, dsf[0], dsf[1], dsf[2]);
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    bf16x8 ktf[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        ktf[p] = *reinterpret_cast<const bf16x8*>(Kt + p * XP + xsw(32 * i2 + l31, 4 * sub + 2 * t2 + half));
+                    mfma_x6(dq[i2], ktf, dsf);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    wave_store_rows(dq, scratch, a.dq + (long)b * a.Tq * a.lddq + h * HD, qw0, a.Tq, a.lddq, lane, 0.125f);
+}
+
+// dK, dV: key on the lane; one stage = 32 queries in both orientations (Q, dO row-major for S / dP, transposed for dK / dV)
+constexpr int QS = 32;                  // queries per stage
+constexpr int XPQ = QS * 32;            // dwords per row-major plane of a stage: 32 rows x 128 B
+constexpr int XPT = 64 * 16;            // dwords per transposed plane: 64 d x 32 positions
+constexpr int DKVX_DW = 6 * XPQ + 6 * XPT;   // 48 KB
+static_assert(DKVX_DW >= SMEM_FLOATS, "per-wave fp32 scratch must fit the stage buffers");
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t xs[DKVX_DW];
+    __shared__ float lse_s[QS], delta_s[QS];
+    uint32_t* Qr = xs;                      // [3][32 q][64 d]
+    uint32_t* Gr = xs + 3 * XPQ;
+    uint32_t* Qt = xs + 6 * XPQ;            // [3][64 d][32 q positions]
+    uint32_t* Gt = xs + 6 * XPQ + 3 * XPT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int kblk = blockIdx.y;
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+    const int k0 = kblk * QB, kw0 = k0 + wave * 32;
+    const int kg = kw0 + l31;
+    float* scratch = reinterpret_cast<float*>(xs) + wave * 32 * KT_LD;
+
+    int klen = (int)a.key_lens[b];
+    if (klen > a.Tk) klen = a.Tk;
+    if (klen < 0) klen = 0;
+
+    const float* qb_ = a.q + (long)b * a.Tq * a.ldq + h * HD;
+    const float* kb_ = a.k + (long)b * a.Tk * a.ldk + h * HD;
+    const float* vb_ = a.v + (long)b * a.Tk * a.ldv + h * HD;
+    const float* gb_ = a.dout + (long)b * a.Tq * a.ldo + h * HD;
+    const long arow = ((long)(b * a.H + h) * a.Tq);
+
+    bf16x8 kf[4][3], vf[4][3];
+    wave_stage_tile(kb_, kw0, a.Tk, a.ldk, lane, scratch, 1.f);
+    wave_lds_sync();
+    load_lane_frags(scratch, l31, half, kf);
+    wave_lds_sync();
+    wave_stage_tile(vb_, kw0, a.Tk, a.ldv, lane, scratch, 1.f);
+    wave_lds_sync();
+    load_lane_frags(scratch, l31, half, vf);
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+
+    const int nqs = (a.Tq + QS - 1) / QS;
+    int qs_begin = CAUSAL ? (k0 / QS) : 0;
+    if (k0 >= klen) qs_begin = nqs;
+
+    // staging roles: threads 0..127 take Q, 128..255 take dO; each a 4 x 4 patch of the 32 x 64 stage
+    const int st_t = tid & 127, rq = st_t >> 4, dqd = st_t & 15;
+    const bool st_q = tid < 128;
+    const int qpos = perm_pos(rq);
+
+    for (int qs = qs_begin; qs < nqs; ++qs) {
+        const int qt0 = qs * QS;
+        __syncthreads();
+        {
+            float4 v[4];
+            if (st_q) {
+                patch_load(qb_, (long)qt0, a.Tq, a.ldq, rq, dqd, 0.125f, v);
+                patch_split_store<true, 32>(v, rq, dqd, qpos, Qr, XPQ, Qt, XPT);
+            } else {
+                patch_load(gb_, (long)qt0, a.Tq, a.ldo, rq, dqd, 1.f, v);
+                patch_split_store<true, 32>(v, rq, dqd, qpos, Gr, XPQ, Gt, XPT);
+            }
+        }
+        if (tid < QS) {
+            int q = qt0 + tid;
+            lse_s[tid] = (q < a.Tq) ? a.lse[arow + q] : 0.f;
+            delta_s[tid] = (q < a.Tq) ? a.delta[arow + q] : 0.f;
+        }
+        __syncthreads();
+        if (CAUSAL && qt0 + 31 < kw0) continue;     // every query of the stage precedes this wave's keys (wave-uniform)
+        if (kw0 >= klen) continue;                  // this wave's keys are all padding
+
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            bf16x8 qfr[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) qfr[p] = *reinterpret_cast<const bf16x8*>(Qr + p * XPQ + xsw(l31, 2 * st + half));
+            mfma_x6(s, qfr, kf[st]);
+        }
+        float pd[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qrow = acc_row(r, half);
+            const int q_g = qt0 + qrow;
+            const bool live = kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq;
+            pd[r] = live ? __expf(s[r] - lse_s[qrow]) : 0.f;
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            bf16x8 gfr[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) gfr[p] = *reinterpret_cast<const bf16x8*>(Gr + p * XPQ + xsw(l31, 2 * st + half));
+            mfma_x6(dp, gfr, vf[st]);
+        }
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qrow = acc_row(r, half);
+            float g = dp[r];
+            float pk = pd[r];
+            if (a.thr != 0u) {
+                const uint32_t hsh = attn_hash(a.seed, (uint32_t)(arow + qt0 + qrow), (uint32_t)kg >> 1);
+                const bool keep = keep_from_hash(hsh, (uint32_t)kg & 1u, a.thr);
+                g = keep ? g * a.drop_scale : 0.f;
+                pk = keep ? pk * a.drop_scale : 0.f;
+            }
+            ds[r] = pd[r] * (g - delta_s[qrow]);
+            pd[r] = pk;
+        }
+        // dV^T[d][key] += dO^T[d][q] P[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            float x[8];
+            bf16x8 f[3];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = pd[8 * t2 + e];
+            split_frag8(x, f[0], f[1], f[2]);
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(Gt + p * XPT + xsw4(32 * i2 + l31, 2 * t2 + half));
+                mfma_x6(dv[i2], af, f);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = ds[8 * t2 + e];
+            split_frag8(x, f[0], f[1], f[2]);
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(Qt + p * XPT + xsw4(32 * i2 + l31, 2 * t2 + half));
+                mfma_x6(dk[i2], af, f);
+            }
+        }
+    }
+    __syncthreads();
+    wave_store_rows(dk, scratch, a.dk + (long)b * a.Tk * a.lddk + h * HD, kw0, a.Tk, a.lddk, lane, 1.f);
+    wave_store_rows(dv, scratch, a.dv + (long)b * a.Tk * a.lddv + h * HD, kw0, a.Tk, a.lddv, lane, 1.f);
+}
+
 static int check_common(const char* name, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, float drop_p) {
     TTTS_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "%s: bad dims", name);
     TTTS_REQUIRE((long)B * H < (1L << 31) && cdiv(Tq, QB) <= 65535 && cdiv(Tk, QB) <= 65535, "%s: grid too large", name);
@@ -822,6 +1178,25 @@ static int check_common(const char* name, int B, int H, int Tq, int Tk, int ldq,
 }  // namespace ttts
 
 using namespace ttts;
+
+template <bool CAUSAL>
+static int launch_bwd_x6(const AttnArgs& a, dim3 gq, dim3 gk, hipStream_t stream) {
+    static bool configured = false;   // 72 KB of dynamic LDS needs an explicit opt-in, once per kernel
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_x6_kernel<CAUSAL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DQX_SMEM);
+        if (e != hipSuccess) {
+            set_error("attention_bwd: cannot reserve %d bytes of LDS: %s", DQX_SMEM, hipGetErrorString(e));
+            return TTTS_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_dq_x6_kernel<CAUSAL>), gq, dim3(256), DQX_SMEM, stream, a);
+    TTTS_LAUNCH_CHECK("attn_bwd_dq_x6_kernel");
+    hipLaunchKernelGGL((attn_bwd_dkv_x6_kernel<CAUSAL>), gk, dim3(256), 0, stream, a);
+    TTTS_LAUNCH_CHECK("attn_bwd_dkv_x6_kernel");
+    return TTTS_OK;
+}
 
 extern "C" {
 
@@ -875,10 +1250,10 @@ int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float*
                               stream);
 }
 
-int ttts_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* do_,
-                       const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
-                       int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                       int causal, float drop_p, uint64_t seed, void* stream_) {
+static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* do_,
+                              const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
+                              int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                              int causal, float drop_p, uint64_t seed, bool x6, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(q && k && v && o && do_ && lse && delta && dq && dk && dv && key_lens, "attention_bwd: null pointer");
     int rc = check_common("attention_bwd", B, H, Tq, Tk, ldq, ldk, ldv, ldo, drop_p);
@@ -896,6 +1271,7 @@ int ttts_attention_bwd(const float* q, const float* k, const float* v, const flo
     a.drop_scale = 1.f / (1.f - drop_p);
     a.seed = seed;
     dim3 gq(B * H, cdiv(Tq, QB), 1), gk(B * H, cdiv(Tk, QB), 1);
+    if (x6) return causal ? launch_bwd_x6<true>(a, gq, gk, stream) : launch_bwd_x6<false>(a, gq, gk, stream);
     if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), gq, dim3(256), 0, stream, a);
         TTTS_LAUNCH_CHECK("attn_bwd_dq_kernel");
@@ -907,6 +1283,21 @@ int ttts_attention_bwd(const float* q, const float* k, const float* v, const flo
     }
     TTTS_LAUNCH_CHECK("attn_bwd_dkv_kernel");
     return TTTS_OK;
+}
+
+int ttts_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* do_,
+                       const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
+                       int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                       int causal, float drop_p, uint64_t seed, void* stream) {
+    return attention_bwd_impl(q, k, v, o, do_, lse, delta, dq, dk, dv, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk,
+                              lddv, causal, drop_p, seed, false, stream);
+}
+int ttts_attention_bwd_x6(const float* q, const float* k, const float* v, const float* o, const float* do_,
+                          const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
+                          int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                          int causal, float drop_p, uint64_t seed, void* stream) {
+    return attention_bwd_impl(q, k, v, o, do_, lse, delta, dq, dk, dv, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk,
+                              lddv, causal, drop_p, seed, true, stream);
 }
 
 }  // extern "C"

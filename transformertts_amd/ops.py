@@ -72,6 +72,10 @@ ATTN_MODE = os.environ.get("TTTS_ATTN_MODE", GEMM_MODE)       # attention produc
 WGRAD_MODE = os.environ.get("TTTS_WGRAD_MODE", GEMM_MODE)    # weight gradients: "x6" (split-precision MFMA) or "f32"
 
 
+def _attn_bwd(lib):
+    return lib.ttts_attention_bwd_x6 if ATTN_MODE == "x6" else lib.ttts_attention_bwd
+
+
 def _wgrad_fn(lib, name: str):
     return getattr(lib, name + "_x6") if WGRAD_MODE == "x6" else getattr(lib, name)
 
@@ -440,7 +444,7 @@ class SelfAttentionFn(torch.autograd.Function):
         do = _chk(do, "self_attention.do")
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
-        _lib.check(lib.ttts_attention_bwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta),
+        _lib.check(_attn_bwd(lib)(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta),
                                           _off(dqkv, 0), _off(dqkv, d), _off(dqkv, 2 * d), _p(lens), B, n_head, T, T, d3,
                                           d3, d3, d, d3, d3, d3, 1 if causal else 0, drop_p, seed, _stream()),
                    "ttts_attention_bwd")
@@ -479,7 +483,7 @@ class CrossAttentionFn(torch.autograd.Function):
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         delta = torch.empty_like(lse)
-        _lib.check(lib.ttts_attention_bwd(_off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
+        _lib.check(_attn_bwd(lib)(_off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
                                           _off(dq, 0), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk, d, 2 * d,
                                           2 * d, d, d, 2 * d, 2 * d, 0, drop_p, seed, _stream()), "ttts_attention_bwd")
         return dq, dkv, None, None, None, None, None
