@@ -12,8 +12,11 @@ qkv = torch.randn(B, T, 3 * d, device=dev); dqkv = torch.empty_like(qkv)
 o = torch.empty(B, T, d, device=dev); do = torch.randn(B, T, d, device=dev)
 lse = torch.empty(B, H, T, device=dev); delta = torch.empty_like(lse)
 lens = torch.full((B,), T, dtype=torch.int64, device=dev)
+x6 = os.environ.get("X6", "1") == "1"
+fwd = lib.ttts_attention_fwd_x6 if x6 else lib.ttts_attention_fwd
+bwd = lib.ttts_attention_bwd_x6 if x6 else lib.ttts_attention_bwd
 for _ in range(3):
-    lib.ttts_attention_fwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(lse), None, _p(lens), B, H, T, T, 3 * d, 3 * d, 3 * d, d, 1, 0.1, 7, _stream())
-    lib.ttts_attention_bwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta), _off(dqkv, 0), _off(dqkv, d),
+    fwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(lse), None, _p(lens), B, H, T, T, 3 * d, 3 * d, 3 * d, d, 1, 0.1, 7, _stream())
+    bwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta), _off(dqkv, 0), _off(dqkv, d),
                            _off(dqkv, 2 * d), _p(lens), B, H, T, T, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, 1, 0.1, 7, _stream())
 torch.cuda.synchronize()

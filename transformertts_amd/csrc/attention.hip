@@ -597,14 +597,16 @@ __device__ __forceinline__ void mfma_x6(f32x16& c, const bf16x8 (&a)[3], const b
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
 }
 
+// waves per SIMD the allocator must leave room for: 3 costs the plain forward a ten-dword spill outside its inner loop
+// and is 7 % faster than 2; the weights-writing form is LDS-limited to 2 workgroups per CU anyway
 #ifndef TTTS_FWDX_W
-#define TTTS_FWDX_W 2
+#define TTTS_FWDX_W 3
 #endif
 constexpr int XSMEM = 6 * XP;   // dwords: K planes + V^T planes of one 64-key stage (48 KB)
 static_assert(XSMEM >= SMEM_FLOATS, "per-wave fp32 scratch must fit the stage buffers");
 
 template <bool CAUSAL, bool WRITE_A>
-__global__ __launch_bounds__(256, TTTS_FWDX_W) void attn_fwd_x6_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDX_W) void attn_fwd_x6_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t xs[XSMEM];
     __shared__ float ptile_all[WRITE_A ? 4 * 32 * 17 : 1];   // per wave: 32 queries x 16 keys (+1 pad)
     uint32_t* Kp = xs;              // [3][64 keys][64 d]
@@ -1120,19 +1122,31 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
             mfma_x6(dp, gfr, vf[st]);
         }
         float ds[16];
+        // dropout: keys 2j, 2j+1 (neighbouring lanes) share one hash per query row -- the even lane computes it for the even
+        // registers, the odd lane for the odd ones, and a quad-permute DPP move hands the other half over
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qrow = acc_row(r, half);
-            float g = dp[r];
-            float pk = pd[r];
+        for (int r = 0; r < 16; r += 2) {
+            uint32_t h0 = 0, h1 = 0;
             if (a.thr != 0u) {
-                const uint32_t hsh = attn_hash(a.seed, (uint32_t)(arow + qt0 + qrow), (uint32_t)kg >> 1);
-                const bool keep = keep_from_hash(hsh, (uint32_t)kg & 1u, a.thr);
-                g = keep ? g * a.drop_scale : 0.f;
-                pk = keep ? pk * a.drop_scale : 0.f;
+                const int rr = r + (lane & 1);
+                const uint32_t mine = attn_hash(a.seed, (uint32_t)(arow + qt0 + acc_row(rr, half)), (uint32_t)kg >> 1);
+                const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+                h0 = (lane & 1) ? other : mine;
+                h1 = (lane & 1) ? mine : other;
             }
-            ds[r] = pd[r] * (g - delta_s[qrow]);
-            pd[r] = pk;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int qrow = acc_row(r + e, half);
+                float g = dp[r + e];
+                float pk = pd[r + e];
+                if (a.thr != 0u) {
+                    const bool keep = keep_from_hash(e ? h1 : h0, (uint32_t)kg & 1u, a.thr);
+                    g = keep ? g * a.drop_scale : 0.f;
+                    pk = keep ? pk * a.drop_scale : 0.f;
+                }
+                ds[r + e] = pd[r + e] * (g - delta_s[qrow]);
+                pd[r + e] = pk;
+            }
         }
         // dV^T[d][key] += dO^T[d][q] P[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
