@@ -1018,21 +1018,38 @@ __global__ __launch_bounds__(256, TTTS_DQX_W) void attn_bwd_dq_x6_kernel(AttnArg
     wave_store_rows(dq, scratch, a.dq + (long)b * a.Tq * a.lddq + h * HD, qw0, a.Tq, a.lddq, lane, 0.125f);
 }
 
-// dK, dV: key on the lane; one stage = 32 queries in both orientations (Q, dO row-major for S / dP, transposed for dK / dV)
+// dK, dV: key on the lane; one stage = 32 queries in both orientations (Q, dO row-major for S / dP, transposed for dK / dV).
+// The raw fp32 rows of stage t+1 are fetched by LDS-DMA (global_load_lds, no registers) while stage t is multiplied,
+// so the split / re-pack pass at the top of a stage reads LDS instead of waiting for HBM or L2.
 constexpr int QS = 32;                  // queries per stage
 constexpr int XPQ = QS * 32;            // dwords per row-major plane of a stage: 32 rows x 128 B
 constexpr int XPT = 64 * 16;            // dwords per transposed plane: 64 d x 32 positions
-constexpr int DKVX_DW = 6 * XPQ + 6 * XPT;   // 48 KB
+constexpr int RAWQ = QS * 64;           // dwords of one raw fp32 stage tile (8 KB)
+constexpr int DKVX_DW = 6 * XPQ + 6 * XPT + 2 * RAWQ + 256;   // planes 48 KB + raw Q, dO 16 KB + 2 x (lse, delta) rows
 static_assert(DKVX_DW >= SMEM_FLOATS, "per-wave fp32 scratch must fit the stage buffers");
+constexpr int DKVX_SMEM = DKVX_DW * 4;   // 66 048 bytes: dynamic (above the 64 KB static limit)
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+__device__ __forceinline__ void dma16(const float* src, uint32_t* lds_wave_base) {
+    // 64 lanes x 16 bytes: lane i lands at lds_wave_base + 16 i (the destination is wave-uniform base + lane * size)
+    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const float* src, uint32_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)lds_wave_base, 4, 0, 0);
+}
 
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t xs[DKVX_DW];
-    __shared__ float lse_s[QS], delta_s[QS];
+    extern __shared__ __attribute__((aligned(16))) uint32_t xsd[];
+    uint32_t* xs = xsd;
     uint32_t* Qr = xs;                      // [3][32 q][64 d]
     uint32_t* Gr = xs + 3 * XPQ;
     uint32_t* Qt = xs + 6 * XPQ;            // [3][64 d][32 q positions]
     uint32_t* Gt = xs + 6 * XPQ + 3 * XPT;
+    uint32_t* rawQ = xs + 6 * XPQ + 6 * XPT;   // [32][64] fp32, filled by DMA
+    uint32_t* rawG = rawQ + RAWQ;
+    float* stat_s = reinterpret_cast<float*>(rawG + RAWQ);  // [2 buffers][lse 64 | delta 64] (32 of each 64 used)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -1074,25 +1091,51 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
     const bool st_q = tid < 128;
     const int qpos = perm_pos(rq);
 
+    // DMA of one stage: wave w moves rows 8w..8w+7 of Q and of dO (two 1-KB instructions each), wave 0 also lse / delta.
+    // Rows past Tq are clamped to the last row here and zeroed when they are split.
+    auto fetch = [&](int qt0, int sb) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 8 * wave + 4 * j + (lane >> 4);
+            long gr = (long)qt0 + row;
+            if (gr > a.Tq - 1) gr = a.Tq - 1;
+            dma16(qb_ + gr * a.ldq + (lane & 15) * 4, rawQ + (8 * wave + 4 * j) * 64);
+            dma16(gb_ + gr * a.ldo + (lane & 15) * 4, rawG + (8 * wave + 4 * j) * 64);
+        }
+        if (wave == 0) {
+            long q = (long)qt0 + l31;
+            if (q > a.Tq - 1) q = a.Tq - 1;
+            dma4(a.lse + arow + q, reinterpret_cast<uint32_t*>(stat_s + sb * 128));
+            dma4(a.delta + arow + q, reinterpret_cast<uint32_t*>(stat_s + sb * 128 + 64));
+        }
+    };
+
+    __syncthreads();                       // the per-wave scratch (aliasing the planes) is dead from here on
+    if (qs_begin < nqs) fetch(qs_begin * QS, qs_begin & 1);
+
     for (int qs = qs_begin; qs < nqs; ++qs) {
         const int qt0 = qs * QS;
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the stage have landed
+        __syncthreads();                                    // ... and everybody else's; previous planes are free
         {
+            const uint32_t* raw = st_q ? rawQ : rawG;
+            const float sc = st_q ? 0.125f : 1.f;
             float4 v[4];
-            if (st_q) {
-                patch_load(qb_, (long)qt0, a.Tq, a.ldq, rq, dqd, 0.125f, v);
-                patch_split_store<true, 32>(v, rq, dqd, qpos, Qr, XPQ, Qt, XPT);
-            } else {
-                patch_load(gb_, (long)qt0, a.Tq, a.ldo, rq, dqd, 1.f, v);
-                patch_split_store<true, 32>(v, rq, dqd, qpos, Gr, XPQ, Gt, XPT);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 4 * rq + i;
+                const u32x4v u = *reinterpret_cast<const u32x4v*>(raw + row * 64 + dqd * 4);
+                const bool ok = qt0 + row < a.Tq;
+                v[i] = make_float4(ok ? __uint_as_float(u[0]) * sc : 0.f, ok ? __uint_as_float(u[1]) * sc : 0.f,
+                                   ok ? __uint_as_float(u[2]) * sc : 0.f, ok ? __uint_as_float(u[3]) * sc : 0.f);
             }
+            if (st_q) patch_split_store<true, 32>(v, rq, dqd, qpos, Qr, XPQ, Qt, XPT);
+            else patch_split_store<true, 32>(v, rq, dqd, qpos, Gr, XPQ, Gt, XPT);
         }
-        if (tid < QS) {
-            int q = qt0 + tid;
-            lse_s[tid] = (q < a.Tq) ? a.lse[arow + q] : 0.f;
-            delta_s[tid] = (q < a.Tq) ? a.delta[arow + q] : 0.f;
-        }
+        const float* lse_s = stat_s + (qs & 1) * 128;
+        const float* delta_s = lse_s + 64;
         __syncthreads();
+        if (qs + 1 < nqs) fetch(qt0 + QS, (qs + 1) & 1);   // in flight while this stage is multiplied
         if (CAUSAL && qt0 + 31 < kw0) continue;     // every query of the stage precedes this wave's keys (wave-uniform)
         if (kw0 >= klen) continue;                  // this wave's keys are all padding
 
@@ -1109,10 +1152,9 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
         float pd[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int qrow = acc_row(r, half);
-            const int q_g = qt0 + qrow;
+            const int q_g = qt0 + acc_row(r, half);
             const bool live = kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq;
-            pd[r] = live ? __expf(s[r] - lse_s[qrow]) : 0.f;
+            pd[r] = live ? __expf(s[r] - lse_s[acc_row(r, half)]) : 0.f;
         }
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
@@ -1136,7 +1178,6 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int qrow = acc_row(r + e, half);
                 float g = dp[r + e];
                 float pk = pd[r + e];
                 if (a.thr != 0u) {
@@ -1144,7 +1185,7 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
                     g = keep ? g * a.drop_scale : 0.f;
                     pk = keep ? pk * a.drop_scale : 0.f;
                 }
-                ds[r + e] = pd[r + e] * (g - delta_s[qrow]);
+                ds[r + e] = pd[r + e] * (g - delta_s[acc_row(r + e, half)]);
                 pd[r + e] = pk;
             }
         }
@@ -1195,10 +1236,13 @@ using namespace ttts;
 
 template <bool CAUSAL>
 static int launch_bwd_x6(const AttnArgs& a, dim3 gq, dim3 gk, hipStream_t stream) {
-    static bool configured = false;   // 72 KB of dynamic LDS needs an explicit opt-in, once per kernel
+    static bool configured = false;   // more than 64 KB of LDS per workgroup needs an explicit opt-in, once per kernel
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_x6_kernel<CAUSAL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, DQX_SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_x6_kernel<CAUSAL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, DKVX_SMEM);
         if (e != hipSuccess) {
             set_error("attention_bwd: cannot reserve %d bytes of LDS: %s", DQX_SMEM, hipGetErrorString(e));
             return TTTS_ERR_LAUNCH;
@@ -1207,7 +1251,7 @@ static int launch_bwd_x6(const AttnArgs& a, dim3 gq, dim3 gk, hipStream_t stream
     }
     hipLaunchKernelGGL((attn_bwd_dq_x6_kernel<CAUSAL>), gq, dim3(256), DQX_SMEM, stream, a);
     TTTS_LAUNCH_CHECK("attn_bwd_dq_x6_kernel");
-    hipLaunchKernelGGL((attn_bwd_dkv_x6_kernel<CAUSAL>), gk, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_x6_kernel<CAUSAL>), gk, dim3(256), DKVX_SMEM, stream, a);
     TTTS_LAUNCH_CHECK("attn_bwd_dkv_x6_kernel");
     return TTTS_OK;
 }
