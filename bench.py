@@ -16,6 +16,7 @@ Inputs are resident in HBM before the timed region.  Prints ONE JSON line on ran
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -244,6 +245,10 @@ def main():
         step(i)
         torch.cuda.synchronize()
         note(f"warm-up step {i} done")
+    # A full (generation-2) pass of Python's cyclic collector costs ~80 ms with torch's object graph loaded and tends to
+    # fire a few steps into a run: collect now and freeze the survivors so that it cannot land inside the timed steps.
+    gc.collect()
+    gc.freeze()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):

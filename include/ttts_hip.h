@@ -71,6 +71,9 @@ size_t ttts_split_bytes(int64_t rows, int64_t cols);
 int ttts_gemm_tile_choice(int64_t M, int N, int x6);
 int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode, int channels_per_tap, int taps,
                       void* stream);
+/* all weights in one launch: descs (device memory) = n x 8 int64 {w, planes, rows, cols, mode, channels_per_tap, taps,
+ * first_block}, first_block = running sum of ceil(rows*cols/256), total_blocks = the final sum */
+int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks, void* stream);
 int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
                        int64_t M, int N, int K, int act, float drop_p, uint64_t seed, int row_shift, int T, void* stream);
 int ttts_linear_bwd_data_x6(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,

@@ -29,6 +29,7 @@ SIGNATURES = {
     "ttts_split_bytes": (Z, [L, L]),
     "ttts_gemm_tile_choice": (I, [L, I, I]),
     "ttts_weight_split": (I, [P, P, I, I, I, I, I, P]),
+    "ttts_weight_split_batched": (I, [P, I, L, P]),
     "ttts_linear_fwd_x6": (I, [P, P, P, P, P, L, I, I, I, F, U, I, I, P]),
     "ttts_linear_bwd_data_x6": (I, [P, P, P, P, L, I, I, P]),
     "ttts_conv1d_fwd_x6": (I, [P, P, P, P, I, I, I, I, I, P]),

@@ -436,10 +436,9 @@ static int dispatch_gemm(const GemmArgs& g, int zdim, int tile, hipStream_t stre
 //   mode 1: linear data-grad    B[r][c] = w[c*R + r]                      (w is (C, R); B = w^T)
 //   mode 2: conv forward        B[co][tap*cin + ci] = w[(co*cin + ci)*taps + tap]       (R = cout, C = taps*cin)
 //   mode 3: conv data-grad      B[ci][tap*cout + co] = w[(co*cin + ci)*taps + tap]      (R = cin,  C = taps*cout)
-__global__ __launch_bounds__(256) void weight_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
-                                                           int R, int C, int mode, int c2, int taps) {
+__device__ __forceinline__ void weight_split_one(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
+                                                 int C, int mode, int c2, int taps, long i) {
     const long n = (long)R * C;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int r = (int)(i / C), c = (int)(i % C);
     float v;
@@ -462,6 +461,23 @@ __global__ __launch_bounds__(256) void weight_split_kernel(const float* __restri
     planes[o] = __builtin_bit_cast(unsigned short, b1);
     planes[o + ps] = __builtin_bit_cast(unsigned short, b2);
     planes[o + 2 * ps] = __builtin_bit_cast(unsigned short, b3);
+}
+__global__ __launch_bounds__(256) void weight_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
+                                                           int R, int C, int mode, int c2, int taps) {
+    weight_split_one(w, planes, R, C, mode, c2, taps, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// every weight of the model in one launch (after an optimizer step): descriptor i = 8 int64
+// {w, planes, R, C, mode, c2, taps, first block}; a workgroup finds its descriptor by bisection on the block starts
+__global__ __launch_bounds__(256) void weight_split_batched_kernel(const long* __restrict__ descs, int n) {
+    int lo = 0, hi = n - 1;
+    const long blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid * 8 + 7] <= blk) lo = mid; else hi = mid - 1;
+    }
+    const long* d = descs + lo * 8;
+    weight_split_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
+                     (int)d[4], (int)d[5], (int)d[6], (blk - d[7]) * 256 + threadIdx.x);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -1124,6 +1140,16 @@ int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode
     hipLaunchKernelGGL(weight_split_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        (unsigned short*)planes, rows, cols, mode, channels_per_tap, taps);
     TTTS_LAUNCH_CHECK("weight_split_kernel");
+    return TTTS_OK;
+}
+
+int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks, void* stream) {
+    // descs (device): n x 8 int64 {w, planes, rows, cols, mode, channels_per_tap, taps, first_block}; first_block are the
+    // prefix sums of ceil(rows*cols / 256); the caller guarantees the per-entry constraints of ttts_weight_split
+    TTTS_REQUIRE(descs && n > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "weight_split_batched: bad arguments");
+    hipLaunchKernelGGL(weight_split_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long*>(descs), n);
+    TTTS_LAUNCH_CHECK("weight_split_batched_kernel");
     return TTTS_OK;
 }
 

@@ -57,8 +57,8 @@ class MultiheadAttention(nn.Module):
     def cross_attention(self, x: Tensor, mem: Tensor, mem_lens: Tensor, residual: Tensor, out_drop: float,
                         need_weights: bool = True):
         d = self.embed_dim
-        q = ops.linear(x, self.in_proj_weight[:d], self.in_proj_bias[:d])
-        kv = ops.linear(mem, self.in_proj_weight[d:], self.in_proj_bias[d:])
+        q = ops.linear(x, ops.param_rows(self.in_proj_weight, 0, d), ops.param_rows(self.in_proj_bias, 0, d))
+        kv = ops.linear(mem, ops.param_rows(self.in_proj_weight, d, 3 * d), ops.param_rows(self.in_proj_bias, d, 3 * d))
         p = self._p()
         ctx, attn = ops.CrossAttentionFn.apply(q, kv, mem_lens, self.num_heads, p, ops.seeds.next() if p > 0 else 0,
                                                need_weights)

@@ -239,7 +239,7 @@ class TransformerTTS(nn.Module):
             layers = list(self.decoder.layers)
             H = layers[0].self_attn.num_heads
             # encoder memory K/V per layer, once; self-attention K/V caches (B, max_len, 2d) filled one row per step
-            mem_kv = [ops.linear(memory, l.multihead_attn.in_proj_weight[d:], l.multihead_attn.in_proj_bias[d:]) for l in layers]
+            mem_kv = [ops.linear(memory, ops.param_rows(l.multihead_attn.in_proj_weight, d, 3 * d), ops.param_rows(l.multihead_attn.in_proj_bias, d, 3 * d)) for l in layers]
             cache = [torch.zeros(B, max_len, 2 * d, device=dev) for _ in layers]
             Tp = memory.size(1)
             for t in range(1, max_len):
@@ -255,7 +255,7 @@ class TransformerTTS(nn.Module):
                     x = ops.layer_norm(ops.linear(ctx, sa.out_proj.weight, sa.out_proj.bias, residual=x),
                                        l.norm1.weight, l.norm1.bias, l.norm1.eps)
                     ca = l.multihead_attn
-                    q = ops.linear(x, ca.in_proj_weight[:d], ca.in_proj_bias[:d])
+                    q = ops.linear(x, ops.param_rows(ca.in_proj_weight, 0, d), ops.param_rows(ca.in_proj_bias, 0, d))
                     ctx, _, _ = ops._attn_fwd(ops._off(q, 0), ops._off(mkv, 0), ops._off(mkv, d), d, 2 * d, 2 * d, B, H, 1, Tp,
                                               phoneme_lens, False, 0.0, 0, False)
                     x = ops.layer_norm(ops.linear(ctx, ca.out_proj.weight, ca.out_proj.bias, residual=x),

@@ -8,6 +8,7 @@ no CPU / eager fallback -- non-CUDA tensors are rejected.
 from __future__ import annotations
 
 import os
+import weakref
 from ctypes import c_void_p
 from typing import Optional
 
@@ -90,27 +91,115 @@ def bump_param_epoch() -> None:
     _param_epoch += 1
 
 
+class _PlaneEntry:
+    __slots__ = ("wref", "off", "mode", "rows", "cols", "c2", "taps", "planes", "tag")
+
+
+_BATCHED_SPLIT = os.environ.get("TTTS_BATCHED_SPLIT", "1") == "1"
+_plane_entries: list = []        # every (weight, mode) split so far, for the one-launch refresh after an optimizer step
+_plane_table = None              # (signature, device descriptor table, pinned host copy, total blocks)
+
+
+def _refresh_all_planes() -> None:
+    """Re-split every registered weight whose storage and version are unchanged (only the parameter epoch moved, i.e. an
+    optimizer stepped through raw pointers) with ONE launch instead of one per weight and mode."""
+    global _plane_table, _plane_entries
+    live, sig = [], []
+    for e in _plane_entries:
+        w = e.wref()
+        if w is None:
+            continue
+        live.append(e)
+        if e.tag[0] == w._version and e.tag[1] == w.data_ptr() + e.off and e.tag[2] != _param_epoch:
+            sig.append((e.tag[1], e.planes.data_ptr(), e.rows, e.cols, e.mode, e.c2, e.taps))
+    _plane_entries = live
+    if not sig:
+        return
+    sig_t = tuple(sig)
+    if _plane_table is None or _plane_table[0] != sig_t:
+        rows, blk = [], 0
+        for s in sig:
+            rows.append(list(s) + [blk])
+            blk += (s[2] * s[3] + 255) // 256
+        host = torch.tensor(rows, dtype=torch.int64).pin_memory()      # page-locked: the upload does not synchronise
+        _plane_table = (sig_t, host.to(live[0].planes.device, non_blocking=True), host, blk)
+    lib = _lib.load()
+    _lib.check(lib.ttts_weight_split_batched(_p(_plane_table[1]), len(sig), _plane_table[3], _stream()),
+               "ttts_weight_split_batched")
+    refreshed = {s[1] for s in sig}
+    for e in live:
+        if e.planes.data_ptr() in refreshed:
+            e.tag = (e.tag[0], e.tag[1], _param_epoch)
+
+
 def _planes(w: torch.Tensor, mode: int, rows: int, cols: int, c2: int = 0, taps: int = 0) -> torch.Tensor:
     """hi/mid/lo bf16 planes of a weight, re-laid as the K-contiguous B operand (ttts_weight_split).  Cached on the
-    tensor object and keyed by its version counter + storage address, so the two forwards and the backward of a
-    step split each weight once and an optimizer step invalidates the planes."""
-    cache = getattr(w, "_ttts_planes", None)
-    tag = (w._version, w.data_ptr(), _param_epoch)
-    if cache is not None:
-        ent = cache.get(mode)
-        if ent is not None and ent[0] == tag:
-            return ent[1]
+    parameter object and keyed by its version counter + storage address + parameter epoch, so the two forwards and the
+    backward of a step split each weight once; after an optimizer step all weights are re-split in one launch.
+    Row slices made by `param_rows` are cached on the parameter they were cut from."""
+    owner = getattr(w, "_ttts_planes_owner", None)
+    holder, sub = owner if owner is not None else (w, 0)
+    cache = getattr(holder, "_ttts_planes", None)
+    tag = (holder._version, w.data_ptr(), _param_epoch)
+    key = (mode, sub)
+    ent = cache.get(key) if cache is not None else None
+    if ent is not None:
+        if ent.tag == tag:
+            return ent.planes
+        if _BATCHED_SPLIT and ent.tag[0] == tag[0] and ent.tag[1] == tag[1]:   # only the epoch moved: refresh everything at once
+            _refresh_all_planes()
+            if ent.tag == tag:
+                return ent.planes
     lib = _lib.load()
-    planes = torch.empty(3 * rows * cols, dtype=torch.int16, device=w.device)
+    if ent is None or ent.planes.numel() != 3 * rows * cols or ent.planes.device != w.device:
+        planes = torch.empty(3 * rows * cols, dtype=torch.int16, device=w.device)
+    else:
+        planes = ent.planes
     _lib.check(lib.ttts_weight_split(_p(w), _p(planes), rows, cols, mode, c2, taps, _stream()), "ttts_weight_split")
     try:
         if cache is None:
             cache = {}
-            w._ttts_planes = cache
-        cache[mode] = (tag, planes)
-    except AttributeError:
+            holder._ttts_planes = cache
+        if ent is None:
+            ent = _PlaneEntry()
+            ent.wref = weakref.ref(holder)
+            _plane_entries.append(ent)
+            cache[key] = ent
+        ent.off = w.data_ptr() - holder.data_ptr()
+        ent.mode, ent.rows, ent.cols, ent.c2, ent.taps, ent.planes, ent.tag = mode, rows, cols, c2, taps, planes, tag
+    except (AttributeError, TypeError):
         pass
     return planes
+
+
+class _ParamRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, r0, r1):
+        ctx.cfg = (p.shape, r0, r1)
+        ctx.set_materialize_grads(False)
+        return p.detach()[r0:r1]
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:                      # the consumer added its gradient straight into the parameter's sink
+            return None, None, None
+        shape, r0, r1 = ctx.cfg
+        full = torch.zeros(shape, dtype=g.dtype, device=g.device)
+        full[r0:r1] = g
+        return full, None, None
+
+
+def param_rows(p: torch.Tensor, r0: int, r1: int) -> torch.Tensor:
+    """Rows r0..r1 of a parameter (e.g. the q or k/v part of a packed in-projection) as an operand of `linear`: unlike a
+    plain slice, the result keeps the parameter's gradient sink (so the weight-gradient kernel adds in place and no
+    slice-backward kernels run) and its weight planes are cached on the parameter."""
+    v = _ParamRowsFn.apply(p, r0, r1)
+    sk = _sink(p)
+    if sk is not None:
+        v._ttts_grad_sink = sk[r0:r1]
+    if p.dim() == 2:
+        v._ttts_planes_owner = (p, r0)
+    return v
 
 
 def _sink(t: Optional[torch.Tensor]):
