@@ -1,0 +1,211 @@
+"""Both arithmetic forms of the MFMA kernels (fp32 MFMA and split-precision bf16x6), called directly through the C ABI
+and held to the same fp64 reference; plus the size-independent properties at the BASELINE batch size."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 5e-6
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(_dev())
+
+
+def _rel(a, b):
+    from conftest import rel_l2
+    return rel_l2(a, b)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1024, 256), (777, 256, 1024), (129, 80, 256)])
+def test_linear_forms_agree_with_fp64(M, N, K):
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
+    dy = _rand(M, N, seed=4)
+    ref = x.double() @ w.double().t() + b.double()
+    dw_ref, dx_ref, db_ref = dy.double().t() @ x.double(), dy.double() @ w.double(), dy.double().sum(0)
+    for x6 in (False, True):
+        y = torch.empty(M, N, device=_dev())
+        if x6:
+            pl = ops._planes(w, 0, N, K)
+            rc = lib.ttts_linear_fwd_x6(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, 0, 0, _stream())
+        else:
+            rc = lib.ttts_linear_fwd(_p(x), _p(w), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, 0, 0, _stream())
+        assert rc == 0 and _rel(y, ref) < TOL
+        dx = torch.empty(M, K, device=_dev())
+        if x6:
+            plt = ops._planes(w, 1, K, N)
+            rc = lib.ttts_linear_bwd_data_x6(_p(dy), _p(plt), None, _p(dx), M, N, K, _stream())
+        else:
+            rc = lib.ttts_linear_bwd_data(_p(dy), _p(w), None, _p(dx), M, N, K, _stream())
+        assert rc == 0 and _rel(dx, dx_ref) < TOL
+        dw, db = torch.empty(N, K, device=_dev()), torch.empty(N, device=_dev())
+        ws = torch.empty(lib.ttts_wgrad_workspace_bytes(M, N, K, 1) // 4, device=_dev())
+        f = lib.ttts_linear_bwd_weight_x6 if x6 else lib.ttts_linear_bwd_weight
+        rc = f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 0, _stream())
+        assert rc == 0 and _rel(dw, dw_ref) < TOL and _rel(db, db_ref) < TOL
+        # accumulate = 1 adds to what is there
+        rc = f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 1, _stream())
+        assert rc == 0 and _rel(dw, 2 * dw_ref) < TOL and _rel(db, 2 * db_ref) < TOL
+
+
+@pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128)])
+def test_conv_weight_gradient_forms(B, T, cin, cout):
+    """Both weight-gradient kernels on the conv form (shifted rows, utterance clipping, utterances shorter than a k-step)."""
+    from transformertts_amd import _lib
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    x, dy = _rand(B, T, cin, seed=1), _rand(B, T, cout, seed=2)
+    xd = x.double().transpose(1, 2)
+    wd = torch.zeros(cout, cin, 5, dtype=torch.float64, device=_dev(), requires_grad=True)
+    torch.nn.functional.conv1d(xd, wd, None, padding=2).backward(dy.double().transpose(1, 2))
+    for f in (lib.ttts_conv1d_bwd_weight, lib.ttts_conv1d_bwd_weight_x6):
+        dw, db = torch.empty(cout, cin, 5, device=_dev()), torch.empty(cout, device=_dev())
+        ws = torch.empty(lib.ttts_wgrad_workspace_bytes(B * T, cout, cin, 5) // 4, device=_dev())
+        assert f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, B, T, cin, cout, 5, 0, _stream()) == 0
+        assert _rel(dw, wd.grad) < TOL
+        assert _rel(db, dy.double().sum((0, 1))) < TOL
+
+
+def test_weight_split_batched_equals_single():
+    from transformertts_amd import _lib
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    specs = [(_rand(256, 128, seed=1), 256, 128, 0, 0, 0), (_rand(256, 128, seed=2), 128, 256, 1, 0, 0),
+             (_rand(64, 32, 5, seed=3), 64, 160, 2, 32, 5), (_rand(64, 32, 5, seed=4), 32, 320, 3, 64, 5)]
+    single, batched, rows, blk = [], [], [], 0
+    for w, R, C, mode, c2, taps in specs:
+        a = torch.zeros(3 * R * C, dtype=torch.int16, device=_dev())
+        b = torch.zeros_like(a)
+        assert lib.ttts_weight_split(_p(w), _p(a), R, C, mode, c2, taps, _stream()) == 0
+        single.append(a); batched.append(b)
+        rows.append([w.data_ptr(), b.data_ptr(), R, C, mode, c2, taps, blk])
+        blk += (R * C + 255) // 256
+    table = torch.tensor(rows, dtype=torch.int64).to(_dev())
+    assert lib.ttts_weight_split_batched(_p(table), len(rows), blk, _stream()) == 0
+    torch.cuda.synchronize()
+    for a, b in zip(single, batched):
+        assert torch.equal(a, b)
+    # the three planes add back to the weight (exact to 2^-25): plane image is [C/16][plane][R][16]
+    w, R, C = specs[0][0], 256, 128
+    pl = single[0].view(torch.bfloat16).view(C // 16, 3, R, 16).float().sum(1)          # (C/16, R, 16)
+    back = pl.permute(1, 0, 2).reshape(R, C)
+    assert (back - w).abs().max().item() <= 2.0 ** -24 * w.abs().max().item()
+    assert lib.ttts_weight_split(_p(w), _p(single[0]), 256, 120, 0, 0, 0, _stream()) != 0    # cols must be a multiple of 16
+
+
+@pytest.mark.parametrize("causal,Tq,Tk,lens", [(1, 200, 200, [200, 131, 64]), (0, 150, 70, [70, 33, 1]), (0, 33, 129, [129, 128, 5])])
+def test_attention_forms_agree(causal, Tq, Tk, lens):
+    """fp32-MFMA and split-precision attention (forward, weights output, backward) against an fp64 reference, dropout off,
+    and bit-identical dropout masks between the two forms with dropout on."""
+    from transformertts_amd import _lib
+    from transformertts_amd.ops import _p, _off, _stream
+    lib = _lib.load()
+    B, H, d = len(lens), 2, 128
+    q, kv, do = _rand(B, Tq, d, seed=1), _rand(B, Tk, 2 * d, seed=2), _rand(B, Tq, d, seed=3)
+    kl = torch.tensor(lens, dtype=torch.int64, device=_dev())
+    qd = q.double().view(B, Tq, H, 64).transpose(1, 2).requires_grad_()
+    kd = kv[..., :d].double().reshape(B, Tk, H, 64).transpose(1, 2).requires_grad_()
+    vd = kv[..., d:].double().reshape(B, Tk, H, 64).transpose(1, 2).requires_grad_()
+    s = qd @ kd.transpose(-1, -2) / 8.0
+    mask = torch.arange(Tk, device=_dev())[None, None, None, :] >= kl[:, None, None, None]
+    if causal:
+        mask = mask | (torch.arange(Tk, device=_dev())[None, :] > torch.arange(Tq, device=_dev())[:, None])
+    p_ref = torch.softmax(s.masked_fill(mask, float("-inf")), -1)
+    o_ref = (p_ref @ vd).transpose(1, 2).reshape(B, Tq, d)
+    o_ref.backward(do.double())
+    dq_ref = qd.grad.transpose(1, 2).reshape(B, Tq, d)
+    dkv_ref = torch.cat([kd.grad.transpose(1, 2).reshape(B, Tk, d), vd.grad.transpose(1, 2).reshape(B, Tk, d)], -1)
+    outs = {}
+    for name in ("", "_x6"):
+        fwd, bwd = getattr(lib, "ttts_attention_fwd" + name), getattr(lib, "ttts_attention_bwd" + name)
+        for p_drop in (0.0, 0.25):
+            o = torch.empty(B, Tq, d, device=_dev()); lse = torch.empty(B, H, Tq, device=_dev())
+            attn = None if causal else torch.empty(B, H, Tq, Tk, device=_dev())
+            assert fwd(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), _p(attn), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d,
+                       causal, p_drop, 99, _stream()) == 0
+            dq, dkv, delta = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(lse)
+            assert bwd(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d),
+                       _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, p_drop, 99, _stream()) == 0
+            outs[(name, p_drop)] = (o, attn, dq, dkv)
+            if p_drop == 0.0:
+                assert _rel(o, o_ref) < TOL and _rel(dq, dq_ref) < TOL and _rel(dkv, dkv_ref) < TOL
+                if attn is not None:
+                    assert _rel(attn, p_ref) < TOL
+    a, b = outs[("", 0.25)], outs[("_x6", 0.25)]
+    assert _rel(b[0], a[0]) < TOL and _rel(b[2], a[2]) < TOL and _rel(b[3], a[3]) < TOL
+    if a[1] is not None:      # same counter-based mask in both forms: identical zero pattern
+        assert torch.equal(a[1] == 0, b[1] == 0)
+
+
+def _base_module(seed=5):
+    from oracle.spec import model_config, fill_state
+    from transformertts_amd.lightning_module import LightningModule
+    cfg = model_config("base")
+    config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
+              "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,
+                           "sync_loss_every_step": False}}
+    lm = LightningModule(config).to(_dev())
+    lm.model.load_state_dict(fill_state(cfg, seed), strict=True)
+    return cfg, lm
+
+
+def test_full_size_batch_composition_invariance():
+    """BASELINE batch (64 ragged LJSpeech-shaped utterances, eval mode): an utterance's outputs do not depend on what it
+    is batched with -- the masks, the conv / go-frame clipping at utterance ends and the padding never leak."""
+    from oracle.synth import synth_batch
+    cfg, lm = _base_module()
+    lm.eval()
+    batch = {k: v.to(_dev()) for k, v in synth_batch(64, 100, 870, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=3).items()}
+    with torch.no_grad():
+        full = lm.model(batch["phoneme"], batch["melspec"], batch["phoneme_lens"], batch["melspec_lens"])
+        idx = [0, 17, 40, 63]
+        pl, ml = batch["phoneme_lens"][idx], batch["melspec_lens"][idx]
+        Tp, Tm = int(pl.max()), int(ml.max())
+        sub = lm.model(batch["phoneme"][idx][:, :Tp].contiguous(), batch["melspec"][idx][:, :Tm].contiguous(), pl, ml)
+    for j, i in enumerate(idx):
+        m, p = int(ml[j]), int(pl[j])
+        for key in ("pred_melspec", "post_melspec"):
+            assert _rel(sub[key][j, :m], full[key][i, :m]) < 1e-5, key
+        assert _rel(sub["pred_stop"][j, :m], full["pred_stop"][i, :m]) < 1e-5
+        a_sub, a_full = sub["alignments"][-1][j, :, :m, :p], full["alignments"][-1][i, :, :m, :p]
+        assert _rel(a_sub, a_full) < 1e-5
+        assert torch.allclose(a_full.sum(-1), torch.ones_like(a_full.sum(-1)), atol=1e-5)     # rows of weights sum to 1
+        assert float(full["alignments"][-1][i, :, :m, p:].abs().max()) == 0.0 if p < full["alignments"][-1].size(-1) else True
+
+
+def test_full_size_training_step_is_reproducible():
+    """Two BASELINE-size training steps from the same state and seeds: bit-identical loss and gradient bucket (fixed-order
+    reductions everywhere, no floating-point atomics), and a different dropout seed changes them."""
+    from oracle.synth import synth_batch
+    from transformertts_amd import ops
+    from transformertts_amd.parallel import FlatGradBucket
+    cfg, lm = _base_module()
+    lm.train()
+    bucket = FlatGradBucket(lm.parameters())
+    batch = {k: v.to(_dev()) for k, v in synth_batch(64, 100, 870, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=4).items()}
+    bn0 = {k: v.clone() for k, v in lm.state_dict().items() if "running" in k or "num_batches" in k}
+
+    def run(seed):
+        lm.load_state_dict(bn0, strict=False)
+        ops.seeds.manual_seed(seed)
+        torch.manual_seed(seed)
+        bucket.zero()
+        loss = lm.training_step(batch, 0)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), bucket.flat.clone()
+
+    l1, g1 = run(7)
+    l2, g2 = run(7)
+    l3, g3 = run(8)
+    assert torch.isfinite(l1) and torch.equal(l1, l2) and torch.equal(g1, g2)
+    assert not torch.equal(g1, g3)
+    assert float(g1.abs().max()) > 0
