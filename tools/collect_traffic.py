@@ -22,6 +22,8 @@ def short(name):
     if not m:
         return None
     args = m.group(2).replace(" ", "")
+    if m.group(1) == "gemm_bf16x6_kernel":
+        args = ",".join(args.split(",")[:4])          # clipped / unclipped loaders of one tile are one line
     if m.group(1) == "gemm_f32_kernel":
         parts = args.split(",")
         args = ",".join(parts[:4] + [parts[4], "*"]) if parts[4] == "true" else args

@@ -480,11 +480,12 @@ __global__ __launch_bounds__(256) void weight_split_batched_kernel(const long* _
                      (int)d[4], (int)d[5], (int)d[6], (blk - d[7]) * 256 + threadIdx.x);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool CLIP>
 __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(GemmArgs g) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(WM * WN == 4 && BK == 16, "4 waves per workgroup, one MFMA k-step per k-tile");
+    static_assert((BM * 4) % 256 == 0, "every thread stages whole float4s of the A tile");
     constexpr int A_PLANE = BM * 8, B_PLANE = BN * 8;          // dwords per plane (32-byte rows)
     constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
     constexpr int NLA = (BM * 4 + 255) / 256;                  // float4 loads per thread for the A tile
@@ -529,39 +530,43 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
     float4 ra[NLA];
     u32x4 rb[3];
 
+    // Loader state.  No per-load validity arithmetic except the utterance clipping of shifted rows (CLIP): rows past the
+    // end of an operand fall outside its buffer descriptor (hardware returns 0), weight rows past N only feed accumulator
+    // columns that are never stored.  The k position (tap, channel offset, row shift) advances incrementally: loads are
+    // requested in k order, each k-tile exactly once.
     int a_t[NLA];
     uint32_t a_off[NLA];
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
-        int idx = tid + i * 256;
-        int row = idx >> 2, ch = idx & 3;
-        int m = m0 + row;
-        a_off[i] = (row < BM && m < g.M) ? (uint32_t)(((long)m * g.lda + ch * 4) * 4) : OOB;
-        a_t[i] = (g.T > 0) ? (m % g.T) : 0;
+        const int idx = tid + i * 256;
+        const int row = idx >> 2, ch = idx & 3;
+        const int m = m0 + row;
+        a_off[i] = (uint32_t)(((long)m * g.lda + ch * 4) * 4);
+        a_t[i] = CLIP ? (m % g.T) : 0;
     }
     // B: thread -> (row = tid>>1, half-chunk = tid&1): 8 bf16 = 16 bytes per plane
     const int b_row = tid >> 1, b_hc = tid & 1;
-    const uint32_t b_off = ((B_ALL || b_row < BN) && (n0 + b_row) < g.N)
-                               ? (uint32_t)((n0 + b_row) * 32 + b_hc * 16) : OOB;
+    uint32_t b_cur = (uint32_t)((n0 + b_row) * 32 + b_hc * 16);
+    int k_c0 = 0, k_shift = g.shift0;
+    uint32_t k_off = (uint32_t)((long)g.shift0 * g.lda * 4);
+    const uint32_t tap_step = (uint32_t)(((long)g.shift_step * g.lda - g.cin) * 4);
 
-    auto load_a = [&](int kt) {
-        const int k0 = kt * BK;
-        const int tap = k0 / g.cin;
-        const int c0 = k0 - tap * g.cin;
-        const int shift = g.shift0 + tap * g.shift_step;
-        const uint32_t koff = (uint32_t)(((long)shift * g.lda + c0) * 4);
+    auto load_a = [&](int) {
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
-            bool ok = a_off[i] != OOB;
-            if (g.T > 0) ok = ok && ((unsigned)(a_t[i] + shift) < (unsigned)g.T);
-            ra[i] = buf_load4(rsrcA, ok ? a_off[i] + koff : OOB);
+            uint32_t off = a_off[i] + k_off;
+            if (CLIP) off = ((unsigned)(a_t[i] + k_shift) < (unsigned)g.T) ? off : OOB;
+            ra[i] = buf_load4(rsrcA, off);
         }
+        k_c0 += BK;
+        k_off += BK * 4;
+        if (k_c0 == g.cin) { k_c0 = 0; k_shift += g.shift_step; k_off += tap_step; }
     };
-    auto load_b = [&](int kt) {
-        const uint32_t kb = (uint32_t)kt * 3u * b_plane_bytes;
+    auto load_b = [&](int) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-            rb[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)(b_off != OOB ? b_off + kb + p * b_plane_bytes : OOB), 0, 0);
+            rb[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)(b_cur + p * b_plane_bytes), 0, 0);
+        b_cur += 3u * b_plane_bytes;
     };
 
     auto store_a = [&](int buf, int i) {
@@ -684,7 +689,10 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
 template <int BM, int BN, int WM, int WN>
 static int launch_split(const GemmArgs& g, hipStream_t stream) {
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), 1);
-    hipLaunchKernelGGL((gemm_bf16x6_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, stream, g);
+    if (g.T > 0)
+        hipLaunchKernelGGL((gemm_bf16x6_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, stream, g);
+    else
+        hipLaunchKernelGGL((gemm_bf16x6_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, stream, g);
     TTTS_LAUNCH_CHECK("gemm_bf16x6_kernel");
     return TTTS_OK;
 }
@@ -745,45 +753,48 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void wgrad_bf16x6_kernel(G
 
     // loader roles: thread -> (column, which 8 of the 16 rows).  2*BM (2*BN) threads take part.
     //               When both operands fit side by side (64x64 tile) A and B slots go to different waves.
+    // No per-load validity arithmetic: rows past the end of the operand fall outside the buffer descriptor (hardware
+    // returns 0), columns past the matrix edge only feed accumulator rows / columns that are never stored, and the
+    // utterance clipping of shifted rows is applied to the loaded VALUES from one 8-bit mask per k-step.
     constexpr int B_T0 = (2 * BM + 2 * BN <= 256) ? 2 * BM : 0;
     const int tb = tid - B_T0;
     const bool a_slot = tid < 2 * BM, b_slot = tb >= 0 && tb < 2 * BN;
     const int a_col = tid % BM, a_rh = (tid / BM) & 1;
     const int b_col = (tb & 0xffff) % BN, b_rh = ((tb & 0xffff) / BN) & 1;
-    const bool a_on = a_slot && (m0 + a_col) < g.M;
-    const bool b_on = b_slot && (n0 + b_col) < g.N;
-    const uint32_t a_base = a_on ? (uint32_t)(((long)(a_rh * 8) * g.lda + m0 + a_col) * 4) : OOB;
-    const uint32_t b_base = b_on ? (uint32_t)(((long)(b_rh * 8 + shift) * g.ldb + n0 + b_col) * 4) : OOB;
     const uint32_t a_row = (uint32_t)(g.lda * 4), b_row = (uint32_t)(g.ldb * 4);
+    // byte offsets of this thread's first row at k-step kt_begin; advanced by 16 rows per step (wrap-around of the
+    // shifted B offset below zero lands beyond the descriptor, i.e. reads 0)
+    uint32_t a_cur = (uint32_t)(((long)kt_begin * BK + a_rh * 8) * g.lda + m0 + a_col) * 4u;
+    uint32_t b_cur = (uint32_t)((((long)kt_begin * BK + b_rh * 8 + shift) * g.ldb + n0 + b_col) * 4);
     // position of this thread's first B row inside its utterance (clipping of shifted rows), kept incrementally
     int b_t = (g.T > 0) ? (int)(((long)kt_begin * BK + b_rh * 8) % g.T) : 0;
+    const bool clip = g.T > 0 && shift != 0;
 
     float av[8], bv[8];
     float csum = 0.f;   // bias gradient: running sum of this thread's dy values
 
-    auto load_tiles = [&](int kt) {
-        const int k0 = kt * BK;
-        const uint32_t ka = (uint32_t)k0 * a_row, kb = (uint32_t)k0 * b_row;
-        const int ra0 = k0 + a_rh * 8, rb0 = k0 + b_rh * 8;
+    auto load_tiles = [&](int) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            av[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcA, (int)(a_cur + j * a_row), 0, 0));
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            bv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcB, (int)(b_cur + j * b_row), 0, 0));
+        a_cur += BK * a_row;
+        b_cur += BK * b_row;
+    };
+    // bit j set = row j of this thread's 8 is clipped: its position t_j = (b_t + j) mod T has t_j + shift outside [0, T)
+    auto clip_mask = [&]() -> uint32_t {
+        uint32_t m = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const bool ok = a_on && (ra0 + j) < g.K;
-            av[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcA, (int)(ok ? a_base + ka + j * a_row : OOB), 0, 0));
+            int t = b_t + j;
+            if (g.T >= BK) { if (t >= g.T) t -= g.T; } else t %= g.T;
+            m |= ((unsigned)(t + shift) >= (unsigned)g.T) ? (1u << j) : 0u;
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            bool ok = b_on && (rb0 + j) < g.K;
-            if (g.T > 0) {
-                int t = b_t + j;
-                if (g.T >= BK) { if (t >= g.T) t -= g.T; } else t %= g.T;
-                ok = ok && ((unsigned)(t + shift) < (unsigned)g.T);
-            }
-            bv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcB, (int)(ok ? b_base + kb + j * b_row : OOB), 0, 0));
-        }
-        if (g.T > 0) {   // utterances shorter than a k-step wrap more than once
-            b_t += BK;
-            if (g.T >= BK) { if (b_t >= g.T) b_t -= g.T; } else b_t %= g.T;
-        }
+        b_t += BK;
+        if (g.T >= BK) { if (b_t >= g.T) b_t -= g.T; } else b_t %= g.T;
+        return m;
     };
 
     auto store_tiles = [&](int buf) {
@@ -804,6 +815,13 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void wgrad_bf16x6_kernel(G
             *reinterpret_cast<u32x4*>(as + 2 * A_PLANE + d) = lo;
         }
         if (b_slot) {
+            if (clip) {                      // block-uniform: only shifted taps pay for the clipping
+                const uint32_t cm = clip_mask();
+                if (cm != 0u) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bv[j] = ((cm >> j) & 1u) ? 0.f : bv[j];
+                }
+            }
             u32x4 hi, mid, lo;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
