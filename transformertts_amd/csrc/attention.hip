@@ -980,6 +980,8 @@ __global__ __launch_bounds__(256, TTTS_DQX_W) void attn_bwd_dq_x6_kernel(AttnArg
                 mfma_x6(dp, vf, gf[st]);
             }
             float ds[16];
+            // a tile every lane sees in full needs no mask arithmetic (wave-uniform test)
+            const bool full = (key0 + 32 <= klen) && (!CAUSAL || key0 + 31 <= qw0);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const int key_g = key0 + acc_row(r, half);
@@ -988,8 +990,8 @@ __global__ __launch_bounds__(256, TTTS_DQX_W) void attn_bwd_dq_x6_kernel(AttnArg
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int kg = key_g + e;
-                    bool live = kg < klen && (!CAUSAL || kg <= qg);
-                    float p = live ? __expf(s[r + e] - lse_q) : 0.f;
+                    float p = __expf(s[r + e] - lse_q);
+                    if (!full) p = (kg < klen && (!CAUSAL || kg <= qg)) ? p : 0.f;
                     float g = dp[r + e];
                     if (a.thr != 0u) g = keep_from_hash(hsh, (uint32_t)e, a.thr) ? g * a.drop_scale : 0.f;
                     ds[r + e] = p * (g - delta);
@@ -1150,11 +1152,13 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
             mfma_x6(s, qfr, kf[st]);
         }
         float pd[16];
+        const bool full = (kw0 + 32 <= klen) && (!CAUSAL || kw0 + 31 <= qt0) && (qt0 + QS <= a.Tq);   // wave-uniform
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q_g = qt0 + acc_row(r, half);
-            const bool live = kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq;
-            pd[r] = live ? __expf(s[r] - lse_s[acc_row(r, half)]) : 0.f;
+            float p = __expf(s[r] - lse_s[acc_row(r, half)]);
+            if (!full) p = (kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq) ? p : 0.f;
+            pd[r] = p;
         }
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
