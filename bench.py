@@ -198,7 +198,7 @@ def main():
     from oracle.synth import synth_batch
     from transformertts_amd import _lib, ops
     from transformertts_amd.lightning_module import LightningModule
-    from transformertts_amd.parallel import FlatGradBucket, broadcast_module_state
+    from transformertts_amd.parallel import FlatGradBucket, broadcast_module_state, overlap_tail_with_backward
 
     cfg = model_config(args.config)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
@@ -212,6 +212,11 @@ def main():
     opt_cfg = lm.configure_optimizers()          # FlatAdam: flat parameters / gradients / moments, clip folded in
     optimizer, scheduler = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
     bucket = optimizer.bucket
+    # N > 1: the decoder / postnet / head gradients (55 % of the bucket) are exchanged while backward is still in the
+    # encoder side; TTTS_DP_OVERLAP=0 keeps the single all-reduce after backward
+    overlap = None
+    if world > 1 and os.environ.get("TTTS_DP_OVERLAP", "1") == "1":
+        overlap = overlap_tail_with_backward(bucket, lm.model, lm.model.decoder)
 
     # per-rank shard of the global synthetic batch (weak scaling: args.batch utterances per GPU)
     batch = synth_batch(args.batch, args.tp, args.tm, cfg["n_mels"], cfg["n_phon"], ragged=args.ragged, seed=1234 + rank)
@@ -224,7 +229,7 @@ def main():
         optimizer.zero_grad()
         loss = lm.training_step(batch, i)
         loss.backward()
-        bucket.allreduce_mean()
+        bucket.finish_allreduce()                # waits for the overlapped tail and reduces the rest (no-op at N = 1)
         optimizer.step()                         # global-norm clip (1.0) + Adam, two kernels over the flat bucket
         scheduler.step()
         return loss
@@ -291,6 +296,7 @@ def main():
                                    f"({'ragged' if args.ragged else 'dense'}), {args.config} config d_model {cfg['d_model']}, "
                                    f"{cfg['encoder_n_layers']}+{cfg['decoder_n_layers']} layers, dropout on, fp32",
                        "global_batch": args.batch * world, "frames_per_step": frames_all, "parallelism": f"dp{world}",
+                       "grad_allreduce": ("tail overlapped with backward" if overlap is not None else "one collective after backward"),
                        "final_loss": final_loss, "per_step_loss_item_sync": False},
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "step_algorithmic_tflops": flops_all / 1e12,

@@ -139,6 +139,25 @@ def _dp_worker(rank, world, port, ret):
             assert torch.allclose(p.grad, q.grad, atol=1e-6), "averaged gradient mismatch"
         flat_ref = torch.cat([q.grad.flatten() for q in ref.parameters()])
         assert abs(float(norm) - float(flat_ref.norm())) < 1e-5
+        # overlapped form: the tail (second Linear) is reduced from a backward hook while the first Linear's gradients
+        # are still being computed; the result is the same mean gradient
+        want = bucket.flat.clone()
+        bucket.zero()
+        lo = bucket.offset_of(net[2].weight)
+        assert lo > 0
+        fired = []
+        h = net[2].register_full_backward_hook(lambda m, gi, go: (fired.append(1), bucket.start_tail_allreduce(lo))[1])
+        loss = ((net(x[rank * per:(rank + 1) * per]) - y[rank * per:(rank + 1) * per]) ** 2).mean()
+        loss.backward()
+        h.remove()
+        assert fired == [1]
+        bucket.finish_allreduce()
+        assert torch.allclose(bucket.flat, want, atol=1e-7)
+        bucket.zero()                                   # without a started tail, finish == plain all-reduce
+        loss = ((net(x[rank * per:(rank + 1) * per]) - y[rank * per:(rank + 1) * per]) ** 2).mean()
+        loss.backward()
+        bucket.finish_allreduce()
+        assert torch.allclose(bucket.flat, want, atol=1e-7)
         batch = {"phoneme": torch.arange(40).view(4, 10), "melspec": torch.zeros(4, 9, 2),
                  "phoneme_lens": torch.tensor([10, 8, 6, 4]), "melspec_lens": torch.tensor([9, 7, 5, 3])}
         sh = shard_batch(batch, rank, world)

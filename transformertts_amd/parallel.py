@@ -59,12 +59,95 @@ class FlatGradBucket:
             return None
         return dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
 
+    # ---- overlap with backward: the tail of the bucket (parameters registered from `first_param` on) can be reduced as
+    # soon as backward has passed the module that owns `first_param`, while the gradients of earlier modules are still
+    # being computed.  For this model: decoder + postnet + heads (55 % of the bytes) finish before the encoder side starts.
+    def offset_of(self, param: torch.nn.Parameter) -> int:
+        for p, o in zip(self.params, self.offsets):
+            if p is param:
+                return o
+        raise ValueError("offset_of: parameter is not in the bucket")
+
+    def _reduce_range(self, lo: int, hi: int, group, async_op: bool):
+        view = self.flat[lo:hi]
+        world = dist.get_world_size(group)
+        if dist.get_backend(group) == "gloo":
+            if view.is_cuda:                     # rehearsal on a GPU box: staged through the host, synchronous
+                host = view.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                view.copy_(host.div_(world))
+                return None
+            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+            if async_op:
+                return (work, view, world)
+            view.div_(world)
+            return None
+        work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+        return (work, None, world) if async_op else None
+
+    def start_tail_allreduce(self, lo: int, group: Optional[dist.ProcessGroup] = None) -> None:
+        """Begin the (asynchronous) mean all-reduce of flat[lo:].  Call it from a backward hook once every gradient in
+        that range is final; every rank must call it at the same point of its step."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        if getattr(self, "_tail", None) is not None:
+            raise RuntimeError("start_tail_allreduce: a tail reduction is already in flight")
+        self._tail = (lo, self._reduce_range(lo, self.flat.numel(), group, True))
+
+    def finish_allreduce(self, group: Optional[dist.ProcessGroup] = None) -> None:
+        """Reduce whatever `start_tail_allreduce` has not covered and wait for the tail: after this the whole bucket
+        holds the mean gradient.  Without a started tail it is `allreduce_mean()`."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        tail = getattr(self, "_tail", None)
+        self._tail = None
+        if tail is None:
+            self.allreduce_mean(group)
+            return
+        lo, pending = tail
+        if lo > 0:
+            self._reduce_range(0, lo, group, False)
+        if pending is not None:
+            work, view, world = pending
+            work.wait()
+            if view is not None:
+                view.div_(world)
+
     def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
         """Global-norm clipping over the flat buffer (train.py:41 `gradient_clip_val`), after the all-reduce."""
         norm = torch.linalg.vector_norm(self.flat)
         scale = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
         self.flat.mul_(scale)
         return norm
+
+
+def overlap_tail_with_backward(bucket: FlatGradBucket, model: torch.nn.Module, boundary: torch.nn.Module, group=None):
+    """Arrange for the bucket's tail -- the gradients of `boundary` and of every module registered after it -- to be
+    all-reduced as soon as backward has left `boundary` (a full backward hook on it), overlapping the exchange with the
+    rest of backward.  Valid only if those later modules sit AFTER `boundary` in the forward pass too, so that their
+    gradients are final by then: that is checked structurally here (their parameters must form exactly the bucket's tail).
+    Returns the hook handle, or None when the layout does not allow it (the caller then just uses finish_allreduce(),
+    which reduces everything at once).  The optimizer side calls bucket.finish_allreduce() either way."""
+    first = next(iter(boundary.parameters()), None)
+    if first is None:
+        return None
+    try:
+        lo = bucket.offset_of(first)
+    except ValueError:
+        return None
+    after, seen = set(), False
+    for _, child in model.named_children():
+        seen = seen or child is boundary
+        if seen:
+            after.update(id(p) for p in child.parameters())
+    tail = {id(p) for p, o in zip(bucket.params, bucket.offsets) if o >= lo}
+    if not seen or lo == 0 or tail != {i for i in after if i in {id(p) for p in bucket.params}}:
+        return None
+
+    def hook(module, grad_input, grad_output):
+        bucket.start_tail_allreduce(lo, group)
+
+    return boundary.register_full_backward_hook(hook)
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) -> None:
