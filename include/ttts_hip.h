@@ -47,9 +47,12 @@ int ttts_abi_version(void);
  * into the loader (row (b,t) reads x[b,t-1], zeros at t = 0). */
 int ttts_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, int64_t M,
                     int N, int K, int act, float drop_p, uint64_t seed, int row_shift, int T, void* stream);
-/* dx[M,K] = dy[M,N] . w[N,K] (+ residual[M,K])                      N % 16 == 0, K % 4 == 0 */
+/* dx[M,K] = gate * (dy[M,N] . w[N,K]) + residual[M,K]               N % 16 == 0, K % 4 == 0
+ * residual may be NULL.  relu_out (NULL or (M,K)): the forward value of the activation dx is the gradient of, when that
+ * activation is drop(relu(.)) of a preceding Linear (model/module.py:76-80 prenet, the torch FFN block): gate =
+ * relu_out > 0 ? relu_scale : 0 with relu_scale = 1/(1-p) -- the relu / dropout backward mask in the epilogue. */
 int ttts_linear_bwd_data(const float* dy, const float* w, const float* residual, float* dx, int64_t M, int N, int K,
-                         void* stream);
+                         const float* relu_out, float relu_scale, void* stream);
 /* dw[N,K] = dy[M,N]^T . x[M,K] (x rows shifted as in forward); dbias[N] = column sums of dy (optional).
  * Every parameter-gradient output in this header takes `accumulate`: 0 stores, 1 adds to what is there, so that
  * gradients can land directly in slices of one flat, pre-zeroed gradient buffer (the data-parallel bucket). */
@@ -77,7 +80,7 @@ int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks,
 int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
                        int64_t M, int N, int K, int act, float drop_p, uint64_t seed, int row_shift, int T, void* stream);
 int ttts_linear_bwd_data_x6(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
-                            int K, void* stream);
+                            int K, const float* relu_out, float relu_scale, void* stream);
 int ttts_conv1d_fwd_x6(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
                        int taps, void* stream);
 int ttts_conv1d_bwd_data_x6(const float* dy, const void* planes_bwd, float* dx, int B, int T, int cin, int cout, int taps,

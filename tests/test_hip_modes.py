@@ -42,10 +42,18 @@ def test_linear_forms_agree_with_fp64(M, N, K):
         dx = torch.empty(M, K, device=_dev())
         if x6:
             plt = ops._planes(w, 1, K, N)
-            rc = lib.ttts_linear_bwd_data_x6(_p(dy), _p(plt), None, _p(dx), M, N, K, _stream())
+            rc = lib.ttts_linear_bwd_data_x6(_p(dy), _p(plt), None, _p(dx), M, N, K, None, 1.0, _stream())
         else:
-            rc = lib.ttts_linear_bwd_data(_p(dy), _p(w), None, _p(dx), M, N, K, _stream())
+            rc = lib.ttts_linear_bwd_data(_p(dy), _p(w), None, _p(dx), M, N, K, None, 1.0, _stream())
         assert rc == 0 and _rel(dx, dx_ref) < TOL
+        # fused relu / dropout backward mask + residual in the data-gradient epilogue
+        hfwd = torch.relu(_rand(M, K, seed=5)) * (torch.rand(M, K, generator=torch.Generator().manual_seed(6)) > 0.3).to(_dev())
+        res = _rand(M, K, seed=7)
+        if x6:
+            rc = lib.ttts_linear_bwd_data_x6(_p(dy), _p(plt), _p(res), _p(dx), M, N, K, _p(hfwd), 1.25, _stream())
+        else:
+            rc = lib.ttts_linear_bwd_data(_p(dy), _p(w), _p(res), _p(dx), M, N, K, _p(hfwd), 1.25, _stream())
+        assert rc == 0 and _rel(dx, dx_ref * (hfwd > 0).double() * 1.25 + res.double()) < TOL
         dw, db = torch.empty(N, K, device=_dev()), torch.empty(N, device=_dev())
         ws = torch.empty(lib.ttts_wgrad_workspace_bytes(M, N, K, 1) // 4, device=_dev())
         f = lib.ttts_linear_bwd_weight_x6 if x6 else lib.ttts_linear_bwd_weight

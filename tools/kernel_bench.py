@@ -57,7 +57,7 @@ def conv_x6(B, T, cin, cout):
 
 def gemm_dgrad(M, N, K):
     dy = torch.randn(M, N, device=dev); w = torch.randn(N, K, device=dev); dx = torch.empty(M, K, device=dev)
-    us = timeit(lambda: lib.ttts_linear_bwd_data(_p(dy), _p(w), None, _p(dx), M, N, K, _stream()))
+    us = timeit(lambda: lib.ttts_linear_bwd_data(_p(dy), _p(w), None, _p(dx), M, N, K, None, 1.0, _stream()))
     print(f"linear_dgrad M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s")
 
 

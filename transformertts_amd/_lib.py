@@ -23,7 +23,7 @@ SIGNATURES = {
     "ttts_last_error": (c_char_p, []),
     "ttts_abi_version": (I, []),
     "ttts_linear_fwd": (I, [P, P, P, P, P, L, I, I, I, F, U, I, I, P]),
-    "ttts_linear_bwd_data": (I, [P, P, P, P, L, I, I, P]),
+    "ttts_linear_bwd_data": (I, [P, P, P, P, L, I, I, P, F, P]),
     "ttts_wgrad_workspace_bytes": (Z, [L, I, I, I]),
     "ttts_linear_bwd_weight": (I, [P, P, P, P, P, Z, L, I, I, I, I, I, P]),
     "ttts_split_bytes": (Z, [L, L]),
@@ -31,7 +31,7 @@ SIGNATURES = {
     "ttts_weight_split": (I, [P, P, I, I, I, I, I, P]),
     "ttts_weight_split_batched": (I, [P, I, L, P]),
     "ttts_linear_fwd_x6": (I, [P, P, P, P, P, L, I, I, I, F, U, I, I, P]),
-    "ttts_linear_bwd_data_x6": (I, [P, P, P, P, L, I, I, P]),
+    "ttts_linear_bwd_data_x6": (I, [P, P, P, P, L, I, I, P, F, P]),
     "ttts_conv1d_fwd_x6": (I, [P, P, P, P, I, I, I, I, I, P]),
     "ttts_conv1d_bwd_data_x6": (I, [P, P, P, I, I, I, I, I, P]),
     "ttts_linear_bwd_weight_x6": (I, [P, P, P, P, P, Z, L, I, I, I, I, I, P]),

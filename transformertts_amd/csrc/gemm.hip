@@ -55,6 +55,10 @@ struct GemmArgs {
     uint64_t seed;
     const float* residual;
     long ldr;
+    // data-gradient form: the output is the gradient w.r.t. an activation h = drop(relu(.)) whose forward value is
+    // relu_out (same shape as C): v = relu_out > 0 ? v * relu_scale : 0   (fused relu / dropout backward mask)
+    const float* relu_out;
+    float relu_scale;
     // weight-gradient form only: per-split column sums of A (= bias gradient partials), [zsplit][M]
     float* colsum;
     // operand extents in bytes (< 4 GiB): loads go through raw buffer descriptors, so an out-of-range offset returns
@@ -319,6 +323,17 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_f32_kernel(GemmA
 #pragma unroll
                 for (int r = 0; r < 16; ++r) res[r] = 0.f;
             }
+            float gate[16];
+            if (g.relu_out != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + acc_row(r, half);
+                    gate[r] = (row < g.M && col_ok && g.relu_out[(long)row * g.ldc + col] > 0.f) ? g.relu_scale : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gate[r] = 1.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + acc_row(r, half);
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_f32_kernel(GemmA
                     uint64_t idx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
                     v = keep_elem(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
                 }
-                v += res[r];
+                v = v * gate[r] + res[r];
                 if (row < g.M && col_ok) C[(long)row * g.ldc + col] = v;
             }
         }
@@ -670,6 +685,17 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
 #pragma unroll
                 for (int r = 0; r < 16; ++r) res[r] = 0.f;
             }
+            float gate[16];
+            if (g.relu_out != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + acc_row(r, half);
+                    gate[r] = (row < g.M && col_ok && g.relu_out[(long)row * g.ldc + col] > 0.f) ? g.relu_scale : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gate[r] = 1.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + acc_row(r, half);
@@ -679,7 +705,7 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
                     uint64_t idx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
                     v = keep_elem(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
                 }
-                v += res[r];
+                v = v * gate[r] + res[r];
                 if (row < g.M && col_ok) C[(long)row * g.ldc + col] = v;
             }
         }
@@ -927,6 +953,7 @@ static GemmArgs base_args() {
     g.kt_per_split = 1 << 30; g.c_zstride = 0;
     g.bias = nullptr; g.act = 0; g.drop_scale = 1.f; g.drop_thr = 0; g.seed = 0;
     g.residual = nullptr; g.ldr = 0; g.colsum = nullptr; g.a_bytes = 0; g.b_bytes = 0;
+    g.relu_out = nullptr; g.relu_scale = 1.f;
     return g;
 }
 
@@ -988,7 +1015,7 @@ int ttts_linear_fwd(const float* x, const float* w, const float* bias, const flo
 }
 
 int ttts_linear_bwd_data(const float* dy, const float* w, const float* residual, float* dx, int64_t M, int N, int K,
-                         void* stream) {
+                         const float* relu_out, float relu_scale, void* stream) {
     // dx[M,K] = dy[M,N] . w[N,K] (+ residual)   (reduction over N; w consumed in its natural [N][K] layout)
     TTTS_REQUIRE(dy && w && dx, "linear_bwd_data: null pointer");
     TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_bwd_data: bad dims");
@@ -1000,6 +1027,7 @@ int ttts_linear_bwd_data(const float* dy, const float* w, const float* residual,
     TTTS_REQUIRE((uint64_t)M * N * 4 < (1ull << 32) && (uint64_t)N * K * 4 < (1ull << 32), "linear_bwd_data: operand larger than 4 GiB");
     g.a_bytes = (uint32_t)((uint64_t)M * N * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 4);
     g.residual = residual; g.ldr = K;
+    g.relu_out = relu_out; g.relu_scale = relu_scale;
     return dispatch_gemm<true, false>(g, 1, TILE_AUTO, (hipStream_t)stream);
 }
 
@@ -1193,7 +1221,7 @@ int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, 
 }
 
 int ttts_linear_bwd_data_x6(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
-                            int K, void* stream) {
+                            int K, const float* relu_out, float relu_scale, void* stream) {
     // dx[M,K] = dy[M,N] . w[N,K] (+ residual); wt_planes = split of w^T, i.e. [K][N] rows (weight_split mode 1)
     TTTS_REQUIRE(dy && wt_planes && dx, "linear_bwd_data_x6: null pointer");
     TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_bwd_data_x6: bad dims");
@@ -1205,6 +1233,7 @@ int ttts_linear_bwd_data_x6(const float* dy, const void* wt_planes, const float*
     g.lda = N; g.ldb = N; g.ldc = K; g.cin = N;
     g.a_bytes = (uint32_t)((uint64_t)M * N * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 6);
     g.residual = residual; g.ldr = K;
+    g.relu_out = relu_out; g.relu_scale = relu_scale;
     return dispatch_split(g, (hipStream_t)stream);
 }
 

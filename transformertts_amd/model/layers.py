@@ -77,7 +77,7 @@ def _ffn_block(layer, x: Tensor, out_dropout: nn.Dropout) -> Tensor:
     h = ops.linear(x, layer.linear1.weight, layer.linear1.bias, act=ops.ACT_RELU, drop_p=p,
                    seed=ops.seeds.next() if p > 0 else 0)
     return ops.linear(h, layer.linear2.weight, layer.linear2.bias, residual=x, drop_p=po,
-                      seed=ops.seeds.next() if po > 0 else 0)
+                      seed=ops.seeds.next() if po > 0 else 0, sole_consumer=True)   # h feeds nothing else: mask fused
 
 
 class TransformerEncoderLayer(nn.Module):

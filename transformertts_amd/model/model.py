@@ -60,7 +60,8 @@ class DecoderPreNet(nn.Module):
         l1, l2 = self.linear1.linear, self.linear2.linear
         x = ops.linear(x, l1.weight, l1.bias, act=ops.ACT_RELU, drop_p=p1, seed=ops.seeds.next() if p1 > 0 else 0,
                        row_shift=-1 if shift_right else 0, T=x.size(1))
-        return ops.linear(x, l2.weight, l2.bias, act=ops.ACT_RELU, drop_p=p2, seed=ops.seeds.next() if p2 > 0 else 0)
+        return ops.linear(x, l2.weight, l2.bias, act=ops.ACT_RELU, drop_p=p2, seed=ops.seeds.next() if p2 > 0 else 0,
+                          sole_consumer=True)
 
 
 class PositionalEncoding(nn.Module):

@@ -223,7 +223,7 @@ class LinearFn(torch.autograd.Function):
     """y = drop(act(x @ w.T + b)) + residual, rows optionally shifted by `row_shift` inside each utterance."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, act, drop_p, seed, row_shift, T):
+    def forward(ctx, x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out=None, tok_in=None):
         lib = _lib.load()
         x = _chk(x, "linear.x")
         w = _chk(w, "linear.weight")
@@ -247,6 +247,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
         ctx.cfg = (act, float(drop_p), seed, row_shift, T, b is not None, residual is not None)
         ctx.sinks = _sinks(w, b)
+        ctx.toks = (tok_out, tok_in)
         return y
 
     @staticmethod
@@ -254,10 +255,14 @@ class LinearFn(torch.autograd.Function):
         lib = _lib.load()
         x, w, y = ctx.saved_tensors
         act, drop_p, seed, row_shift, T, has_b, has_r = ctx.cfg
+        tok_out, tok_in = ctx.toks
         N, K = w.shape
         M = x.numel() // K
         dy = _chk(dy, "linear.dy")
-        if act == ACT_RELU:
+        if act == ACT_RELU and tok_out is not None and tok_out.premasked:
+            dacc = dy                    # the consumer's data-gradient epilogue already applied the relu / dropout mask
+            tok_out.premasked = False
+        elif act == ACT_RELU:
             dacc = torch.empty_like(dy)
             _lib.check(lib.ttts_relu_dropout_bwd(_p(dy), _p(y), _p(dacc), dy.numel(), drop_p, _stream()),
                        "ttts_relu_dropout_bwd")
@@ -271,12 +276,15 @@ class LinearFn(torch.autograd.Function):
             if row_shift != 0:
                 raise RuntimeError("linear: input gradient through a shifted loader is not needed on this path")
             dx = torch.empty_like(x)
+            gate, gscale = (x, tok_in.scale) if tok_in is not None else (None, 1.0)
             if GEMM_MODE == "x6":
                 _lib.check(lib.ttts_linear_bwd_data_x6(_p(dacc), _p(_planes(w, 1, K, N)), None, _p(dx), M, N, K,
-                                                       _stream()), "ttts_linear_bwd_data_x6")
+                                                       _p(gate), gscale, _stream()), "ttts_linear_bwd_data_x6")
             else:
-                _lib.check(lib.ttts_linear_bwd_data(_p(dacc), _p(w), None, _p(dx), M, N, K, _stream()),
+                _lib.check(lib.ttts_linear_bwd_data(_p(dacc), _p(w), None, _p(dx), M, N, K, _p(gate), gscale, _stream()),
                            "ttts_linear_bwd_data")
+            if tok_in is not None:
+                tok_in.premasked = True
         if ctx.needs_input_grad[1]:
             nbytes = lib.ttts_wgrad_workspace_bytes(M, N, K, 1)
             ws = _ws(nbytes, x.device)
@@ -289,11 +297,27 @@ class LinearFn(torch.autograd.Function):
             _lib.check(_wgrad_fn(lib, "ttts_linear_bwd_weight")(_p(dacc), _p(x), _p(dw_t), _p(db_t), _p(ws), ws.numel() * 4,
                                                                  M, N, K, row_shift, T, acc, _stream()),
                        "ttts_linear_bwd_weight")
-        return dx, dw, db, (dy if has_r else None), None, None, None, None, None
+        return dx, dw, db, (dy if has_r else None), None, None, None, None, None, None, None
 
 
-def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_shift=0, T=0):
-    return LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T)
+class _ReluToken:
+    """Handshake between a Linear with a relu(+dropout) epilogue and the ONE Linear that consumes its output: the
+    consumer's data-gradient kernel applies the producer's backward mask in its epilogue and says so here."""
+    __slots__ = ("scale", "premasked")
+
+    def __init__(self, scale: float):
+        self.scale, self.premasked = scale, False
+
+
+def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_shift=0, T=0, sole_consumer=False):
+    """`sole_consumer=True` is the caller's promise that nothing but this Linear reads `x`; if `x` came out of a
+    relu(+dropout) Linear, its backward mask is then fused into this Linear's data-gradient epilogue."""
+    tok_in = getattr(x, "_ttts_relu_token", None) if (sole_consumer and torch.is_grad_enabled()) else None
+    tok_out = _ReluToken(1.0 / (1.0 - float(drop_p))) if act == ACT_RELU else None
+    y = LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out, tok_in)
+    if tok_out is not None:
+        y._ttts_relu_token = tok_out
+    return y
 
 
 # ----------------------------------------------------------------------------------------------- heads
@@ -331,10 +355,11 @@ class HeadsFn(torch.autograd.Function):
         dstop = _chk(dstop, "heads.dstop")
         dx = torch.empty_like(x)
         if GEMM_MODE == "x6":
-            _lib.check(lib.ttts_linear_bwd_data_x6(_p(dmel), _p(_planes(w_mel, 1, K, N)), None, _p(dx), M, N, K, _stream()),
+            _lib.check(lib.ttts_linear_bwd_data_x6(_p(dmel), _p(_planes(w_mel, 1, K, N)), None, _p(dx), M, N, K, None, 1.0,
+                                                   _stream()),
                        "ttts_linear_bwd_data_x6")
         else:
-            _lib.check(lib.ttts_linear_bwd_data(_p(dmel), _p(w_mel), None, _p(dx), M, N, K, _stream()),
+            _lib.check(lib.ttts_linear_bwd_data(_p(dmel), _p(w_mel), None, _p(dx), M, N, K, None, 1.0, _stream()),
                        "ttts_linear_bwd_data")
         ws = _ws(lib.ttts_wgrad_workspace_bytes(M, N, K, 1), x.device)
         sk, acc = ctx.sinks
