@@ -397,7 +397,7 @@ static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t stream) {
     return TTTS_OK;
 }
 
-enum { TILE_AUTO = 0, TILE_64 = 1, TILE_128 = 2, TILE_64x128 = 3, TILE_128x96 = 4 };
+enum { TILE_AUTO = 0, TILE_64 = 1, TILE_128 = 2, TILE_64x128 = 3, TILE_128x96 = 4, TILE_96x128 = 5 };
 
 // Pick the tile that minimises the busiest CU's work: ceil(tiles / 256 CUs) workgroups in sequence, each costing
 // its area divided by how efficiently that tile shape runs.  E.g. M = 55 680, N = 256 in fp32: 870 tiles of 128x128
@@ -941,6 +941,7 @@ static int dispatch_wgrad_split(const GemmArgs& g, int zdim, int tile, hipStream
     switch (tile) {
         case TILE_64: return launch_wgrad_split<64, 64, 2, 2>(g, zdim, stream);
         case TILE_128x96: return launch_wgrad_split<128, 96, 4, 1>(g, zdim, stream);
+        case TILE_96x128: return launch_wgrad_split<96, 128, 1, 4>(g, zdim, stream);
         default: return launch_wgrad_split<128, 128, 2, 2>(g, zdim, stream);
     }
 }
@@ -970,6 +971,7 @@ static WgradPlan plan_wgrad(int64_t M, int N, int K, int taps, bool x6 = false) 
         // the split-precision kernel wants the large tile (its per-thread staging work is fixed per k-step); small
         // outputs get more row splits instead, capped so that the partial sums stay a few tens of MB
         if (N <= 64 && K <= 64) { p.tile = TILE_64; tiles = (long)cdiv(N, 64) * cdiv(K, 64) * taps; }
+        else if (N <= 96 && K > 96) p.tile = TILE_96x128;          // 80-wide mel outputs
     } else if (tiles < 16) {
         p.tile = TILE_64; tiles = (long)cdiv(N, 64) * cdiv(K, 64) * taps;
     }
@@ -984,8 +986,9 @@ static WgradPlan plan_wgrad(int64_t M, int N, int K, int taps, bool x6 = false) 
     return p;
 }
 
-// the split-precision weight-gradient kernel pays off when both output dimensions fill its 128-wide tiles
-static bool wgrad_use_x6(int N, int K) { return N >= 128 && K >= 128; }
+// the split-precision weight-gradient kernel pays off when its 128-wide (or 96-wide, for the 80-channel mel side) tiles
+// are reasonably full
+static bool wgrad_use_x6(int N, int K) { return (N >= 128 || N == 80 || N == 96) && (K >= 128 || K == 80 || K == 96) && (N >= 128 || K >= 128); }
 
 }  // namespace ttts
 
