@@ -33,6 +33,24 @@ constexpr int QB = 128;           // rows per workgroup (4 waves x 32)
 constexpr float NEG_INF = -__builtin_inff();
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
+// Row loads go through a raw buffer descriptor spanning `nrows` rows of the (batch, head) slice: a row index past the
+// end gives an offset outside the descriptor and the hardware returns zeros.  A predicated global load ("if (row <
+// nrows) v = *p") instead compiles to branch + load + s_waitcnt vmcnt(0) and serialises the loads of a stage.
+struct RowSrc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int ld;
+};
+__device__ __forceinline__ RowSrc row_src(const float* base, long nrows, int ld) {
+    RowSrc r;
+    r.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (uint32_t)(nrows * ld * 4), 0x00020000);
+    r.ld = ld;
+    return r;
+}
+__device__ __forceinline__ float4 row_load4(const RowSrc& s, long row, int c4) {
+    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (int)(uint32_t)((row * s.ld + c4 * 4) * 4), 0, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
 struct AttnArgs {
     const float* q; const float* k; const float* v;
     float* o; float* lse; float* attn;
@@ -51,13 +69,13 @@ template <bool PADDED>
 __device__ __forceinline__ void stage_rows(const float* base, long row0, long nrows_total, int ld, int tid, float* dst,
                                            float scale) {
     constexpr int LDD = PADDED ? KT_LD : HD;
+    const RowSrc src = row_src(base, nrows_total, ld);
     float4 v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int row = (tid >> 4) + 16 * i, c4 = tid & 15;
         long gr = row0 + row;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr < nrows_total) v[i] = *reinterpret_cast<const float4*>(base + gr * ld + c4 * 4);
+        v[i] = row_load4(src, gr, c4);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -73,14 +91,18 @@ __device__ __forceinline__ void stage_rows(const float* base, long row0, long nr
 // one wave stages its own 32 x 64 tile (rows beyond nrows_total -> 0) into `dst` (stride KT_LD)
 __device__ __forceinline__ void wave_stage_tile(const float* base, long row0, long nrows_total, int ld, int lane,
                                                 float* dst, float scale) {
+    const RowSrc src = row_src(base, nrows_total, ld);
+    float4 v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         int row = (lane >> 4) + 4 * i, c4 = lane & 15;
-        long gr = row0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr < nrows_total) v = *reinterpret_cast<const float4*>(base + gr * ld + c4 * 4);
+        v[i] = row_load4(src, row0 + row, c4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int row = (lane >> 4) + 4 * i, c4 = lane & 15;
         float* d = dst + row * KT_LD + c4 * 4;
-        d[0] = v.x * scale; d[1] = v.y * scale; d[2] = v.z * scale; d[3] = v.w * scale;
+        d[0] = v[i].x * scale; d[1] = v[i].y * scale; d[2] = v[i].z * scale; d[3] = v[i].w * scale;
     }
 }
 __device__ __forceinline__ void wave_lds_sync() {
@@ -528,13 +550,12 @@ __device__ __forceinline__ int xsw(int row, int chunk) { return row * 32 + ((chu
 // 64 rows x 64 floats (row-major, d fast) -> planes[3][64][64]; rows beyond nrows_total are zero
 __device__ __forceinline__ void stage_split_rows(const float* base, long row0, long nrows_total, int ld, int tid,
                                                  uint32_t* dst) {
+    const RowSrc src = row_src(base, nrows_total, ld);
     float4 v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (tid >> 4) + 16 * i, c4 = tid & 15;
-        const long gr = row0 + row;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr < nrows_total) v[i] = *reinterpret_cast<const float4*>(base + gr * ld + c4 * 4);
+        v[i] = row_load4(src, row0 + row, c4);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -551,13 +572,10 @@ __device__ __forceinline__ void stage_split_rows(const float* base, long row0, l
 __device__ __forceinline__ void stage_split_cols(const float* base, long row0, long nrows_total, int ld, int tid,
                                                  uint32_t* dst) {
     const int dq = tid & 15, kq = tid >> 4;
+    const RowSrc src = row_src(base, nrows_total, ld);
     float4 v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long gr = row0 + 4 * kq + i;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr < nrows_total) v[i] = *reinterpret_cast<const float4*>(base + gr * ld + dq * 4);
-    }
+    for (int i = 0; i < 4; ++i) v[i] = row_load4(src, row0 + 4 * kq + i, dq);
     // keys 4kq..4kq+3 sit at positions pos..pos+3 of their row
     const int pos = (kq >> 3) * 32 + ((kq >> 2) & 1) * 16 + (kq & 1) * 8 + ((kq >> 1) & 1) * 4;
     const float x[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x}, {v[0].y, v[1].y, v[2].y, v[3].y},
@@ -817,14 +835,11 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDX_W) void attn_fwd_x6_ke
 // transposed pairs are re-packed from the row-major ones with v_perm_b32 instead of being split again).
 __device__ __forceinline__ void patch_load(const float* base, long row0, long nrows_total, int ld, int rq, int dq,
                                            float scale, float4 (&v)[4]) {
+    const RowSrc src = row_src(base, nrows_total, ld);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const long gr = row0 + 4 * rq + i;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr < nrows_total) {
-            v[i] = *reinterpret_cast<const float4*>(base + gr * ld + dq * 4);
-            v[i].x *= scale; v[i].y *= scale; v[i].z *= scale; v[i].w *= scale;
-        }
+        v[i] = row_load4(src, row0 + 4 * rq + i, dq);
+        v[i].x *= scale; v[i].y *= scale; v[i].z *= scale; v[i].w *= scale;
     }
 }
 // rows 4rq..4rq+3, columns 4dq..4dq+3 -> row-major planes `rows` (stride XPR dwords per plane, 128-byte rows) and, when

@@ -663,9 +663,17 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
         }
     }
 
-    // ---------------- epilogue (same as the fp32 kernel)
+    // ---------------- epilogue.  The auxiliary operands (residual; the forward activation whose relu / dropout mask gates a
+    // data gradient) are read through buffer descriptors: rows past M fall outside the descriptor and columns past N get
+    // an out-of-range offset, so no load sits behind a branch -- a predicated global load compiles to "branch, load,
+    // s_waitcnt vmcnt(0)" and serialises every one of the 16 loads of a tile.
     float* C = g.C;
     const bool do_drop = g.drop_thr != 0u;
+    const bool has_gate = g.relu_out != nullptr, has_res = g.residual != nullptr;
+    const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_gate ? g.relu_out : g.A), 0, has_gate ? (uint32_t)((long)g.M * g.ldc * 4) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_res ? g.residual : g.A), 0, has_res ? (uint32_t)((long)g.M * g.ldr * 4) : 0u, 0x00020000);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -674,27 +682,25 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
             const bool col_ok = col < g.N;
             const float bv = (g.bias != nullptr && col_ok) ? g.bias[col] : 0.f;
             const int row0 = m0 + wm * WTM + i * 32;
-            float res[16];
-            if (g.residual != nullptr) {
+            float res[16], gsrc[16];
+            if (has_res) {                 // block-uniform: one scalar branch around the whole group of loads
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + acc_row(r, half);
-                    res[r] = (row < g.M && col_ok) ? g.residual[(long)row * g.ldr + col] : 0.f;
+                    const long row = row0 + acc_row(r, half);
+                    res[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        rsrcR, (int)(col_ok ? (uint32_t)((row * g.ldr + col) * 4) : OOB), 0, 0));
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) res[r] = 0.f;
             }
-            float gate[16];
-            if (g.relu_out != nullptr) {
+            if (has_gate) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + acc_row(r, half);
-                    gate[r] = (row < g.M && col_ok && g.relu_out[(long)row * g.ldc + col] > 0.f) ? g.relu_scale : 0.f;
+                    const long row = row0 + acc_row(r, half);
+                    gsrc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        rsrcG, (int)(col_ok ? (uint32_t)((row * g.ldc + col) * 4) : OOB), 0, 0));
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gate[r] = 1.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -705,7 +711,8 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
                     uint64_t idx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
                     v = keep_elem(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
                 }
-                v = v * gate[r] + res[r];
+                if (has_gate) v = gsrc[r] > 0.f ? v * g.relu_scale : 0.f;
+                v += res[r];
                 if (row < g.M && col_ok) C[(long)row * g.ldc + col] = v;
             }
         }
