@@ -1046,14 +1046,25 @@ constexpr int DKVX_DW = 6 * XPQ + 6 * XPT + 2 * RAWQ + 256;   // planes 48 KB + 
 static_assert(DKVX_DW >= SMEM_FLOATS, "per-wave fp32 scratch must fit the stage buffers");
 constexpr int DKVX_SMEM = DKVX_DW * 4;   // 66 048 bytes: dynamic (above the 64 KB static limit)
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
-__device__ __forceinline__ void dma16(const float* src, uint32_t* lds_wave_base) {
-    // 64 lanes x 16 bytes: lane i lands at lds_wave_base + 16 i (the destination is wave-uniform base + lane * size)
-    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
+// LDS-DMA through inline assembly: with the builtin, hipcc treats an in-flight DMA as a pending LDS write and puts
+// s_waitcnt vmcnt(0) in front of the NEXT LDS READ of any address -- i.e. it waits for the prefetch at the first fragment
+// read of the stage it was supposed to overlap.  An asm statement is outside hipcc's counter bookkeeping; the kernel
+// waits for its DMAs itself (vmcnt(0) before the barrier that publishes the stage).  M0 (the LDS destination base) is
+// saved and restored inside the statement.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
-__device__ __forceinline__ void dma4(const float* src, uint32_t* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)lds_wave_base, 4, 0, 0);
+// source = wave-uniform base pointer (SGPR pair) + per-lane 32-bit byte offset: one VGPR per request
+__device__ __forceinline__ void dma16(const float* base, uint32_t lane_off, uint32_t* lds_wave_base) {
+    // 64 lanes x 16 bytes: lane i lands at lds_wave_base + 16 i (the destination is wave-uniform base + lane * size)
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(lds_addr(lds_wave_base)), "s"(base) : "memory");
+}
+__device__ __forceinline__ void dma4(const float* base, uint32_t lane_off, uint32_t* lds_wave_base) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(lds_addr(lds_wave_base)), "s"(base) : "memory");
 }
 
 template <bool CAUSAL>
@@ -1110,20 +1121,24 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
 
     // DMA of one stage: wave w moves rows 8w..8w+7 of Q and of dO (two 1-KB instructions each), wave 0 also lse / delta.
     // Rows past Tq are clamped to the last row here and zeroed when they are split.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar copy: the DMA destinations must not cost VGPRs
+    const int dma_row = 8 * wave + (lane >> 4);
+    const uint32_t dma_col = (uint32_t)(lane & 15) * 16u;
+    const float* lse_b = a.lse + arow;
+    const float* delta_b = a.delta + arow;
     auto fetch = [&](int qt0, int sb) {
+        if (wave_u == 0) {     // first: whatever the allocator does to this address must not wait on the big requests
+            int q = qt0 + l31;
+            if (q > a.Tq - 1) q = a.Tq - 1;
+            dma4(lse_b, (uint32_t)q * 4u, reinterpret_cast<uint32_t*>(stat_s + sb * 128));
+            dma4(delta_b, (uint32_t)q * 4u, reinterpret_cast<uint32_t*>(stat_s + sb * 128 + 64));
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int row = 8 * wave + 4 * j + (lane >> 4);
-            long gr = (long)qt0 + row;
+            int gr = qt0 + dma_row + 4 * j;
             if (gr > a.Tq - 1) gr = a.Tq - 1;
-            dma16(qb_ + gr * a.ldq + (lane & 15) * 4, rawQ + (8 * wave + 4 * j) * 64);
-            dma16(gb_ + gr * a.ldo + (lane & 15) * 4, rawG + (8 * wave + 4 * j) * 64);
-        }
-        if (wave == 0) {
-            long q = (long)qt0 + l31;
-            if (q > a.Tq - 1) q = a.Tq - 1;
-            dma4(a.lse + arow + q, reinterpret_cast<uint32_t*>(stat_s + sb * 128));
-            dma4(a.delta + arow + q, reinterpret_cast<uint32_t*>(stat_s + sb * 128 + 64));
+            dma16(qb_, (uint32_t)gr * (uint32_t)(a.ldq * 4) + dma_col, rawQ + (8 * wave_u + 4 * j) * 64);
+            dma16(gb_, (uint32_t)gr * (uint32_t)(a.ldo * 4) + dma_col, rawG + (8 * wave_u + 4 * j) * 64);
         }
     };
 
