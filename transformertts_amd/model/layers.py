@@ -48,16 +48,18 @@ class MultiheadAttention(nn.Module):
 
     def self_attention(self, x: Tensor, lens: Tensor, causal: bool, residual: Tensor, out_drop: float) -> Tensor:
         """residual + drop(out_proj(attention(in_proj(x))))"""
-        qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias)
+        skip = ops.SkipToken() if residual is x else None      # the skip gradient rides in the in-projection's epilogue
+        qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias, skip_in=skip)
         p = self._p()
         ctx = ops.SelfAttentionFn.apply(qkv, lens, self.num_heads, causal, p, ops.seeds.next() if p > 0 else 0)
         return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, drop_p=out_drop,
-                          seed=ops.seeds.next() if out_drop > 0 else 0)
+                          seed=ops.seeds.next() if out_drop > 0 else 0, skip_out=skip)
 
     def cross_attention(self, x: Tensor, mem: Tensor, mem_lens: Tensor, residual: Tensor, out_drop: float,
                         need_weights: bool = True):
         d = self.embed_dim
-        q = ops.linear(x, ops.param_rows(self.in_proj_weight, 0, d), ops.param_rows(self.in_proj_bias, 0, d))
+        skip = ops.SkipToken() if residual is x else None
+        q = ops.linear(x, ops.param_rows(self.in_proj_weight, 0, d), ops.param_rows(self.in_proj_bias, 0, d), skip_in=skip)
         kv = ops.linear(mem, ops.param_rows(self.in_proj_weight, d, 3 * d), ops.param_rows(self.in_proj_bias, d, 3 * d))
         p = self._p()
         ctx, attn = ops.CrossAttentionFn.apply(q, kv, mem_lens, self.num_heads, p, ops.seeds.next() if p > 0 else 0,
@@ -65,7 +67,7 @@ class MultiheadAttention(nn.Module):
         if not need_weights:
             attn = None
         out = ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, drop_p=out_drop,
-                         seed=ops.seeds.next() if out_drop > 0 else 0)
+                         seed=ops.seeds.next() if out_drop > 0 else 0, skip_out=skip)
         return out, attn
 
 
@@ -74,10 +76,11 @@ def _ffn_block(layer, x: Tensor, out_dropout: nn.Dropout) -> Tensor:
     the second's (torch `_ff_block`, torch/nn/modules/transformer.py:980-982,1197-1199)."""
     p = layer.dropout.p if layer.training else 0.0
     po = out_dropout.p if layer.training else 0.0
+    skip = ops.SkipToken()
     h = ops.linear(x, layer.linear1.weight, layer.linear1.bias, act=ops.ACT_RELU, drop_p=p,
-                   seed=ops.seeds.next() if p > 0 else 0)
+                   seed=ops.seeds.next() if p > 0 else 0, skip_in=skip)
     return ops.linear(h, layer.linear2.weight, layer.linear2.bias, residual=x, drop_p=po,
-                      seed=ops.seeds.next() if po > 0 else 0, sole_consumer=True)   # h feeds nothing else: mask fused
+                      seed=ops.seeds.next() if po > 0 else 0, sole_consumer=True, skip_out=skip)   # h feeds nothing else
 
 
 class TransformerEncoderLayer(nn.Module):

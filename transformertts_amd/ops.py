@@ -223,7 +223,8 @@ class LinearFn(torch.autograd.Function):
     """y = drop(act(x @ w.T + b)) + residual, rows optionally shifted by `row_shift` inside each utterance."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out=None, tok_in=None):
+    def forward(ctx, x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out=None, tok_in=None, skip_in=None,
+                skip_out=None):
         lib = _lib.load()
         x = _chk(x, "linear.x")
         w = _chk(w, "linear.weight")
@@ -247,7 +248,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
         ctx.cfg = (act, float(drop_p), seed, row_shift, T, b is not None, residual is not None)
         ctx.sinks = _sinks(w, b)
-        ctx.toks = (tok_out, tok_in)
+        ctx.toks = (tok_out, tok_in, skip_in, skip_out)
         return y
 
     @staticmethod
@@ -255,7 +256,7 @@ class LinearFn(torch.autograd.Function):
         lib = _lib.load()
         x, w, y = ctx.saved_tensors
         act, drop_p, seed, row_shift, T, has_b, has_r = ctx.cfg
-        tok_out, tok_in = ctx.toks
+        tok_out, tok_in, skip_in, skip_out = ctx.toks
         N, K = w.shape
         M = x.numel() // K
         dy = _chk(dy, "linear.dy")
@@ -277,11 +278,16 @@ class LinearFn(torch.autograd.Function):
                 raise RuntimeError("linear: input gradient through a shifted loader is not needed on this path")
             dx = torch.empty_like(x)
             gate, gscale = (x, tok_in.scale) if tok_in is not None else (None, 1.0)
+            skip = None                    # gradient of the block's skip connection, left here by the block's last Linear
+            if skip_in is not None and skip_in.grad is not None:
+                skip, skip_in.grad = skip_in.grad, None
+                if skip.shape != x.shape or not skip.is_contiguous():
+                    raise RuntimeError("linear: skip-connection gradient does not match the block input")
             if GEMM_MODE == "x6":
-                _lib.check(lib.ttts_linear_bwd_data_x6(_p(dacc), _p(_planes(w, 1, K, N)), None, _p(dx), M, N, K,
+                _lib.check(lib.ttts_linear_bwd_data_x6(_p(dacc), _p(_planes(w, 1, K, N)), _p(skip), _p(dx), M, N, K,
                                                        _p(gate), gscale, _stream()), "ttts_linear_bwd_data_x6")
             else:
-                _lib.check(lib.ttts_linear_bwd_data(_p(dacc), _p(w), None, _p(dx), M, N, K, _p(gate), gscale, _stream()),
+                _lib.check(lib.ttts_linear_bwd_data(_p(dacc), _p(w), _p(skip), _p(dx), M, N, K, _p(gate), gscale, _stream()),
                            "ttts_linear_bwd_data")
             if tok_in is not None:
                 tok_in.premasked = True
@@ -297,7 +303,10 @@ class LinearFn(torch.autograd.Function):
             _lib.check(_wgrad_fn(lib, "ttts_linear_bwd_weight")(_p(dacc), _p(x), _p(dw_t), _p(db_t), _p(ws), ws.numel() * 4,
                                                                  M, N, K, row_shift, T, acc, _stream()),
                        "ttts_linear_bwd_weight")
-        return dx, dw, db, (dy if has_r else None), None, None, None, None, None, None, None
+        dres = dy if has_r else None
+        if has_r and skip_out is not None:      # hand the skip gradient to the block's first Linear instead of autograd
+            skip_out.grad, dres = dy, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
 class _ReluToken:
@@ -309,12 +318,30 @@ class _ReluToken:
         self.scale, self.premasked = scale, False
 
 
-def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_shift=0, T=0, sole_consumer=False):
+class SkipToken:
+    """Residual block `y = last(f(first(x))) + x` whose first and last ops are Linears: the last one's backward parks
+    the skip-connection gradient here and the first one adds it in its data-gradient epilogue, instead of autograd
+    summing two full-size tensors with a separate kernel.  Pass the same token as `skip_in` to the first Linear (its
+    input must be the block input x) and as `skip_out` to the last one (its `residual` must be the same x)."""
+    __slots__ = ("grad",)
+
+    def __init__(self):
+        self.grad = None
+
+
+def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_shift=0, T=0, sole_consumer=False,
+           skip_in=None, skip_out=None):
     """`sole_consumer=True` is the caller's promise that nothing but this Linear reads `x`; if `x` came out of a
-    relu(+dropout) Linear, its backward mask is then fused into this Linear's data-gradient epilogue."""
-    tok_in = getattr(x, "_ttts_relu_token", None) if (sole_consumer and torch.is_grad_enabled()) else None
+    relu(+dropout) Linear, its backward mask is then fused into this Linear's data-gradient epilogue.
+    `skip_in` / `skip_out`: see SkipToken."""
+    grad_on = torch.is_grad_enabled()
+    tok_in = getattr(x, "_ttts_relu_token", None) if (sole_consumer and grad_on) else None
     tok_out = _ReluToken(1.0 / (1.0 - float(drop_p))) if act == ACT_RELU else None
-    y = LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out, tok_in)
+    if not (grad_on and x.requires_grad):
+        skip_in = None                      # nobody will pick the gradient up: leave it to autograd
+    if skip_out is not None and (residual is None or not grad_on):
+        skip_out = None
+    y = LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out, tok_in, skip_in, skip_out)
     if tok_out is not None:
         y._ttts_relu_token = tok_out
     return y
