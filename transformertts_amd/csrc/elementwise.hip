@@ -185,35 +185,59 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict
     }
 }
 
-constexpr int RD_BWD_BLOCKS = 256;
+constexpr int RD_BWD_BLOCKS = 1024;
 
-// dx[m,:] += dy[m]*w ; per-block partials of dw[c] = sum_m dy[m]*x[m,c] and db = sum_m dy[m] -> ws[block][d+1]
+// dx[m,:] += dy[m]*w ; per-block partials of dw[c] = sum_m dy[m]*x[m,c] and db = sum_m dy[m] -> ws[block][d+1].
+// One wave per row, a float4 of 4 consecutive columns per lane (d <= 1024, d % 4 == 0), two rows in flight per wave:
+// the kernel is a read-modify-write stream over dx, so what matters is independent loads in flight.
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ w, float* __restrict__ dx,
                                                          float* __restrict__ ws, long M, int d) {
     __shared__ float red[4][1025];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int MAXPER = 16;
-    const int nper = d >> 6;
-    float acc[MAXPER], wv[MAXPER];
+    constexpr int MAXV = 4;                       // float4s per lane: columns lane*4 + 256*i
+    float4 acc[MAXV], wv[MAXV];
     float accb = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXPER; ++i) { acc[i] = 0.f; wv[i] = (i < nper) ? w[lane + 64 * i] : 0.f; }
-    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
-        const float g = dy[row];
-        accb += g;
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        wv[i] = (c < d) ? *reinterpret_cast<const float4*>(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const long stride = (long)gridDim.x * 4;
+    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += 2 * stride) {
+        const long row2 = row + stride;
+        const bool two = row2 < M;
+        const float g0 = dy[row], g1 = two ? dy[row2] : 0.f;
+        accb += g0 + g1;
 #pragma unroll
-        for (int i = 0; i < MAXPER; ++i) {
-            if (i < nper) {
-                long e = row * d + lane + 64 * i;
-                acc[i] += g * x[e];
-                if (dx) dx[e] += g * wv[i];
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < d) {                           // wave-uniform per i except in the last, partial group of lanes
+                const float4 x0 = *reinterpret_cast<const float4*>(x + row * d + c);
+                const float4 x1 = two ? *reinterpret_cast<const float4*>(x + row2 * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc[i].x += g0 * x0.x + g1 * x1.x; acc[i].y += g0 * x0.y + g1 * x1.y;
+                acc[i].z += g0 * x0.z + g1 * x1.z; acc[i].w += g0 * x0.w + g1 * x1.w;
+                if (dx) {
+                    float4* p0 = reinterpret_cast<float4*>(dx + row * d + c);
+                    float4 a0 = *p0;
+                    a0.x += g0 * wv[i].x; a0.y += g0 * wv[i].y; a0.z += g0 * wv[i].z; a0.w += g0 * wv[i].w;
+                    if (two) {
+                        float4* p1 = reinterpret_cast<float4*>(dx + row2 * d + c);
+                        float4 a1 = *p1;
+                        a1.x += g1 * wv[i].x; a1.y += g1 * wv[i].y; a1.z += g1 * wv[i].z; a1.w += g1 * wv[i].w;
+                        *p1 = a1;
+                    }
+                    *p0 = a0;
+                }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < MAXPER; ++i)
-        if (i < nper) red[wave][lane + 64 * i] = acc[i];
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < d) { red[wave][c] = acc[i].x; red[wave][c + 1] = acc[i].y; red[wave][c + 2] = acc[i].z; red[wave][c + 3] = acc[i].w; }
+    }
     if (lane == 0) red[wave][1024] = accb;
     __syncthreads();
     for (int c = threadIdx.x; c < d; c += 256)
