@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------ BatchNorm
-constexpr int BN_MAXBLK = 128;
+constexpr int BN_MAXBLK = 512;   // row chunks: enough waves (and bytes in flight) to stream at HBM rate
 
 // per (row-chunk, channel): count, mean, M2 = sum (x - mean)^2.  Block = 64 channels x 4 row-lanes; two passes over the
 // chunk (the second one hits L2) so no division sits in the streaming loops; merged deterministically afterwards.
@@ -114,26 +114,29 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
     const float n = (float)(r1 - r0);
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (ok) {
         long r = r0 + rl;
-        for (; r + 4 < r1; r += 8) { s0 += x[r * C + c]; s1 += x[(r + 4) * C + c]; }
-        if (r < r1) s0 += x[r * C + c];
+        for (; r + 12 < r1; r += 16) {       // four independent loads in flight per thread
+            s0 += x[r * C + c]; s1 += x[(r + 4) * C + c]; s2 += x[(r + 8) * C + c]; s3 += x[(r + 12) * C + c];
+        }
+        for (; r < r1; r += 4) s0 += x[r * C + c];
     }
-    red[rl][cl] = s0 + s1;
+    red[rl][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     const float mean = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / n;
     __syncthreads();
-    float q0 = 0.f, q1 = 0.f;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
     if (ok) {
         long r = r0 + rl;
-        for (; r + 4 < r1; r += 8) {
-            float a = x[r * C + c] - mean, b = x[(r + 4) * C + c] - mean;
-            q0 += a * a; q1 += b * b;
+        for (; r + 12 < r1; r += 16) {
+            float a = x[r * C + c] - mean, b = x[(r + 4) * C + c] - mean, d2 = x[(r + 8) * C + c] - mean,
+                  e2 = x[(r + 12) * C + c] - mean;
+            q0 += a * a; q1 += b * b; q2 += d2 * d2; q3 += e2 * e2;
         }
-        if (r < r1) { float a = x[r * C + c] - mean; q0 += a * a; }
+        for (; r < r1; r += 4) { float a = x[r * C + c] - mean; q0 += a * a; }
     }
-    red[rl][cl] = q0 + q1;
+    red[rl][cl] = (q0 + q1) + (q2 + q3);
     __syncthreads();
     if (rl == 0 && ok) {
         float* w = ws + ((long)blockIdx.y * 3) * C;
@@ -149,38 +152,41 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
                                                              float* __restrict__ invstd_out, float* __restrict__ running_mean,
                                                              float* __restrict__ running_var, int64_t* __restrict__ nbt,
                                                              int nblk, int C, float momentum, float eps) {
+    // merge of the row-chunk partials without a serial chain of divisions: N = sum n_b, mean = sum n_b mean_b / N, then
+    // M2 = sum [M2_b + n_b (mean_b - mean)^2] (the pooled-variance identity, centred on the global mean).  16 channels
+    // x 16 chunk-lanes per block, fixed summation order.
     __shared__ float sn[16][17], sm[16][17], sq[16][17];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
+    float n = 0.f, sw = 0.f;
     if (c < C) {
         for (int b = rl; b < nblk; b += 16) {
             const float* w = ws + ((long)b * 3) * C;
-            float nb = w[c], mb = w[C + c], m2b = w[2 * C + c];
-            if (nb > 0.f) {
-                float nn = n + nb;
-                float dlt = mb - mean;
-                mean += dlt * (nb / nn);
-                m2 += m2b + dlt * dlt * (n * nb / nn);
-                n = nn;
-            }
+            const float nb = w[c];
+            n += nb;
+            sw += nb * w[C + c];
         }
     }
-    sn[rl][cl] = n; sm[rl][cl] = mean; sq[rl][cl] = m2;
+    sn[rl][cl] = n; sm[rl][cl] = sw;
+    __syncthreads();
+    n = 0.f; sw = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { n += sn[i][cl]; sw += sm[i][cl]; }
+    const float mean = (n > 0.f) ? sw / n : 0.f;
+    float m2 = 0.f;
+    if (c < C) {
+        for (int b = rl; b < nblk; b += 16) {
+            const float* w = ws + ((long)b * 3) * C;
+            const float dlt = w[C + c] - mean;
+            m2 += w[2 * C + c] + w[c] * dlt * dlt;
+        }
+    }
+    sq[rl][cl] = m2;
     __syncthreads();
     if (rl == 0 && c < C) {
-        n = 0.f; mean = 0.f; m2 = 0.f;
+        m2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float nb = sn[i][cl], mb = sm[i][cl], m2b = sq[i][cl];
-            if (nb > 0.f) {
-                float nn = n + nb;
-                float dlt = mb - mean;
-                mean += dlt * (nb / nn);
-                m2 += m2b + dlt * dlt * (n * nb / nn);
-                n = nn;
-            }
-        }
+        for (int i = 0; i < 16; ++i) m2 += sq[i][cl];
         float var = m2 / n;
         mean_out[c] = mean;
         invstd_out[c] = 1.0f / sqrtf(var + eps);
@@ -254,6 +260,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     float s1 = 0.f, s2 = 0.f;
     if (ok) {
         const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+#pragma unroll 4
         for (long r = r0 + rl; r < r1; r += 4) {
             long e = r * C + c;
             float xh = (x[e] - mu) * is;
