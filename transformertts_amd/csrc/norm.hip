@@ -153,14 +153,14 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
                                                              float* __restrict__ running_var, int64_t* __restrict__ nbt,
                                                              int nblk, int C, float momentum, float eps) {
     // merge of the row-chunk partials without a serial chain of divisions: N = sum n_b, mean = sum n_b mean_b / N, then
-    // M2 = sum [M2_b + n_b (mean_b - mean)^2] (the pooled-variance identity, centred on the global mean).  16 channels
-    // x 16 chunk-lanes per block, fixed summation order.
-    __shared__ float sn[16][17], sm[16][17], sq[16][17];
-    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    // M2 = sum [M2_b + n_b (mean_b - mean)^2] (the pooled-variance identity, centred on the global mean).  4 channels
+    // x 64 chunk-lanes per block (the loop is latency bound: short trips, many lanes), fixed summation order.
+    __shared__ float sn[64][5], sm[64][5], sq[64][5];
+    const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
     float n = 0.f, sw = 0.f;
     if (c < C) {
-        for (int b = rl; b < nblk; b += 16) {
+        for (int b = rl; b < nblk; b += 64) {
             const float* w = ws + ((long)b * 3) * C;
             const float nb = w[c];
             n += nb;
@@ -170,12 +170,12 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
     sn[rl][cl] = n; sm[rl][cl] = sw;
     __syncthreads();
     n = 0.f; sw = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { n += sn[i][cl]; sw += sm[i][cl]; }
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) { n += sn[i][cl]; sw += sm[i][cl]; }
     const float mean = (n > 0.f) ? sw / n : 0.f;
     float m2 = 0.f;
     if (c < C) {
-        for (int b = rl; b < nblk; b += 16) {
+        for (int b = rl; b < nblk; b += 64) {
             const float* w = ws + ((long)b * 3) * C;
             const float dlt = w[C + c] - mean;
             m2 += w[2 * C + c] + w[c] * dlt * dlt;
@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
     __syncthreads();
     if (rl == 0 && c < C) {
         m2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) m2 += sq[i][cl];
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) m2 += sq[i][cl];
         float var = m2 / n;
         mean_out[c] = mean;
         invstd_out[c] = 1.0f / sqrtf(var + eps);
@@ -381,7 +381,7 @@ int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* runni
     int nb = bn_blocks(M, &rpb);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(cdiv(C, 64), nb), dim3(256), 0, stream, x, ws, (long)M, C, rpb);
     TTTS_LAUNCH_CHECK("bn_stats_partial_kernel");
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 16)), dim3(256), 0, stream, ws, mean, invstd, running_mean,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, ws, mean, invstd, running_mean,
                        running_var, num_batches_tracked, nb, C, momentum, eps);
     TTTS_LAUNCH_CHECK("bn_stats_final_kernel");
     return TTTS_OK;
