@@ -674,13 +674,19 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
         const_cast<float*>(has_gate ? g.relu_out : g.A), 0, has_gate ? (uint32_t)((long)g.M * g.ldc * 4) : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(has_res ? g.residual : g.A), 0, has_res ? (uint32_t)((long)g.M * g.ldr * 4) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcBias = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.bias != nullptr ? g.bias : g.A), 0, g.bias != nullptr ? (uint32_t)g.N * 4u : 0u, 0x00020000);
+    float bias_v[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)      // columns past N (and a null bias) fall outside the descriptor: 0
+        bias_v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcBias, (n0 + wn * WTN + j * 32 + l31) * 4, 0, 0));
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * WTN + j * 32 + l31;
             const bool col_ok = col < g.N;
-            const float bv = (g.bias != nullptr && col_ok) ? g.bias[col] : 0.f;
+            const float bv = bias_v[j];
             const int row0 = m0 + wm * WTM + i * 32;
             float res[16], gsrc[16];
             if (has_res) {                 // block-uniform: one scalar branch around the whole group of loads
