@@ -12,6 +12,12 @@ Adam + Noam LR.  Dropout is ON (p = 0.5 / 0.1 as config.yaml), BatchNorm in trai
 Workload at N = 1: BASELINE.json configs[2] -- batch 64, d_model 256, 3+3 layers, 4 heads, dense synthetic
 LJSpeech-shaped batch (100 phonemes, 870 frames x 80 mels per utterance, seed 1234); weak scaling (64 per GPU).
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+The step is driven by `transformertts_amd.step.TrainStep`: after two eager steps it is captured into ONE HIP graph
+(zero-grad + both forwards + loss + backward + clip + Adam; at N > 1 the graph ends after backward and the RCCL
+all-reduce + optimizer kernels follow it on the stream) and replayed.  TTTS_GRAPH=0 keeps the eager launch path
+(with TTTS_DP_OVERLAP=1 the tail of the gradient bucket is then exchanged while backward is still in the encoder).
+Other configs: --config scaled --batch 32 (BASELINE configs[4] per-GPU shard), --batch 16 (configs[1] shape, fp32).
 """
 from __future__ import annotations
 
@@ -34,16 +40,24 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense
 
 
+TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")     # newest first; see tools/collect_traffic.py
+
+
 def measured_traffic(kernel: str):
-    """HBM bytes per launch of the dominant kernel from the committed PMC collection (separate rocprofv3 --pmc passes
-    of this same command, FETCH_SIZE doubled per the gfx950 note; profiles/r01_traffic.json), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            t = json.load(f)
+    """(HBM bytes per launch of `kernel`, source file) from the committed PMC collection -- separate rocprofv3
+    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command, FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md -- or (None, None).  PMC passes cannot run inside the timed bench, so the figure is a stamped
+    reading of the build named in the file, not of this run."""
+    for name in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+        except Exception:  # noqa: BLE001
+            continue
         ent = t.get(kernel)
-        return ent["hbm_bytes_per_launch"] if ent else None
-    except Exception:  # noqa: BLE001
-        return None
+        if ent:
+            return ent["hbm_bytes_per_launch"], f"profiles/{name}" + (f" ({t['_meta']})" if "_meta" in t else "")
+    return None, None
 
 
 def algorithmic_flops_forward(cfg, p: int, m: int) -> float:
@@ -132,10 +146,8 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(cfg, B: int, Tp: int, Tm: int, steps: int) -> dict:
-    """The oracle (CPU restatement, kind 'port') timed on this host's cores on a bounded sample of the same workload."""
-    from oracle import fill_state, synth_batch, oracle_training_step
-    torch.set_num_threads(usable_cores())
+def _cpu_point(cfg, B: int, Tp: int, Tm: int, steps: int):
+    from oracle import fill_state, synth_batch, oracle_training_step          # checker code, used here as the timed CPU port
     sd = fill_state(cfg, 42)
     for k, v in sd.items():
         if v.is_floating_point() and "running" not in k and k != "pe.pe":
@@ -152,9 +164,61 @@ def cpu_baseline(cfg, B: int, Tp: int, Tm: int, steps: int) -> dict:
         if i > 0:
             times.append(dt)
     med = statistics.median(times)
-    return {"value": B * Tm / med, "unit": "mel frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle training step (2 fwd + bwd, fp32, dropout on), dense batch {B} x {Tm} frames x {Tp} phonemes, "
-                      f"median of {len(times)} steps after 1 warm-up, {med:.2f} s/step"}
+    return {"batch": B, "frames": Tm, "phonemes": Tp, "s_per_step": med, "frames_per_s": B * Tm / med, "timed_steps": len(times)}
+
+
+def cpu_baseline(cfg, Tp: int, cfg_name: str) -> dict:
+    """The oracle (CPU restatement, kind 'port') timed on this host's cores on the two points SURVEY.md section 8d makes
+    mandatory: batch 1 x 600 frames (BASELINE configs[0]) and batch 16 x 870 frames (configs[1] shape); `value` is the
+    batch-16 point (the larger sample of the same workload as the GPU line).  About 20-30 s of CPU work in total."""
+    torch.set_num_threads(usable_cores())
+    p1 = _cpu_point(cfg, 1, Tp, 600, 5)
+    p16 = _cpu_point(cfg, 16, Tp, 870, 2 if cfg_name == "base" else 1)
+    return {"value": p16["frames_per_s"], "unit": "mel frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle training step (2 fwd + bwd, fp32, dropout on), {cfg_name} config, dense: batch 16 x 870 frames x {Tp} "
+                      f"phonemes, median of {p16['timed_steps']} after 1 warm-up, {p16['s_per_step']:.2f} s/step [value]; batch 1 x 600 "
+                      f"frames: {p1['frames_per_s']:.0f} frames/s, {p1['s_per_step']:.3f} s/step",
+            "points": [p1, p16]}
+
+
+def rehearsal_gradient_check(ts, rank: int, world: int) -> dict:
+    """Two gloo ranks on one GPU (TTTS_BENCH_REHEARSAL=1): the bucket after the exchange -- overlapped tail or single
+    collective, whichever this run uses -- must equal the MEAN of the ranks' single-process gradients (DDP semantics,
+    SURVEY.md section 8e).  Pass 1 computes this rank's local gradient with the exchange disabled, pass 2 repeats the
+    same step (same dropout seeds: site seeds restart per step, same step-state word) with the exchange on."""
+    from transformertts_amd import ops
+    state, bucket = ts.state, ts.bucket
+    fired0 = ts.trigger.fired if ts.trigger is not None else 0
+    state.push(seed=0x5EED + rank, lr=0.0, p_tf=1.0, step=1)
+    with state:
+        if ts.trigger is not None:
+            ts.trigger.enabled = False
+        ts._forward_backward()
+        local = bucket.flat.detach().cpu().double()
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        mean = sum(gathered) / world
+        if ts.trigger is not None:
+            ts.trigger.enabled = True
+        ts._forward_backward()
+        bucket.finish_allreduce(ts.group)
+    torch.cuda.synchronize()
+    got = bucket.flat.detach().cpu().double()
+    rel = float((got - mean).norm() / mean.norm())
+    differ = float((gathered[0] - gathered[-1]).norm() / mean.norm())          # the ranks really had different gradients
+    return {"rel_l2_vs_mean_of_rank_gradients": rel, "rank_gradients_differ_rel": differ,
+            "overlap_requested": ts.trigger is not None,
+            "tail_trigger_fired": bool(ts.trigger is not None and ts.trigger.fired == fired0 + 1)}
+
+
+def workload_name(args) -> str:
+    if args.config == "base" and args.batch == 64:
+        return "BASELINE configs[2] (batch 64, 1 GPU; per-GPU shard of configs[3])"
+    if args.config == "base" and args.batch == 16:
+        return "BASELINE configs[1] shape (batch 16) in fp32"
+    if args.config == "scaled":
+        return f"BASELINE configs[4] per-GPU shard (scaled model, batch {args.batch})"
+    return f"{args.config} config, batch {args.batch}"
 
 
 def main():
@@ -168,8 +232,6 @@ def main():
     ap.add_argument("--config", default="base")
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--no-probe", action="store_true")
     args = ap.parse_args()
 
@@ -194,29 +256,22 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from oracle.spec import model_config
-    from oracle.synth import synth_batch
     from transformertts_amd import _lib, ops
     from transformertts_amd.lightning_module import LightningModule
-    from transformertts_amd.parallel import FlatGradBucket, broadcast_module_state, overlap_tail_with_backward
+    from transformertts_amd.parallel import broadcast_module_state
+    from transformertts_amd.step import TrainStep
+    from transformertts_amd.workload import model_config, synth_batch
 
     cfg = model_config(args.config)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
               "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,
                            "sync_loss_every_step": False, "fused_clip_norm": 1.0}}
     torch.manual_seed(42)
-    ops.seeds.manual_seed(42 + rank)
     lm = LightningModule(config).to(dev)
     lm.train()
     broadcast_module_state(lm)
     opt_cfg = lm.configure_optimizers()          # FlatAdam: flat parameters / gradients / moments, clip folded in
     optimizer, scheduler = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
-    bucket = optimizer.bucket
-    # N > 1: the decoder / postnet / head gradients (55 % of the bucket) are exchanged while backward is still in the
-    # encoder side; TTTS_DP_OVERLAP=0 keeps the single all-reduce after backward
-    overlap = None
-    if world > 1 and os.environ.get("TTTS_DP_OVERLAP", "1") == "1":
-        overlap = overlap_tail_with_backward(bucket, lm.model, lm.model.decoder)
 
     # per-rank shard of the global synthetic batch (weak scaling: args.batch utterances per GPU)
     batch = synth_batch(args.batch, args.tp, args.tm, cfg["n_mels"], cfg["n_phon"], ragged=args.ragged, seed=1234 + rank)
@@ -225,14 +280,15 @@ def main():
     flops_rank = 4.0 * sum(algorithmic_flops_forward(cfg, int(p), int(m))
                            for p, m in zip(batch["phoneme_lens"].tolist(), batch["melspec_lens"].tolist()))
 
+    use_graph = os.environ.get("TTTS_GRAPH", "1") == "1"
+    want_overlap = os.environ.get("TTTS_DP_OVERLAP", "1") == "1"
+    # one step = zero-grad, training_step (2 forwards + loss), backward, [all-reduce], clip + Adam, scheduler.step();
+    # different ranks draw different dropout masks (seed 42 + rank)
+    ts = TrainStep(lm, optimizer, scheduler, batch, graph=use_graph, seed=42 + rank, overlap=want_overlap,
+                   eager_warmup=2)
+
     def step(i):
-        optimizer.zero_grad()
-        loss = lm.training_step(batch, i)
-        loss.backward()
-        bucket.finish_allreduce()                # waits for the overlapped tail and reduces the rest (no-op at N = 1)
-        optimizer.step()                         # global-norm clip (1.0) + Adam, two kernels over the flat bucket
-        scheduler.step()
-        return loss
+        return ts()
 
     def fence():
         if world > 1:
@@ -252,6 +308,11 @@ def main():
         note(f"warm-up step {i} done")
     # A full (generation-2) pass of Python's cyclic collector costs ~80 ms with torch's object graph loaded and tends to
     # fire a few steps into a run: collect now and freeze the survivors so that it cannot land inside the timed steps.
+    if use_graph:
+        while ts.index < 2:
+            step(ts.index)                       # --warmup < 2: the capture still needs two eager steps before it
+        ts.ensure_captured()                     # capture outside the timed region (nothing executes during capture)
+        note("step captured into a HIP graph")
     gc.collect()
     gc.freeze()
     fence()
@@ -272,9 +333,17 @@ def main():
     frames_all, flops_all = float(tot[0].item()), float(tot[1].item())
     final_loss = float(loss.item())
 
+    rehearsal_check = None
+    if rehearsal and world > 1:
+        rehearsal_check = rehearsal_gradient_check(ts, rank, world)
+        note(f"rehearsal gradient check: {rehearsal_check}")
+        if not rehearsal_check["rel_l2_vs_mean_of_rank_gradients"] <= 1e-6:
+            raise SystemExit(f"rehearsal: reduced gradients differ from the mean of the rank gradients: {rehearsal_check}")
+
     probe = None
     if not args.no_probe:
         # one extra, untimed step on EVERY rank (it contains the gradient all-reduce); rank 0 instruments it
+        ts.use_graph = False                     # the probe times individual launches: this step runs eagerly
         if rank == 0:
             with GemmProbe(_lib.load()) as gp:
                 step(args.warmup + args.steps)
@@ -291,31 +360,44 @@ def main():
             "value": frames_all * args.steps / elapsed, "unit": "mel frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: training step (no-grad fwd + fwd + loss + bwd + clip + Adam), "
+            "config": {"workload": f"{workload_name(args)}: training step (no-grad fwd + fwd + loss + bwd + clip + Adam), "
                                    f"batch {args.batch}/GPU x {args.tm} frames x {args.tp} phonemes "
                                    f"({'ragged' if args.ragged else 'dense'}), {args.config} config d_model {cfg['d_model']}, "
                                    f"{cfg['encoder_n_layers']}+{cfg['decoder_n_layers']} layers, dropout on, fp32",
                        "global_batch": args.batch * world, "frames_per_step": frames_all, "parallelism": f"dp{world}",
-                       "grad_allreduce": ("tail overlapped with backward" if overlap is not None else "one collective after backward"),
+                       "launch_path": ("one HIP graph per step (captured after the eager warm-up steps)" if ts.graphed
+                                       else "eager: one ctypes launch per kernel"),
+                       "grad_allreduce": ("none (1 GPU)" if world == 1 else
+                                          "tail overlapped with backward" if ts.trigger is not None
+                                          else "one collective after backward"),
                        "final_loss": final_loss, "per_step_loss_item_sync": False},
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "step_algorithmic_tflops": flops_all / 1e12,
             "step_achieved_tflops_per_gpu": flops_all / world / (elapsed / args.steps) / 1e12,
         }
+        if rehearsal_check is not None:
+            out["config"]["rehearsal_gradient_check"] = rehearsal_check
         if probe is not None:
-            # fp32 in / fp32 out / fp32-accurate products: priced against the fp32 MFMA peak of the dtype.  The
-            # split-precision kernel executes 6 bf16 MFMA flops per algorithmic flop; that rate and its fraction of the
-            # 2.5 PFLOP/s bf16 peak are reported next to it.
+            # The dominant kernel forms every fp32 product from SIX bf16 x bf16 MFMA terms (3-way split operands), so the
+            # unit that bounds it is the bf16 matrix pipe: its ceiling in algorithmic (fp32-equivalent) FLOP/s is the dense
+            # bf16 peak / 6.  `frac` is priced against THAT ceiling; the fp32-MFMA peak (157.3 TF, what a plain
+            # v_mfma_f32 kernel is bound by, and the peak of the dtype) is reported beside it as a floor the kernel beats.
+            traffic, traffic_src = measured_traffic(probe["kernel"])
+            if probe["x6"]:
+                peak, peak_note = PEAK_BF16_MFMA_TFLOPS / 6.0, "dense bf16 MFMA peak (2.5 PFLOP/s) / 6 MFMA terms per fp32 product"
+            else:
+                peak, peak_note = PEAK_F32_MFMA_TFLOPS, "fp32-input MFMA peak"
             out["roofline"] = {"bound": "mfma", "kernel": probe["kernel"],
-                               "achieved": probe["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": probe["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": measured_traffic(probe["kernel"]),
+                               "achieved": probe["tflops"], "peak": peak, "unit": "TFLOP/s",
+                               "frac": probe["tflops"] / peak, "peak_is": peak_note,
+                               "traffic": traffic, "traffic_source": traffic_src,
+                               "vs_fp32_mfma_peak": probe["tflops"] / PEAK_F32_MFMA_TFLOPS,
                                "launches_per_step": probe["launches"], "avg_launch_ms": probe["avg_ms"],
                                "avg_launch_gflop": probe["avg_flops"] / 1e9, "step_share_ms": probe["total_ms"]}
             if probe["x6"]:
                 out["roofline"]["executed_bf16_tflops"] = 6.0 * probe["tflops"]
-                out["roofline"]["frac_of_bf16_peak"] = 6.0 * probe["tflops"] / PEAK_BF16_MFMA_TFLOPS
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, args.tp, args.tm, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.tp, args.config)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -15,6 +15,11 @@
  *     ttts_last_error() returns a thread-local message for the last failure.
  *   - dropout masks are a pure function of (seed, flat element index), so backward entry points
  *     regenerate the forward mask from the same seed; p = 0 disables dropout.
+ *   - HIP-graph replay: kernel arguments are frozen when a graph is captured, so everything that changes from step to
+ *     step can ALSO be read from a small block of device memory (ttts_step_state): every `seed` argument is
+ *     accompanied by `step_seed` (NULL, or a device pointer whose 64-bit word is XORed into the seed when the kernel
+ *     runs -- &state->seed), and the optimizer / scheduled-sampling entry points take the state block itself.
+ *     The caller refreshes the block with one small host-to-device copy per step, outside the graph.
  */
 #ifndef TTTS_HIP_H
 #define TTTS_HIP_H
@@ -34,6 +39,15 @@ extern "C" {
 #define TTTS_ACT_RELU 1
 #define TTTS_ACT_TANH 2
 
+/* Per-step scalars a captured graph reads from device memory (32 bytes, fields at fixed offsets). */
+typedef struct ttts_step_state {
+    uint64_t seed;    /*  0: XORed into every dropout / sampling site seed of the step */
+    float lr;         /*  8: Adam learning rate of this step (base lr x Noam factor) */
+    float p_tf;       /* 12: teacher-forcing ratio of this step (utils/util.py:54-92) */
+    int64_t step;     /* 16: 1-based optimizer step count (Adam bias correction) */
+    int64_t reserved; /* 24 */
+} ttts_step_state;
+
 const char* ttts_last_error(void);
 int ttts_abi_version(void);
 
@@ -46,7 +60,8 @@ int ttts_abi_version(void);
  * row_shift = -1 with T = frames per utterance folds the go-frame shift of model/model.py:278-279
  * into the loader (row (b,t) reads x[b,t-1], zeros at t = 0). */
 int ttts_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, int64_t M,
-                    int N, int K, int act, float drop_p, uint64_t seed, int row_shift, int T, void* stream);
+                    int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift, int T,
+                    void* stream);
 /* dx[M,K] = gate * (dy[M,N] . w[N,K]) + residual[M,K]               N % 16 == 0, K % 4 == 0
  * residual may be NULL.  relu_out (NULL or (M,K)): the forward value of the activation dx is the gradient of, when that
  * activation is drop(relu(.)) of a preceding Linear (model/module.py:76-80 prenet, the torch FFN block): gate =
@@ -78,7 +93,8 @@ int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode
  * first_block}, first_block = running sum of ceil(rows*cols/256), total_blocks = the final sum */
 int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks, void* stream);
 int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
-                       int64_t M, int N, int K, int act, float drop_p, uint64_t seed, int row_shift, int T, void* stream);
+                       int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift, int T,
+                    void* stream);
 int ttts_linear_bwd_data_x6(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
                             int K, const float* relu_out, float relu_scale, void* stream);
 int ttts_conv1d_fwd_x6(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
@@ -118,11 +134,11 @@ int ttts_bn_eval_stats(const float* running_mean, const float* running_var, floa
                        void* stream);
 /* z = drop(act((x - mean) * invstd * gamma + beta)) */
 int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                      float* z, int64_t M, int C, int act, float drop_p, uint64_t seed, void* stream);
+                      float* z, int64_t M, int C, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 /* train-mode backward through drop/act/BN: dx, dgamma, dbeta from dz and the saved x, mean, invstd */
 int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float* invstd, const float* gamma,
                 const float* beta, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int C,
-                int act, float drop_p, uint64_t seed, int accumulate, void* stream);
+                int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm over the last dim (d % 64 == 0, d <= 1024)
  * Replaces nn.LayerNorm norm1/2/3 of the encoder/decoder layers (torch/nn/modules/transformer.py:951-956,
@@ -146,20 +162,20 @@ int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const
  * attn (optional) receives the per-head, post-dropout weights (B,H,Tq,Tk); lse (B,H,Tq) is saved for backward. */
 int ttts_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                        const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                       int causal, float drop_p, uint64_t seed, void* stream);
+                       int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 /* dq, dk, dv from do_ (recomputes the probabilities from q, k and lse); delta (B,H,Tq) is scratch */
 int ttts_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* do_,
                        const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                        int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                       int causal, float drop_p, uint64_t seed, void* stream);
+                       int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 /* Split-precision forms of the two entry points above (bf16x6 MFMA products, fp32-grade results; same arguments). */
 int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                          int causal, float drop_p, uint64_t seed, void* stream);
+                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 int ttts_attention_bwd_x6(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                          int causal, float drop_p, uint64_t seed, void* stream);
+                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 
 /* ------------------------------------------------------------------ small row / element-wise pieces
  * nn.Embedding gather / scatter-add (model/model.py:168,288; no padding_idx) */
@@ -168,14 +184,15 @@ int ttts_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int
                        void* stream);
 /* PositionalEncoding.forward (model/model.py:91-97): y = drop(x + alpha * pe[t]) */
 int ttts_posenc_fwd(const float* x, const float* pe, const float* alpha, float* y, int B, int T, int d, float drop_p,
-                    uint64_t seed, void* stream);
+                    uint64_t seed, const uint64_t* step_seed, void* stream);
 size_t ttts_posenc_bwd_workspace_bytes(void);
 int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, float* ws, size_t ws_bytes, int B, int T,
-                    int d, float drop_p, uint64_t seed, int accumulate, void* stream);
+                    int d, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate, void* stream);
 /* dx = dy * 1[out > 0] / (1-p): backward of drop(relu(.)) given the forward output */
 int ttts_relu_dropout_bwd(const float* dy, const float* out, float* dx, int64_t n, float drop_p, void* stream);
 /* dx = dy * keep(seed, i) / (1-p) */
-int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, void* stream);
+int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, const uint64_t* step_seed,
+                     void* stream);
 /* z = x + y */
 int ttts_add(const float* x, const float* y, float* z, int64_t n, void* stream);
 /* ---- input side: device-side padding of a ragged batch --------------------------------------
@@ -207,18 +224,22 @@ int ttts_loss_bwd(const float* pred, const float* post, const float* stop, const
                   float pos_weight, void* stream);
 /* block_mask + apply_teacher_forcing (utils/util.py:103-120): u is the (B,T) uniform draw; frame t takes the model's
  * prediction when any u[t-l_bar/2 .. t-l_bar/2+l_bar-1] < 1-p_tf (max_pool1d(k=l_bar, s=1, pad=l_bar/2)[:T]), the
- * ground truth otherwise, and zero beyond lens[b]. */
+ * ground truth otherwise, and zero beyond lens[b].  u == NULL: the draw (torch.rand of utils/util.py:108) is generated
+ * in the kernel from `seed` (a counter-based uniform per frame).  st != NULL: p_tf and the seed word of the step are
+ * read from device memory when the kernel runs (p_tf by value is ignored). */
 int ttts_sched_sampling_mix(const float* pred, const float* mel, const float* u, const int64_t* lens, float* out, int B,
-                            int T, int C, float p_tf, int l_bar, void* stream);
+                            int T, int C, float p_tf, int l_bar, uint64_t seed, const ttts_step_state* st, void* stream);
 
 /* ------------------------------------------------------------------ optimizer over flat buffers
  * Global L2 norm of the flat gradient bucket (clip_grad_norm_, train.py:41) and one torch.optim.Adam step
  * (lightning_module.py:160-163: betas (0.9, 0.98), eps 1e-9, lr = Noam factor set by the host) on flat parameter /
- * gradient / moment buffers; the clip factor min(1, max_grad_norm / (norm + 1e-6)) is applied inside the step. */
+ * gradient / moment buffers; the clip factor min(1, max_grad_norm / (norm + 1e-6)) is applied inside the step.
+ * st != NULL: lr and step are read from the device-side step state when the kernel runs (graph replay). */
 size_t ttts_grad_norm_workspace_bytes(void);
 int ttts_grad_norm(const float* g, float* norm_out, float* ws, size_t ws_bytes, int64_t n, void* stream);
 int ttts_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, const float* grad_norm, int64_t n, float lr,
-                   float beta1, float beta2, float eps, int64_t step, float max_grad_norm, void* stream);
+                   float beta1, float beta2, float eps, int64_t step, float max_grad_norm, const ttts_step_state* st,
+                   void* stream);
 
 #ifdef __cplusplus
 }

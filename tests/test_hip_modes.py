@@ -35,9 +35,9 @@ def test_linear_forms_agree_with_fp64(M, N, K):
         y = torch.empty(M, N, device=_dev())
         if x6:
             pl = ops._planes(w, 0, N, K)
-            rc = lib.ttts_linear_fwd_x6(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, 0, 0, _stream())
+            rc = lib.ttts_linear_fwd_x6(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream())
         else:
-            rc = lib.ttts_linear_fwd(_p(x), _p(w), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, 0, 0, _stream())
+            rc = lib.ttts_linear_fwd(_p(x), _p(w), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream())
         assert rc == 0 and _rel(y, ref) < TOL
         dx = torch.empty(M, K, device=_dev())
         if x6:
@@ -138,10 +138,10 @@ def test_attention_forms_agree(causal, Tq, Tk, lens):
             o = torch.empty(B, Tq, d, device=_dev()); lse = torch.empty(B, H, Tq, device=_dev())
             attn = None if causal else torch.empty(B, H, Tq, Tk, device=_dev())
             assert fwd(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), _p(attn), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d,
-                       causal, p_drop, 99, _stream()) == 0
+                       causal, p_drop, 99, None, _stream()) == 0
             dq, dkv, delta = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(lse)
             assert bwd(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d),
-                       _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, p_drop, 99, _stream()) == 0
+                       _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, p_drop, 99, None, _stream()) == 0
             outs[(name, p_drop)] = (o, attn, dq, dkv)
             if p_drop == 0.0:
                 assert _rel(o, o_ref) < TOL and _rel(dq, dq_ref) < TOL and _rel(dkv, dkv_ref) < TOL

@@ -313,6 +313,61 @@ def test_scheduled_sampling_mix_kernel(golden_dir):
         assert torch.equal(out.cpu(), torch.from_numpy(g[f"ss/mixed_{p_tf}"])), p_tf
 
 
+def test_loss_kernel_matches_reference_fixture(golden_dir):
+    """The fused loss against the values the reference's own TransformerTTSLoss produced (tests/golden/helpers.npz)."""
+    import os
+    import numpy as np
+    from transformertts_amd.loss import TransformerTTSLoss
+    g = np.load(os.path.join(golden_dir, "helpers.npz"))
+    dev = _dev()
+    outs = {"pred_melspec": torch.from_numpy(g["ss/pred"]).to(dev), "post_melspec": torch.from_numpy(g["loss/post"]).to(dev),
+            "pred_stop": torch.from_numpy(g["loss/stop_logits"]).to(dev)}
+    ls = TransformerTTSLoss(8.0).to(dev)(outs, torch.from_numpy(g["ss/mel"]).to(dev), torch.from_numpy(g["ss/lens"]).to(dev))
+    for k in ("total", "pred_mel", "post_mel", "stop"):
+        assert abs(ls[k].item() - float(g[f"loss/{k}"])) < 2e-6 * max(1.0, abs(float(g[f"loss/{k}"]))), k
+
+
+def test_in_kernel_uniform_draw_and_step_state():
+    """u = None: the mix draws its own uniforms.  The replaced fraction follows 1 - (1 - q)^8-ish block statistics of
+    the reference's max-pool dilation, the draw is a pure function of (seed, step-state seed word), and the step state
+    overrides p_tf from device memory (what a captured graph relies on)."""
+    from transformertts_amd import ops
+    dev = _dev()
+    B, T, C = 8, 4000, 16
+    pred = torch.ones(B, T, C, device=dev)
+    mel = torch.zeros(B, T, C, device=dev)
+    lens = torch.full((B,), T, dtype=torch.int64, device=dev)
+    for p_tf in (1.0, 0.9, 0.5):
+        out = ops.sched_sampling_mix(pred, mel, None, lens, p_tf, 8, seed=123)
+        frac = out[..., 0].mean().item()
+        want = 1.0 - p_tf ** 8                      # a frame keeps the truth only if all 8 draws of its window are >= 1-p_tf
+        assert abs(frac - want) < 0.02, (p_tf, frac, want)
+        assert torch.equal(out, ops.sched_sampling_mix(pred, mel, None, lens, p_tf, 8, seed=123))
+        if p_tf < 1.0:
+            assert not torch.equal(out, ops.sched_sampling_mix(pred, mel, None, lens, p_tf, 8, seed=124))
+    st = ops.StepState(dev)
+    st.push(seed=0xABCDEF0123456789, lr=0.0, p_tf=0.5, step=1)
+    with st:
+        a = ops.sched_sampling_mix(pred, mel, None, lens, 1.0, 8, seed=123)       # by-value p_tf = 1.0 is ignored
+    assert abs(a[..., 0].mean().item() - (1.0 - 0.5 ** 8)) < 0.02
+    st.push(seed=0x1111, lr=0.0, p_tf=0.5, step=2)
+    with st:
+        b = ops.sched_sampling_mix(pred, mel, None, lens, 1.0, 8, seed=123)
+    assert not torch.equal(a, b)                                                  # new seed word, new draw
+    # dropout sites follow the seed word too, and backward regenerates the forward mask under the same word
+    x = torch.randn(64, 256, device=dev, requires_grad=True)
+    w = torch.randn(256, 256, device=dev)
+    with st:
+        y1 = ops.linear(x, w, None, drop_p=0.5, seed=7)
+        (g1,) = torch.autograd.grad(y1.sum(), x)
+    st.push(seed=0x2222, lr=0.0, p_tf=0.5, step=3)
+    with st:
+        y2 = ops.linear(x, w, None, drop_p=0.5, seed=7)
+    assert not torch.equal(y1 == 0, y2 == 0)
+    keep = (y1 != 0).float() * 2.0
+    assert rel_l2(g1, keep @ w) < 1e-5
+
+
 def test_flat_adam_matches_torch_adam():
     """FlatAdam (fused clip + Adam over flat buffers) against torch.optim.Adam + clip_grad_norm_ in fp64 on CPU."""
     from transformertts_amd.optim import FlatAdam

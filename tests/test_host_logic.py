@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in ttts_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.ttts_abi_version() >= 2
+    assert lib.ttts_abi_version() >= 3
     # size queries are pure host functions: callable without a GPU
     assert lib.ttts_wgrad_workspace_bytes(55680, 256, 256, 5) > 0
     assert lib.ttts_layernorm_bwd_workspace_bytes(256) > 0
@@ -32,7 +32,7 @@ def test_error_path_without_gpu():
     """Argument validation happens before any launch and reports through ttts_last_error()."""
     from transformertts_amd import _lib
     lib = _lib.load()
-    rc = lib.ttts_linear_fwd(None, None, None, None, None, 10, 16, 16, 0, 0.0, 0, 0, 0, None)
+    rc = lib.ttts_linear_fwd(None, None, None, None, None, 10, 16, 16, 0, 0.0, 0, None, 0, 0, None)
     assert rc == -1 and "null pointer" in _lib.last_error()
     with pytest.raises(RuntimeError):
         _lib.check(rc, "ttts_linear_fwd")
@@ -71,8 +71,7 @@ def test_state_dict_contract_and_ctor_signature():
 
 
 def test_step_helpers_match_golden(golden_dir):
-    from transformertts_amd.utils.util import get_teacher_forcing_ratio, get_noam_scheduler, apply_teacher_forcing
-    from transformertts_amd.loss import TransformerTTSLoss
+    from transformertts_amd.utils.util import get_teacher_forcing_ratio, get_noam_scheduler
     g = np.load(os.path.join(golden_dir, "helpers.npz"))
     for mode in ("linear", "cosine", "constant"):
         got = [get_teacher_forcing_ratio(int(e), 300, mode, cycles=1) for e in g["tf/epochs"]]
@@ -81,15 +80,29 @@ def test_step_helpers_match_golden(golden_dir):
         get_teacher_forcing_ratio(50, 300, "bogus")
     lam = get_noam_scheduler(256, 4000)
     assert np.allclose([lam(int(s)) for s in g["noam/steps"]], g["noam/256_4000"], rtol=1e-14)
-    pred, mel, lens = (torch.from_numpy(g["ss/pred"]), torch.from_numpy(g["ss/mel"]), torch.from_numpy(g["ss/lens"]))
-    for p_tf in (1.0, 0.7, 0.05):
-        torch.manual_seed(99)
-        assert torch.equal(apply_teacher_forcing(pred, mel, lens, p_tf), torch.from_numpy(g[f"ss/mixed_{p_tf}"]))
-    outs = {"pred_melspec": pred, "post_melspec": torch.from_numpy(g["loss/post"]),
-            "pred_stop": torch.from_numpy(g["loss/stop_logits"])}
-    ls = TransformerTTSLoss(8.0)(outs, mel, lens)
-    for k in ("total", "pred_mel", "post_mel", "stop"):
-        assert abs(ls[k].item() - float(g[f"loss/{k}"])) < 2e-6 * max(1.0, abs(float(g[f"loss/{k}"])))
+
+
+def test_loss_mix_and_optimizer_have_no_cpu_path():
+    """The product package holds no second (CPU / stock-torch) backend: the loss, the scheduled-sampling mix and the
+    optimizer reject host tensors instead of computing with torch ops (the CPU restatement is oracle/, test-only)."""
+    from transformertts_amd.loss import TransformerTTSLoss
+    from transformertts_amd.optim import FlatAdam
+    from transformertts_amd.utils.util import apply_teacher_forcing
+    x = torch.zeros(2, 5, 8)
+    lens = torch.tensor([5, 3])
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        TransformerTTSLoss(8.0)({"pred_melspec": x, "post_melspec": x, "pred_stop": torch.zeros(2, 5)}, x, lens)
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        apply_teacher_forcing(x, x, lens, 0.5)
+    with pytest.raises(ValueError, match="no CPU"):
+        FlatAdam([torch.nn.Parameter(torch.zeros(4))])
+    import inspect
+    import transformertts_amd.loss as L
+    import transformertts_amd.utils.util as U
+    import transformertts_amd.lightning_module as M
+    for mod in (L, U, M):
+        src = inspect.getsource(mod)
+        assert "torch.optim.Adam(" not in src and "binary_cross_entropy" not in src and "max_pool1d" not in src
 
 
 def test_synth_batch_honours_collate_contract():
@@ -139,20 +152,51 @@ def _dp_worker(rank, world, port, ret):
             assert torch.allclose(p.grad, q.grad, atol=1e-6), "averaged gradient mismatch"
         flat_ref = torch.cat([q.grad.flatten() for q in ref.parameters()])
         assert abs(float(norm) - float(flat_ref.norm())) < 1e-5
-        # overlapped form: the tail (second Linear) is reduced from a backward hook while the first Linear's gradients
-        # are still being computed; the result is the same mean gradient
+        # overlapped form: the tail (second Linear) is reduced as soon as backward has left it, while the first Linear's
+        # gradients are still being computed; the result is the same mean gradient.  The boundary module is called with
+        # KEYWORD arguments only, the way the reference calls its decoder (model/model.py:298-306): a module-level full
+        # backward hook would fire before the boundary's own parameter gradients exist in that case.
+        from transformertts_amd.parallel import overlap_tail_with_backward
+
+        class Kw(torch.nn.Module):
+            def __init__(self, inner):
+                super().__init__()
+                self.inner = inner
+
+            def forward(self, *, x):
+                return self.inner(x)
+
+        class Net(torch.nn.Module):
+            def __init__(self, seq):
+                super().__init__()
+                self.a, self.act, self.b = seq[0], seq[1], Kw(seq[2])
+
+            def forward(self, x):
+                return self.b(x=self.act(self.a(x)))
+
+        wrapped = Net(net)
         want = bucket.flat.clone()
         bucket.zero()
         lo = bucket.offset_of(net[2].weight)
         assert lo > 0
-        fired = []
-        h = net[2].register_full_backward_hook(lambda m, gi, go: (fired.append(1), bucket.start_tail_allreduce(lo))[1])
-        loss = ((net(x[rank * per:(rank + 1) * per]) - y[rank * per:(rank + 1) * per]) ** 2).mean()
+        seen_at_fire = []
+        trig = overlap_tail_with_backward(
+            bucket, wrapped, wrapped.b,
+            on_ready=lambda lo_: (seen_at_fire.append(bucket.flat[lo_:].clone()), bucket.start_tail_allreduce(lo_))[1])
+        assert trig is not None and trig.lo == lo
+        with torch.no_grad():                           # a no-grad forward must not arm the trigger
+            wrapped(x[:2])
+        loss = ((wrapped(x[rank * per:(rank + 1) * per]) - y[rank * per:(rank + 1) * per]) ** 2).mean()
+        local = torch.autograd.grad(loss, list(net[2].parameters()), retain_graph=True)
         loss.backward()
-        h.remove()
-        assert fired == [1]
+        assert trig.fired == 1 and len(seen_at_fire) == 1
+        # the tail was complete when the trigger fired: it held exactly this rank's local gradients of the boundary
+        assert torch.equal(seen_at_fire[0][:local[0].numel()], local[0].flatten())
         bucket.finish_allreduce()
         assert torch.allclose(bucket.flat, want, atol=1e-7)
+        trig.remove()
+        # a boundary that does not start the bucket's tail (or is not a child) is refused
+        assert overlap_tail_with_backward(bucket, wrapped, wrapped.a) is None
         bucket.zero()                                   # without a started tail, finish == plain all-reduce
         loss = ((net(x[rank * per:(rank + 1) * per]) - y[rank * per:(rank + 1) * per]) ** 2).mean()
         loss.backward()

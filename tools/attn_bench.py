@@ -33,13 +33,13 @@ def run(name, B, H, Tq, Tk, causal, weights, p=0.1):
         if f is None:
             continue
         us = timeit(lambda: f(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), _p(attn), _p(lens), B, H, Tq, Tk, d, 2 * d, 2 * d, d,
-                              causal, p, 7, _stream()))
+                              causal, p, 7, None, _stream()))
         res[suffix] = (o.clone(), lse.clone(), attn.clone() if weights else None)
         out.append(f"fwd{suffix} {us:7.1f}us")
         g = getattr(lib, "ttts_attention_bwd" + suffix, None)
         if g is not None:
             us = timeit(lambda: g(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d),
-                                  _p(lens), B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, p, 7, _stream()))
+                                  _p(lens), B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, p, 7, None, _stream()))
             res["b" + suffix] = (dq.clone(), dkv.clone())
             out.append(f"bwd{suffix} {us:7.1f}us")
     def rel(a, b): return float((a - b).norm() / b.norm())

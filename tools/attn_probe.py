@@ -16,7 +16,7 @@ x6 = os.environ.get("X6", "1") == "1"
 fwd = lib.ttts_attention_fwd_x6 if x6 else lib.ttts_attention_fwd
 bwd = lib.ttts_attention_bwd_x6 if x6 else lib.ttts_attention_bwd
 for _ in range(3):
-    fwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(lse), None, _p(lens), B, H, T, T, 3 * d, 3 * d, 3 * d, d, 1, 0.1, 7, _stream())
+    fwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(lse), None, _p(lens), B, H, T, T, 3 * d, 3 * d, 3 * d, d, 1, 0.1, 7, None, _stream())
     bwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta), _off(dqkv, 0), _off(dqkv, d),
-                           _off(dqkv, 2 * d), _p(lens), B, H, T, T, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, 1, 0.1, 7, _stream())
+                           _off(dqkv, 2 * d), _p(lens), B, H, T, T, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, 1, 0.1, 7, None, _stream())
 torch.cuda.synchronize()

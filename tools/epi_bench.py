@@ -10,7 +10,7 @@ def t(M, N, K, act, p, res, n=20):
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev); y = torch.empty(M, N, device=dev)
     r = torch.randn(M, N, device=dev) if res else None
     pl = ops._planes(w, 0, N, K)
-    f = lambda: lib.ttts_linear_fwd_x6(_p(x), _p(pl), _p(b), _p(r), _p(y), M, N, K, act, p, 7, 0, 0, _stream())
+    f = lambda: lib.ttts_linear_fwd_x6(_p(x), _p(pl), _p(b), _p(r), _p(y), M, N, K, act, p, 7, None, 0, 0, _stream())
     for _ in range(3): f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

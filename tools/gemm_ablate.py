@@ -10,9 +10,9 @@ def t(M, N, K, n=20):
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev); y = torch.empty(M, N, device=dev)
     if os.environ.get("X6", "1") == "1":
         pl = ops._planes(w, 0, N, K)
-        f = lambda: lib.ttts_linear_fwd_x6(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, 0, 0, _stream())
+        f = lambda: lib.ttts_linear_fwd_x6(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream())
     else:
-        f = lambda: lib.ttts_linear_fwd(_p(x), _p(w), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, 0, 0, _stream())
+        f = lambda: lib.ttts_linear_fwd(_p(x), _p(w), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream())
     for _ in range(3): f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

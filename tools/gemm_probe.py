@@ -14,7 +14,7 @@ x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.
 pl = ops._planes(w, 0, N, K)
 for _ in range(reps):
     if x6:
-        lib.ttts_linear_fwd_x6(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, 0, 0, _stream())
+        lib.ttts_linear_fwd_x6(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream())
     else:
-        lib.ttts_linear_fwd(_p(x), _p(w), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, 0, 0, _stream())
+        lib.ttts_linear_fwd(_p(x), _p(w), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream())
 torch.cuda.synchronize()

@@ -30,7 +30,7 @@ def timeit(fn, n=20, warm=3):
 def gemm_fwd(M, N, K, act=0, res=False):
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev)
     y = torch.empty(M, N, device=dev); r = torch.randn(M, N, device=dev) if res else None
-    us = timeit(lambda: lib.ttts_linear_fwd(_p(x), _p(w), _p(b), _p(r), _p(y), M, N, K, act, 0.0, 0, 0, 0, _stream()))
+    us = timeit(lambda: lib.ttts_linear_fwd(_p(x), _p(w), _p(b), _p(r), _p(y), M, N, K, act, 0.0, 0, None, 0, 0, _stream()))
     print(f"linear_fwd   M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s")
 
 
@@ -38,7 +38,7 @@ def gemm_fwd_x6(M, N, K):
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev)
     y = torch.empty(M, N, device=dev)
     pl = ops._planes(w, 0, N, K)
-    us = timeit(lambda: lib.ttts_linear_fwd_x6(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, 0, 0, _stream()))
+    us = timeit(lambda: lib.ttts_linear_fwd_x6(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream()))
     ref = (x[:256].double() @ w.double().t() + b.double())
     err = ((y[:256].double() - ref).norm() / ref.norm()).item()
     print(f"linear_fwd_x6 M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s   rel err vs fp64 {err:.2e}")
@@ -102,10 +102,10 @@ def attn(B, H, Tq, Tk, causal, cross, p=0.1):
     do = torch.randn(B, Tq, d, device=dev)
     fl = 4.0 * B * H * Tq * Tk * 64 * (0.5 if causal else 1.0)
     us = timeit(lambda: lib.ttts_attention_fwd(qa, ka, va, _p(o), _p(lse), _p(a), _p(lens), B, H, Tq, Tk, ldq, ldk, ldk, d,
-                                               int(causal), p, 7, _stream()))
+                                               int(causal), p, 7, None, _stream()))
     print(f"attn_fwd B={B} H={H} Tq={Tq} Tk={Tk} causal={causal} cross={cross}: {us:8.1f} us {fl/us/1e6:6.1f} TF/s (algorithmic)")
     us = timeit(lambda: lib.ttts_attention_bwd(qa, ka, va, _p(o), _p(do), _p(lse), _p(delta), dqa, dka, dva, _p(lens), B, H, Tq,
-                                               Tk, ldq, ldk, ldk, d, lddq, lddk, lddk, int(causal), p, 7, _stream()))
+                                               Tk, ldq, ldk, ldk, d, lddq, lddk, lddk, int(causal), p, 7, None, _stream()))
     print(f"attn_bwd (dq + dkv)                                       : {us:8.1f} us {2.5*fl/us/1e6:6.1f} TF/s (2.5x fwd flops)")
 
 

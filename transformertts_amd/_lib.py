@@ -22,7 +22,7 @@ P, I, L, F, U, Z = c_void_p, c_int, c_int64, c_float, c_uint64, c_size_t
 SIGNATURES = {
     "ttts_last_error": (c_char_p, []),
     "ttts_abi_version": (I, []),
-    "ttts_linear_fwd": (I, [P, P, P, P, P, L, I, I, I, F, U, I, I, P]),
+    "ttts_linear_fwd": (I, [P, P, P, P, P, L, I, I, I, F, U, P, I, I, P]),
     "ttts_linear_bwd_data": (I, [P, P, P, P, L, I, I, P, F, P]),
     "ttts_wgrad_workspace_bytes": (Z, [L, I, I, I]),
     "ttts_linear_bwd_weight": (I, [P, P, P, P, P, Z, L, I, I, I, I, I, P]),
@@ -30,7 +30,7 @@ SIGNATURES = {
     "ttts_gemm_tile_choice": (I, [L, I, I]),
     "ttts_weight_split": (I, [P, P, I, I, I, I, I, P]),
     "ttts_weight_split_batched": (I, [P, I, L, P]),
-    "ttts_linear_fwd_x6": (I, [P, P, P, P, P, L, I, I, I, F, U, I, I, P]),
+    "ttts_linear_fwd_x6": (I, [P, P, P, P, P, L, I, I, I, F, U, P, I, I, P]),
     "ttts_linear_bwd_data_x6": (I, [P, P, P, P, L, I, I, P, F, P]),
     "ttts_conv1d_fwd_x6": (I, [P, P, P, P, I, I, I, I, I, P]),
     "ttts_conv1d_bwd_data_x6": (I, [P, P, P, I, I, I, I, I, P]),
@@ -44,32 +44,32 @@ SIGNATURES = {
     "ttts_bn_workspace_bytes": (Z, [L, I]),
     "ttts_bn_train_stats": (I, [P, P, P, P, P, P, P, Z, L, I, F, F, P]),
     "ttts_bn_eval_stats": (I, [P, P, P, P, I, F, P]),
-    "ttts_bn_apply_fwd": (I, [P, P, P, P, P, P, L, I, I, F, U, P]),
-    "ttts_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, Z, L, I, I, F, U, I, P]),
+    "ttts_bn_apply_fwd": (I, [P, P, P, P, P, P, L, I, I, F, U, P, P]),
+    "ttts_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, Z, L, I, I, F, U, P, I, P]),
     "ttts_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
     "ttts_layernorm_bwd_workspace_bytes": (Z, [I]),
     "ttts_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P]),
-    "ttts_attention_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P]),
-    "ttts_attention_fwd_x6": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P]),
-    "ttts_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P]),
-    "ttts_attention_bwd_x6": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P]),
+    "ttts_attention_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P, P]),
+    "ttts_attention_fwd_x6": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P, P]),
+    "ttts_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P, P]),
+    "ttts_attention_bwd_x6": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P, P]),
     "ttts_embedding_fwd": (I, [P, P, P, L, I, I, P]),
     "ttts_embedding_bwd": (I, [P, P, P, L, I, I, I, P]),
-    "ttts_posenc_fwd": (I, [P, P, P, P, I, I, I, F, U, P]),
+    "ttts_posenc_fwd": (I, [P, P, P, P, I, I, I, F, U, P, P]),
     "ttts_posenc_bwd_workspace_bytes": (Z, []),
-    "ttts_posenc_bwd": (I, [P, P, P, P, P, Z, I, I, I, F, U, I, P]),
+    "ttts_posenc_bwd": (I, [P, P, P, P, P, Z, I, I, I, F, U, P, I, P]),
     "ttts_relu_dropout_bwd": (I, [P, P, P, L, F, P]),
-    "ttts_dropout_bwd": (I, [P, P, L, F, U, P]),
+    "ttts_dropout_bwd": (I, [P, P, L, F, U, P, P]),
     "ttts_add": (I, [P, P, P, L, P]),
     "ttts_collate_melspec": (I, [P, P, P, I, I, I, P]),
     "ttts_collate_phoneme": (I, [P, P, P, I, I, P]),
     "ttts_loss_workspace_bytes": (Z, []),
     "ttts_loss_fwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, F, P]),
     "ttts_loss_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, F, P]),
-    "ttts_sched_sampling_mix": (I, [P, P, P, P, P, I, I, I, F, I, P]),
+    "ttts_sched_sampling_mix": (I, [P, P, P, P, P, I, I, I, F, I, U, P, P]),
     "ttts_grad_norm_workspace_bytes": (Z, []),
     "ttts_grad_norm": (I, [P, P, P, Z, L, P]),
-    "ttts_adam_step": (I, [P, P, P, P, P, L, F, F, F, F, L, F, P]),
+    "ttts_adam_step": (I, [P, P, P, P, P, L, F, F, F, F, L, F, P, P]),
     "ttts_rowdot_fwd": (I, [P, P, P, P, L, I, P]),
     "ttts_rowdot_bwd_workspace_bytes": (Z, [I]),
     "ttts_rowdot_bwd": (I, [P, P, P, P, P, P, P, Z, L, I, I, P]),

@@ -58,7 +58,7 @@ struct AttnArgs {
     const int64_t* key_lens;
     int B, H, Tq, Tk;
     int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
-    float drop_scale; uint32_t thr; uint64_t seed;
+    float drop_scale; uint32_t thr; uint64_t seed; const uint64_t* step_seed;
 };
 
 // ---- cooperative staging (256 threads): KB rows x 64 floats from global straight into LDS; rows beyond
@@ -136,6 +136,7 @@ static_assert(2 * KB * KT_LD <= SMEM_FLOATS, "staging buffers must fit the share
 // =====================================================================================  forward
 template <bool CAUSAL, bool WRITE_A>
 __global__ __launch_bounds__(256, TTTS_FWD_W) void attn_fwd_kernel(AttnArgs a) {
+    const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     __shared__ float ptile_all[WRITE_A ? 4 * 32 * 33 : 1];
     float* Ks = smem;                  // [KB][65]
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, TTTS_FWD_W) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const int key_g = key0 + acc_row(r, half);
-            const uint32_t hsh = attn_hash(a.seed, rowid, (uint32_t)key_g >> 1);
+            const uint32_t hsh = attn_hash(seed_eff, rowid, (uint32_t)key_g >> 1);
             p[r] = keep_from_hash(hsh, 0u, a.thr) ? p[r] * a.drop_scale : 0.f;
             p[r + 1] = keep_from_hash(hsh, 1u, a.thr) ? p[r + 1] * a.drop_scale : 0.f;
         }
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(256, TTTS_FWD_W) void attn_fwd_kernel(AttnArgs a) {
 // =====================================================================================  backward: dQ (+ delta)
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, TTTS_DQ_W) void attn_bwd_dq_kernel(AttnArgs a) {
+    const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* Ks = smem;                  // [KB][65]
     float* Vs = smem + KB * KT_LD;     // [KB][65]
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(256, TTTS_DQ_W) void attn_bwd_dq_kernel(AttnArgs a)
             for (int r = 0; r < 16; r += 2) {
                 const int key_g = key0 + acc_row(r, half);
                 uint32_t hsh = 0;
-                if (a.thr != 0u) hsh = attn_hash(a.seed, rowid, (uint32_t)key_g >> 1);
+                if (a.thr != 0u) hsh = attn_hash(seed_eff, rowid, (uint32_t)key_g >> 1);
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int kg = key_g + e;
@@ -427,6 +429,7 @@ __global__ __launch_bounds__(256, TTTS_DQ_W) void attn_bwd_dq_kernel(AttnArgs a)
 // =====================================================================================  backward: dK, dV
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, TTTS_DKV_W) void attn_bwd_dkv_kernel(AttnArgs a) {
+    const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     __shared__ float lse_s[KB], delta_s[KB];
     float* Qs = smem;                  // [KB][65]
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(256, TTTS_DKV_W) void attn_bwd_dkv_kernel(AttnArgs 
                 float g = dp[r];
                 float pk = p;
                 if (a.thr != 0u) {
-                    const uint32_t hsh = attn_hash(a.seed, (uint32_t)(arow + q_g), (uint32_t)kg >> 1);
+                    const uint32_t hsh = attn_hash(seed_eff, (uint32_t)(arow + q_g), (uint32_t)kg >> 1);
                     bool keep = keep_from_hash(hsh, (uint32_t)kg & 1u, a.thr);
                     g = keep ? g * a.drop_scale : 0.f;
                     pk = keep ? p * a.drop_scale : 0.f;
@@ -625,6 +628,7 @@ static_assert(XSMEM >= SMEM_FLOATS, "per-wave fp32 scratch must fit the stage bu
 
 template <bool CAUSAL, bool WRITE_A>
 __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDX_W) void attn_fwd_x6_kernel(AttnArgs a) {
+    const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
     __shared__ __attribute__((aligned(16))) uint32_t xs[XSMEM];
     __shared__ float ptile_all[WRITE_A ? 4 * 32 * 17 : 1];   // per wave: 32 queries x 16 keys (+1 pad)
     uint32_t* Kp = xs;              // [3][64 keys][64 d]
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDX_W) void attn_fwd_x6_ke
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const int key_g = key0 + acc_row(r, half);
-            const uint32_t hsh = attn_hash(a.seed, rowid, (uint32_t)key_g >> 1);
+            const uint32_t hsh = attn_hash(seed_eff, rowid, (uint32_t)key_g >> 1);
             p[r] = keep_from_hash(hsh, 0u, a.thr) ? p[r] * a.drop_scale : 0.f;
             p[r + 1] = keep_from_hash(hsh, 1u, a.thr) ? p[r + 1] * a.drop_scale : 0.f;
         }
@@ -904,6 +908,7 @@ constexpr int DQX_SMEM = 9 * XP * 4;   // bytes: K rows, V rows, K^T of one 64-k
 
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, TTTS_DQX_W) void attn_bwd_dq_x6_kernel(AttnArgs a) {
+    const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
     extern __shared__ __attribute__((aligned(16))) uint32_t xsd[];
     uint32_t* Kr = xsd;              // [3][64 keys][64 d]
     uint32_t* Vr = xsd + 3 * XP;     // [3][64 keys][64 d]
@@ -1001,7 +1006,7 @@ __global__ __launch_bounds__(256, TTTS_DQX_W) void attn_bwd_dq_x6_kernel(AttnArg
             for (int r = 0; r < 16; r += 2) {
                 const int key_g = key0 + acc_row(r, half);
                 uint32_t hsh = 0;
-                if (a.thr != 0u) hsh = attn_hash(a.seed, rowid, (uint32_t)key_g >> 1);
+                if (a.thr != 0u) hsh = attn_hash(seed_eff, rowid, (uint32_t)key_g >> 1);
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int kg = key_g + e;
@@ -1069,6 +1074,7 @@ __device__ __forceinline__ void dma4(const float* base, uint32_t lane_off, uint3
 
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnArgs a) {
+    const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
     extern __shared__ __attribute__((aligned(16))) uint32_t xsd[];
     uint32_t* xs = xsd;
     uint32_t* Qr = xs;                      // [3][32 q][64 d]
@@ -1205,7 +1211,7 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
             uint32_t h0 = 0, h1 = 0;
             if (a.thr != 0u) {
                 const int rr = r + (lane & 1);
-                const uint32_t mine = attn_hash(a.seed, (uint32_t)(arow + qt0 + acc_row(rr, half)), (uint32_t)kg >> 1);
+                const uint32_t mine = attn_hash(seed_eff, (uint32_t)(arow + qt0 + acc_row(rr, half)), (uint32_t)kg >> 1);
                 const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);   // lane ^ 1
                 h0 = (lane & 1) ? other : mine;
                 h1 = (lane & 1) ? mine : other;
@@ -1294,7 +1300,7 @@ extern "C" {
 
 static int attention_fwd_impl(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                               const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                              int causal, float drop_p, uint64_t seed, bool x6, void* stream_) {
+                              int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, bool x6, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(q && k && v && o && key_lens, "attention_fwd: null pointer");
     int rc = check_common("attention_fwd", B, H, Tq, Tk, ldq, ldk, ldv, ldo, drop_p);
@@ -1307,7 +1313,7 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, fl
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     a.drop_scale = 1.f / (1.f - drop_p);
-    a.seed = seed;
+    a.seed = seed; a.step_seed = step_seed;
     dim3 grid(B * H, cdiv(Tq, QB), 1);
     if (x6) {
         if (causal)
@@ -1331,21 +1337,21 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, fl
 
 int ttts_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                        const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                       int causal, float drop_p, uint64_t seed, void* stream) {
-    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, false,
+                       int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
+    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, step_seed, false,
                               stream);
 }
 int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                          int causal, float drop_p, uint64_t seed, void* stream) {
-    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, true,
+                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
+    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, step_seed, true,
                               stream);
 }
 
 static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* do_,
                               const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                               int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                              int causal, float drop_p, uint64_t seed, bool x6, void* stream_) {
+                              int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, bool x6, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(q && k && v && o && do_ && lse && delta && dq && dk && dv && key_lens, "attention_bwd: null pointer");
     int rc = check_common("attention_bwd", B, H, Tq, Tk, ldq, ldk, ldv, ldo, drop_p);
@@ -1361,7 +1367,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
     a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     a.drop_scale = 1.f / (1.f - drop_p);
-    a.seed = seed;
+    a.seed = seed; a.step_seed = step_seed;
     dim3 gq(B * H, cdiv(Tq, QB), 1), gk(B * H, cdiv(Tk, QB), 1);
     if (x6) return causal ? launch_bwd_x6<true>(a, gq, gk, stream) : launch_bwd_x6<false>(a, gq, gk, stream);
     if (causal) {
@@ -1380,16 +1386,16 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
 int ttts_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* do_,
                        const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                        int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                       int causal, float drop_p, uint64_t seed, void* stream) {
+                       int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
     return attention_bwd_impl(q, k, v, o, do_, lse, delta, dq, dk, dv, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk,
-                              lddv, causal, drop_p, seed, false, stream);
+                              lddv, causal, drop_p, seed, step_seed, false, stream);
 }
 int ttts_attention_bwd_x6(const float* q, const float* k, const float* v, const float* o, const float* do_,
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                          int causal, float drop_p, uint64_t seed, void* stream) {
+                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
     return attention_bwd_impl(q, k, v, o, do_, lse, delta, dq, dk, dv, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk,
-                              lddv, causal, drop_p, seed, true, stream);
+                              lddv, causal, drop_p, seed, step_seed, true, stream);
 }
 
 }  // extern "C"

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __res
 // ------------------------------------------------------------------ positional encoding
 __global__ __launch_bounds__(256) void posenc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pe,
                                                          const float* __restrict__ alpha, float* __restrict__ y, long n4,
-                                                         int T, int d, float drop_scale, uint32_t thr, uint64_t seed) {
+                                                         int T, int d, float drop_scale, uint32_t thr, uint64_t seed, const uint64_t* step_seed) {
+    seed = site_seed(seed, step_seed);
     const float a = alpha[0];
     const long td = (long)T * d;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -103,7 +104,8 @@ constexpr int PE_BWD_BLOCKS = 1024;
 // dx = dy*keep/(1-p); block partial of sum(dx * pe) -> ws[block]
 __global__ __launch_bounds__(256) void posenc_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pe,
                                                          float* __restrict__ dx, float* __restrict__ ws, long n4, int T,
-                                                         int d, float drop_scale, uint32_t thr, uint64_t seed) {
+                                                         int d, float drop_scale, uint32_t thr, uint64_t seed, const uint64_t* step_seed) {
+    seed = site_seed(seed, step_seed);
     __shared__ float red[4];
     const long td = (long)T * d;
     float s = 0.f;
@@ -149,7 +151,8 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float* __re
 }
 
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long n4,
-                                                          float scale, uint32_t thr, uint64_t seed) {
+                                                          float scale, uint32_t thr, uint64_t seed, const uint64_t* step_seed) {
+    seed = site_seed(seed, step_seed);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long e = i * 4;
         float4 g = reinterpret_cast<const float4*>(dy)[i];
@@ -253,7 +256,7 @@ using namespace ttts;
 extern "C" {
 
 const char* ttts_last_error(void) { return ttts::g_err; }
-int ttts_abi_version(void) { return 2; }
+int ttts_abi_version(void) { return 3; }
 
 int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d, void* stream) {
     TTTS_REQUIRE(ids && table && out, "embedding_fwd: null pointer");
@@ -277,14 +280,14 @@ int ttts_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int
 }
 
 int ttts_posenc_fwd(const float* x, const float* pe, const float* alpha, float* y, int B, int T, int d, float drop_p,
-                    uint64_t seed, void* stream) {
+                    uint64_t seed, const uint64_t* step_seed, void* stream) {
     TTTS_REQUIRE(x && pe && alpha && y, "posenc_fwd: null pointer");
     TTTS_REQUIRE(B > 0 && T > 0 && d > 0 && d % 4 == 0, "posenc_fwd: d=%d must be a multiple of 4", d);
     TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "posenc_fwd: bad dropout p");
     long n4 = (long)B * T * d / 4;
     uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     hipLaunchKernelGGL(posenc_fwd_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, pe, alpha, y, n4, T, d,
-                       1.f / (1.f - drop_p), thr, seed);
+                       1.f / (1.f - drop_p), thr, seed, step_seed);
     TTTS_LAUNCH_CHECK("posenc_fwd_kernel");
     return TTTS_OK;
 }
@@ -292,7 +295,8 @@ int ttts_posenc_fwd(const float* x, const float* pe, const float* alpha, float* 
 size_t ttts_posenc_bwd_workspace_bytes(void) { return (size_t)PE_BWD_BLOCKS * sizeof(float); }
 
 int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, float* ws, size_t ws_bytes, int B, int T,
-                    int d, float drop_p, uint64_t seed, int accumulate, void* stream_) {
+                    int d, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate,
+                void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && pe && dx && dalpha && ws, "posenc_bwd: null pointer");
     TTTS_REQUIRE(B > 0 && T > 0 && d > 0 && d % 4 == 0, "posenc_bwd: bad dims");
@@ -302,7 +306,7 @@ int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, 
     if (grid > PE_BWD_BLOCKS) grid = PE_BWD_BLOCKS;
     uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid), dim3(256), 0, stream, dy, pe, dx, ws, n4, T, d, 1.f / (1.f - drop_p),
-                       thr, seed);
+                       thr, seed, step_seed);
     TTTS_LAUNCH_CHECK("posenc_bwd_kernel");
     hipLaunchKernelGGL(scalar_reduce_kernel, dim3(1), dim3(64), 0, stream, ws, dalpha, grid, accumulate);
     TTTS_LAUNCH_CHECK("scalar_reduce_kernel");
@@ -318,11 +322,11 @@ int ttts_relu_dropout_bwd(const float* dy, const float* out, float* dx, int64_t 
     return TTTS_OK;
 }
 
-int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, void* stream) {
+int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
     TTTS_REQUIRE(dy && dx && n > 0 && n % 4 == 0, "dropout_bwd: bad arguments (n %% 4 must be 0)");
     TTTS_REQUIRE(drop_p > 0.f && drop_p < 1.f, "dropout_bwd: p must be in (0,1)");
     hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, dx, (long)(n / 4),
-                       1.f / (1.f - drop_p), drop_threshold(drop_p), seed);
+                       1.f / (1.f - drop_p), drop_threshold(drop_p), seed, step_seed);
     TTTS_LAUNCH_CHECK("dropout_bwd_kernel");
     return TTTS_OK;
 }

@@ -53,6 +53,7 @@ struct GemmArgs {
     float drop_scale;
     uint32_t drop_thr;
     uint64_t seed;
+    const uint64_t* step_seed;   // per-step word XORed into seed (NULL: none); see site_seed()
     const float* residual;
     long ldr;
     // data-gradient form: the output is the gradient w.r.t. an activation h = drop(relu(.)) whose forward value is
@@ -75,6 +76,7 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, uint32_
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_f32_kernel(GemmArgs g) {
+    const uint64_t seed_eff = site_seed(g.seed, g.step_seed);
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_f32_kernel(GemmA
                 if (g.act == 1) v = fmaxf(v, 0.f);
                 if (do_drop) {
                     uint64_t idx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
-                    v = keep_elem(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
+                    v = keep_elem(seed_eff, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
                 }
                 v = v * gate[r] + res[r];
                 if (row < g.M && col_ok) C[(long)row * g.ldc + col] = v;
@@ -497,6 +499,7 @@ __global__ __launch_bounds__(256) void weight_split_batched_kernel(const long* _
 
 template <int BM, int BN, int WM, int WN, bool CLIP>
 __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(GemmArgs g) {
+    const uint64_t seed_eff = site_seed(g.seed, g.step_seed);
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(WM * WN == 4 && BK == 16, "4 waves per workgroup, one MFMA k-step per k-tile");
@@ -715,7 +718,7 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_bf16x6_kernel(Ge
                 if (g.act == 1) v = fmaxf(v, 0.f);
                 if (do_drop) {
                     uint64_t idx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
-                    v = keep_elem(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
+                    v = keep_elem(seed_eff, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
                 }
                 if (has_gate) v = gsrc[r] > 0.f ? v * g.relu_scale : 0.f;
                 v += res[r];
@@ -965,7 +968,7 @@ static GemmArgs base_args() {
     g.M = g.N = g.K = 0; g.lda = g.ldb = g.ldc = 0;
     g.T = 0; g.cin = 1; g.shift0 = 0; g.shift_step = 0; g.ztaps = 1;
     g.kt_per_split = 1 << 30; g.c_zstride = 0;
-    g.bias = nullptr; g.act = 0; g.drop_scale = 1.f; g.drop_thr = 0; g.seed = 0;
+    g.bias = nullptr; g.act = 0; g.drop_scale = 1.f; g.drop_thr = 0; g.seed = 0; g.step_seed = nullptr;
     g.residual = nullptr; g.ldr = 0; g.colsum = nullptr; g.a_bytes = 0; g.b_bytes = 0;
     g.relu_out = nullptr; g.relu_scale = 1.f;
     return g;
@@ -1010,7 +1013,7 @@ using namespace ttts;
 extern "C" {
 
 int ttts_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, int64_t M,
-                    int N, int K, int act, float drop_p, uint64_t seed, int row_shift, int T, void* stream) {
+                    int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift, int T, void* stream) {
     TTTS_REQUIRE(x && w && y, "linear_fwd: null pointer");
     TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_fwd: bad dims M=%lld N=%d K=%d", (long long)M, N, K);
     TTTS_REQUIRE(K % BK == 0, "linear_fwd: K=%d must be a multiple of %d", K, BK);
@@ -1025,7 +1028,7 @@ int ttts_linear_fwd(const float* x, const float* w, const float* bias, const flo
     g.a_bytes = (uint32_t)((uint64_t)M * K * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 4);
     g.cin = K; g.shift0 = row_shift; g.T = (row_shift != 0) ? T : 0;
     g.bias = bias; g.act = act;
-    if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; }
+    if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; g.step_seed = step_seed; }
     g.residual = residual; g.ldr = N;
     return dispatch_gemm<true, true>(g, 1, TILE_AUTO, (hipStream_t)stream);
 }
@@ -1216,7 +1219,7 @@ int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks,
 }
 
 int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
-                       int64_t M, int N, int K, int act, float drop_p, uint64_t seed, int row_shift, int T, void* stream) {
+                       int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift, int T, void* stream) {
     TTTS_REQUIRE(x && w_planes && y, "linear_fwd_x6: null pointer");
     TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_fwd_x6: bad dims");
     TTTS_REQUIRE(K % BK == 0, "linear_fwd_x6: K=%d must be a multiple of %d", K, BK);
@@ -1231,7 +1234,7 @@ int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, 
     g.a_bytes = (uint32_t)((uint64_t)M * K * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 6);
     g.cin = K; g.shift0 = row_shift; g.T = (row_shift != 0) ? T : 0;
     g.bias = bias; g.act = act;
-    if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; }
+    if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; g.step_seed = step_seed; }
     g.residual = residual; g.ldr = N;
     return dispatch_split(g, (hipStream_t)stream);
 }

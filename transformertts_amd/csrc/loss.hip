@@ -118,10 +118,16 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
 }
 
 // mixed[b,t,:] = (t < len) ? (any(u[b, t-4 .. t+3] < 1-p_tf) ? pred : mel) : 0
+// u == NULL: the uniform draw of frame (b,s) is generated here, 24 bits of hash(seed, b*T + s) -- one value per
+// frame whichever thread asks for it, so the 8-frame windows of neighbouring outputs see the same draws.
 __global__ __launch_bounds__(256) void sched_mix_kernel(const float* __restrict__ pred, const float* __restrict__ mel,
                                                         const float* __restrict__ u, const int64_t* __restrict__ lens,
                                                         float* __restrict__ out, int B, int T, int C, float thresh,
-                                                        int l_bar) {
+                                                        int l_bar, uint64_t seed, const ttts_step_state* __restrict__ st) {
+    if (st != nullptr) {                 // captured-graph form: this step's ratio and seed word live in device memory
+        thresh = 1.0f - st->p_tf;
+        seed ^= st->seed;
+    }
     const int c4n = C >> 2;
     const long n4 = (long)B * T * c4n;
     const int pad = l_bar / 2;
@@ -131,10 +137,15 @@ __global__ __launch_bounds__(256) void sched_mix_kernel(const float* __restrict_
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t < lens[b]) {
             bool take_pred = false;
-            const float* ub = u + (long)b * T;
             for (int k = 0; k < l_bar; ++k) {                 // window of output t: inputs t-pad .. t-pad+l_bar-1
                 int s = t - pad + k;
-                if (s >= 0 && s < T) take_pred = take_pred || (ub[s] < thresh);
+                if (s >= 0 && s < T) {
+                    const long f = (long)b * T + s;
+                    const float us = u != nullptr ? u[f]
+                                                  : (float)(hash_pair(seed, (uint32_t)f, (uint32_t)(f >> 32) + 0x51ED27u) >> 8) *
+                                                        (1.0f / 16777216.0f);
+                    take_pred = take_pred || (us < thresh);
+                }
             }
             v = take_pred ? reinterpret_cast<const float4*>(pred)[i] : reinterpret_cast<const float4*>(mel)[i];
         }
@@ -184,11 +195,11 @@ int ttts_loss_bwd(const float* pred, const float* post, const float* stop, const
 }
 
 int ttts_sched_sampling_mix(const float* pred, const float* mel, const float* u, const int64_t* lens, float* out, int B,
-                            int T, int C, float p_tf, int l_bar, void* stream) {
-    TTTS_REQUIRE(pred && mel && u && lens && out, "sched_sampling_mix: null pointer");
+                            int T, int C, float p_tf, int l_bar, uint64_t seed, const ttts_step_state* st, void* stream) {
+    TTTS_REQUIRE(pred && mel && lens && out, "sched_sampling_mix: null pointer");
     TTTS_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && l_bar > 0, "sched_sampling_mix: bad dims (C %% 4 must be 0)");
     hipLaunchKernelGGL(sched_mix_kernel, dim3(grid_for((long)B * T * (C / 4), 2048)), dim3(256), 0, (hipStream_t)stream, pred,
-                       mel, u, lens, out, B, T, C, 1.0f - p_tf, l_bar);
+                       mel, u, lens, out, B, T, C, 1.0f - p_tf, l_bar, seed, st);
     TTTS_LAUNCH_CHECK("sched_mix_kernel");
     return TTTS_OK;
 }

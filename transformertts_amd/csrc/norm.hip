@@ -212,7 +212,8 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* 
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ z, long n4,
-                                                           int C, int act, float drop_scale, uint32_t thr, uint64_t seed) {
+                                                           int C, int act, float drop_scale, uint32_t thr, uint64_t seed, const uint64_t* step_seed) {
+    seed = site_seed(seed, step_seed);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long e = i * 4;
         const int c = (int)(e % C);
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ ws, long M, int C, int rows_per_block,
-                                                             int act, float drop_scale, uint32_t thr, uint64_t seed) {
+                                                             int act, float drop_scale, uint32_t thr, uint64_t seed, const uint64_t* step_seed) {
+    seed = site_seed(seed, step_seed);
     __shared__ float red[2][4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -292,7 +294,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ sums, float* __restrict__ dx, long n4,
                                                            int C, float inv_m, int act, float drop_scale, uint32_t thr,
-                                                           uint64_t seed) {
+                                                           uint64_t seed, const uint64_t* step_seed) {
+    seed = site_seed(seed, step_seed);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long e = i * 4;
         const int c = (int)(e % C);
@@ -397,7 +400,7 @@ int ttts_bn_eval_stats(const float* running_mean, const float* running_var, floa
 }
 
 int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                      float* z, int64_t M, int C, int act, float drop_p, uint64_t seed, void* stream) {
+                      float* z, int64_t M, int C, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
     TTTS_REQUIRE(x && mean && invstd && gamma && beta && z, "bn_apply_fwd: null pointer");
     TTTS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_apply_fwd: C=%d must be a multiple of 4", C);
     TTTS_REQUIRE(act == TTTS_ACT_NONE || act == TTTS_ACT_TANH, "bn_apply_fwd: act must be none or tanh");
@@ -407,14 +410,15 @@ int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, co
     if (grid > 4096) grid = 4096;
     uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, z,
-                       n4, C, act, 1.f / (1.f - drop_p), thr, seed);
+                       n4, C, act, 1.f / (1.f - drop_p), thr, seed, step_seed);
     TTTS_LAUNCH_CHECK("bn_apply_fwd_kernel");
     return TTTS_OK;
 }
 
 int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float* invstd, const float* gamma,
                 const float* beta, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int C,
-                int act, float drop_p, uint64_t seed, int accumulate, void* stream_) {
+                int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate,
+                void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dz && x && mean && invstd && gamma && beta && dx && ws, "bn_bwd: null pointer");
     TTTS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd: C=%d must be a multiple of 4", C);
@@ -425,7 +429,7 @@ int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float*
     float scale = 1.f / (1.f - drop_p);
     float* sums = ws + (size_t)BN_MAXBLK * 3 * C;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(C, 64), nb), dim3(256), 0, stream, dz, x, mean, invstd, gamma, beta,
-                       ws, (long)M, C, rpb, act, scale, thr, seed);
+                       ws, (long)M, C, rpb, act, scale, thr, seed, step_seed);
     TTTS_LAUNCH_CHECK("bn_bwd_partial_kernel");
     int rc = launch_reduce_rows(ws, 2 * C, nb, 2 * C, sums, 2 * C, nullptr, 0, stream);
     if (rc) return rc;
@@ -435,7 +439,7 @@ int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float*
     int grid = (int)((n4 + 255) / 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, dz, x, mean, invstd, gamma, beta, sums, dx, n4,
-                       C, 1.0f / (float)M, act, scale, thr, seed);
+                       C, 1.0f / (float)M, act, scale, thr, seed, step_seed);
     TTTS_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return TTTS_OK;
 }

@@ -30,9 +30,18 @@ __global__ void norm_final_kernel(const float* __restrict__ ws, float* __restric
 
 __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
-                                                        const float* __restrict__ gnorm, long n4, float step_size,
-                                                        float beta1, float beta2, float eps, float inv_bc2_sqrt,
-                                                        float max_norm) {
+                                                        const float* __restrict__ gnorm, long n4, float lr,
+                                                        long step, const ttts_step_state* __restrict__ st, float beta1,
+                                                        float beta2, float eps, float max_norm) {
+    if (st != nullptr) {                 // captured-graph form: this step's lr and step count live in device memory
+        lr = st->lr;
+        step = st->step;
+    }
+    // bias corrections in double, exactly as torch.optim.Adam's host arithmetic (a few thousand cycles per thread, once)
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     float scale = 1.f;
     if (gnorm != nullptr && max_norm > 0.f) {
         const float c = max_norm / (gnorm[0] + 1e-6f);      // torch.nn.utils.clip_grad_norm_: coef clamped to 1
@@ -84,20 +93,19 @@ int ttts_grad_norm(const float* g, float* norm_out, float* ws, size_t ws_bytes, 
 }
 
 int ttts_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, const float* grad_norm, int64_t n, float lr,
-                   float beta1, float beta2, float eps, int64_t step, float max_grad_norm, void* stream) {
+                   float beta1, float beta2, float eps, int64_t step, float max_grad_norm, const ttts_step_state* st,
+                   void* stream) {
     // one torch.optim.Adam step (step >= 1 is the 1-based step count) on flat buffers; gradients are scaled by
-    // min(1, max_grad_norm / (grad_norm + 1e-6)) first when grad_norm != NULL and max_grad_norm > 0
+    // min(1, max_grad_norm / (grad_norm + 1e-6)) first when grad_norm != NULL and max_grad_norm > 0.
+    // st != NULL: lr and step are read from st (device memory) when the kernel runs and the by-value ones are ignored.
     TTTS_REQUIRE(p && g && exp_avg && exp_avg_sq && n > 0 && n % 4 == 0, "adam_step: bad arguments (n %% 4 must be 0)");
-    TTTS_REQUIRE(step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adam_step: bad hyper-parameters");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    TTTS_REQUIRE((st != nullptr || step >= 1) && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f,
+                 "adam_step: bad hyper-parameters");
     long n4 = n / 4;
     long gl = (n4 + 255) / 256;
     int grid = (int)(gl > 2048 ? 2048 : (gl < 1 ? 1 : gl));
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq, grad_norm,
-                       n4, step_size, beta1, beta2, eps, inv_bc2_sqrt, max_grad_norm);
+                       n4, lr, (long)step, st, beta1, beta2, eps, max_grad_norm);
     TTTS_LAUNCH_CHECK("adam_step_kernel");
     return TTTS_OK;
 }

@@ -43,6 +43,12 @@ __device__ __forceinline__ uint32_t hash_pair(uint64_t seed, uint32_t a, uint32_
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
+// Effective seed of a dropout site in this step: the site seed passed by value, XORed with a per-step 64-bit word read
+// from device memory (NULL: none).  A captured HIP graph replays the same kernel arguments every step; the per-step
+// word is what the host (one 8-byte copy per step) changes so that every replay draws fresh masks.
+__device__ __forceinline__ uint64_t site_seed(uint64_t seed, const uint64_t* step_seed) {
+    return step_seed != nullptr ? (seed ^ *step_seed) : seed;
+}
 __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
     double t = (double)p * 65536.0 + 0.5;
     if (t < 0.0) t = 0.0;

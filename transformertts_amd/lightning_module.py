@@ -51,15 +51,19 @@ class LightningModule(_Base):
     def forward(self, phoneme, melspec, phoneme_lens, melspec_lens, **kwargs):
         return self.model(phoneme, melspec, phoneme_lens, melspec_lens, **kwargs)
 
+    def teacher_forcing_ratio(self) -> float:
+        """p_tf of the current epoch (lightning_module.py:62-67)."""
+        return get_teacher_forcing_ratio(epoch=self.current_epoch + 1,
+                                         total_epochs=self.config['training']['num_epochs'],
+                                         mode=self.config['training']['teacher_forcing_mode'], cycles=1)
+
     def training_step(self, batch, batch_idx):
         phoneme, melspec, phoneme_lens, melspec_lens = prepare_batch(batch, self.device)
         # forward #1 (no grad, train mode: dropout on, BN statistics updated) -> the model's own prediction
         with torch.no_grad():   # only pred_melspec is used: do not materialise the attention maps
             pred_melspec = self.forward(phoneme, melspec, phoneme_lens, melspec_lens,
                                         need_alignments=False)['pred_melspec']
-        p_tf = get_teacher_forcing_ratio(epoch=self.current_epoch + 1,
-                                         total_epochs=self.config['training']['num_epochs'],
-                                         mode=self.config['training']['teacher_forcing_mode'], cycles=1)
+        p_tf = self.teacher_forcing_ratio()
         mel_mixed = apply_teacher_forcing(pred_melspec, melspec, melspec_lens, p_tf, self.device)
         # forward #2 (with grad) on the mixed input, loss against the ground truth
         output = self.forward(phoneme, mel_mixed, phoneme_lens, melspec_lens)
@@ -88,14 +92,12 @@ class LightningModule(_Base):
         self.valid_losses.clear()
 
     def configure_optimizers(self):
-        if next(self.parameters()).is_cuda:
-            # same Adam arithmetic as the reference, fused over flat buffers; `fused_clip_norm` (> 0) folds the
-            # Trainer's gradient_clip_val (train.py:41) into the step for loops that do not clip themselves
-            from .optim import FlatAdam
-            optimizer = FlatAdam(self.parameters(), lr=1.0, betas=(0.9, 0.98), eps=1e-9,
-                                 max_grad_norm=float(self.config['training'].get('fused_clip_norm', 0.0)))
-        else:
-            optimizer = torch.optim.Adam(self.parameters(), lr=1.0, betas=(0.9, 0.98), eps=1e-9)
+        # same Adam arithmetic as the reference (lightning_module.py:160-163), fused over flat buffers; `fused_clip_norm`
+        # (> 0) folds the Trainer's gradient_clip_val (train.py:41) into the step for loops that do not clip themselves.
+        # FlatAdam raises for parameters that are not on the HIP device: there is no CPU optimizer path.
+        from .optim import FlatAdam
+        optimizer = FlatAdam(self.parameters(), lr=1.0, betas=(0.9, 0.98), eps=1e-9,
+                             max_grad_norm=float(self.config['training'].get('fused_clip_norm', 0.0)))
         lr_lambda = get_noam_scheduler(d_model=self.config['model']['d_model'],
                                        warmup_steps=self.config['training']['warmup_steps'])
         scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lr_lambda)

@@ -1,10 +1,9 @@
 """TransformerTTSLoss -- masked MSE (pred + 0.5 * post) + stop-gate BCE-with-logits (pos_weight).
 
 Same constructor, call signature, returned dict and `pos_weight` buffer as the reference's `loss.py:8-55`.
-On HIP tensors the whole loss (and its backward) runs in the fused kernels of csrc/loss.hip (SURVEY.md
-section 8f, row 1): one streaming masked reduction instead of the reference's boolean-index gathers
-(`mel[mask]`, loss.py:34-36,44), which allocate data-dependent shapes and force a device->host sync.
-On CPU tensors (host-side checks only) the same arithmetic is evaluated with masked sums in torch.
+The whole loss (and its backward) runs in the fused kernels of csrc/loss.hip: one
+streaming masked reduction instead of the reference's boolean-index gathers (`mel[mask]`, loss.py:34-36,44), which
+allocate data-dependent shapes and force a device->host sync.  HIP tensors only.
 """
 from __future__ import annotations
 
@@ -12,7 +11,6 @@ from typing import Dict
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 from torch import Tensor
 
 
@@ -28,21 +26,7 @@ class TransformerTTSLoss(nn.Module):
             self._pos_weight_host = float(state_dict[prefix + "pos_weight"])
 
     def forward(self, outputs: Dict[str, Tensor], mel: Tensor, lengths: Tensor) -> Dict[str, Tensor]:
+        from . import ops          # rejects non-HIP tensors: there is no CPU path (the CPU restatement is oracle/)
         pred, post, stop = outputs["pred_melspec"], outputs["post_melspec"], outputs["pred_stop"]
-        if pred.is_cuda:
-            from . import ops
-            out = ops.TTSLossFn.apply(pred, post, stop, mel, lengths.to(torch.int64), self._pos_weight_host)
-            return {"total": out[0], "pred_mel": out[1], "post_mel": out[2], "stop": out[3]}
-        B, T, C = pred.shape
-        pos = torch.arange(T, device=pred.device).unsqueeze(0)
-        valid = (pos < lengths.unsqueeze(1)).to(pred.dtype)                 # (B,T)
-        gate = (pos == (lengths.unsqueeze(1) - 1)).to(pred.dtype)
-        n_frames = valid.sum()
-        vm = valid.unsqueeze(-1)
-        pred_mel_loss = (((pred - mel) ** 2) * vm).sum() / (n_frames * C)
-        post_mel_loss = (((post - mel) ** 2) * vm).sum() / (n_frames * C)
-        bce = F.binary_cross_entropy_with_logits(stop, gate, reduction='none', pos_weight=self.pos_weight)
-        stop_loss = (bce * valid).sum() / n_frames
-        mel_loss = pred_mel_loss + 0.5 * post_mel_loss
-        return {"total": mel_loss + stop_loss, "pred_mel": pred_mel_loss, "post_mel": post_mel_loss,
-                "stop": stop_loss}
+        out = ops.TTSLossFn.apply(pred, post, stop, mel, lengths.to(torch.int64), self._pos_weight_host)
+        return {"total": out[0], "pred_mel": out[1], "post_mel": out[2], "stop": out[3]}

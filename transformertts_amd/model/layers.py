@@ -197,7 +197,7 @@ class TransformerDecoder(nn.Module):
             memory_lens = _lens_from_kpm(memory_key_padding_mask, B, memory.size(1), tgt.device)
         alignments = []
         for layer in self.layers:
-            tgt, alignment = layer(tgt=tgt, memory=memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+            tgt, alignment = layer(tgt, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
                                    tgt_is_causal=True if tgt_is_causal is None else tgt_is_causal,
                                    memory_is_causal=bool(memory_is_causal), tgt_lens=tgt_lens,
                                    memory_lens=memory_lens, need_alignments=need_alignments)

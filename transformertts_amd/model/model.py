@@ -200,7 +200,7 @@ class TransformerTTS(nn.Module):
         melspec_lens = melspec_lens.to(torch.int64)
         memory = self.encode(phoneme, phoneme_lens)
         tgt = self.pe(self.dec_prenet(melspec, shift_right=True))
-        tgt_out, alignments = self.decoder(tgt=tgt, memory=memory, tgt_is_causal=True, memory_is_causal=False,
+        tgt_out, alignments = self.decoder(tgt, memory, tgt_is_causal=True, memory_is_causal=False,
                                            tgt_lens=melspec_lens, memory_lens=phoneme_lens,
                                            need_alignments=need_alignments)
         pred_melspec, pred_stop = ops.HeadsFn.apply(tgt_out, self.linear1.linear.weight, self.linear1.linear.bias,
@@ -275,7 +275,7 @@ class TransformerTTS(nn.Module):
                 cur = ys[:, :t].contiguous()
                 tgt = self.pe(self.dec_prenet(cur))
                 lens_t = torch.full((B,), t, dtype=torch.int64, device=dev)
-                out, _ = self.decoder(tgt=tgt, memory=memory, tgt_is_causal=True, tgt_lens=lens_t,
+                out, _ = self.decoder(tgt, memory, tgt_is_causal=True, tgt_lens=lens_t,
                                       memory_lens=phoneme_lens, need_alignments=False)
                 last = out[:, -1:, :].contiguous()
                 mel, stop = ops.HeadsFn.apply(last, *heads)

@@ -65,6 +65,61 @@ class _SeedStream:
 
 seeds = _SeedStream()
 
+
+class StepState:
+    """Device-side per-step scalars (`ttts_step_state` of include/ttts_hip.h: seed word, lr, p_tf, step count).
+
+    Kernel arguments are frozen when a HIP graph is captured, so whatever changes from step to step must be read from
+    device memory by the kernels.  While a StepState is ACTIVE (`with state:` or `activate()`), every dropout site
+    passes `&state.seed` as its `step_seed`, FlatAdam reads lr / step from it and the scheduled-sampling mix reads p_tf
+    from it.  `push()` refreshes the block with ONE small host-to-device copy from a ring of pinned slots (no
+    synchronisation unless the host gets `ring` steps ahead of the device)."""
+
+    SIZE = 32
+
+    def __init__(self, device, ring: int = 64):
+        self.dev = torch.zeros(self.SIZE // 8, dtype=torch.int64, device=device)
+        self._host = torch.zeros(ring, self.SIZE // 8, dtype=torch.int64).pin_memory()
+        self._f32 = self._host.view(torch.float32)           # (ring, 8) float view of the same bytes
+        self._events = [None] * ring
+        self._i = 0
+        self.ptr = c_void_p(self.dev.data_ptr())
+
+    def push(self, seed: int, lr: float, p_tf: float, step: int) -> None:
+        i = self._i % len(self._events)
+        ev = self._events[i]
+        if ev is not None:
+            ev.synchronize()                                  # slot still in flight only if the host is `ring` steps ahead
+        seed &= 0xFFFFFFFFFFFFFFFF
+        self._host[i, 0] = seed - (1 << 64) if seed >= (1 << 63) else seed
+        self._f32[i, 2] = float(lr)
+        self._f32[i, 3] = float(p_tf)
+        self._host[i, 2] = int(step)
+        self._host[i, 3] = 0
+        self.dev.copy_(self._host[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[i] = ev
+        self._i += 1
+
+    def __enter__(self):
+        global _active_state
+        self._prev = _active_state
+        _active_state = self
+        return self
+
+    def __exit__(self, *exc):
+        global _active_state
+        _active_state = self._prev
+
+
+_active_state: Optional[StepState] = None
+
+
+def _ss():
+    """`step_seed` / `ttts_step_state*` argument of the C ABI: the active StepState block, or NULL."""
+    return None if _active_state is None else _active_state.ptr
+
 # Forward / data-gradient GEMMs and convolutions: "x6" = fp32-accurate split-precision products on the bf16 MFMA
 # (3-way bf16 split, six MFMA terms, fp32 accumulate; error 1.1e-7 vs 2.9e-7 for the plain fp32 MFMA chain),
 # "f32" = the plain v_mfma_f32_32x32x2_f32 kernel.  Weight gradients always use the fp32 kernel.
@@ -241,13 +296,14 @@ class LinearFn(torch.autograd.Function):
             raise ValueError("linear: residual shape mismatch")
         if GEMM_MODE == "x6":
             _lib.check(lib.ttts_linear_fwd_x6(_p(x), _p(_planes(w, 0, N, K)), _p(b_), _p(r_), _p(y), M, N, K, act,
-                                              float(drop_p), seed, row_shift, T, _stream()), "ttts_linear_fwd_x6")
+                                              float(drop_p), seed, _ss(), row_shift, T, _stream()), "ttts_linear_fwd_x6")
         else:
             _lib.check(lib.ttts_linear_fwd(_p(x), _p(w), _p(b_), _p(r_), _p(y), M, N, K, act, float(drop_p), seed,
-                                           row_shift, T, _stream()), "ttts_linear_fwd")
+                                           _ss(), row_shift, T, _stream()), "ttts_linear_fwd")
         ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
         ctx.cfg = (act, float(drop_p), seed, row_shift, T, b is not None, residual is not None)
         ctx.sinks = _sinks(w, b)
+        ctx.ss = _ss()              # backward regenerates the dropout mask under the step-state word of ITS forward
         ctx.toks = (tok_out, tok_in, skip_in, skip_out)
         return y
 
@@ -269,7 +325,7 @@ class LinearFn(torch.autograd.Function):
                        "ttts_relu_dropout_bwd")
         elif drop_p > 0.0:
             dacc = torch.empty_like(dy)
-            _lib.check(lib.ttts_dropout_bwd(_p(dy), _p(dacc), dy.numel(), drop_p, seed, _stream()), "ttts_dropout_bwd")
+            _lib.check(lib.ttts_dropout_bwd(_p(dy), _p(dacc), dy.numel(), drop_p, seed, ctx.ss, _stream()), "ttts_dropout_bwd")
         else:
             dacc = dy
         dx = dw = db = None
@@ -362,10 +418,10 @@ class HeadsFn(torch.autograd.Function):
         w_mel = _chk(w_mel, "w_mel")
         if GEMM_MODE == "x6":
             _lib.check(lib.ttts_linear_fwd_x6(_p(x), _p(_planes(w_mel, 0, N, K)), _p(b_mel), None, _p(mel), M, N, K,
-                                              ACT_NONE, 0.0, 0, 0, 0, _stream()), "ttts_linear_fwd_x6")
+                                              ACT_NONE, 0.0, 0, None, 0, 0, _stream()), "ttts_linear_fwd_x6")
         else:
             _lib.check(lib.ttts_linear_fwd(_p(x), _p(w_mel), _p(b_mel), None, _p(mel), M, N, K, ACT_NONE, 0.0,
-                                           0, 0, 0, _stream()), "ttts_linear_fwd")
+                                           0, None, 0, 0, _stream()), "ttts_linear_fwd")
         _lib.check(lib.ttts_rowdot_fwd(_p(x), _p(_chk(w_stop, "w_stop")), _p(b_stop), _p(stop), M, K, _stream()),
                    "ttts_rowdot_fwd")
         ctx.save_for_backward(x, w_mel, w_stop)
@@ -444,9 +500,10 @@ class ConvBNFn(torch.autograd.Function):
                                               _stream()), "ttts_bn_eval_stats")
         z = torch.empty_like(y)
         _lib.check(lib.ttts_bn_apply_fwd(_p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(z), M, cout, act,
-                                         float(drop_p), seed, _stream()), "ttts_bn_apply_fwd")
+                                         float(drop_p), seed, _ss(), _stream()), "ttts_bn_apply_fwd")
         ctx.save_for_backward(x, conv_w, y, mean, invstd, gamma, beta)
         ctx.cfg = (training, act, float(drop_p), seed, conv_b is not None)
+        ctx.ss = _ss()
         ctx.sinks = _sinks(conv_w, conv_b, gamma, beta)
         return z
 
@@ -474,7 +531,7 @@ class ConvBNFn(torch.autograd.Function):
             t_be = dbeta = torch.empty_like(beta)
         ws = _ws(lib.ttts_bn_workspace_bytes(M, cout), dev)
         _lib.check(lib.ttts_bn_bwd(_p(dz), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(t_g), _p(t_be),
-                                   _p(ws), ws.numel() * 4, M, cout, act, drop_p, seed, acc, _stream()), "ttts_bn_bwd")
+                                   _p(ws), ws.numel() * 4, M, cout, act, drop_p, seed, ctx.ss, acc, _stream()), "ttts_bn_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -550,7 +607,7 @@ def _attn_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, lens, causal, drop_p, seed, 
     attn = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=dev) if need_weights else None
     fwd = lib.ttts_attention_fwd_x6 if ATTN_MODE == "x6" else lib.ttts_attention_fwd
     _lib.check(fwd(q, k, v, _p(o), _p(lse), _p(attn), _p(lens), B, H, Tq, Tk, ldq, ldk, ldv, H * 64,
-                   1 if causal else 0, float(drop_p), seed, _stream()), "ttts_attention_fwd")
+                   1 if causal else 0, float(drop_p), seed, _ss(), _stream()), "ttts_attention_fwd")
     return o, lse, attn
 
 
@@ -573,6 +630,7 @@ class SelfAttentionFn(torch.autograd.Function):
                               drop_p, seed, False)
         ctx.save_for_backward(qkv, o, lse, lens)
         ctx.cfg = (n_head, causal, float(drop_p), seed)
+        ctx.ss = _ss()
         return o
 
     @staticmethod
@@ -587,7 +645,7 @@ class SelfAttentionFn(torch.autograd.Function):
         delta = torch.empty_like(lse)
         _lib.check(_attn_bwd(lib)(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta),
                                           _off(dqkv, 0), _off(dqkv, d), _off(dqkv, 2 * d), _p(lens), B, n_head, T, T, d3,
-                                          d3, d3, d, d3, d3, d3, 1 if causal else 0, drop_p, seed, _stream()),
+                                          d3, d3, d, d3, d3, d3, 1 if causal else 0, drop_p, seed, ctx.ss, _stream()),
                    "ttts_attention_bwd")
         return dqkv, None, None, None, None, None
 
@@ -608,6 +666,7 @@ class CrossAttentionFn(torch.autograd.Function):
                                  drop_p, seed, need_weights)
         ctx.save_for_backward(q, kv, o, lse, lens)
         ctx.cfg = (n_head, float(drop_p), seed)
+        ctx.ss = _ss()
         if attn is None:       # weights not requested: single-pass online softmax, nothing written
             attn = torch.empty(0, dtype=torch.float32, device=q.device)
         ctx.mark_non_differentiable(attn)
@@ -626,7 +685,7 @@ class CrossAttentionFn(torch.autograd.Function):
         delta = torch.empty_like(lse)
         _lib.check(_attn_bwd(lib)(_off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
                                           _off(dq, 0), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk, d, 2 * d,
-                                          2 * d, d, d, 2 * d, 2 * d, 0, drop_p, seed, _stream()), "ttts_attention_bwd")
+                                          2 * d, d, d, 2 * d, 2 * d, 0, drop_p, seed, ctx.ss, _stream()), "ttts_attention_bwd")
         return dq, dkv, None, None, None, None, None
 
 
@@ -674,10 +733,11 @@ class PosEncFn(torch.autograd.Function):
         if T > pe.shape[0] or d != pe.shape[1]:
             raise ValueError("posenc: sequence longer than the table or width mismatch")
         y = torch.empty_like(x)
-        _lib.check(lib.ttts_posenc_fwd(_p(x), _p(pe), _p(alpha), _p(y), B, T, d, float(drop_p), seed, _stream()),
+        _lib.check(lib.ttts_posenc_fwd(_p(x), _p(pe), _p(alpha), _p(y), B, T, d, float(drop_p), seed, _ss(), _stream()),
                    "ttts_posenc_fwd")
         ctx.save_for_backward(pe)
         ctx.cfg = (float(drop_p), seed)
+        ctx.ss = _ss()
         ctx.sinks = _sinks(alpha)
         return y
 
@@ -696,7 +756,7 @@ class PosEncFn(torch.autograd.Function):
         else:
             t = dalpha = torch.empty(1, dtype=torch.float32, device=dy.device)
         ws = _ws(lib.ttts_posenc_bwd_workspace_bytes(), dy.device)
-        _lib.check(lib.ttts_posenc_bwd(_p(dy), _p(pe), _p(dx), _p(t), _p(ws), ws.numel() * 4, B, T, d, drop_p, seed, acc,
+        _lib.check(lib.ttts_posenc_bwd(_p(dy), _p(pe), _p(dx), _p(t), _p(ws), ws.numel() * 4, B, T, d, drop_p, seed, ctx.ss, acc,
                                        _stream()), "ttts_posenc_bwd")
         return dx, None, dalpha, None, None
 
@@ -749,13 +809,16 @@ class TTSLossFn(torch.autograd.Function):
         return dpred, dpost, dstop, None, None, None
 
 
-def sched_sampling_mix(pred, mel, u, lens, p_tf: float, l_bar: int = 8):
-    """Block-wise scheduled-sampling mix on the device; `u` is the (B,T) uniform draw."""
+def sched_sampling_mix(pred, mel, u, lens, p_tf: float, l_bar: int = 8, seed: int = 0):
+    """Block-wise scheduled-sampling mix on the device.  `u` is the (B,T) uniform draw, or None to draw it inside the
+    kernel from `seed` (and the active StepState's seed word); with an active StepState p_tf is read from it."""
     lib = _lib.load()
-    pred, mel, u = _chk(pred, "mix.pred"), _chk(mel, "mix.mel"), _chk(u, "mix.u")
+    pred, mel = _chk(pred, "mix.pred"), _chk(mel, "mix.mel")
+    if u is not None:
+        u = _chk(u, "mix.u")
     lens = _chk(lens, "mix.lens", torch.int64)
     B, T, C = pred.shape
     out = torch.empty_like(mel)
-    _lib.check(lib.ttts_sched_sampling_mix(_p(pred), _p(mel), _p(u), _p(lens), _p(out), B, T, C, float(p_tf), l_bar,
-                                           _stream()), "ttts_sched_sampling_mix")
+    _lib.check(lib.ttts_sched_sampling_mix(_p(pred), _p(mel), _p(u), _p(lens), _p(out), B, T, C, float(p_tf), l_bar, seed,
+                                           _ss(), _stream()), "ttts_sched_sampling_mix")
     return out

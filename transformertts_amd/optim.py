@@ -43,9 +43,18 @@ class FlatAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):   # gradients live in the bucket: zero it, keep the views attached
         self.bucket.zero()
 
-    @torch.no_grad()
     def step(self, closure=None):
-        loss = closure() if closure is not None else None
+        """`closure` (Lightning's automatic optimisation passes one that runs training_step + backward) is evaluated
+        with gradients enabled, as torch.optim.Adam does; only the update itself runs under no_grad."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        with torch.no_grad():
+            self._update()
+        return loss
+
+    def _update(self) -> None:
         lib = _lib.load()
         g = self.param_groups[0]
         b = self.bucket
@@ -58,9 +67,14 @@ class FlatAdam(torch.optim.Optimizer):
             norm_ptr = _p(self.grad_norm)
         _lib.check(lib.ttts_adam_step(_p(self.flat_params), _p(b.flat), _p(self.exp_avg), _p(self.exp_avg_sq), norm_ptr, n,
                                       float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self._step,
-                                      float(g["max_grad_norm"] or 0.0), _stream()), "ttts_adam_step")
+                                      float(g["max_grad_norm"] or 0.0), ops._ss(), _stream()), "ttts_adam_step")
         ops.bump_param_epoch()      # parameters changed behind autograd's version counters: drop cached weight splits
-        return loss
+
+    def note_external_step(self) -> None:
+        """Host bookkeeping for an update that ran without `step()` being called -- a replayed HIP graph that contains
+        the clip + Adam kernels (step.TrainStep): advance the step count and drop the cached weight splits."""
+        self._step += 1
+        ops.bump_param_epoch()
 
     def state_dict(self):
         d = super().state_dict()

@@ -121,13 +121,63 @@ class FlatGradBucket:
         return norm
 
 
-def overlap_tail_with_backward(bucket: FlatGradBucket, model: torch.nn.Module, boundary: torch.nn.Module, group=None):
+class _TailTrigger:
+    """Fires `on_ready(lo)` once per backward pass, when the gradient of EVERY grad-requiring tensor that entered
+    `boundary` in the last grad-enabled forward has been computed -- i.e. when backward has left the module and all of
+    its parameter gradients (and those of everything after it) have been enqueued.
+
+    The trigger hangs on the input TENSORS (Tensor.register_hook), found by a forward pre-hook that sees positional and
+    keyword arguments alike.  A module-level `register_full_backward_hook` is NOT usable here: it only tracks
+    positional inputs, and for a module called with keyword arguments PyTorch fires it as soon as the gradient w.r.t.
+    the module's OUTPUT exists -- before any of its parameter gradients do."""
+
+    def __init__(self, boundary: torch.nn.Module, lo: int, on_ready):
+        self.lo, self.on_ready = lo, on_ready
+        self.pending = 0
+        self.generation = 0
+        self.fired = 0
+        self.enabled = True               # False: forwards do not arm the trigger (nothing fires)
+        self._pre = boundary.register_forward_pre_hook(self._arm, with_kwargs=True)
+
+    def _arm(self, module, args, kwargs):
+        if not torch.is_grad_enabled() or not self.enabled:
+            return None
+        tensors = [t for t in list(args) + list(kwargs.values())
+                   if isinstance(t, torch.Tensor) and t.requires_grad and t.is_floating_point()]
+        self.generation += 1
+        gen = self.generation
+        self.pending = len(tensors)           # no visible grad-requiring input: never fires, finish_allreduce() does it all
+
+        def arrived(grad, _gen=gen):
+            if _gen == self.generation:
+                self.pending -= 1
+                if self.pending == 0:
+                    self.fired += 1
+                    self.on_ready(self.lo)
+            return None
+        seen = set()
+        for t in tensors:
+            if id(t) in seen:                  # the same tensor passed twice gets one hook
+                self.pending -= 1
+                continue
+            seen.add(id(t))
+            t.register_hook(arrived)
+        return None
+
+    def remove(self) -> None:
+        self._pre.remove()
+        self.generation += 1
+
+
+def overlap_tail_with_backward(bucket: FlatGradBucket, model: torch.nn.Module, boundary: torch.nn.Module, group=None,
+                               on_ready=None):
     """Arrange for the bucket's tail -- the gradients of `boundary` and of every module registered after it -- to be
-    all-reduced as soon as backward has left `boundary` (a full backward hook on it), overlapping the exchange with the
-    rest of backward.  Valid only if those later modules sit AFTER `boundary` in the forward pass too, so that their
-    gradients are final by then: that is checked structurally here (their parameters must form exactly the bucket's tail).
-    Returns the hook handle, or None when the layout does not allow it (the caller then just uses finish_allreduce(),
-    which reduces everything at once).  The optimizer side calls bucket.finish_allreduce() either way."""
+    all-reduced as soon as backward has left `boundary`, overlapping the exchange with the rest of backward.  Valid
+    only if those later modules sit AFTER `boundary` in the forward pass too, so that their gradients are final by
+    then: that is checked structurally here (their parameters must form exactly the bucket's tail).
+    Returns the trigger (call `.remove()` to uninstall), or None when the layout does not allow it (the caller then
+    just uses finish_allreduce(), which reduces everything at once).  The optimizer side calls
+    bucket.finish_allreduce() either way.  `on_ready(lo)` replaces the default action (tests)."""
     first = next(iter(boundary.parameters()), None)
     if first is None:
         return None
@@ -140,14 +190,14 @@ def overlap_tail_with_backward(bucket: FlatGradBucket, model: torch.nn.Module, b
         seen = seen or child is boundary
         if seen:
             after.update(id(p) for p in child.parameters())
+    in_bucket = {id(p) for p in bucket.params}
     tail = {id(p) for p, o in zip(bucket.params, bucket.offsets) if o >= lo}
-    if not seen or lo == 0 or tail != {i for i in after if i in {id(p) for p in bucket.params}}:
+    if not seen or lo == 0 or tail != {i for i in after if i in in_bucket}:
         return None
-
-    def hook(module, grad_input, grad_output):
-        bucket.start_tail_allreduce(lo, group)
-
-    return boundary.register_full_backward_hook(hook)
+    if on_ready is None:
+        def on_ready(lo_):
+            bucket.start_tail_allreduce(lo_, group)
+    return _TailTrigger(boundary, lo, on_ready)
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) -> None:
@@ -162,6 +212,9 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) ->
             t.data.copy_(host)
         else:
             dist.broadcast(t.data, src=src, group=group)
+    # raw .data writes do not move autograd's version counters: drop every cached bf16 weight split explicitly
+    from . import ops
+    ops.bump_param_epoch()
 
 
 def shard_batch(batch: dict, rank: int, world: int) -> dict:

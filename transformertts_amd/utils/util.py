@@ -1,14 +1,13 @@
 """Step-surface helpers with the reference's names and semantics (`utils/util.py:42-120`): Noam schedule,
-teacher-forcing ratio, block-wise scheduled-sampling mix, batch placement.  Pure host logic plus a handful of
-element-wise torch ops on the device; experiment-directory and loguru plumbing of the reference is out of
-scope."""
+teacher-forcing ratio, block-wise scheduled-sampling mix (a HIP kernel), batch placement.  Experiment-directory and
+loguru plumbing of the reference is out of scope.  No CPU arithmetic lives here: the
+CPU restatement used by the tests is oracle/ref_model.py."""
 from __future__ import annotations
 
 import math
 from typing import Dict, Tuple
 
 import torch
-import torch.nn.functional as F
 from torch import Tensor
 
 
@@ -45,22 +44,18 @@ def prepare_batch(batch: Dict[str, Tensor], device) -> Tuple[Tensor, ...]:
     return tuple(batch[k].to(device, non_blocking=True) for k in ['phoneme', 'melspec', 'phoneme_lens', 'melspec_lens'])
 
 
-def block_mask(mel: Tensor, p_tf: float, L_bar: int) -> Tensor:
-    """(B,T,1) bool: frames replaced by the model's own prediction; a Bernoulli(1-p_tf) seed per frame dilated to
-    blocks of about L_bar frames with a max-pool."""
-    B, T, _ = mel.shape
-    seed = (torch.rand(B, 1, T, device=mel.device) < (1 - p_tf)).float()
-    dilated = F.max_pool1d(seed, kernel_size=L_bar, stride=1, padding=L_bar // 2)
-    return dilated.squeeze(1).bool().unsqueeze(-1)[:, :T, :]
+# Test seam: a callable (B, T, device) -> (B, T) uniform tensor that replaces the in-kernel draw, so that parity tests
+# can inject the reference's own `torch.rand` values (tests/test_hip_model.py::test_training_step_surface).
+_uniform_draw = None
 
 
 def apply_teacher_forcing(pred_melspec: Tensor, melspec: Tensor, melspec_lens: Tensor, p_tf: float, device=None) -> Tensor:
-    if pred_melspec.is_cuda:   # fused HIP kernel; the uniform draw stays torch.rand on the device, as in the reference
-        from .. import ops
-        B, T, _ = pred_melspec.shape
-        u = torch.rand(B, 1, T, device=pred_melspec.device)
-        return ops.sched_sampling_mix(pred_melspec.detach(), melspec, u.view(B, T), melspec_lens.to(torch.int64), p_tf, 8)
-    mask = block_mask(pred_melspec, p_tf, L_bar=8)
-    mel_mixed = torch.where(mask, pred_melspec.detach(), melspec)
-    valid = torch.arange(pred_melspec.size(1), device=pred_melspec.device).unsqueeze(0) < melspec_lens.unsqueeze(1)
-    return mel_mixed * valid.unsqueeze(-1)
+    """`block_mask` + `apply_teacher_forcing` of the reference (utils/util.py:103-120) as ONE fused HIP kernel: frame t
+    takes the model's own prediction when any uniform draw in its 8-frame window falls below 1 - p_tf, the ground truth
+    otherwise, and zero beyond the utterance.  The draw (the reference's `torch.rand(B,1,T)`) is generated inside the
+    kernel from a counter-based hash -- no separate RNG launch, and replayable from a captured HIP graph."""
+    from .. import ops
+    B, T, _ = pred_melspec.shape
+    u = _uniform_draw(B, T, pred_melspec.device).reshape(B, T).contiguous() if _uniform_draw is not None else None
+    return ops.sched_sampling_mix(pred_melspec.detach(), melspec, u, melspec_lens.to(torch.int64), p_tf, 8,
+                                  seed=ops.seeds.next())
