@@ -21,5 +21,5 @@ against those fixtures on every run.
 """
 
 from .spec import CONFIGS, model_config, state_spec, fill_state  # noqa: F401
-from .ref_model import oracle_forward, oracle_loss, oracle_training_step, oracle_inference  # noqa: F401
+from .ref_model import oracle_forward, oracle_loss, oracle_training_step, oracle_inference, relu_gates  # noqa: F401
 from .synth import synth_batch  # noqa: F401

@@ -17,6 +17,40 @@ import torch.nn.functional as F
 Tensor = torch.Tensor
 
 
+class relu_gates:
+    """Test instrument for the ReLU sites of the training forward (FFN blocks, decoder pre-net), visited in call order.
+
+    `with relu_gates() as rec:` records, per site, the pre-activation tensor (`rec.pre`) -- so a test can see which units
+    sit within rounding distance of zero.  `with relu_gates(gates=[...])` REPLACES relu(x) by x * gate with the given
+    0/1 tensors, one per site: the forward/backward is then evaluated under another implementation's gating decisions.
+    A ReLU is the only discontinuous operation of the path; two correct evaluations in different precisions may gate a
+    unit whose pre-activation is ~1e-7 differently, and that is the whole difference between their gradients
+    (tests/test_hip_model.py::test_gradient_gap_is_relu_gate_flips)."""
+    active = None
+
+    def __init__(self, gates=None):
+        self.gates, self.pre, self.i = gates, [], 0
+
+    def __enter__(self):
+        relu_gates.active = self
+        return self
+
+    def __exit__(self, *exc):
+        relu_gates.active = None
+
+
+def _relu(x: Tensor) -> Tensor:
+    g = relu_gates.active
+    if g is None:
+        return F.relu(x)
+    if g.gates is None:
+        g.pre.append(x.detach())
+        return F.relu(x)
+    gate = g.gates[g.i].to(dtype=x.dtype).reshape(x.shape)
+    g.i += 1
+    return x * gate
+
+
 def _drop(x: Tensor, p: float, on: bool) -> Tensor:
     return F.dropout(x, p, training=True) if (on and p > 0.0) else x
 
@@ -84,7 +118,7 @@ def multi_head_attention(sd, prefix: str, xq: Tensor, xkv: Tensor, n_head: int,
 
 def _ffn(sd, prefix: str, x: Tensor, p: float, drop_on: bool) -> Tensor:
     """torch `_ff_block` (torch/nn/modules/transformer.py:980-982): W2 . Drop(relu(W1 x)), then Drop."""
-    h = _drop(F.relu(F.linear(x, sd[f"{prefix}.linear1.weight"], sd[f"{prefix}.linear1.bias"])), p, drop_on)
+    h = _drop(_relu(F.linear(x, sd[f"{prefix}.linear1.weight"], sd[f"{prefix}.linear1.bias"])), p, drop_on)
     return _drop(F.linear(h, sd[f"{prefix}.linear2.weight"], sd[f"{prefix}.linear2.bias"]), p, drop_on)
 
 
@@ -131,9 +165,9 @@ def oracle_forward(sd: Dict[str, Tensor], cfg: dict, phoneme: Tensor, melspec: T
     memory = x
 
     # decoder side (:297-306); DecoderPreNet :65-66 has fixed dropout 0.5
-    y = _drop(F.relu(F.linear(tgt_in, sd["dec_prenet.linear1.linear.weight"],
+    y = _drop(_relu(F.linear(tgt_in, sd["dec_prenet.linear1.linear.weight"],
                               sd["dec_prenet.linear1.linear.bias"])), 0.5, drop_on)
-    y = _drop(F.relu(F.linear(y, sd["dec_prenet.linear2.linear.weight"],
+    y = _drop(_relu(F.linear(y, sd["dec_prenet.linear2.linear.weight"],
                               sd["dec_prenet.linear2.linear.bias"])), 0.5, drop_on)
     y = positional_encoding(sd, y, 0.1, drop_on)
     aligns: List[Tensor] = []

@@ -18,7 +18,8 @@ GATE = 1e-4        # outputs: north_star's stated fp32 tolerance (measured 1e-6 
 # Measured on the base config: all gradients above the first flipped FFN layer agree to 5e-7, everything below it
 # to 3e-5 .. 6e-4 (pe.alpha and dec_prenet.linear1.weight, both cancellation-heavy sums, are the worst; which
 # units flip depends on the rounding of the particular GEMM kernel in use).
-GRAD_GATE = 2e-3       # base config (hundreds of thousands of ReLU units: flips happen in most runs)
+GRAD_GATE = 2e-3       # base config, flips included (3e7 ReLU units: a few flip in every run; asserted to be the whole
+#                        gap in test_gradient_gap_is_relu_gate_flips, where the flip-free gate is 2e-5)
 GRAD_GATE_TINY = 1e-4  # tiny config (no flip observed): the tight end-to-end gradient check
 
 
@@ -130,6 +131,114 @@ def test_golden_outputs_direct(golden_dir):
         assert rel_l2(out[k], torch.from_numpy(g[f"train/{k}"])) < GATE, k
     for i, a in enumerate(out["alignments"]):
         assert rel_l2(a[:, :, ::st], torch.from_numpy(g[f"train/align{i}"])) < GATE
+
+
+def test_golden_gradients_direct(golden_dir):
+    """HIP gradients against the reference's OWN fp32 backward (tests/golden/base_model.npz: per-parameter norms and
+    strided samples written by make_golden.py from the imported reference).  Both sides are fp32 evaluations with their
+    own ReLU gate flips against exact arithmetic (see test_gradient_gap_is_relu_gate_flips), so the gate is the sum of
+    the two spreads; parameters that no flip reaches agree to ~1e-6."""
+    from oracle import synth_batch
+    from transformertts_amd.loss import TransformerTTSLoss
+    g = np.load(os.path.join(golden_dir, "base_model.npz"))
+    cfg, m = _build(str(g["meta/cfg_name"]), int(g["meta/w_seed"]))
+    batch = synth_batch(int(g["meta/B"]), int(g["meta/Tp"]), int(g["meta/Tm"]), cfg["n_mels"], cfg["n_phon"], ragged=True,
+                        seed=int(g["meta/b_seed"]))
+    args = [batch[k].to("cuda") for k in ("phoneme", "melspec", "phoneme_lens", "melspec_lens")]
+    m.train()
+    loss = TransformerTTSLoss(8.0).to("cuda")(m(*args), args[1], args[3])
+    assert abs(loss["total"].item() - float(g["train/loss_total"])) < 1e-5 * abs(float(g["train/loss_total"]))
+    loss["total"].backward()
+    errs = {}
+    for name, p in m.named_parameters():
+        ref_norm = float(g[f"gradnorm/{name}"])
+        flat = p.grad.flatten()[::int(g[f"gradstride/{name}"])].cpu()
+        ref = torch.from_numpy(g[f"gradsample/{name}"])
+        if ref_norm < 1e-7:                       # analytically zero (conv bias in front of BN, key bias of a softmax)
+            assert float(p.grad.norm()) < 1e-4, name
+            continue
+        assert abs(float(p.grad.double().norm()) - ref_norm) < GRAD_GATE * ref_norm, name
+        errs[name] = rel_l2(flat, ref)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_golden_gradients.txt", "w") as f:
+        for k, v in sorted(errs.items(), key=lambda kv: -kv[1]):
+            f.write(f"{v:.3e} {k}\n")
+    bad = {k: v for k, v in errs.items() if not v < GRAD_GATE}
+    assert not bad, bad
+    assert sorted(errs.values())[len(errs) // 2] < 1e-4        # the typical parameter is far inside the gate
+
+
+def test_gradient_gap_is_relu_gate_flips():
+    """Why the end-to-end gradient gate is looser than the 1e-6 every backward kernel meets on its own: a ReLU is the one
+    discontinuous operation on the path.  A pre-activation within rounding distance of zero is gated differently by two
+    correct evaluations in different precision, and a flipped unit perturbs its own weight gradient and everything below
+    it.  Made an assertion here, on the full-length base case:
+      (1) the HIP path and the fp64 oracle disagree on the gate of only a handful of units out of ~1.4e7, and every one of
+          them has |pre-activation| < 1e-5 in fp64 (measured: 1 unit of 1.37e7);
+      (2) evaluating the fp64 oracle UNDER THE HIP PATH'S GATES makes every parameter gradient agree to FLIP_FREE_GATE --
+          the flips are the entire gap;
+      (3) the HIP path's typical parameter error is no larger than that of the oracle evaluated in stock fp32."""
+    from oracle import synth_batch, oracle_forward, oracle_loss, relu_gates
+    from transformertts_amd import ops
+    from transformertts_amd.loss import TransformerTTSLoss
+    cfg_name, B, Tp, Tm, w_seed, b_seed = "base", 4, 100, 870, 13, 23
+    cfg, m = _build(cfg_name, w_seed)
+    batch = synth_batch(B, Tp, Tm, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=b_seed)
+    args = [batch[k].to("cuda") for k in ("phoneme", "melspec", "phoneme_lens", "melspec_lens")]
+    m.train()
+    hip_out = []
+    ops._relu_observer = lambda y: hip_out.append((y.detach() > 0).cpu())
+    try:
+        out = m(*args)
+    finally:
+        ops._relu_observer = None
+    TransformerTTSLoss(8.0).to("cuda")(out, args[1], args[3])["total"].backward()
+
+    def oracle_grads(dtype, gates=None, record=False):
+        from oracle import fill_state
+        sd = fill_state(cfg, w_seed)
+        for k in list(sd):
+            if sd[k].is_floating_point():
+                sd[k] = sd[k].to(dtype)
+                if "running" not in k and k != "pe.pe":
+                    sd[k].requires_grad_(True)
+        with relu_gates(gates=gates) as rec:
+            ref = oracle_forward(sd, cfg, batch["phoneme"], batch["melspec"].to(dtype), batch["phoneme_lens"],
+                                 batch["melspec_lens"], training=True, dropout=False)
+        oracle_loss(ref, batch["melspec"].to(dtype), batch["melspec_lens"])["total"].backward()
+        return {k: v.grad for k, v in sd.items() if v.requires_grad}, rec.pre
+
+    g64, pre64 = oracle_grads(torch.float64)
+    assert len(pre64) == len(hip_out) == cfg["encoder_n_layers"] + 2 + cfg["decoder_n_layers"]
+    flips, units = 0, 0
+    for pre, gate in zip(pre64, hip_out):
+        diff = (pre > 0) != gate.reshape(pre.shape)
+        flips += int(diff.sum())
+        units += pre.numel()
+        if diff.any():
+            assert float(pre[diff].abs().max()) < 1e-5, "a unit far from zero was gated differently"
+    assert flips < 200 and units > 1e7, (flips, units)
+    ggate, _ = oracle_grads(torch.float64, gates=[g.to(torch.float64) for g in hip_out])
+    g32, _ = oracle_grads(torch.float32)
+    FLIP_FREE_GATE = 2e-5
+    rows = []
+    for name, p in m.named_parameters():
+        if g64[name].norm().item() < 1e-7 * max(1.0, p.detach().norm().item()):
+            continue
+        rows.append((name, rel_l2(p.grad, ggate[name]), rel_l2(p.grad, g64[name]), rel_l2(g32[name], g64[name])))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_gate_flips.txt", "w") as f:
+        f.write(f"# {flips} of {units} ReLU units gated differently by the HIP path and the fp64 oracle\n")
+        f.write("# hip_vs_fp64_under_hip_gates  hip_vs_fp64  oracle_fp32_vs_fp64  parameter\n")
+        for name, a, b, c in sorted(rows, key=lambda r: -r[2]):
+            f.write(f"{a:.3e} {b:.3e} {c:.3e} {name}\n")
+    bad = {n: a for n, a, _, _ in rows if not a < FLIP_FREE_GATE}
+    assert not bad, bad
+    # (3) stock fp32 torch against its own fp64 (whether IT flips a unit depends on its summation order, i.e. on the
+    # host's thread count: 8e-5 on the 8-core build container, 5e-6 on the 16-core GPU box): the HIP path's typical
+    # parameter is no worse than stock fp32's
+    med = lambda xs: sorted(xs)[len(xs) // 2]
+    assert med([b for _, _, b, _ in rows]) <= 3.0 * med([c for _, _, _, c in rows])
 
 
 def test_training_step_surface():

@@ -365,6 +365,10 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
+# Test seam: called with the output of every relu-epilogue Linear, in call order (which units the HIP path gated off).
+_relu_observer = None
+
+
 class _ReluToken:
     """Handshake between a Linear with a relu(+dropout) epilogue and the ONE Linear that consumes its output: the
     consumer's data-gradient kernel applies the producer's backward mask in its epilogue and says so here."""
@@ -400,6 +404,8 @@ def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_sh
     y = LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out, tok_in, skip_in, skip_out)
     if tok_out is not None:
         y._ttts_relu_token = tok_out
+        if _relu_observer is not None:
+            _relu_observer(y)
     return y
 
 
