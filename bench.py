@@ -78,11 +78,15 @@ class GemmProbe:
     the kernel instantiation the library dispatches it to (ttts_gemm_tile_choice); `summary()` reports the
     instantiation with the largest total time = the dominant kernel of the step."""
 
-    TILES = {1: "64,64,2,2", 2: "128,128,2,2", 3: "64,128,2,2", 4: "128,96,4,1"}
+    TILES = {1: "64,64,2,2", 2: "128,128,2,2", 3: "64,128,2,2", 4: "128,96,4,1", 6: "256,256,2,4", 7: "256,128,4,2"}
     # name -> (x6?, extractor of (M, N, K) from the C-ABI argument tuple)
     CALLS = {
         "ttts_linear_fwd": (0, lambda a: (a[5], a[6], a[7])),
         "ttts_linear_fwd_x6": (1, lambda a: (a[5], a[6], a[7])),
+        "ttts_linear_fwd_h3": (2, lambda a: (a[5], a[6], a[7])),
+        "ttts_conv1d_fwd_h3": (2, lambda a: (a[4] * a[5], a[7], a[6] * a[8])),
+        "ttts_linear_bwd_data_h3": (2, lambda a: (a[4], a[6], a[5])),
+        "ttts_conv1d_bwd_data_h3": (2, lambda a: (a[3] * a[4], a[5], a[6] * a[7])),
         "ttts_linear_bwd_data": (0, lambda a: (a[4], a[6], a[5])),        # (dy, w, res, dx, M, N, K): out N_gemm = K, red = N
         "ttts_linear_bwd_data_x6": (1, lambda a: (a[4], a[6], a[5])),
         "ttts_conv1d_fwd": (0, lambda a: (a[4] * a[5], a[7], a[6] * a[8])),
@@ -128,9 +132,13 @@ class GemmProbe:
         key = max(groups, key=lambda k: groups[k][1])
         n, ms, fl = groups[key]
         x6, tile = key
-        name = (f"gemm_bf16x6_kernel<{self.TILES[tile]}>" if x6 else f"gemm_f32_kernel<{self.TILES[tile]},true,*>")
-        return {"kernel": name, "x6": bool(x6), "launches": n, "avg_ms": ms / n, "avg_flops": fl / n,
-                "tflops": fl / (ms * 1e-3) / 1e12, "total_ms": ms}
+        name = (f"gemm_f32_kernel<{self.TILES[tile]},true,*>", f"gemm_bf16x6_kernel<{self.TILES[tile]}>",
+                f"gemm_h3_kernel<{self.TILES[tile]}>")[x6]
+        others = {(f"{('f32', 'bf16x6', 'h3')[k[0]]}<{self.TILES[k[1]]}>"): {"launches": v[0], "total_ms": v[1],
+                                                                              "tflops": v[2] / (v[1] * 1e-3) / 1e12}
+                  for k, v in groups.items()}
+        return {"kernel": name, "form": x6, "launches": n, "avg_ms": ms / n, "avg_flops": fl / n,
+                "tflops": fl / (ms * 1e-3) / 1e12, "total_ms": ms, "all": others}
 
 
 def usable_cores() -> int:
@@ -383,8 +391,10 @@ def main():
             # bf16 peak / 6.  `frac` is priced against THAT ceiling; the fp32-MFMA peak (157.3 TF, what a plain
             # v_mfma_f32 kernel is bound by, and the peak of the dtype) is reported beside it as a floor the kernel beats.
             traffic, traffic_src = measured_traffic(probe["kernel"])
-            if probe["x6"]:
-                peak, peak_note = PEAK_BF16_MFMA_TFLOPS / 6.0, "dense bf16 MFMA peak (2.5 PFLOP/s) / 6 MFMA terms per fp32 product"
+            terms = (0, 6, 3)[probe["form"]]
+            if terms:
+                peak = PEAK_BF16_MFMA_TFLOPS / terms
+                peak_note = (f"dense {'bf16' if terms == 6 else 'f16'} MFMA peak (2.5 PFLOP/s) / {terms} MFMA terms per fp32 product")
             else:
                 peak, peak_note = PEAK_F32_MFMA_TFLOPS, "fp32-input MFMA peak"
             out["roofline"] = {"bound": "mfma", "kernel": probe["kernel"],
@@ -394,8 +404,9 @@ def main():
                                "vs_fp32_mfma_peak": probe["tflops"] / PEAK_F32_MFMA_TFLOPS,
                                "launches_per_step": probe["launches"], "avg_launch_ms": probe["avg_ms"],
                                "avg_launch_gflop": probe["avg_flops"] / 1e9, "step_share_ms": probe["total_ms"]}
-            if probe["x6"]:
-                out["roofline"]["executed_bf16_tflops"] = 6.0 * probe["tflops"]
+            if terms:
+                out["roofline"]["executed_16bit_mfma_tflops"] = terms * probe["tflops"]
+            out["roofline"]["gemm_kernels"] = probe["all"]
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.tp, args.config)
         print(json.dumps(out), flush=True)

@@ -83,9 +83,18 @@ int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db
  *   mode 0  linear forward     planes of w (N,K)               rows = N,    cols = K
  *   mode 1  linear data-grad   planes of w^T                   rows = K,    cols = N
  *   mode 2  conv forward       [co][tap*cin + ci]              rows = cout, cols = taps*cin,  channels_per_tap = cin
- *   mode 3  conv data-grad     [ci][tap*cout + co]             rows = cin,  cols = taps*cout, channels_per_tap = cout */
+ *   mode 3  conv data-grad     [ci][tap*cout + co]             rows = cin,  cols = taps*cout, channels_per_tap = cout
+ *
+ * fp16x3 ("h3") form: modes 4-7 of ttts_weight_split are the same four matrices as modes 0-3 written as
+ * TWO f16 planes (hi, lo) of w * 2^12, stored [cols/32][plane][rows][32] (cols, and channels_per_tap for the conv modes,
+ * must be multiples of 32).  ttts_linear_fwd_h3 / ttts_conv1d_fwd_h3 take such planes and form each product from three
+ * f16 x f16 MFMA terms (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, activations pre-scaled by 2^4 while they are staged): the
+ * same fp32-grade result (error vs fp64 a few 1e-7) for half the matrix-pipe work.  f16 has no bf16-like exponent range:
+ * the fixed pre-scales suit O(1) activations and O(1/sqrt(fan_in)) weights -- the forward operands of this model --
+ * and activations of magnitude >= 4096 come out as inf.  Gradient operands get a dynamic pre-scale (ttts_amax_partials). */
 size_t ttts_split_bytes(int64_t rows, int64_t cols);
-/* tile shape the forward / data-gradient dispatch uses for an M x N output (1: 64x64, 2: 128x128, 3: 64x128, 4: 128x96) */
+/* tile shape the forward / data-gradient dispatch uses for an M x N output (1: 64x64, 2: 128x128, 3: 64x128, 4: 128x96);
+ * x6 = 0: fp32-MFMA kernel, 1: bf16x6 kernel, 2: fp16x3 kernel */
 int ttts_gemm_tile_choice(int64_t M, int N, int x6);
 int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode, int channels_per_tap, int taps,
                       void* stream);
@@ -95,6 +104,20 @@ int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks,
 int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
                        int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift, int T,
                     void* stream);
+int ttts_linear_fwd_h3(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
+                       int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift,
+                       int T, void* stream);
+int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
+                       int taps, void* stream);
+/* fp16x3 data gradients.  A gradient's magnitude is not known in advance (1e-7 .. 1e-5 behind a mean-reduced loss), so
+ * its pre-scale is dynamic: ttts_amax_partials writes 1024 partial maxima of |dy| (one read of dy, no atomics, no host
+ * round trip) and the GEMM scales dy by the power of two that puts max|dy| in [2^11, 2^12) -- full 22-bit precision for
+ * every element within 2^-15 of the largest, absolute error 2^-29 * 2^-11 * max|dy| below that.  planes: modes 5 / 7. */
+int ttts_amax_partials(const float* x, int64_t n, float* partials /* 1024 floats */, void* stream);
+int ttts_linear_bwd_data_h3(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
+                            int K, const float* relu_out, float relu_scale, const float* dy_amax, void* stream);
+int ttts_conv1d_bwd_data_h3(const float* dy, const void* planes_bwd, float* dx, int B, int T, int cin, int cout, int taps,
+                            const float* dy_amax, void* stream);
 int ttts_linear_bwd_data_x6(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
                             int K, const float* relu_out, float relu_scale, void* stream);
 int ttts_conv1d_fwd_x6(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,

@@ -64,6 +64,107 @@ def test_linear_forms_agree_with_fp64(M, N, K):
         assert rc == 0 and _rel(dw, 2 * dw_ref) < TOL and _rel(db, 2 * db_ref) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1024, 256), (777, 256, 1024), (129, 80, 256), (64, 96, 32)])
+def test_fp16x3_forward_form_agrees_with_fp64(M, N, K):
+    """The fp16x3 forward kernel (three f16 MFMA terms on pre-scaled operands, csrc/gemm_h3.hip) against fp64: same gate
+    as the bf16x6 and fp32-MFMA forms, with every epilogue (bias, relu, residual, dropout mask identical to the bf16x6
+    kernel's, go-frame row shift), and over the operand magnitudes its fixed pre-scales are specified for."""
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    b = _rand(N, seed=3)
+    for a_scale, w_scale in ((1.0, 1.0), (30.0, 0.2), (0.02, 5.0)):         # large and small activations / weights
+        x, w = _rand(M, K, seed=1) * a_scale, _rand(N, K, seed=2, scale=K ** -0.5) * w_scale
+        ref = x.double() @ w.double().t() + b.double()
+        y = torch.empty(M, N, device=_dev())
+        pl = ops._planes(w, 4, N, K)
+        assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream()) == 0
+        assert _rel(y, ref) < TOL, (a_scale, w_scale, _rel(y, ref))
+    x, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    pl, pl6 = ops._planes(w, 4, N, K), ops._planes(w, 0, N, K)
+    res = _rand(M, N, seed=8)
+    ref = x.double() @ w.double().t() + b.double()
+    y, y6 = torch.empty(M, N, device=_dev()), torch.empty(M, N, device=_dev())
+    assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), _p(res), _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream()) == 0
+    assert _rel(y, ref + res.double()) < TOL
+    assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 1, 0.0, 0, None, 0, 0, _stream()) == 0
+    assert _rel(y, torch.relu(ref)) < TOL
+    assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.3, 1234, None, 0, 0, _stream()) == 0
+    assert lib.ttts_linear_fwd_x6(_p(x), _p(pl6), _p(b), None, _p(y6), M, N, K, 0, 0.3, 1234, None, 0, 0, _stream()) == 0
+    assert torch.equal(y == 0, y6 == 0) and _rel(y, y6) < TOL           # same counter-based mask in both forms
+    if M % 10 == 0:                                                     # go-frame shift inside utterances of T rows
+        T = M // 10
+        assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, -1, T, _stream()) == 0
+        xs = torch.roll(x.view(10, T, K), 1, dims=1).clone()
+        xs[:, 0] = 0
+        assert _rel(y, xs.view(M, K).double() @ w.double().t() + b.double()) < TOL
+    # out of the window the kernel is specified for: an activation >= 4096 saturates visibly, never silently
+    x2 = x.clone()
+    x2[3, 5] = 5000.0
+    assert lib.ttts_linear_fwd_h3(_p(x2), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream()) == 0
+    assert not torch.isfinite(y[3]).all() and torch.isfinite(y[4]).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1024, 256), (777, 256, 1024), (129, 96, 80)])
+@pytest.mark.parametrize("mag", [1.0, 3e-7, 1e-12, 1e6])
+def test_fp16x3_data_gradient_with_dynamic_scale(M, N, K, mag):
+    """dx = dy . w in the fp16x3 form for gradients of ANY magnitude (3e-7 is what a mean-reduced loss produces): the
+    pre-scale comes from ttts_amax_partials.  Includes a wide in-tensor range (one row 1e4 x larger than the rest, padded
+    rows exactly zero), the fused relu-gate / residual epilogue, and an all-zero dy."""
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    w = _rand(N, K, seed=2, scale=K ** -0.5)
+    dy = _rand(M, N, seed=4) * mag
+    dy[5] *= 1e4
+    dy[M - 7:] = 0.0
+    plt = ops._planes(w, 5, K, N)
+    dx = torch.empty(M, K, device=_dev())
+    am = ops._amax(dy)
+    assert abs(am.max().item() - dy.abs().max().item()) == 0.0
+    assert lib.ttts_linear_bwd_data_h3(_p(dy), _p(plt), None, _p(dx), M, N, K, None, 1.0, _p(am), _stream()) == 0
+    ref = dy.double() @ w.double()
+    assert _rel(dx, ref) < TOL, _rel(dx, ref)
+    small = torch.ones(M, dtype=torch.bool); small[5] = False                  # the small rows on their own, not drowned by row 5
+    assert _rel(dx[small.to(_dev())], ref[small.to(_dev())]) < TOL
+    hfwd = torch.relu(_rand(M, K, seed=5))
+    res = _rand(M, K, seed=7) * mag
+    assert lib.ttts_linear_bwd_data_h3(_p(dy), _p(plt), _p(res), _p(dx), M, N, K, _p(hfwd), 1.25, _p(am), _stream()) == 0
+    assert _rel(dx, ref * (hfwd > 0).double() * 1.25 + res.double()) < TOL
+    zero = torch.zeros_like(dy)
+    assert lib.ttts_linear_bwd_data_h3(_p(zero), _p(plt), None, _p(dx), M, N, K, None, 1.0, _p(ops._amax(zero)), _stream()) == 0
+    assert float(dx.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128), (4, 33, 80, 64)])
+def test_fp16x3_conv_data_gradient(B, T, cin, cout):
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    w = _rand(cout, cin, 5, seed=2, scale=(5 * cin) ** -0.5)
+    dy = _rand(B, T, cout, seed=3) * 2e-7
+    xd = torch.zeros(B, T, cin, dtype=torch.float64, device=_dev(), requires_grad=True)
+    y = torch.nn.functional.conv1d(xd.transpose(1, 2), w.double(), None, padding=2).transpose(1, 2)
+    y.backward(dy.double())
+    dx = torch.empty(B, T, cin, device=_dev())
+    pl = ops._planes(w, 7, cin, 5 * cout, cout, 5)
+    assert lib.ttts_conv1d_bwd_data_h3(_p(dy), _p(pl), _p(dx), B, T, cin, cout, 5, _p(ops._amax(dy)), _stream()) == 0
+    assert _rel(dx, xd.grad) < TOL, _rel(dx, xd.grad)
+
+
+@pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128), (4, 33, 64, 80)])
+def test_fp16x3_conv_forward_agrees_with_fp64(B, T, cin, cout):
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    x, w, b = _rand(B, T, cin, seed=1), _rand(cout, cin, 5, seed=2, scale=(5 * cin) ** -0.5), _rand(cout, seed=3)
+    ref = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), b.double(), padding=2).transpose(1, 2)
+    y = torch.empty(B, T, cout, device=_dev())
+    pl = ops._planes(w, 6, cout, 5 * cin, cin, 5)
+    assert lib.ttts_conv1d_fwd_h3(_p(x), _p(pl), _p(b), _p(y), B, T, cin, cout, 5, _stream()) == 0
+    assert _rel(y, ref) < TOL, _rel(y, ref)
+
+
 @pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128)])
 def test_conv_weight_gradient_forms(B, T, cin, cout):
     """Both weight-gradient kernels on the conv form (shifted rows, utterance clipping, utterances shorter than a k-step)."""

@@ -31,6 +31,11 @@ SIGNATURES = {
     "ttts_weight_split": (I, [P, P, I, I, I, I, I, P]),
     "ttts_weight_split_batched": (I, [P, I, L, P]),
     "ttts_linear_fwd_x6": (I, [P, P, P, P, P, L, I, I, I, F, U, P, I, I, P]),
+    "ttts_linear_fwd_h3": (I, [P, P, P, P, P, L, I, I, I, F, U, P, I, I, P]),
+    "ttts_conv1d_fwd_h3": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "ttts_amax_partials": (I, [P, L, P, P]),
+    "ttts_linear_bwd_data_h3": (I, [P, P, P, P, L, I, I, P, F, P, P]),
+    "ttts_conv1d_bwd_data_h3": (I, [P, P, P, I, I, I, I, I, P, P]),
     "ttts_linear_bwd_data_x6": (I, [P, P, P, P, L, I, I, P, F, P]),
     "ttts_conv1d_fwd_x6": (I, [P, P, P, P, I, I, I, I, I, P]),
     "ttts_conv1d_bwd_data_x6": (I, [P, P, P, I, I, I, I, I, P]),

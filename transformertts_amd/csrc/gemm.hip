@@ -17,7 +17,7 @@
 //           gradients (with the same per-tap row shift / utterance clipping as above).
 #include <stdlib.h>
 
-#include "ttts_common.h"
+#include "gemm_common.h"
 
 namespace ttts {
 
@@ -33,46 +33,6 @@ namespace ttts {
 constexpr int BK = TTTS_GEMM_BK;          // k-tile depth (floats)
 constexpr int KC_LD = BK + 1;   // LDS row stride for K-contiguous tiles (odd -> conflict-free b32 reads)
 
-struct GemmArgs {
-    const float* A;
-    const float* B;
-    float* C;
-    int M, N, K;
-    long lda, ldb, ldc;
-    // implicit row shift (conv taps / go-frame): rows are (b*T + t)
-    int T;           // 0: no utterance clipping (shift must be 0)
-    int cin;         // A_KC: channels per tap (K = taps*cin)
-    int shift0, shift_step;
-    int ztaps;       // !B_KC: number of taps spread over blockIdx.z (z = split*ztaps + tap)
-    // split over the reduction dimension
-    int kt_per_split;
-    long c_zstride;  // C offset per z slice
-    // epilogue (applied only when kt range covers all of K, i.e. no split)
-    const float* bias;
-    int act;         // 0 none, 1 relu
-    float drop_scale;
-    uint32_t drop_thr;
-    uint64_t seed;
-    const uint64_t* step_seed;   // per-step word XORed into seed (NULL: none); see site_seed()
-    const float* residual;
-    long ldr;
-    // data-gradient form: the output is the gradient w.r.t. an activation h = drop(relu(.)) whose forward value is
-    // relu_out (same shape as C): v = relu_out > 0 ? v * relu_scale : 0   (fused relu / dropout backward mask)
-    const float* relu_out;
-    float relu_scale;
-    // weight-gradient form only: per-split column sums of A (= bias gradient partials), [zsplit][M]
-    float* colsum;
-    // operand extents in bytes (< 4 GiB): loads go through raw buffer descriptors, so an out-of-range offset returns
-    // zeros in hardware -- row / column / tap clipping costs a select on the offset instead of a branch around the load
-    uint32_t a_bytes, b_bytes;
-};
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr uint32_t OOB = 0xFFFFFFFFu;
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_f32_kernel(GemmArgs g) {
@@ -399,7 +359,6 @@ static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t stream) {
     return TTTS_OK;
 }
 
-enum { TILE_AUTO = 0, TILE_64 = 1, TILE_128 = 2, TILE_64x128 = 3, TILE_128x96 = 4, TILE_96x128 = 5 };
 
 // Pick the tile that minimises the busiest CU's work: ceil(tiles / 256 CUs) workgroups in sequence, each costing
 // its area divided by how efficiently that tile shape runs.  E.g. M = 55 680, N = 256 in fp32: 870 tiles of 128x128
@@ -493,8 +452,12 @@ __global__ __launch_bounds__(256) void weight_split_batched_kernel(const long* _
         if (descs[mid * 8 + 7] <= blk) lo = mid; else hi = mid - 1;
     }
     const long* d = descs + lo * 8;
-    weight_split_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
-                     (int)d[4], (int)d[5], (int)d[6], (blk - d[7]) * 256 + threadIdx.x);
+    if (d[4] >= 4)      // modes 4-7: the fp16x3 image of modes 0-3 (block-uniform branch)
+        weight_split_h3_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2],
+                            (int)d[3], (int)d[4] - 4, (int)d[5], (int)d[6], (blk - d[7]) * 256 + threadIdx.x);
+    else
+        weight_split_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
+                         (int)d[4], (int)d[5], (int)d[6], (blk - d[7]) * 256 + threadIdx.x);
 }
 
 template <int BM, int BN, int WM, int WN, bool CLIP>
@@ -971,6 +934,7 @@ static GemmArgs base_args() {
     g.bias = nullptr; g.act = 0; g.drop_scale = 1.f; g.drop_thr = 0; g.seed = 0; g.step_seed = nullptr;
     g.residual = nullptr; g.ldr = 0; g.colsum = nullptr; g.a_bytes = 0; g.b_bytes = 0;
     g.relu_out = nullptr; g.relu_scale = 1.f;
+    g.a_amax = nullptr; g.a_amax_n = 0;
     return g;
 }
 
@@ -1186,7 +1150,9 @@ int ttts_conv1d_bwd_weight_x6(const float* dy, const float* x, float* dw, float*
 
 int ttts_gemm_tile_choice(int64_t M, int N, int x6) {
     // which tile the forward / data-gradient dispatch picks for an M x N output: 1 = 64x64, 2 = 128x128, 3 = 64x128,
-    // 4 = 128x96 (profiling aid: lets a host-side probe attribute a launch to its kernel instantiation)
+    // 4 = 128x96 (profiling aid: lets a host-side probe attribute a launch to its kernel instantiation);
+    // x6 = 0: fp32 MFMA kernel, 1: bf16x6, 2: fp16x3
+    if (x6 == 2) return h3_tile_choice(M, N);
     if (N <= 96 && (long)cdiv(M, 128) >= 384) return TILE_128x96;
     return choose_tile(M, N, 1, x6 != 0);
 }
@@ -1197,10 +1163,16 @@ int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode
                       void* stream) {
     // planes[3][rows][cols] bf16 (hi, mid, lo) of a weight re-laid as the K-contiguous B operand; modes in gemm.hip
     TTTS_REQUIRE(w && planes && rows > 0 && cols > 0, "weight_split: bad arguments");
-    TTTS_REQUIRE(mode >= 0 && mode <= 3, "weight_split: mode must be 0..3");
-    TTTS_REQUIRE(cols % BK == 0, "weight_split: cols=%d must be a multiple of %d", cols, BK);
-    TTTS_REQUIRE(mode < 2 || (channels_per_tap > 0 && taps > 0 && cols == channels_per_tap * taps),
+    TTTS_REQUIRE(mode >= 0 && mode <= 7, "weight_split: mode must be 0..7");
+    TTTS_REQUIRE(cols % (mode >= 4 ? HBK : BK) == 0, "weight_split: cols=%d must be a multiple of %d", cols, mode >= 4 ? HBK : BK);
+    TTTS_REQUIRE((mode & 3) < 2 || (channels_per_tap > 0 && taps > 0 && cols == channels_per_tap * taps),
                  "weight_split: conv modes need cols == channels_per_tap * taps");
+    if (mode >= 4) {
+        TTTS_REQUIRE((mode & 3) < 2 || channels_per_tap % HBK == 0, "weight_split: fp16x3 conv image needs channels %% 32 == 0");
+        launch_weight_split_h3(w, planes, rows, cols, mode - 4, channels_per_tap, taps, (hipStream_t)stream);
+        TTTS_LAUNCH_CHECK("weight_split_h3_kernel");
+        return TTTS_OK;
+    }
     long n = (long)rows * cols;
     hipLaunchKernelGGL(weight_split_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        (unsigned short*)planes, rows, cols, mode, channels_per_tap, taps);
@@ -1237,6 +1209,79 @@ int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, 
     if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; g.step_seed = step_seed; }
     g.residual = residual; g.ldr = N;
     return dispatch_split(g, (hipStream_t)stream);
+}
+
+int ttts_linear_fwd_h3(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
+                       int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift,
+                       int T, void* stream) {
+    TTTS_REQUIRE(x && w_planes && y, "linear_fwd_h3: null pointer");
+    TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_fwd_h3: bad dims");
+    TTTS_REQUIRE(K % HBK == 0 && N % 4 == 0, "linear_fwd_h3: K=%d must be a multiple of %d and N=%d of 4", K, HBK, N);
+    TTTS_REQUIRE(aligned16(x) && aligned16(w_planes), "linear_fwd_h3: x / planes must be 16-byte aligned");
+    TTTS_REQUIRE(act == 0 || act == 1, "linear_fwd_h3: act must be 0 (none) or 1 (relu)");
+    TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "linear_fwd_h3: dropout p out of [0,1)");
+    TTTS_REQUIRE(row_shift == 0 || (T > 0 && M % T == 0), "linear_fwd_h3: row_shift needs T>0 and M %% T == 0");
+    TTTS_REQUIRE((uint64_t)M * K * 4 < (1ull << 32) && (uint64_t)N * K * 4 < (1ull << 32), "linear_fwd_h3: operand larger than 4 GiB");
+    GemmArgs g = base_args();
+    g.A = x; g.B = (const float*)w_planes; g.C = y; g.M = (int)M; g.N = N; g.K = K;
+    g.lda = K; g.ldb = K; g.ldc = N;
+    g.a_bytes = (uint32_t)((uint64_t)M * K * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 4);
+    g.cin = K; g.shift0 = row_shift; g.T = (row_shift != 0) ? T : 0;
+    g.bias = bias; g.act = act;
+    if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; g.step_seed = step_seed; }
+    g.residual = residual; g.ldr = N;
+    return dispatch_h3(g, (hipStream_t)stream);
+}
+
+int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
+                       int taps, void* stream) {
+    TTTS_REQUIRE(x && planes_fwd && y, "conv1d_fwd_h3: null pointer");
+    TTTS_REQUIRE(B > 0 && T > 0 && cin > 0 && cout > 0 && taps > 0 && (taps & 1), "conv1d_fwd_h3: bad dims");
+    TTTS_REQUIRE(cin % HBK == 0 && cout % 4 == 0, "conv1d_fwd_h3: cin=%d must be a multiple of %d and cout=%d of 4", cin, HBK, cout);
+    TTTS_REQUIRE((uint64_t)B * T * cin * 4 < (1ull << 32), "conv1d_fwd_h3: activation larger than 4 GiB");
+    TTTS_REQUIRE(aligned16(x) && aligned16(planes_fwd), "conv1d_fwd_h3: pointers must be 16-byte aligned");
+    GemmArgs g = base_args();
+    g.A = x; g.B = (const float*)planes_fwd; g.C = y; g.M = B * T; g.N = cout; g.K = taps * cin;
+    g.lda = cin; g.ldb = (long)taps * cin; g.ldc = cout;
+    g.a_bytes = (uint32_t)((uint64_t)B * T * cin * 4); g.b_bytes = (uint32_t)((uint64_t)cout * taps * cin * 4);
+    g.T = T; g.cin = cin; g.shift0 = -((taps - 1) / 2); g.shift_step = 1;
+    g.bias = bias;
+    return dispatch_h3(g, (hipStream_t)stream);
+}
+
+int ttts_linear_bwd_data_h3(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
+                            int K, const float* relu_out, float relu_scale, const float* dy_amax, void* stream) {
+    // dx[M,K] = dy[M,N] . w[N,K] (+ residual) in the fp16x3 form; wt_planes = weight_split mode 5 (w^T as [K][N] rows);
+    // dy_amax = the partial maxima of |dy| written by ttts_amax_partials (the dynamic pre-scale of the gradient operand)
+    TTTS_REQUIRE(dy && wt_planes && dx && dy_amax, "linear_bwd_data_h3: null pointer");
+    TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_bwd_data_h3: bad dims");
+    TTTS_REQUIRE(N % HBK == 0 && K % 4 == 0, "linear_bwd_data_h3: N=%d must be a multiple of %d and K=%d of 4", N, HBK, K);
+    TTTS_REQUIRE(aligned16(dy) && aligned16(wt_planes), "linear_bwd_data_h3: pointers must be 16-byte aligned");
+    TTTS_REQUIRE((uint64_t)M * N * 4 < (1ull << 32) && (uint64_t)N * K * 4 < (1ull << 32), "linear_bwd_data_h3: operand larger than 4 GiB");
+    GemmArgs g = base_args();
+    g.A = dy; g.B = (const float*)wt_planes; g.C = dx; g.M = (int)M; g.N = K; g.K = N;
+    g.lda = N; g.ldb = N; g.ldc = K; g.cin = N;
+    g.a_bytes = (uint32_t)((uint64_t)M * N * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 4);
+    g.residual = residual; g.ldr = K;
+    g.relu_out = relu_out; g.relu_scale = relu_scale;
+    g.a_amax = dy_amax; g.a_amax_n = H3_AMAX_PARTIALS;
+    return dispatch_h3(g, (hipStream_t)stream);
+}
+
+int ttts_conv1d_bwd_data_h3(const float* dy, const void* planes_bwd, float* dx, int B, int T, int cin, int cout, int taps,
+                            const float* dy_amax, void* stream) {
+    TTTS_REQUIRE(dy && planes_bwd && dx && dy_amax, "conv1d_bwd_data_h3: null pointer");
+    TTTS_REQUIRE(B > 0 && T > 0 && cin > 0 && cout > 0 && taps > 0 && (taps & 1), "conv1d_bwd_data_h3: bad dims");
+    TTTS_REQUIRE(cout % HBK == 0 && cin % 4 == 0, "conv1d_bwd_data_h3: cout=%d must be a multiple of %d and cin=%d of 4", cout, HBK, cin);
+    TTTS_REQUIRE((uint64_t)B * T * cout * 4 < (1ull << 32), "conv1d_bwd_data_h3: activation larger than 4 GiB");
+    TTTS_REQUIRE(aligned16(dy) && aligned16(planes_bwd), "conv1d_bwd_data_h3: pointers must be 16-byte aligned");
+    GemmArgs g = base_args();
+    g.A = dy; g.B = (const float*)planes_bwd; g.C = dx; g.M = B * T; g.N = cin; g.K = taps * cout;
+    g.lda = cout; g.ldb = (long)taps * cout; g.ldc = cin;
+    g.a_bytes = (uint32_t)((uint64_t)B * T * cout * 4); g.b_bytes = (uint32_t)((uint64_t)cin * taps * cout * 4);
+    g.T = T; g.cin = cout; g.shift0 = (taps - 1) / 2; g.shift_step = -1;
+    g.a_amax = dy_amax; g.a_amax_n = H3_AMAX_PARTIALS;
+    return dispatch_h3(g, (hipStream_t)stream);
 }
 
 int ttts_linear_bwd_data_x6(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,

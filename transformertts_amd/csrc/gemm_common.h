@@ -1,0 +1,102 @@
+// GemmArgs and the raw-buffer load helpers shared by the GEMM translation units (gemm.hip, gemm_h3.hip).
+#pragma once
+#include "ttts_common.h"
+
+namespace ttts {
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    // implicit row shift (conv taps / go-frame): rows are (b*T + t)
+    int T;           // 0: no utterance clipping (shift must be 0)
+    int cin;         // A_KC: channels per tap (K = taps*cin)
+    int shift0, shift_step;
+    int ztaps;       // !B_KC: number of taps spread over blockIdx.z (z = split*ztaps + tap)
+    // split over the reduction dimension
+    int kt_per_split;
+    long c_zstride;  // C offset per z slice
+    // epilogue (applied only when kt range covers all of K, i.e. no split)
+    const float* bias;
+    int act;         // 0 none, 1 relu
+    float drop_scale;
+    uint32_t drop_thr;
+    uint64_t seed;
+    const uint64_t* step_seed;   // per-step word XORed into seed (NULL: none); see site_seed()
+    const float* residual;
+    long ldr;
+    // data-gradient form: the output is the gradient w.r.t. an activation h = drop(relu(.)) whose forward value is
+    // relu_out (same shape as C): v = relu_out > 0 ? v * relu_scale : 0   (fused relu / dropout backward mask)
+    const float* relu_out;
+    float relu_scale;
+    // weight-gradient form only: per-split column sums of A (= bias gradient partials), [zsplit][M]
+    float* colsum;
+    // operand extents in bytes (< 4 GiB): loads go through raw buffer descriptors, so an out-of-range offset returns
+    // zeros in hardware -- row / column / tap clipping costs a select on the offset instead of a branch around the load
+    uint32_t a_bytes, b_bytes;
+    // fp16x3 kernel only: the A operand is a gradient whose magnitude is not known in advance.  a_amax (NULL: use the
+    // static activation pre-scale) points at a_amax_n partial maxima of |A| (ttts_amax_partials); every workgroup
+    // reduces them and pre-scales A by the power of two that puts max|A| in [2^11, 2^12).
+    const float* a_amax;
+    int a_amax_n;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t OOB = 0xFFFFFFFFu;
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// ---- fp16x3 ("h3") split: constants and the weight-plane image (see gemm_h3.hip)
+constexpr int HBK = 32;                 // k-tile depth
+constexpr float H3_A_SCALE = 16.0f;     // 2^4
+constexpr float H3_W_SCALE = 4096.0f;   // 2^12
+constexpr float H3_OUT_SCALE = 1.0f / (16.0f * 4096.0f);
+constexpr int H3_AMAX_PARTIALS = 1024;  // length of the partial-maxima array of ttts_amax_partials
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// two fp32 (already pre-scaled) -> (hi, lo) f16 pairs, each packed in one dword (element 0 in the low half)
+__device__ __forceinline__ void split2_pair(f32x2 x, uint32_t& hi, uint32_t& lo) {
+    const f16x2 h = __builtin_convertvector(x, f16x2);
+    const f32x2 r = x - __builtin_convertvector(h, f32x2);          // exact: h is within 2^-11 of x
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
+
+// B[r][c] of weight_split (gemm.hip) as two f16 planes of w * 2^12, stored [c/32][plane][r][c%32]
+__device__ __forceinline__ void weight_split_h3_one(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
+                                                    int C, int mode, int c2, int taps, long i) {
+    const long n = (long)R * C;
+    if (i >= n) return;
+    const int r = (int)(i / C), c = (int)(i % C);
+    float v;
+    if (mode == 0) v = w[i];
+    else if (mode == 1) v = w[(long)c * R + r];
+    else {
+        const int tap = c / c2, ch = c % c2;
+        if (mode == 2) v = w[((long)r * c2 + ch) * taps + tap];
+        else v = w[((long)ch * R + r) * taps + tap];
+    }
+    v *= H3_W_SCALE;
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    const long o = ((long)(c >> 5) * 2 * R + r) * 32 + (c & 31);
+    planes[o] = __builtin_bit_cast(unsigned short, h);
+    planes[o + (long)R * 32] = __builtin_bit_cast(unsigned short, l);
+}
+
+enum { TILE_AUTO = 0, TILE_64 = 1, TILE_128 = 2, TILE_64x128 = 3, TILE_128x96 = 4, TILE_96x128 = 5 };
+
+// fp16x3 split-precision GEMM (gemm_h3.hip): true when it can take this problem (shape constraints of its 32-deep
+// k-tiles); the caller falls back to the bf16x6 kernel otherwise
+bool h3_supports(const GemmArgs& g);
+int h3_tile_choice(long M, long N);
+void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, int mode, int c2, int taps, hipStream_t stream);
+int dispatch_h3(const GemmArgs& g, hipStream_t stream);
+
+}  // namespace ttts

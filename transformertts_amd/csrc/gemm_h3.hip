@@ -1,0 +1,386 @@
+// Split-precision GEMM, fp16 form ("h3"): fp32-grade products from THREE f16 x f16 MFMA terms.
+//
+// The bf16x6 kernel of gemm.hip writes each fp32 operand as hi + mid + lo (3 x 8 significand bits) and needs six
+// MFMA terms per product.  f16 carries 11 significand bits, so TWO pieces already hold 22 bits, and the three leading
+// cross products
+//         a_hi*b_hi + (a_hi*b_lo + a_lo*b_hi)                    (dropped: a_lo*b_lo, 2^-22 relative)
+// accumulated in fp32 by v_mfma_f32_32x32x16_f16 (each f16 x f16 product is exact in fp32) give a result within a few
+// 2^-22 of the exact product: half the matrix-pipe work of bf16x6 for the same fp32-grade answer (measured against
+// fp64 in tests/test_hip_modes.py, same 5e-6 gate as the other forms; typically 2-4e-7).
+//
+// What f16 lacks is bf16's exponent range (normal numbers 6.1e-5 .. 65504), so operands are pre-scaled by powers of
+// two (exact) that centre their typical magnitude in that window:
+//     activations x 2^4    (full 22-bit precision for 0.0078 <= |a| < 4096, absolute error <= 2^-29 below that)
+//     weights     x 2^12   (full precision for 3.1e-5 <= |w| < 16,     absolute error <= 2^-37 below that)
+// and the accumulator is scaled back by 2^-16 in the epilogue.  This fits the FORWARD operands of this model -- LayerNorm /
+// BatchNorm / tanh / ReLU outputs and N(0,1) mels are O(1), weights O(1/sqrt(fan_in)) -- and that is where the kernel is
+// used (nn.Linear and Conv1d forward: two of the four GEMM passes of a training step).  Gradients (1e-7 .. 1e-5 after
+// the mean-reduced loss) do not fit a fixed window; data- and weight-gradient GEMMs stay on bf16x6.
+// An activation >= 4096 in magnitude saturates to +-inf and shows up as inf / NaN in the output (never silently wrong);
+// TTTS_FWD_MODE=x6 selects the bf16 form for such models.
+//
+// Structure: 128x128 (or 64x128 / 128x96) tile, 4 waves, 32-deep k-tiles = two MFMA k-steps per barrier (the bf16x6
+// kernel has one 16-deep step per barrier: with half the MFMAs per step its barrier / staging overhead would double in
+// relative terms).  LDS rows are 64 bytes (32 f16) per plane; the 16-byte chunk of a row is XORed with (row >> 2) & 3,
+// which makes both the ds_write of the staged pieces and the ds_read_b128 of the MFMA fragments conflict-free.
+// Weights are split once per step by weight_split (modes 4-7) into two f16 planes laid [K/32][plane][N][32].
+#include <stdlib.h>
+
+#include "gemm_common.h"
+
+namespace ttts {
+
+__global__ __launch_bounds__(256) void weight_split_h3_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
+                                                              int R, int C, int mode, int c2, int taps) {
+    weight_split_h3_one(w, planes, R, C, mode, c2, taps, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, int mode, int c2, int taps, hipStream_t stream) {
+    const long n = (long)rows * cols;
+    hipLaunchKernelGGL(weight_split_h3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, w, (unsigned short*)planes, rows,
+                       cols, mode, c2, taps);
+}
+
+// partial maxima of |x|: block b writes max over its grid-stride share to out[b]; blocks past the data write 0
+__global__ __launch_bounds__(256) void amax_partials_kernel(const float* __restrict__ x, long n4, long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0)                                    // tail (n % 4 elements)
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    // fmaxf drops NaNs (they still reach the output through the split itself); an infinity makes the partial inf and the
+    // consumer then scales by 1, so non-finite gradients travel on visibly either way
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// power-of-two pre-scale of a gradient operand from its partial maxima, and the matching accumulator scale (x 2^-12 for
+// the weight planes).  max|A| * a_scale lands in [2^11, 2^12); all-zero / denormal-small / non-finite operands use 1.
+__device__ __forceinline__ void h3_dynamic_scale(const float* __restrict__ partials, int n, int lane, float& a_scale,
+                                                 float& out_scale) {
+    float m = 0.f;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, partials[i]);
+    m = wave_max(m);
+    const uint32_t e = (__float_as_uint(m) >> 23) & 0xffu;
+    if (e >= 24u && e < 255u) {
+        a_scale = __uint_as_float((265u - e) << 23);          // 2^(138 - e): max|A| -> [2^11, 2^12)
+        out_scale = __uint_as_float((e - 23u) << 23);         // 2^(e - 150) = 1 / (a_scale * 2^12)
+    } else {
+        a_scale = 1.0f;
+        out_scale = 1.0f / H3_W_SCALE;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool CLIP>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
+    const uint64_t seed_eff = site_seed(g.seed, g.step_seed);
+    constexpr int NT = WM * WN * 64;                            // threads per workgroup (4 or 8 waves)
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
+    static_assert((BM * 8) % NT == 0, "every thread stages whole float4s of the A tile");
+    constexpr int A_PLANE = BM * 16, B_PLANE = BN * 16;         // dwords per plane (64-byte rows)
+    constexpr int STAGE = 2 * (A_PLANE + B_PLANE);
+    constexpr int NLA = BM * 8 / NT;                            // float4 loads per thread for the A tile (8 per row)
+    constexpr int NLB = (BN * 4 + NT - 1) / NT;                 // 16-byte pieces per thread and plane for the B tile (4 per row)
+    constexpr bool B_ALL = (BN * 4) % NT == 0;
+    constexpr int NTILE = 2 * TM * TN;                          // accumulator-tile visits per k-tile (two MFMA k-steps)
+
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile numbering (as the bf16x6 kernel): the column blocks of one A row panel run on one XCD / L2
+    const int nx = gridDim.x;
+    const int ntiles = nx * gridDim.y;
+    const int bid = blockIdx.y * nx + blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int per = ntiles >> 3, rem = ntiles & 7;
+    const int t = xcd * per + min(xcd, rem) + slot;
+    const int ty = t / nx, tx = t - ty * nx;
+    const int m0 = ty * BM, n0 = tx * BN;
+    const int nkt = g.K / HBK;
+    float a_scale = H3_A_SCALE, out_scale = H3_OUT_SCALE;
+    if (g.a_amax != nullptr) h3_dynamic_scale(g.a_amax, g.a_amax_n, lane, a_scale, out_scale);
+
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
+    const uint32_t b_plane_bytes = (uint32_t)g.N * 64u;            // one plane of one k-tile: N rows of 32 f16
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[NLA];
+    u32x4 rb[2][NLB];
+
+    // A: thread -> (row = idx >> 3, float4 chunk = idx & 7) for idx = tid + i*NT; rows past M fall outside the buffer
+    // descriptor (hardware zero), shifted rows outside their utterance are clipped on the offset (CLIP).  Per-thread
+    // offsets are loop-invariant VGPRs; the k position travels in SGPRs (the loads' scalar offset), so advancing k costs
+    // no vector instruction.
+    int a_t[NLA];
+    uint32_t a_off[NLA], a_lds[NLA];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        const int idx = tid + i * NT;
+        const int row = idx >> 3, ch = idx & 7;
+        const int m = m0 + row;
+        a_off[i] = (uint32_t)(((long)m * g.lda + ch * 4) * 4);
+        a_t[i] = CLIP ? (m % g.T) : 0;
+        a_lds[i] = (uint32_t)(row * 16 + (((ch >> 1) ^ ((row >> 2) & 3)) * 4) + (ch & 1) * 2);
+    }
+    // B: piece idx = tid + j*NT -> (row = idx >> 2, 16-byte chunk = idx & 3) of each plane
+    uint32_t b_off[NLB], b_lds[NLB];
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) {
+        const int idx = tid + j * NT;
+        const int row = idx >> 2, c = idx & 3;
+        b_off[j] = (uint32_t)((n0 + row) * 64 + c * 16);
+        b_lds[j] = (uint32_t)(row * 16 + ((c ^ ((row >> 2) & 3)) * 4));
+    }
+    uint32_t b_cur = 0;                                            // scalar: byte offset of the current k-tile's planes
+    int k_c0 = 0, k_shift = g.shift0;
+    uint32_t k_off = (uint32_t)((long)g.shift0 * g.lda * 4);       // scalar: byte offset of the current k position in a row
+    const uint32_t tap_step = (uint32_t)(((long)g.shift_step * g.lda - g.cin) * 4);
+
+    auto load_a_piece = [&](int i) {
+        if (CLIP) {
+            uint32_t off = a_off[i] + k_off;
+            off = ((unsigned)(a_t[i] + k_shift) < (unsigned)g.T) ? off : OOB;
+            ra[i] = buf_load4(rsrcA, off);
+        } else {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (int)a_off[i], (int)k_off, 0);
+            ra[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+    };
+    auto advance_a = [&]() {
+        k_c0 += HBK;
+        k_off += HBK * 4;
+        if (k_c0 == g.cin) { k_c0 = 0; k_shift += g.shift_step; k_off += tap_step; }
+    };
+    auto load_b_piece = [&](int j) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            rb[p][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)b_off[j], (int)(b_cur + p * b_plane_bytes), 0);
+    };
+    auto advance_b = [&]() { b_cur += 2u * b_plane_bytes; };
+    auto store_a_piece = [&](int buf, int i) {
+        uint32_t* as = lds + buf * STAGE;
+        uint2 hi, lo;
+        split2_pair(f32x2{ra[i].x, ra[i].y} * a_scale, hi.x, lo.x);
+        split2_pair(f32x2{ra[i].z, ra[i].w} * a_scale, hi.y, lo.y);
+        *reinterpret_cast<uint2*>(as + a_lds[i]) = hi;
+        *reinterpret_cast<uint2*>(as + A_PLANE + a_lds[i]) = lo;
+    };
+    auto store_b_piece = [&](int buf, int j) {
+        uint32_t* bs = lds + buf * STAGE + 2 * A_PLANE;
+        if (B_ALL || (tid + j * NT) < BN * 4) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(bs + p * B_PLANE + b_lds[j]) = rb[p][j];
+        }
+    };
+    // All staging of a k-tile in one block: write the registers (tile kt+1, requested a whole k-tile ago, so the single
+    // s_waitcnt vmcnt(0) in front of it is free) to LDS[buf^1], then re-use them at once to request tile kt+2.  Spreading
+    // the pieces over the MFMA gaps does not work with hipcc: every piece then waits vmcnt(0), i.e. for the loads issued
+    // a few instructions earlier (measured: 0.65x).
+    auto stage_all = [&](int buf, bool stage, bool fetch) {
+        if (stage) {
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) store_a_piece(buf ^ 1, i);
+#pragma unroll
+            for (int j = 0; j < NLB; ++j) store_b_piece(buf ^ 1, j);
+        }
+        if (fetch) {
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) load_a_piece(i);
+            advance_a();
+#pragma unroll
+            for (int j = 0; j < NLB; ++j) load_b_piece(j);
+            advance_b();
+        }
+    };
+
+    // One 32-deep k-tile = two MFMA k-steps over the wave's TM x TN accumulator tiles.  LDS[buf] holds tile kt, the staging
+    // registers tile kt+1.  The staging block sits behind the first accumulator-tile visit in the first half of the waves
+    // and behind the middle visit in the second half: the two waves that share a SIMD in an 8-wave workgroup run the same
+    // program in lockstep (one barrier per k-tile), and offsetting their VALU-heavy staging blocks lets one wave's MFMAs
+    // run under the other's staging.
+    const bool late = (NT == 512) && wave >= (NT / 128);
+    auto step = [&](int buf, bool stage, bool fetch) {
+        const uint32_t* as = lds + buf * STAGE;
+        const uint32_t* bs = as + 2 * A_PLANE;
+        const int sw = (l31 >> 2) & 3;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int cw = ((s * 2 + half) ^ sw) * 4;            // swizzled 16-byte chunk of this lane's 8 k values
+            f16x8 a[2][TM], b[2][TN];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[p][i] = *reinterpret_cast<const f16x8*>(as + p * A_PLANE + (wm * WTM + i * 32 + l31) * 16 + cw);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[p][j] = *reinterpret_cast<const f16x8*>(bs + p * B_PLANE + (wn * WTN + j * 32 + l31) * 16 + cw);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    // the WEIGHT fragment is the MFMA's first operand: the accumulator tile is C^T (lane = output row m,
+                    // registers 4g..4g+3 = four consecutive output columns), so the epilogue moves float4s
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[0][j], a[1][i], c, 0, 0, 0);   // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[1][j], a[0][i], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[0][j], a[0][i], c, 0, 0, 0);
+                    acc[i][j] = c;
+                    const int visit = (s * TM + i) * TN + j;
+                    if (visit == 0 && !late) stage_all(buf, stage, fetch);
+                    if (NT == 512 && visit == NTILE / 2 && late) stage_all(buf, stage, fetch);
+                }
+        }
+    };
+
+    if (nkt > 0) {
+        stage_all(1, false, true);              // request tile 0
+        stage_all(1, true, nkt > 1);            // stage tile 0 into LDS[0], request tile 1
+        __syncthreads();
+        int buf = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+            step(buf, kt + 1 < nkt, kt + 2 < nkt);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ---------------- epilogue.  Accumulator tile (i, j) holds C[m][n] for m = row0 + l31 (the lane) and, in registers
+    // 4g .. 4g+3, the four consecutive columns n = col0 + 8g + 4*half + (0..3): every memory operation of the epilogue
+    // (bias, residual, relu gate, the store) is a 16-byte access, a quarter of the instructions of a dword epilogue -- at
+    // K = 256 (most GEMMs of the step) the dword epilogue took longer than the main loop.  N % 4 == 0 is required.
+    // Auxiliary operands go through buffer descriptors (rows past M / columns past N read 0, no load behind a branch).
+    float* C = g.C;
+    const bool do_drop = g.drop_thr != 0u;
+    const bool has_gate = g.relu_out != nullptr, has_res = g.residual != nullptr;
+    const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_gate ? g.relu_out : g.A), 0, has_gate ? (uint32_t)((long)g.M * g.ldc * 4) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_res ? g.residual : g.A), 0, has_res ? (uint32_t)((long)g.M * g.ldr * 4) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcBias = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.bias != nullptr ? g.bias : g.A), 0, g.bias != nullptr ? (uint32_t)g.N * 4u : 0u, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int colb = n0 + wn * WTN + j * 32 + 4 * half;          // this lane's column of register group 0
+        float4 bias_v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias_v[q] = buf_load4(rsrcBias, (uint32_t)(colb + 8 * q) * 4u);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long row = m0 + wm * WTM + i * 32 + l31;
+            float4 res[4], gsrc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = colb + 8 * q;
+                const bool col_ok = col < g.N;
+                res[q] = has_res ? buf_load4(rsrcR, col_ok ? (uint32_t)((row * g.ldr + col) * 4) : OOB) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (has_gate) gsrc[q] = buf_load4(rsrcG, col_ok ? (uint32_t)((row * g.ldc + col) * 4) : OOB);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = colb + 8 * q;
+                float v[4] = {acc[i][j][4 * q] * out_scale + bias_v[q].x, acc[i][j][4 * q + 1] * out_scale + bias_v[q].y,
+                              acc[i][j][4 * q + 2] * out_scale + bias_v[q].z, acc[i][j][4 * q + 3] * out_scale + bias_v[q].w};
+                const float rr[4] = {res[q].x, res[q].y, res[q].z, res[q].w};
+                const float gg[4] = {has_gate ? gsrc[q].x : 1.f, has_gate ? gsrc[q].y : 1.f, has_gate ? gsrc[q].z : 1.f,
+                                     has_gate ? gsrc[q].w : 1.f};
+                uint32_t h01 = 0, h23 = 0;
+                if (do_drop) {                       // elements 2i, 2i+1 share a hash (keep_elem): two hashes per float4
+                    const uint64_t idx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
+                    h01 = hash_pair(seed_eff, (uint32_t)(idx >> 1), (uint32_t)(idx >> 33));
+                    h23 = hash_pair(seed_eff, (uint32_t)((idx + 2) >> 1), (uint32_t)((idx + 2) >> 33));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (g.act == 1) v[e] = fmaxf(v[e], 0.f);
+                    if (do_drop) v[e] = keep_from_hash(e < 2 ? h01 : h23, (uint32_t)e & 1u, g.drop_thr) ? v[e] * g.drop_scale : 0.f;
+                    if (has_gate) v[e] = gg[e] > 0.f ? v[e] * g.relu_scale : 0.f;
+                    v[e] += rr[e];
+                }
+                if (row < g.M && col < g.N) *reinterpret_cast<float4*>(C + row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_h3(const GemmArgs& g, hipStream_t stream) {
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), 1);
+    if (g.T > 0)
+        hipLaunchKernelGGL((gemm_h3_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, stream, g);
+    else
+        hipLaunchKernelGGL((gemm_h3_kernel<BM, BN, WM, WN, false>), grid, dim3(WM * WN * 64), 0, stream, g);
+    TTTS_LAUNCH_CHECK("gemm_h3_kernel");
+    return TTTS_OK;
+}
+
+bool h3_supports(const GemmArgs& g) {
+    // 32-deep k-tiles must not straddle a conv tap; B rows are addressed as 64-byte pieces
+    return g.K % HBK == 0 && g.cin % HBK == 0 && g.N % 4 == 0 && (uint64_t)g.N * g.K * 4 < (1ull << 32);
+}
+
+enum { H3_TILE_256 = 6, H3_TILE_256x128 = 7 };
+
+int h3_tile_choice(long M, long N) {
+    static int forced = -1;                       // development aid: TTTS_H3_TILE forces a tile shape
+    if (forced < 0) { const char* e = getenv("TTTS_H3_TILE"); forced = e ? atoi(e) : 0; }
+    if (forced > 0) return forced;
+    if (N <= 96 && (long)cdiv(M, 128) >= 384) return TILE_128x96;
+    // busiest-CU cost model of gemm.hip's choose_tile: workgroups a CU runs one after the other x tile area / efficiency
+    // (a 256-wide tile is one workgroup per CU at a time, the 128-wide ones two)
+    struct Cand { int tile, bm, bn, per_cu; float eff; };
+    const Cand cands[] = {{H3_TILE_256, 256, 256, 1, 1.25f}, {H3_TILE_256x128, 256, 128, 1, 1.05f},
+                          {TILE_128, 128, 128, 2, 1.00f}, {TILE_64x128, 64, 128, 2, 0.75f}};
+    int best = TILE_128;
+    float best_cost = 1e30f;
+    for (const Cand& c : cands) {
+        long tiles = (long)cdiv(M, c.bm) * cdiv(N, c.bn);
+        long rounds = (tiles + 256L * c.per_cu - 1) / (256L * c.per_cu);
+        float cost = (float)rounds * (float)(c.bm * c.bn) * (float)c.per_cu / c.eff;
+        if (cost < best_cost) { best_cost = cost; best = c.tile; }
+    }
+    return best;
+}
+
+int dispatch_h3(const GemmArgs& g, hipStream_t stream) {
+    switch (h3_tile_choice(g.M, g.N)) {
+        case H3_TILE_256: return launch_h3<256, 256, 2, 4>(g, stream);
+        case H3_TILE_256x128: return launch_h3<256, 128, 4, 2>(g, stream);
+        case TILE_64x128: return launch_h3<64, 128, 2, 2>(g, stream);
+        case TILE_128x96: return launch_h3<128, 96, 4, 1>(g, stream);
+        default: return launch_h3<128, 128, 2, 2>(g, stream);
+    }
+}
+
+}  // namespace ttts
+
+extern "C" int ttts_amax_partials(const float* x, int64_t n, float* partials, void* stream) {
+    // partials[0 .. 1023] = partial maxima of |x[0 .. n)| (the max over them is max|x|);
+    // feeds the dynamic pre-scale of the gradient operand of the *_h3 backward entry points
+    using namespace ttts;
+    TTTS_REQUIRE(x && partials && n > 0, "amax_partials: bad arguments");
+    TTTS_REQUIRE((((uintptr_t)x) & 15) == 0, "amax_partials: x must be 16-byte aligned");
+    hipLaunchKernelGGL(amax_partials_kernel, dim3(H3_AMAX_PARTIALS), dim3(256), 0, (hipStream_t)stream, x, (long)(n / 4), (long)n,
+                       partials);
+    TTTS_LAUNCH_CHECK("amax_partials_kernel");
+    return TTTS_OK;
+}

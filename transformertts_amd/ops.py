@@ -126,6 +126,30 @@ def _ss():
 GEMM_MODE = os.environ.get("TTTS_GEMM_MODE", "x6")
 ATTN_MODE = os.environ.get("TTTS_ATTN_MODE", GEMM_MODE)       # attention products: "x6" or "f32"
 WGRAD_MODE = os.environ.get("TTTS_WGRAD_MODE", GEMM_MODE)    # weight gradients: "x6" (split-precision MFMA) or "f32"
+# Forward GEMMs (nn.Linear / Conv1d forward) under GEMM_MODE "x6": "h3" = fp16x3 split (three f16 MFMA terms on operands
+# pre-scaled into f16's range: O(1) activations, O(1/sqrt(fan_in)) weights; csrc/gemm_h3.hip), "x6" = bf16x6 as the
+# gradients use.  Shapes the fp16 kernel cannot take (K or channels not a multiple of 32) go to bf16x6.
+FWD_MODE = os.environ.get("TTTS_FWD_MODE", "h3")
+
+
+# Data-gradient GEMMs: "h3" = fp16x3 with a dynamic pre-scale of the gradient operand (one amax pass over dy), "x6".
+BWD_MODE = os.environ.get("TTTS_BWD_MODE", "h3")
+
+
+def _fwd_h3(K: int, N: int, channels: int = 0) -> bool:
+    """fp16x3 takes reduction depths (and conv channel counts) that are multiples of 32 and output widths % 4 == 0."""
+    return GEMM_MODE == "x6" and FWD_MODE == "h3" and K % 32 == 0 and channels % 32 == 0 and N % 4 == 0
+
+
+def _bwd_h3(K: int, N: int, channels: int = 0) -> bool:
+    return GEMM_MODE == "x6" and BWD_MODE == "h3" and K % 32 == 0 and channels % 32 == 0 and N % 4 == 0
+
+
+def _amax(t: torch.Tensor) -> torch.Tensor:
+    """1024 partial maxima of |t| (device), the dynamic pre-scale input of the fp16x3 gradient GEMMs."""
+    out = torch.empty(1024, dtype=torch.float32, device=t.device)
+    _lib.check(_lib.load().ttts_amax_partials(_p(t), t.numel(), _p(out), _stream()), "ttts_amax_partials")
+    return out
 
 
 def _attn_bwd(lib):
@@ -294,7 +318,10 @@ class LinearFn(torch.autograd.Function):
         r_ = _chk(residual, "linear.residual") if residual is not None else None
         if r_ is not None and r_.shape != y.shape:
             raise ValueError("linear: residual shape mismatch")
-        if GEMM_MODE == "x6":
+        if _fwd_h3(K, N):
+            _lib.check(lib.ttts_linear_fwd_h3(_p(x), _p(_planes(w, 4, N, K)), _p(b_), _p(r_), _p(y), M, N, K, act,
+                                              float(drop_p), seed, _ss(), row_shift, T, _stream()), "ttts_linear_fwd_h3")
+        elif GEMM_MODE == "x6":
             _lib.check(lib.ttts_linear_fwd_x6(_p(x), _p(_planes(w, 0, N, K)), _p(b_), _p(r_), _p(y), M, N, K, act,
                                               float(drop_p), seed, _ss(), row_shift, T, _stream()), "ttts_linear_fwd_x6")
         else:
@@ -339,7 +366,10 @@ class LinearFn(torch.autograd.Function):
                 skip, skip_in.grad = skip_in.grad, None
                 if skip.shape != x.shape or not skip.is_contiguous():
                     raise RuntimeError("linear: skip-connection gradient does not match the block input")
-            if GEMM_MODE == "x6":
+            if _bwd_h3(N, K):
+                _lib.check(lib.ttts_linear_bwd_data_h3(_p(dacc), _p(_planes(w, 5, K, N)), _p(skip), _p(dx), M, N, K,
+                                                       _p(gate), gscale, _p(_amax(dacc)), _stream()), "ttts_linear_bwd_data_h3")
+            elif GEMM_MODE == "x6":
                 _lib.check(lib.ttts_linear_bwd_data_x6(_p(dacc), _p(_planes(w, 1, K, N)), _p(skip), _p(dx), M, N, K,
                                                        _p(gate), gscale, _stream()), "ttts_linear_bwd_data_x6")
             else:
@@ -422,7 +452,10 @@ class HeadsFn(torch.autograd.Function):
         mel = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
         stop = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
         w_mel = _chk(w_mel, "w_mel")
-        if GEMM_MODE == "x6":
+        if _fwd_h3(K, N):
+            _lib.check(lib.ttts_linear_fwd_h3(_p(x), _p(_planes(w_mel, 4, N, K)), _p(b_mel), None, _p(mel), M, N, K,
+                                              ACT_NONE, 0.0, 0, None, 0, 0, _stream()), "ttts_linear_fwd_h3")
+        elif GEMM_MODE == "x6":
             _lib.check(lib.ttts_linear_fwd_x6(_p(x), _p(_planes(w_mel, 0, N, K)), _p(b_mel), None, _p(mel), M, N, K,
                                               ACT_NONE, 0.0, 0, None, 0, 0, _stream()), "ttts_linear_fwd_x6")
         else:
@@ -484,7 +517,10 @@ class ConvBNFn(torch.autograd.Function):
         dev = x.device
         conv_w = _chk(conv_w, "conv.weight")
         y = torch.empty(B, T, cout, dtype=torch.float32, device=dev)
-        if GEMM_MODE == "x6":
+        if _fwd_h3(taps * cin, cout, cin):
+            _lib.check(lib.ttts_conv1d_fwd_h3(_p(x), _p(_planes(conv_w, 6, cout, taps * cin, cin, taps)), _p(conv_b), _p(y),
+                                              B, T, cin, cout, taps, _stream()), "ttts_conv1d_fwd_h3")
+        elif GEMM_MODE == "x6":
             _lib.check(lib.ttts_conv1d_fwd_x6(_p(x), _p(_planes(conv_w, 2, cout, taps * cin, cin, taps)), _p(conv_b), _p(y),
                                               B, T, cin, cout, taps, _stream()), "ttts_conv1d_fwd_x6")
         else:
@@ -541,7 +577,10 @@ class ConvBNFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            if GEMM_MODE == "x6":
+            if _bwd_h3(taps * cout, cin, cout):
+                _lib.check(lib.ttts_conv1d_bwd_data_h3(_p(dy), _p(_planes(conv_w, 7, cin, taps * cout, cout, taps)), _p(dx),
+                                                       B, T, cin, cout, taps, _p(_amax(dy)), _stream()), "ttts_conv1d_bwd_data_h3")
+            elif GEMM_MODE == "x6":
                 _lib.check(lib.ttts_conv1d_bwd_data_x6(_p(dy), _p(_planes(conv_w, 3, cin, taps * cout, cout, taps)), _p(dx),
                                                        B, T, cin, cout, taps, _stream()), "ttts_conv1d_bwd_data_x6")
             else:
