@@ -130,6 +130,14 @@ int ttts_linear_bwd_weight_x6(const float* dy, const float* x, float* dw, float*
                               int64_t M, int N, int K, int row_shift, int T, int accumulate, void* stream);
 int ttts_conv1d_bwd_weight_x6(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
                               int T, int cin, int cout, int taps, int accumulate, void* stream);
+/* fp16x3 weight gradients: dy pre-scaled dynamically from dy_amax (ttts_amax_partials, shared with the data gradient of
+ * the same dy), x by the static activation scale; shapes the split kernels do not cover fall back to the fp32-MFMA kernel
+ * exactly as the _x6 entry points do. */
+int ttts_linear_bwd_weight_h3(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
+                              int64_t M, int N, int K, int row_shift, int T, int accumulate, const float* dy_amax,
+                              void* stream);
+int ttts_conv1d_bwd_weight_h3(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
+                              int T, int cin, int cout, int taps, int accumulate, const float* dy_amax, void* stream);
 
 /* ------------------------------------------------------------------ Conv1d (k taps, same padding) on (B,T,C)
  * Replaces ConvNormBN's permute -> nn.Conv1d(pad=(k-1)//2) -> permute (model/module.py:28-33) as an

@@ -136,6 +136,50 @@ def test_fp16x3_data_gradient_with_dynamic_scale(M, N, K, mag):
     assert float(dx.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1024, 256), (777, 256, 1024), (129, 80, 256), (4000, 256, 80)])
+@pytest.mark.parametrize("mag", [1.0, 3e-7])
+def test_fp16x3_weight_gradient(M, N, K, mag):
+    """dW = dy^T x and db = column sums of dy in the fp16x3 form (dynamic pre-scale of dy, 32-row k-steps), stored and
+    accumulated, with the go-frame row shift of the decoder pre-net."""
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    x, dy = _rand(M, K, seed=1), _rand(M, N, seed=4) * mag
+    dy[M // 2] *= 300.0
+    am = ops._amax(dy)
+    dw, db = torch.empty(N, K, device=_dev()), torch.empty(N, device=_dev())
+    ws = torch.empty(lib.ttts_wgrad_workspace_bytes(M, N, K, 1) // 4, device=_dev())
+    f = lib.ttts_linear_bwd_weight_h3
+    assert f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 0, _p(am), _stream()) == 0
+    dw_ref, db_ref = dy.double().t() @ x.double(), dy.double().sum(0)
+    assert _rel(dw, dw_ref) < TOL and _rel(db, db_ref) < TOL, (_rel(dw, dw_ref), _rel(db, db_ref))
+    assert f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 1, _p(am), _stream()) == 0
+    assert _rel(dw, 2 * dw_ref) < TOL and _rel(db, 2 * db_ref) < TOL
+    if M % 10 == 0:
+        T = M // 10
+        assert f(_p(dy), _p(x), _p(dw), None, _p(ws), ws.numel() * 4, M, N, K, -1, T, 0, _p(am), _stream()) == 0
+        xs = torch.roll(x.view(10, T, K), 1, dims=1).clone()
+        xs[:, 0] = 0
+        assert _rel(dw, dy.double().t() @ xs.view(M, K).double()) < TOL
+
+
+@pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128), (6, 45, 80, 256), (6, 45, 256, 80)])
+def test_fp16x3_conv_weight_gradient(B, T, cin, cout):
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    x, dy = _rand(B, T, cin, seed=1), _rand(B, T, cout, seed=2) * 2e-7
+    wd = torch.zeros(cout, cin, 5, dtype=torch.float64, device=_dev(), requires_grad=True)
+    bd = torch.zeros(cout, dtype=torch.float64, device=_dev(), requires_grad=True)
+    y = torch.nn.functional.conv1d(x.double().transpose(1, 2), wd, bd, padding=2).transpose(1, 2)
+    y.backward(dy.double())
+    dw, db = torch.empty(cout, cin, 5, device=_dev()), torch.empty(cout, device=_dev())
+    ws = torch.empty(lib.ttts_wgrad_workspace_bytes(B * T, cout, cin, 5) // 4, device=_dev())
+    assert lib.ttts_conv1d_bwd_weight_h3(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, B, T, cin, cout, 5, 0,
+                                         _p(ops._amax(dy)), _stream()) == 0
+    assert _rel(dw, wd.grad) < TOL and _rel(db, bd.grad) < TOL, (_rel(dw, wd.grad), _rel(db, bd.grad))
+
+
 @pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128), (4, 33, 80, 64)])
 def test_fp16x3_conv_data_gradient(B, T, cin, cout):
     from transformertts_amd import _lib, ops

@@ -942,11 +942,11 @@ static int aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // how the row (reduction) dimension of a weight gradient is split: about 768 workgroups (3 per CU) in flight
 struct WgradPlan { int tile; int nsplit; int kt_per_split; };
-static WgradPlan plan_wgrad(int64_t M, int N, int K, int taps, bool x6 = false) {
+static WgradPlan plan_wgrad(int64_t M, int N, int K, int taps, bool x6 = false, int bk = BK) {
     WgradPlan p;
     long tiles = (long)cdiv(N, 128) * cdiv(K, 128) * taps;
     p.tile = (K <= 96) ? TILE_128x96 : TILE_128;
-    long nkt = (M + BK - 1) / BK;
+    long nkt = (M + bk - 1) / bk;
     if (x6) {
         // the split-precision kernel wants the large tile (its per-thread staging work is fixed per k-step); small
         // outputs get more row splits instead, capped so that the partial sums stay a few tens of MB
@@ -1016,14 +1016,17 @@ int ttts_linear_bwd_data(const float* dy, const float* w, const float* residual,
 
 size_t ttts_wgrad_workspace_bytes(int64_t M, int N, int K, int taps) {
     // covers both kernel forms (their row-split counts differ)
-    WgradPlan p = plan_wgrad(M, N, K, taps, false), q = plan_wgrad(M, N, K, taps, true);
+    WgradPlan p = plan_wgrad(M, N, K, taps, false), q = plan_wgrad(M, N, K, taps, true), r = plan_wgrad(M, N, K, taps, true, HBK);
     size_t ns = (size_t)(p.nsplit > q.nsplit ? p.nsplit : q.nsplit);
+    if ((size_t)r.nsplit > ns) ns = (size_t)r.nsplit;
     return (ns * taps * N * K + ns * N) * sizeof(float);
 }
 
 static int wgrad_common(const float* dy, const float* x, float* ws, float* colsum_ws, int64_t M, int N, int K, int taps,
-                        int T, int shift0, int shift_step, WgradPlan* plan_out, bool x6, hipStream_t stream) {
-    WgradPlan p = plan_wgrad(M, N, K, taps, x6);
+                        int T, int shift0, int shift_step, WgradPlan* plan_out, bool x6, hipStream_t stream,
+                        const float* dy_amax = nullptr) {
+    // dy_amax != NULL selects the fp16x3 kernel (32-row k-steps, dynamic pre-scale of dy); x6 must be true then
+    WgradPlan p = plan_wgrad(M, N, K, taps, x6, dy_amax ? HBK : BK);
     GemmArgs g = base_args();
     // C[N][K] (per tap) = dy^T[N][M] . xshift[M][K]
     g.A = dy; g.B = x; g.C = ws; g.M = N; g.N = K; g.K = (int)M;
@@ -1037,12 +1040,17 @@ static int wgrad_common(const float* dy, const float* x, float* ws, float* colsu
     g.kt_per_split = p.kt_per_split; g.c_zstride = (long)N * K;
     g.colsum = colsum_ws;
     *plan_out = p;
+    if (dy_amax) {
+        g.a_amax = dy_amax; g.a_amax_n = H3_AMAX_PARTIALS;
+        return dispatch_wgrad_h3(g, p.nsplit * taps, p.tile, stream);
+    }
     if (x6) return dispatch_wgrad_split(g, p.nsplit * taps, p.tile, stream);
     return dispatch_gemm<false, false>(g, p.nsplit * taps, p.tile, stream);
 }
 
 static int linear_bwd_weight_impl(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
-                                  int64_t M, int N, int K, int row_shift, int T, int accumulate, bool x6, void* stream_) {
+                                  int64_t M, int N, int K, int row_shift, int T, int accumulate, bool x6, void* stream_,
+                                  const float* dy_amax = nullptr) {
     // dw[N,K] (+)= dy[M,N]^T . x[M,K] ; dbias[N] (+)= column sums of dy
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && x && dw && ws, "linear_bwd_weight: null pointer");
@@ -1054,13 +1062,11 @@ static int linear_bwd_weight_impl(const float* dy, const float* x, float* dw, fl
     WgradPlan p;
     long n = (long)N * K;
     x6 = x6 && wgrad_use_x6(N, K);
-    float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, N, K, 1, x6).nsplit * n : nullptr;
-    int rc = wgrad_common(dy, x, ws, colsum_ws, M, N, K, 1, row_shift != 0 ? T : 0, row_shift, 0, &p, x6, stream);
+    if (!x6) dy_amax = nullptr;
+    float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, N, K, 1, x6, dy_amax ? HBK : BK).nsplit * n : nullptr;
+    int rc = wgrad_common(dy, x, ws, colsum_ws, M, N, K, 1, row_shift != 0 ? T : 0, row_shift, 0, &p, x6, stream, dy_amax);
     if (rc) return rc;
-    rc = launch_reduce_rows(ws, n, p.nsplit, n, dw, n, nullptr, accumulate, stream);
-    if (rc) return rc;
-    if (dbias) rc = launch_reduce_rows(colsum_ws, N, p.nsplit, N, dbias, N, nullptr, accumulate, stream);
-    return rc;
+    return launch_reduce_rows_pair(ws, n, p.nsplit, n, dw, colsum_ws, N, N, dbias, accumulate, stream);
 }
 
 int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
@@ -1070,6 +1076,11 @@ int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db
 int ttts_linear_bwd_weight_x6(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
                               int64_t M, int N, int K, int row_shift, int T, int accumulate, void* stream) {
     return linear_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, M, N, K, row_shift, T, accumulate, true, stream);
+}
+int ttts_linear_bwd_weight_h3(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
+                              int64_t M, int N, int K, int row_shift, int T, int accumulate, const float* dy_amax, void* stream) {
+    TTTS_REQUIRE(dy_amax, "linear_bwd_weight_h3: dy_amax (ttts_amax_partials of dy) is required");
+    return linear_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, M, N, K, row_shift, T, accumulate, true, stream, dy_amax);
 }
 
 size_t ttts_conv1d_pack_bytes(int cout, int cin, int taps) { return (size_t)cout * cin * taps * sizeof(float); }
@@ -1118,7 +1129,8 @@ int ttts_conv1d_bwd_data(const float* dy, const float* w_bwd, float* dx, int B, 
 }
 
 static int conv1d_bwd_weight_impl(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
-                                  int T, int cin, int cout, int taps, int accumulate, bool x6, void* stream_) {
+                                  int T, int cin, int cout, int taps, int accumulate, bool x6, void* stream_,
+                                  const float* dy_amax = nullptr) {
     // dw[co,ci,tap] (+)= sum_{b,t} dy[b,t,co] * x[b,t+tap-pad,ci] ; dbias[co] (+)= sum dy
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && x && dw && ws, "conv1d_bwd_weight: null pointer");
@@ -1129,8 +1141,9 @@ static int conv1d_bwd_weight_impl(const float* dy, const float* x, float* dw, fl
     WgradPlan p;
     long n = (long)cout * cin * taps;
     x6 = x6 && wgrad_use_x6(cout, cin);
-    float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, cout, cin, taps, x6).nsplit * n : nullptr;
-    int rc = wgrad_common(dy, x, ws, colsum_ws, M, cout, cin, taps, T, -((taps - 1) / 2), 1, &p, x6, stream);
+    if (!x6) dy_amax = nullptr;
+    float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, cout, cin, taps, x6, dy_amax ? HBK : BK).nsplit * n : nullptr;
+    int rc = wgrad_common(dy, x, ws, colsum_ws, M, cout, cin, taps, T, -((taps - 1) / 2), 1, &p, x6, stream, dy_amax);
     if (rc) return rc;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, ws, dw, cout, cin, taps,
                        p.nsplit, accumulate);
@@ -1146,6 +1159,12 @@ int ttts_conv1d_bwd_weight(const float* dy, const float* x, float* dw, float* db
 int ttts_conv1d_bwd_weight_x6(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
                               int T, int cin, int cout, int taps, int accumulate, void* stream) {
     return conv1d_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, B, T, cin, cout, taps, accumulate, true, stream);
+}
+
+int ttts_conv1d_bwd_weight_h3(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
+                              int T, int cin, int cout, int taps, int accumulate, const float* dy_amax, void* stream) {
+    TTTS_REQUIRE(dy_amax, "conv1d_bwd_weight_h3: dy_amax (ttts_amax_partials of dy) is required");
+    return conv1d_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, B, T, cin, cout, taps, accumulate, true, stream, dy_amax);
 }
 
 int ttts_gemm_tile_choice(int64_t M, int N, int x6) {

@@ -98,5 +98,6 @@ bool h3_supports(const GemmArgs& g);
 int h3_tile_choice(long M, long N);
 void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, int mode, int c2, int taps, hipStream_t stream);
 int dispatch_h3(const GemmArgs& g, hipStream_t stream);
+int dispatch_wgrad_h3(const GemmArgs& g, int zdim, int tile, hipStream_t stream);
 
 }  // namespace ttts

@@ -371,6 +371,257 @@ int dispatch_h3(const GemmArgs& g, hipStream_t stream) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients in the fp16x3 form: C[n][k] (per tap, per row split) = sum_m dy[m][n] * x[m + shift][k].
+// Both operands are activations whose REDUCTION index (the row m) is the slow one in memory, while an MFMA fragment wants 8
+// consecutive reduction indices of ONE column per lane.  The loader turns them in registers: a thread fetches a
+// 4-column x 8-row block with eight 16-byte loads (a wave covers whole 512-byte row pieces), so it holds, for each of
+// its four columns, exactly the 8 consecutive rows of one 16-byte LDS piece.  It splits them (dy pre-scaled by the dynamic
+// power of two from its partial maxima, x by the static activation scale; two f16 planes each) and writes four pieces per
+// plane into the [column][32 k] image the forward kernel also uses; three MFMA terms per product, two MFMA k-steps (32
+// rows) per barrier.
+//   * LDS row of matrix column c = 4q + e of the tile is  e * (C/4) + q  (C = columns of the operand tile): the eight lanes
+//     of one ds_write_b128 then hit eight consecutive rows, which the swizzle below makes conflict-free; accumulator rows /
+//     columns are mapped back in the epilogue.
+//   * swizzle: 16-byte chunk ^= f(row), f = ((row>>1 ^ row>>3) & 1) | ((row>>2 & 1) << 1) -- conflict-free for the
+//     ds_read_b128 fragment reads AND for 8-consecutive-row ds_write_b128 (found by enumeration; (row>>2)&3 of the
+//     forward kernel is 2-way on these writes).
+//   * two register sets: the loads of step kt+2 are issued as soon as the set of step kt+1 has arrived, so every load has
+//     a whole step (compute + staging of the other set) to land, and the wait in front of the staging is an s_waitcnt
+//     vmcnt(0) with nothing younger outstanding.
+// GemmArgs as wgrad_bf16x6_kernel: A = dy (K x M), B = x (K x N), K = rows, z = split * ztaps + tap, kt_per_split in units
+// of 32 rows, colsum = per-split column sums of dy (bias gradient, from the fp32 values).
+__device__ __forceinline__ int wg_swz(int row) { return (((row >> 1) ^ (row >> 3)) & 1) | (((row >> 2) & 1) << 1); }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(GemmArgs g) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(WM * WN == 4 && BM <= 128 && BN <= 128 && BM % 32 == 0 && BN % 32 == 0, "4 waves, <= 128 columns per operand");
+    constexpr int A_PLANE = BM * 16, B_PLANE = BN * 16;         // dwords per plane (64-byte rows)
+    constexpr int STAGE = 2 * (A_PLANE + B_PLANE);
+    constexpr int QA = BM / 4, QB = BN / 4;                     // column quads per operand tile
+
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+    const int ztap = (g.ztaps > 1) ? (z % g.ztaps) : 0;
+    const int zsplit = (g.ztaps > 1) ? (z / g.ztaps) : z;
+    const int nkt = (g.K + HBK - 1) / HBK;
+    const int kt_begin = zsplit * g.kt_per_split;
+    int kt_end = kt_begin + g.kt_per_split;
+    if (kt_end > nkt) kt_end = nkt;
+    const int shift = g.shift0 + ztap * g.shift_step;
+
+    float a_scale = 1.0f, out_scale = 1.0f;
+    {
+        float os;
+        h3_dynamic_scale(g.a_amax, g.a_amax_n, lane, a_scale, os);
+        out_scale = os * (H3_W_SCALE / H3_A_SCALE);            // os = 1 / (a_scale * 2^12); here the B scale is 2^4
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // loader roles: threads [0, BM) stage the dy tile, threads [128, 128 + BN) the x tile; thread -> (column quad q, row
+    // group rg of 8 rows).  Rows past the end of the operand fall outside the buffer descriptor (hardware 0), columns past
+    // the matrix edge only feed accumulator rows / columns that are never stored, and the utterance clipping of shifted
+    // rows is applied to the loaded VALUES from one 8-bit mask per step.
+    // the role is wave-uniform (waves 0-1: dy, waves 2-3: x); say so, or the buffer descriptor select below becomes a
+    // per-lane value and every load is wrapped in a waterfall loop
+    const bool is_b = __builtin_amdgcn_readfirstlane(tid >> 7) != 0;
+    const int tl = tid & 127;
+    const int QX = is_b ? QB : QA;
+    const bool slot = tl < (is_b ? BN : BM);
+    const int q = tl % QX, rg = tl / QX;                        // rg < 4 for every slot thread
+    // buffer descriptor of this wave's operand, built by hand because the loads below are inline assembly: word 0-1 base
+    // address (stride 0), word 2 extent in bytes, word 3 raw-buffer flags (as __builtin_amdgcn_make_buffer_rsrc)
+    const uint64_t base_addr = reinterpret_cast<uint64_t>(is_b ? g.B : g.A);
+    const u32x4 rsrc = {(uint32_t)base_addr, (uint32_t)(base_addr >> 32) & 0xffffu, is_b ? g.b_bytes : g.a_bytes, 0x00020000u};
+    const long ld = is_b ? g.ldb : g.lda;
+    const uint32_t row_bytes = (uint32_t)(ld * 4);
+    // byte offset of this thread's first row at k-step kt_begin (wrap-around of the shifted x offset below zero lands
+    // beyond the descriptor, i.e. reads 0)
+    uint32_t cur = (uint32_t)((((long)kt_begin * HBK + rg * 8 + (is_b ? shift : 0)) * ld + (is_b ? n0 : m0) + 4 * q) * 4);
+    if (!slot) cur = OOB;
+    int b_t = (g.T > 0) ? (int)(((long)kt_begin * HBK + rg * 8) % g.T) : 0;
+    const bool clip = is_b && g.T > 0 && shift != 0;
+    const float scale = is_b ? H3_A_SCALE : a_scale;
+    // LDS dword offsets of this thread's four pieces (one per column e), plane 0
+    int dst[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = e * QX + q;
+        dst[e] = (is_b ? 2 * A_PLANE : 0) + row * 16 + ((rg ^ wg_swz(row)) * 4);
+    }
+    const int plane_stride = is_b ? B_PLANE : A_PLANE;
+
+    f32x4 v0[8], v1[8];
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // The loads are inline assembly so that hipcc does not count them: with two register sets in flight it otherwise
+    // waits s_waitcnt vmcnt(0) at the first use of the OLDER set, i.e. also for the set it has just requested (seen in the
+    // ISA: the prefetch was drained every step).  The wait is ours: `arrived` below, one vmcnt(0) per step at a point where
+    // only the older set is outstanding, naming every destination register so that no consumer is scheduled above it.
+    auto issue = [&](f32x4 (&v)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t off = slot ? cur + j * row_bytes : OOB;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[j]) : "v"(off), "s"(rsrc));
+        }
+        cur += HBK * row_bytes;
+    };
+    // bit j set = row j of this thread's 8 is clipped: its position t_j = (b_t + j) mod T has t_j + shift outside [0, T)
+    auto clip_mask = [&]() -> uint32_t {
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = (b_t + j) % g.T;
+            m |= ((unsigned)(t + shift) >= (unsigned)g.T) ? (1u << j) : 0u;
+        }
+        b_t = (b_t + HBK) % g.T;
+        return m;
+    };
+    auto stash = [&](f32x4 (&v)[8], int buf) {
+        if (!slot) return;
+        uint32_t* base = lds + buf * STAGE;
+        if (clip) {                          // block-uniform: only shifted taps pay for the clipping
+            const uint32_t cm = clip_mask();
+            if (cm != 0u) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if ((cm >> j) & 1u) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float col[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) col[j] = v[j][e];
+            if (!is_b) csum[e] += ((col[0] + col[1]) + (col[2] + col[3])) + ((col[4] + col[5]) + (col[6] + col[7]));
+            u32x4 hi, lo;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                uint32_t h, l;
+                split2_pair(f32x2{col[2 * p], col[2 * p + 1]} * scale, h, l);
+                hi[p] = h; lo[p] = l;
+            }
+            *reinterpret_cast<u32x4*>(base + dst[e]) = hi;
+            *reinterpret_cast<u32x4*>(base + plane_stride + dst[e]) = lo;
+        }
+    };
+    auto arrived = [&](f32x4 (&v)[8]) {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    };
+
+    auto compute = [&](int buf) {
+        const uint32_t* as = lds + buf * STAGE;
+        const uint32_t* bs = as + 2 * A_PLANE;
+        const int sw = wg_swz(l31);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int cw = ((s * 2 + half) ^ sw) * 4;
+            f16x8 a[2][TM], b[2][TN];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[p][i] = *reinterpret_cast<const f16x8*>(as + p * A_PLANE + (wm * WTM + i * 32 + l31) * 16 + cw);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[p][j] = *reinterpret_cast<const f16x8*>(bs + p * B_PLANE + (wn * WTN + j * 32 + l31) * 16 + cw);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0][j], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+    };
+    // step kt: LDS[buf] holds step kt, X the rows of step kt+1 (requested a step ago), Y is free
+    auto step = [&](f32x4 (&X)[8], f32x4 (&Y)[8], int buf, bool more1, bool more2) {
+        if (more1) arrived(X);
+        if (more2) issue(Y);
+        compute(buf);
+        if (more1) stash(X, buf ^ 1);
+        __syncthreads();
+    };
+
+    if (kt_begin < kt_end) {
+        issue(v0);
+        arrived(v0);
+        if (kt_begin + 1 < kt_end) issue(v1);
+        stash(v0, 0);
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; kt += 2) {
+            step(v1, v0, 0, kt + 1 < kt_end, kt + 2 < kt_end);
+            if (kt + 1 < kt_end) step(v0, v1, 1, kt + 2 < kt_end, kt + 3 < kt_end);
+        }
+    }
+
+    if (g.colsum != nullptr && blockIdx.x == 0 && ztap == 0) {
+        float* fs = reinterpret_cast<float*>(lds);
+        __syncthreads();
+        if (!is_b && slot) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fs[rg * BM + 4 * q + e] = csum[e];
+        }
+        __syncthreads();
+        if (tid < BM && m0 + tid < g.M)
+            g.colsum[(long)zsplit * g.M + m0 + tid] = (fs[tid] + fs[BM + tid]) + (fs[2 * BM + tid] + fs[3 * BM + tid]);
+    }
+
+    // accumulator row r_lds / column c_lds are LDS rows: map them back to matrix columns of dy / x (see the LDS row rule)
+    float* C = g.C + (long)z * g.c_zstride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c_lds = wn * WTN + j * 32 + l31;
+            const int col = n0 + 4 * (c_lds % QB) + c_lds / QB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int r_lds = wm * WTM + i * 32 + acc_row(r, half);
+                const int row = m0 + 4 * (r_lds % QA) + r_lds / QA;
+                if (row < g.M && col < g.N) C[(long)row * g.ldc + col] = acc[i][j][r] * out_scale;
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_wgrad_h3(const GemmArgs& g, int zdim, hipStream_t stream) {
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), zdim);
+    hipLaunchKernelGGL((wgrad_h3_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, stream, g);
+    TTTS_LAUNCH_CHECK("wgrad_h3_kernel");
+    return TTTS_OK;
+}
+
+int dispatch_wgrad_h3(const GemmArgs& g, int zdim, int tile, hipStream_t stream) {
+    switch (tile) {
+        case TILE_64: return launch_wgrad_h3<64, 64, 2, 2>(g, zdim, stream);
+        case TILE_128x96: return launch_wgrad_h3<128, 96, 4, 1>(g, zdim, stream);
+        case TILE_96x128: return launch_wgrad_h3<96, 128, 1, 4>(g, zdim, stream);
+        default: return launch_wgrad_h3<128, 128, 2, 2>(g, zdim, stream);
+    }
+}
+
 }  // namespace ttts
 
 extern "C" int ttts_amax_partials(const float* x, int64_t n, float* partials, void* stream) {

@@ -33,6 +33,9 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // out0[c] (+)= sum_r ws[r*ld + c] for c < n0, out1[c - n0] for the rest (reduce.hip); fixed summation order
 int launch_reduce_rows(const float* ws, long ld, int nrows, long ncols, float* out0, long n0, float* out1, int accumulate,
                        hipStream_t stream);
+// weight-matrix partials and the matching bias partials in one launch (reduce.hip)
+int launch_reduce_rows_pair(const float* ws, long ld, int nrows, long ncols, float* out, const float* ws2, long ld2,
+                            long ncols2, float* out2, int accumulate, hipStream_t stream);
 
 // ---------------------------------------------------------------- counter-based dropout RNG
 // keep(seed, idx) is a pure function of the 64-bit site seed and the element index, so the backward kernels

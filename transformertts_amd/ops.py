@@ -125,7 +125,7 @@ def _ss():
 # "f32" = the plain v_mfma_f32_32x32x2_f32 kernel.  Weight gradients always use the fp32 kernel.
 GEMM_MODE = os.environ.get("TTTS_GEMM_MODE", "x6")
 ATTN_MODE = os.environ.get("TTTS_ATTN_MODE", GEMM_MODE)       # attention products: "x6" or "f32"
-WGRAD_MODE = os.environ.get("TTTS_WGRAD_MODE", GEMM_MODE)    # weight gradients: "x6" (split-precision MFMA) or "f32"
+WGRAD_MODE = os.environ.get("TTTS_WGRAD_MODE", "h3" if GEMM_MODE == "x6" else GEMM_MODE)   # weight gradients: "h3", "x6", "f32"
 # Forward GEMMs (nn.Linear / Conv1d forward) under GEMM_MODE "x6": "h3" = fp16x3 split (three f16 MFMA terms on operands
 # pre-scaled into f16's range: O(1) activations, O(1/sqrt(fan_in)) weights; csrc/gemm_h3.hip), "x6" = bf16x6 as the
 # gradients use.  Shapes the fp16 kernel cannot take (K or channels not a multiple of 32) go to bf16x6.
@@ -156,8 +156,13 @@ def _attn_bwd(lib):
     return lib.ttts_attention_bwd_x6 if ATTN_MODE == "x6" else lib.ttts_attention_bwd
 
 
-def _wgrad_fn(lib, name: str):
-    return getattr(lib, name + "_x6") if WGRAD_MODE == "x6" else getattr(lib, name)
+def _wgrad(lib, name: str, dy: torch.Tensor, amax, *args):
+    """Weight-gradient entry point `name` in the configured form; `args` = everything after (dy ...) up to `accumulate`.
+    The fp16x3 form takes the partial maxima of |dy| (computed here unless the caller already has them)."""
+    if WGRAD_MODE == "h3":
+        am = amax if amax is not None else _amax(dy)
+        return getattr(lib, name + "_h3")(_p(dy), *args, _p(am), _stream())
+    return getattr(lib, name + ("_x6" if WGRAD_MODE == "x6" else ""))(_p(dy), *args, _stream())
 
 
 _param_epoch = 0
@@ -356,6 +361,7 @@ class LinearFn(torch.autograd.Function):
         else:
             dacc = dy
         dx = dw = db = None
+        am = None                          # partial maxima of |dacc|: shared by the fp16x3 data and weight gradients
         if ctx.needs_input_grad[0]:
             if row_shift != 0:
                 raise RuntimeError("linear: input gradient through a shifted loader is not needed on this path")
@@ -367,8 +373,9 @@ class LinearFn(torch.autograd.Function):
                 if skip.shape != x.shape or not skip.is_contiguous():
                     raise RuntimeError("linear: skip-connection gradient does not match the block input")
             if _bwd_h3(N, K):
+                am = _amax(dacc)
                 _lib.check(lib.ttts_linear_bwd_data_h3(_p(dacc), _p(_planes(w, 5, K, N)), _p(skip), _p(dx), M, N, K,
-                                                       _p(gate), gscale, _p(_amax(dacc)), _stream()), "ttts_linear_bwd_data_h3")
+                                                       _p(gate), gscale, _p(am), _stream()), "ttts_linear_bwd_data_h3")
             elif GEMM_MODE == "x6":
                 _lib.check(lib.ttts_linear_bwd_data_x6(_p(dacc), _p(_planes(w, 1, K, N)), _p(skip), _p(dx), M, N, K,
                                                        _p(gate), gscale, _stream()), "ttts_linear_bwd_data_x6")
@@ -386,9 +393,8 @@ class LinearFn(torch.autograd.Function):
             else:
                 dw_t = dw = torch.empty_like(w)
                 db_t = db = torch.empty(N, dtype=torch.float32, device=x.device) if has_b else None
-            _lib.check(_wgrad_fn(lib, "ttts_linear_bwd_weight")(_p(dacc), _p(x), _p(dw_t), _p(db_t), _p(ws), ws.numel() * 4,
-                                                                 M, N, K, row_shift, T, acc, _stream()),
-                       "ttts_linear_bwd_weight")
+            _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dacc, am, _p(x), _p(dw_t), _p(db_t), _p(ws), ws.numel() * 4,
+                              M, N, K, row_shift, T, acc), "ttts_linear_bwd_weight")
         dres = dy if has_r else None
         if has_r and skip_out is not None:      # hand the skip gradient to the block's first Linear instead of autograd
             skip_out.grad, dres = dy, None
@@ -493,8 +499,8 @@ class HeadsFn(torch.autograd.Function):
             t_bm = db_mel = torch.empty(N, dtype=torch.float32, device=x.device)
             t_ws = dw_stop = torch.empty_like(w_stop)
             t_bs = db_stop = torch.empty(1, dtype=torch.float32, device=x.device)
-        _lib.check(_wgrad_fn(lib, "ttts_linear_bwd_weight")(_p(dmel), _p(x), _p(t_wm), _p(t_bm), _p(ws), ws.numel() * 4, M, N,
-                                                             K, 0, 0, acc, _stream()), "ttts_linear_bwd_weight")
+        _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dmel, None, _p(x), _p(t_wm), _p(t_bm), _p(ws), ws.numel() * 4, M, N,
+                          K, 0, 0, acc), "ttts_linear_bwd_weight")
         ws2 = _ws(lib.ttts_rowdot_bwd_workspace_bytes(K), x.device)
         _lib.check(lib.ttts_rowdot_bwd(_p(dstop), _p(x), _p(w_stop), _p(dx), _p(t_ws), _p(t_bs), _p(ws2),
                                        ws2.numel() * 4, M, K, acc, _stream()), "ttts_rowdot_bwd")
@@ -575,11 +581,13 @@ class ConvBNFn(torch.autograd.Function):
         _lib.check(lib.ttts_bn_bwd(_p(dz), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(t_g), _p(t_be),
                                    _p(ws), ws.numel() * 4, M, cout, act, drop_p, seed, ctx.ss, acc, _stream()), "ttts_bn_bwd")
         dx = None
+        am = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if _bwd_h3(taps * cout, cin, cout):
+                am = _amax(dy)
                 _lib.check(lib.ttts_conv1d_bwd_data_h3(_p(dy), _p(_planes(conv_w, 7, cin, taps * cout, cout, taps)), _p(dx),
-                                                       B, T, cin, cout, taps, _p(_amax(dy)), _stream()), "ttts_conv1d_bwd_data_h3")
+                                                       B, T, cin, cout, taps, _p(am), _stream()), "ttts_conv1d_bwd_data_h3")
             elif GEMM_MODE == "x6":
                 _lib.check(lib.ttts_conv1d_bwd_data_x6(_p(dy), _p(_planes(conv_w, 3, cin, taps * cout, cout, taps)), _p(dx),
                                                        B, T, cin, cout, taps, _stream()), "ttts_conv1d_bwd_data_x6")
@@ -590,8 +598,8 @@ class ConvBNFn(torch.autograd.Function):
                 _lib.check(lib.ttts_conv1d_bwd_data(_p(dy), _p(w_bwd), _p(dx), B, T, cin, cout, taps, _stream()),
                            "ttts_conv1d_bwd_data")
         ws2 = _ws(lib.ttts_wgrad_workspace_bytes(M, cout, cin, taps), dev)
-        _lib.check(_wgrad_fn(lib, "ttts_conv1d_bwd_weight")(_p(dy), _p(x), _p(t_w), _p(t_b), _p(ws2), ws2.numel() * 4, B, T,
-                                                             cin, cout, taps, acc, _stream()), "ttts_conv1d_bwd_weight")
+        _lib.check(_wgrad(lib, "ttts_conv1d_bwd_weight", dy, am, _p(x), _p(t_w), _p(t_b), _p(ws2), ws2.numel() * 4, B, T,
+                          cin, cout, taps, acc), "ttts_conv1d_bwd_weight")
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
