@@ -18,11 +18,11 @@ def per_kernel(root, counter):
     return acc
 
 def short(name):
-    m = re.search(r"ttts::(gemm_\w+_kernel)<([^>]*)>", name)
+    m = re.search(r"ttts::((?:gemm|wgrad)_\w+_kernel)<([^>]*)>", name)
     if not m:
         return None
     args = m.group(2).replace(" ", "")
-    if m.group(1) == "gemm_bf16x6_kernel":
+    if m.group(1) in ("gemm_bf16x6_kernel", "gemm_h3_kernel"):
         args = ",".join(args.split(",")[:4])          # clipped / unclipped loaders of one tile are one line
     if m.group(1) == "gemm_f32_kernel":
         parts = args.split(",")
@@ -45,5 +45,7 @@ for s, e in out.items():
               "write_bytes_per_launch": e["write"] / e["launches"],
               "hbm_bytes_per_launch": (e["fetch"] + e["write"]) / e["launches"],
               "note": "FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE exact; separate --pmc passes of bench.py"}
+if len(sys.argv) > 4:
+    res["_meta"] = sys.argv[4]
 json.dump(res, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(res, indent=1))

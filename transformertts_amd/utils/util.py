@@ -11,6 +11,47 @@ import torch
 from torch import Tensor
 
 
+def increment_path(base_path: str) -> str:
+    """Next free experiment directory `exp_<n>_<MMDD-HHMM>` under `base_path`, with the sub-directories the reference's
+    plot helpers write into (utils/util.py:18-35).  Host bookkeeping only; kept so that the reference's `train.py` binds
+    against this package without edits."""
+    import os
+    from datetime import datetime, timedelta, timezone
+    os.makedirs(base_path, exist_ok=True)
+    stamp = datetime.now(timezone(timedelta(hours=9))).strftime('%m%d-%H%M')      # the reference stamps in KST
+    taken = os.listdir(base_path)
+    n = 1
+    while any(name.startswith(f"exp_{n}") for name in taken):
+        n += 1
+    path = os.path.join(base_path, f"exp_{n}_{stamp}")
+    for sub in ('mels_batch', 'mels_single', 'align_batch', 'align_single', 'mels_scheduled'):
+        os.makedirs(os.path.join(path, sub), exist_ok=True)
+    return path
+
+
+def setup_logger(log_path: str = None):
+    """Console (and optional file) logging as the reference configures it (utils/util.py:123-132): loguru when it is
+    installed, the standard `logging` module otherwise."""
+    import os
+    import sys
+    try:
+        from loguru import logger
+        logger.remove()
+        logger.add(sys.stdout, level="INFO")
+        if log_path:
+            os.makedirs(os.path.dirname(log_path) or ".", exist_ok=True)
+            logger.add(log_path, level="DEBUG", rotation="10 MB")
+        return logger
+    except ImportError:
+        import logging
+        handlers = [logging.StreamHandler(sys.stdout)]
+        if log_path:
+            os.makedirs(os.path.dirname(log_path) or ".", exist_ok=True)
+            handlers.append(logging.FileHandler(log_path))
+        logging.basicConfig(level=logging.INFO, format="%(asctime)s | %(levelname)s | %(message)s", handlers=handlers, force=True)
+        return logging.getLogger("transformertts_amd")
+
+
 def get_device() -> torch.device:
     return torch.device('cuda' if torch.cuda.is_available() else 'cpu')
 
