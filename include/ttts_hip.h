@@ -203,6 +203,12 @@ int ttts_attention_bwd(const float* q, const float* k, const float* v, const flo
 int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
+/* fp16x3 form of the forward (three f16 MFMA terms on operands pre-scaled into f16's range: Q/8, K, V x 2^4 -- O(1)
+ * projections of normalised activations -- and probabilities x 2^10); same arguments, lse in natural units, so either
+ * backward form can follow it. */
+int ttts_attention_fwd_h3(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
+                          const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
+                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 int ttts_attention_bwd_x6(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,

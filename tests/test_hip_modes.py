@@ -298,6 +298,53 @@ def test_attention_forms_agree(causal, Tq, Tk, lens):
         assert torch.equal(a[1] == 0, b[1] == 0)
 
 
+@pytest.mark.parametrize("causal,Tq,Tk,lens", [(1, 200, 200, [200, 131, 64]), (0, 150, 70, [70, 33, 1]), (0, 33, 129, [129, 128, 5]),
+                                               (1, 870, 870, [870, 500])])
+@pytest.mark.parametrize("qk_scale", [1.0, 6.0])
+def test_fp16x3_attention_forward(causal, Tq, Tk, lens, qk_scale):
+    """The fp16x3 forward kernel against fp64 (context, per-head weights, lse via the bf16x6 backward that consumes it),
+    with peaked softmaxes (scores of +-100 at qk_scale 6), and the same counter-based dropout mask as the bf16x6 form."""
+    from transformertts_amd import _lib
+    from transformertts_amd.ops import _p, _off, _stream
+    lib = _lib.load()
+    B, H, d = len(lens), 2, 128
+    q, kv, do = _rand(B, Tq, d, seed=1) * qk_scale, _rand(B, Tk, 2 * d, seed=2), _rand(B, Tq, d, seed=3)
+    kv[..., :d] *= qk_scale
+    kl = torch.tensor(lens, dtype=torch.int64, device=_dev())
+    qd = q.double().view(B, Tq, H, 64).transpose(1, 2).requires_grad_()
+    kd = kv[..., :d].double().reshape(B, Tk, H, 64).transpose(1, 2).requires_grad_()
+    vd = kv[..., d:].double().reshape(B, Tk, H, 64).transpose(1, 2).requires_grad_()
+    s = qd @ kd.transpose(-1, -2) / 8.0
+    mask = torch.arange(Tk, device=_dev())[None, None, None, :] >= kl[:, None, None, None]
+    if causal:
+        mask = mask | (torch.arange(Tk, device=_dev())[None, :] > torch.arange(Tq, device=_dev())[:, None])
+    p_ref = torch.softmax(s.masked_fill(mask, float("-inf")), -1)
+    o_ref = (p_ref @ vd).transpose(1, 2).reshape(B, Tq, d)
+    o_ref.backward(do.double())
+    dq_ref = qd.grad.transpose(1, 2).reshape(B, Tq, d)
+    o = torch.empty(B, Tq, d, device=_dev()); lse = torch.empty(B, H, Tq, device=_dev())
+    attn = None if causal else torch.empty(B, H, Tq, Tk, device=_dev())
+    assert lib.ttts_attention_fwd_h3(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), _p(attn), _p(kl), B, H, Tq, Tk, d, 2 * d,
+                                     2 * d, d, causal, 0.0, 0, None, _stream()) == 0
+    assert _rel(o, o_ref) < TOL, _rel(o, o_ref)
+    if attn is not None:
+        assert _rel(attn, p_ref) < TOL
+        assert float(attn.sum(-1).sub(1).abs().max()) < 1e-5
+    dq, dkv, delta = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(lse)
+    assert lib.ttts_attention_bwd_x6(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _off(dkv, 0),
+                                     _off(dkv, d), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, 0.0, 0, None,
+                                     _stream()) == 0
+    if qk_scale == 1.0:                                                 # the backward recomputes P from this forward's lse
+        assert _rel(dq, dq_ref) < TOL
+    o6 = torch.empty_like(o); a6 = None if causal else torch.empty_like(attn); l6 = torch.empty_like(lse)
+    for f, oo, aa, ll in ((lib.ttts_attention_fwd_h3, o, attn, lse), (lib.ttts_attention_fwd_x6, o6, a6, l6)):
+        assert f(_p(q), _off(kv, 0), _off(kv, d), _p(oo), _p(ll), _p(aa), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, causal, 0.25,
+                 99, None, _stream()) == 0
+    assert _rel(o, o6) < TOL and _rel(lse, l6) < TOL
+    if attn is not None:
+        assert torch.equal(attn == 0, a6 == 0)
+
+
 def _base_module(seed=5):
     from oracle.spec import model_config, fill_state
     from transformertts_amd.lightning_module import LightningModule

@@ -834,6 +834,304 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDX_W) void attn_fwd_x6_ke
     wave_store_rows(o, scratch, a.o + (long)b * a.Tq * a.ldo + h * HD, qw0, a.Tq, a.ldo, lane, 1.f);
 }
 
+// =====================================================================================================================
+// fp16x3 form of the forward kernel ("h3", see gemm_h3.hip): the same algorithm with every product formed from THREE
+// f16 x f16 MFMA terms of two-way hi/lo f16 splits (a_hi b_hi + a_hi b_lo + a_lo b_hi) instead of six bf16 terms.  f16
+// has 11 significand bits but a narrow exponent range, so operands are pre-scaled by fixed powers of two that suit what
+// attention multiplies: Q/8, K and V are O(1) projections of normalised activations (x 2^4: full 22-bit precision for
+// 0.008 <= |x| < 4096), probabilities lie in [0, 1/(1-p)] (x 2^10: absolute error 3e-11 for the small ones).  The scores
+// stay in accumulator units (256 x the true score) and the scale rides in the exp2's fused multiply-add; the output
+// accumulator is scaled back once at the end.  Two planes per staged operand: 32 KB of LDS per workgroup instead of 48.
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+constexpr float H3A_Q = 16.0f, H3A_K = 16.0f, H3A_V = 16.0f, H3A_P = 1024.0f;
+constexpr float H3A_C = 1.0f / (H3A_Q * H3A_K);                 // accumulator units -> true score
+constexpr float H3A_C2 = H3A_C * 1.4426950408889634f;           // ... -> base-2 exponent
+constexpr float H3A_O = 1.0f / (H3A_V * H3A_P);
+#ifndef TTTS_FWDH_W
+#define TTTS_FWDH_W 3
+#endif
+constexpr int HSMEM = (4 * XP > SMEM_FLOATS) ? 4 * XP : SMEM_FLOATS;   // K + V^T planes (32 KB), re-used as per-wave fp32 scratch
+
+__device__ __forceinline__ void split2_pair_h(f32x2 x, uint32_t& hi, uint32_t& lo) {
+    const f16x2v h = __builtin_convertvector(x, f16x2v);
+    const f32x2 r = x - __builtin_convertvector(h, f32x2);          // exact
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2v));
+}
+// 64 rows x 64 floats (row-major, d fast) -> planes[2][64][64] of x * scale; rows beyond nrows_total are zero
+__device__ __forceinline__ void stage_split_rows_h3(const float* base, long row0, long nrows_total, int ld, int tid,
+                                                    uint32_t* dst, float scale) {
+    const RowSrc src = row_src(base, nrows_total, ld);
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 4) + 16 * i, c4 = tid & 15;
+        v[i] = row_load4(src, row0 + row, c4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 4) + 16 * i, c4 = tid & 15;
+        uint2 hi, lo;
+        split2_pair_h(f32x2{v[i].x, v[i].y} * scale, hi.x, lo.x);
+        split2_pair_h(f32x2{v[i].z, v[i].w} * scale, hi.y, lo.y);
+        const int d = xsw(row, c4 >> 1) + (c4 & 1) * 2;
+        *reinterpret_cast<uint2*>(dst + d) = hi;
+        *reinterpret_cast<uint2*>(dst + XP + d) = lo;
+    }
+}
+// 64 rows (keys) x 64 floats -> TRANSPOSED planes[2][64 d][64 key positions], key order as in stage_split_cols
+__device__ __forceinline__ void stage_split_cols_h3(const float* base, long row0, long nrows_total, int ld, int tid,
+                                                    uint32_t* dst, float scale) {
+    const int dq = tid & 15, kq = tid >> 4;
+    const RowSrc src = row_src(base, nrows_total, ld);
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = row_load4(src, row0 + 4 * kq + i, dq);
+    const int pos = (kq >> 3) * 32 + ((kq >> 2) & 1) * 16 + (kq & 1) * 8 + ((kq >> 1) & 1) * 4;
+    const float x[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x}, {v[0].y, v[1].y, v[2].y, v[3].y},
+                           {v[0].z, v[1].z, v[2].z, v[3].z}, {v[0].w, v[1].w, v[2].w, v[3].w}};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int d = 4 * dq + c;
+        uint2 hi, lo;
+        split2_pair_h(f32x2{x[c][0], x[c][1]} * scale, hi.x, lo.x);
+        split2_pair_h(f32x2{x[c][2], x[c][3]} * scale, hi.y, lo.y);
+        const int dd = xsw(d, pos >> 3) + ((pos >> 2) & 1) * 2;
+        *reinterpret_cast<uint2*>(dst + dd) = hi;
+        *reinterpret_cast<uint2*>(dst + XP + dd) = lo;
+    }
+}
+// 8 fp32 -> two f16x8 fragments of x * scale
+__device__ __forceinline__ void split_frag8_h3(const float (&x)[8], float scale, f16x8v& hi, f16x8v& lo) {
+    u32x4v h, l;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        uint32_t a, b;
+        split2_pair_h(f32x2{x[2 * u], x[2 * u + 1]} * scale, a, b);
+        h[u] = a; l[u] = b;
+    }
+    hi = __builtin_bit_cast(f16x8v, h);
+    lo = __builtin_bit_cast(f16x8v, l);
+}
+// c += a (hi,lo) x b (hi,lo), three products, smallest terms first
+__device__ __forceinline__ void mfma_h3(f32x16& c, const f16x8v (&a)[2], const f16x8v (&b)[2]) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c, 0, 0, 0);
+}
+
+template <bool CAUSAL, bool WRITE_A>
+__global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_kernel(AttnArgs a) {
+    const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
+    __shared__ __attribute__((aligned(16))) uint32_t xs[HSMEM];
+    __shared__ float ptile_all[WRITE_A ? 4 * 32 * 17 : 1];   // per wave: 32 queries x 16 keys (+1 pad)
+    uint32_t* Kp = xs;              // [2][64 keys][64 d]      f16 hi / lo planes of K * 2^4
+    uint32_t* Vt = xs + 2 * XP;     // [2][64 d][64 key positions]   of V * 2^4
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    float* ptile = ptile_all + (WRITE_A ? wave * 32 * 17 : 0);
+    const int qblk = CAUSAL ? (gridDim.y - 1 - blockIdx.y) : blockIdx.y;
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+    const int q0 = qblk * QB, qw0 = q0 + wave * 32;
+    const int qg = qw0 + l31;
+    float* scratch = reinterpret_cast<float*>(xs) + wave * 32 * KT_LD;
+
+    int klen = (int)a.key_lens[b];
+    if (klen > a.Tk) klen = a.Tk;
+    if (klen < 0) klen = 0;
+    int kend = klen;
+    if (CAUSAL && kend > q0 + QB) kend = q0 + QB;
+    const int nst_live = (kend + KB - 1) / KB;
+    const int nst = WRITE_A ? (a.Tk + KB - 1) / KB : nst_live;
+    int wave_kend = WRITE_A ? a.Tk : kend;
+    if (CAUSAL && wave_kend > qw0 + 32) wave_kend = qw0 + 32;
+
+    const float* qb_ = a.q + (long)b * a.Tq * a.ldq + h * HD;
+    const float* kb_ = a.k + (long)b * a.Tk * a.ldk + h * HD;
+    const float* vb_ = a.v + (long)b * a.Tk * a.ldv + h * HD;
+
+    // Q fragments: lane (query l31, half) holds Q[q][16 s + 8 half + 0..7] / 8 * 2^4 for the four d-steps s, split in two
+    f16x8v qf[4][2];
+    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
+    wave_lds_sync();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = scratch[l31 * KT_LD + 16 * s + 8 * half + e];
+        split_frag8_h3(x, H3A_Q, qf[s][0], qf[s][1]);
+    }
+
+    float m = NEG_INF, l = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+
+    const long arow = ((long)(b * a.H + h) * a.Tq);
+    const uint32_t rowid = (uint32_t)(arow + qg);
+
+    auto scores = [&](int sub, f32x16& s) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            f16x8v kf[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                kf[p] = *reinterpret_cast<const f16x8v*>(Kp + p * XP + xsw(sub * 32 + l31, 2 * st + half));
+            mfma_h3(s, kf, qf[st]);
+        }
+    };
+    auto alive = [&](int key_g) -> bool { return key_g < klen && (!CAUSAL || key_g <= qg); };
+    auto drop16 = [&](float (&p)[16], int key0) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const int key_g = key0 + acc_row(r, half);
+            const uint32_t hsh = attn_hash(seed_eff, rowid, (uint32_t)key_g >> 1);
+            p[r] = keep_from_hash(hsh, 0u, a.thr) ? p[r] * a.drop_scale : 0.f;
+            p[r + 1] = keep_from_hash(hsh, 1u, a.thr) ? p[r + 1] * a.drop_scale : 0.f;
+        }
+    };
+
+    if (WRITE_A) {
+        // ---------------- pass 1: row max / row sum only
+        for (int t = 0; t < nst_live; ++t) {
+            __syncthreads();
+            stage_split_rows_h3(kb_, (long)t * KB, a.Tk, a.ldk, tid, Kp, H3A_K);
+            __syncthreads();
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int key0 = t * KB + sub * 32;
+                if (key0 >= kend) break;
+                f32x16 s;
+                scores(sub, s);
+                float mx = NEG_INF;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[r] = alive(key0 + acc_row(r, half)) ? s[r] : NEG_INF;
+                    mx = fmaxf(mx, s[r]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float m_new = fmaxf(m, mx);
+                float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+                float alpha = exp2f((m - m_use) * H3A_C2);
+                const float mc = m_use * H3A_C2;
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ps += exp2f(__builtin_fmaf(s[r], H3A_C2, -mc));
+                l = l * alpha + ps;
+                m = m_new;
+            }
+        }
+        l = l + __shfl_xor(l, 32, 64);
+    }
+
+    const float m_fin = (m == NEG_INF) ? 0.f : m;
+    const float inv_l = (l > 0.f) ? 1.f / l : 0.f;
+
+    // ---------------- main pass
+    for (int t = 0; t < nst; ++t) {
+        __syncthreads();
+        stage_split_rows_h3(kb_, (long)t * KB, a.Tk, a.ldk, tid, Kp, H3A_K);
+        stage_split_cols_h3(vb_, (long)t * KB, a.Tk, a.ldv, tid, Vt, H3A_V);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int key0 = t * KB + sub * 32;
+            if (key0 >= wave_kend) break;
+            f32x16 s;
+            scores(sub, s);
+            float p[16];
+            // a tile every lane sees in full needs no mask arithmetic (wave-uniform test)
+            const bool full = (key0 + 32 <= klen) && (!CAUSAL || key0 + 31 <= qw0);
+            if (WRITE_A) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    p[r] = alive(key0 + acc_row(r, half)) ? exp2f(__builtin_fmaf(s[r], H3A_C2, -m_fin * H3A_C2)) * inv_l : 0.f;
+            } else {
+                float mx = NEG_INF;
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        s[r] = alive(key0 + acc_row(r, half)) ? s[r] : NEG_INF;
+                        mx = fmaxf(mx, s[r]);
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float m_new = fmaxf(m, mx);
+                float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+                float alpha = exp2f((m - m_use) * H3A_C2);
+                const float mc = m_use * H3A_C2;
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { p[r] = exp2f(__builtin_fmaf(s[r], H3A_C2, -mc)); ps += p[r]; }
+                l = l * alpha + ps;
+                m = m_new;
+                if (__any(alpha != 1.f)) {   // the running maximum rarely moves after the first tiles
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+                }
+            }
+            if (a.thr != 0u) drop16(p, key0);
+            if (WRITE_A) {
+                // transpose through LDS in two halves of 16 keys (registers 8g..8g+7 are keys 16g..16g+15) so that the
+                // weights leave as 64-byte row segments
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ptile[l31 * 17 + (acc_row(8 * g2 + e, half) & 15)] = p[8 * g2 + e];
+                    wave_lds_sync();
+#pragma unroll 4
+                    for (int i = 0; i < 8; ++i) {
+                        const int qrow = 4 * i + (lane >> 4), kc = lane & 15;
+                        const float v = ptile[qrow * 17 + kc];
+                        const int q_g = qw0 + qrow, key_g = key0 + 16 * g2 + kc;
+                        if (q_g < a.Tq && key_g < a.Tk) a.attn[(arow + q_g) * a.Tk + key_g] = v;
+                    }
+                    wave_lds_sync();
+                }
+            }
+            // O^T[d][q] += V^T[d][key] P^T[key][q]: two 16-key steps, registers 8t..8t+7 of the lane are its B fragment
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = p[8 * t2 + e];
+                f16x8v pf[2];
+                split_frag8_h3(x, H3A_P, pf[0], pf[1]);
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    f16x8v vf[2];
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        vf[pl] = *reinterpret_cast<const f16x8v*>(Vt + pl * XP + xsw(32 * i2 + l31, 4 * sub + 2 * t2 + half));
+                    mfma_h3(o[i2], vf, pf);
+                }
+            }
+        }
+    }
+
+    float out_scale = H3A_O;       // the O accumulator holds (V * 2^4)^T (P * 2^10)^T
+    float lse_v;
+    if (WRITE_A) {
+        lse_v = m_fin * H3A_C + __logf(l > 0.f ? l : 1.f);
+    } else {
+        float lt = l + __shfl_xor(l, 32, 64);
+        out_scale = (lt > 0.f) ? H3A_O / lt : 0.f;
+        lse_v = ((m == NEG_INF) ? 0.f : m) * H3A_C + __logf(lt > 0.f ? lt : 1.f);
+    }
+    if (a.lse != nullptr && half == 0 && qg < a.Tq) a.lse[arow + qg] = lse_v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= out_scale; o[1][r] *= out_scale; }
+    __syncthreads();
+    wave_store_rows(o, scratch, a.o + (long)b * a.Tq * a.ldo + h * HD, qw0, a.Tq, a.ldo, lane, 1.f);
+}
+
 // ---- backward, split-precision.  Both kernels need one streamed operand in BOTH orientations (row-major for the score
 // products, transposed for the gradient products), so a thread stages a 4 x 4 patch: split once, packed twice (the
 // transposed pairs are re-packed from the row-major ones with v_perm_b32 instead of being split again).
@@ -1300,7 +1598,8 @@ extern "C" {
 
 static int attention_fwd_impl(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                               const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                              int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, bool x6, void* stream_) {
+                              int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, int form, void* stream_) {
+    // form: 0 = fp32 MFMA, 1 = bf16x6, 2 = fp16x3
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(q && k && v && o && key_lens, "attention_fwd: null pointer");
     int rc = check_common("attention_fwd", B, H, Tq, Tk, ldq, ldk, ldv, ldo, drop_p);
@@ -1315,7 +1614,17 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, fl
     a.drop_scale = 1.f / (1.f - drop_p);
     a.seed = seed; a.step_seed = step_seed;
     dim3 grid(B * H, cdiv(Tq, QB), 1);
-    if (x6) {
+    if (form == 2) {
+        if (causal)
+            hipLaunchKernelGGL((attn_fwd_h3_kernel<true, false>), grid, dim3(256), 0, stream, a);
+        else if (attn)
+            hipLaunchKernelGGL((attn_fwd_h3_kernel<false, true>), grid, dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((attn_fwd_h3_kernel<false, false>), grid, dim3(256), 0, stream, a);
+        TTTS_LAUNCH_CHECK("attn_fwd_h3_kernel");
+        return TTTS_OK;
+    }
+    if (form == 1) {
         if (causal)
             hipLaunchKernelGGL((attn_fwd_x6_kernel<true, false>), grid, dim3(256), 0, stream, a);
         else if (attn)
@@ -1338,13 +1647,19 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, fl
 int ttts_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                        const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                        int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
-    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, step_seed, false,
+    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, step_seed, 0,
                               stream);
 }
 int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
-    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, step_seed, true,
+    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, step_seed, 1,
+                              stream);
+}
+int ttts_attention_fwd_h3(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
+                          const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
+                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
+    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, step_seed, 2,
                               stream);
 }
 

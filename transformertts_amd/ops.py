@@ -124,7 +124,8 @@ def _ss():
 # (3-way bf16 split, six MFMA terms, fp32 accumulate; error 1.1e-7 vs 2.9e-7 for the plain fp32 MFMA chain),
 # "f32" = the plain v_mfma_f32_32x32x2_f32 kernel.  Weight gradients always use the fp32 kernel.
 GEMM_MODE = os.environ.get("TTTS_GEMM_MODE", "x6")
-ATTN_MODE = os.environ.get("TTTS_ATTN_MODE", GEMM_MODE)       # attention products: "x6" or "f32"
+ATTN_MODE = os.environ.get("TTTS_ATTN_MODE", GEMM_MODE)       # attention products (backward; forward unless ATTN_FWD_MODE): "x6" or "f32"
+ATTN_FWD_MODE = os.environ.get("TTTS_ATTN_FWD_MODE", "h3" if ATTN_MODE == "x6" else ATTN_MODE)   # forward: "h3", "x6", "f32"
 WGRAD_MODE = os.environ.get("TTTS_WGRAD_MODE", "h3" if GEMM_MODE == "x6" else GEMM_MODE)   # weight gradients: "h3", "x6", "f32"
 # Forward GEMMs (nn.Linear / Conv1d forward) under GEMM_MODE "x6": "h3" = fp16x3 split (three f16 MFMA terms on operands
 # pre-scaled into f16's range: O(1) activations, O(1/sqrt(fan_in)) weights; csrc/gemm_h3.hip), "x6" = bf16x6 as the
@@ -658,7 +659,7 @@ def _attn_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, lens, causal, drop_p, seed, 
     o = torch.empty(B, Tq, H * 64, dtype=torch.float32, device=dev)
     lse = torch.empty(B, H, Tq, dtype=torch.float32, device=dev)
     attn = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=dev) if need_weights else None
-    fwd = lib.ttts_attention_fwd_x6 if ATTN_MODE == "x6" else lib.ttts_attention_fwd
+    fwd = {"h3": lib.ttts_attention_fwd_h3, "x6": lib.ttts_attention_fwd_x6}.get(ATTN_FWD_MODE, lib.ttts_attention_fwd)
     _lib.check(fwd(q, k, v, _p(o), _p(lse), _p(attn), _p(lens), B, H, Tq, Tk, ldq, ldk, ldv, H * 64,
                    1 if causal else 0, float(drop_p), seed, _ss(), _stream()), "ttts_attention_fwd")
     return o, lse, attn
