@@ -225,11 +225,16 @@ int ttts_posenc_fwd(const float* x, const float* pe, const float* alpha, float* 
 size_t ttts_posenc_bwd_workspace_bytes(void);
 int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, float* ws, size_t ws_bytes, int B, int T,
                     int d, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate, void* stream);
-/* dx = dy * 1[out > 0] / (1-p): backward of drop(relu(.)) given the forward output */
-int ttts_relu_dropout_bwd(const float* dy, const float* out, float* dx, int64_t n, float drop_p, void* stream);
-/* dx = dy * keep(seed, i) / (1-p) */
+/* dx = dy * 1[out > 0] / (1-p): backward of drop(relu(.)) given the forward output.  amax_partials (NULL, or 1024
+ * floats): also emit the partial maxima of |dx| that ttts_amax_partials(dx) would produce -- the dynamic pre-scale input of
+ * the fp16x3 gradient GEMMs that consume dx -- without a second pass over it. */
+int ttts_relu_dropout_bwd(const float* dy, const float* out, float* dx, int64_t n, float drop_p, float* amax_partials,
+                          void* stream);
+/* dx = dy * keep(seed, i) / (1-p); amax_partials as above */
 int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, const uint64_t* step_seed,
-                     void* stream);
+                     float* amax_partials, void* stream);
+/* p[0 .. nbytes) = 0, enqueued as a memset on the stream (the flat gradient bucket at the start of a step) */
+int ttts_zero(void* p, size_t nbytes, void* stream);
 /* z = x + y */
 int ttts_add(const float* x, const float* y, float* z, int64_t n, void* stream);
 /* ---- input side: device-side padding of a ragged batch --------------------------------------
@@ -251,14 +256,15 @@ int ttts_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx_a
 /* ------------------------------------------------------------------ loss and scheduled-sampling mix
  * TransformerTTSLoss.forward (loss.py:15-55): out4 = [total, pred_mel, post_mel, stop]; masked MSE over frames
  * t < lens[b] (x2, post weighted 0.5 in the total) + BCE-with-logits on the stop gate (1 at t = lens[b]-1) with
- * pos_weight, mean over valid frames.  ws keeps the normalisers for ttts_loss_bwd, which takes the upstream gradient
- * of the four outputs (grad4) and writes the gradients of pred / post / stop. */
+ * pos_weight, mean over valid frames.  ws keeps the normalisers for ttts_loss_bwd, which takes the upstream gradients
+ * of the four outputs as device scalars (NULL = no gradient for that output) and writes the gradients of pred / post /
+ * stop. */
 size_t ttts_loss_workspace_bytes(void);
 int ttts_loss_fwd(const float* pred, const float* post, const float* stop, const float* mel, const int64_t* lens,
                   float* out4, float* ws, size_t ws_bytes, int B, int T, int C, float pos_weight, void* stream);
 int ttts_loss_bwd(const float* pred, const float* post, const float* stop, const float* mel, const int64_t* lens,
-                  const float* ws, const float* grad4, float* dpred, float* dpost, float* dstop, int B, int T, int C,
-                  float pos_weight, void* stream);
+                  const float* ws, const float* g_total, const float* g_pred_mel, const float* g_post_mel, const float* g_stop,
+                  float* dpred, float* dpost, float* dstop, int B, int T, int C, float pos_weight, void* stream);
 /* block_mask + apply_teacher_forcing (utils/util.py:103-120): u is the (B,T) uniform draw; frame t takes the model's
  * prediction when any u[t-l_bar/2 .. t-l_bar/2+l_bar-1] < 1-p_tf (max_pool1d(k=l_bar, s=1, pad=l_bar/2)[:T]), the
  * ground truth otherwise, and zero beyond lens[b].  u == NULL: the draw (torch.rand of utils/util.py:108) is generated

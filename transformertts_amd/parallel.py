@@ -40,7 +40,12 @@ class FlatGradBucket:
             p._ttts_grad_sink = v
 
     def zero(self) -> None:
-        self.flat.zero_()
+        if self.flat.is_cuda:        # a memset on the stream, not a fill kernel (one node of the captured step graph)
+            from . import _lib, ops
+            _lib.check(_lib.load().ttts_zero(ops._p(self.flat), self.flat.numel() * self.flat.element_size(), ops._stream()),
+                       "ttts_zero")
+        else:                        # host-side buckets exist only in the gloo CPU tests
+            self.flat.zero_()
         self.attach()
 
     def allreduce_mean(self, group: Optional[dist.ProcessGroup] = None, async_op: bool = False):

@@ -59,6 +59,7 @@ class TrainStep:
         if any(v.device != dev for v in self.batch.values()):
             raise ValueError("TrainStep: the batch must live on the model's HIP device")
         self.state = ops.StepState(dev)
+        self._one = torch.ones((), dtype=torch.float32, device=dev)
         self.base_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.index = 0                       # steps taken
         self.use_graph = bool(graph)
@@ -89,7 +90,7 @@ class TrainStep:
         ops.seeds.counter = 0                # site seeds are numbered per step; the step's seed word makes them fresh
         self.opt.zero_grad()
         loss = self.lm.training_step(self.batch, self.index)
-        loss.backward()
+        loss.backward(gradient=self._one)    # a resident 1.0 instead of autograd's ones_like fill kernel
         return loss
 
     def _reduce_and_update(self) -> None:
