@@ -213,6 +213,14 @@ int ttts_attention_bwd_x6(const float* q, const float* k, const float* v, const 
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
+/* fp16x3 form of the backward.  d_o is pre-scaled by the power of two that puts max|d_o| in [2^11, 2^12) (do_amax = the
+ * 1024 partial maxima of ttts_amax_partials(d_o)); dS = P (dP - delta) lives in registers as a lane-local accumulator
+ * column and gets a lane-local pre-scale that is lowered on the fly together with its accumulator. */
+int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                          const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
+                          int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
+                          void* stream);
 
 /* ------------------------------------------------------------------ small row / element-wise pieces
  * nn.Embedding gather / scatter-add (model/model.py:168,288; no padding_idx) */

@@ -345,6 +345,57 @@ def test_fp16x3_attention_forward(causal, Tq, Tk, lens, qk_scale):
         assert torch.equal(attn == 0, a6 == 0)
 
 
+@pytest.mark.parametrize("causal,Tq,Tk,lens", [(1, 200, 200, [200, 131, 64]), (0, 150, 70, [70, 33, 1]), (0, 33, 129, [129, 128, 5]),
+                                               (1, 870, 870, [870, 500])])
+@pytest.mark.parametrize("mag,grow", [(1.0, False), (3e-7, False), (3e-7, True)])
+def test_fp16x3_attention_backward(causal, Tq, Tk, lens, mag, grow):
+    """dQ, dK, dV of the fp16x3 backward against fp64 for gradients of realistic magnitude (3e-7), and with inputs that FORCE
+    the rare branch of the lane-local dS scale tracking (`grow`: the last keys' V rows and the last queries' dO rows are
+    1000 x larger, so late tiles outgrow the scale chosen from the first ones and the accumulators are rescaled);
+    dropout on: same masks and results as the bf16x6 form."""
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _off, _stream
+    lib = _lib.load()
+    B, H, d = len(lens), 2, 128
+    q, kv, do = _rand(B, Tq, d, seed=1), _rand(B, Tk, 2 * d, seed=2), _rand(B, Tq, d, seed=3) * mag
+    if grow:
+        kv[:, Tk - Tk // 4:, d:] *= 100.0          # (|V| stays below the 4096 of the static forward-operand window)
+        do[:, Tq - Tq // 4:] *= 1000.0
+    kl = torch.tensor(lens, dtype=torch.int64, device=_dev())
+    qd = q.double().view(B, Tq, H, 64).transpose(1, 2).requires_grad_()
+    kd = kv[..., :d].double().reshape(B, Tk, H, 64).transpose(1, 2).requires_grad_()
+    vd = kv[..., d:].double().reshape(B, Tk, H, 64).transpose(1, 2).requires_grad_()
+    sc = qd @ kd.transpose(-1, -2) / 8.0
+    mask = torch.arange(Tk, device=_dev())[None, None, None, :] >= kl[:, None, None, None]
+    if causal:
+        mask = mask | (torch.arange(Tk, device=_dev())[None, :] > torch.arange(Tq, device=_dev())[:, None])
+    p_ref = torch.softmax(sc.masked_fill(mask, float("-inf")), -1)
+    o_ref = (p_ref @ vd).transpose(1, 2).reshape(B, Tq, d)
+    o_ref.backward(do.double())
+    dq_ref = qd.grad.transpose(1, 2).reshape(B, Tq, d)
+    dkv_ref = torch.cat([kd.grad.transpose(1, 2).reshape(B, Tk, d), vd.grad.transpose(1, 2).reshape(B, Tk, d)], -1)
+
+    def run(fwd, bwd, p_drop, h3):
+        o = torch.empty(B, Tq, d, device=_dev()); lse = torch.empty(B, H, Tq, device=_dev())
+        assert fwd(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), None, _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, causal,
+                   p_drop, 99, None, _stream()) == 0
+        dq, dkv, delta = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(lse)
+        args = (_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(kl),
+                B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, p_drop, 99, None)
+        assert (bwd(*args, _p(ops._amax(do)), _stream()) if h3 else bwd(*args, _stream())) == 0
+        return dq, dkv
+    dq, dkv = run(lib.ttts_attention_fwd_h3, lib.ttts_attention_bwd_h3, 0.0, True)
+    assert _rel(dq, dq_ref) < TOL, _rel(dq, dq_ref)
+    assert _rel(dkv[..., :d], dkv_ref[..., :d]) < TOL and _rel(dkv[..., d:], dkv_ref[..., d:]) < TOL, \
+        (_rel(dkv[..., :d], dkv_ref[..., :d]), _rel(dkv[..., d:], dkv_ref[..., d:]))
+    if grow:     # the small early rows on their own, not drowned by the large late ones
+        n = Tq - Tq // 4
+        assert _rel(dq[:, :n], dq_ref[:, :n]) < 4 * TOL, _rel(dq[:, :n], dq_ref[:, :n])
+    a = run(lib.ttts_attention_fwd_h3, lib.ttts_attention_bwd_h3, 0.25, True)
+    b = run(lib.ttts_attention_fwd_x6, lib.ttts_attention_bwd_x6, 0.25, False)
+    assert _rel(a[0], b[0]) < TOL and _rel(a[1], b[1]) < TOL
+
+
 def _base_module(seed=5):
     from oracle.spec import model_config, fill_state
     from transformertts_amd.lightning_module import LightningModule

@@ -59,6 +59,7 @@ struct AttnArgs {
     int B, H, Tq, Tk;
     int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
     float drop_scale; uint32_t thr; uint64_t seed; const uint64_t* step_seed;
+    const float* do_amax; int do_amax_n;      // fp16x3 backward: partial maxima of |dout| (ttts_amax_partials)
 };
 
 // ---- cooperative staging (256 threads): KB rows x 64 floats from global straight into LDS; rows beyond
@@ -1559,6 +1560,449 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
     wave_store_rows(dv, scratch, a.dv + (long)b * a.Tk * a.lddv + h * HD, kw0, a.Tk, a.lddv, lane, 1.f);
 }
 
+// =====================================================================================================================
+// fp16x3 forms of the backward kernels.  Static pre-scales for Q / 8, K, V (x 2^4) and P (x 2^10) as in the forward; the
+// two gradient operands need dynamic ones:
+//   * dO: the power of two that puts max|dO| over the whole tensor in [2^11, 2^12), from the partial maxima of
+//     ttts_amax_partials (AttnArgs.do_amax).  It is one value for the tensor because dO is contracted over its rows in
+//     dV^T += dO^T P and over its columns in dP = dO V^T.
+//   * dS = P (dP - delta): produced and consumed in registers as the lane's own accumulator column (its query in the dQ
+//     kernel, its key in the dK/dV kernel), so its pre-scale is lane-local -- but the products of all tiles accumulate into
+//     the same registers, so it must be one value per lane for the whole loop.  attn_h3_track_scale sets it from the first
+//     non-zero tile (max -> [2^11, 2^12)) and, when a later tile would exceed 2^13, lowers it and rescales the lane's
+//     accumulator column by the same power of two (the online-softmax trick applied to a scale instead of a maximum).
+#ifndef TTTS_DQH_W
+#define TTTS_DQH_W 2
+#endif
+#ifndef TTTS_DKVH_W
+#define TTTS_DKVH_W 2
+#endif
+constexpr int DQH_SMEM = ((6 * XP > SMEM_FLOATS) ? 6 * XP : SMEM_FLOATS) * 4;   // K rows, V rows, K^T: 2 planes each (48 KB)
+constexpr int DKVH_DW = 4 * XPQ + 4 * XPT + 2 * RAWQ + 256;                    // planes 32 KB + raw Q, dO 16 KB + stats
+static_assert(DKVH_DW >= SMEM_FLOATS, "per-wave fp32 scratch must fit the stage buffers");
+constexpr int DKVH_SMEM = DKVH_DW * 4;
+
+__device__ __forceinline__ void attn_h3_grad_scale(const float* __restrict__ partials, int n, int lane, float& s, float& inv_s) {
+    float m = 0.f;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, partials[i]);
+    m = wave_max(m);
+    const uint32_t e = (__float_as_uint(m) >> 23) & 0xffu;
+    if (e >= 24u && e < 255u) {
+        s = __uint_as_float((265u - e) << 23);             // 2^(138 - e): max|dO| -> [2^11, 2^12)
+        inv_s = __uint_as_float((e - 11u) << 23);          // 2^(e - 138)
+    } else {
+        s = 1.f; inv_s = 1.f;
+    }
+}
+// ds: this lane's 16 dS values of the tile (true units); sds: the lane's current pre-scale (0 = unset); acc: the
+// accumulator pair the products land in (lane-local column).  Both half-waves hold halves of the same column.
+__device__ __forceinline__ void attn_h3_track_scale(const float (&ds)[16], float& sds, f32x16 (&acc)[2]) {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(ds[r]));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const uint32_t e = (__float_as_uint(m) >> 23) & 0xffu;
+    const bool change = e >= 24u && e < 255u && (sds == 0.f || m * sds > 8192.f);
+    if (__any(change)) {
+        const float snew = change ? __uint_as_float((265u - e) << 23) : sds;
+        const float f = (change && sds != 0.f) ? snew / sds : 1.f;        // a power of two <= 2^-1 when it applies
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] *= f; acc[1][r] *= f; }
+        sds = snew;
+    }
+}
+// rows 4rq..4rq+3, columns 4dq..4dq+3 (already pre-scaled) -> row-major f16 planes `rows` and, when TR, transposed planes
+// `cols`; layouts, swizzles and the v_perm re-pack as patch_split_store
+template <bool TR, int NPOS>
+__device__ __forceinline__ void patch_split_store_h3(const float4 (&v)[4], int rq, int dq, int pos, uint32_t* rows, int XPR,
+                                                     uint32_t* cols, int XPC) {
+    uint2 hi[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        split2_pair_h(f32x2{v[i].x, v[i].y}, hi[i].x, lo[i].x);
+        split2_pair_h(f32x2{v[i].z, v[i].w}, hi[i].y, lo[i].y);
+        const int d = xsw(4 * rq + i, dq >> 1) + (dq & 1) * 2;
+        *reinterpret_cast<uint2*>(rows + d) = hi[i];
+        *reinterpret_cast<uint2*>(rows + XPR + d) = lo[i];
+    }
+    if (TR) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t sel = (c & 1) ? 0x07060302u : 0x05040100u;   // high / low halves of the two source dwords
+            uint2 th, tl;
+            if (c < 2) {
+                th.x = __builtin_amdgcn_perm(hi[1].x, hi[0].x, sel); th.y = __builtin_amdgcn_perm(hi[3].x, hi[2].x, sel);
+                tl.x = __builtin_amdgcn_perm(lo[1].x, lo[0].x, sel); tl.y = __builtin_amdgcn_perm(lo[3].x, lo[2].x, sel);
+            } else {
+                th.x = __builtin_amdgcn_perm(hi[1].y, hi[0].y, sel); th.y = __builtin_amdgcn_perm(hi[3].y, hi[2].y, sel);
+                tl.x = __builtin_amdgcn_perm(lo[1].y, lo[0].y, sel); tl.y = __builtin_amdgcn_perm(lo[3].y, lo[2].y, sel);
+            }
+            const int d = 4 * dq + c;
+            const int dd = (NPOS == 64 ? xsw(d, pos >> 3) : xsw4(d, pos >> 3)) + ((pos >> 2) & 1) * 2;
+            *reinterpret_cast<uint2*>(cols + dd) = th;
+            *reinterpret_cast<uint2*>(cols + XPC + dd) = tl;
+        }
+    }
+}
+// lane-resident B operand: the 64 values of this lane's row (query or key) x scale, split in two, for the four 16-deep steps
+__device__ __forceinline__ void load_lane_frags_h3(const float* scratch, int l31, int half, float scale, f16x8v (&f)[4][2]) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = scratch[l31 * KT_LD + 16 * st + 8 * half + e];
+        split_frag8_h3(x, scale, f[st][0], f[st][1]);
+    }
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArgs a) {
+    const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
+    extern __shared__ __attribute__((aligned(16))) uint32_t xsd[];
+    uint32_t* Kr = xsd;              // [2][64 keys][64 d]       f16 hi / lo of K * 2^4
+    uint32_t* Vr = xsd + 2 * XP;     // [2][64 keys][64 d]       of V * 2^4
+    uint32_t* Kt = xsd + 4 * XP;     // [2][64 d][64 key positions]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int qblk = CAUSAL ? (gridDim.y - 1 - blockIdx.y) : blockIdx.y;
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+    const int q0 = qblk * QB, qw0 = q0 + wave * 32;
+    const int qg = qw0 + l31;
+    float* scratch = reinterpret_cast<float*>(xsd) + wave * 32 * KT_LD;
+
+    int klen = (int)a.key_lens[b];
+    if (klen > a.Tk) klen = a.Tk;
+    if (klen < 0) klen = 0;
+    int kend = klen;
+    if (CAUSAL && kend > q0 + QB) kend = q0 + QB;
+    const int nst = (kend + KB - 1) / KB;
+    int wave_kend = kend;
+    if (CAUSAL && wave_kend > qw0 + 32) wave_kend = qw0 + 32;
+
+    const float* qb_ = a.q + (long)b * a.Tq * a.ldq + h * HD;
+    const float* kb_ = a.k + (long)b * a.Tk * a.ldk + h * HD;
+    const float* vb_ = a.v + (long)b * a.Tk * a.ldv + h * HD;
+    const float* ob_ = a.o + (long)b * a.Tq * a.ldo + h * HD;
+    const float* gb_ = a.dout + (long)b * a.Tq * a.ldo + h * HD;
+    const long arow = ((long)(b * a.H + h) * a.Tq);
+    const uint32_t rowid = (uint32_t)(arow + qg);
+
+    // dO is a gradient: its pre-scale is the power of two that puts max|dO| (over the whole tensor) in [2^11, 2^12)
+    float s_g, inv_g;
+    attn_h3_grad_scale(a.do_amax, a.do_amax_n, lane, s_g, inv_g);
+    f16x8v qf[4][2], gf[4][2];
+    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
+    wave_lds_sync();
+    load_lane_frags_h3(scratch, l31, half, H3A_Q, qf);
+    wave_lds_sync();
+    wave_stage_tile(ob_, qw0, a.Tq, a.ldo, lane, scratch, 1.f);
+    wave_lds_sync();
+    float orow[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) orow[j] = scratch[l31 * KT_LD + 2 * j + half];
+    wave_lds_sync();
+    wave_stage_tile(gb_, qw0, a.Tq, a.ldo, lane, scratch, 1.f);
+    wave_lds_sync();
+    float delta = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) delta += scratch[l31 * KT_LD + 2 * j + half] * orow[j];
+    delta += __shfl_xor(delta, 32, 64);
+    load_lane_frags_h3(scratch, l31, half, s_g, gf);
+    if (half == 0 && qg < a.Tq) a.delta[arow + qg] = delta;
+    const float lse_q2 = ((qg < a.Tq) ? a.lse[arow + qg] : 0.f) * 1.4426950408889634f;
+    const float dp_unscale = inv_g / H3A_V;      // dP accumulator units -> true dP
+    float sds = 0.f;                              // this query's dS pre-scale (power of two), set / lowered on the fly
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+
+    const int rq = tid >> 4, dqd = tid & 15;
+    const int kpos = (rq >> 3) * 32 + perm_pos(rq);
+    for (int t = 0; t < nst; ++t) {
+        __syncthreads();
+        {
+            float4 v[4];
+            patch_load(kb_, (long)t * KB, a.Tk, a.ldk, rq, dqd, H3A_K, v);
+            patch_split_store_h3<true, 64>(v, rq, dqd, kpos, Kr, XP, Kt, XP);
+            patch_load(vb_, (long)t * KB, a.Tk, a.ldv, rq, dqd, H3A_V, v);
+            patch_split_store_h3<false, 64>(v, rq, dqd, 0, Vr, XP, nullptr, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int key0 = t * KB + sub * 32;
+            if (key0 >= wave_kend) break;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                f16x8v kf[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    kf[p] = *reinterpret_cast<const f16x8v*>(Kr + p * XP + xsw(sub * 32 + l31, 2 * st + half));
+                mfma_h3(s, kf, qf[st]);
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                f16x8v vf[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    vf[p] = *reinterpret_cast<const f16x8v*>(Vr + p * XP + xsw(sub * 32 + l31, 2 * st + half));
+                mfma_h3(dp, vf, gf[st]);
+            }
+            float ds[16];
+            // a tile every lane sees in full needs no mask arithmetic (wave-uniform test)
+            const bool full = (key0 + 32 <= klen) && (!CAUSAL || key0 + 31 <= qw0);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int key_g = key0 + acc_row(r, half);
+                uint32_t hsh = 0;
+                if (a.thr != 0u) hsh = attn_hash(seed_eff, rowid, (uint32_t)key_g >> 1);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int kg = key_g + e;
+                    float p = exp2f(__builtin_fmaf(s[r + e], H3A_C2, -lse_q2));
+                    if (!full) p = (kg < klen && (!CAUSAL || kg <= qg)) ? p : 0.f;
+                    float g = dp[r + e] * dp_unscale;
+                    if (a.thr != 0u) g = keep_from_hash(hsh, (uint32_t)e, a.thr) ? g * a.drop_scale : 0.f;
+                    ds[r + e] = p * (g - delta);
+                }
+            }
+            // dQ^T[d][q] += K^T[d][key] dS^T[key][q].  dS is the lane's own column (its query), so its f16 pre-scale is
+            // lane-local; it has to be ONE value over all key tiles because they accumulate into the same dq registers,
+            // so it is lowered when a tile outgrows it and the (lane-local) accumulator column is rescaled with it
+            attn_h3_track_scale(ds, sds, dq);
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = ds[8 * t2 + e];
+                f16x8v dsf[2];
+                split_frag8_h3(x, sds, dsf[0], dsf[1]);
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    f16x8v ktf[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        ktf[p] = *reinterpret_cast<const f16x8v*>(Kt + p * XP + xsw(32 * i2 + l31, 4 * sub + 2 * t2 + half));
+                    mfma_h3(dq[i2], ktf, dsf);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const float fin = (sds > 0.f) ? 0.125f / (H3A_K * sds) : 0.f;      // accumulator units -> dQ (incl. the 1/8 of q / 8)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq[0][r] *= fin; dq[1][r] *= fin; }
+    }
+    wave_store_rows(dq, scratch, a.dq + (long)b * a.Tq * a.lddq + h * HD, qw0, a.Tq, a.lddq, lane, 1.f);
+}
+
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnArgs a) {
+    const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
+    extern __shared__ __attribute__((aligned(16))) uint32_t xsd[];
+    uint32_t* xs = xsd;
+    uint32_t* Qr = xs;                      // [2][32 q][64 d]     f16 hi / lo of Q / 8 * 2^4
+    uint32_t* Gr = xs + 2 * XPQ;            //                     of dO * s_g
+    uint32_t* Qt = xs + 4 * XPQ;            // [2][64 d][32 q positions]
+    uint32_t* Gt = xs + 4 * XPQ + 2 * XPT;
+    uint32_t* rawQ = xs + 4 * XPQ + 4 * XPT;   // [32][64] fp32, filled by DMA
+    uint32_t* rawG = rawQ + RAWQ;
+    float* stat_s = reinterpret_cast<float*>(rawG + RAWQ);  // [2 buffers][lse 64 | delta 64] (32 of each 64 used)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int kblk = blockIdx.y;
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+    const int k0 = kblk * QB, kw0 = k0 + wave * 32;
+    const int kg = kw0 + l31;
+    float* scratch = reinterpret_cast<float*>(xs) + wave * 32 * KT_LD;
+
+    int klen = (int)a.key_lens[b];
+    if (klen > a.Tk) klen = a.Tk;
+    if (klen < 0) klen = 0;
+
+    const float* qb_ = a.q + (long)b * a.Tq * a.ldq + h * HD;
+    const float* kb_ = a.k + (long)b * a.Tk * a.ldk + h * HD;
+    const float* vb_ = a.v + (long)b * a.Tk * a.ldv + h * HD;
+    const float* gb_ = a.dout + (long)b * a.Tq * a.ldo + h * HD;
+    const long arow = ((long)(b * a.H + h) * a.Tq);
+
+    float s_g, inv_g;
+    attn_h3_grad_scale(a.do_amax, a.do_amax_n, lane, s_g, inv_g);
+    f16x8v kf[4][2], vf[4][2];
+    wave_stage_tile(kb_, kw0, a.Tk, a.ldk, lane, scratch, 1.f);
+    wave_lds_sync();
+    load_lane_frags_h3(scratch, l31, half, H3A_K, kf);
+    wave_lds_sync();
+    wave_stage_tile(vb_, kw0, a.Tk, a.ldv, lane, scratch, 1.f);
+    wave_lds_sync();
+    load_lane_frags_h3(scratch, l31, half, H3A_V, vf);
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+
+    const float dp_unscale = inv_g / H3A_V;
+    float sds = 0.f;                        // this key's dS pre-scale (power of two), see attn_bwd_dq_h3_kernel
+    const int nqs = (a.Tq + QS - 1) / QS;
+    int qs_begin = CAUSAL ? (k0 / QS) : 0;
+    if (k0 >= klen) qs_begin = nqs;
+
+    // staging roles: threads 0..127 take Q, 128..255 take dO; each a 4 x 4 patch of the 32 x 64 stage
+    const int st_t = tid & 127, rq = st_t >> 4, dqd = st_t & 15;
+    const bool st_q = tid < 128;
+    const int qpos = perm_pos(rq);
+
+    // DMA of one stage: wave w moves rows 8w..8w+7 of Q and of dO (two 1-KB instructions each), wave 0 also lse / delta.
+    // Rows past Tq are clamped to the last row here and zeroed when they are split.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar copy: the DMA destinations must not cost VGPRs
+    const int dma_row = 8 * wave + (lane >> 4);
+    const uint32_t dma_col = (uint32_t)(lane & 15) * 16u;
+    const float* lse_b = a.lse + arow;
+    const float* delta_b = a.delta + arow;
+    auto fetch = [&](int qt0, int sb) {
+        if (wave_u == 0) {     // first: whatever the allocator does to this address must not wait on the big requests
+            int q = qt0 + l31;
+            if (q > a.Tq - 1) q = a.Tq - 1;
+            dma4(lse_b, (uint32_t)q * 4u, reinterpret_cast<uint32_t*>(stat_s + sb * 128));
+            dma4(delta_b, (uint32_t)q * 4u, reinterpret_cast<uint32_t*>(stat_s + sb * 128 + 64));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int gr = qt0 + dma_row + 4 * j;
+            if (gr > a.Tq - 1) gr = a.Tq - 1;
+            dma16(qb_, (uint32_t)gr * (uint32_t)(a.ldq * 4) + dma_col, rawQ + (8 * wave_u + 4 * j) * 64);
+            dma16(gb_, (uint32_t)gr * (uint32_t)(a.ldo * 4) + dma_col, rawG + (8 * wave_u + 4 * j) * 64);
+        }
+    };
+
+    __syncthreads();                       // the per-wave scratch (aliasing the planes) is dead from here on
+    if (qs_begin < nqs) fetch(qs_begin * QS, qs_begin & 1);
+
+    for (int qs = qs_begin; qs < nqs; ++qs) {
+        const int qt0 = qs * QS;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the stage have landed
+        __syncthreads();                                    // ... and everybody else's; previous planes are free
+        {
+            const uint32_t* raw = st_q ? rawQ : rawG;
+            const float sc = st_q ? 0.125f * H3A_Q : s_g;
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 4 * rq + i;
+                const u32x4v u = *reinterpret_cast<const u32x4v*>(raw + row * 64 + dqd * 4);
+                const bool ok = qt0 + row < a.Tq;
+                v[i] = make_float4(ok ? __uint_as_float(u[0]) * sc : 0.f, ok ? __uint_as_float(u[1]) * sc : 0.f,
+                                   ok ? __uint_as_float(u[2]) * sc : 0.f, ok ? __uint_as_float(u[3]) * sc : 0.f);
+            }
+            if (st_q) patch_split_store_h3<true, 32>(v, rq, dqd, qpos, Qr, XPQ, Qt, XPT);
+            else patch_split_store_h3<true, 32>(v, rq, dqd, qpos, Gr, XPQ, Gt, XPT);
+        }
+        const float* lse_s = stat_s + (qs & 1) * 128;
+        const float* delta_s = lse_s + 64;
+        __syncthreads();
+        if (qs + 1 < nqs) fetch(qt0 + QS, (qs + 1) & 1);   // in flight while this stage is multiplied
+        if (CAUSAL && qt0 + 31 < kw0) continue;     // every query of the stage precedes this wave's keys (wave-uniform)
+        if (kw0 >= klen) continue;                  // this wave's keys are all padding
+
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            f16x8v qfr[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) qfr[p] = *reinterpret_cast<const f16x8v*>(Qr + p * XPQ + xsw(l31, 2 * st + half));
+            mfma_h3(s, qfr, kf[st]);
+        }
+        float pd[16];
+        const bool full = (kw0 + 32 <= klen) && (!CAUSAL || kw0 + 31 <= qt0) && (qt0 + QS <= a.Tq);   // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q_g = qt0 + acc_row(r, half);
+            float p = exp2f(__builtin_fmaf(s[r], H3A_C2, -lse_s[acc_row(r, half)] * 1.4426950408889634f));
+            if (!full) p = (kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq) ? p : 0.f;
+            pd[r] = p;
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            f16x8v gfr[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) gfr[p] = *reinterpret_cast<const f16x8v*>(Gr + p * XPQ + xsw(l31, 2 * st + half));
+            mfma_h3(dp, gfr, vf[st]);
+        }
+        float ds[16];
+        // dropout: keys 2j, 2j+1 (neighbouring lanes) share one hash per query row -- the even lane computes it for the even
+        // registers, the odd lane for the odd ones, and a quad-permute DPP move hands the other half over
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            uint32_t h0 = 0, h1 = 0;
+            if (a.thr != 0u) {
+                const int rr = r + (lane & 1);
+                const uint32_t mine = attn_hash(seed_eff, (uint32_t)(arow + qt0 + acc_row(rr, half)), (uint32_t)kg >> 1);
+                const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+                h0 = (lane & 1) ? other : mine;
+                h1 = (lane & 1) ? mine : other;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float g = dp[r + e] * dp_unscale;
+                float pk = pd[r + e];
+                if (a.thr != 0u) {
+                    const bool keep = keep_from_hash(e ? h1 : h0, (uint32_t)kg & 1u, a.thr);
+                    g = keep ? g * a.drop_scale : 0.f;
+                    pk = keep ? pk * a.drop_scale : 0.f;
+                }
+                ds[r + e] = pd[r + e] * (g - delta_s[acc_row(r + e, half)]);
+                pd[r + e] = pk;
+            }
+        }
+        // dV^T[d][key] += dO^T[d][q] P[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key]
+        attn_h3_track_scale(ds, sds, dk);       // lane-local dS pre-scale (this lane's key), lowered on the fly with dk
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            float x[8];
+            f16x8v f[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = pd[8 * t2 + e];
+            split_frag8_h3(x, H3A_P, f[0], f[1]);
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                f16x8v af[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const f16x8v*>(Gt + p * XPT + xsw4(32 * i2 + l31, 2 * t2 + half));
+                mfma_h3(dv[i2], af, f);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = ds[8 * t2 + e];
+            split_frag8_h3(x, sds, f[0], f[1]);
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                f16x8v af[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const f16x8v*>(Qt + p * XPT + xsw4(32 * i2 + l31, 2 * t2 + half));
+                mfma_h3(dk[i2], af, f);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const float fk = (sds > 0.f) ? 1.f / (H3A_Q * sds) : 0.f;        // dk accumulator: (Q / 8 * 2^4)^T (dS * sds)
+        const float fv = inv_g / H3A_P;                                   // dv accumulator: (dO * s_g)^T (P * 2^10)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[0][r] *= fk; dk[1][r] *= fk; dv[0][r] *= fv; dv[1][r] *= fv; }
+    }
+    wave_store_rows(dk, scratch, a.dk + (long)b * a.Tk * a.lddk + h * HD, kw0, a.Tk, a.lddk, lane, 1.f);
+    wave_store_rows(dv, scratch, a.dv + (long)b * a.Tk * a.lddv + h * HD, kw0, a.Tk, a.lddv, lane, 1.f);
+}
+
 static int check_common(const char* name, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, float drop_p) {
     TTTS_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "%s: bad dims", name);
     TTTS_REQUIRE((long)B * H < (1L << 31) && cdiv(Tq, QB) <= 65535 && cdiv(Tk, QB) <= 65535, "%s: grid too large", name);
@@ -1591,6 +2035,28 @@ static int launch_bwd_x6(const AttnArgs& a, dim3 gq, dim3 gk, hipStream_t stream
     TTTS_LAUNCH_CHECK("attn_bwd_dq_x6_kernel");
     hipLaunchKernelGGL((attn_bwd_dkv_x6_kernel<CAUSAL>), gk, dim3(256), DKVX_SMEM, stream, a);
     TTTS_LAUNCH_CHECK("attn_bwd_dkv_x6_kernel");
+    return TTTS_OK;
+}
+
+template <bool CAUSAL>
+static int launch_bwd_h3(const AttnArgs& a, dim3 gq, dim3 gk, hipStream_t stream) {
+    static bool configured = false;   // dynamic LDS sizes are registered once per kernel
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_h3_kernel<CAUSAL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DQH_SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_h3_kernel<CAUSAL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, DKVH_SMEM);
+        if (e != hipSuccess) {
+            set_error("attention_bwd_h3: cannot reserve %d bytes of LDS: %s", DKVH_SMEM, hipGetErrorString(e));
+            return TTTS_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_dq_h3_kernel<CAUSAL>), gq, dim3(256), DQH_SMEM, stream, a);
+    TTTS_LAUNCH_CHECK("attn_bwd_dq_h3_kernel");
+    hipLaunchKernelGGL((attn_bwd_dkv_h3_kernel<CAUSAL>), gk, dim3(256), DKVH_SMEM, stream, a);
+    TTTS_LAUNCH_CHECK("attn_bwd_dkv_h3_kernel");
     return TTTS_OK;
 }
 
@@ -1666,9 +2132,12 @@ int ttts_attention_fwd_h3(const float* q, const float* k, const float* v, float*
 static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* do_,
                               const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                               int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                              int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, bool x6, void* stream_) {
+                              int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, int form, void* stream_,
+                              const float* do_amax = nullptr) {
+    // form: 0 = fp32 MFMA, 1 = bf16x6, 2 = fp16x3 (needs do_amax)
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(q && k && v && o && do_ && lse && delta && dq && dk && dv && key_lens, "attention_bwd: null pointer");
+    TTTS_REQUIRE(form != 2 || do_amax, "attention_bwd_h3: do_amax (ttts_amax_partials of d_o) is required");
     int rc = check_common("attention_bwd", B, H, Tq, Tk, ldq, ldk, ldv, ldo, drop_p);
     if (rc) return rc;
     TTTS_REQUIRE(lddq >= H * HD && lddk >= H * HD && lddv >= H * HD, "attention_bwd: gradient strides must be >= H*64");
@@ -1684,7 +2153,11 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
     a.drop_scale = 1.f / (1.f - drop_p);
     a.seed = seed; a.step_seed = step_seed;
     dim3 gq(B * H, cdiv(Tq, QB), 1), gk(B * H, cdiv(Tk, QB), 1);
-    if (x6) return causal ? launch_bwd_x6<true>(a, gq, gk, stream) : launch_bwd_x6<false>(a, gq, gk, stream);
+    if (form == 2) {
+        a.do_amax = do_amax; a.do_amax_n = 1024;
+        return causal ? launch_bwd_h3<true>(a, gq, gk, stream) : launch_bwd_h3<false>(a, gq, gk, stream);
+    }
+    if (form == 1) return causal ? launch_bwd_x6<true>(a, gq, gk, stream) : launch_bwd_x6<false>(a, gq, gk, stream);
     if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), gq, dim3(256), 0, stream, a);
         TTTS_LAUNCH_CHECK("attn_bwd_dq_kernel");
@@ -1703,14 +2176,22 @@ int ttts_attention_bwd(const float* q, const float* k, const float* v, const flo
                        int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                        int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
     return attention_bwd_impl(q, k, v, o, do_, lse, delta, dq, dk, dv, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk,
-                              lddv, causal, drop_p, seed, step_seed, false, stream);
+                              lddv, causal, drop_p, seed, step_seed, 0, stream);
 }
 int ttts_attention_bwd_x6(const float* q, const float* k, const float* v, const float* o, const float* do_,
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
     return attention_bwd_impl(q, k, v, o, do_, lse, delta, dq, dk, dv, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk,
-                              lddv, causal, drop_p, seed, step_seed, true, stream);
+                              lddv, causal, drop_p, seed, step_seed, 1, stream);
+}
+int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                          const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
+                          int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
+                          void* stream) {
+    return attention_bwd_impl(q, k, v, o, d_o, lse, delta, dq, dk, dv, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk,
+                              lddv, causal, drop_p, seed, step_seed, 2, stream, do_amax);
 }
 
 }  // extern "C"

@@ -126,6 +126,7 @@ def _ss():
 GEMM_MODE = os.environ.get("TTTS_GEMM_MODE", "x6")
 ATTN_MODE = os.environ.get("TTTS_ATTN_MODE", GEMM_MODE)       # attention products (backward; forward unless ATTN_FWD_MODE): "x6" or "f32"
 ATTN_FWD_MODE = os.environ.get("TTTS_ATTN_FWD_MODE", "h3" if ATTN_MODE == "x6" else ATTN_MODE)   # forward: "h3", "x6", "f32"
+ATTN_BWD_MODE = os.environ.get("TTTS_ATTN_BWD_MODE", "h3" if ATTN_MODE == "x6" else ATTN_MODE)   # backward: "h3", "x6", "f32"
 WGRAD_MODE = os.environ.get("TTTS_WGRAD_MODE", "h3" if GEMM_MODE == "x6" else GEMM_MODE)   # weight gradients: "h3", "x6", "f32"
 # Forward GEMMs (nn.Linear / Conv1d forward) under GEMM_MODE "x6": "h3" = fp16x3 split (three f16 MFMA terms on operands
 # pre-scaled into f16's range: O(1) activations, O(1/sqrt(fan_in)) weights; csrc/gemm_h3.hip), "x6" = bf16x6 as the
@@ -153,8 +154,11 @@ def _amax(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _attn_bwd(lib):
-    return lib.ttts_attention_bwd_x6 if ATTN_MODE == "x6" else lib.ttts_attention_bwd
+def _attn_bwd(lib, do, *args):
+    """Attention backward in the configured form; `args` = every C-ABI argument up to step_seed."""
+    if ATTN_BWD_MODE == "h3":
+        return lib.ttts_attention_bwd_h3(*args, _p(_amax(do)), _stream())
+    return (lib.ttts_attention_bwd_x6 if ATTN_BWD_MODE == "x6" else lib.ttts_attention_bwd)(*args, _stream())
 
 
 def _wgrad(lib, name: str, dy: torch.Tensor, amax, *args):
@@ -703,10 +707,9 @@ class SelfAttentionFn(torch.autograd.Function):
         do = _chk(do, "self_attention.do")
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
-        _lib.check(_attn_bwd(lib)(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta),
-                                          _off(dqkv, 0), _off(dqkv, d), _off(dqkv, 2 * d), _p(lens), B, n_head, T, T, d3,
-                                          d3, d3, d, d3, d3, d3, 1 if causal else 0, drop_p, seed, ctx.ss, _stream()),
-                   "ttts_attention_bwd")
+        _lib.check(_attn_bwd(lib, do, _off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta),
+                             _off(dqkv, 0), _off(dqkv, d), _off(dqkv, 2 * d), _p(lens), B, n_head, T, T, d3,
+                             d3, d3, d, d3, d3, d3, 1 if causal else 0, drop_p, seed, ctx.ss), "ttts_attention_bwd")
         return dqkv, None, None, None, None, None
 
 
@@ -743,9 +746,9 @@ class CrossAttentionFn(torch.autograd.Function):
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         delta = torch.empty_like(lse)
-        _lib.check(_attn_bwd(lib)(_off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
-                                          _off(dq, 0), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk, d, 2 * d,
-                                          2 * d, d, d, 2 * d, 2 * d, 0, drop_p, seed, ctx.ss, _stream()), "ttts_attention_bwd")
+        _lib.check(_attn_bwd(lib, do, _off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
+                             _off(dq, 0), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk, d, 2 * d,
+                             2 * d, d, d, 2 * d, 2 * d, 0, drop_p, seed, ctx.ss), "ttts_attention_bwd")
         return dq, dkv, None, None, None, None, None
 
 
