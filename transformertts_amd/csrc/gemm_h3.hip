@@ -97,18 +97,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    // XCD-aware tile numbering (as the bf16x6 kernel): the column blocks of one A row panel run on one XCD / L2
-    const int nx = gridDim.x;
-    const int ntiles = nx * gridDim.y;
-    const int bid = blockIdx.y * nx + blockIdx.x;
+    const int nkt = g.K / HBK;
+    float a_scale = H3_A_SCALE, out_scale = H3_OUT_SCALE;
+    if (g.a_amax != nullptr) h3_dynamic_scale(g.a_amax, g.a_amax_n, lane, a_scale, out_scale);
+    // Persistent tile loop: the grid is (at most) as many workgroups as the chip holds at once and each walks over tiles
+    // bid, bid + gridDim.x, ...  A workgroup that has issued the stores of one tile goes straight on to the loads of the next,
+    // so the output burst drains from L2 to HBM under the next tile's main loop instead of in front of a new workgroup's
+    // start.  XCD-aware numbering (as the bf16x6 kernel): workgroups are dealt round-robin to the 8 XCDs, so virtual block
+    // ids that are equal mod 8 share an L2, and the column blocks of one A row panel get consecutive ids of one XCD.
+    const int nx = (g.N + BN - 1) / BN;
+    const int ntiles = nx * ((g.M + BM - 1) / BM);
+    for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
     const int xcd = bid & 7, slot = bid >> 3;
     const int per = ntiles >> 3, rem = ntiles & 7;
     const int t = xcd * per + min(xcd, rem) + slot;
     const int ty = t / nx, tx = t - ty * nx;
     const int m0 = ty * BM, n0 = tx * BN;
-    const int nkt = g.K / HBK;
-    float a_scale = H3_A_SCALE, out_scale = H3_OUT_SCALE;
-    if (g.a_amax != nullptr) h3_dynamic_scale(g.a_amax, g.a_amax_n, lane, a_scale, out_scale);
 
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
@@ -265,10 +269,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
     }
 
     // ---------------- epilogue.  Accumulator tile (i, j) holds C[m][n] for m = row0 + l31 (the lane) and, in registers
-    // 4g .. 4g+3, the four consecutive columns n = col0 + 8g + 4*half + (0..3): every memory operation of the epilogue
-    // (bias, residual, relu gate, the store) is a 16-byte access, a quarter of the instructions of a dword epilogue -- at
-    // K = 256 (most GEMMs of the step) the dword epilogue took longer than the main loop.  N % 4 == 0 is required.
-    // Auxiliary operands go through buffer descriptors (rows past M / columns past N read 0, no load behind a branch).
+    // 4q .. 4q+3, four consecutive columns.  Written from that layout a wave-store touches 32 rows x 32 bytes -- a quarter
+    // of 32 different 128-byte lines -- and the output burst of a tile (256 KB per workgroup, every CU at the same time) ran
+    // at 3.4 TB/s.  So each 32-row slab of the wave tile is turned through LDS (free at this point: one barrier after the last
+    // k-tile) and leaves in row-major order: a wave instruction then moves whole lines (4 rows x 256 B for a 64-wide wave
+    // tile), and so do the reads of the auxiliary operands (bias, residual, the forward activation whose relu / dropout mask
+    // gates a data gradient), which go through buffer descriptors (rows past M / columns past N read 0, no load behind a
+    // branch).  N % 4 == 0 is required.
     float* C = g.C;
     const bool do_drop = g.drop_thr != 0u;
     const bool has_gate = g.relu_out != nullptr, has_res = g.residual != nullptr;
@@ -278,36 +285,66 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
         const_cast<float*>(has_res ? g.residual : g.A), 0, has_res ? (uint32_t)((long)g.M * g.ldr * 4) : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcBias = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(g.bias != nullptr ? g.bias : g.A), 0, g.bias != nullptr ? (uint32_t)g.N * 4u : 0u, 0x00020000);
+    constexpr int EP_LD = WTN + 4;                        // floats per slab row (+16 B: conflict-free float4 column writes)
+    constexpr int C4 = WTN / 4;                           // float4 per slab row
+    constexpr int NIT = (32 * C4 + 63) / 64;              // float4 per lane and slab
+    constexpr bool EVEN = (32 * C4) % 64 == 0 && 64 % C4 == 0;   // every lane keeps ONE column group for the whole tile
+    static_assert((WM * WN) * 32 * EP_LD <= 2 * STAGE, "epilogue slabs must fit the staging buffers");
+    float* slab = reinterpret_cast<float*>(lds) + wave * (32 * EP_LD);
+    const int col_base = n0 + wn * WTN;
+    // vmcnt is an in-order counter shared by loads and stores: a load issued behind a slab's stores cannot be waited for
+    // without waiting for those stores to complete.  The bias of a lane's (fixed) column group is therefore read once per
+    // tile, so that a bias-only epilogue (in-projections, FFN1, convolutions) issues its stores back to back; residual /
+    // gate operands are requested per slab, all of them before the slab's first store.
+    float4 bias_fixed = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EVEN) bias_fixed = buf_load4(rsrcBias, (col_base + 4 * (lane % C4) < g.N) ? (uint32_t)(col_base + 4 * (lane % C4)) * 4u : OOB);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int colb = n0 + wn * WTN + j * 32 + 4 * half;          // this lane's column of register group 0
-        float4 bias_v[4];
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bias_v[q] = buf_load4(rsrcBias, (uint32_t)(colb + 8 * q) * 4u);
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const long row = m0 + wm * WTM + i * 32 + l31;
-            float4 res[4], gsrc[4];
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(slab + l31 * EP_LD + j * 32 + 8 * q + 4 * half) =
+                    make_float4(acc[i][j][4 * q] * out_scale, acc[i][j][4 * q + 1] * out_scale,
+                                acc[i][j][4 * q + 2] * out_scale, acc[i][j][4 * q + 3] * out_scale);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const long row_base = m0 + wm * WTM + i * 32;
+        // the slab leaves in groups of GR float4 per lane: the auxiliary operands of a group are all requested before its
+        // first store (a bias-only epilogue has none and issues its stores back to back)
+        constexpr int GR = (NIT % 4 == 0) ? 4 : NIT;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = colb + 8 * q;
-                const bool col_ok = col < g.N;
-                res[q] = has_res ? buf_load4(rsrcR, col_ok ? (uint32_t)((row * g.ldr + col) * 4) : OOB) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (has_gate) gsrc[q] = buf_load4(rsrcG, col_ok ? (uint32_t)((row * g.ldc + col) * 4) : OOB);
+        for (int g0 = 0; g0 < NIT; g0 += GR) {
+            float4 r4[GR], g4[GR];
+#pragma unroll
+            for (int u = 0; u < GR; ++u) {
+                const int idx = (g0 + u) * 64 + lane;
+                const int r = idx / C4, c4 = idx - r * C4;
+                const long row = row_base + r;
+                const int col = col_base + 4 * c4;
+                const bool ok = (EVEN || idx < 32 * C4) && row < g.M && col < g.N;
+                r4[u] = has_res ? buf_load4(rsrcR, ok ? (uint32_t)((row * g.ldr + col) * 4) : OOB) : make_float4(0.f, 0.f, 0.f, 0.f);
+                g4[u] = has_gate ? buf_load4(rsrcG, ok ? (uint32_t)((row * g.ldc + col) * 4) : OOB) : make_float4(1.f, 1.f, 1.f, 1.f);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = colb + 8 * q;
-                float v[4] = {acc[i][j][4 * q] * out_scale + bias_v[q].x, acc[i][j][4 * q + 1] * out_scale + bias_v[q].y,
-                              acc[i][j][4 * q + 2] * out_scale + bias_v[q].z, acc[i][j][4 * q + 3] * out_scale + bias_v[q].w};
-                const float rr[4] = {res[q].x, res[q].y, res[q].z, res[q].w};
-                const float gg[4] = {has_gate ? gsrc[q].x : 1.f, has_gate ? gsrc[q].y : 1.f, has_gate ? gsrc[q].z : 1.f,
-                                     has_gate ? gsrc[q].w : 1.f};
+            for (int u = 0; u < GR; ++u) {
+                const int idx = (g0 + u) * 64 + lane;
+                const int r = idx / C4, c4 = idx - r * C4;
+                const bool in_slab = EVEN || idx < 32 * C4;
+                const long row = row_base + r;
+                const int col = col_base + 4 * c4;
+                const bool ok = in_slab && row < g.M && col < g.N;
+                const float4 a4 = *reinterpret_cast<const float4*>(slab + (in_slab ? r : 0) * EP_LD + 4 * (in_slab ? c4 : 0));
+                const float4 b4 = EVEN ? bias_fixed : buf_load4(rsrcBias, ok ? (uint32_t)col * 4u : OOB);
+                float v[4] = {a4.x + b4.x, a4.y + b4.y, a4.z + b4.z, a4.w + b4.w};
+                const float rr[4] = {r4[u].x, r4[u].y, r4[u].z, r4[u].w};
+                const float gg[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
                 uint32_t h01 = 0, h23 = 0;
                 if (do_drop) {                       // elements 2i, 2i+1 share a hash (keep_elem): two hashes per float4
-                    const uint64_t idx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
-                    h01 = hash_pair(seed_eff, (uint32_t)(idx >> 1), (uint32_t)(idx >> 33));
-                    h23 = hash_pair(seed_eff, (uint32_t)((idx + 2) >> 1), (uint32_t)((idx + 2) >> 33));
+                    const uint64_t eidx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
+                    h01 = hash_pair(seed_eff, (uint32_t)(eidx >> 1), (uint32_t)(eidx >> 33));
+                    h23 = hash_pair(seed_eff, (uint32_t)((eidx + 2) >> 1), (uint32_t)((eidx + 2) >> 33));
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -316,15 +353,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
                     if (has_gate) v[e] = gg[e] > 0.f ? v[e] * g.relu_scale : 0.f;
                     v[e] += rr[e];
                 }
-                if (row < g.M && col < g.N) *reinterpret_cast<float4*>(C + row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                if (ok) *reinterpret_cast<float4*>(C + row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    __syncthreads();        // the slabs alias the staging buffers the next tile's prologue writes
+    }   // persistent tile loop
 }
 
 template <int BM, int BN, int WM, int WN>
 static int launch_h3(const GemmArgs& g, hipStream_t stream) {
-    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), 1);
+    // persistent grid: one workgroup per CU for the 8-wave tiles (128 KB / 96 KB of LDS), two for the 4-wave ones
+    static int persist = -1;                      // development aid: TTTS_H3_PERSIST=0 launches one workgroup per tile
+    if (persist < 0) { const char* e = getenv("TTTS_H3_PERSIST"); persist = e ? atoi(e) : 1; }
+    const long ntiles = (long)cdiv(g.N, BN) * cdiv(g.M, BM);
+    const long cap = persist ? 256L * (WM * WN == 8 ? 1 : 2) : ntiles;
+    dim3 grid((unsigned)(ntiles < cap ? ntiles : cap), 1, 1);
     if (g.T > 0)
         hipLaunchKernelGGL((gemm_h3_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, stream, g);
     else
