@@ -112,10 +112,15 @@ int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias
 /* fp16x3 data gradients.  A gradient's magnitude is not known in advance (1e-7 .. 1e-5 behind a mean-reduced loss), so
  * its pre-scale is dynamic: ttts_amax_partials writes 1024 partial maxima of |dy| (one read of dy, no atomics, no host
  * round trip) and the GEMM scales dy by the power of two that puts max|dy| in [2^11, 2^12) -- full 22-bit precision for
- * every element within 2^-15 of the largest, absolute error 2^-29 * 2^-11 * max|dy| below that.  planes: modes 5 / 7. */
+ * every element within 2^-15 of the largest, absolute error 2^-29 * 2^-11 * max|dy| below that.  planes: modes 5 / 7.
+ * A kernel that PRODUCES a gradient another fp16x3 GEMM consumes can emit these maxima itself and save the pass: the
+ * `*_amax_out` / `*_amax_partials` arguments (NULL, or 1024 floats) of ttts_linear_bwd_data_h3, ttts_attention_bwd_h3,
+ * ttts_bn_bwd, ttts_dropout_bwd and ttts_relu_dropout_bwd.  Arrays named `*_amax_out` are filled with slot-wise atomic
+ * maxima and must be zeroed by the caller first (ttts_zero); `*_amax_partials` are fully written. */
 int ttts_amax_partials(const float* x, int64_t n, float* partials /* 1024 floats */, void* stream);
 int ttts_linear_bwd_data_h3(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
-                            int K, const float* relu_out, float relu_scale, const float* dy_amax, void* stream);
+                            int K, const float* relu_out, float relu_scale, const float* dy_amax, float* dx_amax_out,
+                            void* stream);
 int ttts_conv1d_bwd_data_h3(const float* dy, const void* planes_bwd, float* dx, int B, int T, int cin, int cout, int taps,
                             const float* dy_amax, void* stream);
 int ttts_linear_bwd_data_x6(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
@@ -169,7 +174,8 @@ int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, co
 /* train-mode backward through drop/act/BN: dx, dgamma, dbeta from dz and the saved x, mean, invstd */
 int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float* invstd, const float* gamma,
                 const float* beta, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int C,
-                int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate, void* stream);
+                int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate, float* dx_amax_partials,
+                void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm over the last dim (d % 64 == 0, d <= 1024)
  * Replaces nn.LayerNorm norm1/2/3 of the encoder/decoder layers (torch/nn/modules/transformer.py:951-956,
@@ -220,7 +226,7 @@ int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const 
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
-                          void* stream);
+                          float* dq_amax_out, float* dkv_amax_out, void* stream);
 
 /* ------------------------------------------------------------------ small row / element-wise pieces
  * nn.Embedding gather / scatter-add (model/model.py:168,288; no padding_idx) */

@@ -122,17 +122,19 @@ def test_fp16x3_data_gradient_with_dynamic_scale(M, N, K, mag):
     dx = torch.empty(M, K, device=_dev())
     am = ops._amax(dy)
     assert abs(am.max().item() - dy.abs().max().item()) == 0.0
-    assert lib.ttts_linear_bwd_data_h3(_p(dy), _p(plt), None, _p(dx), M, N, K, None, 1.0, _p(am), _stream()) == 0
+    slots = torch.zeros(1024, device=_dev())
+    assert lib.ttts_linear_bwd_data_h3(_p(dy), _p(plt), None, _p(dx), M, N, K, None, 1.0, _p(am), _p(slots), _stream()) == 0
+    assert slots.max().item() == dx.abs().max().item()          # the epilogue's own maxima of dx (slot-wise atomic max)
     ref = dy.double() @ w.double()
     assert _rel(dx, ref) < TOL, _rel(dx, ref)
     small = torch.ones(M, dtype=torch.bool); small[5] = False                  # the small rows on their own, not drowned by row 5
     assert _rel(dx[small.to(_dev())], ref[small.to(_dev())]) < TOL
     hfwd = torch.relu(_rand(M, K, seed=5))
     res = _rand(M, K, seed=7) * mag
-    assert lib.ttts_linear_bwd_data_h3(_p(dy), _p(plt), _p(res), _p(dx), M, N, K, _p(hfwd), 1.25, _p(am), _stream()) == 0
+    assert lib.ttts_linear_bwd_data_h3(_p(dy), _p(plt), _p(res), _p(dx), M, N, K, _p(hfwd), 1.25, _p(am), None, _stream()) == 0
     assert _rel(dx, ref * (hfwd > 0).double() * 1.25 + res.double()) < TOL
     zero = torch.zeros_like(dy)
-    assert lib.ttts_linear_bwd_data_h3(_p(zero), _p(plt), None, _p(dx), M, N, K, None, 1.0, _p(ops._amax(zero)), _stream()) == 0
+    assert lib.ttts_linear_bwd_data_h3(_p(zero), _p(plt), None, _p(dx), M, N, K, None, 1.0, _p(ops._amax(zero)), None, _stream()) == 0
     assert float(dx.abs().max()) == 0.0
 
 
@@ -382,7 +384,12 @@ def test_fp16x3_attention_backward(causal, Tq, Tk, lens, mag, grow):
         dq, dkv, delta = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(lse)
         args = (_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(kl),
                 B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, p_drop, 99, None)
-        assert (bwd(*args, _p(ops._amax(do)), _stream()) if h3 else bwd(*args, _stream())) == 0
+        if h3:
+            sq, sk = torch.zeros(1024, device=_dev()), torch.zeros(1024, device=_dev())
+            assert bwd(*args, _p(ops._amax(do)), _p(sq), _p(sk), _stream()) == 0
+            assert sq.max().item() == dq.abs().max().item() and sk.max().item() == dkv.abs().max().item()
+        else:
+            assert bwd(*args, _stream()) == 0
         return dq, dkv
     dq, dkv = run(lib.ttts_attention_fwd_h3, lib.ttts_attention_bwd_h3, 0.0, True)
     assert _rel(dq, dq_ref) < TOL, _rel(dq, dq_ref)

@@ -60,6 +60,7 @@ struct AttnArgs {
     int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
     float drop_scale; uint32_t thr; uint64_t seed; const uint64_t* step_seed;
     const float* do_amax; int do_amax_n;      // fp16x3 backward: partial maxima of |dout| (ttts_amax_partials)
+    float* amax_dq; float* amax_dkv;          // fp16x3 backward: NULL, or caller-zeroed 1024-slot arrays receiving max|dq| / max|dk, dv|
 };
 
 // ---- cooperative staging (256 threads): KB rows x 64 floats from global straight into LDS; rows beyond
@@ -1796,8 +1797,13 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
     __syncthreads();
     {
         const float fin = (sds > 0.f) ? 0.125f / (H3A_K * sds) : 0.f;      // accumulator units -> dQ (incl. the 1/8 of q / 8)
+        float mx = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dq[0][r] *= fin; dq[1][r] *= fin; }
+        for (int r = 0; r < 16; ++r) {
+            dq[0][r] *= fin; dq[1][r] *= fin;
+            mx = fmaxf(mx, fmaxf(fabsf(dq[0][r]), fabsf(dq[1][r])));
+        }
+        if (a.amax_dq != nullptr) amax_publish(qg < a.Tq ? mx : 0.f, a.amax_dq, blockIdx.y * gridDim.x + blockIdx.x);
     }
     wave_store_rows(dq, scratch, a.dq + (long)b * a.Tq * a.lddq + h * HD, qw0, a.Tq, a.lddq, lane, 1.f);
 }
@@ -1996,8 +2002,13 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
     {
         const float fk = (sds > 0.f) ? 1.f / (H3A_Q * sds) : 0.f;        // dk accumulator: (Q / 8 * 2^4)^T (dS * sds)
         const float fv = inv_g / H3A_P;                                   // dv accumulator: (dO * s_g)^T (P * 2^10)
+        float mx = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[0][r] *= fk; dk[1][r] *= fk; dv[0][r] *= fv; dv[1][r] *= fv; }
+        for (int r = 0; r < 16; ++r) {
+            dk[0][r] *= fk; dk[1][r] *= fk; dv[0][r] *= fv; dv[1][r] *= fv;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(dk[0][r]), fabsf(dk[1][r]))), fmaxf(fabsf(dv[0][r]), fabsf(dv[1][r])));
+        }
+        if (a.amax_dkv != nullptr) amax_publish(kg < a.Tk ? mx : 0.f, a.amax_dkv, blockIdx.y * gridDim.x + blockIdx.x);
     }
     wave_store_rows(dk, scratch, a.dk + (long)b * a.Tk * a.lddk + h * HD, kw0, a.Tk, a.lddk, lane, 1.f);
     wave_store_rows(dv, scratch, a.dv + (long)b * a.Tk * a.lddv + h * HD, kw0, a.Tk, a.lddv, lane, 1.f);
@@ -2133,7 +2144,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
                               const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                               int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                               int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, int form, void* stream_,
-                              const float* do_amax = nullptr) {
+                              const float* do_amax = nullptr, float* dq_amax_out = nullptr, float* dkv_amax_out = nullptr) {
     // form: 0 = fp32 MFMA, 1 = bf16x6, 2 = fp16x3 (needs do_amax)
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(q && k && v && o && do_ && lse && delta && dq && dk && dv && key_lens, "attention_bwd: null pointer");
@@ -2155,6 +2166,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
     dim3 gq(B * H, cdiv(Tq, QB), 1), gk(B * H, cdiv(Tk, QB), 1);
     if (form == 2) {
         a.do_amax = do_amax; a.do_amax_n = 1024;
+        a.amax_dq = dq_amax_out; a.amax_dkv = dkv_amax_out;
         return causal ? launch_bwd_h3<true>(a, gq, gk, stream) : launch_bwd_h3<false>(a, gq, gk, stream);
     }
     if (form == 1) return causal ? launch_bwd_x6<true>(a, gq, gk, stream) : launch_bwd_x6<false>(a, gq, gk, stream);
@@ -2189,9 +2201,9 @@ int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const 
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
-                          void* stream) {
+                          float* dq_amax_out, float* dkv_amax_out, void* stream) {
     return attention_bwd_impl(q, k, v, o, d_o, lse, delta, dq, dk, dv, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk,
-                              lddv, causal, drop_p, seed, step_seed, 2, stream, do_amax);
+                              lddv, causal, drop_p, seed, step_seed, 2, stream, do_amax, dq_amax_out, dkv_amax_out);
 }
 
 }  // extern "C"

@@ -934,7 +934,7 @@ static GemmArgs base_args() {
     g.bias = nullptr; g.act = 0; g.drop_scale = 1.f; g.drop_thr = 0; g.seed = 0; g.step_seed = nullptr;
     g.residual = nullptr; g.ldr = 0; g.colsum = nullptr; g.a_bytes = 0; g.b_bytes = 0;
     g.relu_out = nullptr; g.relu_scale = 1.f;
-    g.a_amax = nullptr; g.a_amax_n = 0;
+    g.a_amax = nullptr; g.a_amax_n = 0; g.c_amax = nullptr;
     return g;
 }
 
@@ -1269,7 +1269,8 @@ int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias
 }
 
 int ttts_linear_bwd_data_h3(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
-                            int K, const float* relu_out, float relu_scale, const float* dy_amax, void* stream) {
+                            int K, const float* relu_out, float relu_scale, const float* dy_amax, float* dx_amax_out,
+                            void* stream) {
     // dx[M,K] = dy[M,N] . w[N,K] (+ residual) in the fp16x3 form; wt_planes = weight_split mode 5 (w^T as [K][N] rows);
     // dy_amax = the partial maxima of |dy| written by ttts_amax_partials (the dynamic pre-scale of the gradient operand)
     TTTS_REQUIRE(dy && wt_planes && dx && dy_amax, "linear_bwd_data_h3: null pointer");
@@ -1284,6 +1285,7 @@ int ttts_linear_bwd_data_h3(const float* dy, const void* wt_planes, const float*
     g.residual = residual; g.ldr = K;
     g.relu_out = relu_out; g.relu_scale = relu_scale;
     g.a_amax = dy_amax; g.a_amax_n = H3_AMAX_PARTIALS;
+    g.c_amax = dx_amax_out;
     return dispatch_h3(g, (hipStream_t)stream);
 }
 

@@ -41,6 +41,9 @@ struct GemmArgs {
     // reduces them and pre-scales A by the power of two that puts max|A| in [2^11, 2^12).
     const float* a_amax;
     int a_amax_n;
+    // fp16x3 kernel: NULL, or a caller-zeroed 1024-slot array that receives max|C| (amax_publish): the output is a
+    // gradient that another fp16x3 GEMM will consume
+    float* c_amax;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

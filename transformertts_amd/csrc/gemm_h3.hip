@@ -296,6 +296,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
     // without waiting for those stores to complete.  The bias of a lane's (fixed) column group is therefore read once per
     // tile, so that a bias-only epilogue (in-projections, FFN1, convolutions) issues its stores back to back; residual /
     // gate operands are requested per slab, all of them before the slab's first store.
+    float cmax = 0.f;                 // max|C| of what this lane stores (published when g.c_amax is set)
     float4 bias_fixed = make_float4(0.f, 0.f, 0.f, 0.f);
     if (EVEN) bias_fixed = buf_load4(rsrcBias, (col_base + 4 * (lane % C4) < g.N) ? (uint32_t)(col_base + 4 * (lane % C4)) * 4u : OOB);
 #pragma unroll
@@ -353,13 +354,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
                     if (has_gate) v[e] = gg[e] > 0.f ? v[e] * g.relu_scale : 0.f;
                     v[e] += rr[e];
                 }
-                if (ok) *reinterpret_cast<float4*>(C + row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                if (ok) {
+                    *reinterpret_cast<float4*>(C + row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    if (g.c_amax != nullptr) amax_publish(cmax, g.c_amax, bid);
     __syncthreads();        // the slabs alias the staging buffers the next tile's prologue writes
     }   // persistent tile loop
 }
@@ -396,7 +401,7 @@ int h3_tile_choice(long M, long N) {
     // (a 256-wide tile is one workgroup per CU at a time, the 128-wide ones two)
     struct Cand { int tile, bm, bn, per_cu; float eff; };
     const Cand cands[] = {{H3_TILE_256, 256, 256, 1, 1.25f}, {H3_TILE_256x128, 256, 128, 1, 1.05f},
-                          {TILE_128, 128, 128, 2, 1.00f}, {TILE_64x128, 64, 128, 2, 0.75f}};
+                          {TILE_128, 128, 128, 2, 1.00f}, {TILE_64x128, 64, 128, 2, 0.75f}, {TILE_64, 64, 64, 2, 0.55f}};
     int best = TILE_128;
     float best_cost = 1e30f;
     for (const Cand& c : cands) {
@@ -413,6 +418,7 @@ int dispatch_h3(const GemmArgs& g, hipStream_t stream) {
         case H3_TILE_256: return launch_h3<256, 256, 2, 4>(g, stream);
         case H3_TILE_256x128: return launch_h3<256, 128, 4, 2>(g, stream);
         case TILE_64x128: return launch_h3<64, 128, 2, 2>(g, stream);
+        case TILE_64: return launch_h3<64, 64, 2, 2>(g, stream);
         case TILE_128x96: return launch_h3<128, 96, 4, 1>(g, stream);
         default: return launch_h3<128, 128, 2, 2>(g, stream);
     }

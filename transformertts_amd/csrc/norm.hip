@@ -294,8 +294,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ sums, float* __restrict__ dx, long n4,
                                                            int C, float inv_m, int act, float drop_scale, uint32_t thr,
-                                                           uint64_t seed, const uint64_t* step_seed) {
+                                                           uint64_t seed, const uint64_t* step_seed, float* __restrict__ amax) {
     seed = site_seed(seed, step_seed);
+    float mx = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long e = i * 4;
         const int c = (int)(e % C);
@@ -312,6 +313,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             o[j] = ga * is * (g - sums[c + j] * inv_m - xh * sums[C + c + j] * inv_m);
         }
         *reinterpret_cast<float4*>(dx + e) = make_float4(o[0], o[1], o[2], o[3]);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    }
+    if (amax != nullptr) {           // partial maxima of |dx|, one per block (the launch then has exactly 1024 blocks)
+        __shared__ float red[4];
+        mx = wave_max(mx);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     }
 }
 
@@ -418,7 +427,7 @@ int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, co
 int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float* invstd, const float* gamma,
                 const float* beta, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int C,
                 int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate,
-                void* stream_) {
+                float* dx_amax_partials, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dz && x && mean && invstd && gamma && beta && dx && ws, "bn_bwd: null pointer");
     TTTS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd: C=%d must be a multiple of 4", C);
@@ -438,8 +447,9 @@ int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float*
     long n4 = (long)M * C / 4;
     int grid = (int)((n4 + 255) / 256);
     if (grid > 4096) grid = 4096;
+    if (dx_amax_partials) grid = 1024;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, dz, x, mean, invstd, gamma, beta, sums, dx, n4,
-                       C, 1.0f / (float)M, act, scale, thr, seed, step_seed);
+                       C, 1.0f / (float)M, act, scale, thr, seed, step_seed, dx_amax_partials);
     TTTS_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return TTTS_OK;
 }

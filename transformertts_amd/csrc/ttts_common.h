@@ -82,6 +82,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Publish a wave's max|value| of a gradient tensor it has just written: slot-wise atomic max on the float's bit pattern
+// (non-negative floats order like unsigned integers, so the result does not depend on arrival order).  `slots` is a
+// caller-zeroed array of 1024 floats -- the partial-maxima array the fp16x3 gradient GEMMs take as `dy_amax`.
+__device__ __forceinline__ void amax_publish(float m, float* __restrict__ slots, int slot) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(slots) + (slot & 1023), __float_as_uint(m));
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -148,26 +148,48 @@ def _bwd_h3(K: int, N: int, channels: int = 0) -> bool:
 
 
 def _amax(t: torch.Tensor) -> torch.Tensor:
-    """1024 partial maxima of |t| (device), the dynamic pre-scale input of the fp16x3 gradient GEMMs."""
+    """1024 partial maxima of |t| (device), the dynamic pre-scale input of the fp16x3 gradient GEMMs: the array the kernel
+    that produced `t` left on it (`_ttts_amax`, see _amax_slots), or a separate pass over `t`."""
+    ready = getattr(t, "_ttts_amax", None)
+    if ready is not None:
+        return ready
     out = torch.empty(1024, dtype=torch.float32, device=t.device)
     _lib.check(_lib.load().ttts_amax_partials(_p(t), t.numel(), _p(out), _stream()), "ttts_amax_partials")
     return out
 
 
-def _attn_bwd(lib, do, *args):
-    """Attention backward in the configured form; `args` = every C-ABI argument up to step_seed."""
+def _amax_slots(device, zero: bool) -> torch.Tensor:
+    """A 1024-float array for a gradient-producing kernel to leave the partial maxima of its output in (attached to that
+    output as `_ttts_amax`; a tensor attribute survives the hop to the next autograd Function, and when it does not the
+    consumer simply runs the separate pass).  `zero`: the producer fills it with atomic maxima."""
+    a = torch.empty(1024, dtype=torch.float32, device=device)
+    if zero:
+        _lib.check(_lib.load().ttts_zero(_p(a), 4096, _stream()), "ttts_zero")
+    return a
+
+
+def _wgrad_is_split(N: int, K: int) -> bool:
+    """Mirror of wgrad_use_x6 (csrc/gemm.hip): shapes the split-precision weight-gradient kernels take (the others run on
+    the fp32-MFMA kernel and need no maxima)."""
+    return (N >= 128 or N in (80, 96)) and (K >= 128 or K in (80, 96)) and (N >= 128 or K >= 128)
+
+
+def _attn_bwd(lib, do, dq_am, dkv_am, *args):
+    """Attention backward in the configured form; `args` = every C-ABI argument up to step_seed.  dq_am / dkv_am: zeroed
+    1024-slot arrays in which the fp16x3 kernels leave max|dq| / max|dk, dv| (the in-projection gradients consume them)."""
     if ATTN_BWD_MODE == "h3":
-        return lib.ttts_attention_bwd_h3(*args, _p(_amax(do)), _stream())
+        return lib.ttts_attention_bwd_h3(*args, _p(_amax(do)), _p(dq_am), _p(dkv_am), _stream())
     return (lib.ttts_attention_bwd_x6 if ATTN_BWD_MODE == "x6" else lib.ttts_attention_bwd)(*args, _stream())
 
 
-def _wgrad(lib, name: str, dy: torch.Tensor, amax, *args):
+def _wgrad(lib, name: str, dy: torch.Tensor, amax, split_ok: bool, *args):
     """Weight-gradient entry point `name` in the configured form; `args` = everything after (dy ...) up to `accumulate`.
-    The fp16x3 form takes the partial maxima of |dy| (computed here unless the caller already has them)."""
-    if WGRAD_MODE == "h3":
+    The fp16x3 form takes the partial maxima of |dy| (computed here unless the caller already has them); shapes the split
+    kernels do not take (`split_ok` False) run on the fp32-MFMA kernel behind the _x6 entry point and need none."""
+    if WGRAD_MODE == "h3" and split_ok:
         am = amax if amax is not None else _amax(dy)
         return getattr(lib, name + "_h3")(_p(dy), *args, _p(am), _stream())
-    return getattr(lib, name + ("_x6" if WGRAD_MODE == "x6" else ""))(_p(dy), *args, _stream())
+    return getattr(lib, name + ("_x6" if WGRAD_MODE in ("x6", "h3") else ""))(_p(dy), *args, _stream())
 
 
 _param_epoch = 0
@@ -355,7 +377,8 @@ class LinearFn(torch.autograd.Function):
         dy = _chk(dy, "linear.dy")
         # partial maxima of |dacc| (dynamic pre-scale of the fp16x3 data / weight gradients): emitted by the mask kernel
         # that produces dacc when there is one, by a separate pass otherwise
-        want_am = (ctx.needs_input_grad[0] and _bwd_h3(N, K)) or (ctx.needs_input_grad[1] and WGRAD_MODE == "h3")
+        want_am = (ctx.needs_input_grad[0] and _bwd_h3(N, K)) or \
+                  (ctx.needs_input_grad[1] and WGRAD_MODE == "h3" and _wgrad_is_split(N, K))
         am = None
         if act == ACT_RELU and tok_out is not None and tok_out.premasked:
             dacc = dy                    # the consumer's data-gradient epilogue already applied the relu / dropout mask
@@ -385,8 +408,13 @@ class LinearFn(torch.autograd.Function):
                     raise RuntimeError("linear: skip-connection gradient does not match the block input")
             if _bwd_h3(N, K):
                 am = am if am is not None else _amax(dacc)
+                # dx with the producer's relu mask applied here is exactly the `dacc` of that producer's backward: leave its
+                # maxima on it
+                dx_am = _amax_slots(dx.device, True) if tok_in is not None else None
                 _lib.check(lib.ttts_linear_bwd_data_h3(_p(dacc), _p(_planes(w, 5, K, N)), _p(skip), _p(dx), M, N, K,
-                                                       _p(gate), gscale, _p(am), _stream()), "ttts_linear_bwd_data_h3")
+                                                       _p(gate), gscale, _p(am), _p(dx_am), _stream()), "ttts_linear_bwd_data_h3")
+                if dx_am is not None:
+                    dx._ttts_amax = dx_am
             elif GEMM_MODE == "x6":
                 _lib.check(lib.ttts_linear_bwd_data_x6(_p(dacc), _p(_planes(w, 1, K, N)), _p(skip), _p(dx), M, N, K,
                                                        _p(gate), gscale, _stream()), "ttts_linear_bwd_data_x6")
@@ -404,8 +432,8 @@ class LinearFn(torch.autograd.Function):
             else:
                 dw_t = dw = torch.empty_like(w)
                 db_t = db = torch.empty(N, dtype=torch.float32, device=x.device) if has_b else None
-            _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dacc, am, _p(x), _p(dw_t), _p(db_t), _p(ws), ws.numel() * 4,
-                              M, N, K, row_shift, T, acc), "ttts_linear_bwd_weight")
+            _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dacc, am, _wgrad_is_split(N, K), _p(x), _p(dw_t), _p(db_t), _p(ws),
+                              ws.numel() * 4, M, N, K, row_shift, T, acc), "ttts_linear_bwd_weight")
         dres = dy if has_r else None
         if has_r and skip_out is not None:      # hand the skip gradient to the block's first Linear instead of autograd
             skip_out.grad, dres = dy, None
@@ -510,8 +538,8 @@ class HeadsFn(torch.autograd.Function):
             t_bm = db_mel = torch.empty(N, dtype=torch.float32, device=x.device)
             t_ws = dw_stop = torch.empty_like(w_stop)
             t_bs = db_stop = torch.empty(1, dtype=torch.float32, device=x.device)
-        _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dmel, None, _p(x), _p(t_wm), _p(t_bm), _p(ws), ws.numel() * 4, M, N,
-                          K, 0, 0, acc), "ttts_linear_bwd_weight")
+        _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dmel, None, _wgrad_is_split(N, K), _p(x), _p(t_wm), _p(t_bm), _p(ws),
+                          ws.numel() * 4, M, N, K, 0, 0, acc), "ttts_linear_bwd_weight")
         ws2 = _ws(lib.ttts_rowdot_bwd_workspace_bytes(K), x.device)
         _lib.check(lib.ttts_rowdot_bwd(_p(dstop), _p(x), _p(w_stop), _p(dx), _p(t_ws), _p(t_bs), _p(ws2),
                                        ws2.numel() * 4, M, K, acc, _stream()), "ttts_rowdot_bwd")
@@ -589,14 +617,17 @@ class ConvBNFn(torch.autograd.Function):
             t_g = dgamma = torch.empty_like(gamma)
             t_be = dbeta = torch.empty_like(beta)
         ws = _ws(lib.ttts_bn_workspace_bytes(M, cout), dev)
+        # the BatchNorm backward writes dy, the gradient both conv GEMMs below consume: it leaves dy's partial maxima too
+        want_am = (ctx.needs_input_grad[0] and _bwd_h3(taps * cout, cin, cout)) or \
+                  (WGRAD_MODE == "h3" and _wgrad_is_split(cout, cin))
+        am = _amax_slots(dev, False) if want_am else None
         _lib.check(lib.ttts_bn_bwd(_p(dz), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(t_g), _p(t_be),
-                                   _p(ws), ws.numel() * 4, M, cout, act, drop_p, seed, ctx.ss, acc, _stream()), "ttts_bn_bwd")
+                                   _p(ws), ws.numel() * 4, M, cout, act, drop_p, seed, ctx.ss, acc, _p(am), _stream()),
+                   "ttts_bn_bwd")
         dx = None
-        am = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if _bwd_h3(taps * cout, cin, cout):
-                am = _amax(dy)
                 _lib.check(lib.ttts_conv1d_bwd_data_h3(_p(dy), _p(_planes(conv_w, 7, cin, taps * cout, cout, taps)), _p(dx),
                                                        B, T, cin, cout, taps, _p(am), _stream()), "ttts_conv1d_bwd_data_h3")
             elif GEMM_MODE == "x6":
@@ -609,8 +640,8 @@ class ConvBNFn(torch.autograd.Function):
                 _lib.check(lib.ttts_conv1d_bwd_data(_p(dy), _p(w_bwd), _p(dx), B, T, cin, cout, taps, _stream()),
                            "ttts_conv1d_bwd_data")
         ws2 = _ws(lib.ttts_wgrad_workspace_bytes(M, cout, cin, taps), dev)
-        _lib.check(_wgrad(lib, "ttts_conv1d_bwd_weight", dy, am, _p(x), _p(t_w), _p(t_b), _p(ws2), ws2.numel() * 4, B, T,
-                          cin, cout, taps, acc), "ttts_conv1d_bwd_weight")
+        _lib.check(_wgrad(lib, "ttts_conv1d_bwd_weight", dy, am, _wgrad_is_split(cout, cin), _p(x), _p(t_w), _p(t_b), _p(ws2),
+                          ws2.numel() * 4, B, T, cin, cout, taps, acc), "ttts_conv1d_bwd_weight")
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
@@ -707,9 +738,12 @@ class SelfAttentionFn(torch.autograd.Function):
         do = _chk(do, "self_attention.do")
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
-        _lib.check(_attn_bwd(lib, do, _off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta),
+        am = _amax_slots(qkv.device, True) if ATTN_BWD_MODE == "h3" else None     # max|dqkv| for the in-projection gradients
+        _lib.check(_attn_bwd(lib, do, am, am, _off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta),
                              _off(dqkv, 0), _off(dqkv, d), _off(dqkv, 2 * d), _p(lens), B, n_head, T, T, d3,
                              d3, d3, d, d3, d3, d3, 1 if causal else 0, drop_p, seed, ctx.ss), "ttts_attention_bwd")
+        if am is not None:
+            dqkv._ttts_amax = am
         return dqkv, None, None, None, None, None
 
 
@@ -746,9 +780,14 @@ class CrossAttentionFn(torch.autograd.Function):
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         delta = torch.empty_like(lse)
-        _lib.check(_attn_bwd(lib, do, _off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
+        am_q = am_kv = None
+        if ATTN_BWD_MODE == "h3":
+            am_q, am_kv = _amax_slots(q.device, True), _amax_slots(q.device, True)
+        _lib.check(_attn_bwd(lib, do, am_q, am_kv, _off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
                              _off(dq, 0), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk, d, 2 * d,
                              2 * d, d, d, 2 * d, 2 * d, 0, drop_p, seed, ctx.ss), "ttts_attention_bwd")
+        if am_q is not None:
+            dq._ttts_amax, dkv._ttts_amax = am_q, am_kv
         return dq, dkv, None, None, None, None, None
 
 
