@@ -158,10 +158,54 @@ def _amax(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class _AmaxArena:
+    """Per-device pool of 1024-float partial-maxima arrays that ONE memset zeroes for a whole backward pass.  ~20 kernels
+    of a backward pass fill such an array with atomic maxima and each would otherwise need a memset of its own."""
+    SLICES = 64
+
+    def __init__(self, device):
+        self.buf = torch.empty(self.SLICES, 1024, dtype=torch.float32, device=device)
+        self.next = 0
+        self.clean = False          # True between reset() and release(): unissued slices are known to be zero
+
+    def reset(self) -> None:
+        _lib.check(_lib.load().ttts_zero(_p(self.buf), self.buf.numel() * 4, _stream()), "ttts_zero")
+        self.next, self.clean = 0, True
+
+    def take(self):
+        if not self.clean or self.next >= self.SLICES:
+            return None
+        self.next += 1
+        return self.buf[self.next - 1]
+
+
+_amax_arenas = {}
+
+
+def amax_arena_reset(device) -> None:
+    """Call once per step in front of backward (step.TrainStep does)."""
+    arena = _amax_arenas.get(device)
+    if arena is None:
+        arena = _amax_arenas[device] = _AmaxArena(device)
+    arena.reset()
+
+
+def amax_arena_release(device) -> None:
+    """After backward: arrays handed out from here on are zeroed individually again."""
+    arena = _amax_arenas.get(device)
+    if arena is not None:
+        arena.clean = False
+
+
 def _amax_slots(device, zero: bool) -> torch.Tensor:
     """A 1024-float array for a gradient-producing kernel to leave the partial maxima of its output in (attached to that
     output as `_ttts_amax`; a tensor attribute survives the hop to the next autograd Function, and when it does not the
     consumer simply runs the separate pass).  `zero`: the producer fills it with atomic maxima."""
+    if zero:
+        arena = _amax_arenas.get(device)
+        got = arena.take() if arena is not None else None
+        if got is not None:
+            return got
     a = torch.empty(1024, dtype=torch.float32, device=device)
     if zero:
         _lib.check(_lib.load().ttts_zero(_p(a), 4096, _stream()), "ttts_zero")

@@ -90,7 +90,10 @@ class TrainStep:
         ops.seeds.counter = 0                # site seeds are numbered per step; the step's seed word makes them fresh
         self.opt.zero_grad()
         loss = self.lm.training_step(self.batch, self.index)
+        dev = self.bucket.flat.device
+        ops.amax_arena_reset(dev)            # one memset for all partial-maxima arrays of this backward pass
         loss.backward(gradient=self._one)    # a resident 1.0 instead of autograd's ones_like fill kernel
+        ops.amax_arena_release(dev)
         return loss
 
     def _reduce_and_update(self) -> None:
