@@ -46,6 +46,59 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
+// d = 256 * NV: a lane owns NV float4 (16-byte accesses, one 1-KB wave instruction per 256 columns) and a wave walks
+// over ROWS consecutive rows with all their loads in flight before the first reduction -- a quarter of the memory
+// instructions and a quarter of the waves of the kernel above (23.8 -> 19.3 us for 55 680 x 256, 5.9 TB/s).
+template <int NV, int ROWS>
+__global__ __launch_bounds__(256) void layernorm_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ y,
+                                                               float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                               long M, float eps) {
+    constexpr int d = 256 * NV;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row0 = ((long)blockIdx.x * 4 + wave) * ROWS;
+    if (row0 >= M) return;
+    float4 v[ROWS][NV];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const long row = (row0 + r < M) ? row0 + r : M - 1;          // tail rows re-read the last row, not stored
+            v[r][k] = reinterpret_cast<const float4*>(x + row * d)[lane + 64 * k];
+        }
+    float4 ga[NV], be[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        ga[k] = reinterpret_cast<const float4*>(gamma)[lane + 64 * k];
+        be[k] = reinterpret_cast<const float4*>(beta)[lane + 64 * k];
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) s += (v[r][k].x + v[r][k].y) + (v[r][k].z + v[r][k].w);
+        const float mean = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const float a = v[r][k].x - mean, b = v[r][k].y - mean, c = v[r][k].z - mean, e = v[r][k].w - mean;
+            q += (a * a + b * b) + (c * c + e * e);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+        if (row0 + r < M) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                reinterpret_cast<float4*>(y + (row0 + r) * d)[lane + 64 * k] =
+                    make_float4((v[r][k].x - mean) * rstd * ga[k].x + be[k].x, (v[r][k].y - mean) * rstd * ga[k].y + be[k].y,
+                                (v[r][k].z - mean) * rstd * ga[k].z + be[k].z, (v[r][k].w - mean) * rstd * ga[k].w + be[k].w);
+            if (lane == 0) {
+                if (mean_out) mean_out[row0 + r] = mean;
+                if (rstd_out) rstd_out[row0 + r] = rstd;
+            }
+        }
+    }
+}
+
 constexpr int LN_BWD_BLOCKS = 256;
 
 // dx per row; per-block partial column sums of dy*xhat (dgamma) and dy (dbeta) -> ws[block][2][d]
@@ -90,6 +143,75 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int i = 0; i < NPER; ++i) {
         red[wave][0][lane + 64 * i] = accg[i];
         red[wave][1][lane + 64 * i] = accb[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * d; c += 256) {
+        int which = c / d, col = c - which * d;
+        float sum = (red[0][which][col] + red[1][which][col]) + (red[2][which][col] + red[3][which][col]);
+        ws[((long)blockIdx.x * 2 + which) * d + col] = sum;
+    }
+}
+
+// d = 256 * NV form of the backward: 16-byte accesses, two rows per wave iteration in flight
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, float* __restrict__ dx,
+                                                               float* __restrict__ ws, long M) {
+    constexpr int d = 256 * NV;
+    __shared__ float red[4][2][d];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 g[NV], accg[NV], accb[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        g[k] = reinterpret_cast<const float4*>(gamma)[lane + 64 * k];
+        accg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        accb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const long stride = (long)gridDim.x * 4;
+    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += 2 * stride) {
+        float4 dv[2][NV], xv[2][NV];
+        float mu[2], rs[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long r = (row + u * stride < M) ? row + u * stride : row;       // second row may not exist: redo the first
+            mu[u] = mean[r]; rs[u] = rstd[r];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                dv[u][k] = reinterpret_cast<const float4*>(dy + r * d)[lane + 64 * k];
+                xv[u][k] = reinterpret_cast<const float4*>(x + r * d)[lane + 64 * k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long r = row + u * stride;
+            if (r >= M) break;
+            float4 xh[NV], gd[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                xh[k] = make_float4((xv[u][k].x - mu[u]) * rs[u], (xv[u][k].y - mu[u]) * rs[u], (xv[u][k].z - mu[u]) * rs[u],
+                                    (xv[u][k].w - mu[u]) * rs[u]);
+                gd[k] = make_float4(dv[u][k].x * g[k].x, dv[u][k].y * g[k].y, dv[u][k].z * g[k].z, dv[u][k].w * g[k].w);
+                s1 += (gd[k].x + gd[k].y) + (gd[k].z + gd[k].w);
+                s2 += (gd[k].x * xh[k].x + gd[k].y * xh[k].y) + (gd[k].z * xh[k].z + gd[k].w * xh[k].w);
+                accg[k].x += dv[u][k].x * xh[k].x; accg[k].y += dv[u][k].y * xh[k].y;
+                accg[k].z += dv[u][k].z * xh[k].z; accg[k].w += dv[u][k].w * xh[k].w;
+                accb[k].x += dv[u][k].x; accb[k].y += dv[u][k].y; accb[k].z += dv[u][k].z; accb[k].w += dv[u][k].w;
+            }
+            s1 = wave_sum(s1) / (float)d;
+            s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                reinterpret_cast<float4*>(dx + r * d)[lane + 64 * k] =
+                    make_float4(rs[u] * (gd[k].x - s1 - xh[k].x * s2), rs[u] * (gd[k].y - s1 - xh[k].y * s2),
+                                rs[u] * (gd[k].z - s1 - xh[k].z * s2), rs[u] * (gd[k].w - s1 - xh[k].w * s2));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        reinterpret_cast<float4*>(&red[wave][0][0])[lane + 64 * k] = accg[k];
+        reinterpret_cast<float4*>(&red[wave][1][0])[lane + 64 * k] = accb[k];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < 2 * d; c += 256) {
@@ -344,8 +466,20 @@ int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
     TTTS_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
     TTTS_REQUIRE(M > 0 && d > 0 && d % 64 == 0 && d <= 64 * LN_MAXPER, "layernorm_fwd: d=%d must be a multiple of 64, <= %d",
                  d, 64 * LN_MAXPER);
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
-                       rstd, (long)M, d, eps);
+    const bool v4 = (d == 256 || d == 512 || d == 1024) &&
+                    ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0;
+    if (v4 && d == 256)
+        hipLaunchKernelGGL((layernorm_fwd_v4_kernel<1, 4>), dim3(cdiv(M, 16)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                           mean, rstd, (long)M, eps);
+    else if (v4 && d == 512)
+        hipLaunchKernelGGL((layernorm_fwd_v4_kernel<2, 2>), dim3(cdiv(M, 8)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                           mean, rstd, (long)M, eps);
+    else if (v4)
+        hipLaunchKernelGGL((layernorm_fwd_v4_kernel<4, 1>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                           mean, rstd, (long)M, eps);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
+                           rstd, (long)M, d, eps);
     TTTS_LAUNCH_CHECK("layernorm_fwd_kernel");
     return TTTS_OK;
 }
@@ -361,6 +495,15 @@ int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const
     TTTS_REQUIRE(ws_bytes >= ttts_layernorm_bwd_workspace_bytes(d), "layernorm_bwd: workspace too small");
     int nblk = LN_BWD_BLOCKS;
     if ((long)nblk * 4 > M) nblk = cdiv(M, 4);
+    const bool v4 = (d == 256 || d == 512 || d == 1024) &&
+                    ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)gamma)) & 15) == 0;
+    if (v4) {
+        if (d == 256) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<1>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M);
+        else if (d == 512) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<2>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M);
+        else hipLaunchKernelGGL((layernorm_bwd_v4_kernel<4>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M);
+        TTTS_LAUNCH_CHECK("layernorm_bwd_v4_kernel");
+        return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate, stream);
+    }
 #define TTTS_LN_BWD(NPER)                                                                                         \
     hipLaunchKernelGGL((layernorm_bwd_kernel<NPER>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, \
                        (long)M)
