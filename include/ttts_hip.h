@@ -249,6 +249,19 @@ int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64
                      float* amax_partials, void* stream);
 /* p[0 .. nbytes) = 0, enqueued as a memset on the stream (the flat gradient bucket at the start of a step) */
 int ttts_zero(void* p, size_t nbytes, void* stream);
+/* ---- deferred second-stage reductions ---------------------------------------------------------------------------
+ * The weight-gradient (linear / conv1d / rowdot) and LayerNorm-backward entry points end in a small reduction of
+ * their split-K or per-block partials into the parameter gradient -- ~90 launches of a few microseconds each per training
+ * step.  Between ttts_reduce_defer_begin() and ttts_reduce_defer_flush() those reductions are queued on the host instead,
+ * and flush runs the whole queue in one launch per 48 entries (same summation order as the immediate form).  The caller
+ * must keep every workspace (`ws`) it passed alive, and must not read the gradients, until the flush has been enqueued
+ * on the same stream.  Process-wide state, guarded by a mutex (autograd runs backward nodes on its own threads).
+ * flush(keep_deferring != 0) runs what is queued and stays in deferred mode (gradients needed mid-pass, e.g. to start a
+ * collective); abort drops the queue and returns to immediate launches (after a failed pass). */
+int ttts_reduce_defer_begin(void);
+int64_t ttts_reduce_defer_pending(void);
+int ttts_reduce_defer_flush(int keep_deferring, void* stream);
+int ttts_reduce_defer_abort(void);
 /* z = x + y */
 int ttts_add(const float* x, const float* y, float* z, int64_t n, void* stream);
 /* ---- input side: device-side padding of a ragged batch --------------------------------------

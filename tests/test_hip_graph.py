@@ -70,3 +70,73 @@ def test_graph_step_accepts_new_batches_of_the_same_shape():
     assert a == b
     with pytest.raises(ValueError, match="shape"):
         ts({k: v[:2] for k, v in mk(3).items()})
+
+
+def test_deferred_reductions_equal_immediate_bitwise(monkeypatch):
+    """The parameter-gradient reductions queued during backward and run as one batched launch at its end
+    (ops._defer / ttts_reduce_defer_*) sum in the same order as the per-parameter launches: identical state after three
+    steps, eager and replayed, and nothing is left queued."""
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.step import TrainStep
+    from transformertts_amd.workload import synth_batch
+    lib = _lib.load()
+    runs = []
+    for defer, graph in ((False, False), (True, False), (True, True)):
+        monkeypatch.setattr(ops, "DEFER_REDUCE", defer)
+        cfg, lm, opt, sch = _setup("base", 3, 0)
+        batch = {k: v.to("cuda") for k, v in synth_batch(3, 40, 200, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=8).items()}
+        ts = TrainStep(lm, opt, sch, batch, graph=graph, seed=9)
+        losses = [ts().detach().clone() for _ in range(4)]
+        torch.cuda.synchronize()
+        assert lib.ttts_reduce_defer_pending() == 0 and not ops._defer_keep and not ops._defer_armed
+        runs.append((losses, opt.flat_params.clone(), opt.exp_avg_sq.clone()))
+    for losses, p, v in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(losses, runs[0][0]))
+        assert torch.equal(p, runs[0][1]) and torch.equal(v, runs[0][2])
+
+
+def test_deferred_reduction_queue_semantics():
+    """Entry points called with accumulate bit 1 queue only while deferral is open; a second reduction into the same
+    destination is ordered behind the first; abort drops the queue."""
+    from transformertts_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    M, N, K = 4096, 256, 256
+    dy = torch.randn(M, N, device="cuda", generator=g) * 1e-3
+    x = torch.randn(M, K, device="cuda", generator=g)
+    nb = lib.ttts_wgrad_workspace_bytes(M, N, K, 1)
+    st = ops._stream()
+
+    def call(dw, db, ws, acc):
+        _lib.check(lib.ttts_linear_bwd_weight(ops._p(dy), ops._p(x), ops._p(dw), ops._p(db), ops._p(ws), ws.numel() * 4, M, N, K,
+                                              0, 0, acc, st), "ttts_linear_bwd_weight")
+    ref_w, ref_b = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+    call(ref_w, ref_b, ops._ws(nb, "cuda"), 0)
+    # bit 1 without an open deferral: immediate
+    w1, b1 = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+    call(w1, b1, ops._ws(nb, "cuda"), 2)
+    assert lib.ttts_reduce_defer_pending() == 0 and torch.equal(w1, ref_w) and torch.equal(b1, ref_b)
+    # open: queued (twice into the same destination, accumulating), nothing written before the flush
+    w2, b2 = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+    wsa, wsb = ops._ws(nb, "cuda"), ops._ws(nb, "cuda")
+    _lib.check(lib.ttts_reduce_defer_begin(), "begin")
+    try:
+        call(w2, b2, wsa, 3)
+        call(w2, b2, wsb, 3)
+        assert lib.ttts_reduce_defer_pending() == 4
+        torch.cuda.synchronize()
+        assert float(w2.abs().max()) == 0.0
+        _lib.check(lib.ttts_reduce_defer_flush(0, st), "flush")
+    finally:
+        lib.ttts_reduce_defer_abort()
+    assert lib.ttts_reduce_defer_pending() == 0
+    assert torch.equal(w2, ref_w + ref_w) and torch.equal(b2, ref_b + ref_b)
+    # abort drops what is queued
+    w3, b3 = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+    _lib.check(lib.ttts_reduce_defer_begin(), "begin")
+    call(w3, b3, wsa, 3)
+    assert lib.ttts_reduce_defer_pending() == 2
+    lib.ttts_reduce_defer_abort()
+    assert lib.ttts_reduce_defer_pending() == 0
+    call(w3, b3, wsa, 1)
+    assert torch.equal(w3, ref_w)

@@ -76,6 +76,10 @@ SIGNATURES = {
     "ttts_loss_fwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, F, P]),
     "ttts_loss_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P]),
     "ttts_zero": (I, [P, Z, P]),
+    "ttts_reduce_defer_begin": (I, []),
+    "ttts_reduce_defer_pending": (L, []),
+    "ttts_reduce_defer_flush": (I, [I, P]),
+    "ttts_reduce_defer_abort": (I, []),
     "ttts_sched_sampling_mix": (I, [P, P, P, P, P, I, I, I, F, I, U, P, P]),
     "ttts_grad_norm_workspace_bytes": (Z, []),
     "ttts_grad_norm": (I, [P, P, P, Z, L, P]),

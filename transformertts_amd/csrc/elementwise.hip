@@ -274,7 +274,7 @@ using namespace ttts;
 extern "C" {
 
 const char* ttts_last_error(void) { return ttts::g_err; }
-int ttts_abi_version(void) { return 4; }
+int ttts_abi_version(void) { return 5; }
 
 int ttts_zero(void* p, size_t nbytes, void* stream) {
     TTTS_REQUIRE(p != nullptr || nbytes == 0, "zero: null pointer");
@@ -390,7 +390,7 @@ int ttts_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx_a
     if ((long)nblk * 4 > M) nblk = (int)((M + 3) / 4);
     hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dy, x, w, dx_accum, ws, (long)M, d);
     TTTS_LAUNCH_CHECK("rowdot_bwd_kernel");
-    return launch_reduce_rows(ws, d + 1, nblk, d + 1, dw, d, db, accumulate, stream);
+    return launch_reduce_rows(ws, d + 1, nblk, d + 1, dw, d, db, accumulate & 1, stream, (accumulate & 2) != 0);
 }
 
 }  // extern "C"

@@ -312,29 +312,6 @@ __global__ __launch_bounds__(256, TTTS_GEMM_MINWAVES) void gemm_f32_kernel(GemmA
     }
 }
 
-// conv weight gradient: ws[split][tap][co][ci] -> dw[co][ci][tap] (+= when accumulate)
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                                int cout, int cin, int taps, int nsplit, int accumulate) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // index into [tap][co][ci]
-    long per = (long)cout * cin;
-    long n = per * taps;
-    if (i >= n) return;
-    int tap = (int)(i / per);
-    long rem = i - (long)tap * per;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int z = 0;
-    for (; z + 4 <= nsplit; z += 4) {
-        s0 += ws[(long)z * n + i];
-        s1 += ws[(long)(z + 1) * n + i];
-        s2 += ws[(long)(z + 2) * n + i];
-        s3 += ws[(long)(z + 3) * n + i];
-    }
-    for (; z < nsplit; ++z) s0 += ws[(long)z * n + i];
-    float s = (s0 + s1) + (s2 + s3);
-    long o = rem * taps + tap;
-    dw[o] = accumulate ? dw[o] + s : s;
-}
-
 // w[co][ci][tap] -> wp[co][tap][ci]  (forward: K-contiguous rows per output channel)
 //                -> wt[ci][tap][co]  (data gradient: K-contiguous rows per input channel)
 __global__ void conv_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wt,
@@ -1066,7 +1043,7 @@ static int linear_bwd_weight_impl(const float* dy, const float* x, float* dw, fl
     float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, N, K, 1, x6, dy_amax ? HBK : BK).nsplit * n : nullptr;
     int rc = wgrad_common(dy, x, ws, colsum_ws, M, N, K, 1, row_shift != 0 ? T : 0, row_shift, 0, &p, x6, stream, dy_amax);
     if (rc) return rc;
-    return launch_reduce_rows_pair(ws, n, p.nsplit, n, dw, colsum_ws, N, N, dbias, accumulate, stream);
+    return launch_reduce_rows_pair(ws, n, p.nsplit, n, dw, colsum_ws, N, N, dbias, accumulate & 1, stream, (accumulate & 2) != 0);
 }
 
 int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
@@ -1145,10 +1122,10 @@ static int conv1d_bwd_weight_impl(const float* dy, const float* x, float* dw, fl
     float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, cout, cin, taps, x6, dy_amax ? HBK : BK).nsplit * n : nullptr;
     int rc = wgrad_common(dy, x, ws, colsum_ws, M, cout, cin, taps, T, -((taps - 1) / 2), 1, &p, x6, stream, dy_amax);
     if (rc) return rc;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, ws, dw, cout, cin, taps,
-                       p.nsplit, accumulate);
-    TTTS_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
-    if (dbias) rc = launch_reduce_rows(colsum_ws, cout, p.nsplit, cout, dbias, cout, nullptr, accumulate, stream);
+    const bool defer = (accumulate & 2) != 0;
+    rc = launch_conv_wgrad_reduce(ws, dw, cout, cin, taps, p.nsplit, accumulate & 1, stream, defer);
+    if (rc == TTTS_OK && dbias)
+        rc = launch_reduce_rows(colsum_ws, cout, p.nsplit, cout, dbias, cout, nullptr, accumulate & 1, stream, defer);
     return rc;
 }
 

@@ -152,14 +152,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
-// d = 256 * NV form of the backward: 16-byte accesses, two rows per wave iteration in flight
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// d = 256 * NV form of the backward: 16-byte accesses, two rows per wave iteration in flight, NW waves per block (the
+// block count is fixed by the partial-sum workspace, so occupancy comes from the block size: 16 waves per CU at d = 256)
+template <int NV, int NW>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, float* __restrict__ dx,
                                                                float* __restrict__ ws, long M) {
     constexpr int d = 256 * NV;
-    __shared__ float red[4][2][d];
+    __shared__ float red[NW][2][d];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 g[NV], accg[NV], accb[NV];
 #pragma unroll
@@ -168,8 +169,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const float* __re
         accg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         accb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const long stride = (long)gridDim.x * 4;
-    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += 2 * stride) {
+    const long stride = (long)gridDim.x * NW;
+    for (long row = (long)blockIdx.x * NW + wave; row < M; row += 2 * stride) {
         float4 dv[2][NV], xv[2][NV];
         float mu[2], rs[2];
 #pragma unroll
@@ -214,9 +215,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const float* __re
         reinterpret_cast<float4*>(&red[wave][1][0])[lane + 64 * k] = accb[k];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * d; c += 256) {
+    for (int c = threadIdx.x; c < 2 * d; c += 64 * NW) {
         int which = c / d, col = c - which * d;
-        float sum = (red[0][which][col] + red[1][which][col]) + (red[2][which][col] + red[3][which][col]);
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4)
+            sum += (red[w][which][col] + red[w + 1][which][col]) + (red[w + 2][which][col] + red[w + 3][which][col]);
         ws[((long)blockIdx.x * 2 + which) * d + col] = sum;
     }
 }
@@ -498,11 +502,11 @@ int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const
     const bool v4 = (d == 256 || d == 512 || d == 1024) &&
                     ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)gamma)) & 15) == 0;
     if (v4) {
-        if (d == 256) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<1>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M);
-        else if (d == 512) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<2>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M);
-        else hipLaunchKernelGGL((layernorm_bwd_v4_kernel<4>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M);
+        if (d == 256) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<1, 16>), dim3(nblk), dim3(1024), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M);
+        else if (d == 512) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<2, 8>), dim3(nblk), dim3(512), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M);
+        else hipLaunchKernelGGL((layernorm_bwd_v4_kernel<4, 4>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M);
         TTTS_LAUNCH_CHECK("layernorm_bwd_v4_kernel");
-        return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate, stream);
+        return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate & 1, stream, (accumulate & 2) != 0);
     }
 #define TTTS_LN_BWD(NPER)                                                                                         \
     hipLaunchKernelGGL((layernorm_bwd_kernel<NPER>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, \
@@ -517,7 +521,7 @@ int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const
     }
 #undef TTTS_LN_BWD
     TTTS_LAUNCH_CHECK("layernorm_bwd_kernel");
-    return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate, stream);
+    return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate & 1, stream, (accumulate & 2) != 0);
 }
 
 size_t ttts_bn_workspace_bytes(int64_t M, int C) {

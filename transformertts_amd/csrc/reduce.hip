@@ -1,20 +1,48 @@
 // Deterministic second-stage reductions shared by the weight-gradient, bias-gradient, LayerNorm and BatchNorm
 // backward kernels: partial results laid out [nrows][ncols] are summed over rows in a fixed order (no atomics),
 // and either stored or added to the destination (`accumulate`: gradients land directly in a flat gradient buffer).
+//
+// Deferred form: a training step has ~90 of these (one per weight / bias / LayerNorm parameter pair), each a few
+// microseconds of work behind a launch.  Between ttts_reduce_defer_begin() and ttts_reduce_defer_flush() the launchers
+// called with `deferrable` queue a descriptor on the host instead, and flush runs them all in ONE launch per 48
+// descriptors (the table travels in the kernel-argument segment: nothing to copy, nothing to keep alive, and a captured
+// HIP graph replays it as it stands).  Every form sums in the same order whether deferred or not.
 #include "ttts_common.h"
+#include <mutex>
+#include <vector>
 
 namespace ttts {
 
-int launch_reduce_rows(const float* ws, long ld, int nrows, long ncols, float* out0, long n0, float* out1, int accumulate,
-                       hipStream_t stream);
+enum { RED_NARROW = 0, RED_WIDE = 1, RED_CONV = 2 };
+
+struct ReduceDesc {
+    const float* ws;
+    float* out0;
+    float* out1;       // narrow form only: columns >= n0 go here (may be NULL: dropped)
+    int ld;            // row stride of ws in floats (conv form: floats per split)
+    int ncols;         // narrow / conv: columns; wide: float4 columns
+    int n0;            // narrow: split point between out0 and out1; conv: cout * cin
+    int nrows;
+    int kind;
+    int accumulate;
+    int first_block;
+    int taps;          // conv form
+    int pad;
+};
+static_assert(sizeof(ReduceDesc) == 64, "descriptor layout");
+
+constexpr int RED_BATCH = 48;
+struct ReduceBatch {
+    ReduceDesc d[RED_BATCH];
+    int n;
+};
 
 // narrow outputs (a few hundred .. few thousand columns, up to a few hundred rows): 16 columns x 16 row-lanes
-__global__ __launch_bounds__(256) void reduce_rows_narrow_kernel(const float* __restrict__ ws, long ld, int nrows,
-                                                                 long ncols, float* __restrict__ out0, long n0,
-                                                                 float* __restrict__ out1, int accumulate) {
-    __shared__ float red[16][17];
+__device__ __forceinline__ void reduce_narrow_body(const float* __restrict__ ws, long ld, int nrows, long ncols,
+                                                   float* __restrict__ out0, long n0, float* __restrict__ out1,
+                                                   int accumulate, int block, float (*red)[17]) {
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const long c = (long)blockIdx.x * 16 + cl;
+    const long c = (long)block * 16 + cl;
     float s = 0.f;
     if (c < ncols) {
         for (int r = rl; r < nrows; r += 16) s += ws[(long)r * ld + c];
@@ -25,15 +53,15 @@ __global__ __launch_bounds__(256) void reduce_rows_narrow_kernel(const float* __
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += red[i][cl];
-        float* o = (c < n0) ? (out0 + c) : (out1 + (c - n0));
+        float* o = (c < n0) ? (out0 + c) : (out1 != nullptr ? out1 + (c - n0) : nullptr);
         if (o != nullptr) *o = accumulate ? (*o + t) : t;
     }
 }
 
 // wide outputs (weight matrices): one float4 of columns per thread, rows unrolled by 4
-__global__ __launch_bounds__(256) void reduce_rows_wide_kernel(const float* __restrict__ ws, long ld, int nrows, long ncols4,
-                                                               float* __restrict__ out, int accumulate) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void reduce_wide_body(const float* __restrict__ ws, long ld, int nrows, long ncols4,
+                                                 float* __restrict__ out, int accumulate, int block) {
+    const long i = (long)block * 256 + threadIdx.x;
     if (i >= ncols4) return;
     const float4* p = reinterpret_cast<const float4*>(ws) + i;
     const long ld4 = ld >> 2;
@@ -60,69 +88,123 @@ __global__ __launch_bounds__(256) void reduce_rows_wide_kernel(const float* __re
     *o = s;
 }
 
+// conv weight gradient: ws[split][tap][co][ci] -> dw[co][ci][tap] (+= when accumulate)
+__device__ __forceinline__ void reduce_conv_body(const float* __restrict__ ws, float* __restrict__ dw, long per, int taps,
+                                                 int nsplit, int accumulate, int block) {
+    const long i = (long)block * 256 + threadIdx.x;   // index into [tap][co][ci]
+    const long n = per * taps;
+    if (i >= n) return;
+    const int tap = (int)(i / per);
+    const long rem = i - (long)tap * per;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 4 <= nsplit; z += 4) {
+        s0 += ws[(long)z * n + i];
+        s1 += ws[(long)(z + 1) * n + i];
+        s2 += ws[(long)(z + 2) * n + i];
+        s3 += ws[(long)(z + 3) * n + i];
+    }
+    for (; z < nsplit; ++z) s0 += ws[(long)z * n + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    const long o = rem * taps + tap;
+    dw[o] = accumulate ? dw[o] + s : s;
+}
+
+__global__ __launch_bounds__(256) void reduce_rows_narrow_kernel(const float* __restrict__ ws, long ld, int nrows,
+                                                                 long ncols, float* __restrict__ out0, long n0,
+                                                                 float* __restrict__ out1, int accumulate) {
+    __shared__ float red[16][17];
+    reduce_narrow_body(ws, ld, nrows, ncols, out0, n0, out1, accumulate, blockIdx.x, red);
+}
+
+__global__ __launch_bounds__(256) void reduce_rows_wide_kernel(const float* __restrict__ ws, long ld, int nrows, long ncols4,
+                                                               float* __restrict__ out, int accumulate) {
+    reduce_wide_body(ws, ld, nrows, ncols4, out, accumulate, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                int cout, int cin, int taps, int nsplit, int accumulate) {
+    reduce_conv_body(ws, dw, (long)cout * cin, taps, nsplit, accumulate, blockIdx.x);
+}
+
 // a weight matrix (wide form above) AND its bias vector in ONE launch: blocks [0, nb_wide) reduce the matrix partials,
 // the blocks behind them the ncols2 bias partials (16 columns x 16 row-lanes per block, as the narrow kernel)
 __global__ __launch_bounds__(256) void reduce_rows_pair_kernel(const float* __restrict__ ws, long ld, int nrows, long ncols4,
                                                                float* __restrict__ out, int nb_wide,
                                                                const float* __restrict__ ws2, long ld2, long ncols2,
                                                                float* __restrict__ out2, int accumulate) {
-    if ((int)blockIdx.x < nb_wide) {
-        const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-        if (i >= ncols4) return;
-        const float4* p = reinterpret_cast<const float4*>(ws) + i;
-        const long ld4 = ld >> 2;
-        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-        int r = 0;
-        for (; r + 4 <= nrows; r += 4) {
-            float4 v0 = p[(long)r * ld4], v1 = p[(long)(r + 1) * ld4], v2 = p[(long)(r + 2) * ld4], v3 = p[(long)(r + 3) * ld4];
-            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-            a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
-            a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
-        }
-        for (; r < nrows; ++r) {
-            float4 v0 = p[(long)r * ld4];
-            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-        }
-        float4 s = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
-                               (a0.w + a1.w) + (a2.w + a3.w));
-        float4* o = reinterpret_cast<float4*>(out) + i;
-        if (accumulate) {
-            float4 t = *o;
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-        }
-        *o = s;
-        return;
-    }
     __shared__ float red[16][17];
-    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const long c = (long)((int)blockIdx.x - nb_wide) * 16 + cl;
-    float s = 0.f;
-    if (c < ncols2) {
-        for (int r = rl; r < nrows; r += 16) s += ws2[(long)r * ld2 + c];
-    }
-    red[rl][cl] = s;
-    __syncthreads();
-    if (rl == 0 && c < ncols2) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += red[i][cl];
-        out2[c] = accumulate ? (out2[c] + t) : t;
-    }
+    if ((int)blockIdx.x < nb_wide) reduce_wide_body(ws, ld, nrows, ncols4, out, accumulate, blockIdx.x);
+    else reduce_narrow_body(ws2, ld2, nrows, ncols2, out2, ncols2, nullptr, accumulate, (int)blockIdx.x - nb_wide, red);
+}
+
+// every queued reduction of a backward pass: the block finds its descriptor (first_block ascending, wave-uniform scan
+// of the kernel-argument table) and runs the body of the kernel that would have been launched for it
+__global__ __launch_bounds__(256) void reduce_batched_kernel(const ReduceBatch b) {
+    __shared__ float red[16][17];
+    const int bi = blockIdx.x;
+    int k = 0;
+    for (int i = 1; i < b.n; ++i)
+        if (b.d[i].first_block <= bi) k = i;
+    const ReduceDesc& D = b.d[k];
+    const int block = bi - D.first_block;
+    if (D.kind == RED_WIDE) reduce_wide_body(D.ws, D.ld, D.nrows, D.ncols, D.out0, D.accumulate, block);
+    else if (D.kind == RED_CONV) reduce_conv_body(D.ws, D.out0, D.n0, D.taps, D.nrows, D.accumulate, block);
+    else reduce_narrow_body(D.ws, D.ld, D.nrows, D.ncols, D.out0, D.n0, D.out1, D.accumulate, block, red);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static std::mutex g_defer_mu;          // autograd runs backward nodes and its final callbacks on its own threads
+static bool g_deferring = false;
+static std::vector<ReduceDesc> g_queue;
+
+static bool defer_push(ReduceDesc d, long blocks) {
+    std::lock_guard<std::mutex> lock(g_defer_mu);
+    if (!g_deferring) return false;
+    d.first_block = (int)blocks;        // block COUNT for now; flush turns the counts into prefix sums per batch
+    d.pad = 0;
+    g_queue.push_back(d);
+    return true;
+}
+
+static bool fits_int(long v) { return v >= 0 && v < (1L << 31); }
+
+static bool wide_ok(const float* ws, long ld, long ncols, const float* out) {
+    return ncols >= 8192 && (ncols % 4) == 0 && (ld % 4) == 0 && ((((uintptr_t)ws) | ((uintptr_t)out)) & 15) == 0;
+}
+
+static ReduceDesc narrow_desc(const float* ws, long ld, int nrows, long ncols, float* out0, long n0, float* out1, int accumulate) {
+    ReduceDesc d{};
+    d.ws = ws; d.out0 = out0; d.out1 = out1; d.ld = (int)ld; d.ncols = (int)ncols; d.n0 = (int)(n0 < ncols ? n0 : ncols);
+    d.nrows = nrows; d.kind = RED_NARROW; d.accumulate = accumulate;
+    return d;
+}
+static ReduceDesc wide_desc(const float* ws, long ld, int nrows, long ncols4, float* out, int accumulate) {
+    ReduceDesc d{};
+    d.ws = ws; d.out0 = out; d.ld = (int)ld; d.ncols = (int)ncols4; d.nrows = nrows; d.kind = RED_WIDE; d.accumulate = accumulate;
+    return d;
 }
 
 // out (+)= column sums of ws [nrows][ncols] and out2 (+)= column sums of ws2 [nrows][ncols2]; one launch when the first is
 // a wide (weight-matrix) reduction, two otherwise.  Same summation order as launch_reduce_rows for either part.
 int launch_reduce_rows_pair(const float* ws, long ld, int nrows, long ncols, float* out, const float* ws2, long ld2,
-                            long ncols2, float* out2, int accumulate, hipStream_t stream) {
-    const bool wide = ncols >= 8192 && (ncols % 4) == 0 && (ld % 4) == 0 && ((((uintptr_t)ws) | ((uintptr_t)out)) & 15) == 0;
+                            long ncols2, float* out2, int accumulate, hipStream_t stream, bool deferrable) {
+    const bool wide = wide_ok(ws, ld, ncols, out);
     if (!wide || out2 == nullptr) {
-        int rc = launch_reduce_rows(ws, ld, nrows, ncols, out, ncols, nullptr, accumulate, stream);
+        int rc = launch_reduce_rows(ws, ld, nrows, ncols, out, ncols, nullptr, accumulate, stream, deferrable);
         if (rc || out2 == nullptr) return rc;
-        return launch_reduce_rows(ws2, ld2, nrows, ncols2, out2, ncols2, nullptr, accumulate, stream);
+        return launch_reduce_rows(ws2, ld2, nrows, ncols2, out2, ncols2, nullptr, accumulate, stream, deferrable);
     }
     const long n4 = ncols / 4;
     const int nb_wide = cdiv(n4, 256);
+    if (deferrable && fits_int(ld) && fits_int(ld2) && fits_int(ncols) &&
+        defer_push(wide_desc(ws, ld, nrows, n4, out, accumulate), nb_wide)) {
+        if (!defer_push(narrow_desc(ws2, ld2, nrows, ncols2, out2, ncols2, nullptr, accumulate), cdiv(ncols2, 16))) {
+            set_error("reduce: deferral ended between the two halves of a weight / bias pair");
+            return TTTS_ERR_INVALID;
+        }
+        return TTTS_OK;
+    }
     hipLaunchKernelGGL(reduce_rows_pair_kernel, dim3(nb_wide + cdiv(ncols2, 16)), dim3(256), 0, stream, ws, ld, nrows, n4, out,
                        nb_wide, ws2, ld2, ncols2, out2, accumulate);
     TTTS_LAUNCH_CHECK("reduce_rows_pair_kernel");
@@ -130,14 +212,16 @@ int launch_reduce_rows_pair(const float* ws, long ld, int nrows, long ncols, flo
 }
 
 int launch_reduce_rows(const float* ws, long ld, int nrows, long ncols, float* out0, long n0, float* out1, int accumulate,
-                       hipStream_t stream) {
-    const bool wide = ncols >= 8192 && out1 == nullptr && n0 >= ncols && (ncols % 4) == 0 && (ld % 4) == 0 &&
-                      ((((uintptr_t)ws) | ((uintptr_t)out0)) & 15) == 0;
+                       hipStream_t stream, bool deferrable) {
+    const bool wide = out1 == nullptr && n0 >= ncols && wide_ok(ws, ld, ncols, out0);
+    const bool q = deferrable && fits_int(ld) && fits_int(ncols);
     if (wide) {
         long n4 = ncols / 4;
+        if (q && defer_push(wide_desc(ws, ld, nrows, n4, out0, accumulate), cdiv(n4, 256))) return TTTS_OK;
         hipLaunchKernelGGL(reduce_rows_wide_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, stream, ws, ld, nrows, n4, out0,
                            accumulate);
     } else {
+        if (q && defer_push(narrow_desc(ws, ld, nrows, ncols, out0, n0, out1, accumulate), cdiv(ncols, 16))) return TTTS_OK;
         hipLaunchKernelGGL(reduce_rows_narrow_kernel, dim3(cdiv(ncols, 16)), dim3(256), 0, stream, ws, ld, nrows, ncols,
                            out0, n0, out1, accumulate);
     }
@@ -145,4 +229,78 @@ int launch_reduce_rows(const float* ws, long ld, int nrows, long ncols, float* o
     return TTTS_OK;
 }
 
+int launch_conv_wgrad_reduce(const float* ws, float* dw, int cout, int cin, int taps, int nsplit, int accumulate,
+                             hipStream_t stream, bool deferrable) {
+    const long n = (long)cout * cin * taps;
+    if (deferrable && fits_int(n)) {
+        ReduceDesc d{};
+        d.ws = ws; d.out0 = dw; d.n0 = cout * cin; d.taps = taps; d.nrows = nsplit; d.kind = RED_CONV; d.accumulate = accumulate;
+        d.ncols = (int)n;
+        if (defer_push(d, cdiv(n, 256))) return TTTS_OK;
+    }
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, ws, dw, cout, cin, taps, nsplit,
+                       accumulate);
+    TTTS_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
+    return TTTS_OK;
+}
+
 }  // namespace ttts
+
+using namespace ttts;
+
+extern "C" {
+
+int ttts_reduce_defer_begin(void) {
+    std::lock_guard<std::mutex> lock(g_defer_mu);
+    g_deferring = true;
+    return TTTS_OK;
+}
+
+int64_t ttts_reduce_defer_pending(void) {
+    std::lock_guard<std::mutex> lock(g_defer_mu);
+    return (int64_t)g_queue.size();
+}
+
+int ttts_reduce_defer_abort(void) {
+    std::lock_guard<std::mutex> lock(g_defer_mu);
+    g_deferring = false;
+    g_queue.clear();
+    return TTTS_OK;
+}
+
+int ttts_reduce_defer_flush(int keep_deferring, void* stream_) {
+    // run everything queued since begin and, unless keep_deferring, go back to immediate launches.  Entries of one launch
+    // run concurrently, so a second reduction into a destination already in the batch (a parameter used twice in the
+    // pass) starts a new launch: queue order is kept per destination.
+    std::vector<ReduceDesc> q;
+    {
+        std::lock_guard<std::mutex> lock(g_defer_mu);
+        q.swap(g_queue);
+        if (!keep_deferring) g_deferring = false;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    for (size_t at = 0; at < q.size();) {
+        ReduceBatch b;
+        b.n = 0;
+        long blocks = 0;
+        while (at < q.size() && b.n < RED_BATCH) {
+            const ReduceDesc& d = q[at];
+            bool clash = false;
+            for (int i = 0; i < b.n && !clash; ++i)
+                clash = b.d[i].out0 == d.out0 || (d.out1 && (b.d[i].out1 == d.out1 || b.d[i].out0 == d.out1)) ||
+                        (b.d[i].out1 && b.d[i].out1 == d.out0);
+            if (clash) break;
+            b.d[b.n] = d;
+            b.d[b.n].first_block = (int)blocks;
+            blocks += d.first_block;
+            ++b.n;
+            ++at;
+        }
+        TTTS_REQUIRE(blocks > 0 && blocks < (1L << 31), "reduce_defer_flush: bad block count");
+        hipLaunchKernelGGL(reduce_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, b);
+        TTTS_LAUNCH_CHECK("reduce_batched_kernel");
+    }
+    return TTTS_OK;
+}
+
+}  // extern "C"

@@ -31,11 +31,16 @@ void set_error(const char* fmt, ...);
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // out0[c] (+)= sum_r ws[r*ld + c] for c < n0, out1[c - n0] for the rest (reduce.hip); fixed summation order
+// `deferrable`: nothing later in the same pass reads the result (parameter gradients), so the launch may be queued while
+// ttts_reduce_defer_begin() .. ttts_reduce_defer_flush() is open
 int launch_reduce_rows(const float* ws, long ld, int nrows, long ncols, float* out0, long n0, float* out1, int accumulate,
-                       hipStream_t stream);
+                       hipStream_t stream, bool deferrable = false);
 // weight-matrix partials and the matching bias partials in one launch (reduce.hip)
 int launch_reduce_rows_pair(const float* ws, long ld, int nrows, long ncols, float* out, const float* ws2, long ld2,
-                            long ncols2, float* out2, int accumulate, hipStream_t stream);
+                            long ncols2, float* out2, int accumulate, hipStream_t stream, bool deferrable = false);
+// conv weight-gradient partials ws[split][tap][co][ci] -> dw[co][ci][tap] (reduce.hip)
+int launch_conv_wgrad_reduce(const float* ws, float* dw, int cout, int cin, int taps, int nsplit, int accumulate,
+                             hipStream_t stream, bool deferrable = false);
 
 // ---------------------------------------------------------------- counter-based dropout RNG
 // keep(seed, idx) is a pure function of the 64-bit site seed and the element index, so the backward kernels

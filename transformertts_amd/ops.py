@@ -212,6 +212,54 @@ def _amax_slots(device, zero: bool) -> torch.Tensor:
     return a
 
 
+# ----------------------------------------------------------------------------------------------- deferred reductions
+# The parameter-gradient kernels end in a small reduction of their partials into the gradient sink.  With sinks (the
+# results are not read before the pass ends) those ~90 launches are queued in the library and run as two at the end of
+# the backward pass: the first deferring backward node registers a final callback with the autograd engine.
+DEFER_REDUCE = os.environ.get("TTTS_DEFER_REDUCE", "1") == "1"
+_defer_armed = False
+_defer_keep: list = []           # workspaces the queued reductions still read
+
+
+def _defer(acc: int, ws: torch.Tensor) -> int:
+    """`accumulate` argument for a parameter-gradient entry point writing into sinks: adds the "may defer" bit and keeps
+    `ws` alive until the flush.  Only called from backward nodes (the engine's final-callback queue is open there)."""
+    global _defer_armed
+    if not DEFER_REDUCE:
+        return acc
+    if not _defer_armed:
+        _lib.check(_lib.load().ttts_reduce_defer_begin(), "ttts_reduce_defer_begin")
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred_final)
+        _defer_armed = True
+    _defer_keep.append(ws)
+    return acc | 2
+
+
+def flush_deferred(final: bool = False) -> None:
+    """Run every queued reduction now (on the current stream).  Mid-pass (`final` False: e.g. before a collective over the
+    gradients finished so far) the pass keeps deferring afterwards."""
+    global _defer_armed
+    if not _defer_armed:
+        return
+    if final:
+        _defer_armed = False
+    _lib.check(_lib.load().ttts_reduce_defer_flush(0 if final else 1, _stream()), "ttts_reduce_defer_flush")
+    _defer_keep.clear()
+
+
+def _flush_deferred_final() -> None:
+    flush_deferred(True)
+
+
+def abort_deferred() -> None:
+    """Drop whatever an interrupted backward pass left queued (its final callback never ran)."""
+    global _defer_armed
+    if _defer_armed or _defer_keep:
+        _lib.check(_lib.load().ttts_reduce_defer_abort(), "ttts_reduce_defer_abort")
+        _defer_armed = False
+        _defer_keep.clear()
+
+
 def _wgrad_is_split(N: int, K: int) -> bool:
     """Mirror of wgrad_use_x6 (csrc/gemm.hip): shapes the split-precision weight-gradient kernels take (the others run on
     the fp32-MFMA kernel and need no maxima)."""
@@ -473,6 +521,7 @@ class LinearFn(torch.autograd.Function):
             sk, acc = ctx.sinks
             if sk is not None:
                 dw_t, db_t = sk
+                acc = _defer(acc, ws)
             else:
                 dw_t = dw = torch.empty_like(w)
                 db_t = db = torch.empty(N, dtype=torch.float32, device=x.device) if has_b else None
@@ -574,9 +623,11 @@ class HeadsFn(torch.autograd.Function):
                        "ttts_linear_bwd_data")
         ws = _ws(lib.ttts_wgrad_workspace_bytes(M, N, K, 1), x.device)
         sk, acc = ctx.sinks
+        ws2 = _ws(lib.ttts_rowdot_bwd_workspace_bytes(K), x.device)
         if sk is not None:
             t_wm, t_bm, t_ws, t_bs = sk
             dw_mel = db_mel = dw_stop = db_stop = None
+            acc = _defer(_defer(acc, ws), ws2)
         else:
             t_wm = dw_mel = torch.empty_like(w_mel)
             t_bm = db_mel = torch.empty(N, dtype=torch.float32, device=x.device)
@@ -584,7 +635,6 @@ class HeadsFn(torch.autograd.Function):
             t_bs = db_stop = torch.empty(1, dtype=torch.float32, device=x.device)
         _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dmel, None, _wgrad_is_split(N, K), _p(x), _p(t_wm), _p(t_bm), _p(ws),
                           ws.numel() * 4, M, N, K, 0, 0, acc), "ttts_linear_bwd_weight")
-        ws2 = _ws(lib.ttts_rowdot_bwd_workspace_bytes(K), x.device)
         _lib.check(lib.ttts_rowdot_bwd(_p(dstop), _p(x), _p(w_stop), _p(dx), _p(t_ws), _p(t_bs), _p(ws2),
                                        ws2.numel() * 4, M, K, acc, _stream()), "ttts_rowdot_bwd")
         return dx, dw_mel, db_mel, dw_stop, db_stop
@@ -685,7 +735,8 @@ class ConvBNFn(torch.autograd.Function):
                            "ttts_conv1d_bwd_data")
         ws2 = _ws(lib.ttts_wgrad_workspace_bytes(M, cout, cin, taps), dev)
         _lib.check(_wgrad(lib, "ttts_conv1d_bwd_weight", dy, am, _wgrad_is_split(cout, cin), _p(x), _p(t_w), _p(t_b), _p(ws2),
-                          ws2.numel() * 4, B, T, cin, cout, taps, acc), "ttts_conv1d_bwd_weight")
+                          ws2.numel() * 4, B, T, cin, cout, taps, _defer(acc, ws2) if sk is not None else acc),
+                   "ttts_conv1d_bwd_weight")
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
@@ -729,7 +780,8 @@ class LayerNormFn(torch.autograd.Function):
             t_b = dbeta = torch.empty_like(gamma)
         ws = _ws(lib.ttts_layernorm_bwd_workspace_bytes(d), x.device)
         _lib.check(lib.ttts_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(t_g), _p(t_b),
-                                          _p(ws), ws.numel() * 4, M, d, acc, _stream()), "ttts_layernorm_bwd")
+                                          _p(ws), ws.numel() * 4, M, d, _defer(acc, ws) if sk is not None else acc, _stream()),
+                   "ttts_layernorm_bwd")
         return dx, dgamma, dbeta, None
 
 

@@ -158,6 +158,8 @@ class _TailTrigger:
                 self.pending -= 1
                 if self.pending == 0:
                     self.fired += 1
+                    from . import ops
+                    ops.flush_deferred()       # parameter-gradient reductions queued so far land in the bucket first
                     self.on_ready(self.lo)
             return None
         seen = set()

@@ -88,6 +88,7 @@ class TrainStep:
 
     def _forward_backward(self) -> torch.Tensor:
         ops.seeds.counter = 0                # site seeds are numbered per step; the step's seed word makes them fresh
+        ops.abort_deferred()                 # leftovers of a backward pass that raised
         self.opt.zero_grad()
         loss = self.lm.training_step(self.batch, self.index)
         dev = self.bucket.flat.device
