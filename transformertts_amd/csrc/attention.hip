@@ -31,6 +31,9 @@ constexpr int HD = 64;            // head dim
 constexpr int KT_LD = HD + 1;     // LDS row stride (odd: conflict-free "row per lane" reads)
 constexpr int QB = 128;           // rows per workgroup (4 waves x 32)
 constexpr float NEG_INF = -__builtin_inff();
+// v_exp_f32 as it is: exp2f() wraps it in a range reduction for results below 2^-126 (compare, select, add, ldexp: four more
+// instructions per element in kernels whose speed is set by their VALU count); such weights are zero at fp32 anyway
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
 // Row loads go through a raw buffer descriptor spanning `nrows` rows of the (batch, head) slice: a row index past the
@@ -139,6 +142,7 @@ static_assert(2 * KB * KT_LD <= SMEM_FLOATS, "staging buffers must fit the share
 template <bool CAUSAL, bool WRITE_A>
 __global__ __launch_bounds__(256, TTTS_FWD_W) void attn_fwd_kernel(AttnArgs a) {
     const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
+    const uint32_t thr16 = a.thr << 16;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     __shared__ float ptile_all[WRITE_A ? 4 * 32 * 33 : 1];
     float* Ks = smem;                  // [KB][65]
@@ -197,11 +201,10 @@ __global__ __launch_bounds__(256, TTTS_FWD_W) void attn_fwd_kernel(AttnArgs a) {
     // dropout on the 16 weights of this lane: keys (r, r+1) with r even are neighbours and share one hash
     auto drop16 = [&](float (&p)[16], int key0) {
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const int key_g = key0 + acc_row(r, half);
-            const uint32_t hsh = attn_hash(seed_eff, rowid, (uint32_t)key_g >> 1);
-            p[r] = keep_from_hash(hsh, 0u, a.thr) ? p[r] * a.drop_scale : 0.f;
-            p[r + 1] = keep_from_hash(hsh, 1u, a.thr) ? p[r + 1] * a.drop_scale : 0.f;
+        for (int r = 0; r < 16; r += 4) {     // registers r .. r+3 are four neighbouring keys: one hash
+            const uint32_t qh = attn_quad_hash(seed_eff, rowid, (uint32_t)(key0 + acc_row(r, half)) >> 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[r + e] = attn_keep_word(qh, attn_drop_mult(e), thr16) ? p[r + e] * a.drop_scale : 0.f;
         }
     };
 
@@ -324,6 +327,7 @@ __global__ __launch_bounds__(256, TTTS_FWD_W) void attn_fwd_kernel(AttnArgs a) {
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, TTTS_DQ_W) void attn_bwd_dq_kernel(AttnArgs a) {
     const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
+    const uint32_t thr16 = a.thr << 16;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* Ks = smem;                  // [KB][65]
     float* Vs = smem + KB * KT_LD;     // [KB][65]
@@ -400,17 +404,17 @@ __global__ __launch_bounds__(256, TTTS_DQ_W) void attn_bwd_dq_kernel(AttnArgs a)
             }
             float ds[16];
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
+            for (int r = 0; r < 16; r += 4) {
                 const int key_g = key0 + acc_row(r, half);
-                uint32_t hsh = 0;
-                if (a.thr != 0u) hsh = attn_hash(seed_eff, rowid, (uint32_t)key_g >> 1);
+                uint32_t qh = 0;
+                if (a.thr != 0u) qh = attn_quad_hash(seed_eff, rowid, (uint32_t)key_g >> 2);
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
+                for (int e = 0; e < 4; ++e) {
                     const int kg = key_g + e;
                     bool live = kg < klen && (!CAUSAL || kg <= qg);
                     float p = live ? __expf(s[r + e] - lse_q) : 0.f;
                     float g = dp[r + e];
-                    if (a.thr != 0u) g = keep_from_hash(hsh, (uint32_t)e, a.thr) ? g * a.drop_scale : 0.f;
+                    if (a.thr != 0u) g = attn_keep_word(qh, attn_drop_mult(e), thr16) ? g * a.drop_scale : 0.f;
                     ds[r + e] = p * (g - delta);
                 }
             }
@@ -432,6 +436,7 @@ __global__ __launch_bounds__(256, TTTS_DQ_W) void attn_bwd_dq_kernel(AttnArgs a)
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, TTTS_DKV_W) void attn_bwd_dkv_kernel(AttnArgs a) {
     const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
+    const uint32_t thr16 = a.thr << 16;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     __shared__ float lse_s[KB], delta_s[KB];
     float* Qs = smem;                  // [KB][65]
@@ -511,8 +516,7 @@ __global__ __launch_bounds__(256, TTTS_DKV_W) void attn_bwd_dkv_kernel(AttnArgs 
                 float g = dp[r];
                 float pk = p;
                 if (a.thr != 0u) {
-                    const uint32_t hsh = attn_hash(seed_eff, (uint32_t)(arow + q_g), (uint32_t)kg >> 1);
-                    bool keep = keep_from_hash(hsh, (uint32_t)kg & 1u, a.thr);
+                    bool keep = attn_keep(seed_eff, (uint32_t)(arow + q_g), (uint32_t)kg, thr16);
                     g = keep ? g * a.drop_scale : 0.f;
                     pk = keep ? p * a.drop_scale : 0.f;
                 }
@@ -631,6 +635,7 @@ static_assert(XSMEM >= SMEM_FLOATS, "per-wave fp32 scratch must fit the stage bu
 template <bool CAUSAL, bool WRITE_A>
 __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDX_W) void attn_fwd_x6_kernel(AttnArgs a) {
     const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
+    const uint32_t thr16 = a.thr << 16;
     __shared__ __attribute__((aligned(16))) uint32_t xs[XSMEM];
     __shared__ float ptile_all[WRITE_A ? 4 * 32 * 17 : 1];   // per wave: 32 queries x 16 keys (+1 pad)
     uint32_t* Kp = xs;              // [3][64 keys][64 d]
@@ -694,11 +699,10 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDX_W) void attn_fwd_x6_ke
     auto alive = [&](int key_g) -> bool { return key_g < klen && (!CAUSAL || key_g <= qg); };
     auto drop16 = [&](float (&p)[16], int key0) {
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const int key_g = key0 + acc_row(r, half);
-            const uint32_t hsh = attn_hash(seed_eff, rowid, (uint32_t)key_g >> 1);
-            p[r] = keep_from_hash(hsh, 0u, a.thr) ? p[r] * a.drop_scale : 0.f;
-            p[r + 1] = keep_from_hash(hsh, 1u, a.thr) ? p[r + 1] * a.drop_scale : 0.f;
+        for (int r = 0; r < 16; r += 4) {     // registers r .. r+3 are four neighbouring keys: one hash
+            const uint32_t qh = attn_quad_hash(seed_eff, rowid, (uint32_t)(key0 + acc_row(r, half)) >> 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[r + e] = attn_keep_word(qh, attn_drop_mult(e), thr16) ? p[r + e] * a.drop_scale : 0.f;
         }
     };
 
@@ -926,6 +930,7 @@ __device__ __forceinline__ void mfma_h3(f32x16& c, const f16x8v (&a)[2], const f
 template <bool CAUSAL, bool WRITE_A>
 __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_kernel(AttnArgs a) {
     const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
+    const uint32_t thr16 = a.thr << 16;
     __shared__ __attribute__((aligned(16))) uint32_t xs[HSMEM];
     __shared__ float ptile_all[WRITE_A ? 4 * 32 * 17 : 1];   // per wave: 32 queries x 16 keys (+1 pad)
     uint32_t* Kp = xs;              // [2][64 keys][64 d]      f16 hi / lo planes of K * 2^4
@@ -989,11 +994,10 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
     auto alive = [&](int key_g) -> bool { return key_g < klen && (!CAUSAL || key_g <= qg); };
     auto drop16 = [&](float (&p)[16], int key0) {
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const int key_g = key0 + acc_row(r, half);
-            const uint32_t hsh = attn_hash(seed_eff, rowid, (uint32_t)key_g >> 1);
-            p[r] = keep_from_hash(hsh, 0u, a.thr) ? p[r] * a.drop_scale : 0.f;
-            p[r + 1] = keep_from_hash(hsh, 1u, a.thr) ? p[r + 1] * a.drop_scale : 0.f;
+        for (int r = 0; r < 16; r += 4) {     // registers r .. r+3 are four neighbouring keys: one hash
+            const uint32_t qh = attn_quad_hash(seed_eff, rowid, (uint32_t)(key0 + acc_row(r, half)) >> 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[r + e] = attn_keep_word(qh, attn_drop_mult(e), thr16) ? p[r + e] * a.drop_scale : 0.f;
         }
     };
 
@@ -1018,11 +1022,11 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 float m_new = fmaxf(m, mx);
                 float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-                float alpha = exp2f((m - m_use) * H3A_C2);
+                float alpha = fast_exp2((m - m_use) * H3A_C2);
                 const float mc = m_use * H3A_C2;
                 float ps = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ps += exp2f(__builtin_fmaf(s[r], H3A_C2, -mc));
+                for (int r = 0; r < 16; ++r) ps += fast_exp2(__builtin_fmaf(s[r], H3A_C2, -mc));
                 l = l * alpha + ps;
                 m = m_new;
             }
@@ -1051,7 +1055,7 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
             if (WRITE_A) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    p[r] = alive(key0 + acc_row(r, half)) ? exp2f(__builtin_fmaf(s[r], H3A_C2, -m_fin * H3A_C2)) * inv_l : 0.f;
+                    p[r] = alive(key0 + acc_row(r, half)) ? fast_exp2(__builtin_fmaf(s[r], H3A_C2, -m_fin * H3A_C2)) * inv_l : 0.f;
             } else {
                 float mx = NEG_INF;
                 if (full) {
@@ -1067,11 +1071,12 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 float m_new = fmaxf(m, mx);
                 float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-                float alpha = exp2f((m - m_use) * H3A_C2);
-                const float mc = m_use * H3A_C2;
+                float alpha = fast_exp2((m - m_use) * H3A_C2);
+                // the weights are born pre-scaled by 2^10 (the f16 split scale rides in the exponent): l sums them scaled
+                const float mc = m_use * H3A_C2 - 10.f;
                 float ps = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { p[r] = exp2f(__builtin_fmaf(s[r], H3A_C2, -mc)); ps += p[r]; }
+                for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(__builtin_fmaf(s[r], H3A_C2, -mc)); ps += p[r]; }
                 l = l * alpha + ps;
                 m = m_new;
                 if (__any(alpha != 1.f)) {   // the running maximum rarely moves after the first tiles
@@ -1105,7 +1110,7 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = p[8 * t2 + e];
                 f16x8v pf[2];
-                split_frag8_h3(x, H3A_P, pf[0], pf[1]);
+                split_frag8_h3(x, WRITE_A ? H3A_P : 1.0f, pf[0], pf[1]);
 #pragma unroll
                 for (int i2 = 0; i2 < 2; ++i2) {
                     f16x8v vf[2];
@@ -1123,9 +1128,9 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
     if (WRITE_A) {
         lse_v = m_fin * H3A_C + __logf(l > 0.f ? l : 1.f);
     } else {
-        float lt = l + __shfl_xor(l, 32, 64);
-        out_scale = (lt > 0.f) ? H3A_O / lt : 0.f;
-        lse_v = ((m == NEG_INF) ? 0.f : m) * H3A_C + __logf(lt > 0.f ? lt : 1.f);
+        float lt = l + __shfl_xor(l, 32, 64);                 // = 2^10 * the sum of the weights
+        out_scale = (lt > 0.f) ? (1.0f / H3A_V) / lt : 0.f;
+        lse_v = ((m == NEG_INF) ? 0.f : m) * H3A_C + __logf(lt > 0.f ? lt * (1.0f / H3A_P) : 1.f);
     }
     if (a.lse != nullptr && half == 0 && qg < a.Tq) a.lse[arow + qg] = lse_v;
 #pragma unroll
@@ -1209,6 +1214,7 @@ constexpr int DQX_SMEM = 9 * XP * 4;   // bytes: K rows, V rows, K^T of one 64-k
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, TTTS_DQX_W) void attn_bwd_dq_x6_kernel(AttnArgs a) {
     const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
+    const uint32_t thr16 = a.thr << 16;
     extern __shared__ __attribute__((aligned(16))) uint32_t xsd[];
     uint32_t* Kr = xsd;              // [3][64 keys][64 d]
     uint32_t* Vr = xsd + 3 * XP;     // [3][64 keys][64 d]
@@ -1303,17 +1309,17 @@ __global__ __launch_bounds__(256, TTTS_DQX_W) void attn_bwd_dq_x6_kernel(AttnArg
             // a tile every lane sees in full needs no mask arithmetic (wave-uniform test)
             const bool full = (key0 + 32 <= klen) && (!CAUSAL || key0 + 31 <= qw0);
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
+            for (int r = 0; r < 16; r += 4) {
                 const int key_g = key0 + acc_row(r, half);
-                uint32_t hsh = 0;
-                if (a.thr != 0u) hsh = attn_hash(seed_eff, rowid, (uint32_t)key_g >> 1);
+                uint32_t qh = 0;
+                if (a.thr != 0u) qh = attn_quad_hash(seed_eff, rowid, (uint32_t)key_g >> 2);
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
+                for (int e = 0; e < 4; ++e) {
                     const int kg = key_g + e;
                     float p = __expf(s[r + e] - lse_q);
                     if (!full) p = (kg < klen && (!CAUSAL || kg <= qg)) ? p : 0.f;
                     float g = dp[r + e];
-                    if (a.thr != 0u) g = keep_from_hash(hsh, (uint32_t)e, a.thr) ? g * a.drop_scale : 0.f;
+                    if (a.thr != 0u) g = attn_keep_word(qh, attn_drop_mult(e), thr16) ? g * a.drop_scale : 0.f;
                     ds[r + e] = p * (g - delta);
                 }
             }
@@ -1375,6 +1381,7 @@ __device__ __forceinline__ void dma4(const float* base, uint32_t lane_off, uint3
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnArgs a) {
     const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
+    const uint32_t thr16 = a.thr << 16;
     extern __shared__ __attribute__((aligned(16))) uint32_t xsd[];
     uint32_t* xs = xsd;
     uint32_t* Qr = xs;                      // [3][32 q][64 d]
@@ -1391,6 +1398,7 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
     const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
     const int k0 = kblk * QB, kw0 = k0 + wave * 32;
     const int kg = kw0 + l31;
+    const uint32_t key_mult = attn_drop_mult((uint32_t)kg);
     float* scratch = reinterpret_cast<float*>(xs) + wave * 32 * KT_LD;
 
     int klen = (int)a.key_lens[b];
@@ -1504,24 +1512,26 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
             mfma_x6(dp, gfr, vf[st]);
         }
         float ds[16];
-        // dropout: keys 2j, 2j+1 (neighbouring lanes) share one hash per query row -- the even lane computes it for the even
-        // registers, the odd lane for the odd ones, and a quad-permute DPP move hands the other half over
+        // dropout: keys 4j .. 4j+3 (a quad of lanes) share one hash word per query row -- lane 4j+i computes it for registers
+        // r+i of each group of four, quad-permute DPP broadcasts hand every lane the word of each row, and the lane's own
+        // multiplier (its key & 3) picks its 16 bits
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            uint32_t h0 = 0, h1 = 0;
+        for (int r = 0; r < 16; r += 4) {
+            uint32_t hq[4] = {0u, 0u, 0u, 0u};
             if (a.thr != 0u) {
-                const int rr = r + (lane & 1);
-                const uint32_t mine = attn_hash(seed_eff, (uint32_t)(arow + qt0 + acc_row(rr, half)), (uint32_t)kg >> 1);
-                const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);   // lane ^ 1
-                h0 = (lane & 1) ? other : mine;
-                h1 = (lane & 1) ? mine : other;
+                const int rr = r + (lane & 3);
+                const uint32_t mine = attn_quad_hash(seed_eff, (uint32_t)(arow + qt0 + acc_row(rr, half)), (uint32_t)kg >> 2);
+                hq[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0x00, 0xF, 0xF, true);   // quad_perm [0,0,0,0]
+                hq[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0x55, 0xF, 0xF, true);
+                hq[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xAA, 0xF, 0xF, true);
+                hq[3] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xFF, 0xF, 0xF, true);
             }
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < 4; ++e) {
                 float g = dp[r + e];
                 float pk = pd[r + e];
                 if (a.thr != 0u) {
-                    const bool keep = keep_from_hash(e ? h1 : h0, (uint32_t)kg & 1u, a.thr);
+                    const bool keep = attn_keep_word(hq[e], key_mult, thr16);
                     g = keep ? g * a.drop_scale : 0.f;
                     pk = keep ? pk * a.drop_scale : 0.f;
                 }
@@ -1659,6 +1669,7 @@ __device__ __forceinline__ void load_lane_frags_h3(const float* scratch, int l31
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArgs a) {
     const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
+    const uint32_t thr16 = a.thr << 16;
     extern __shared__ __attribute__((aligned(16))) uint32_t xsd[];
     uint32_t* Kr = xsd;              // [2][64 keys][64 d]       f16 hi / lo of K * 2^4
     uint32_t* Vr = xsd + 2 * XP;     // [2][64 keys][64 d]       of V * 2^4
@@ -1758,17 +1769,17 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
             // a tile every lane sees in full needs no mask arithmetic (wave-uniform test)
             const bool full = (key0 + 32 <= klen) && (!CAUSAL || key0 + 31 <= qw0);
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
+            for (int r = 0; r < 16; r += 4) {
                 const int key_g = key0 + acc_row(r, half);
-                uint32_t hsh = 0;
-                if (a.thr != 0u) hsh = attn_hash(seed_eff, rowid, (uint32_t)key_g >> 1);
+                uint32_t qh = 0;
+                if (a.thr != 0u) qh = attn_quad_hash(seed_eff, rowid, (uint32_t)key_g >> 2);
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
+                for (int e = 0; e < 4; ++e) {
                     const int kg = key_g + e;
-                    float p = exp2f(__builtin_fmaf(s[r + e], H3A_C2, -lse_q2));
+                    float p = fast_exp2(__builtin_fmaf(s[r + e], H3A_C2, -lse_q2));
                     if (!full) p = (kg < klen && (!CAUSAL || kg <= qg)) ? p : 0.f;
                     float g = dp[r + e] * dp_unscale;
-                    if (a.thr != 0u) g = keep_from_hash(hsh, (uint32_t)e, a.thr) ? g * a.drop_scale : 0.f;
+                    if (a.thr != 0u) g = attn_keep_word(qh, attn_drop_mult(e), thr16) ? g * a.drop_scale : 0.f;
                     ds[r + e] = p * (g - delta);
                 }
             }
@@ -1812,6 +1823,7 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnArgs a) {
     const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
+    const uint32_t thr16 = a.thr << 16;
     extern __shared__ __attribute__((aligned(16))) uint32_t xsd[];
     uint32_t* xs = xsd;
     uint32_t* Qr = xs;                      // [2][32 q][64 d]     f16 hi / lo of Q / 8 * 2^4
@@ -1828,6 +1840,7 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
     const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
     const int k0 = kblk * QB, kw0 = k0 + wave * 32;
     const int kg = kw0 + l31;
+    const uint32_t key_mult = attn_drop_mult((uint32_t)kg);
     float* scratch = reinterpret_cast<float*>(xs) + wave * 32 * KT_LD;
 
     int klen = (int)a.key_lens[b];
@@ -1933,7 +1946,7 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q_g = qt0 + acc_row(r, half);
-            float p = exp2f(__builtin_fmaf(s[r], H3A_C2, -lse_s[acc_row(r, half)] * 1.4426950408889634f));
+            float p = fast_exp2(__builtin_fmaf(s[r], H3A_C2, -lse_s[acc_row(r, half)] * 1.4426950408889634f));
             if (!full) p = (kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq) ? p : 0.f;
             pd[r] = p;
         }
@@ -1945,24 +1958,26 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
             mfma_h3(dp, gfr, vf[st]);
         }
         float ds[16];
-        // dropout: keys 2j, 2j+1 (neighbouring lanes) share one hash per query row -- the even lane computes it for the even
-        // registers, the odd lane for the odd ones, and a quad-permute DPP move hands the other half over
+        // dropout: keys 4j .. 4j+3 (a quad of lanes) share one hash word per query row -- lane 4j+i computes it for registers
+        // r+i of each group of four, quad-permute DPP broadcasts hand every lane the word of each row, and the lane's own
+        // multiplier (its key & 3) picks its 16 bits
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            uint32_t h0 = 0, h1 = 0;
+        for (int r = 0; r < 16; r += 4) {
+            uint32_t hq[4] = {0u, 0u, 0u, 0u};
             if (a.thr != 0u) {
-                const int rr = r + (lane & 1);
-                const uint32_t mine = attn_hash(seed_eff, (uint32_t)(arow + qt0 + acc_row(rr, half)), (uint32_t)kg >> 1);
-                const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);   // lane ^ 1
-                h0 = (lane & 1) ? other : mine;
-                h1 = (lane & 1) ? mine : other;
+                const int rr = r + (lane & 3);
+                const uint32_t mine = attn_quad_hash(seed_eff, (uint32_t)(arow + qt0 + acc_row(rr, half)), (uint32_t)kg >> 2);
+                hq[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0x00, 0xF, 0xF, true);   // quad_perm [0,0,0,0]
+                hq[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0x55, 0xF, 0xF, true);
+                hq[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xAA, 0xF, 0xF, true);
+                hq[3] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xFF, 0xF, 0xF, true);
             }
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < 4; ++e) {
                 float g = dp[r + e] * dp_unscale;
                 float pk = pd[r + e];
                 if (a.thr != 0u) {
-                    const bool keep = keep_from_hash(e ? h1 : h0, (uint32_t)kg & 1u, a.thr);
+                    const bool keep = attn_keep_word(hq[e], key_mult, thr16);
                     g = keep ? g * a.drop_scale : 0.f;
                     pk = keep ? pk * a.drop_scale : 0.f;
                 }

@@ -70,9 +70,24 @@ __device__ __forceinline__ bool keep_from_hash(uint32_t h, uint32_t odd, uint32_
 __device__ __forceinline__ bool keep_elem(uint64_t seed, uint64_t idx, uint32_t thr) {
     return keep_from_hash(hash_pair(seed, (uint32_t)(idx >> 1), (uint32_t)(idx >> 33)), (uint32_t)idx & 1u, thr);
 }
-// attention-weight form: element (row, key) of the (B*H*Tq, Tk) weight matrix; keys 2j and 2j+1 share a hash
-__device__ __forceinline__ uint32_t attn_hash(uint64_t seed, uint32_t row, uint32_t key_pair) {
-    return hash_pair(seed, row, key_pair + 0x632BE5ABu);
+// attention-weight form: element (row, key) of the (B*H*Tq, Tk) weight matrix.  Keys 4j .. 4j+3 of a row share ONE mixed
+// 32-bit word (attn_quad_hash); key 4j+e keeps its weight iff the top 16 bits of word * ATTN_DROP_MULT[e] reach the
+// threshold, i.e. iff (word * mult) >= (thr << 16) -- one multiply and one compare per weight, no field extraction.  The
+// forward / dq kernels hold four neighbouring keys in four registers of a lane (one hash per four weights); in the dk/dv
+// kernels a lane is a key and a quad of lanes shares the word through a DPP broadcast.
+__device__ __forceinline__ uint32_t attn_quad_hash(uint64_t seed, uint32_t row, uint32_t key_quad) {
+    uint32_t x = (row * 0x9E3779B1u) ^ ((key_quad + 0x632BE5ABu) * 0x85EBCA77u) ^ (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0xC2B2AE3Du);
+    x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu;
+    return x;
+}
+__device__ __forceinline__ uint32_t attn_drop_mult(uint32_t key) {
+    const uint32_t e = key & 3u;
+    return e == 0u ? 0x9E3779B1u : e == 1u ? 0xC2B2AE3Du : e == 2u ? 0x27D4EB2Fu : 0x165667B1u;
+}
+// thr16 = thr << 16 (thr = drop_threshold(p) < 65536)
+__device__ __forceinline__ bool attn_keep_word(uint32_t quad_hash, uint32_t mult, uint32_t thr16) { return quad_hash * mult >= thr16; }
+__device__ __forceinline__ bool attn_keep(uint64_t seed, uint32_t row, uint32_t key, uint32_t thr16) {
+    return attn_keep_word(attn_quad_hash(seed, row, key >> 2), attn_drop_mult(key), thr16);
 }
 
 // ---------------------------------------------------------------- wave helpers (wave = 64 lanes)
