@@ -917,7 +917,11 @@ static GemmArgs base_args() {
 
 static int aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-// how the row (reduction) dimension of a weight gradient is split: about 768 workgroups (3 per CU) in flight
+// how the row (reduction) dimension of a weight gradient is split.  The fp32-MFMA / bf16x6 kernels aim at about 768
+// workgroups (3 per CU).  The fp16x3 kernel holds two workgroups per CU, so 768 is one full round plus a half-empty one;
+// it gets ONE round -- 512 workgroups for outputs of more than 12 tiles over long row ranges, else 256: every split costs
+// a partial tile written and read again, which for the small outputs weighs more than a second workgroup per CU brings
+// (measured on the step's shapes, tools/wgrad_bench.py: 256x256 118 -> 134, 768x256 157 -> 188, 256x1024 189 -> 214 TF).
 struct WgradPlan { int tile; int nsplit; int kt_per_split; };
 static WgradPlan plan_wgrad(int64_t M, int N, int K, int taps, bool x6 = false, int bk = BK) {
     WgradPlan p;
@@ -932,7 +936,11 @@ static WgradPlan plan_wgrad(int64_t M, int N, int K, int taps, bool x6 = false, 
     } else if (tiles < 16) {
         p.tile = TILE_64; tiles = (long)cdiv(N, 64) * cdiv(K, 64) * taps;
     }
-    long want = 768 / tiles;
+    static const long forced = getenv("TTTS_WGRAD_BLOCKS") ? atol(getenv("TTTS_WGRAD_BLOCKS")) : 0;   // experiments
+    long target = 768;
+    if (bk == HBK) target = (tiles > 12 && nkt >= 800) ? 512 : 256;
+    if (forced > 0) target = forced;
+    long want = target / tiles;
     if (want < 1) want = 1;
     if (x6 && want > 128) want = 128;
     if (want > nkt) want = nkt;
