@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(GemmArgs g) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 uint32_t h, l;
-                split2_pair(f32x2{col[2 * p], col[2 * p + 1]} * scale, h, l);
+                split2_scaled(col[2 * p], col[2 * p + 1], scale, h, l);
                 hi[p] = h; lo[p] = l;
             }
             *reinterpret_cast<u32x4*>(base + dst[e]) = hi;

@@ -90,6 +90,22 @@ __device__ __forceinline__ bool attn_keep(uint64_t seed, uint32_t row, uint32_t 
     return attn_keep_word(attn_quad_hash(seed, row, key >> 2), attn_drop_mult(key), thr16);
 }
 
+// ---------------------------------------------------------------- two-way f16 split of a pair of fp32 values
+// hi = f16(x * scale), lo = f16(x * scale - hi), both pairs packed (element 0 in the low half).  Four mixed-precision
+// FMAs (v_fma_mixlo/mixhi_f16: fp32 x fp32 [+ f16] -> f16 written into one half of the destination) instead of
+// multiply + pack-convert + two conversions back + subtract + pack-convert: same bits (scale is a power of two, so
+// x * scale is exact and each value is rounded once), a third fewer instructions.  Used by the weight-gradient loader
+// (-4 % kernel time); in the attention kernels and the forward GEMM staging the same swap measured 3-7 % SLOWER (the
+// compiler schedules its own conversion sequence around the MFMAs better than opaque asm), so they keep split2_pair.
+__device__ __forceinline__ void split2_scaled(float x0, float x1, float scale, uint32_t& hi, uint32_t& lo) {
+    uint32_t h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x0), "v"(scale));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x1), "v"(scale));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(scale), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(scale), "v"(h));
+    hi = h; lo = l;
+}
+
 // ---------------------------------------------------------------- wave helpers (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
