@@ -21,9 +21,8 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     ts()
     torch.cuda.synchronize()
-for ev in prof.key_averages(group_by_stack_n=6):
+for ev in prof.key_averages(group_by_stack_n=12):
     if ev.key.startswith("aten::") and ev.device_time_total > 0 and ev.key not in ("aten::empty",):
         print(f"{ev.key:28s} n={ev.count:3d} dev_us={ev.device_time_total:8.1f}")
-        for fr in ev.stack[:6]:
-            if "transformertts_amd" in fr or "bench" in fr:
-                print("      ", fr)
+        for fr in ev.stack[:12]:
+            print("      ", fr)

@@ -863,10 +863,13 @@ class CrossAttentionFn(torch.autograd.Function):
         if attn is None:       # weights not requested: single-pass online softmax, nothing written
             attn = torch.empty(0, dtype=torch.float32, device=q.device)
         ctx.mark_non_differentiable(attn)
+        ctx.set_materialize_grads(False)     # or the engine fills a zero "gradient" the size of the weights every backward
         return o, attn
 
     @staticmethod
     def backward(ctx, do, _dattn):
+        if do is None:
+            return None, None, None, None, None, None, None
         lib = _lib.load()
         q, kv, o, lse, lens = ctx.saved_tensors
         n_head, drop_p, seed = ctx.cfg
