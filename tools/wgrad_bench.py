@@ -52,5 +52,5 @@ def conv(B, T, cin, cout):
 for (M, N, K) in [(55680, 256, 256), (55680, 768, 256), (55680, 1024, 256), (55680, 256, 1024), (55680, 512, 256),
                   (55680, 256, 80), (55680, 80, 256), (6400, 768, 256), (6400, 1024, 256), (6400, 256, 1024)]:
     lin(M, N, K)
-for (B, T, cin, cout) in [(64, 870, 512, 512), (64, 870, 80, 512), (64, 870, 512, 80), (64, 100, 256, 256)]:
+for (B, T, cin, cout) in [(64, 870, 256, 256), (64, 870, 80, 256), (64, 870, 256, 80), (64, 100, 256, 256), (32, 870, 512, 512)]:
     conv(B, T, cin, cout)

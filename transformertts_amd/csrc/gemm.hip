@@ -937,8 +937,23 @@ static WgradPlan plan_wgrad(int64_t M, int N, int K, int taps, bool x6 = false, 
         p.tile = TILE_64; tiles = (long)cdiv(N, 64) * cdiv(K, 64) * taps;
     }
     static const long forced = getenv("TTTS_WGRAD_BLOCKS") ? atol(getenv("TTTS_WGRAD_BLOCKS")) : 0;   // experiments
+    static const int big = getenv("TTTS_WGRAD_256") ? atoi(getenv("TTTS_WGRAD_256")) : 1;
     long target = 768;
-    if (bk == HBK) target = (tiles > 12 && nkt >= 800) ? 512 : 256;
+    if (bk == HBK) {
+        // The kernel's speed is set by the operand bytes its workgroups request (tiles x rows x (BM + BN) x 4 B at about
+        // 7.7 TB/s over the chip: 1024x256 with 128-wide tiles asks for 913 MB = 119 us, measured 119), so outputs of three
+        // or more 256 x 256 tiles take the 8-wave 256-wide tile (half the bytes per product) on one workgroup per CU.  Smaller
+        // outputs stay on the 128-wide tile: at 256 row splits their partial sums (256 KB each, written and read back)
+        // would cost what the operands save.
+        const long tiles256 = (long)cdiv(N, 256) * cdiv(K, 256) * taps;
+        if (big && p.tile == TILE_128 && N >= 256 && K >= 256 && tiles256 >= 3 && nkt >= 800) {
+            p.tile = H3_TILE_256;
+            tiles = tiles256;
+            target = 256;
+        } else {
+            target = (tiles > 12 && nkt >= 800) ? 512 : 256;
+        }
+    }
     if (forced > 0) target = forced;
     long want = target / tiles;
     if (want < 1) want = 1;

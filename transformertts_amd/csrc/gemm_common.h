@@ -93,7 +93,8 @@ __device__ __forceinline__ void weight_split_h3_one(const float* __restrict__ w,
     planes[o + (long)R * 32] = __builtin_bit_cast(unsigned short, l);
 }
 
-enum { TILE_AUTO = 0, TILE_64 = 1, TILE_128 = 2, TILE_64x128 = 3, TILE_128x96 = 4, TILE_96x128 = 5 };
+enum { TILE_AUTO = 0, TILE_64 = 1, TILE_128 = 2, TILE_64x128 = 3, TILE_128x96 = 4, TILE_96x128 = 5,
+       H3_TILE_256 = 6, H3_TILE_256x128 = 7 };     // 8-wave tiles of the fp16x3 kernels
 
 // fp16x3 split-precision GEMM (gemm_h3.hip): true when it can take this problem (shape constraints of its 32-deep
 // k-tiles); the caller falls back to the bf16x6 kernel otherwise

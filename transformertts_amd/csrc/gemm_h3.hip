@@ -390,7 +390,6 @@ bool h3_supports(const GemmArgs& g) {
     return g.K % HBK == 0 && g.cin % HBK == 0 && g.N % 4 == 0 && (uint64_t)g.N * g.K * 4 < (1ull << 32);
 }
 
-enum { H3_TILE_256 = 6, H3_TILE_256x128 = 7 };
 
 int h3_tile_choice(long M, long N) {
     static int forced = -1;                       // development aid: TTTS_H3_TILE forces a tile shape
@@ -448,10 +447,13 @@ int dispatch_h3(const GemmArgs& g, hipStream_t stream) {
 __device__ __forceinline__ int wg_swz(int row) { return (((row >> 1) ^ (row >> 3)) & 1) | (((row >> 2) & 1) << 1); }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_kernel(GemmArgs g) {
+    constexpr int NT = WM * WN * 64, HALF = NT / 2;             // half of the threads stage dy, the other half x
+    constexpr bool TWO_SETS = (WM * WN == 4);                   // 8 waves: 128 accumulator registers leave room for one set
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    static_assert(WM * WN == 4 && BM <= 128 && BN <= 128 && BM % 32 == 0 && BN % 32 == 0, "4 waves, <= 128 columns per operand");
+    static_assert((WM * WN == 4 || WM * WN == 8) && BM <= HALF && BN <= HALF && BM % 32 == 0 && BN % 32 == 0,
+                  "4 or 8 waves, at most one operand column per staging thread");
     constexpr int A_PLANE = BM * 16, B_PLANE = BN * 16;         // dwords per plane (64-byte rows)
     constexpr int STAGE = 2 * (A_PLANE + B_PLANE);
     constexpr int QA = BM / 4, QB = BN / 4;                     // column quads per operand tile
@@ -462,8 +464,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(GemmArgs g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int z = blockIdx.z;
+    // XCD-aware numbering (as the forward kernel): workgroups are dealt round-robin to the 8 XCDs in x-fastest order, so the
+    // tiles of one row split -- which read the same rows of dy and x -- would land on different L2s and each fetch its
+    // operands from HBM again (a 1024 x 256 weight asks for 3.2x the unique bytes).  Renumbered, XCD e works on one
+    // contiguous run of (split, tile) pairs: the tiles of a split start together on the CUs of one XCD and share its L2.
+    int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int total = gx * gy * (int)gridDim.z;
+        const int bid = bx + gx * (by + gy * z);
+        const int per = total >> 3, rem = total & 7;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int t = xcd * per + min(xcd, rem) + slot;
+        bx = t % gx;
+        by = (t / gx) % gy;
+        z = t / (gx * gy);
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const int ztap = (g.ztaps > 1) ? (z % g.ztaps) : 0;
     const int zsplit = (g.ztaps > 1) ? (z / g.ztaps) : z;
     const int nkt = (g.K + HBK - 1) / HBK;
@@ -487,14 +504,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // loader roles: threads [0, BM) stage the dy tile, threads [128, 128 + BN) the x tile; thread -> (column quad q, row
+    // loader roles: threads [0, BM) stage the dy tile, threads [NT/2, NT/2 + BN) the x tile; thread -> (column quad q, row
     // group rg of 8 rows).  Rows past the end of the operand fall outside the buffer descriptor (hardware 0), columns past
     // the matrix edge only feed accumulator rows / columns that are never stored, and the utterance clipping of shifted
     // rows is applied to the loaded VALUES from one 8-bit mask per step.
-    // the role is wave-uniform (waves 0-1: dy, waves 2-3: x); say so, or the buffer descriptor select below becomes a
-    // per-lane value and every load is wrapped in a waterfall loop
-    const bool is_b = __builtin_amdgcn_readfirstlane(tid >> 7) != 0;
-    const int tl = tid & 127;
+    // the role is wave-uniform (first half of the waves: dy, second half: x); say so, or the buffer descriptor select
+    // below becomes a per-lane value and every load is wrapped in a waterfall loop
+    const bool is_b = __builtin_amdgcn_readfirstlane(tid / HALF) != 0;
+    const int tl = tid % HALF;
     const int QX = is_b ? QB : QA;
     const bool slot = tl < (is_b ? BN : BM);
     const int q = tl % QX, rg = tl / QX;                        // rg < 4 for every slot thread
@@ -520,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(GemmArgs g) {
     }
     const int plane_stride = is_b ? B_PLANE : A_PLANE;
 
-    f32x4 v0[8], v1[8];
+    f32x4 v0[8], v1[TWO_SETS ? 8 : 1];
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
     // The loads are inline assembly so that hipcc does not count them: with two register sets in flight it otherwise
@@ -608,28 +625,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(GemmArgs g) {
                 }
         }
     };
-    // step kt: LDS[buf] holds step kt, X the rows of step kt+1 (requested a step ago), Y is free
-    auto step = [&](f32x4 (&X)[8], f32x4 (&Y)[8], int buf, bool more1, bool more2) {
-        if (more1) arrived(X);
-        if (more2) issue(Y);
-        compute(buf);
-        if (more1) stash(X, buf ^ 1);
-        __syncthreads();
-    };
-
     if (kt_begin < kt_end) {
         issue(v0);
         arrived(v0);
-        if (kt_begin + 1 < kt_end) issue(v1);
-        stash(v0, 0);
-        __syncthreads();
-        for (int kt = kt_begin; kt < kt_end; kt += 2) {
-            step(v1, v0, 0, kt + 1 < kt_end, kt + 2 < kt_end);
-            if (kt + 1 < kt_end) step(v0, v1, 1, kt + 2 < kt_end, kt + 3 < kt_end);
+        if constexpr (TWO_SETS) {
+            // step kt: LDS[buf] holds step kt, X the rows of step kt+1 (requested a step ago), Y is free
+            auto step = [&](f32x4 (&X)[8], f32x4 (&Y)[8], int buf, bool more1, bool more2) {
+                if (more1) arrived(X);
+                if (more2) issue(Y);
+                compute(buf);
+                if (more1) stash(X, buf ^ 1);
+                __syncthreads();
+            };
+            if (kt_begin + 1 < kt_end) issue(v1);
+            stash(v0, 0);
+            __syncthreads();
+            for (int kt = kt_begin; kt < kt_end; kt += 2) {
+                step(v1, v0, 0, kt + 1 < kt_end, kt + 2 < kt_end);
+                if (kt + 1 < kt_end) step(v0, v1, 1, kt + 2 < kt_end, kt + 3 < kt_end);
+            }
+        } else {
+            // one register set: the rows of step kt+1 are requested before the products of step kt and staged behind them
+            stash(v0, 0);
+            __syncthreads();
+            int buf = 0;
+            for (int kt = kt_begin; kt < kt_end; ++kt) {
+                const bool more = kt + 1 < kt_end;
+                if (more) issue(v0);
+                compute(buf);
+                if (more) { arrived(v0); stash(v0, buf ^ 1); }
+                __syncthreads();
+                buf ^= 1;
+            }
         }
     }
 
-    if (g.colsum != nullptr && blockIdx.x == 0 && ztap == 0) {
+    if (g.colsum != nullptr && bx == 0 && ztap == 0) {
         float* fs = reinterpret_cast<float*>(lds);
         __syncthreads();
         if (!is_b && slot) {
@@ -661,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_h3_kernel(GemmArgs g) {
 template <int BM, int BN, int WM, int WN>
 static int launch_wgrad_h3(const GemmArgs& g, int zdim, hipStream_t stream) {
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), zdim);
-    hipLaunchKernelGGL((wgrad_h3_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, stream, g);
+    hipLaunchKernelGGL((wgrad_h3_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), 0, stream, g);
     TTTS_LAUNCH_CHECK("wgrad_h3_kernel");
     return TTTS_OK;
 }
@@ -671,6 +702,7 @@ int dispatch_wgrad_h3(const GemmArgs& g, int zdim, int tile, hipStream_t stream)
         case TILE_64: return launch_wgrad_h3<64, 64, 2, 2>(g, zdim, stream);
         case TILE_128x96: return launch_wgrad_h3<128, 96, 4, 1>(g, zdim, stream);
         case TILE_96x128: return launch_wgrad_h3<96, 128, 1, 4>(g, zdim, stream);
+        case H3_TILE_256: return launch_wgrad_h3<256, 256, 2, 4>(g, zdim, stream);
         default: return launch_wgrad_h3<128, 128, 2, 2>(g, zdim, stream);
     }
 }
