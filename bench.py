@@ -110,7 +110,9 @@ class GemmProbe:
                 e0.record()
                 rc = _fn(*a)
                 e1.record()
-                self.records.append((e0, e1, 2.0 * M * N * K, (_x6, tile)))
+                # compulsory HBM bytes of the launch: the activation read once, the output written once, the weights once
+                # (residual / gate operands of some epilogues not counted)
+                self.records.append((e0, e1, 2.0 * M * N * K, (_x6, tile), 4.0 * (M * K + M * N + N * K)))
                 return rc
             setattr(self.lib, n, wrapped)
         return self
@@ -122,15 +124,16 @@ class GemmProbe:
     def summary(self):
         torch.cuda.synchronize()
         groups = {}
-        for e0, e1, fl, key in self.records:
-            g = groups.setdefault(key, [0, 0.0, 0.0])
+        for e0, e1, fl, key, nbytes in self.records:
+            g = groups.setdefault(key, [0, 0.0, 0.0, 0.0])
             g[0] += 1
             g[1] += e0.elapsed_time(e1)
             g[2] += fl
+            g[3] += nbytes
         if not groups:
             return None
         key = max(groups, key=lambda k: groups[k][1])
-        n, ms, fl = groups[key]
+        n, ms, fl, nbytes = groups[key]
         x6, tile = key
         name = (f"gemm_f32_kernel<{self.TILES[tile]},true,*>", f"gemm_bf16x6_kernel<{self.TILES[tile]}>",
                 f"gemm_h3_kernel<{self.TILES[tile]}>")[x6]
@@ -138,7 +141,8 @@ class GemmProbe:
                                                                               "tflops": v[2] / (v[1] * 1e-3) / 1e12}
                   for k, v in groups.items()}
         return {"kernel": name, "form": x6, "launches": n, "avg_ms": ms / n, "avg_flops": fl / n,
-                "tflops": fl / (ms * 1e-3) / 1e12, "total_ms": ms, "all": others}
+                "tflops": fl / (ms * 1e-3) / 1e12, "total_ms": ms, "all": others, "avg_bytes": nbytes / n,
+                "gbps": nbytes / (ms * 1e-3) / 1e9}
 
 
 def usable_cores() -> int:
@@ -406,6 +410,12 @@ def main():
                                "avg_launch_gflop": probe["avg_flops"] / 1e9, "step_share_ms": probe["total_ms"]}
             if terms:
                 out["roofline"]["executed_16bit_mfma_tflops"] = terms * probe["tflops"]
+            # the same launches against the other ceiling: at K = 256 (most of them) the kernel moves 285 MB for 29 GFLOP, and
+            # its time follows the bytes its tiles request from L2 / HBM rather than the MFMA count
+            out["roofline"]["hbm_view"] = {"achieved": probe["gbps"], "peak": 8000.0, "unit": "GB/s",
+                                           "frac": probe["gbps"] / 8000.0,
+                                           "algorithmic_bytes_per_launch": probe["avg_bytes"],
+                                           "bytes_are": "4 * (M*K + M*N + N*K) per launch: activation read, output write, weights"}
             out["roofline"]["gemm_kernels"] = probe["all"]
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.tp, args.config)
