@@ -300,6 +300,20 @@ def test_attention_forms_agree(causal, Tq, Tk, lens):
     assert _rel(b[0], a[0]) < TOL and _rel(b[2], a[2]) < TOL and _rel(b[3], a[3]) < TOL
     if a[1] is not None:      # same counter-based mask in both forms: identical zero pattern
         assert torch.equal(a[1] == 0, b[1] == 0)
+        # ... and the BACKWARD kernels regenerate exactly the mask the forward applied: an fp64 reference that drops the
+        # weights the returned (post-dropout) weights show as dropped must reproduce output and all three gradients
+        keep = (a[1] != 0) | mask.expand_as(a[1])            # masked keys are zero with or without dropout
+        for t in (qd, kd, vd):
+            t.grad = None
+        pd = torch.softmax((qd @ kd.transpose(-1, -2) / 8.0).masked_fill(mask, float("-inf")), -1) * keep / 0.75
+        od = (pd @ vd).transpose(1, 2).reshape(B, Tq, d)
+        od.backward(do.double())
+        dq2 = qd.grad.transpose(1, 2).reshape(B, Tq, d)
+        dkv2 = torch.cat([kd.grad.transpose(1, 2).reshape(B, Tk, d), vd.grad.transpose(1, 2).reshape(B, Tk, d)], -1)
+        for o, attn, dq, dkv in (a, b):
+            assert _rel(o, od) < TOL and _rel(dq, dq2) < TOL and _rel(dkv, dkv2) < TOL, (_rel(o, od), _rel(dq, dq2), _rel(dkv, dkv2))
+        drop_rate = 1.0 - float(keep[~mask.expand_as(keep)].double().mean())
+        assert abs(drop_rate - 0.25) < 0.02, drop_rate
 
 
 @pytest.mark.parametrize("causal,Tq,Tk,lens", [(1, 200, 200, [200, 131, 64]), (0, 150, 70, [70, 33, 1]), (0, 33, 129, [129, 128, 5]),
