@@ -6,13 +6,17 @@ i=0
 while read -r set; do
   [ -z "$set" ] && continue
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/set$i -- python3 tools/h3_probe.py $M $N $K 3 > $out/set$i.log 2>&1
-  echo "set $i done: $set"
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/set$i -- python3 tools/h3_probe.py $M $N $K 3 > $out/set$i.log 2>&1 || exit 1
 done <<SETS
 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES
 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS
 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA
-SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VMEM
-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC
+SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_VMEM
 TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
+TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum
+FETCH_SIZE
+WRITE_SIZE
 SETS
+python3 tools/pmc_report.py $out gemm_h3 > $out/report.txt
+find $out -name "*.csv" -delete; find $out -type d -empty -delete

@@ -52,6 +52,18 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, uint32_
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+// ... with a wave-uniform scalar byte offset on top of the per-lane one, and the matching 16-byte store (an offset at or
+// beyond the descriptor's extent reads 0 / writes nothing)
+__device__ __forceinline__ float4 buf_load4s(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint32_t soff) {
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, (int)soff, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+__device__ __forceinline__ void buf_store4s(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint32_t soff, float4 x) {
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ v = {__float_as_uint(x.x), __float_as_uint(x.y), __float_as_uint(x.z), __float_as_uint(x.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, (int)soff, 0);
+}
 
 // ---- fp16x3 ("h3") split: constants and the weight-plane image (see gemm_h3.hip)
 constexpr int HBK = 32;                 // k-tile depth

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "gemm_common.h"
+#include <type_traits>
 
 namespace ttts {
 
@@ -297,72 +298,151 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
     // tile, so that a bias-only epilogue (in-projections, FFN1, convolutions) issues its stores back to back; residual /
     // gate operands are requested per slab, all of them before the slab's first store.
     float cmax = 0.f;                 // max|C| of what this lane stores (published when g.c_amax is set)
+    // Fast form (every tile whose lanes keep one column group, outputs below 4 GB): the epilogue of a K = 256 GEMM is as long
+    // as its main loop, and written naively it spends ~27 vector instructions per output element on index arithmetic,
+    // bounds tests, unconditional residual / gate arithmetic and a separate scale multiply (counters: 10 VALU per MFMA
+    // over the whole kernel).  Here the store / load offsets are ONE per-lane 32-bit offset plus a scalar offset per slab
+    // row group (buffer instructions: rows past M fall outside the descriptor, so no row test), the scale-back rides in the
+    // bias FMA, and the residual / gate / dropout arithmetic exists only in the variant that needs it.
     float4 bias_fixed = make_float4(0.f, 0.f, 0.f, 0.f);
     if (EVEN) bias_fixed = buf_load4(rsrcBias, (col_base + 4 * (lane % C4) < g.N) ? (uint32_t)(col_base + 4 * (lane % C4)) * 4u : OOB);
+    // (dispatch_h3 checks that output / residual byte offsets, one tile of overhang included, stay below 4 GB)
+    if constexpr (EVEN) {
+        constexpr int RPI = 64 / C4;                              // slab rows covered by one wave instruction
+        const int c4 = lane % C4, rsub = lane / C4;
+        const int col = col_base + 4 * c4;
+        const bool col_ok = col < g.N;
+        const long row_l = (long)m0 + wm * WTM + rsub;            // this lane's row in slab 0, group 0
+        const uint32_t offC = col_ok ? (uint32_t)((row_l * g.ldc + col) * 4) : OOB;
+        const uint32_t offR = col_ok ? (uint32_t)((row_l * g.ldr + col) * 4) : OOB;
+        const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(C, 0, (uint32_t)((long)g.M * g.ldc * 4), 0x00020000);
+        const bool want_max = g.c_amax != nullptr;
+        const float relu_lo = (g.act == 1) ? 0.f : -__builtin_inff();
+        auto run = [&](auto has_res_c, auto has_gate_c) {
+            constexpr bool HAS_RES = decltype(has_res_c)::value, HAS_GATE = decltype(has_gate_c)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(slab + l31 * EP_LD + j * 32 + 8 * q + 4 * half) =
-                    make_float4(acc[i][j][4 * q] * out_scale, acc[i][j][4 * q + 1] * out_scale,
-                                acc[i][j][4 * q + 2] * out_scale, acc[i][j][4 * q + 3] * out_scale);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const long row_base = m0 + wm * WTM + i * 32;
-        // the slab leaves in groups of GR float4 per lane: the auxiliary operands of a group are all requested before its
-        // first store (a bias-only epilogue has none and issues its stores back to back)
-        constexpr int GR = (NIT % 4 == 0) ? 4 : NIT;
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(slab + l31 * EP_LD + j * 32 + 8 * q + 4 * half) =
+                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                constexpr int GR = (NIT % 4 == 0) ? 4 : NIT;
 #pragma unroll
-        for (int g0 = 0; g0 < NIT; g0 += GR) {
-            float4 r4[GR], g4[GR];
+                for (int g0 = 0; g0 < NIT; g0 += GR) {
+                    float4 r4[HAS_RES ? GR : 1], g4[HAS_GATE ? GR : 1];
 #pragma unroll
-            for (int u = 0; u < GR; ++u) {
-                const int idx = (g0 + u) * 64 + lane;
-                const int r = idx / C4, c4 = idx - r * C4;
-                const long row = row_base + r;
-                const int col = col_base + 4 * c4;
-                const bool ok = (EVEN || idx < 32 * C4) && row < g.M && col < g.N;
-                r4[u] = has_res ? buf_load4(rsrcR, ok ? (uint32_t)((row * g.ldr + col) * 4) : OOB) : make_float4(0.f, 0.f, 0.f, 0.f);
-                g4[u] = has_gate ? buf_load4(rsrcG, ok ? (uint32_t)((row * g.ldc + col) * 4) : OOB) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    for (int u = 0; u < GR; ++u) {
+                        const int rg = i * 32 + (g0 + u) * RPI;           // slab row group, wave-uniform
+                        if (HAS_RES) r4[u] = buf_load4s(rsrcR, offR, (uint32_t)(rg * g.ldr * 4));
+                        if (HAS_GATE) g4[u] = buf_load4s(rsrcG, offC, (uint32_t)(rg * g.ldc * 4));
+                    }
+#pragma unroll
+                    for (int u = 0; u < GR; ++u) {
+                        const int rg = i * 32 + (g0 + u) * RPI;
+                        const float4 a4 = *reinterpret_cast<const float4*>(slab + ((g0 + u) * RPI + rsub) * EP_LD + 4 * c4);
+                        float v[4] = {__builtin_fmaf(a4.x, out_scale, bias_fixed.x), __builtin_fmaf(a4.y, out_scale, bias_fixed.y),
+                                      __builtin_fmaf(a4.z, out_scale, bias_fixed.z), __builtin_fmaf(a4.w, out_scale, bias_fixed.w)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_lo);
+                        if (do_drop) {                       // elements 2i, 2i+1 share a hash (keep_elem): two hashes per float4
+                            const uint64_t eidx = (uint64_t)(row_l + rg) * (uint64_t)g.N + (uint64_t)col;
+                            const uint32_t h01 = hash_pair(seed_eff, (uint32_t)(eidx >> 1), (uint32_t)(eidx >> 33));
+                            const uint32_t h23 = hash_pair(seed_eff, (uint32_t)((eidx + 2) >> 1), (uint32_t)((eidx + 2) >> 33));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                v[e] = keep_from_hash(e < 2 ? h01 : h23, (uint32_t)e & 1u, g.drop_thr) ? v[e] * g.drop_scale : 0.f;
+                        }
+                        if (HAS_GATE) {
+                            const float gg[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gg[e] > 0.f ? v[e] * g.relu_scale : 0.f;
+                        }
+                        if (HAS_RES) { v[0] += r4[u].x; v[1] += r4[u].y; v[2] += r4[u].z; v[3] += r4[u].w; }
+                        buf_store4s(rsrcC, offC, (uint32_t)(rg * g.ldc * 4), make_float4(v[0], v[1], v[2], v[3]));
+                        if (want_max && col_ok && row_l + rg < g.M)
+                            cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-#pragma unroll
-            for (int u = 0; u < GR; ++u) {
-                const int idx = (g0 + u) * 64 + lane;
-                const int r = idx / C4, c4 = idx - r * C4;
-                const bool in_slab = EVEN || idx < 32 * C4;
-                const long row = row_base + r;
-                const int col = col_base + 4 * c4;
-                const bool ok = in_slab && row < g.M && col < g.N;
-                const float4 a4 = *reinterpret_cast<const float4*>(slab + (in_slab ? r : 0) * EP_LD + 4 * (in_slab ? c4 : 0));
-                const float4 b4 = EVEN ? bias_fixed : buf_load4(rsrcBias, ok ? (uint32_t)col * 4u : OOB);
-                float v[4] = {a4.x + b4.x, a4.y + b4.y, a4.z + b4.z, a4.w + b4.w};
-                const float rr[4] = {r4[u].x, r4[u].y, r4[u].z, r4[u].w};
-                const float gg[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
-                uint32_t h01 = 0, h23 = 0;
-                if (do_drop) {                       // elements 2i, 2i+1 share a hash (keep_elem): two hashes per float4
-                    const uint64_t eidx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
-                    h01 = hash_pair(seed_eff, (uint32_t)(eidx >> 1), (uint32_t)(eidx >> 33));
-                    h23 = hash_pair(seed_eff, (uint32_t)((eidx + 2) >> 1), (uint32_t)((eidx + 2) >> 33));
+        };
+        if (has_res && has_gate) run(std::true_type{}, std::true_type{});
+        else if (has_res) run(std::true_type{}, std::false_type{});
+        else if (has_gate) run(std::false_type{}, std::true_type{});
+        else run(std::false_type{}, std::false_type{});
+    } else {
+    #pragma unroll
+        for (int i = 0; i < TM; ++i) {
+    #pragma unroll
+            for (int j = 0; j < TN; ++j)
+    #pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(slab + l31 * EP_LD + j * 32 + 8 * q + 4 * half) =
+                        make_float4(acc[i][j][4 * q] * out_scale, acc[i][j][4 * q + 1] * out_scale,
+                                    acc[i][j][4 * q + 2] * out_scale, acc[i][j][4 * q + 3] * out_scale);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const long row_base = m0 + wm * WTM + i * 32;
+            // the slab leaves in groups of GR float4 per lane: the auxiliary operands of a group are all requested before its
+            // first store (a bias-only epilogue has none and issues its stores back to back)
+            constexpr int GR = (NIT % 4 == 0) ? 4 : NIT;
+    #pragma unroll
+            for (int g0 = 0; g0 < NIT; g0 += GR) {
+                float4 r4[GR], g4[GR];
+    #pragma unroll
+                for (int u = 0; u < GR; ++u) {
+                    const int idx = (g0 + u) * 64 + lane;
+                    const int r = idx / C4, c4 = idx - r * C4;
+                    const long row = row_base + r;
+                    const int col = col_base + 4 * c4;
+                    const bool ok = (EVEN || idx < 32 * C4) && row < g.M && col < g.N;
+                    r4[u] = has_res ? buf_load4(rsrcR, ok ? (uint32_t)((row * g.ldr + col) * 4) : OOB) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    g4[u] = has_gate ? buf_load4(rsrcG, ok ? (uint32_t)((row * g.ldc + col) * 4) : OOB) : make_float4(1.f, 1.f, 1.f, 1.f);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (g.act == 1) v[e] = fmaxf(v[e], 0.f);
-                    if (do_drop) v[e] = keep_from_hash(e < 2 ? h01 : h23, (uint32_t)e & 1u, g.drop_thr) ? v[e] * g.drop_scale : 0.f;
-                    if (has_gate) v[e] = gg[e] > 0.f ? v[e] * g.relu_scale : 0.f;
-                    v[e] += rr[e];
-                }
-                if (ok) {
-                    *reinterpret_cast<float4*>(C + row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-                    cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    #pragma unroll
+                for (int u = 0; u < GR; ++u) {
+                    const int idx = (g0 + u) * 64 + lane;
+                    const int r = idx / C4, c4 = idx - r * C4;
+                    const bool in_slab = EVEN || idx < 32 * C4;
+                    const long row = row_base + r;
+                    const int col = col_base + 4 * c4;
+                    const bool ok = in_slab && row < g.M && col < g.N;
+                    const float4 a4 = *reinterpret_cast<const float4*>(slab + (in_slab ? r : 0) * EP_LD + 4 * (in_slab ? c4 : 0));
+                    const float4 b4 = EVEN ? bias_fixed : buf_load4(rsrcBias, ok ? (uint32_t)col * 4u : OOB);
+                    float v[4] = {a4.x + b4.x, a4.y + b4.y, a4.z + b4.z, a4.w + b4.w};
+                    const float rr[4] = {r4[u].x, r4[u].y, r4[u].z, r4[u].w};
+                    const float gg[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
+                    uint32_t h01 = 0, h23 = 0;
+                    if (do_drop) {                       // elements 2i, 2i+1 share a hash (keep_elem): two hashes per float4
+                        const uint64_t eidx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
+                        h01 = hash_pair(seed_eff, (uint32_t)(eidx >> 1), (uint32_t)(eidx >> 33));
+                        h23 = hash_pair(seed_eff, (uint32_t)((eidx + 2) >> 1), (uint32_t)((eidx + 2) >> 33));
+                    }
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (g.act == 1) v[e] = fmaxf(v[e], 0.f);
+                        if (do_drop) v[e] = keep_from_hash(e < 2 ? h01 : h23, (uint32_t)e & 1u, g.drop_thr) ? v[e] * g.drop_scale : 0.f;
+                        if (has_gate) v[e] = gg[e] > 0.f ? v[e] * g.relu_scale : 0.f;
+                        v[e] += rr[e];
+                    }
+                    if (ok) {
+                        *reinterpret_cast<float4*>(C + row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                        cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     if (g.c_amax != nullptr) amax_publish(cmax, g.c_amax, bid);
     __syncthreads();        // the slabs alias the staging buffers the next tile's prologue writes
@@ -413,6 +493,12 @@ int h3_tile_choice(long M, long N) {
 }
 
 int dispatch_h3(const GemmArgs& g, hipStream_t stream) {
+    // the epilogue addresses the output, the residual and the gate operand with 32-bit byte offsets (buffer instructions)
+    const long ldmax = g.ldc > g.ldr ? g.ldc : g.ldr;
+    if (((long)g.M + 256) * ldmax * 4 >= (1L << 32)) {
+        set_error("fp16x3 GEMM: output larger than 4 GiB (M=%d, row stride %ld)", g.M, ldmax);
+        return TTTS_ERR_INVALID;
+    }
     switch (h3_tile_choice(g.M, g.N)) {
         case H3_TILE_256: return launch_h3<256, 256, 2, 4>(g, stream);
         case H3_TILE_256x128: return launch_h3<256, 128, 4, 2>(g, stream);
