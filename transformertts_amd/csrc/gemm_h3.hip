@@ -349,13 +349,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
                                       __builtin_fmaf(a4.z, out_scale, bias_fixed.z), __builtin_fmaf(a4.w, out_scale, bias_fixed.w)};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_lo);
-                        if (do_drop) {                       // elements 2i, 2i+1 share a hash (keep_elem): two hashes per float4
-                            const uint64_t eidx = (uint64_t)(row_l + rg) * (uint64_t)g.N + (uint64_t)col;
-                            const uint32_t h01 = hash_pair(seed_eff, (uint32_t)(eidx >> 1), (uint32_t)(eidx >> 33));
-                            const uint32_t h23 = hash_pair(seed_eff, (uint32_t)((eidx + 2) >> 1), (uint32_t)((eidx + 2) >> 33));
+                        if (do_drop) {                       // the float4 is one dropout quad (N % 4 == 0): one hash
+                            bool kp[4];
+                            keep_quad(seed_eff, (uint64_t)(row_l + rg) * (uint64_t)g.N + (uint64_t)col, g.drop_thr, kp);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                v[e] = keep_from_hash(e < 2 ? h01 : h23, (uint32_t)e & 1u, g.drop_thr) ? v[e] * g.drop_scale : 0.f;
+                            for (int e = 0; e < 4; ++e) v[e] = kp[e] ? v[e] * g.drop_scale : 0.f;
                         }
                         if (HAS_GATE) {
                             const float gg[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
@@ -420,16 +418,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
                     float v[4] = {a4.x + b4.x, a4.y + b4.y, a4.z + b4.z, a4.w + b4.w};
                     const float rr[4] = {r4[u].x, r4[u].y, r4[u].z, r4[u].w};
                     const float gg[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
-                    uint32_t h01 = 0, h23 = 0;
-                    if (do_drop) {                       // elements 2i, 2i+1 share a hash (keep_elem): two hashes per float4
-                        const uint64_t eidx = (uint64_t)row * (uint64_t)g.N + (uint64_t)col;
-                        h01 = hash_pair(seed_eff, (uint32_t)(eidx >> 1), (uint32_t)(eidx >> 33));
-                        h23 = hash_pair(seed_eff, (uint32_t)((eidx + 2) >> 1), (uint32_t)((eidx + 2) >> 33));
-                    }
-    #pragma unroll
+                    bool kp[4] = {true, true, true, true};
+                    if (do_drop) keep_quad(seed_eff, (uint64_t)row * (uint64_t)g.N + (uint64_t)col, g.drop_thr, kp);
+#pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (g.act == 1) v[e] = fmaxf(v[e], 0.f);
-                        if (do_drop) v[e] = keep_from_hash(e < 2 ? h01 : h23, (uint32_t)e & 1u, g.drop_thr) ? v[e] * g.drop_scale : 0.f;
+                        if (do_drop) v[e] = kp[e] ? v[e] * g.drop_scale : 0.f;
                         if (has_gate) v[e] = gg[e] > 0.f ? v[e] * g.relu_scale : 0.f;
                         v[e] += rr[e];
                     }

@@ -448,12 +448,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, be[4] = {be4.x, be4.y, be4.z, be4.w};
         const float s1[4] = {s14.x, s14.y, s14.z, s14.w}, s2[4] = {s24.x, s24.y, s24.z, s24.w};
         bool keep[4] = {true, true, true, true};
-        if (thr != 0u) {                                    // elements 2j, 2j+1 share a hash (keep_elem)
-            const uint32_t h0 = hash_pair(seed, (uint32_t)(e >> 1), (uint32_t)(e >> 33));
-            const uint32_t h1 = hash_pair(seed, (uint32_t)((e + 2) >> 1), (uint32_t)((e + 2) >> 33));
-            keep[0] = keep_from_hash(h0, 0u, thr); keep[1] = keep_from_hash(h0, 1u, thr);
-            keep[2] = keep_from_hash(h1, 0u, thr); keep[3] = keep_from_hash(h1, 1u, thr);
-        }
+        if (thr != 0u) keep_quad(seed, (uint64_t)e, thr, keep);     // e is a multiple of 4: one hash for the float4
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

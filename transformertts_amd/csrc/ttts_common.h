@@ -44,8 +44,9 @@ int launch_conv_wgrad_reduce(const float* ws, float* dw, int cout, int cin, int 
 
 // ---------------------------------------------------------------- counter-based dropout RNG
 // keep(seed, idx) is a pure function of the 64-bit site seed and the element index, so the backward kernels
-// regenerate exactly the forward mask without storing it.  One 32-bit hash serves TWO neighbouring elements
-// (16 random bits each): the keep test is `r16 >= round(p * 65536)`, i.e. p is honoured to 1.5e-5.
+// regenerate exactly the forward mask without storing it.  One mixed 32-bit word serves FOUR neighbouring elements
+// (each sees the top 16 bits of word * its own odd constant): the keep test is `r16 >= round(p * 65536)`, i.e. p is
+// honoured to 1.5e-5.  hash_pair is the stronger two-round mixer (still used for the scheduled-sampling draw).
 __device__ __forceinline__ uint32_t hash_pair(uint64_t seed, uint32_t a, uint32_t b) {
     uint32_t x = (a * 0x9E3779B1u) ^ (b * 0x85EBCA77u) ^ (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0xC2B2AE3Du);
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -66,10 +67,6 @@ __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
 __device__ __forceinline__ bool keep_from_hash(uint32_t h, uint32_t odd, uint32_t thr) {
     return (odd ? (h >> 16) : (h & 0xFFFFu)) >= thr;
 }
-// flat-index form (GEMM epilogues, element-wise kernels): elements 2i and 2i+1 share a hash
-__device__ __forceinline__ bool keep_elem(uint64_t seed, uint64_t idx, uint32_t thr) {
-    return keep_from_hash(hash_pair(seed, (uint32_t)(idx >> 1), (uint32_t)(idx >> 33)), (uint32_t)idx & 1u, thr);
-}
 // attention-weight form: element (row, key) of the (B*H*Tq, Tk) weight matrix.  Keys 4j .. 4j+3 of a row share ONE mixed
 // 32-bit word (attn_quad_hash); key 4j+e keeps its weight iff the top 16 bits of word * ATTN_DROP_MULT[e] reach the
 // threshold, i.e. iff (word * mult) >= (thr << 16) -- one multiply and one compare per weight, no field extraction.  The
@@ -88,6 +85,20 @@ __device__ __forceinline__ uint32_t attn_drop_mult(uint32_t key) {
 __device__ __forceinline__ bool attn_keep_word(uint32_t quad_hash, uint32_t mult, uint32_t thr16) { return quad_hash * mult >= thr16; }
 __device__ __forceinline__ bool attn_keep(uint64_t seed, uint32_t row, uint32_t key, uint32_t thr16) {
     return attn_keep_word(attn_quad_hash(seed, row, key >> 2), attn_drop_mult(key), thr16);
+}
+// flat-index form (GEMM epilogues, element-wise kernels, BatchNorm): the same scheme on the element index -- elements
+// 4i .. 4i+3 share one mixed word (a float4 of outputs costs one hash, four multiplies and four compares)
+__device__ __forceinline__ uint32_t elem_quad_hash(uint64_t seed, uint64_t idx) {
+    return attn_quad_hash(seed, (uint32_t)(idx >> 2), (uint32_t)(idx >> 34));
+}
+__device__ __forceinline__ bool keep_elem(uint64_t seed, uint64_t idx, uint32_t thr) {
+    return attn_keep_word(elem_quad_hash(seed, idx), attn_drop_mult((uint32_t)idx), thr << 16);
+}
+// idx4: a multiple of 4; k[e] = keep_elem(seed, idx4 + e, thr)
+__device__ __forceinline__ void keep_quad(uint64_t seed, uint64_t idx4, uint32_t thr, bool (&k)[4]) {
+    const uint32_t w = elem_quad_hash(seed, idx4), thr16 = thr << 16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) k[e] = attn_keep_word(w, attn_drop_mult((uint32_t)e), thr16);
 }
 
 // ---------------------------------------------------------------- two-way f16 split of a pair of fp32 values
