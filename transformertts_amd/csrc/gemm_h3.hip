@@ -318,8 +318,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
         const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(C, 0, (uint32_t)((long)g.M * g.ldc * 4), 0x00020000);
         const bool want_max = g.c_amax != nullptr;
         const float relu_lo = (g.act == 1) ? 0.f : -__builtin_inff();
-        auto run = [&](auto has_res_c, auto has_gate_c) {
+        // rows / columns past the matrix edge exist only in edge tiles: everywhere else the running maximum needs no test
+        const bool tile_full = m0 + BM <= g.M && n0 + BN <= g.N;
+        auto run = [&](auto has_res_c, auto has_gate_c, auto drop_c) {
             constexpr bool HAS_RES = decltype(has_res_c)::value, HAS_GATE = decltype(has_gate_c)::value;
+            constexpr bool DROP = decltype(drop_c)::value;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
                                       __builtin_fmaf(a4.z, out_scale, bias_fixed.z), __builtin_fmaf(a4.w, out_scale, bias_fixed.w)};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_lo);
-                        if (do_drop) {                       // the float4 is one dropout quad (N % 4 == 0): one hash
+                        if (DROP) {                          // the float4 is one dropout quad (N % 4 == 0): one hash
                             bool kp[4];
                             keep_quad(seed_eff, (uint64_t)(row_l + rg) * (uint64_t)g.N + (uint64_t)col, g.drop_thr, kp);
 #pragma unroll
@@ -362,8 +365,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
                         }
                         if (HAS_RES) { v[0] += r4[u].x; v[1] += r4[u].y; v[2] += r4[u].z; v[3] += r4[u].w; }
                         buf_store4s(rsrcC, offC, (uint32_t)(rg * g.ldc * 4), make_float4(v[0], v[1], v[2], v[3]));
-                        if (want_max && col_ok && row_l + rg < g.M)
-                            cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                        if (want_max) {
+                            if (tile_full)
+                                cmax = fmaxf(fmaxf(fmaxf(cmax, fabsf(v[0])), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                            else if (col_ok && row_l + rg < g.M)
+                                cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -371,10 +378,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
         };
-        if (has_res && has_gate) run(std::true_type{}, std::true_type{});
-        else if (has_res) run(std::true_type{}, std::false_type{});
-        else if (has_gate) run(std::false_type{}, std::true_type{});
-        else run(std::false_type{}, std::false_type{});
+        // (a gate operand belongs to data gradients, which have no dropout of their own)
+        if (has_gate) {
+            if (has_res) run(std::true_type{}, std::true_type{}, std::false_type{});
+            else run(std::false_type{}, std::true_type{}, std::false_type{});
+        } else if (do_drop) {
+            if (has_res) run(std::true_type{}, std::false_type{}, std::true_type{});
+            else run(std::false_type{}, std::false_type{}, std::true_type{});
+        } else {
+            if (has_res) run(std::true_type{}, std::false_type{}, std::false_type{});
+            else run(std::false_type{}, std::false_type{}, std::false_type{});
+        }
     } else {
     #pragma unroll
         for (int i = 0; i < TM; ++i) {
