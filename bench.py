@@ -78,7 +78,8 @@ class GemmProbe:
     the kernel instantiation the library dispatches it to (ttts_gemm_tile_choice); `summary()` reports the
     instantiation with the largest total time = the dominant kernel of the step."""
 
-    TILES = {1: "64,64,2,2", 2: "128,128,2,2", 3: "64,128,2,2", 4: "128,96,4,1", 6: "256,256,2,4", 7: "256,128,4,2"}
+    TILES = {1: "64,64,2,2", 2: "128,128,2,2", 3: "64,128,2,2", 4: "128,96,4,1", 6: "256,256,2,4", 7: "256,128,4,2",
+             8: "256,128,2,2"}
     # name -> (x6?, extractor of (M, N, K) from the C-ABI argument tuple)
     CALLS = {
         "ttts_linear_fwd": (0, lambda a: (a[5], a[6], a[7])),
@@ -105,7 +106,7 @@ class GemmProbe:
 
             def wrapped(*a, _fn=fn, _x6=x6, _dims=dims):
                 M, N, K = _dims(a)
-                tile = self.lib.ttts_gemm_tile_choice(M, N, _x6)
+                tile = self.lib.ttts_gemm_tile_choice(M, N, K, _x6)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = _fn(*a)

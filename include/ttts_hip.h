@@ -93,9 +93,10 @@ int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db
  * the fixed pre-scales suit O(1) activations and O(1/sqrt(fan_in)) weights -- the forward operands of this model --
  * and activations of magnitude >= 4096 come out as inf.  Gradient operands get a dynamic pre-scale (ttts_amax_partials). */
 size_t ttts_split_bytes(int64_t rows, int64_t cols);
-/* tile shape the forward / data-gradient dispatch uses for an M x N output (1: 64x64, 2: 128x128, 3: 64x128, 4: 128x96);
- * x6 = 0: fp32-MFMA kernel, 1: bf16x6 kernel, 2: fp16x3 kernel */
-int ttts_gemm_tile_choice(int64_t M, int N, int x6);
+/* tile shape the forward / data-gradient dispatch uses for an M x N output with reduction length K (1: 64x64, 2: 128x128,
+ * 3: 64x128, 4: 128x96; fp16x3 only: 6: 256x256 / 8 waves, 7: 256x128 / 8 waves, 8: 256x128 / 4 waves, two workgroups per
+ * CU); x6 = 0: fp32-MFMA kernel, 1: bf16x6 kernel, 2: fp16x3 kernel.  A profiling aid (bench.py attributes launches). */
+int ttts_gemm_tile_choice(int64_t M, int N, int K, int x6);
 int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode, int channels_per_tap, int taps,
                       void* stream);
 /* all weights in one launch: descs (device memory) = n x 8 int64 {w, planes, rows, cols, mode, channels_per_tap, taps,

@@ -27,7 +27,7 @@ SIGNATURES = {
     "ttts_wgrad_workspace_bytes": (Z, [L, I, I, I]),
     "ttts_linear_bwd_weight": (I, [P, P, P, P, P, Z, L, I, I, I, I, I, P]),
     "ttts_split_bytes": (Z, [L, L]),
-    "ttts_gemm_tile_choice": (I, [L, I, I]),
+    "ttts_gemm_tile_choice": (I, [L, I, I, I]),
     "ttts_weight_split": (I, [P, P, I, I, I, I, I, P]),
     "ttts_weight_split_batched": (I, [P, I, L, P]),
     "ttts_linear_fwd_x6": (I, [P, P, P, P, P, L, I, I, I, F, U, P, I, I, P]),

@@ -274,7 +274,7 @@ using namespace ttts;
 extern "C" {
 
 const char* ttts_last_error(void) { return ttts::g_err; }
-int ttts_abi_version(void) { return 5; }
+int ttts_abi_version(void) { return 6; }
 
 int ttts_zero(void* p, size_t nbytes, void* stream) {
     TTTS_REQUIRE(p != nullptr || nbytes == 0, "zero: null pointer");

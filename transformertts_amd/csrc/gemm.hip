@@ -1167,11 +1167,11 @@ int ttts_conv1d_bwd_weight_h3(const float* dy, const float* x, float* dw, float*
     return conv1d_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, B, T, cin, cout, taps, accumulate, true, stream, dy_amax);
 }
 
-int ttts_gemm_tile_choice(int64_t M, int N, int x6) {
+int ttts_gemm_tile_choice(int64_t M, int N, int K, int x6) {
     // which tile the forward / data-gradient dispatch picks for an M x N output: 1 = 64x64, 2 = 128x128, 3 = 64x128,
     // 4 = 128x96 (profiling aid: lets a host-side probe attribute a launch to its kernel instantiation);
     // x6 = 0: fp32 MFMA kernel, 1: bf16x6, 2: fp16x3
-    if (x6 == 2) return h3_tile_choice(M, N);
+    if (x6 == 2) return h3_tile_choice(M, N, K);
     if (N <= 96 && (long)cdiv(M, 128) >= 384) return TILE_128x96;
     return choose_tile(M, N, 1, x6 != 0);
 }

@@ -106,12 +106,13 @@ __device__ __forceinline__ void weight_split_h3_one(const float* __restrict__ w,
 }
 
 enum { TILE_AUTO = 0, TILE_64 = 1, TILE_128 = 2, TILE_64x128 = 3, TILE_128x96 = 4, TILE_96x128 = 5,
-       H3_TILE_256 = 6, H3_TILE_256x128 = 7 };     // 8-wave tiles of the fp16x3 kernels
+       H3_TILE_256 = 6, H3_TILE_256x128 = 7,     // 8-wave tiles of the fp16x3 kernels
+       H3_TILE_256x128_PAIR = 8 };                 // 4-wave 256x128 tile, one LDS stage, TWO workgroups per CU
 
 // fp16x3 split-precision GEMM (gemm_h3.hip): true when it can take this problem (shape constraints of its 32-deep
 // k-tiles); the caller falls back to the bf16x6 kernel otherwise
 bool h3_supports(const GemmArgs& g);
-int h3_tile_choice(long M, long N);
+int h3_tile_choice(long M, long N, long K);
 void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, int mode, int c2, int taps, hipStream_t stream);
 int dispatch_h3(const GemmArgs& g, hipStream_t stream);
 int dispatch_wgrad_h3(const GemmArgs& g, int zdim, int tile, hipStream_t stream);

@@ -87,12 +87,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
     static_assert((BM * 8) % NT == 0, "every thread stages whole float4s of the A tile");
     constexpr int A_PLANE = BM * 16, B_PLANE = BN * 16;         // dwords per plane (64-byte rows)
     constexpr int STAGE = 2 * (A_PLANE + B_PLANE);
+    // A 4-wave workgroup on a 256-row tile keeps ONE LDS stage (48 KB) so that two workgroups share a CU: a wave cannot
+    // run loads past its own outstanding stores (vmcnt is one in-order counter for both), so the 10 us store burst of a
+    // K = 256 tile can only drain under ANOTHER workgroup's main loop.
+    constexpr bool SINGLE = (NT == 256 && BM == 256);
+    constexpr int NSTAGE = SINGLE ? 1 : 2;
     constexpr int NLA = BM * 8 / NT;                            // float4 loads per thread for the A tile (8 per row)
     constexpr int NLB = (BN * 4 + NT - 1) / NT;                 // 16-byte pieces per thread and plane for the B tile (4 per row)
     constexpr bool B_ALL = (BN * 4) % NT == 0;
     constexpr int NTILE = 2 * TM * TN;                          // accumulator-tile visits per k-tile (two MFMA k-steps)
 
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[NSTAGE * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -257,7 +262,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
         }
     };
 
-    if (nkt > 0) {
+    if (SINGLE) {
+        if (nkt > 0) stage_all(1, false, true);                 // request tile 0
+        for (int kt = 0; kt < nkt; ++kt) {
+            stage_all(1, true, kt + 1 < nkt);                   // registers (tile kt) -> LDS[0], request tile kt+1
+            __syncthreads();
+            step(0, false, false);                              // products only
+            __syncthreads();                                    // LDS[0] free again
+        }
+    } else if (nkt > 0) {
         stage_all(1, false, true);              // request tile 0
         stage_all(1, true, nkt > 1);            // stage tile 0 into LDS[0], request tile 1
         __syncthreads();
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
     constexpr int C4 = WTN / 4;                           // float4 per slab row
     constexpr int NIT = (32 * C4 + 63) / 64;              // float4 per lane and slab
     constexpr bool EVEN = (32 * C4) % 64 == 0 && 64 % C4 == 0;   // every lane keeps ONE column group for the whole tile
-    static_assert((WM * WN) * 32 * EP_LD <= 2 * STAGE, "epilogue slabs must fit the staging buffers");
+    static_assert((WM * WN) * 32 * EP_LD <= NSTAGE * STAGE, "epilogue slabs must fit the staging buffers");
     float* slab = reinterpret_cast<float*>(lds) + wave * (32 * EP_LD);
     const int col_base = n0 + wn * WTN;
     // vmcnt is an in-order counter shared by loads and stores: a load issued behind a slab's stores cannot be waited for
@@ -463,7 +476,7 @@ static int launch_h3(const GemmArgs& g, hipStream_t stream) {
     static int persist = -1;                      // development aid: TTTS_H3_PERSIST=0 launches one workgroup per tile
     if (persist < 0) { const char* e = getenv("TTTS_H3_PERSIST"); persist = e ? atoi(e) : 1; }
     const long ntiles = (long)cdiv(g.N, BN) * cdiv(g.M, BM);
-    const long cap = persist ? 256L * (WM * WN == 8 ? 1 : 2) : ntiles;
+    const long cap = persist ? 256L * (WM * WN == 8 ? 1 : 2) : ntiles;     // 4-wave tiles: two workgroups per CU
     dim3 grid((unsigned)(ntiles < cap ? ntiles : cap), 1, 1);
     if (g.T > 0)
         hipLaunchKernelGGL((gemm_h3_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, stream, g);
@@ -479,7 +492,7 @@ bool h3_supports(const GemmArgs& g) {
 }
 
 
-int h3_tile_choice(long M, long N) {
+int h3_tile_choice(long M, long N, long K) {
     static int forced = -1;                       // development aid: TTTS_H3_TILE forces a tile shape
     if (forced < 0) { const char* e = getenv("TTTS_H3_TILE"); forced = e ? atoi(e) : 0; }
     if (forced > 0) return forced;
@@ -487,11 +500,18 @@ int h3_tile_choice(long M, long N) {
     // busiest-CU cost model of gemm.hip's choose_tile: workgroups a CU runs one after the other x tile area / efficiency
     // (a 256-wide tile is one workgroup per CU at a time, the 128-wide ones two)
     struct Cand { int tile, bm, bn, per_cu; float eff; };
+    static int pair = -1;                         // TTTS_H3_PAIR=0: never pick the two-workgroup 256x128 tile
+    if (pair < 0) { const char* e = getenv("TTTS_H3_PAIR"); pair = e ? atoi(e) : 1; }
+    // the two-workgroup 256x128 tile lets one workgroup's store burst drain under the other's main loop: it wins where the
+    // epilogue weighs as much as the main loop (K <= 512: +3 .. 9 % at M = 55 680, +24 % at M = 6 400) and loses where the
+    // main loop dominates (K >= 1024: -8 %, one LDS stage and two barriers per k-tile)
     const Cand cands[] = {{H3_TILE_256, 256, 256, 1, 1.25f}, {H3_TILE_256x128, 256, 128, 1, 1.05f},
-                          {TILE_128, 128, 128, 2, 1.00f}, {TILE_64x128, 64, 128, 2, 0.75f}, {TILE_64, 64, 64, 2, 0.55f}};
+                          {TILE_128, 128, 128, 2, 1.00f}, {TILE_64x128, 64, 128, 2, 0.75f}, {TILE_64, 64, 64, 2, 0.55f},
+                          {H3_TILE_256x128_PAIR, 256, 128, 2, 1.33f}};
     int best = TILE_128;
     float best_cost = 1e30f;
     for (const Cand& c : cands) {
+        if (c.tile == H3_TILE_256x128_PAIR && (!pair || K <= 0 || K > 512)) continue;
         long tiles = (long)cdiv(M, c.bm) * cdiv(N, c.bn);
         long rounds = (tiles + 256L * c.per_cu - 1) / (256L * c.per_cu);
         float cost = (float)rounds * (float)(c.bm * c.bn) * (float)c.per_cu / c.eff;
@@ -507,9 +527,10 @@ int dispatch_h3(const GemmArgs& g, hipStream_t stream) {
         set_error("fp16x3 GEMM: output larger than 4 GiB (M=%d, row stride %ld)", g.M, ldmax);
         return TTTS_ERR_INVALID;
     }
-    switch (h3_tile_choice(g.M, g.N)) {
+    switch (h3_tile_choice(g.M, g.N, g.K)) {
         case H3_TILE_256: return launch_h3<256, 256, 2, 4>(g, stream);
         case H3_TILE_256x128: return launch_h3<256, 128, 4, 2>(g, stream);
+        case H3_TILE_256x128_PAIR: return launch_h3<256, 128, 2, 2>(g, stream);
         case TILE_64x128: return launch_h3<64, 128, 2, 2>(g, stream);
         case TILE_64: return launch_h3<64, 64, 2, 2>(g, stream);
         case TILE_128x96: return launch_h3<128, 96, 4, 1>(g, stream);
