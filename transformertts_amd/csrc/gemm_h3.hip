@@ -502,16 +502,17 @@ int h3_tile_choice(long M, long N, long K) {
     struct Cand { int tile, bm, bn, per_cu; float eff; };
     static int pair = -1;                         // TTTS_H3_PAIR=0: never pick the two-workgroup 256x128 tile
     if (pair < 0) { const char* e = getenv("TTTS_H3_PAIR"); pair = e ? atoi(e) : 1; }
-    // the two-workgroup 256x128 tile lets one workgroup's store burst drain under the other's main loop: it wins where the
-    // epilogue weighs as much as the main loop (K <= 512: +3 .. 9 % at M = 55 680, +24 % at M = 6 400) and loses where the
-    // main loop dominates (K >= 1024: -8 %, one LDS stage and two barriers per k-tile)
+    // the two-workgroup 256x128 tile lets one workgroup's store burst drain under the other's main loop.  Per kernel it wins
+    // where the epilogue weighs as much as the main loop (K <= 512: +3 .. 9 % at M = 55 680, +24 % at M = 6 400) and loses
+    // where the main loop dominates (K >= 1024: -8 %, one LDS stage and two barriers per k-tile); over the whole step at
+    // M = 55 680 the two are level (same-box A/B), so it is used where the 256 x 256 grid cannot fill the chip anyway.
     const Cand cands[] = {{H3_TILE_256, 256, 256, 1, 1.25f}, {H3_TILE_256x128, 256, 128, 1, 1.05f},
                           {TILE_128, 128, 128, 2, 1.00f}, {TILE_64x128, 64, 128, 2, 0.75f}, {TILE_64, 64, 64, 2, 0.55f},
                           {H3_TILE_256x128_PAIR, 256, 128, 2, 1.33f}};
     int best = TILE_128;
     float best_cost = 1e30f;
     for (const Cand& c : cands) {
-        if (c.tile == H3_TILE_256x128_PAIR && (!pair || K <= 0 || K > 512)) continue;
+        if (c.tile == H3_TILE_256x128_PAIR && (!pair || K <= 0 || K > 512 || (long)cdiv(M, 256) * cdiv(N, 256) >= 256)) continue;
         long tiles = (long)cdiv(M, c.bm) * cdiv(N, c.bn);
         long rounds = (tiles + 256L * c.per_cu - 1) / (256L * c.per_cu);
         float cost = (float)rounds * (float)(c.bm * c.bn) * (float)c.per_cu / c.eff;
