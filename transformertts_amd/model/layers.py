@@ -52,6 +52,7 @@ class MultiheadAttention(nn.Module):
         qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias, skip_in=skip)
         p = self._p()
         ctx = ops.SelfAttentionFn.apply(qkv, lens, self.num_heads, causal, p, ops.seeds.next() if p > 0 else 0)
+        ctx._ttts_sole_consumer = True      # only the out-projection below reads it (see LinearFn.forward)
         return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, drop_p=out_drop,
                           seed=ops.seeds.next() if out_drop > 0 else 0, skip_out=skip)
 
@@ -64,6 +65,7 @@ class MultiheadAttention(nn.Module):
         p = self._p()
         ctx, attn = ops.CrossAttentionFn.apply(q, kv, mem_lens, self.num_heads, p, ops.seeds.next() if p > 0 else 0,
                                                need_weights)
+        ctx._ttts_sole_consumer = True
         if not need_weights:
             attn = None
         out = ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, drop_p=out_drop,

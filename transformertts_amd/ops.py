@@ -456,6 +456,9 @@ class LinearFn(torch.autograd.Function):
         ctx.sinks = _sinks(w, b)
         ctx.ss = _ss()              # backward regenerates the dropout mask under the step-state word of ITS forward
         ctx.toks = (tok_out, tok_in, skip_in, skip_out)
+        # x is the output of an attention kernel and feeds nothing but this Linear: the gradient this backward returns for it
+        # reaches the attention backward as it is (never summed with another one), so its maxima can ride on the tensor
+        ctx.sole_consumer = bool(getattr(x, "_ttts_sole_consumer", False))
         return y
 
     @staticmethod
@@ -502,7 +505,7 @@ class LinearFn(torch.autograd.Function):
                 am = am if am is not None else _amax(dacc)
                 # dx with the producer's relu mask applied here is exactly the `dacc` of that producer's backward: leave its
                 # maxima on it
-                dx_am = _amax_slots(dx.device, True) if tok_in is not None else None
+                dx_am = _amax_slots(dx.device, True) if (tok_in is not None or ctx.sole_consumer) else None
                 _lib.check(lib.ttts_linear_bwd_data_h3(_p(dacc), _p(_planes(w, 5, K, N)), _p(skip), _p(dx), M, N, K,
                                                        _p(gate), gscale, _p(am), _p(dx_am), _stream()), "ttts_linear_bwd_data_h3")
                 if dx_am is not None:
