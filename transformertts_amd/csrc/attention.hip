@@ -997,7 +997,11 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
         for (int r = 0; r < 16; r += 4) {     // registers r .. r+3 are four neighbouring keys: one hash
             const uint32_t qh = attn_quad_hash(seed_eff, rowid, (uint32_t)(key0 + acc_row(r, half)) >> 2);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) p[r + e] = attn_keep_word(qh, attn_drop_mult(e), thr16) ? p[r + e] * a.drop_scale : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                // (the 1/(1-p) of the kept weights rides in the final output scale unless the weights themselves are returned)
+                const bool keep = attn_keep_word(qh, attn_drop_mult(e), thr16);
+                p[r + e] = keep ? (WRITE_A ? p[r + e] * a.drop_scale : p[r + e]) : 0.f;
+            }
         }
     };
 
@@ -1129,7 +1133,7 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
         lse_v = m_fin * H3A_C + __logf(l > 0.f ? l : 1.f);
     } else {
         float lt = l + __shfl_xor(l, 32, 64);                 // = 2^10 * the sum of the weights
-        out_scale = (lt > 0.f) ? (1.0f / H3A_V) / lt : 0.f;
+        out_scale = (lt > 0.f) ? (a.drop_scale / H3A_V) / lt : 0.f;
         lse_v = ((m == NEG_INF) ? 0.f : m) * H3A_C + __logf(lt > 0.f ? lt * (1.0f / H3A_P) : 1.f);
     }
     if (a.lse != nullptr && half == 0 && qg < a.Tq) a.lse[arow + qg] = lse_v;
@@ -1723,7 +1727,7 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
     load_lane_frags_h3(scratch, l31, half, s_g, gf);
     if (half == 0 && qg < a.Tq) a.delta[arow + qg] = delta;
     const float lse_q2 = ((qg < a.Tq) ? a.lse[arow + qg] : 0.f) * 1.4426950408889634f;
-    const float dp_unscale = inv_g / H3A_V;      // dP accumulator units -> true dP
+    const float dp_unscale = inv_g / H3A_V * a.drop_scale;   // dP accumulator units -> true dP, times the 1/(1-p) of kept weights
     float sds = 0.f;                              // this query's dS pre-scale (power of two), set / lowered on the fly
 
     f32x16 dq[2];
@@ -1779,7 +1783,7 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
                     float p = fast_exp2(__builtin_fmaf(s[r + e], H3A_C2, -lse_q2));
                     if (!full) p = (kg < klen && (!CAUSAL || kg <= qg)) ? p : 0.f;
                     float g = dp[r + e] * dp_unscale;
-                    if (a.thr != 0u) g = attn_keep_word(qh, attn_drop_mult(e), thr16) ? g * a.drop_scale : 0.f;
+                    if (a.thr != 0u) g = attn_keep_word(qh, attn_drop_mult(e), thr16) ? g : 0.f;
                     ds[r + e] = p * (g - delta);
                 }
             }
@@ -1868,7 +1872,7 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
 
-    const float dp_unscale = inv_g / H3A_V;
+    const float dp_unscale = inv_g / H3A_V * a.drop_scale;      // ... times the 1/(1-p) of kept weights (1 without dropout)
     float sds = 0.f;                        // this key's dS pre-scale (power of two), see attn_bwd_dq_h3_kernel
     const int nqs = (a.Tq + QS - 1) / QS;
     int qs_begin = CAUSAL ? (k0 / QS) : 0;
@@ -1978,8 +1982,8 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
                 float pk = pd[r + e];
                 if (a.thr != 0u) {
                     const bool keep = attn_keep_word(hq[e], key_mult, thr16);
-                    g = keep ? g * a.drop_scale : 0.f;
-                    pk = keep ? pk * a.drop_scale : 0.f;
+                    g = keep ? g : 0.f;                  // the 1/(1-p) factors ride in dp_unscale and in dv's final scale
+                    pk = keep ? pk : 0.f;
                 }
                 ds[r + e] = pd[r + e] * (g - delta_s[acc_row(r + e, half)]);
                 pd[r + e] = pk;
@@ -2016,7 +2020,7 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
     __syncthreads();
     {
         const float fk = (sds > 0.f) ? 1.f / (H3A_Q * sds) : 0.f;        // dk accumulator: (Q / 8 * 2^4)^T (dS * sds)
-        const float fv = inv_g / H3A_P;                                   // dv accumulator: (dO * s_g)^T (P * 2^10)
+        const float fv = inv_g / H3A_P * a.drop_scale;                    // dv accumulator: (dO * s_g)^T (kept P * 2^10) / (1-p)
         float mx = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
