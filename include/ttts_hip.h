@@ -187,6 +187,14 @@ size_t ttts_layernorm_bwd_workspace_bytes(int d);
 int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
                        int accumulate, void* stream);
+/* the same, and in the same pass dacc = dx * keep(seed, element) / (1 - drop_p): the gradient behind the residual dropout
+ * of the sublayer whose output this LayerNorm normalised (ttts_dropout_bwd(dx) without a pass of its own; same mask as
+ * the forward epilogue of that sublayer's last Linear).  dacc_amax: NULL, or a caller-zeroed 1024-float array that receives
+ * partial maxima of |dacc|.  d in {256, 512, 1024}, operands 16-byte aligned. */
+int ttts_layernorm_bwd_drop(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                            float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
+                            int accumulate, float* dacc, float drop_p, uint64_t seed, const uint64_t* step_seed,
+                            float* dacc_amax, void* stream);
 
 /* ------------------------------------------------------------------ attention (head_dim = 64)
  * Scaled dot-product attention with masks computed from lengths in-kernel (no mask tensors):

@@ -129,6 +129,38 @@ def test_layernorm(M, d):
     assert rel_l2(bg.grad, bd.grad) < TOL
 
 
+@pytest.mark.parametrize("M,d", [(777, 256), (130, 512), (65, 1024)])
+def test_layernorm_backward_with_fused_dropout_backward(M, d):
+    """ttts_layernorm_bwd_drop == ttts_layernorm_bwd followed by ttts_dropout_bwd on its dx, bit for bit (dx, the dropped
+    copy, the parameter gradients), and the published maxima are those of the dropped copy."""
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    dev = _dev()
+    x, g, dy = (_rand(M, d, seed=1) * 2 + 0.3).to(dev), (1 + _rand(d, seed=2, scale=0.2)).to(dev), _rand(M, d, seed=4).to(dev)
+    b = torch.zeros(d, device=dev)
+    y, mean, rstd = torch.empty_like(x), torch.empty(M, device=dev), torch.empty(M, device=dev)
+    assert lib.ttts_layernorm_fwd(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), M, d, 1e-5, _stream()) == 0
+    nb = lib.ttts_layernorm_bwd_workspace_bytes(d)
+    outs = []
+    for fused in (False, True):
+        dx, dg, db, ws = torch.empty_like(x), torch.empty(d, device=dev), torch.empty(d, device=dev), ops._ws(nb, dev)
+        dacc, am = torch.empty_like(x), torch.zeros(1024, device=dev)
+        if fused:
+            assert lib.ttts_layernorm_bwd_drop(_p(dy), _p(x), _p(mean), _p(rstd), _p(g), _p(dx), _p(dg), _p(db), _p(ws),
+                                               ws.numel() * 4, M, d, 0, _p(dacc), 0.3, 4242, None, _p(am), _stream()) == 0
+        else:
+            assert lib.ttts_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(g), _p(dx), _p(dg), _p(db), _p(ws),
+                                          ws.numel() * 4, M, d, 0, _stream()) == 0
+            assert lib.ttts_dropout_bwd(_p(dx), _p(dacc), dx.numel(), 0.3, 4242, None, None, _stream()) == 0
+        outs.append((dx, dg, db, dacc, am))
+    for a, c in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a, c)
+    assert float(outs[1][4].max()) == float(outs[1][3].abs().max())
+    frac = float((outs[1][3] == 0).float().mean())
+    assert abs(frac - 0.3) < 0.02, frac
+
+
 def _ref_attention(q, k, v, lens, causal):
     """q,k,v (B,H,T,64) fp64; q.k^T with q pre-scaled by sqrt(1/64); -inf masks; softmax; weights @ v"""
     B, H, Tq, _ = q.shape

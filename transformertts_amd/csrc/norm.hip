@@ -154,14 +154,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 // d = 256 * NV form of the backward: 16-byte accesses, two rows per wave iteration in flight, NW waves per block (the
 // block count is fixed by the partial-sum workspace, so occupancy comes from the block size: 16 waves per CU at d = 256)
-template <int NV, int NW>
+// DROP: also write dacc = dx * keep(seed, element) / (1-p) -- the gradient behind the residual dropout of the sublayer whose
+// output this LayerNorm normalised (what ttts_dropout_bwd would compute from dx in a pass of its own) -- and publish the
+// maximum of |dacc| (atomic maxima into a caller-zeroed 1024-slot array)
+template <int NV, int NW, bool DROP>
 __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, float* __restrict__ dx,
-                                                               float* __restrict__ ws, long M) {
+                                                               float* __restrict__ ws, long M, float* __restrict__ dacc,
+                                                               float drop_scale, uint32_t thr, uint64_t seed,
+                                                               const uint64_t* step_seed, float* __restrict__ dacc_amax) {
     constexpr int d = 256 * NV;
     __shared__ float red[NW][2][d];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t seed_eff = DROP ? site_seed(seed, step_seed) : 0;
+    float amx = 0.f;
     float4 g[NV], accg[NV], accb[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -203,12 +210,22 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const float* 
             s1 = wave_sum(s1) / (float)d;
             s2 = wave_sum(s2) / (float)d;
 #pragma unroll
-            for (int k = 0; k < NV; ++k)
-                reinterpret_cast<float4*>(dx + r * d)[lane + 64 * k] =
-                    make_float4(rs[u] * (gd[k].x - s1 - xh[k].x * s2), rs[u] * (gd[k].y - s1 - xh[k].y * s2),
-                                rs[u] * (gd[k].z - s1 - xh[k].z * s2), rs[u] * (gd[k].w - s1 - xh[k].w * s2));
+            for (int k = 0; k < NV; ++k) {
+                const float4 o = make_float4(rs[u] * (gd[k].x - s1 - xh[k].x * s2), rs[u] * (gd[k].y - s1 - xh[k].y * s2),
+                                             rs[u] * (gd[k].z - s1 - xh[k].z * s2), rs[u] * (gd[k].w - s1 - xh[k].w * s2));
+                reinterpret_cast<float4*>(dx + r * d)[lane + 64 * k] = o;
+                if (DROP) {
+                    bool kp[4];
+                    keep_quad(seed_eff, (uint64_t)(r * d + 4 * (lane + 64 * k)), thr, kp);
+                    const float4 da = make_float4(kp[0] ? o.x * drop_scale : 0.f, kp[1] ? o.y * drop_scale : 0.f,
+                                                  kp[2] ? o.z * drop_scale : 0.f, kp[3] ? o.w * drop_scale : 0.f);
+                    reinterpret_cast<float4*>(dacc + r * d)[lane + 64 * k] = da;
+                    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(da.x), fabsf(da.y))), fmaxf(fabsf(da.z), fabsf(da.w)));
+                }
+            }
         }
     }
+    if (DROP && dacc_amax != nullptr) amax_publish(amx, dacc_amax, blockIdx.x * NW + wave);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         reinterpret_cast<float4*>(&red[wave][0][0])[lane + 64 * k] = accg[k];
@@ -513,21 +530,30 @@ int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 
 size_t ttts_layernorm_bwd_workspace_bytes(int d) { return (size_t)LN_BWD_BLOCKS * 2 * d * sizeof(float); }
 
-int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                       float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
-                       int accumulate, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int layernorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                              float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
+                              int accumulate, float* dacc, float drop_p, uint64_t seed, const uint64_t* step_seed,
+                              float* dacc_amax, hipStream_t stream) {
     TTTS_REQUIRE(dy && x && mean && rstd && gamma && dx && ws, "layernorm_bwd: null pointer");
     TTTS_REQUIRE(M > 0 && d > 0 && d % 64 == 0 && d <= 64 * LN_MAXPER, "layernorm_bwd: bad d=%d", d);
     TTTS_REQUIRE(ws_bytes >= ttts_layernorm_bwd_workspace_bytes(d), "layernorm_bwd: workspace too small");
     int nblk = LN_BWD_BLOCKS;
     if ((long)nblk * 4 > M) nblk = cdiv(M, 4);
     const bool v4 = (d == 256 || d == 512 || d == 1024) &&
-                    ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)gamma)) & 15) == 0;
+                    ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)gamma) | ((uintptr_t)dacc)) & 15) == 0;
+    TTTS_REQUIRE(dacc == nullptr || v4, "layernorm_bwd_drop: needs d in {256, 512, 1024} and 16-byte aligned operands");
     if (v4) {
-        if (d == 256) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<1, 16>), dim3(nblk), dim3(1024), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M);
-        else if (d == 512) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<2, 8>), dim3(nblk), dim3(512), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M);
-        else hipLaunchKernelGGL((layernorm_bwd_v4_kernel<4, 4>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, (long)M);
+        const uint32_t thr = (dacc && drop_p > 0.f) ? drop_threshold(drop_p) : 0u;
+        const float sc = 1.f / (1.f - drop_p);
+#define TTTS_LN_BWD4(NV, NW, DROP)                                                                                          \
+        hipLaunchKernelGGL((layernorm_bwd_v4_kernel<NV, NW, DROP>), dim3(nblk), dim3(64 * NW), 0, stream, dy, x, mean, rstd, \
+                           gamma, dx, ws, (long)M, dacc, sc, thr, seed, step_seed, dacc_amax)
+        if (dacc) {
+            if (d == 256) TTTS_LN_BWD4(1, 16, true); else if (d == 512) TTTS_LN_BWD4(2, 8, true); else TTTS_LN_BWD4(4, 4, true);
+        } else {
+            if (d == 256) TTTS_LN_BWD4(1, 16, false); else if (d == 512) TTTS_LN_BWD4(2, 8, false); else TTTS_LN_BWD4(4, 4, false);
+        }
+#undef TTTS_LN_BWD4
         TTTS_LAUNCH_CHECK("layernorm_bwd_v4_kernel");
         return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate & 1, stream, (accumulate & 2) != 0);
     }
@@ -545,6 +571,23 @@ int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const
 #undef TTTS_LN_BWD
     TTTS_LAUNCH_CHECK("layernorm_bwd_kernel");
     return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate & 1, stream, (accumulate & 2) != 0);
+}
+
+int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
+                       int accumulate, void* stream) {
+    return layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, ws_bytes, M, d, accumulate, nullptr, 0.f, 0,
+                              nullptr, nullptr, (hipStream_t)stream);
+}
+
+int ttts_layernorm_bwd_drop(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                            float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
+                            int accumulate, float* dacc, float drop_p, uint64_t seed, const uint64_t* step_seed,
+                            float* dacc_amax, void* stream) {
+    TTTS_REQUIRE(dacc, "layernorm_bwd_drop: dacc is required");
+    TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd_drop: bad dropout p");
+    return layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, ws_bytes, M, d, accumulate, dacc, drop_p, seed,
+                              step_seed, dacc_amax, (hipStream_t)stream);
 }
 
 size_t ttts_bn_workspace_bytes(int64_t M, int C) {

@@ -103,8 +103,9 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, src: Tensor, src_lens: Tensor) -> Tensor:
         p1 = self.dropout1.p if self.training else 0.0
         s = self.self_attn.self_attention(src, src_lens, False, residual=src, out_drop=p1)
-        x = ops.layer_norm(s, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        x = ops.layer_norm(_ffn_block(self, x, self.dropout2), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x = ops.layer_norm(s, self.norm1.weight, self.norm1.bias, self.norm1.eps, sole_consumer=True)
+        x = ops.layer_norm(_ffn_block(self, x, self.dropout2), self.norm2.weight, self.norm2.bias, self.norm2.eps,
+                           sole_consumer=True)
         return x
 
 
@@ -167,12 +168,13 @@ class TransformerDecoderLayer(nn.Module):
         causal = bool(tgt_is_causal) or tgt_mask is not None
         tr = self.training
         s = self.self_attn.self_attention(tgt, tgt_lens, causal, residual=tgt, out_drop=self.dropout1.p if tr else 0.0)
-        x = ops.layer_norm(s, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = ops.layer_norm(s, self.norm1.weight, self.norm1.bias, self.norm1.eps, sole_consumer=True)
         s, alignments = self.multihead_attn.cross_attention(x, memory, memory_lens, residual=x,
                                                             out_drop=self.dropout2.p if tr else 0.0,
                                                             need_weights=need_alignments)
-        x = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        x = ops.layer_norm(_ffn_block(self, x, self.dropout3), self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        x = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps, sole_consumer=True)
+        x = ops.layer_norm(_ffn_block(self, x, self.dropout3), self.norm3.weight, self.norm3.bias, self.norm3.eps,
+                           sole_consumer=True)
         return x, alignments
 
 

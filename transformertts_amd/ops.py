@@ -427,7 +427,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out=None, tok_in=None, skip_in=None,
-                skip_out=None):
+                skip_out=None, tok_drop=None):
         lib = _lib.load()
         x = _chk(x, "linear.x")
         w = _chk(w, "linear.weight")
@@ -456,6 +456,7 @@ class LinearFn(torch.autograd.Function):
         ctx.sinks = _sinks(w, b)
         ctx.ss = _ss()              # backward regenerates the dropout mask under the step-state word of ITS forward
         ctx.toks = (tok_out, tok_in, skip_in, skip_out)
+        ctx.tok_drop = tok_drop
         # x is the output of an attention kernel and feeds nothing but this Linear: the gradient this backward returns for it
         # reaches the attention backward as it is (never summed with another one), so its maxima can ride on the tensor
         ctx.sole_consumer = bool(getattr(x, "_ttts_sole_consumer", False))
@@ -484,10 +485,15 @@ class LinearFn(torch.autograd.Function):
             _lib.check(lib.ttts_relu_dropout_bwd(_p(dy), _p(y), _p(dacc), dy.numel(), drop_p, _p(am), _stream()),
                        "ttts_relu_dropout_bwd")
         elif drop_p > 0.0:
-            dacc = torch.empty_like(dy)
-            am = torch.empty(1024, dtype=torch.float32, device=dy.device) if want_am else None
-            _lib.check(lib.ttts_dropout_bwd(_p(dy), _p(dacc), dy.numel(), drop_p, seed, ctx.ss, _p(am), _stream()),
-                       "ttts_dropout_bwd")
+            td = ctx.tok_drop
+            if td is not None and td.dacc is not None and td.dx is dy:
+                dacc, am = td.dacc, td.amax          # written by the LayerNorm backward that produced dy
+                td.dx = td.dacc = td.amax = None
+            else:
+                dacc = torch.empty_like(dy)
+                am = torch.empty(1024, dtype=torch.float32, device=dy.device) if want_am else None
+                _lib.check(lib.ttts_dropout_bwd(_p(dy), _p(dacc), dy.numel(), drop_p, seed, ctx.ss, _p(am), _stream()),
+                           "ttts_dropout_bwd")
         else:
             dacc = dy
         dx = dw = db = None
@@ -533,7 +539,7 @@ class LinearFn(torch.autograd.Function):
         dres = dy if has_r else None
         if has_r and skip_out is not None:      # hand the skip gradient to the block's first Linear instead of autograd
             skip_out.grad, dres = dy, None
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None
 
 
 # Test seam: called with the output of every relu-epilogue Linear, in call order (which units the HIP path gated off).
@@ -547,6 +553,17 @@ class _ReluToken:
 
     def __init__(self, scale: float):
         self.scale, self.premasked = scale, False
+
+
+class _DropToken:
+    """Handshake between a Linear with a residual-dropout epilogue (y = drop(x W + b) + residual) and the LayerNorm that is
+    the ONLY reader of y: the LayerNorm's backward kernel writes, next to its dx, the dropped copy the Linear's backward
+    would compute from dx in a pass of its own (`ttts_dropout_bwd`), with its partial maxima."""
+    __slots__ = ("p", "seed", "ss", "dx", "dacc", "amax")
+
+    def __init__(self, p: float, seed: int, ss):
+        self.p, self.seed, self.ss = p, seed, ss
+        self.dx = self.dacc = self.amax = None
 
 
 class SkipToken:
@@ -572,7 +589,12 @@ def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_sh
         skip_in = None                      # nobody will pick the gradient up: leave it to autograd
     if skip_out is not None and (residual is None or not grad_on):
         skip_out = None
-    y = LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out, tok_in, skip_in, skip_out)
+    tok_drop = None
+    if grad_on and act == ACT_NONE and float(drop_p) > 0.0 and residual is not None and x.is_cuda:
+        tok_drop = _DropToken(float(drop_p), seed, _ss())
+    y = LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out, tok_in, skip_in, skip_out, tok_drop)
+    if tok_drop is not None:
+        y._ttts_drop_token = tok_drop           # picked up by layer_norm(y, ..., sole_consumer=True)
     if tok_out is not None:
         y._ttts_relu_token = tok_out
         if _relu_observer is not None:
@@ -752,8 +774,9 @@ def conv_bn(x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, trai
 # ----------------------------------------------------------------------------------------------- layer norm
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, tok_drop=None):
         lib = _lib.load()
+        ctx.tok_drop = tok_drop
         x = _chk(x, "layernorm.x")
         d = x.shape[-1]
         M = x.numel() // d
@@ -782,14 +805,27 @@ class LayerNormFn(torch.autograd.Function):
             t_g = dgamma = torch.empty_like(gamma)
             t_b = dbeta = torch.empty_like(gamma)
         ws = _ws(lib.ttts_layernorm_bwd_workspace_bytes(d), x.device)
-        _lib.check(lib.ttts_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(t_g), _p(t_b),
-                                          _p(ws), ws.numel() * 4, M, d, _defer(acc, ws) if sk is not None else acc, _stream()),
-                   "ttts_layernorm_bwd")
-        return dx, dgamma, dbeta, None
+        accf = _defer(acc, ws) if sk is not None else acc
+        td = ctx.tok_drop
+        if td is not None and d in (256, 512, 1024):
+            # x is the output of a Linear with residual dropout and feeds nothing but this LayerNorm: dx is that Linear's dy
+            dacc = torch.empty_like(x)
+            am = _amax_slots(x.device, True)
+            _lib.check(lib.ttts_layernorm_bwd_drop(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(t_g), _p(t_b),
+                                                   _p(ws), ws.numel() * 4, M, d, accf, _p(dacc), td.p, td.seed, td.ss, _p(am),
+                                                   _stream()), "ttts_layernorm_bwd_drop")
+            td.dx, td.dacc, td.amax = dx, dacc, am
+        else:
+            _lib.check(lib.ttts_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(t_g), _p(t_b),
+                                              _p(ws), ws.numel() * 4, M, d, accf, _stream()), "ttts_layernorm_bwd")
+        return dx, dgamma, dbeta, None, None
 
 
-def layer_norm(x, gamma, beta, eps=1e-5):
-    return LayerNormFn.apply(x, gamma, beta, eps)
+def layer_norm(x, gamma, beta, eps=1e-5, sole_consumer=False):
+    """`sole_consumer=True` is the caller's promise that nothing but this LayerNorm reads `x`; if `x` came out of a Linear
+    with a residual-dropout epilogue, that Linear's dropout backward is then written by this LayerNorm's backward kernel."""
+    tok = getattr(x, "_ttts_drop_token", None) if (sole_consumer and torch.is_grad_enabled()) else None
+    return LayerNormFn.apply(x, gamma, beta, eps, tok)
 
 
 # ----------------------------------------------------------------------------------------------- attention
