@@ -9,8 +9,10 @@
  * Conventions:
  *   - plain pointers + sizes only; activations are row-major contiguous (B,T,C) fp32, weights keep the
  *     state-dict layouts ((out,in) linear, (Cout,Cin,K) conv, packed (3d,d) in-proj); lengths are int64.
- *   - every function only ENQUEUES work on `stream` (a hipStream_t passed as void*); no allocation,
- *     no synchronisation, no global state.  Workspaces are owned by the caller.
+ *   - every function only ENQUEUES work on `stream` (a hipStream_t passed as void*); no device allocation, no
+ *     synchronisation, no state that outlives the call: workspaces are owned by the caller, and so is the one host-side
+ *     object of the ABI, the deferred-reduction queue (ttts_reduce_queue).  The library reads no environment variables.
+ *     Calls are re-entrant from several host threads on different streams (different queues, different workspaces).
  *   - return 0 on success, a negative TTTS_ERR_* otherwise (never throws / exits);
  *     ttts_last_error() returns a thread-local message for the last failure.
  *   - dropout masks are a pure function of (seed, flat element index), so backward entry points
@@ -51,6 +53,23 @@ typedef struct ttts_step_state {
 const char* ttts_last_error(void);
 int ttts_abi_version(void);
 
+/* ---- deferred second-stage reductions ---------------------------------------------------------------------------
+ * The weight-gradient (linear / conv1d / rowdot) and LayerNorm-backward entry points end in a small reduction of
+ * their split-K or per-block partials into the parameter gradient -- ~90 launches of a few microseconds each per training
+ * step.  They take a `queue` argument: NULL launches the reduction at once; a queue created by the caller makes the
+ * entry point append a descriptor to it instead, and ttts_reduce_queue_flush runs everything appended so far in one
+ * launch per 48 entries (same summation order as the immediate form, bit for bit).  Until the flush has been enqueued on
+ * the same stream the caller must keep every workspace (`ws`) it passed alive and must not read those gradients.
+ * The queue is host memory owned by its creator; the library keeps no queue of its own.  Appending (from whichever
+ * thread runs the backward node) and flushing are safe against each other; two independent backward passes use two
+ * queues.  clear drops what is queued (after a failed pass). */
+typedef struct ttts_reduce_queue ttts_reduce_queue;
+ttts_reduce_queue* ttts_reduce_queue_create(void);
+void ttts_reduce_queue_destroy(ttts_reduce_queue* queue);
+int64_t ttts_reduce_queue_pending(ttts_reduce_queue* queue);
+int ttts_reduce_queue_flush(ttts_reduce_queue* queue, void* stream);
+int ttts_reduce_queue_clear(ttts_reduce_queue* queue);
+
 /* ------------------------------------------------------------------ linear (nn.Linear / LinearNorm)
  * y[M,N] = drop(act(x[M,K] . w[N,K]^T + bias)) + residual          K % 16 == 0
  * Replaces: LinearNorm.forward (model/module.py:52-53); MHA in/out projections
@@ -73,7 +92,8 @@ int ttts_linear_bwd_data(const float* dy, const float* w, const float* residual,
  * gradients can land directly in slices of one flat, pre-zeroed gradient buffer (the data-parallel bucket). */
 size_t ttts_wgrad_workspace_bytes(int64_t M, int N, int K, int taps);
 int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
-                           int64_t M, int N, int K, int row_shift, int T, int accumulate, void* stream);
+                           int64_t M, int N, int K, int row_shift, int T, int accumulate, ttts_reduce_queue* queue,
+                           void* stream);
 
 /* ---- split-precision ("bf16x6") forms of the forward / data-gradient GEMMs.  Same arithmetic contract (fp32 in,
  * fp32 out, fp32 accumulate) with every product formed as six bf16 x bf16 MFMA terms of a 3-way hi/mid/lo split:
@@ -85,13 +105,20 @@ int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db
  *   mode 2  conv forward       [co][tap*cin + ci]              rows = cout, cols = taps*cin,  channels_per_tap = cin
  *   mode 3  conv data-grad     [ci][tap*cout + co]             rows = cin,  cols = taps*cout, channels_per_tap = cout
  *
- * fp16x3 ("h3") form: modes 4-7 of ttts_weight_split are the same four matrices as modes 0-3 written as
- * TWO f16 planes (hi, lo) of w * 2^12, stored [cols/32][plane][rows][32] (cols, and channels_per_tap for the conv modes,
- * must be multiples of 32).  ttts_linear_fwd_h3 / ttts_conv1d_fwd_h3 take such planes and form each product from three
- * f16 x f16 MFMA terms (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, activations pre-scaled by 2^4 while they are staged): the
- * same fp32-grade result (error vs fp64 a few 1e-7) for half the matrix-pipe work.  f16 has no bf16-like exponent range:
- * the fixed pre-scales suit O(1) activations and O(1/sqrt(fan_in)) weights -- the forward operands of this model --
- * and activations of magnitude >= 4096 come out as inf.  Gradient operands get a dynamic pre-scale (ttts_amax_partials). */
+ * fp16x3 ("h3") form: modes 4-7 of ttts_weight_split are the same four matrices as modes 0-3 written as TWO f16 planes
+ * (hi, lo) of w * s, stored [cols/32][plane][rows][32] (cols, and channels_per_tap for the conv modes, must be multiples
+ * of 32), followed by a 16-byte tail whose first float is max|w|: s is the power of two that puts max|w| in [2^11, 2^12),
+ * measured by the split itself and re-derived from the tail by every kernel that takes the planes.
+ * ttts_linear_fwd_h3 / ttts_conv1d_fwd_h3 take such planes and form each product from three f16 x f16 MFMA terms
+ * (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi): the same fp32-grade result (error vs fp64 a few 1e-7) for half the matrix-pipe
+ * work.  f16 has no bf16-like exponent range, so the ACTIVATION operand is pre-scaled while it is staged, by the power
+ * of two that puts ITS measured maximum in [2^11, 2^12): `x_amax` = 1024 partial maxima of |x| (their maximum must be
+ * >= max|x|; ttts_amax_partials computes them with one read of x, and every kernel of this header that PRODUCES an
+ * activation or a gradient can leave them behind itself: the `*_amax_out` arguments).  Every element within 2^-15 of the
+ * largest keeps 22 significant bits, smaller ones an absolute error of 2^-37 * max|x| -- no assumption about the operands'
+ * magnitudes is left.
+ * Arrays named `*_amax_out` are filled with slot-wise atomic maxima and must be zeroed by the caller first (ttts_zero);
+ * `*_amax_partials` are fully written. */
 size_t ttts_split_bytes(int64_t rows, int64_t cols);
 /* tile shape the forward / data-gradient dispatch uses for an M x N output with reduction length K (1: 64x64, 2: 128x128,
  * 3: 64x128, 4: 128x96; fp16x3 only: 6: 256x256 / 8 waves, 7: 256x128 / 8 waves, 8: 256x128 / 4 waves, two workgroups per
@@ -105,19 +132,14 @@ int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks,
 int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
                        int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift, int T,
                     void* stream);
+/* y_amax_out: NULL, or a caller-zeroed 1024-float array receiving max|y| (y feeds another fp16x3 GEMM / attention) */
 int ttts_linear_fwd_h3(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
                        int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift,
-                       int T, void* stream);
+                       int T, const float* x_amax, float* y_amax_out, void* stream);
 int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
-                       int taps, void* stream);
-/* fp16x3 data gradients.  A gradient's magnitude is not known in advance (1e-7 .. 1e-5 behind a mean-reduced loss), so
- * its pre-scale is dynamic: ttts_amax_partials writes 1024 partial maxima of |dy| (one read of dy, no atomics, no host
- * round trip) and the GEMM scales dy by the power of two that puts max|dy| in [2^11, 2^12) -- full 22-bit precision for
- * every element within 2^-15 of the largest, absolute error 2^-29 * 2^-11 * max|dy| below that.  planes: modes 5 / 7.
- * A kernel that PRODUCES a gradient another fp16x3 GEMM consumes can emit these maxima itself and save the pass: the
- * `*_amax_out` / `*_amax_partials` arguments (NULL, or 1024 floats) of ttts_linear_bwd_data_h3, ttts_attention_bwd_h3,
- * ttts_bn_bwd, ttts_dropout_bwd and ttts_relu_dropout_bwd.  Arrays named `*_amax_out` are filled with slot-wise atomic
- * maxima and must be zeroed by the caller first (ttts_zero); `*_amax_partials` are fully written. */
+                       int taps, const float* x_amax, void* stream);
+/* fp16x3 data gradients: as the forward, with the gradient as the activation operand (dy_amax: its partial maxima;
+ * 1e-7 .. 1e-5 behind a mean-reduced loss, any magnitude in general).  planes: modes 5 / 7. */
 int ttts_amax_partials(const float* x, int64_t n, float* partials /* 1024 floats */, void* stream);
 int ttts_linear_bwd_data_h3(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
                             int K, const float* relu_out, float relu_scale, const float* dy_amax, float* dx_amax_out,
@@ -133,17 +155,19 @@ int ttts_conv1d_bwd_data_x6(const float* dy, const void* planes_bwd, float* dx, 
 /* Weight gradients in the same split-precision form (both operands are activations, split while they are staged);
  * arguments, workspace (ttts_wgrad_workspace_bytes) and results as ttts_linear_bwd_weight / ttts_conv1d_bwd_weight. */
 int ttts_linear_bwd_weight_x6(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
-                              int64_t M, int N, int K, int row_shift, int T, int accumulate, void* stream);
+                              int64_t M, int N, int K, int row_shift, int T, int accumulate, ttts_reduce_queue* queue,
+                              void* stream);
 int ttts_conv1d_bwd_weight_x6(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
-                              int T, int cin, int cout, int taps, int accumulate, void* stream);
-/* fp16x3 weight gradients: dy pre-scaled dynamically from dy_amax (ttts_amax_partials, shared with the data gradient of
- * the same dy), x by the static activation scale; shapes the split kernels do not cover fall back to the fp32-MFMA kernel
- * exactly as the _x6 entry points do. */
+                              int T, int cin, int cout, int taps, int accumulate, ttts_reduce_queue* queue, void* stream);
+/* fp16x3 weight gradients: both operands are activations, pre-scaled from their partial maxima (dy_amax is shared with the
+ * data gradient of the same dy, x_amax with the forward GEMM that read x); shapes the split kernels do not cover fall
+ * back to the fp32-MFMA kernel exactly as the _x6 entry points do. */
 int ttts_linear_bwd_weight_h3(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
                               int64_t M, int N, int K, int row_shift, int T, int accumulate, const float* dy_amax,
-                              void* stream);
+                              const float* x_amax, ttts_reduce_queue* queue, void* stream);
 int ttts_conv1d_bwd_weight_h3(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
-                              int T, int cin, int cout, int taps, int accumulate, const float* dy_amax, void* stream);
+                              int T, int cin, int cout, int taps, int accumulate, const float* dy_amax, const float* x_amax,
+                              ttts_reduce_queue* queue, void* stream);
 
 /* ------------------------------------------------------------------ Conv1d (k taps, same padding) on (B,T,C)
  * Replaces ConvNormBN's permute -> nn.Conv1d(pad=(k-1)//2) -> permute (model/module.py:28-33) as an
@@ -156,7 +180,7 @@ int ttts_conv1d_fwd(const float* x, const float* w_fwd, const float* bias, float
 int ttts_conv1d_bwd_data(const float* dy, const float* w_bwd, float* dx, int B, int T, int cin, int cout, int taps,
                          void* stream);
 int ttts_conv1d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
-                           int T, int cin, int cout, int taps, int accumulate, void* stream);
+                           int T, int cin, int cout, int taps, int accumulate, ttts_reduce_queue* queue, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm1d over (M = B*T rows, C channels)
  * Replaces nn.BatchNorm1d inside ConvNormBN (model/module.py:19,31) plus the Tanh / Dropout entries that
@@ -169,9 +193,10 @@ int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* runni
                         float eps, void* stream);
 int ttts_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C, float eps,
                        void* stream);
-/* z = drop(act((x - mean) * invstd * gamma + beta)) */
+/* z = drop(act((x - mean) * invstd * gamma + beta)); z_amax_out: NULL, or a caller-zeroed 1024-float array receiving max|z| */
 int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                      float* z, int64_t M, int C, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
+                      float* z, int64_t M, int C, int act, float drop_p, uint64_t seed, const uint64_t* step_seed,
+                      float* z_amax_out, void* stream);
 /* train-mode backward through drop/act/BN: dx, dgamma, dbeta from dz and the saved x, mean, invstd */
 int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float* invstd, const float* gamma,
                 const float* beta, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int C,
@@ -182,11 +207,11 @@ int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float*
  * Replaces nn.LayerNorm norm1/2/3 of the encoder/decoder layers (torch/nn/modules/transformer.py:951-956,
  * model/layers.py:47-50).  The residual sum is produced by the preceding GEMM's epilogue. */
 int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                       int64_t M, int d, float eps, void* stream);
+                       int64_t M, int d, float eps, float* y_amax_out /* NULL, or zeroed 1024 floats: max|y| */, void* stream);
 size_t ttts_layernorm_bwd_workspace_bytes(int d);
 int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
-                       int accumulate, void* stream);
+                       int accumulate, ttts_reduce_queue* queue, void* stream);
 /* the same, and in the same pass dacc = dx * keep(seed, element) / (1 - drop_p): the gradient behind the residual dropout
  * of the sublayer whose output this LayerNorm normalised (ttts_dropout_bwd(dx) without a pass of its own; same mask as
  * the forward epilogue of that sublayer's last Linear).  dacc_amax: NULL, or a caller-zeroed 1024-float array that receives
@@ -194,7 +219,7 @@ int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const
 int ttts_layernorm_bwd_drop(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                             float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
                             int accumulate, float* dacc, float drop_p, uint64_t seed, const uint64_t* step_seed,
-                            float* dacc_amax, void* stream);
+                            float* dacc_amax, ttts_reduce_queue* queue, void* stream);
 
 /* ------------------------------------------------------------------ attention (head_dim = 64)
  * Scaled dot-product attention with masks computed from lengths in-kernel (no mask tensors):
@@ -218,12 +243,13 @@ int ttts_attention_bwd(const float* q, const float* k, const float* v, const flo
 int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
-/* fp16x3 form of the forward (three f16 MFMA terms on operands pre-scaled into f16's range: Q/8, K, V x 2^4 -- O(1)
- * projections of normalised activations -- and probabilities x 2^10); same arguments, lse in natural units, so either
- * backward form can follow it. */
+/* fp16x3 form of the forward (three f16 MFMA terms; Q/8, K and V pre-scaled from their partial maxima q_amax / k_amax /
+ * v_amax -- 1024 floats each, the same array three times for a packed projection output -- and probabilities x 2^10);
+ * lse in natural units, so either backward form can follow it.  o_amax_out: NULL, or zeroed 1024 floats: max|o|. */
 int ttts_attention_fwd_h3(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
+                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* q_amax,
+                          const float* k_amax, const float* v_amax, float* o_amax_out, void* stream);
 int ttts_attention_bwd_x6(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
@@ -235,16 +261,18 @@ int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const 
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
-                          float* dq_amax_out, float* dkv_amax_out, void* stream);
+                          float* dq_amax_out, float* dkv_amax_out, const float* q_amax, const float* k_amax,
+                          const float* v_amax, void* stream);
 
 /* ------------------------------------------------------------------ small row / element-wise pieces
  * nn.Embedding gather / scatter-add (model/model.py:168,288; no padding_idx) */
-int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d, void* stream);
+int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d,
+                       float* out_amax_out /* NULL, or zeroed 1024 floats: max|out| */, void* stream);
 int ttts_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t n, int vocab, int d, int accumulate,
                        void* stream);
 /* PositionalEncoding.forward (model/model.py:91-97): y = drop(x + alpha * pe[t]) */
 int ttts_posenc_fwd(const float* x, const float* pe, const float* alpha, float* y, int B, int T, int d, float drop_p,
-                    uint64_t seed, const uint64_t* step_seed, void* stream);
+                    uint64_t seed, const uint64_t* step_seed, float* y_amax_out /* NULL, or zeroed 1024 floats */, void* stream);
 size_t ttts_posenc_bwd_workspace_bytes(void);
 int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, float* ws, size_t ws_bytes, int B, int T,
                     int d, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate, void* stream);
@@ -258,19 +286,6 @@ int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64
                      float* amax_partials, void* stream);
 /* p[0 .. nbytes) = 0, enqueued as a memset on the stream (the flat gradient bucket at the start of a step) */
 int ttts_zero(void* p, size_t nbytes, void* stream);
-/* ---- deferred second-stage reductions ---------------------------------------------------------------------------
- * The weight-gradient (linear / conv1d / rowdot) and LayerNorm-backward entry points end in a small reduction of
- * their split-K or per-block partials into the parameter gradient -- ~90 launches of a few microseconds each per training
- * step.  Between ttts_reduce_defer_begin() and ttts_reduce_defer_flush() those reductions are queued on the host instead,
- * and flush runs the whole queue in one launch per 48 entries (same summation order as the immediate form).  The caller
- * must keep every workspace (`ws`) it passed alive, and must not read the gradients, until the flush has been enqueued
- * on the same stream.  Process-wide state, guarded by a mutex (autograd runs backward nodes on its own threads).
- * flush(keep_deferring != 0) runs what is queued and stays in deferred mode (gradients needed mid-pass, e.g. to start a
- * collective); abort drops the queue and returns to immediate launches (after a failed pass). */
-int ttts_reduce_defer_begin(void);
-int64_t ttts_reduce_defer_pending(void);
-int ttts_reduce_defer_flush(int keep_deferring, void* stream);
-int ttts_reduce_defer_abort(void);
 /* z = x + y */
 int ttts_add(const float* x, const float* y, float* z, int64_t n, void* stream);
 /* ---- input side: device-side padding of a ragged batch --------------------------------------
@@ -287,7 +302,7 @@ int ttts_collate_phoneme(const int64_t* ragged, const int64_t* offsets, int64_t*
 int ttts_rowdot_fwd(const float* x, const float* w, const float* b, float* y, int64_t M, int d, void* stream);
 size_t ttts_rowdot_bwd_workspace_bytes(int d);
 int ttts_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx_accum, float* dw, float* db, float* ws,
-                    size_t ws_bytes, int64_t M, int d, int accumulate, void* stream);
+                    size_t ws_bytes, int64_t M, int d, int accumulate, ttts_reduce_queue* queue, void* stream);
 
 /* ------------------------------------------------------------------ loss and scheduled-sampling mix
  * TransformerTTSLoss.forward (loss.py:15-55): out4 = [total, pred_mel, post_mel, stop]; masked MSE over frames

@@ -57,52 +57,78 @@ def test_linear_forms_agree_with_fp64(M, N, K):
         dw, db = torch.empty(N, K, device=_dev()), torch.empty(N, device=_dev())
         ws = torch.empty(lib.ttts_wgrad_workspace_bytes(M, N, K, 1) // 4, device=_dev())
         f = lib.ttts_linear_bwd_weight_x6 if x6 else lib.ttts_linear_bwd_weight
-        rc = f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 0, _stream())
+        rc = f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 0, None, _stream())
         assert rc == 0 and _rel(dw, dw_ref) < TOL and _rel(db, db_ref) < TOL
         # accumulate = 1 adds to what is there
-        rc = f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 1, _stream())
+        rc = f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 1, None, _stream())
         assert rc == 0 and _rel(dw, 2 * dw_ref) < TOL and _rel(db, 2 * db_ref) < TOL
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1024, 256), (777, 256, 1024), (129, 80, 256), (64, 96, 32)])
 def test_fp16x3_forward_form_agrees_with_fp64(M, N, K):
-    """The fp16x3 forward kernel (three f16 MFMA terms on pre-scaled operands, csrc/gemm_h3.hip) against fp64: same gate
-    as the bf16x6 and fp32-MFMA forms, with every epilogue (bias, relu, residual, dropout mask identical to the bf16x6
-    kernel's, go-frame row shift), and over the operand magnitudes its fixed pre-scales are specified for."""
+    """The fp16x3 forward kernel (three f16 MFMA terms, both operands pre-scaled from their measured maxima,
+    csrc/gemm_h3.hip) against fp64: same gate as the bf16x6 and fp32-MFMA forms, with every epilogue (bias, relu, residual,
+    dropout mask identical to the bf16x6 kernel's, go-frame row shift) -- and for operands of ANY magnitude: activations and
+    weights from 1e-6 to 1e6, an outlier 5000 x the rest (which the fixed pre-scales of round 2 turned into inf)."""
     from transformertts_amd import _lib, ops
     from transformertts_amd.ops import _p, _stream
     lib = _lib.load()
-    b = _rand(N, seed=3)
-    for a_scale, w_scale in ((1.0, 1.0), (30.0, 0.2), (0.02, 5.0)):         # large and small activations / weights
+
+    def fwd(x, pl, b, res, y, act=0, p=0.0, seed=0, shift=0, T=0, y_am=None):
+        return lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), _p(res), _p(y), M, N, K, act, p, seed, None, shift, T,
+                                      _p(ops._amax(x)), _p(y_am), _stream())
+    b0 = _rand(N, seed=3)
+    for a_scale, w_scale in ((1.0, 1.0), (30.0, 0.2), (0.02, 5.0), (1e-6, 1.0), (1e6, 1.0), (1.0, 1e-6), (1.0, 1e6),
+                             (1e6, 1e-6), (1e-6, 1e6), (1e-6, 1e-6), (1e6, 1e6), (3e-20, 7e12)):
         x, w = _rand(M, K, seed=1) * a_scale, _rand(N, K, seed=2, scale=K ** -0.5) * w_scale
+        b = b0 * (a_scale * w_scale)                                   # a bias of the products' magnitude
         ref = x.double() @ w.double().t() + b.double()
         y = torch.empty(M, N, device=_dev())
         pl = ops._planes(w, 4, N, K)
-        assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream()) == 0
+        assert fwd(x, pl, b, None, y) == 0
         assert _rel(y, ref) < TOL, (a_scale, w_scale, _rel(y, ref))
+    b = b0
     x, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
     pl, pl6 = ops._planes(w, 4, N, K), ops._planes(w, 0, N, K)
     res = _rand(M, N, seed=8)
     ref = x.double() @ w.double().t() + b.double()
     y, y6 = torch.empty(M, N, device=_dev()), torch.empty(M, N, device=_dev())
-    assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), _p(res), _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream()) == 0
+    assert fwd(x, pl, b, res, y) == 0
     assert _rel(y, ref + res.double()) < TOL
-    assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 1, 0.0, 0, None, 0, 0, _stream()) == 0
+    slots = torch.zeros(1024, device=_dev())
+    assert fwd(x, pl, b, None, y, act=1, y_am=slots) == 0
     assert _rel(y, torch.relu(ref)) < TOL
-    assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.3, 1234, None, 0, 0, _stream()) == 0
+    assert slots.max().item() == y.abs().max().item()           # the epilogue's own maxima of y (slot-wise atomic max)
+    assert fwd(x, pl, b, None, y, p=0.3, seed=1234) == 0
     assert lib.ttts_linear_fwd_x6(_p(x), _p(pl6), _p(b), None, _p(y6), M, N, K, 0, 0.3, 1234, None, 0, 0, _stream()) == 0
     assert torch.equal(y == 0, y6 == 0) and _rel(y, y6) < TOL           # same counter-based mask in both forms
     if M % 10 == 0:                                                     # go-frame shift inside utterances of T rows
         T = M // 10
-        assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, -1, T, _stream()) == 0
+        assert fwd(x, pl, b, None, y, shift=-1, T=T) == 0
         xs = torch.roll(x.view(10, T, K), 1, dims=1).clone()
         xs[:, 0] = 0
         assert _rel(y, xs.view(M, K).double() @ w.double().t() + b.double()) < TOL
-    # out of the window the kernel is specified for: an activation >= 4096 saturates visibly, never silently
+    # an outlier activation: finite, and both its row and the ordinary rows beside it are fp32-grade
     x2 = x.clone()
     x2[3, 5] = 5000.0
-    assert lib.ttts_linear_fwd_h3(_p(x2), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream()) == 0
-    assert not torch.isfinite(y[3]).all() and torch.isfinite(y[4]).all()
+    assert fwd(x2, pl, b, None, y) == 0
+    ref2 = x2.double() @ w.double().t() + b.double()
+    assert torch.isfinite(y).all() and _rel(y[3], ref2[3]) < TOL and _rel(y[4:], ref2[4:]) < TOL and _rel(y, ref2) < TOL
+    # an outlier weight (|w| >= 16 overflowed the fixed 2^12 weight scale of round 2)
+    w2 = w.clone()
+    w2[1, 2] = 300.0
+    pl2 = ops._planes(w2, 4, N, K)
+    assert fwd(x, pl2, b, None, y) == 0
+    ref3 = x.double() @ w2.double().t() + b.double()
+    assert torch.isfinite(y).all() and _rel(y, ref3) < TOL and _rel(y[:, 2:], ref3[:, 2:]) < TOL
+    # non-finite operands travel on visibly, as in fp32 arithmetic
+    x3 = x.clone()
+    x3[7, 1] = float("inf")
+    assert fwd(x3, pl, b, None, y) == 0
+    assert not torch.isfinite(y[7]).any()
+    # an all-zero activation
+    assert fwd(torch.zeros_like(x), pl, b, None, y) == 0
+    assert _rel(y, b.double().expand(M, N)) < TOL
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1024, 256), (777, 256, 1024), (129, 96, 80)])
@@ -153,14 +179,22 @@ def test_fp16x3_weight_gradient(M, N, K, mag):
     dw, db = torch.empty(N, K, device=_dev()), torch.empty(N, device=_dev())
     ws = torch.empty(lib.ttts_wgrad_workspace_bytes(M, N, K, 1) // 4, device=_dev())
     f = lib.ttts_linear_bwd_weight_h3
-    assert f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 0, _p(am), _stream()) == 0
+    xm = ops._amax(x)
+    assert f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 0, _p(am), _p(xm), None, _stream()) == 0
     dw_ref, db_ref = dy.double().t() @ x.double(), dy.double().sum(0)
     assert _rel(dw, dw_ref) < TOL and _rel(db, db_ref) < TOL, (_rel(dw, dw_ref), _rel(db, db_ref))
-    assert f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 1, _p(am), _stream()) == 0
+    assert f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 1, _p(am), _p(xm), None, _stream()) == 0
     assert _rel(dw, 2 * dw_ref) < TOL and _rel(db, 2 * db_ref) < TOL
+    # activations of any magnitude (the x operand had a fixed 2^4 pre-scale in round 2)
+    for xs_ in (1e-6, 1e6):
+        x2 = x * xs_
+        x2[M // 3, 1] *= 3000.0
+        assert f(_p(dy), _p(x2), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 0, _p(am), _p(ops._amax(x2)), None,
+                 _stream()) == 0
+        assert torch.isfinite(dw).all() and _rel(dw, dy.double().t() @ x2.double()) < TOL
     if M % 10 == 0:
         T = M // 10
-        assert f(_p(dy), _p(x), _p(dw), None, _p(ws), ws.numel() * 4, M, N, K, -1, T, 0, _p(am), _stream()) == 0
+        assert f(_p(dy), _p(x), _p(dw), None, _p(ws), ws.numel() * 4, M, N, K, -1, T, 0, _p(am), _p(xm), None, _stream()) == 0
         xs = torch.roll(x.view(10, T, K), 1, dims=1).clone()
         xs[:, 0] = 0
         assert _rel(dw, dy.double().t() @ xs.view(M, K).double()) < TOL
@@ -180,7 +214,7 @@ def test_fp16x3_conv_weight_gradient(B, T, cin, cout):
     dw, db = torch.empty(cout, cin, 5, device=_dev()), torch.empty(cout, device=_dev())
     ws = torch.empty(lib.ttts_wgrad_workspace_bytes(B * T, cout, cin, 5) // 4, device=_dev())
     assert lib.ttts_conv1d_bwd_weight_h3(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, B, T, cin, cout, 5, 0,
-                                         _p(ops._amax(dy)), _stream()) == 0
+                                         _p(ops._amax(dy)), _p(ops._amax(x)), None, _stream()) == 0
     assert _rel(dw, wd.grad) < TOL and _rel(db, bd.grad) < TOL, (_rel(dw, wd.grad), _rel(db, bd.grad))
 
 
@@ -209,8 +243,12 @@ def test_fp16x3_conv_forward_agrees_with_fp64(B, T, cin, cout):
     ref = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), b.double(), padding=2).transpose(1, 2)
     y = torch.empty(B, T, cout, device=_dev())
     pl = ops._planes(w, 6, cout, 5 * cin, cin, 5)
-    assert lib.ttts_conv1d_fwd_h3(_p(x), _p(pl), _p(b), _p(y), B, T, cin, cout, 5, _stream()) == 0
+    assert lib.ttts_conv1d_fwd_h3(_p(x), _p(pl), _p(b), _p(y), B, T, cin, cout, 5, _p(ops._amax(x)), _stream()) == 0
     assert _rel(y, ref) < TOL, _rel(y, ref)
+    x2 = x * 1e5                                                    # any magnitude
+    assert lib.ttts_conv1d_fwd_h3(_p(x2), _p(pl), _p(b), _p(y), B, T, cin, cout, 5, _p(ops._amax(x2)), _stream()) == 0
+    ref2 = torch.nn.functional.conv1d(x2.double().transpose(1, 2), w.double(), b.double(), padding=2).transpose(1, 2)
+    assert torch.isfinite(y).all() and _rel(y, ref2) < TOL
 
 
 @pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128)])
@@ -226,7 +264,7 @@ def test_conv_weight_gradient_forms(B, T, cin, cout):
     for f in (lib.ttts_conv1d_bwd_weight, lib.ttts_conv1d_bwd_weight_x6):
         dw, db = torch.empty(cout, cin, 5, device=_dev()), torch.empty(cout, device=_dev())
         ws = torch.empty(lib.ttts_wgrad_workspace_bytes(B * T, cout, cin, 5) // 4, device=_dev())
-        assert f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, B, T, cin, cout, 5, 0, _stream()) == 0
+        assert f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, B, T, cin, cout, 5, 0, None, _stream()) == 0
         assert _rel(dw, wd.grad) < TOL
         assert _rel(db, dy.double().sum((0, 1))) < TOL
 
@@ -236,7 +274,10 @@ def test_weight_split_batched_equals_single():
     from transformertts_amd.ops import _p, _stream
     lib = _lib.load()
     specs = [(_rand(256, 128, seed=1), 256, 128, 0, 0, 0), (_rand(256, 128, seed=2), 128, 256, 1, 0, 0),
-             (_rand(64, 32, 5, seed=3), 64, 160, 2, 32, 5), (_rand(64, 32, 5, seed=4), 32, 320, 3, 64, 5)]
+             (_rand(64, 32, 5, seed=3), 64, 160, 2, 32, 5), (_rand(64, 32, 5, seed=4), 32, 320, 3, 64, 5),
+             # fp16x3 images: two f16 planes + a tail holding max|w| (the pre-scale follows from it)
+             (_rand(256, 128, seed=5) * 40.0, 256, 128, 4, 0, 0), (_rand(256, 128, seed=6) * 1e-5, 128, 256, 5, 0, 0),
+             (_rand(64, 32, 5, seed=7), 64, 160, 6, 32, 5), (_rand(64, 64, 5, seed=8), 64, 320, 7, 64, 5)]
     single, batched, rows, blk = [], [], [], 0
     for w, R, C, mode, c2, taps in specs:
         a = torch.zeros(3 * R * C, dtype=torch.int16, device=_dev())
@@ -256,6 +297,15 @@ def test_weight_split_batched_equals_single():
     back = pl.permute(1, 0, 2).reshape(R, C)
     assert (back - w).abs().max().item() <= 2.0 ** -24 * w.abs().max().item()
     assert lib.ttts_weight_split(_p(w), _p(single[0]), 256, 120, 0, 0, 0, _stream()) != 0    # cols must be a multiple of 16
+    # fp16x3 image of specs[4]: tail = max|w|, planes = w * 2^k with max|w| * 2^k in [2^11, 2^12), hi + lo exact to 2^-22
+    w, R, C = specs[4][0], 256, 128
+    img = single[4]
+    tail = img.view(torch.uint8)[R * C * 4: R * C * 4 + 4].view(torch.float32)
+    assert tail.item() == w.abs().max().item()
+    sc = 2.0 ** (11 - int(np.floor(np.log2(tail.item()))))
+    pl = img[: 2 * R * C].view(torch.float16).view(C // 32, 2, R, 32).double().sum(1).permute(1, 0, 2).reshape(R, C)
+    assert 2048.0 <= tail.item() * sc < 4096.0
+    assert (pl / sc - w.double()).abs().max().item() <= 2.0 ** -21 * w.abs().max().item()
 
 
 @pytest.mark.parametrize("causal,Tq,Tk,lens", [(1, 200, 200, [200, 131, 64]), (0, 150, 70, [70, 33, 1]), (0, 33, 129, [129, 128, 5])])
@@ -322,7 +372,7 @@ def test_attention_forms_agree(causal, Tq, Tk, lens):
 def test_fp16x3_attention_forward(causal, Tq, Tk, lens, qk_scale):
     """The fp16x3 forward kernel against fp64 (context, per-head weights, lse via the bf16x6 backward that consumes it),
     with peaked softmaxes (scores of +-100 at qk_scale 6), and the same counter-based dropout mask as the bf16x6 form."""
-    from transformertts_amd import _lib
+    from transformertts_amd import _lib, ops
     from transformertts_amd.ops import _p, _off, _stream
     lib = _lib.load()
     B, H, d = len(lens), 2, 128
@@ -342,9 +392,11 @@ def test_fp16x3_attention_forward(causal, Tq, Tk, lens, qk_scale):
     dq_ref = qd.grad.transpose(1, 2).reshape(B, Tq, d)
     o = torch.empty(B, Tq, d, device=_dev()); lse = torch.empty(B, H, Tq, device=_dev())
     attn = None if causal else torch.empty(B, H, Tq, Tk, device=_dev())
+    qa, kva, oslots = ops._amax(q), ops._amax(kv), torch.zeros(1024, device=_dev())
     assert lib.ttts_attention_fwd_h3(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), _p(attn), _p(kl), B, H, Tq, Tk, d, 2 * d,
-                                     2 * d, d, causal, 0.0, 0, None, _stream()) == 0
+                                     2 * d, d, causal, 0.0, 0, None, _p(qa), _p(kva), _p(kva), _p(oslots), _stream()) == 0
     assert _rel(o, o_ref) < TOL, _rel(o, o_ref)
+    assert oslots.max().item() == o.abs().max().item()
     if attn is not None:
         assert _rel(attn, p_ref) < TOL
         assert float(attn.sum(-1).sub(1).abs().max()) < 1e-5
@@ -355,9 +407,10 @@ def test_fp16x3_attention_forward(causal, Tq, Tk, lens, qk_scale):
     if qk_scale == 1.0:                                                 # the backward recomputes P from this forward's lse
         assert _rel(dq, dq_ref) < TOL
     o6 = torch.empty_like(o); a6 = None if causal else torch.empty_like(attn); l6 = torch.empty_like(lse)
-    for f, oo, aa, ll in ((lib.ttts_attention_fwd_h3, o, attn, lse), (lib.ttts_attention_fwd_x6, o6, a6, l6)):
+    for f, oo, aa, ll, extra in ((lib.ttts_attention_fwd_h3, o, attn, lse, (_p(qa), _p(kva), _p(kva), None)),
+                                 (lib.ttts_attention_fwd_x6, o6, a6, l6, ())):
         assert f(_p(q), _off(kv, 0), _off(kv, d), _p(oo), _p(ll), _p(aa), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, causal, 0.25,
-                 99, None, _stream()) == 0
+                 99, None, *extra, _stream()) == 0
     assert _rel(o, o6) < TOL and _rel(lse, l6) < TOL
     if attn is not None and qk_scale == 1.0:       # (peaked softmaxes underflow to 0 at slightly different places)
         assert torch.equal(attn == 0, a6 == 0)
@@ -377,7 +430,7 @@ def test_fp16x3_attention_backward(causal, Tq, Tk, lens, mag, grow):
     B, H, d = len(lens), 2, 128
     q, kv, do = _rand(B, Tq, d, seed=1), _rand(B, Tk, 2 * d, seed=2), _rand(B, Tq, d, seed=3) * mag
     if grow:
-        kv[:, Tk - Tk // 4:, d:] *= 100.0          # (|V| stays below the 4096 of the static forward-operand window)
+        kv[:, Tk - Tk // 4:, d:] *= 100.0
         do[:, Tq - Tq // 4:] *= 1000.0
     kl = torch.tensor(lens, dtype=torch.int64, device=_dev())
     qd = q.double().view(B, Tq, H, 64).transpose(1, 2).requires_grad_()
@@ -393,16 +446,19 @@ def test_fp16x3_attention_backward(causal, Tq, Tk, lens, mag, grow):
     dq_ref = qd.grad.transpose(1, 2).reshape(B, Tq, d)
     dkv_ref = torch.cat([kd.grad.transpose(1, 2).reshape(B, Tk, d), vd.grad.transpose(1, 2).reshape(B, Tk, d)], -1)
 
+    qa, kva = ops._amax(q), ops._amax(kv)
+
     def run(fwd, bwd, p_drop, h3):
         o = torch.empty(B, Tq, d, device=_dev()); lse = torch.empty(B, H, Tq, device=_dev())
+        extra = (_p(qa), _p(kva), _p(kva), None) if h3 else ()
         assert fwd(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), None, _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, causal,
-                   p_drop, 99, None, _stream()) == 0
+                   p_drop, 99, None, *extra, _stream()) == 0
         dq, dkv, delta = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(lse)
         args = (_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(kl),
                 B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, p_drop, 99, None)
         if h3:
             sq, sk = torch.zeros(1024, device=_dev()), torch.zeros(1024, device=_dev())
-            assert bwd(*args, _p(ops._amax(do)), _p(sq), _p(sk), _stream()) == 0
+            assert bwd(*args, _p(ops._amax(do)), _p(sq), _p(sk), _p(qa), _p(kva), _p(kva), _stream()) == 0
             assert sq.max().item() == dq.abs().max().item() and sk.max().item() == dkv.abs().max().item()
         else:
             assert bwd(*args, _stream()) == 0
@@ -417,6 +473,55 @@ def test_fp16x3_attention_backward(causal, Tq, Tk, lens, mag, grow):
     a = run(lib.ttts_attention_fwd_h3, lib.ttts_attention_bwd_h3, 0.25, True)
     b = run(lib.ttts_attention_fwd_x6, lib.ttts_attention_bwd_x6, 0.25, False)
     assert _rel(a[0], b[0]) < TOL and _rel(a[1], b[1]) < TOL
+
+
+@pytest.mark.parametrize("vs,qs,ks", [(1e4, 1.0, 1.0), (1e-5, 1e3, 1e-3), (1e6, 1e-4, 1e4), (1.0, 3e-3, 3e2)])
+@pytest.mark.parametrize("causal", [0, 1])
+def test_fp16x3_attention_any_magnitude(vs, qs, ks, causal):
+    """Q, K and V of any magnitude (the scores stay ordinary because qs * ks = 1): the fp16x3 forward and backward take
+    their pre-scales from the operands' measured maxima, so nothing saturates and the results stay fp32-grade.  Round 2's
+    fixed 2^4 pre-scale made |V| >= 4096 an inf and lost |Q| ~ 1e-3 below the f16 window."""
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _off, _stream
+    lib = _lib.load()
+    B, H, d, T = 2, 2, 128, 160
+    lens = [160, 97]
+    q, kv, do = _rand(B, T, d, seed=1) * qs, _rand(B, T, 2 * d, seed=2), _rand(B, T, d, seed=3) * 1e-6
+    kv[..., :d] *= ks
+    kv[..., d:] *= vs
+    kv[0, 5, d + 3] *= 50.0                                    # an outlier value on top
+    kl = torch.tensor(lens, dtype=torch.int64, device=_dev())
+    qd = q.double().view(B, T, H, 64).transpose(1, 2).requires_grad_()
+    kd = kv[..., :d].double().reshape(B, T, H, 64).transpose(1, 2).requires_grad_()
+    vd = kv[..., d:].double().reshape(B, T, H, 64).transpose(1, 2).requires_grad_()
+    mask = torch.arange(T, device=_dev())[None, None, None, :] >= kl[:, None, None, None]
+    if causal:
+        mask = mask | (torch.arange(T, device=_dev())[None, :] > torch.arange(T, device=_dev())[:, None])
+    p_ref = torch.softmax((qd @ kd.transpose(-1, -2) / 8.0).masked_fill(mask, float("-inf")), -1)
+    o_ref = (p_ref @ vd).transpose(1, 2).reshape(B, T, d)
+    o_ref.backward(do.double())
+    dq_ref = qd.grad.transpose(1, 2).reshape(B, T, d)
+    dk_ref, dv_ref = kd.grad.transpose(1, 2).reshape(B, T, d), vd.grad.transpose(1, 2).reshape(B, T, d)
+    # q and kv come from different producers in cross-attention; in self-attention one array covers all three
+    qa, ka, va = ops._amax(q), ops._amax(kv[..., :d].contiguous()), ops._amax(kv[..., d:].contiguous())
+    o, lse = torch.empty(B, T, d, device=_dev()), torch.empty(B, H, T, device=_dev())
+    assert lib.ttts_attention_fwd_h3(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), None, _p(kl), B, H, T, T, d, 2 * d, 2 * d,
+                                     d, causal, 0.0, 0, None, _p(qa), _p(ka), _p(va), None, _stream()) == 0
+    assert torch.isfinite(o).all() and _rel(o, o_ref) < TOL, _rel(o, o_ref)
+    dq, dkv, delta = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(lse)
+    assert lib.ttts_attention_bwd_h3(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _off(dkv, 0),
+                                     _off(dkv, d), _p(kl), B, H, T, T, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, 0.0, 0, None,
+                                     _p(ops._amax(do)), None, None, _p(qa), _p(ka), _p(va), _stream()) == 0
+    assert torch.isfinite(dq).all() and torch.isfinite(dkv).all()
+    assert _rel(dq, dq_ref) < TOL and _rel(dkv[..., :d], dk_ref) < TOL and _rel(dkv[..., d:], dv_ref) < TOL, \
+        (_rel(dq, dq_ref), _rel(dkv[..., :d], dk_ref), _rel(dkv[..., d:], dv_ref))
+    # one shared array for a packed projection whose parts differ by 1e3 .. 1e8 still works (graceful: the small part
+    # keeps an absolute error of 2^-37 of the largest element)
+    am_all = torch.maximum(torch.maximum(qa, ka), va)
+    if max(vs, qs, ks) / min(vs, qs, ks) <= 1e4:
+        assert lib.ttts_attention_fwd_h3(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), None, _p(kl), B, H, T, T, d, 2 * d,
+                                         2 * d, d, causal, 0.0, 0, None, _p(am_all), _p(am_all), _p(am_all), None, _stream()) == 0
+        assert _rel(o, o_ref) < 4 * TOL, _rel(o, o_ref)
 
 
 def _base_module(seed=5):

@@ -25,47 +25,47 @@ SIGNATURES = {
     "ttts_linear_fwd": (I, [P, P, P, P, P, L, I, I, I, F, U, P, I, I, P]),
     "ttts_linear_bwd_data": (I, [P, P, P, P, L, I, I, P, F, P]),
     "ttts_wgrad_workspace_bytes": (Z, [L, I, I, I]),
-    "ttts_linear_bwd_weight": (I, [P, P, P, P, P, Z, L, I, I, I, I, I, P]),
+    "ttts_linear_bwd_weight": (I, [P, P, P, P, P, Z, L, I, I, I, I, I, P, P]),
     "ttts_split_bytes": (Z, [L, L]),
     "ttts_gemm_tile_choice": (I, [L, I, I, I]),
     "ttts_weight_split": (I, [P, P, I, I, I, I, I, P]),
     "ttts_weight_split_batched": (I, [P, I, L, P]),
     "ttts_linear_fwd_x6": (I, [P, P, P, P, P, L, I, I, I, F, U, P, I, I, P]),
-    "ttts_linear_fwd_h3": (I, [P, P, P, P, P, L, I, I, I, F, U, P, I, I, P]),
-    "ttts_conv1d_fwd_h3": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "ttts_linear_fwd_h3": (I, [P, P, P, P, P, L, I, I, I, F, U, P, I, I, P, P, P]),
+    "ttts_conv1d_fwd_h3": (I, [P, P, P, P, I, I, I, I, I, P, P]),
     "ttts_amax_partials": (I, [P, L, P, P]),
     "ttts_linear_bwd_data_h3": (I, [P, P, P, P, L, I, I, P, F, P, P, P]),
     "ttts_conv1d_bwd_data_h3": (I, [P, P, P, I, I, I, I, I, P, P]),
     "ttts_linear_bwd_data_x6": (I, [P, P, P, P, L, I, I, P, F, P]),
     "ttts_conv1d_fwd_x6": (I, [P, P, P, P, I, I, I, I, I, P]),
     "ttts_conv1d_bwd_data_x6": (I, [P, P, P, I, I, I, I, I, P]),
-    "ttts_linear_bwd_weight_x6": (I, [P, P, P, P, P, Z, L, I, I, I, I, I, P]),
-    "ttts_conv1d_bwd_weight_x6": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, P]),
-    "ttts_linear_bwd_weight_h3": (I, [P, P, P, P, P, Z, L, I, I, I, I, I, P, P]),
-    "ttts_conv1d_bwd_weight_h3": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, P, P]),
+    "ttts_linear_bwd_weight_x6": (I, [P, P, P, P, P, Z, L, I, I, I, I, I, P, P]),
+    "ttts_conv1d_bwd_weight_x6": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, P, P]),
+    "ttts_linear_bwd_weight_h3": (I, [P, P, P, P, P, Z, L, I, I, I, I, I, P, P, P, P]),
+    "ttts_conv1d_bwd_weight_h3": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, P, P, P, P]),
     "ttts_conv1d_pack_bytes": (Z, [I, I, I]),
     "ttts_conv1d_pack_weight": (I, [P, P, P, I, I, I, P]),
     "ttts_conv1d_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "ttts_conv1d_bwd_data": (I, [P, P, P, I, I, I, I, I, P]),
-    "ttts_conv1d_bwd_weight": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, P]),
+    "ttts_conv1d_bwd_weight": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, P, P]),
     "ttts_bn_workspace_bytes": (Z, [L, I]),
     "ttts_bn_train_stats": (I, [P, P, P, P, P, P, P, Z, L, I, F, F, P]),
     "ttts_bn_eval_stats": (I, [P, P, P, P, I, F, P]),
-    "ttts_bn_apply_fwd": (I, [P, P, P, P, P, P, L, I, I, F, U, P, P]),
+    "ttts_bn_apply_fwd": (I, [P, P, P, P, P, P, L, I, I, F, U, P, P, P]),
     "ttts_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, Z, L, I, I, F, U, P, I, P, P]),
-    "ttts_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
+    "ttts_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P, P]),
     "ttts_layernorm_bwd_workspace_bytes": (Z, [I]),
-    "ttts_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P]),
-    "ttts_layernorm_bwd_drop": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P, F, U, P, P, P]),
+    "ttts_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P, P]),
+    "ttts_layernorm_bwd_drop": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P, F, U, P, P, P, P]),
     "ttts_attention_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P, P]),
     "ttts_attention_fwd_x6": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P, P]),
-    "ttts_attention_fwd_h3": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P, P]),
+    "ttts_attention_fwd_h3": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P, P, P, P, P, P]),
     "ttts_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P, P]),
     "ttts_attention_bwd_x6": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P, P]),
-    "ttts_attention_bwd_h3": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P, P, P, P, P]),
-    "ttts_embedding_fwd": (I, [P, P, P, L, I, I, P]),
+    "ttts_attention_bwd_h3": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P, P, P, P, P, P, P, P]),
+    "ttts_embedding_fwd": (I, [P, P, P, L, I, I, P, P]),
     "ttts_embedding_bwd": (I, [P, P, P, L, I, I, I, P]),
-    "ttts_posenc_fwd": (I, [P, P, P, P, I, I, I, F, U, P, P]),
+    "ttts_posenc_fwd": (I, [P, P, P, P, I, I, I, F, U, P, P, P]),
     "ttts_posenc_bwd_workspace_bytes": (Z, []),
     "ttts_posenc_bwd": (I, [P, P, P, P, P, Z, I, I, I, F, U, P, I, P]),
     "ttts_relu_dropout_bwd": (I, [P, P, P, L, F, P, P]),
@@ -77,17 +77,18 @@ SIGNATURES = {
     "ttts_loss_fwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, F, P]),
     "ttts_loss_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P]),
     "ttts_zero": (I, [P, Z, P]),
-    "ttts_reduce_defer_begin": (I, []),
-    "ttts_reduce_defer_pending": (L, []),
-    "ttts_reduce_defer_flush": (I, [I, P]),
-    "ttts_reduce_defer_abort": (I, []),
+    "ttts_reduce_queue_create": (P, []),
+    "ttts_reduce_queue_destroy": (None, [P]),
+    "ttts_reduce_queue_pending": (L, [P]),
+    "ttts_reduce_queue_flush": (I, [P, P]),
+    "ttts_reduce_queue_clear": (I, [P]),
     "ttts_sched_sampling_mix": (I, [P, P, P, P, P, I, I, I, F, I, U, P, P]),
     "ttts_grad_norm_workspace_bytes": (Z, []),
     "ttts_grad_norm": (I, [P, P, P, Z, L, P]),
     "ttts_adam_step": (I, [P, P, P, P, P, L, F, F, F, F, L, F, P, P]),
     "ttts_rowdot_fwd": (I, [P, P, P, P, L, I, P]),
     "ttts_rowdot_bwd_workspace_bytes": (Z, [I]),
-    "ttts_rowdot_bwd": (I, [P, P, P, P, P, P, P, Z, L, I, I, P]),
+    "ttts_rowdot_bwd": (I, [P, P, P, P, P, P, P, Z, L, I, I, P, P]),
 }
 
 _lib = None

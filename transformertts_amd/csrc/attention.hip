@@ -64,6 +64,10 @@ struct AttnArgs {
     float drop_scale; uint32_t thr; uint64_t seed; const uint64_t* step_seed;
     const float* do_amax; int do_amax_n;      // fp16x3 backward: partial maxima of |dout| (ttts_amax_partials)
     float* amax_dq; float* amax_dkv;          // fp16x3 backward: NULL, or caller-zeroed 1024-slot arrays receiving max|dq| / max|dk, dv|
+    // fp16x3 forms: 1024 partial maxima of |q|, |k|, |v| each (the same array three times for a packed projection output):
+    // the operands' dynamic pre-scales.  o_amax (forward): NULL, or a caller-zeroed 1024-slot array receiving max|o|.
+    const float* q_amax; const float* k_amax; const float* v_amax;
+    float* o_amax;
 };
 
 // ---- cooperative staging (256 threads): KB rows x 64 floats from global straight into LDS; rows beyond
@@ -843,17 +847,36 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDX_W) void attn_fwd_x6_ke
 // =====================================================================================================================
 // fp16x3 form of the forward kernel ("h3", see gemm_h3.hip): the same algorithm with every product formed from THREE
 // f16 x f16 MFMA terms of two-way hi/lo f16 splits (a_hi b_hi + a_hi b_lo + a_lo b_hi) instead of six bf16 terms.  f16
-// has 11 significand bits but a narrow exponent range, so operands are pre-scaled by fixed powers of two that suit what
-// attention multiplies: Q/8, K and V are O(1) projections of normalised activations (x 2^4: full 22-bit precision for
-// 0.008 <= |x| < 4096), probabilities lie in [0, 1/(1-p)] (x 2^10: absolute error 3e-11 for the small ones).  The scores
-// stay in accumulator units (256 x the true score) and the scale rides in the exp2's fused multiply-add; the output
-// accumulator is scaled back once at the end.  Two planes per staged operand: 32 KB of LDS per workgroup instead of 48.
+// has 11 significand bits but a narrow exponent range, so operands are pre-scaled by powers of two: Q/8, K and V by the
+// power of two that puts their measured maximum in [2^11, 2^12) (h3_pow2_scale on the partial maxima their producer
+// left: nothing is assumed about their magnitude), probabilities -- which lie in [0, 1/(1-p)] whatever the inputs -- by
+// 2^10 (absolute error 3e-11 for the small ones).  The scores stay in accumulator units and the scale rides in the exp2's
+// fused multiply-add; the output accumulator is scaled back once at the end.  Two planes per staged operand: 32 KB of
+// LDS per workgroup instead of 48.
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
-constexpr float H3A_Q = 16.0f, H3A_K = 16.0f, H3A_V = 16.0f, H3A_P = 1024.0f;
-constexpr float H3A_C = 1.0f / (H3A_Q * H3A_K);                 // accumulator units -> true score
-constexpr float H3A_C2 = H3A_C * 1.4426950408889634f;           // ... -> base-2 exponent
-constexpr float H3A_O = 1.0f / (H3A_V * H3A_P);
+constexpr float H3A_P = 1024.0f;
+// the dynamic pre-scales of one launch (wave-uniform, held in scalar registers)
+struct H3Scales {
+    float sq, sk, sv;          // Q / 8, K, V pre-scales
+    float inv_sq, inv_sk, inv_sv;
+    float c;                   // accumulator units -> true score: 1 / (sq * sk)
+    float c2;                  // ... -> base-2 exponent
+};
+__device__ __forceinline__ float sgpr(float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); }
+__device__ __forceinline__ H3Scales attn_h3_scales(const float* q_amax, const float* k_amax, const float* v_amax, int lane) {
+    H3Scales h;
+    float s, i;
+    h3_pow2_scale(0.125f * h3_partials_max(q_amax, 1024, lane), s, i);   // Q is multiplied by 1/8 before it is split
+    h.sq = sgpr(s); h.inv_sq = sgpr(i);
+    h3_pow2_scale(h3_partials_max(k_amax, 1024, lane), s, i);
+    h.sk = sgpr(s); h.inv_sk = sgpr(i);
+    h3_pow2_scale(h3_partials_max(v_amax, 1024, lane), s, i);
+    h.sv = sgpr(s); h.inv_sv = sgpr(i);
+    h.c = h.inv_sq * h.inv_sk;
+    h.c2 = h.c * 1.4426950408889634f;
+    return h;
+}
 #ifndef TTTS_FWDH_W
 #define TTTS_FWDH_W 3
 #endif
@@ -958,8 +981,10 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
     const float* qb_ = a.q + (long)b * a.Tq * a.ldq + h * HD;
     const float* kb_ = a.k + (long)b * a.Tk * a.ldk + h * HD;
     const float* vb_ = a.v + (long)b * a.Tk * a.ldv + h * HD;
+    const H3Scales hs = attn_h3_scales(a.q_amax, a.k_amax, a.v_amax, lane);
+    const float H3A_C = hs.c, H3A_C2 = hs.c2;
 
-    // Q fragments: lane (query l31, half) holds Q[q][16 s + 8 half + 0..7] / 8 * 2^4 for the four d-steps s, split in two
+    // Q fragments: lane (query l31, half) holds Q[q][16 s + 8 half + 0..7] / 8 * sq for the four d-steps s, split in two
     f16x8v qf[4][2];
     wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
     wave_lds_sync();
@@ -968,7 +993,7 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = scratch[l31 * KT_LD + 16 * s + 8 * half + e];
-        split_frag8_h3(x, H3A_Q, qf[s][0], qf[s][1]);
+        split_frag8_h3(x, hs.sq, qf[s][0], qf[s][1]);
     }
 
     float m = NEG_INF, l = 0.f;
@@ -1009,7 +1034,7 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
         // ---------------- pass 1: row max / row sum only
         for (int t = 0; t < nst_live; ++t) {
             __syncthreads();
-            stage_split_rows_h3(kb_, (long)t * KB, a.Tk, a.ldk, tid, Kp, H3A_K);
+            stage_split_rows_h3(kb_, (long)t * KB, a.Tk, a.ldk, tid, Kp, hs.sk);
             __syncthreads();
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
@@ -1044,8 +1069,8 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
     // ---------------- main pass
     for (int t = 0; t < nst; ++t) {
         __syncthreads();
-        stage_split_rows_h3(kb_, (long)t * KB, a.Tk, a.ldk, tid, Kp, H3A_K);
-        stage_split_cols_h3(vb_, (long)t * KB, a.Tk, a.ldv, tid, Vt, H3A_V);
+        stage_split_rows_h3(kb_, (long)t * KB, a.Tk, a.ldk, tid, Kp, hs.sk);
+        stage_split_cols_h3(vb_, (long)t * KB, a.Tk, a.ldv, tid, Vt, hs.sv);
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -1127,18 +1152,24 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
         }
     }
 
-    float out_scale = H3A_O;       // the O accumulator holds (V * 2^4)^T (P * 2^10)^T
+    float out_scale = hs.inv_sv * (1.0f / H3A_P);       // the O accumulator holds (V * sv)^T (P * 2^10)^T
     float lse_v;
     if (WRITE_A) {
         lse_v = m_fin * H3A_C + __logf(l > 0.f ? l : 1.f);
     } else {
         float lt = l + __shfl_xor(l, 32, 64);                 // = 2^10 * the sum of the weights
-        out_scale = (lt > 0.f) ? (a.drop_scale / H3A_V) / lt : 0.f;
+        out_scale = (lt > 0.f) ? (a.drop_scale * hs.inv_sv) / lt : 0.f;
         lse_v = ((m == NEG_INF) ? 0.f : m) * H3A_C + __logf(lt > 0.f ? lt * (1.0f / H3A_P) : 1.f);
     }
     if (a.lse != nullptr && half == 0 && qg < a.Tq) a.lse[arow + qg] = lse_v;
+    float omax = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] *= out_scale; o[1][r] *= out_scale; }
+    for (int r = 0; r < 16; ++r) {
+        o[0][r] *= out_scale; o[1][r] *= out_scale;
+        omax = fmaxf(omax, fmaxf(fabsf(o[0][r]), fabsf(o[1][r])));
+    }
+    // max|o| for the fp16x3 out-projection that consumes it (rows past Tq are not stored)
+    if (a.o_amax != nullptr) amax_publish(qg < a.Tq ? omax : 0.f, a.o_amax, blockIdx.y * gridDim.x + blockIdx.x);
     __syncthreads();
     wave_store_rows(o, scratch, a.o + (long)b * a.Tq * a.ldo + h * HD, qw0, a.Tq, a.ldo, lane, 1.f);
 }
@@ -1576,8 +1607,8 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
 }
 
 // =====================================================================================================================
-// fp16x3 forms of the backward kernels.  Static pre-scales for Q / 8, K, V (x 2^4) and P (x 2^10) as in the forward; the
-// two gradient operands need dynamic ones:
+// fp16x3 forms of the backward kernels.  Q / 8, K, V get the forward's dynamic pre-scales (attn_h3_scales, from the same
+// partial maxima), P x 2^10; the two gradient operands:
 //   * dO: the power of two that puts max|dO| over the whole tensor in [2^11, 2^12), from the partial maxima of
 //     ttts_amax_partials (AttnArgs.do_amax).  It is one value for the tensor because dO is contracted over its rows in
 //     dV^T += dO^T P and over its columns in dP = dO V^T.
@@ -1598,16 +1629,9 @@ static_assert(DKVH_DW >= SMEM_FLOATS, "per-wave fp32 scratch must fit the stage 
 constexpr int DKVH_SMEM = DKVH_DW * 4;
 
 __device__ __forceinline__ void attn_h3_grad_scale(const float* __restrict__ partials, int n, int lane, float& s, float& inv_s) {
-    float m = 0.f;
-    for (int i = lane; i < n; i += 64) m = fmaxf(m, partials[i]);
-    m = wave_max(m);
-    const uint32_t e = (__float_as_uint(m) >> 23) & 0xffu;
-    if (e >= 24u && e < 255u) {
-        s = __uint_as_float((265u - e) << 23);             // 2^(138 - e): max|dO| -> [2^11, 2^12)
-        inv_s = __uint_as_float((e - 11u) << 23);          // 2^(e - 138)
-    } else {
-        s = 1.f; inv_s = 1.f;
-    }
+    float s_, i_;
+    h3_operand_scale(partials, n, lane, s_, i_);           // max|dO| -> [2^11, 2^12)
+    s = sgpr(s_); inv_s = sgpr(i_);
 }
 // ds: this lane's 16 dS values of the tile (true units); sds: the lane's current pre-scale (0 = unset); acc: the
 // accumulator pair the products land in (lane-local column).  Both half-waves hold halves of the same column.
@@ -1707,10 +1731,12 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
     // dO is a gradient: its pre-scale is the power of two that puts max|dO| (over the whole tensor) in [2^11, 2^12)
     float s_g, inv_g;
     attn_h3_grad_scale(a.do_amax, a.do_amax_n, lane, s_g, inv_g);
+    const H3Scales hs = attn_h3_scales(a.q_amax, a.k_amax, a.v_amax, lane);
+    const float H3A_C2 = hs.c2;
     f16x8v qf[4][2], gf[4][2];
     wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
     wave_lds_sync();
-    load_lane_frags_h3(scratch, l31, half, H3A_Q, qf);
+    load_lane_frags_h3(scratch, l31, half, hs.sq, qf);
     wave_lds_sync();
     wave_stage_tile(ob_, qw0, a.Tq, a.ldo, lane, scratch, 1.f);
     wave_lds_sync();
@@ -1727,7 +1753,7 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
     load_lane_frags_h3(scratch, l31, half, s_g, gf);
     if (half == 0 && qg < a.Tq) a.delta[arow + qg] = delta;
     const float lse_q2 = ((qg < a.Tq) ? a.lse[arow + qg] : 0.f) * 1.4426950408889634f;
-    const float dp_unscale = inv_g / H3A_V * a.drop_scale;   // dP accumulator units -> true dP, times the 1/(1-p) of kept weights
+    const float dp_unscale = inv_g * hs.inv_sv * a.drop_scale;   // dP accumulator units -> true dP, times the 1/(1-p) of kept weights
     float sds = 0.f;                              // this query's dS pre-scale (power of two), set / lowered on the fly
 
     f32x16 dq[2];
@@ -1740,9 +1766,9 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
         __syncthreads();
         {
             float4 v[4];
-            patch_load(kb_, (long)t * KB, a.Tk, a.ldk, rq, dqd, H3A_K, v);
+            patch_load(kb_, (long)t * KB, a.Tk, a.ldk, rq, dqd, hs.sk, v);
             patch_split_store_h3<true, 64>(v, rq, dqd, kpos, Kr, XP, Kt, XP);
-            patch_load(vb_, (long)t * KB, a.Tk, a.ldv, rq, dqd, H3A_V, v);
+            patch_load(vb_, (long)t * KB, a.Tk, a.ldv, rq, dqd, hs.sv, v);
             patch_split_store_h3<false, 64>(v, rq, dqd, 0, Vr, XP, nullptr, 0);
         }
         __syncthreads();
@@ -1811,7 +1837,7 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
     }
     __syncthreads();
     {
-        const float fin = (sds > 0.f) ? 0.125f / (H3A_K * sds) : 0.f;      // accumulator units -> dQ (incl. the 1/8 of q / 8)
+        const float fin = (sds > 0.f) ? 0.125f * hs.inv_sk / sds : 0.f;    // accumulator units -> dQ (incl. the 1/8 of q / 8)
         float mx = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1859,20 +1885,22 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
 
     float s_g, inv_g;
     attn_h3_grad_scale(a.do_amax, a.do_amax_n, lane, s_g, inv_g);
+    const H3Scales hs = attn_h3_scales(a.q_amax, a.k_amax, a.v_amax, lane);
+    const float H3A_C2 = hs.c2;
     f16x8v kf[4][2], vf[4][2];
     wave_stage_tile(kb_, kw0, a.Tk, a.ldk, lane, scratch, 1.f);
     wave_lds_sync();
-    load_lane_frags_h3(scratch, l31, half, H3A_K, kf);
+    load_lane_frags_h3(scratch, l31, half, hs.sk, kf);
     wave_lds_sync();
     wave_stage_tile(vb_, kw0, a.Tk, a.ldv, lane, scratch, 1.f);
     wave_lds_sync();
-    load_lane_frags_h3(scratch, l31, half, H3A_V, vf);
+    load_lane_frags_h3(scratch, l31, half, hs.sv, vf);
 
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
 
-    const float dp_unscale = inv_g / H3A_V * a.drop_scale;      // ... times the 1/(1-p) of kept weights (1 without dropout)
+    const float dp_unscale = inv_g * hs.inv_sv * a.drop_scale;  // ... times the 1/(1-p) of kept weights (1 without dropout)
     float sds = 0.f;                        // this key's dS pre-scale (power of two), see attn_bwd_dq_h3_kernel
     const int nqs = (a.Tq + QS - 1) / QS;
     int qs_begin = CAUSAL ? (k0 / QS) : 0;
@@ -1915,7 +1943,7 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
         __syncthreads();                                    // ... and everybody else's; previous planes are free
         {
             const uint32_t* raw = st_q ? rawQ : rawG;
-            const float sc = st_q ? 0.125f * H3A_Q : s_g;
+            const float sc = st_q ? 0.125f * hs.sq : s_g;
             float4 v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -2019,7 +2047,7 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
     }
     __syncthreads();
     {
-        const float fk = (sds > 0.f) ? 1.f / (H3A_Q * sds) : 0.f;        // dk accumulator: (Q / 8 * 2^4)^T (dS * sds)
+        const float fk = (sds > 0.f) ? hs.inv_sq / sds : 0.f;            // dk accumulator: (Q / 8 * sq)^T (dS * sds)
         const float fv = inv_g / H3A_P * a.drop_scale;                    // dv accumulator: (dO * s_g)^T (kept P * 2^10) / (1-p)
         float mx = 0.f;
 #pragma unroll
@@ -2094,10 +2122,13 @@ extern "C" {
 
 static int attention_fwd_impl(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                               const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                              int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, int form, void* stream_) {
-    // form: 0 = fp32 MFMA, 1 = bf16x6, 2 = fp16x3
+                              int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, int form, void* stream_,
+                              const float* q_amax = nullptr, const float* k_amax = nullptr, const float* v_amax = nullptr,
+                              float* o_amax_out = nullptr) {
+    // form: 0 = fp32 MFMA, 1 = bf16x6, 2 = fp16x3 (needs the partial maxima of q, k, v)
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(q && k && v && o && key_lens, "attention_fwd: null pointer");
+    TTTS_REQUIRE(form != 2 || (q_amax && k_amax && v_amax), "attention_fwd_h3: q_amax / k_amax / v_amax are required");
     int rc = check_common("attention_fwd", B, H, Tq, Tk, ldq, ldk, ldv, ldo, drop_p);
     if (rc) return rc;
     TTTS_REQUIRE(!(causal && attn), "attention_fwd: weights output is only provided for the non-causal (cross) form");
@@ -2109,6 +2140,7 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, fl
     a.thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     a.drop_scale = 1.f / (1.f - drop_p);
     a.seed = seed; a.step_seed = step_seed;
+    a.q_amax = q_amax; a.k_amax = k_amax; a.v_amax = v_amax; a.o_amax = o_amax_out;
     dim3 grid(B * H, cdiv(Tq, QB), 1);
     if (form == 2) {
         if (causal)
@@ -2154,20 +2186,23 @@ int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float*
 }
 int ttts_attention_fwd_h3(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
+                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* q_amax,
+                          const float* k_amax, const float* v_amax, float* o_amax_out, void* stream) {
     return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, step_seed, 2,
-                              stream);
+                              stream, q_amax, k_amax, v_amax, o_amax_out);
 }
 
 static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* do_,
                               const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                               int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                               int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, int form, void* stream_,
-                              const float* do_amax = nullptr, float* dq_amax_out = nullptr, float* dkv_amax_out = nullptr) {
-    // form: 0 = fp32 MFMA, 1 = bf16x6, 2 = fp16x3 (needs do_amax)
+                              const float* do_amax = nullptr, float* dq_amax_out = nullptr, float* dkv_amax_out = nullptr,
+                              const float* q_amax = nullptr, const float* k_amax = nullptr, const float* v_amax = nullptr) {
+    // form: 0 = fp32 MFMA, 1 = bf16x6, 2 = fp16x3 (needs do_amax and the partial maxima of q, k, v)
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(q && k && v && o && do_ && lse && delta && dq && dk && dv && key_lens, "attention_bwd: null pointer");
-    TTTS_REQUIRE(form != 2 || do_amax, "attention_bwd_h3: do_amax (ttts_amax_partials of d_o) is required");
+    TTTS_REQUIRE(form != 2 || (do_amax && q_amax && k_amax && v_amax),
+                 "attention_bwd_h3: do_amax, q_amax, k_amax and v_amax (partial maxima of the operands) are required");
     int rc = check_common("attention_bwd", B, H, Tq, Tk, ldq, ldk, ldv, ldo, drop_p);
     if (rc) return rc;
     TTTS_REQUIRE(lddq >= H * HD && lddk >= H * HD && lddv >= H * HD, "attention_bwd: gradient strides must be >= H*64");
@@ -2186,6 +2221,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
     if (form == 2) {
         a.do_amax = do_amax; a.do_amax_n = 1024;
         a.amax_dq = dq_amax_out; a.amax_dkv = dkv_amax_out;
+        a.q_amax = q_amax; a.k_amax = k_amax; a.v_amax = v_amax;
         return causal ? launch_bwd_h3<true>(a, gq, gk, stream) : launch_bwd_h3<false>(a, gq, gk, stream);
     }
     if (form == 1) return causal ? launch_bwd_x6<true>(a, gq, gk, stream) : launch_bwd_x6<false>(a, gq, gk, stream);
@@ -2220,9 +2256,11 @@ int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const 
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
-                          float* dq_amax_out, float* dkv_amax_out, void* stream) {
+                          float* dq_amax_out, float* dkv_amax_out, const float* q_amax, const float* k_amax,
+                          const float* v_amax, void* stream) {
     return attention_bwd_impl(q, k, v, o, d_o, lse, delta, dq, dk, dv, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk,
-                              lddv, causal, drop_p, seed, step_seed, 2, stream, do_amax, dq_amax_out, dkv_amax_out);
+                              lddv, causal, drop_p, seed, step_seed, 2, stream, do_amax, dq_amax_out, dkv_amax_out, q_amax, k_amax,
+                              v_amax);
 }
 
 }  // extern "C"

@@ -24,17 +24,24 @@ static inline int ew_grid(long n_items) {
 
 // ------------------------------------------------------------------ embedding
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
-                                                            float* __restrict__ out, long n, int vocab, int d4) {
+                                                            float* __restrict__ out, long n, int vocab, int d4,
+                                                            float* __restrict__ amax_out) {
     // one wave per output row, float4 per lane
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = 0.f;
     for (long row = (long)blockIdx.x * 4 + wave; row < n; row += (long)gridDim.x * 4) {
         long id = ids[row];
         if (id < 0) id = 0;
         if (id >= vocab) id = vocab - 1;
         const float4* src = reinterpret_cast<const float4*>(table) + id * d4;
         float4* dst = reinterpret_cast<float4*>(out) + row * d4;
-        for (int c = lane; c < d4; c += 64) dst[c] = src[c];
+        for (int c = lane; c < d4; c += 64) {
+            const float4 v = src[c];
+            dst[c] = v;
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
     }
+    if (amax_out != nullptr) amax_publish(m, amax_out, blockIdx.x * 4 + wave);
 }
 
 // one workgroup per vocabulary row.  Positions holding this id are compacted IN ORDER into LDS, 256 ids per step
@@ -81,10 +88,12 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __res
 // ------------------------------------------------------------------ positional encoding
 __global__ __launch_bounds__(256) void posenc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pe,
                                                          const float* __restrict__ alpha, float* __restrict__ y, long n4,
-                                                         int T, int d, float drop_scale, uint32_t thr, uint64_t seed, const uint64_t* step_seed) {
+                                                         int T, int d, float drop_scale, uint32_t thr, uint64_t seed, const uint64_t* step_seed,
+                                                         float* __restrict__ amax_out) {
     seed = site_seed(seed, step_seed);
     const float a = alpha[0];
     const long td = (long)T * d;
+    float ymax = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long e = i * 4;
         const long pe_off = e % td;   // (t, c) offset inside the (T, d) table
@@ -96,7 +105,9 @@ __global__ __launch_bounds__(256) void posenc_fwd_kernel(const float* __restrict
             for (int j = 0; j < 4; ++j) o[j] = keep_elem(seed, (uint64_t)(e + j), thr) ? o[j] * drop_scale : 0.f;
         }
         *reinterpret_cast<float4*>(y + e) = make_float4(o[0], o[1], o[2], o[3]);
+        ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
     }
+    if (amax_out != nullptr) amax_publish(ymax, amax_out, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 constexpr int PE_BWD_BLOCKS = 1024;
@@ -274,7 +285,7 @@ using namespace ttts;
 extern "C" {
 
 const char* ttts_last_error(void) { return ttts::g_err; }
-int ttts_abi_version(void) { return 6; }
+int ttts_abi_version(void) { return 7; }
 
 int ttts_zero(void* p, size_t nbytes, void* stream) {
     TTTS_REQUIRE(p != nullptr || nbytes == 0, "zero: null pointer");
@@ -287,13 +298,14 @@ int ttts_zero(void* p, size_t nbytes, void* stream) {
     return TTTS_OK;
 }
 
-int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d, void* stream) {
+int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d, float* out_amax_out,
+                       void* stream) {
     TTTS_REQUIRE(ids && table && out, "embedding_fwd: null pointer");
     TTTS_REQUIRE(n > 0 && vocab > 0 && d > 0 && d % 4 == 0, "embedding_fwd: d=%d must be a multiple of 4", d);
     int grid = (int)((n + 3) / 4);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, table, out, (long)n, vocab,
-                       d / 4);
+                       d / 4, out_amax_out);
     TTTS_LAUNCH_CHECK("embedding_fwd_kernel");
     return TTTS_OK;
 }
@@ -309,14 +321,14 @@ int ttts_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int
 }
 
 int ttts_posenc_fwd(const float* x, const float* pe, const float* alpha, float* y, int B, int T, int d, float drop_p,
-                    uint64_t seed, const uint64_t* step_seed, void* stream) {
+                    uint64_t seed, const uint64_t* step_seed, float* y_amax_out, void* stream) {
     TTTS_REQUIRE(x && pe && alpha && y, "posenc_fwd: null pointer");
     TTTS_REQUIRE(B > 0 && T > 0 && d > 0 && d % 4 == 0, "posenc_fwd: d=%d must be a multiple of 4", d);
     TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "posenc_fwd: bad dropout p");
     long n4 = (long)B * T * d / 4;
     uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     hipLaunchKernelGGL(posenc_fwd_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, pe, alpha, y, n4, T, d,
-                       1.f / (1.f - drop_p), thr, seed, step_seed);
+                       1.f / (1.f - drop_p), thr, seed, step_seed, y_amax_out);
     TTTS_LAUNCH_CHECK("posenc_fwd_kernel");
     return TTTS_OK;
 }
@@ -381,7 +393,7 @@ int ttts_rowdot_fwd(const float* x, const float* w, const float* b, float* y, in
 size_t ttts_rowdot_bwd_workspace_bytes(int d) { return (size_t)RD_BWD_BLOCKS * (d + 1) * sizeof(float); }
 
 int ttts_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx_accum, float* dw, float* db, float* ws,
-                    size_t ws_bytes, int64_t M, int d, int accumulate, void* stream_) {
+                    size_t ws_bytes, int64_t M, int d, int accumulate, ttts_reduce_queue* queue, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && x && w && ws, "rowdot_bwd: null pointer");
     TTTS_REQUIRE(M > 0 && d > 0 && d % 64 == 0 && d <= 1024, "rowdot_bwd: d=%d must be a multiple of 64, <= 1024", d);
@@ -390,7 +402,7 @@ int ttts_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx_a
     if ((long)nblk * 4 > M) nblk = (int)((M + 3) / 4);
     hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dy, x, w, dx_accum, ws, (long)M, d);
     TTTS_LAUNCH_CHECK("rowdot_bwd_kernel");
-    return launch_reduce_rows(ws, d + 1, nblk, d + 1, dw, d, db, accumulate & 1, stream, (accumulate & 2) != 0);
+    return launch_reduce_rows(ws, d + 1, nblk, d + 1, dw, d, db, accumulate != 0, stream, queue);
 }
 
 }  // extern "C"

@@ -342,9 +342,6 @@ static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t stream) {
 // are 4 deep on some CUs (65 536), 1 740 tiles of 64x128 are 7 deep at 0.93 efficiency (61 660) -> 64x128.
 // The split-precision kernel is latency / traffic bound, so small tiles cost it more (second efficiency table).
 static int choose_tile(long M, long N, long zdim, bool x6 = false) {
-    static int forced = -1;                       // development aid: TTTS_GEMM_TILE=1..4 forces a tile shape
-    if (forced < 0) { const char* e = getenv("TTTS_GEMM_TILE"); forced = e ? atoi(e) : 0; }
-    if (forced > 0) return forced;
     struct Cand { int tile, bm, bn; float eff_f32, eff_x6; };
     const Cand cands[] = {{TILE_128, 128, 128, 1.00f, 1.00f}, {TILE_64x128, 64, 128, 0.93f, 0.75f}, {TILE_64, 64, 64, 0.80f, 0.60f}};
     int best = TILE_128;
@@ -421,14 +418,34 @@ __global__ __launch_bounds__(256) void weight_split_kernel(const float* __restri
 }
 // every weight of the model in one launch (after an optimizer step): descriptor i = 8 int64
 // {w, planes, R, C, mode, c2, taps, first block}; a workgroup finds its descriptor by bisection on the block starts
-__global__ __launch_bounds__(256) void weight_split_batched_kernel(const long* __restrict__ descs, int n) {
+// descriptor of the weight that block `blk` of a batched launch works on (first_block ascending)
+__device__ __forceinline__ const long* batched_desc(const long* __restrict__ descs, int n, long blk) {
     int lo = 0, hi = n - 1;
-    const long blk = blockIdx.x;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (descs[mid * 8 + 7] <= blk) lo = mid; else hi = mid - 1;
     }
-    const long* d = descs + lo * 8;
+    return descs + lo * 8;
+}
+
+// fp16x3 images (modes 4-7) carry max|w| in their tail: zero the tails, then one atomic max per wave
+__global__ __launch_bounds__(256) void weight_tail_zero_batched_kernel(const long* __restrict__ descs, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const long* d = descs + i * 8;
+        if (d[4] >= 4) *reinterpret_cast<float*>(reinterpret_cast<char*>(d[1]) + h3_plane_bytes(d[2], d[3])) = 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void weight_amax_batched_kernel(const long* __restrict__ descs, int n) {
+    const long blk = blockIdx.x;
+    const long* d = batched_desc(descs, n, blk);
+    if (d[4] >= 4)
+        weight_amax_h3_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
+                           (blk - d[7]) * 256 + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void weight_split_batched_kernel(const long* __restrict__ descs, int n) {
+    const long blk = blockIdx.x;
+    const long* d = batched_desc(descs, n, blk);
     if (d[4] >= 4)      // modes 4-7: the fp16x3 image of modes 0-3 (block-uniform branch)
         weight_split_h3_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2],
                             (int)d[3], (int)d[4] - 4, (int)d[5], (int)d[6], (blk - d[7]) * 256 + threadIdx.x);
@@ -911,7 +928,7 @@ static GemmArgs base_args() {
     g.bias = nullptr; g.act = 0; g.drop_scale = 1.f; g.drop_thr = 0; g.seed = 0; g.step_seed = nullptr;
     g.residual = nullptr; g.ldr = 0; g.colsum = nullptr; g.a_bytes = 0; g.b_bytes = 0;
     g.relu_out = nullptr; g.relu_scale = 1.f;
-    g.a_amax = nullptr; g.a_amax_n = 0; g.c_amax = nullptr;
+    g.a_amax = nullptr; g.a_amax_n = 0; g.b_amax = nullptr; g.b_amax_n = 0; g.c_amax = nullptr;
     return g;
 }
 
@@ -936,8 +953,8 @@ static WgradPlan plan_wgrad(int64_t M, int N, int K, int taps, bool x6 = false, 
     } else if (tiles < 16) {
         p.tile = TILE_64; tiles = (long)cdiv(N, 64) * cdiv(K, 64) * taps;
     }
-    static const long forced = getenv("TTTS_WGRAD_BLOCKS") ? atol(getenv("TTTS_WGRAD_BLOCKS")) : 0;   // experiments
-    static const int big = getenv("TTTS_WGRAD_256") ? atoi(getenv("TTTS_WGRAD_256")) : 1;
+    constexpr long forced = 0;
+    constexpr int big = 1;
     long target = 768;
     if (bk == HBK) {
         // The kernel's speed is set by the operand bytes its workgroups request (tiles x rows x (BM + BN) x 4 B at about
@@ -1024,8 +1041,8 @@ size_t ttts_wgrad_workspace_bytes(int64_t M, int N, int K, int taps) {
 
 static int wgrad_common(const float* dy, const float* x, float* ws, float* colsum_ws, int64_t M, int N, int K, int taps,
                         int T, int shift0, int shift_step, WgradPlan* plan_out, bool x6, hipStream_t stream,
-                        const float* dy_amax = nullptr) {
-    // dy_amax != NULL selects the fp16x3 kernel (32-row k-steps, dynamic pre-scale of dy); x6 must be true then
+                        const float* dy_amax = nullptr, const float* x_amax = nullptr) {
+    // dy_amax != NULL selects the fp16x3 kernel (32-row k-steps, dynamic pre-scales of dy and x); x6 must be true then
     WgradPlan p = plan_wgrad(M, N, K, taps, x6, dy_amax ? HBK : BK);
     GemmArgs g = base_args();
     // C[N][K] (per tap) = dy^T[N][M] . xshift[M][K]
@@ -1042,6 +1059,7 @@ static int wgrad_common(const float* dy, const float* x, float* ws, float* colsu
     *plan_out = p;
     if (dy_amax) {
         g.a_amax = dy_amax; g.a_amax_n = H3_AMAX_PARTIALS;
+        g.b_amax = x_amax; g.b_amax_n = H3_AMAX_PARTIALS;
         return dispatch_wgrad_h3(g, p.nsplit * taps, p.tile, stream);
     }
     if (x6) return dispatch_wgrad_split(g, p.nsplit * taps, p.tile, stream);
@@ -1049,8 +1067,9 @@ static int wgrad_common(const float* dy, const float* x, float* ws, float* colsu
 }
 
 static int linear_bwd_weight_impl(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
-                                  int64_t M, int N, int K, int row_shift, int T, int accumulate, bool x6, void* stream_,
-                                  const float* dy_amax = nullptr) {
+                                  int64_t M, int N, int K, int row_shift, int T, int accumulate, bool x6,
+                                  ttts_reduce_queue* queue, void* stream_, const float* dy_amax = nullptr,
+                                  const float* x_amax = nullptr) {
     // dw[N,K] (+)= dy[M,N]^T . x[M,K] ; dbias[N] (+)= column sums of dy
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && x && dw && ws, "linear_bwd_weight: null pointer");
@@ -1064,23 +1083,25 @@ static int linear_bwd_weight_impl(const float* dy, const float* x, float* dw, fl
     x6 = x6 && wgrad_use_x6(N, K);
     if (!x6) dy_amax = nullptr;
     float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, N, K, 1, x6, dy_amax ? HBK : BK).nsplit * n : nullptr;
-    int rc = wgrad_common(dy, x, ws, colsum_ws, M, N, K, 1, row_shift != 0 ? T : 0, row_shift, 0, &p, x6, stream, dy_amax);
+    int rc = wgrad_common(dy, x, ws, colsum_ws, M, N, K, 1, row_shift != 0 ? T : 0, row_shift, 0, &p, x6, stream, dy_amax, x_amax);
     if (rc) return rc;
-    return launch_reduce_rows_pair(ws, n, p.nsplit, n, dw, colsum_ws, N, N, dbias, accumulate & 1, stream, (accumulate & 2) != 0);
+    return launch_reduce_rows_pair(ws, n, p.nsplit, n, dw, colsum_ws, N, N, dbias, accumulate != 0, stream, queue);
 }
 
 int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
-                           int64_t M, int N, int K, int row_shift, int T, int accumulate, void* stream) {
-    return linear_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, M, N, K, row_shift, T, accumulate, false, stream);
+                           int64_t M, int N, int K, int row_shift, int T, int accumulate, ttts_reduce_queue* queue, void* stream) {
+    return linear_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, M, N, K, row_shift, T, accumulate, false, queue, stream);
 }
 int ttts_linear_bwd_weight_x6(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
-                              int64_t M, int N, int K, int row_shift, int T, int accumulate, void* stream) {
-    return linear_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, M, N, K, row_shift, T, accumulate, true, stream);
+                              int64_t M, int N, int K, int row_shift, int T, int accumulate, ttts_reduce_queue* queue, void* stream) {
+    return linear_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, M, N, K, row_shift, T, accumulate, true, queue, stream);
 }
 int ttts_linear_bwd_weight_h3(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes,
-                              int64_t M, int N, int K, int row_shift, int T, int accumulate, const float* dy_amax, void* stream) {
-    TTTS_REQUIRE(dy_amax, "linear_bwd_weight_h3: dy_amax (ttts_amax_partials of dy) is required");
-    return linear_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, M, N, K, row_shift, T, accumulate, true, stream, dy_amax);
+                              int64_t M, int N, int K, int row_shift, int T, int accumulate, const float* dy_amax,
+                              const float* x_amax, ttts_reduce_queue* queue, void* stream) {
+    TTTS_REQUIRE(dy_amax && x_amax, "linear_bwd_weight_h3: dy_amax and x_amax (partial maxima of dy and x) are required");
+    return linear_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, M, N, K, row_shift, T, accumulate, true, queue, stream, dy_amax,
+                                  x_amax);
 }
 
 size_t ttts_conv1d_pack_bytes(int cout, int cin, int taps) { return (size_t)cout * cin * taps * sizeof(float); }
@@ -1129,8 +1150,8 @@ int ttts_conv1d_bwd_data(const float* dy, const float* w_bwd, float* dx, int B, 
 }
 
 static int conv1d_bwd_weight_impl(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
-                                  int T, int cin, int cout, int taps, int accumulate, bool x6, void* stream_,
-                                  const float* dy_amax = nullptr) {
+                                  int T, int cin, int cout, int taps, int accumulate, bool x6, ttts_reduce_queue* queue,
+                                  void* stream_, const float* dy_amax = nullptr, const float* x_amax = nullptr) {
     // dw[co,ci,tap] (+)= sum_{b,t} dy[b,t,co] * x[b,t+tap-pad,ci] ; dbias[co] (+)= sum dy
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && x && dw && ws, "conv1d_bwd_weight: null pointer");
@@ -1143,28 +1164,29 @@ static int conv1d_bwd_weight_impl(const float* dy, const float* x, float* dw, fl
     x6 = x6 && wgrad_use_x6(cout, cin);
     if (!x6) dy_amax = nullptr;
     float* colsum_ws = dbias ? ws + (size_t)plan_wgrad(M, cout, cin, taps, x6, dy_amax ? HBK : BK).nsplit * n : nullptr;
-    int rc = wgrad_common(dy, x, ws, colsum_ws, M, cout, cin, taps, T, -((taps - 1) / 2), 1, &p, x6, stream, dy_amax);
+    int rc = wgrad_common(dy, x, ws, colsum_ws, M, cout, cin, taps, T, -((taps - 1) / 2), 1, &p, x6, stream, dy_amax, x_amax);
     if (rc) return rc;
-    const bool defer = (accumulate & 2) != 0;
-    rc = launch_conv_wgrad_reduce(ws, dw, cout, cin, taps, p.nsplit, accumulate & 1, stream, defer);
+    rc = launch_conv_wgrad_reduce(ws, dw, cout, cin, taps, p.nsplit, accumulate != 0, stream, queue);
     if (rc == TTTS_OK && dbias)
-        rc = launch_reduce_rows(colsum_ws, cout, p.nsplit, cout, dbias, cout, nullptr, accumulate & 1, stream, defer);
+        rc = launch_reduce_rows(colsum_ws, cout, p.nsplit, cout, dbias, cout, nullptr, accumulate != 0, stream, queue);
     return rc;
 }
 
 int ttts_conv1d_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
-                           int T, int cin, int cout, int taps, int accumulate, void* stream) {
-    return conv1d_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, B, T, cin, cout, taps, accumulate, false, stream);
+                           int T, int cin, int cout, int taps, int accumulate, ttts_reduce_queue* queue, void* stream) {
+    return conv1d_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, B, T, cin, cout, taps, accumulate, false, queue, stream);
 }
 int ttts_conv1d_bwd_weight_x6(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
-                              int T, int cin, int cout, int taps, int accumulate, void* stream) {
-    return conv1d_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, B, T, cin, cout, taps, accumulate, true, stream);
+                              int T, int cin, int cout, int taps, int accumulate, ttts_reduce_queue* queue, void* stream) {
+    return conv1d_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, B, T, cin, cout, taps, accumulate, true, queue, stream);
 }
 
 int ttts_conv1d_bwd_weight_h3(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
-                              int T, int cin, int cout, int taps, int accumulate, const float* dy_amax, void* stream) {
-    TTTS_REQUIRE(dy_amax, "conv1d_bwd_weight_h3: dy_amax (ttts_amax_partials of dy) is required");
-    return conv1d_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, B, T, cin, cout, taps, accumulate, true, stream, dy_amax);
+                              int T, int cin, int cout, int taps, int accumulate, const float* dy_amax, const float* x_amax,
+                              ttts_reduce_queue* queue, void* stream) {
+    TTTS_REQUIRE(dy_amax && x_amax, "conv1d_bwd_weight_h3: dy_amax and x_amax (partial maxima of dy and x) are required");
+    return conv1d_bwd_weight_impl(dy, x, dw, dbias, ws, ws_bytes, B, T, cin, cout, taps, accumulate, true, queue, stream, dy_amax,
+                                  x_amax);
 }
 
 int ttts_gemm_tile_choice(int64_t M, int N, int K, int x6) {
@@ -1203,6 +1225,10 @@ int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks,
     // descs (device): n x 8 int64 {w, planes, rows, cols, mode, channels_per_tap, taps, first_block}; first_block are the
     // prefix sums of ceil(rows*cols / 256); the caller guarantees the per-entry constraints of ttts_weight_split
     TTTS_REQUIRE(descs && n > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "weight_split_batched: bad arguments");
+    hipLaunchKernelGGL(weight_tail_zero_batched_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long*>(descs), n);
+    hipLaunchKernelGGL(weight_amax_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long*>(descs), n);
     hipLaunchKernelGGL(weight_split_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const long*>(descs), n);
     TTTS_LAUNCH_CHECK("weight_split_batched_kernel");
@@ -1232,8 +1258,8 @@ int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, 
 
 int ttts_linear_fwd_h3(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
                        int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift,
-                       int T, void* stream) {
-    TTTS_REQUIRE(x && w_planes && y, "linear_fwd_h3: null pointer");
+                       int T, const float* x_amax, float* y_amax_out, void* stream) {
+    TTTS_REQUIRE(x && w_planes && y && x_amax, "linear_fwd_h3: null pointer (x_amax, the partial maxima of |x|, is required)");
     TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_fwd_h3: bad dims");
     TTTS_REQUIRE(K % HBK == 0 && N % 4 == 0, "linear_fwd_h3: K=%d must be a multiple of %d and N=%d of 4", K, HBK, N);
     TTTS_REQUIRE(aligned16(x) && aligned16(w_planes), "linear_fwd_h3: x / planes must be 16-byte aligned");
@@ -1249,12 +1275,15 @@ int ttts_linear_fwd_h3(const float* x, const void* w_planes, const float* bias, 
     g.bias = bias; g.act = act;
     if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; g.step_seed = step_seed; }
     g.residual = residual; g.ldr = N;
+    g.a_amax = x_amax; g.a_amax_n = H3_AMAX_PARTIALS;
+    g.b_amax = h3_plane_tail(w_planes, N, K); g.b_amax_n = 1;
+    g.c_amax = y_amax_out;
     return dispatch_h3(g, (hipStream_t)stream);
 }
 
 int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
-                       int taps, void* stream) {
-    TTTS_REQUIRE(x && planes_fwd && y, "conv1d_fwd_h3: null pointer");
+                       int taps, const float* x_amax, void* stream) {
+    TTTS_REQUIRE(x && planes_fwd && y && x_amax, "conv1d_fwd_h3: null pointer (x_amax, the partial maxima of |x|, is required)");
     TTTS_REQUIRE(B > 0 && T > 0 && cin > 0 && cout > 0 && taps > 0 && (taps & 1), "conv1d_fwd_h3: bad dims");
     TTTS_REQUIRE(cin % HBK == 0 && cout % 4 == 0, "conv1d_fwd_h3: cin=%d must be a multiple of %d and cout=%d of 4", cin, HBK, cout);
     TTTS_REQUIRE((uint64_t)B * T * cin * 4 < (1ull << 32), "conv1d_fwd_h3: activation larger than 4 GiB");
@@ -1265,6 +1294,8 @@ int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias
     g.a_bytes = (uint32_t)((uint64_t)B * T * cin * 4); g.b_bytes = (uint32_t)((uint64_t)cout * taps * cin * 4);
     g.T = T; g.cin = cin; g.shift0 = -((taps - 1) / 2); g.shift_step = 1;
     g.bias = bias;
+    g.a_amax = x_amax; g.a_amax_n = H3_AMAX_PARTIALS;
+    g.b_amax = h3_plane_tail(planes_fwd, cout, (long)taps * cin); g.b_amax_n = 1;
     return dispatch_h3(g, (hipStream_t)stream);
 }
 
@@ -1285,6 +1316,7 @@ int ttts_linear_bwd_data_h3(const float* dy, const void* wt_planes, const float*
     g.residual = residual; g.ldr = K;
     g.relu_out = relu_out; g.relu_scale = relu_scale;
     g.a_amax = dy_amax; g.a_amax_n = H3_AMAX_PARTIALS;
+    g.b_amax = h3_plane_tail(wt_planes, K, N); g.b_amax_n = 1;
     g.c_amax = dx_amax_out;
     return dispatch_h3(g, (hipStream_t)stream);
 }
@@ -1302,6 +1334,7 @@ int ttts_conv1d_bwd_data_h3(const float* dy, const void* planes_bwd, float* dx, 
     g.a_bytes = (uint32_t)((uint64_t)B * T * cout * 4); g.b_bytes = (uint32_t)((uint64_t)cin * taps * cout * 4);
     g.T = T; g.cin = cout; g.shift0 = (taps - 1) / 2; g.shift_step = -1;
     g.a_amax = dy_amax; g.a_amax_n = H3_AMAX_PARTIALS;
+    g.b_amax = h3_plane_tail(planes_bwd, cin, (long)taps * cout); g.b_amax_n = 1;
     return dispatch_h3(g, (hipStream_t)stream);
 }
 

@@ -36,11 +36,15 @@ struct GemmArgs {
     // operand extents in bytes (< 4 GiB): loads go through raw buffer descriptors, so an out-of-range offset returns
     // zeros in hardware -- row / column / tap clipping costs a select on the offset instead of a branch around the load
     uint32_t a_bytes, b_bytes;
-    // fp16x3 kernel only: the A operand is a gradient whose magnitude is not known in advance.  a_amax (NULL: use the
-    // static activation pre-scale) points at a_amax_n partial maxima of |A| (ttts_amax_partials); every workgroup
-    // reduces them and pre-scales A by the power of two that puts max|A| in [2^11, 2^12).
+    // fp16x3 kernels only: f16 has no exponent range to spare, so both operands are pre-scaled by powers of two taken from
+    // their measured maxima.  a_amax / b_amax point at a_amax_n / b_amax_n partial maxima of |A| / |B| (the arrays of
+    // ttts_amax_partials or of a producer's `*_amax_out`; a weight-plane image carries ONE value, its tail): every workgroup
+    // reduces them and scales the operand by the power of two that puts its maximum in [2^11, 2^12).  Weight planes were
+    // written with that scale already (weight_split_h3_one), activations are scaled while they are staged.
     const float* a_amax;
     int a_amax_n;
+    const float* b_amax;
+    int b_amax_n;
     // fp16x3 kernel: NULL, or a caller-zeroed 1024-slot array that receives max|C| (amax_publish): the output is a
     // gradient that another fp16x3 GEMM will consume
     float* c_amax;
@@ -67,10 +71,14 @@ __device__ __forceinline__ void buf_store4s(__amdgpu_buffer_rsrc_t rsrc, uint32_
 
 // ---- fp16x3 ("h3") split: constants and the weight-plane image (see gemm_h3.hip)
 constexpr int HBK = 32;                 // k-tile depth
-constexpr float H3_A_SCALE = 16.0f;     // 2^4
-constexpr float H3_W_SCALE = 4096.0f;   // 2^12
-constexpr float H3_OUT_SCALE = 1.0f / (16.0f * 4096.0f);
 constexpr int H3_AMAX_PARTIALS = 1024;  // length of the partial-maxima array of ttts_amax_partials
+
+// byte size of the fp16x3 image of a rows x cols weight: two f16 planes, then a 16-byte tail whose first float is max|w|
+// (written by the split, read by every GEMM that takes the planes: the scale the planes were written with follows from it)
+__host__ __device__ __forceinline__ size_t h3_plane_bytes(long rows, long cols) { return (size_t)rows * cols * 4; }
+__host__ __device__ __forceinline__ const float* h3_plane_tail(const void* planes, long rows, long cols) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(planes) + h3_plane_bytes(rows, cols));
+}
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -83,11 +91,25 @@ __device__ __forceinline__ void split2_pair(f32x2 x, uint32_t& hi, uint32_t& lo)
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
 }
 
-// B[r][c] of weight_split (gemm.hip) as two f16 planes of w * 2^12, stored [c/32][plane][r][c%32]
+// |w| maximum of one weight into the tail of its plane image (atomic max on the bit pattern; the tail was zeroed first)
+__device__ __forceinline__ void weight_amax_h3_one(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
+                                                   int C, long i) {
+    const long n = (long)R * C;
+    float m = (i < n) ? fabsf(w[i]) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f)
+        atomicMax(reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(planes) + h3_plane_bytes(R, C)), __float_as_uint(m));
+}
+
+// B[r][c] of weight_split (gemm.hip) as two f16 planes of w * scale, stored [c/32][plane][r][c%32]; scale = the power of two
+// of h3_pow2_scale(max|w|), max|w| read from the tail (weight_amax_h3_one has run)
 __device__ __forceinline__ void weight_split_h3_one(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
                                                     int C, int mode, int c2, int taps, long i) {
     const long n = (long)R * C;
     if (i >= n) return;
+    float w_scale, w_inv;
+    h3_pow2_scale(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(planes) + h3_plane_bytes(R, C)), w_scale, w_inv);
     const int r = (int)(i / C), c = (int)(i % C);
     float v;
     if (mode == 0) v = w[i];
@@ -97,7 +119,7 @@ __device__ __forceinline__ void weight_split_h3_one(const float* __restrict__ w,
         if (mode == 2) v = w[((long)r * c2 + ch) * taps + tap];
         else v = w[((long)ch * R + r) * taps + tap];
     }
-    v *= H3_W_SCALE;
+    v *= w_scale;
     const _Float16 h = (_Float16)v;
     const _Float16 l = (_Float16)(v - (float)h);
     const long o = ((long)(c >> 5) * 2 * R + r) * 32 + (c & 31);

@@ -8,36 +8,39 @@
 // 2^-22 of the exact product: half the matrix-pipe work of bf16x6 for the same fp32-grade answer (measured against
 // fp64 in tests/test_hip_modes.py, same 5e-6 gate as the other forms; typically 2-4e-7).
 //
-// What f16 lacks is bf16's exponent range (normal numbers 6.1e-5 .. 65504), so operands are pre-scaled by powers of
-// two (exact) that centre their typical magnitude in that window:
-//     activations x 2^4    (full 22-bit precision for 0.0078 <= |a| < 4096, absolute error <= 2^-29 below that)
-//     weights     x 2^12   (full precision for 3.1e-5 <= |w| < 16,     absolute error <= 2^-37 below that)
-// and the accumulator is scaled back by 2^-16 in the epilogue.  This fits the FORWARD operands of this model -- LayerNorm /
-// BatchNorm / tanh / ReLU outputs and N(0,1) mels are O(1), weights O(1/sqrt(fan_in)) -- and that is where the kernel is
-// used (nn.Linear and Conv1d forward: two of the four GEMM passes of a training step).  Gradients (1e-7 .. 1e-5 after
-// the mean-reduced loss) do not fit a fixed window; data- and weight-gradient GEMMs stay on bf16x6.
-// An activation >= 4096 in magnitude saturates to +-inf and shows up as inf / NaN in the output (never silently wrong);
-// TTTS_FWD_MODE=x6 selects the bf16 form for such models.
+// What f16 lacks is bf16's exponent range (normal numbers 6.1e-5 .. 65504), so BOTH operands are pre-scaled by powers of
+// two (exact) taken from their measured maxima (h3_pow2_scale, gemm_common.h): the largest magnitude lands in
+// [2^11, 2^12), every element within 2^-15 of it keeps 22 significant bits, smaller ones an absolute error of 2^-37 of
+// the maximum, and the accumulator is scaled back in the epilogue.  Nothing about the operands' magnitude is assumed:
+//   * activations / gradients: 1024 partial maxima left by the kernel that produced the tensor (GEMM epilogues, LayerNorm,
+//     BatchNorm, positional encoding, attention, the dropout / relu backward masks ...) or by ttts_amax_partials (one read);
+//   * weights: max|w| sits in the tail of the plane image, measured by the split itself.
+// A non-finite operand gives a non-finite result, as fp32 arithmetic would.
 //
 // Structure: 128x128 (or 64x128 / 128x96) tile, 4 waves, 32-deep k-tiles = two MFMA k-steps per barrier (the bf16x6
 // kernel has one 16-deep step per barrier: with half the MFMAs per step its barrier / staging overhead would double in
 // relative terms).  LDS rows are 64 bytes (32 f16) per plane; the 16-byte chunk of a row is XORed with (row >> 2) & 3,
 // which makes both the ds_write of the staged pieces and the ds_read_b128 of the MFMA fragments conflict-free.
 // Weights are split once per step by weight_split (modes 4-7) into two f16 planes laid [K/32][plane][N][32].
-#include <stdlib.h>
-
 #include "gemm_common.h"
 #include <type_traits>
 
 namespace ttts {
 
+__global__ __launch_bounds__(256) void weight_amax_h3_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
+                                                             int R, int C) {
+    weight_amax_h3_one(w, planes, R, C, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
 __global__ __launch_bounds__(256) void weight_split_h3_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
                                                               int R, int C, int mode, int c2, int taps) {
     weight_split_h3_one(w, planes, R, C, mode, c2, taps, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// tail = 0, max|w| into the tail, then the planes scaled by the power of two that follows from it
 void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, int mode, int c2, int taps, hipStream_t stream) {
     const long n = (long)rows * cols;
+    (void)hipMemsetAsync(reinterpret_cast<char*>(planes) + h3_plane_bytes(rows, cols), 0, 16, stream);
+    hipLaunchKernelGGL(weight_amax_h3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, w, (unsigned short*)planes, rows, cols);
     hipLaunchKernelGGL(weight_split_h3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, w, (unsigned short*)planes, rows,
                        cols, mode, c2, taps);
 }
@@ -58,23 +61,6 @@ __global__ __launch_bounds__(256) void amax_partials_kernel(const float* __restr
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-}
-
-// power-of-two pre-scale of a gradient operand from its partial maxima, and the matching accumulator scale (x 2^-12 for
-// the weight planes).  max|A| * a_scale lands in [2^11, 2^12); all-zero / denormal-small / non-finite operands use 1.
-__device__ __forceinline__ void h3_dynamic_scale(const float* __restrict__ partials, int n, int lane, float& a_scale,
-                                                 float& out_scale) {
-    float m = 0.f;
-    for (int i = lane; i < n; i += 64) m = fmaxf(m, partials[i]);
-    m = wave_max(m);
-    const uint32_t e = (__float_as_uint(m) >> 23) & 0xffu;
-    if (e >= 24u && e < 255u) {
-        a_scale = __uint_as_float((265u - e) << 23);          // 2^(138 - e): max|A| -> [2^11, 2^12)
-        out_scale = __uint_as_float((e - 23u) << 23);         // 2^(e - 150) = 1 / (a_scale * 2^12)
-    } else {
-        a_scale = 1.0f;
-        out_scale = 1.0f / H3_W_SCALE;
-    }
 }
 
 template <int BM, int BN, int WM, int WN, bool CLIP>
@@ -104,8 +90,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int nkt = g.K / HBK;
-    float a_scale = H3_A_SCALE, out_scale = H3_OUT_SCALE;
-    if (g.a_amax != nullptr) h3_dynamic_scale(g.a_amax, g.a_amax_n, lane, a_scale, out_scale);
+    float a_scale, out_scale;
+    {
+        float a_inv, w_scale, w_inv;
+        h3_operand_scale(g.a_amax, g.a_amax_n, lane, a_scale, a_inv);
+        h3_operand_scale(g.b_amax, g.b_amax_n, lane, w_scale, w_inv);      // the planes already carry w_scale
+        out_scale = a_inv * w_inv;
+    }
     // Persistent tile loop: the grid is (at most) as many workgroups as the chip holds at once and each walks over tiles
     // bid, bid + gridDim.x, ...  A workgroup that has issued the stores of one tile goes straight on to the loads of the next,
     // so the output burst drains from L2 to HBM under the next tile's main loop instead of in front of a new workgroup's
@@ -473,10 +464,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
 template <int BM, int BN, int WM, int WN>
 static int launch_h3(const GemmArgs& g, hipStream_t stream) {
     // persistent grid: one workgroup per CU for the 8-wave tiles (128 KB / 96 KB of LDS), two for the 4-wave ones
-    static int persist = -1;                      // development aid: TTTS_H3_PERSIST=0 launches one workgroup per tile
-    if (persist < 0) { const char* e = getenv("TTTS_H3_PERSIST"); persist = e ? atoi(e) : 1; }
     const long ntiles = (long)cdiv(g.N, BN) * cdiv(g.M, BM);
-    const long cap = persist ? 256L * (WM * WN == 8 ? 1 : 2) : ntiles;     // 4-wave tiles: two workgroups per CU
+    const long cap = 256L * (WM * WN == 8 ? 1 : 2);                        // 4-wave tiles: two workgroups per CU
     dim3 grid((unsigned)(ntiles < cap ? ntiles : cap), 1, 1);
     if (g.T > 0)
         hipLaunchKernelGGL((gemm_h3_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, stream, g);
@@ -493,15 +482,10 @@ bool h3_supports(const GemmArgs& g) {
 
 
 int h3_tile_choice(long M, long N, long K) {
-    static int forced = -1;                       // development aid: TTTS_H3_TILE forces a tile shape
-    if (forced < 0) { const char* e = getenv("TTTS_H3_TILE"); forced = e ? atoi(e) : 0; }
-    if (forced > 0) return forced;
     if (N <= 96 && (long)cdiv(M, 128) >= 384) return TILE_128x96;
     // busiest-CU cost model of gemm.hip's choose_tile: workgroups a CU runs one after the other x tile area / efficiency
     // (a 256-wide tile is one workgroup per CU at a time, the 128-wide ones two)
     struct Cand { int tile, bm, bn, per_cu; float eff; };
-    static int pair = -1;                         // TTTS_H3_PAIR=0: never pick the two-workgroup 256x128 tile
-    if (pair < 0) { const char* e = getenv("TTTS_H3_PAIR"); pair = e ? atoi(e) : 1; }
     // the two-workgroup 256x128 tile lets one workgroup's store burst drain under the other's main loop.  Per kernel it wins
     // where the epilogue weighs as much as the main loop (K <= 512: +3 .. 9 % at M = 55 680, +24 % at M = 6 400) and loses
     // where the main loop dominates (K >= 1024: -8 %, one LDS stage and two barriers per k-tile); over the whole step at
@@ -512,7 +496,7 @@ int h3_tile_choice(long M, long N, long K) {
     int best = TILE_128;
     float best_cost = 1e30f;
     for (const Cand& c : cands) {
-        if (c.tile == H3_TILE_256x128_PAIR && (!pair || K <= 0 || K > 512 || (long)cdiv(M, 256) * cdiv(N, 256) >= 256)) continue;
+        if (c.tile == H3_TILE_256x128_PAIR && (K <= 0 || K > 512 || (long)cdiv(M, 256) * cdiv(N, 256) >= 256)) continue;
         long tiles = (long)cdiv(M, c.bm) * cdiv(N, c.bn);
         long rounds = (tiles + 256L * c.per_cu - 1) / (256L * c.per_cu);
         float cost = (float)rounds * (float)(c.bm * c.bn) * (float)c.per_cu / c.eff;
@@ -605,11 +589,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_k
     if (kt_end > nkt) kt_end = nkt;
     const int shift = g.shift0 + ztap * g.shift_step;
 
-    float a_scale = 1.0f, out_scale = 1.0f;
+    float a_scale, b_scale, out_scale;
     {
-        float os;
-        h3_dynamic_scale(g.a_amax, g.a_amax_n, lane, a_scale, os);
-        out_scale = os * (H3_W_SCALE / H3_A_SCALE);            // os = 1 / (a_scale * 2^12); here the B scale is 2^4
+        float a_inv, b_inv;
+        h3_operand_scale(g.a_amax, g.a_amax_n, lane, a_scale, a_inv);      // dy
+        h3_operand_scale(g.b_amax, g.b_amax_n, lane, b_scale, b_inv);      // x
+        out_scale = a_inv * b_inv;
     }
 
     f32x16 acc[TM][TN];
@@ -643,7 +628,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_k
     if (!slot) cur = OOB;
     int b_t = (g.T > 0) ? (int)(((long)kt_begin * HBK + rg * 8) % g.T) : 0;
     const bool clip = is_b && g.T > 0 && shift != 0;
-    const float scale = is_b ? H3_A_SCALE : a_scale;
+    const float scale = is_b ? b_scale : a_scale;
     // LDS dword offsets of this thread's four pieces (one per column e), plane 0
     int dst[4];
 #pragma unroll

@@ -12,10 +12,11 @@ constexpr int LN_MAXPER = 16;   // d <= 1024
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            long M, int d, float eps) {
+                                                            long M, int d, float eps, float* __restrict__ amax_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long row = (long)blockIdx.x * 4 + wave;
     if (row >= M) return;
+    float ymax = 0.f;
     const int nper = d >> 6;
     const float* xr = x + row * d;
     float v[LN_MAXPER];
@@ -37,13 +38,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     for (int i = 0; i < LN_MAXPER; ++i) {
         if (i < nper) {
             int c = lane + 64 * i;
-            yr[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+            const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+            yr[c] = o;
+            ymax = fmaxf(ymax, fabsf(o));
         }
     }
     if (lane == 0) {
         if (mean_out) mean_out[row] = mean;
         if (rstd_out) rstd_out[row] = rstd;
     }
+    if (amax_out != nullptr) amax_publish(ymax, amax_out, (int)row);
 }
 
 // d = 256 * NV: a lane owns NV float4 (16-byte accesses, one 1-KB wave instruction per 256 columns) and a wave walks
@@ -53,11 +57,12 @@ template <int NV, int ROWS>
 __global__ __launch_bounds__(256) void layernorm_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ y,
                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                               long M, float eps) {
+                                                               long M, float eps, float* __restrict__ amax_out) {
     constexpr int d = 256 * NV;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long row0 = ((long)blockIdx.x * 4 + wave) * ROWS;
     if (row0 >= M) return;
+    float ymax = 0.f;
     float4 v[ROWS][NV];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r)
@@ -87,16 +92,20 @@ __global__ __launch_bounds__(256) void layernorm_fwd_v4_kernel(const float* __re
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
         if (row0 + r < M) {
 #pragma unroll
-            for (int k = 0; k < NV; ++k)
-                reinterpret_cast<float4*>(y + (row0 + r) * d)[lane + 64 * k] =
-                    make_float4((v[r][k].x - mean) * rstd * ga[k].x + be[k].x, (v[r][k].y - mean) * rstd * ga[k].y + be[k].y,
-                                (v[r][k].z - mean) * rstd * ga[k].z + be[k].z, (v[r][k].w - mean) * rstd * ga[k].w + be[k].w);
+            for (int k = 0; k < NV; ++k) {
+                const float4 o = make_float4((v[r][k].x - mean) * rstd * ga[k].x + be[k].x, (v[r][k].y - mean) * rstd * ga[k].y + be[k].y,
+                                             (v[r][k].z - mean) * rstd * ga[k].z + be[k].z, (v[r][k].w - mean) * rstd * ga[k].w + be[k].w);
+                reinterpret_cast<float4*>(y + (row0 + r) * d)[lane + 64 * k] = o;
+                ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            }
             if (lane == 0) {
                 if (mean_out) mean_out[row0 + r] = mean;
                 if (rstd_out) rstd_out[row0 + r] = rstd;
             }
         }
     }
+    // max|y| of the rows this wave wrote, for the fp16x3 GEMM / attention that consumes y (caller-zeroed slots)
+    if (amax_out != nullptr) amax_publish(ymax, amax_out, blockIdx.x * 4 + wave);
 }
 
 constexpr int LN_BWD_BLOCKS = 256;
@@ -360,8 +369,10 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* 
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ z, long n4,
-                                                           int C, int act, float drop_scale, uint32_t thr, uint64_t seed, const uint64_t* step_seed) {
+                                                           int C, int act, float drop_scale, uint32_t thr, uint64_t seed, const uint64_t* step_seed,
+                                                           float* __restrict__ amax_out) {
     seed = site_seed(seed, step_seed);
+    float zmax = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long e = i * 4;
         const int c = (int)(e % C);
@@ -378,7 +389,9 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
             if (thr != 0u) o[j] = keep_elem(seed, (uint64_t)(e + j), thr) ? o[j] * drop_scale : 0.f;
         }
         *reinterpret_cast<float4*>(z + e) = make_float4(o[0], o[1], o[2], o[3]);
+        zmax = fmaxf(fmaxf(zmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
     }
+    if (amax_out != nullptr) amax_publish(zmax, amax_out, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 // 1 - tanh(u)^2 for the backward pass: tanh from one v_exp and one v_rcp (absolute error ~1e-7 in tanh, i.e. relative
@@ -506,7 +519,7 @@ using namespace ttts;
 extern "C" {
 
 int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                       int64_t M, int d, float eps, void* stream) {
+                       int64_t M, int d, float eps, float* y_amax_out, void* stream) {
     TTTS_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
     TTTS_REQUIRE(M > 0 && d > 0 && d % 64 == 0 && d <= 64 * LN_MAXPER, "layernorm_fwd: d=%d must be a multiple of 64, <= %d",
                  d, 64 * LN_MAXPER);
@@ -514,16 +527,16 @@ int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
                     ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0;
     if (v4 && d == 256)
         hipLaunchKernelGGL((layernorm_fwd_v4_kernel<1, 4>), dim3(cdiv(M, 16)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                           mean, rstd, (long)M, eps);
+                           mean, rstd, (long)M, eps, y_amax_out);
     else if (v4 && d == 512)
         hipLaunchKernelGGL((layernorm_fwd_v4_kernel<2, 2>), dim3(cdiv(M, 8)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                           mean, rstd, (long)M, eps);
+                           mean, rstd, (long)M, eps, y_amax_out);
     else if (v4)
         hipLaunchKernelGGL((layernorm_fwd_v4_kernel<4, 1>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                           mean, rstd, (long)M, eps);
+                           mean, rstd, (long)M, eps, y_amax_out);
     else
         hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
-                           rstd, (long)M, d, eps);
+                           rstd, (long)M, d, eps, y_amax_out);
     TTTS_LAUNCH_CHECK("layernorm_fwd_kernel");
     return TTTS_OK;
 }
@@ -533,7 +546,7 @@ size_t ttts_layernorm_bwd_workspace_bytes(int d) { return (size_t)LN_BWD_BLOCKS 
 static int layernorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                               float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
                               int accumulate, float* dacc, float drop_p, uint64_t seed, const uint64_t* step_seed,
-                              float* dacc_amax, hipStream_t stream) {
+                              float* dacc_amax, ttts_reduce_queue* queue, hipStream_t stream) {
     TTTS_REQUIRE(dy && x && mean && rstd && gamma && dx && ws, "layernorm_bwd: null pointer");
     TTTS_REQUIRE(M > 0 && d > 0 && d % 64 == 0 && d <= 64 * LN_MAXPER, "layernorm_bwd: bad d=%d", d);
     TTTS_REQUIRE(ws_bytes >= ttts_layernorm_bwd_workspace_bytes(d), "layernorm_bwd: workspace too small");
@@ -555,7 +568,7 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* mean
         }
 #undef TTTS_LN_BWD4
         TTTS_LAUNCH_CHECK("layernorm_bwd_v4_kernel");
-        return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate & 1, stream, (accumulate & 2) != 0);
+        return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate != 0, stream, queue);
     }
 #define TTTS_LN_BWD(NPER)                                                                                         \
     hipLaunchKernelGGL((layernorm_bwd_kernel<NPER>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, \
@@ -570,24 +583,24 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* mean
     }
 #undef TTTS_LN_BWD
     TTTS_LAUNCH_CHECK("layernorm_bwd_kernel");
-    return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate & 1, stream, (accumulate & 2) != 0);
+    return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate != 0, stream, queue);
 }
 
 int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
-                       int accumulate, void* stream) {
+                       int accumulate, ttts_reduce_queue* queue, void* stream) {
     return layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, ws_bytes, M, d, accumulate, nullptr, 0.f, 0,
-                              nullptr, nullptr, (hipStream_t)stream);
+                              nullptr, nullptr, queue, (hipStream_t)stream);
 }
 
 int ttts_layernorm_bwd_drop(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                             float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
                             int accumulate, float* dacc, float drop_p, uint64_t seed, const uint64_t* step_seed,
-                            float* dacc_amax, void* stream) {
+                            float* dacc_amax, ttts_reduce_queue* queue, void* stream) {
     TTTS_REQUIRE(dacc, "layernorm_bwd_drop: dacc is required");
     TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd_drop: bad dropout p");
     return layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, ws_bytes, M, d, accumulate, dacc, drop_p, seed,
-                              step_seed, dacc_amax, (hipStream_t)stream);
+                              step_seed, dacc_amax, queue, (hipStream_t)stream);
 }
 
 size_t ttts_bn_workspace_bytes(int64_t M, int C) {
@@ -622,7 +635,8 @@ int ttts_bn_eval_stats(const float* running_mean, const float* running_var, floa
 }
 
 int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                      float* z, int64_t M, int C, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
+                      float* z, int64_t M, int C, int act, float drop_p, uint64_t seed, const uint64_t* step_seed,
+                      float* z_amax_out, void* stream) {
     TTTS_REQUIRE(x && mean && invstd && gamma && beta && z, "bn_apply_fwd: null pointer");
     TTTS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_apply_fwd: C=%d must be a multiple of 4", C);
     TTTS_REQUIRE(act == TTTS_ACT_NONE || act == TTTS_ACT_TANH, "bn_apply_fwd: act must be none or tanh");
@@ -632,7 +646,7 @@ int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, co
     if (grid > 4096) grid = 4096;
     uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, z,
-                       n4, C, act, 1.f / (1.f - drop_p), thr, seed, step_seed);
+                       n4, C, act, 1.f / (1.f - drop_p), thr, seed, step_seed, z_amax_out);
     TTTS_LAUNCH_CHECK("bn_apply_fwd_kernel");
     return TTTS_OK;
 }

@@ -3,12 +3,15 @@
 // and either stored or added to the destination (`accumulate`: gradients land directly in a flat gradient buffer).
 //
 // Deferred form: a training step has ~90 of these (one per weight / bias / LayerNorm parameter pair), each a few
-// microseconds of work behind a launch.  Between ttts_reduce_defer_begin() and ttts_reduce_defer_flush() the launchers
-// called with `deferrable` queue a descriptor on the host instead, and flush runs them all in ONE launch per 48
-// descriptors (the table travels in the kernel-argument segment: nothing to copy, nothing to keep alive, and a captured
-// HIP graph replays it as it stands).  Every form sums in the same order whether deferred or not.
+// microseconds of work behind a launch.  Given a caller-owned `ttts_reduce_queue` the launchers append a descriptor to it
+// on the host instead of launching, and ttts_reduce_queue_flush runs them all in ONE launch per 48 descriptors (the table
+// travels in the kernel-argument segment: nothing to copy, nothing to keep alive, and a captured HIP graph replays it as it
+// stands).  Every form sums in the same order whether deferred or not.  The library keeps no queue of its own: a queue
+// belongs to whoever created it (one per gradient bucket in the Python host code), and independent callers on different
+// threads / streams use different queues.
 #include "ttts_common.h"
 #include <mutex>
+#include <new>
 #include <vector>
 
 namespace ttts {
@@ -154,16 +157,21 @@ __global__ __launch_bounds__(256) void reduce_batched_kernel(const ReduceBatch b
 }
 
 // ------------------------------------------------------------------------------------------ host side
-static std::mutex g_defer_mu;          // autograd runs backward nodes and its final callbacks on its own threads
-static bool g_deferring = false;
-static std::vector<ReduceDesc> g_queue;
+}  // namespace ttts
+// the opaque handle of include/ttts_hip.h: descriptors appended by the *_bwd_* entry points that were given this queue.
+// The mutex only protects the vector: autograd runs backward nodes on worker threads while the owner flushes from its own.
+struct ttts_reduce_queue {
+    std::mutex mu;
+    std::vector<ttts::ReduceDesc> q;
+};
+namespace ttts {
 
-static bool defer_push(ReduceDesc d, long blocks) {
-    std::lock_guard<std::mutex> lock(g_defer_mu);
-    if (!g_deferring) return false;
+static bool defer_push(ttts_reduce_queue* queue, ReduceDesc d, long blocks) {
+    if (queue == nullptr) return false;
+    std::lock_guard<std::mutex> lock(queue->mu);
     d.first_block = (int)blocks;        // block COUNT for now; flush turns the counts into prefix sums per batch
     d.pad = 0;
-    g_queue.push_back(d);
+    queue->q.push_back(d);
     return true;
 }
 
@@ -188,21 +196,18 @@ static ReduceDesc wide_desc(const float* ws, long ld, int nrows, long ncols4, fl
 // out (+)= column sums of ws [nrows][ncols] and out2 (+)= column sums of ws2 [nrows][ncols2]; one launch when the first is
 // a wide (weight-matrix) reduction, two otherwise.  Same summation order as launch_reduce_rows for either part.
 int launch_reduce_rows_pair(const float* ws, long ld, int nrows, long ncols, float* out, const float* ws2, long ld2,
-                            long ncols2, float* out2, int accumulate, hipStream_t stream, bool deferrable) {
+                            long ncols2, float* out2, int accumulate, hipStream_t stream, ttts_reduce_queue* queue) {
     const bool wide = wide_ok(ws, ld, ncols, out);
     if (!wide || out2 == nullptr) {
-        int rc = launch_reduce_rows(ws, ld, nrows, ncols, out, ncols, nullptr, accumulate, stream, deferrable);
+        int rc = launch_reduce_rows(ws, ld, nrows, ncols, out, ncols, nullptr, accumulate, stream, queue);
         if (rc || out2 == nullptr) return rc;
-        return launch_reduce_rows(ws2, ld2, nrows, ncols2, out2, ncols2, nullptr, accumulate, stream, deferrable);
+        return launch_reduce_rows(ws2, ld2, nrows, ncols2, out2, ncols2, nullptr, accumulate, stream, queue);
     }
     const long n4 = ncols / 4;
     const int nb_wide = cdiv(n4, 256);
-    if (deferrable && fits_int(ld) && fits_int(ld2) && fits_int(ncols) &&
-        defer_push(wide_desc(ws, ld, nrows, n4, out, accumulate), nb_wide)) {
-        if (!defer_push(narrow_desc(ws2, ld2, nrows, ncols2, out2, ncols2, nullptr, accumulate), cdiv(ncols2, 16))) {
-            set_error("reduce: deferral ended between the two halves of a weight / bias pair");
-            return TTTS_ERR_INVALID;
-        }
+    if (queue != nullptr && fits_int(ld) && fits_int(ld2) && fits_int(ncols)) {
+        defer_push(queue, wide_desc(ws, ld, nrows, n4, out, accumulate), nb_wide);
+        defer_push(queue, narrow_desc(ws2, ld2, nrows, ncols2, out2, ncols2, nullptr, accumulate), cdiv(ncols2, 16));
         return TTTS_OK;
     }
     hipLaunchKernelGGL(reduce_rows_pair_kernel, dim3(nb_wide + cdiv(ncols2, 16)), dim3(256), 0, stream, ws, ld, nrows, n4, out,
@@ -212,16 +217,16 @@ int launch_reduce_rows_pair(const float* ws, long ld, int nrows, long ncols, flo
 }
 
 int launch_reduce_rows(const float* ws, long ld, int nrows, long ncols, float* out0, long n0, float* out1, int accumulate,
-                       hipStream_t stream, bool deferrable) {
+                       hipStream_t stream, ttts_reduce_queue* queue) {
     const bool wide = out1 == nullptr && n0 >= ncols && wide_ok(ws, ld, ncols, out0);
-    const bool q = deferrable && fits_int(ld) && fits_int(ncols);
+    const bool q = queue != nullptr && fits_int(ld) && fits_int(ncols);
     if (wide) {
         long n4 = ncols / 4;
-        if (q && defer_push(wide_desc(ws, ld, nrows, n4, out0, accumulate), cdiv(n4, 256))) return TTTS_OK;
+        if (q && defer_push(queue, wide_desc(ws, ld, nrows, n4, out0, accumulate), cdiv(n4, 256))) return TTTS_OK;
         hipLaunchKernelGGL(reduce_rows_wide_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, stream, ws, ld, nrows, n4, out0,
                            accumulate);
     } else {
-        if (q && defer_push(narrow_desc(ws, ld, nrows, ncols, out0, n0, out1, accumulate), cdiv(ncols, 16))) return TTTS_OK;
+        if (q && defer_push(queue, narrow_desc(ws, ld, nrows, ncols, out0, n0, out1, accumulate), cdiv(ncols, 16))) return TTTS_OK;
         hipLaunchKernelGGL(reduce_rows_narrow_kernel, dim3(cdiv(ncols, 16)), dim3(256), 0, stream, ws, ld, nrows, ncols,
                            out0, n0, out1, accumulate);
     }
@@ -230,13 +235,13 @@ int launch_reduce_rows(const float* ws, long ld, int nrows, long ncols, float* o
 }
 
 int launch_conv_wgrad_reduce(const float* ws, float* dw, int cout, int cin, int taps, int nsplit, int accumulate,
-                             hipStream_t stream, bool deferrable) {
+                             hipStream_t stream, ttts_reduce_queue* queue) {
     const long n = (long)cout * cin * taps;
-    if (deferrable && fits_int(n)) {
+    if (queue != nullptr && fits_int(n)) {
         ReduceDesc d{};
         d.ws = ws; d.out0 = dw; d.n0 = cout * cin; d.taps = taps; d.nrows = nsplit; d.kind = RED_CONV; d.accumulate = accumulate;
         d.ncols = (int)n;
-        if (defer_push(d, cdiv(n, 256))) return TTTS_OK;
+        if (defer_push(queue, d, cdiv(n, 256))) return TTTS_OK;
     }
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, ws, dw, cout, cin, taps, nsplit,
                        accumulate);
@@ -250,33 +255,32 @@ using namespace ttts;
 
 extern "C" {
 
-int ttts_reduce_defer_begin(void) {
-    std::lock_guard<std::mutex> lock(g_defer_mu);
-    g_deferring = true;
+ttts_reduce_queue* ttts_reduce_queue_create(void) { return new (std::nothrow) ttts_reduce_queue(); }
+
+void ttts_reduce_queue_destroy(ttts_reduce_queue* queue) { delete queue; }
+
+int64_t ttts_reduce_queue_pending(ttts_reduce_queue* queue) {
+    if (queue == nullptr) return 0;
+    std::lock_guard<std::mutex> lock(queue->mu);
+    return (int64_t)queue->q.size();
+}
+
+int ttts_reduce_queue_clear(ttts_reduce_queue* queue) {
+    TTTS_REQUIRE(queue, "reduce_queue_clear: null queue");
+    std::lock_guard<std::mutex> lock(queue->mu);
+    queue->q.clear();
     return TTTS_OK;
 }
 
-int64_t ttts_reduce_defer_pending(void) {
-    std::lock_guard<std::mutex> lock(g_defer_mu);
-    return (int64_t)g_queue.size();
-}
-
-int ttts_reduce_defer_abort(void) {
-    std::lock_guard<std::mutex> lock(g_defer_mu);
-    g_deferring = false;
-    g_queue.clear();
-    return TTTS_OK;
-}
-
-int ttts_reduce_defer_flush(int keep_deferring, void* stream_) {
-    // run everything queued since begin and, unless keep_deferring, go back to immediate launches.  Entries of one launch
-    // run concurrently, so a second reduction into a destination already in the batch (a parameter used twice in the
-    // pass) starts a new launch: queue order is kept per destination.
+int ttts_reduce_queue_flush(ttts_reduce_queue* queue, void* stream_) {
+    // run everything appended since the last flush.  Entries of one launch run concurrently, so a second reduction into a
+    // destination already in the batch (a parameter used twice in the pass) starts a new launch: queue order is kept per
+    // destination.
+    TTTS_REQUIRE(queue, "reduce_queue_flush: null queue");
     std::vector<ReduceDesc> q;
     {
-        std::lock_guard<std::mutex> lock(g_defer_mu);
-        q.swap(g_queue);
-        if (!keep_deferring) g_deferring = false;
+        std::lock_guard<std::mutex> lock(queue->mu);
+        q.swap(queue->q);
     }
     hipStream_t stream = (hipStream_t)stream_;
     for (size_t at = 0; at < q.size();) {
@@ -296,7 +300,7 @@ int ttts_reduce_defer_flush(int keep_deferring, void* stream_) {
             ++b.n;
             ++at;
         }
-        TTTS_REQUIRE(blocks > 0 && blocks < (1L << 31), "reduce_defer_flush: bad block count");
+        TTTS_REQUIRE(blocks > 0 && blocks < (1L << 31), "reduce_queue_flush: bad block count");
         hipLaunchKernelGGL(reduce_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, b);
         TTTS_LAUNCH_CHECK("reduce_batched_kernel");
     }

@@ -31,16 +31,16 @@ void set_error(const char* fmt, ...);
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // out0[c] (+)= sum_r ws[r*ld + c] for c < n0, out1[c - n0] for the rest (reduce.hip); fixed summation order
-// `deferrable`: nothing later in the same pass reads the result (parameter gradients), so the launch may be queued while
-// ttts_reduce_defer_begin() .. ttts_reduce_defer_flush() is open
+// `queue` != NULL: nothing later in the same pass reads the result (parameter gradients), so the reduction is appended to
+// the caller's queue (ttts_reduce_queue_flush runs it) instead of being launched now
 int launch_reduce_rows(const float* ws, long ld, int nrows, long ncols, float* out0, long n0, float* out1, int accumulate,
-                       hipStream_t stream, bool deferrable = false);
+                       hipStream_t stream, ttts_reduce_queue* queue = nullptr);
 // weight-matrix partials and the matching bias partials in one launch (reduce.hip)
 int launch_reduce_rows_pair(const float* ws, long ld, int nrows, long ncols, float* out, const float* ws2, long ld2,
-                            long ncols2, float* out2, int accumulate, hipStream_t stream, bool deferrable = false);
+                            long ncols2, float* out2, int accumulate, hipStream_t stream, ttts_reduce_queue* queue = nullptr);
 // conv weight-gradient partials ws[split][tap][co][ci] -> dw[co][ci][tap] (reduce.hip)
 int launch_conv_wgrad_reduce(const float* ws, float* dw, int cout, int cin, int taps, int nsplit, int accumulate,
-                             hipStream_t stream, bool deferrable = false);
+                             hipStream_t stream, ttts_reduce_queue* queue = nullptr);
 
 // ---------------------------------------------------------------- counter-based dropout RNG
 // keep(seed, idx) is a pure function of the 64-bit site seed and the element index, so the backward kernels
@@ -135,6 +135,32 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ void amax_publish(float m, float* __restrict__ slots, int slot) {
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(slots) + (slot & 1023), __float_as_uint(m));
+}
+
+// Power-of-two pre-scale of an fp16x3 operand whose largest magnitude is m: scale * m lands in [2^11, 2^12), i.e. every
+// element within 2^-15 of the largest keeps 22 significant bits in its (hi, lo) f16 pair and smaller ones an absolute
+// error of 2^-37 * m.  inv = 1 / scale (exact).  Zero, denormal-small (< 2^-103) and non-finite maxima use 1: nothing
+// to scale, or the infinity / NaN travels through the product visibly.
+__host__ __device__ __forceinline__ void h3_pow2_scale(float m, float& scale, float& inv) {
+    union { float f; uint32_t u; } v;
+    v.f = m;
+    const uint32_t e = (v.u >> 23) & 0xffu;
+    if (e >= 24u && e < 255u) {
+        v.u = (265u - e) << 23; scale = v.f;               // m in [2^(e-127), 2^(e-126)): scale = 2^(138 - e)
+        v.u = (e - 11u) << 23; inv = v.f;                  // 2^(e - 138)
+    } else {
+        scale = 1.0f; inv = 1.0f;
+    }
+}
+// the maximum over an operand's partial maxima (1024 floats from ttts_amax_partials or a producer's `*_amax_out`; a weight
+// image carries one value); every lane of the wave gets it
+__device__ __forceinline__ float h3_partials_max(const float* __restrict__ partials, int n, int lane) {
+    float m = 0.f;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, partials[i]);
+    return wave_max(m);
+}
+__device__ __forceinline__ void h3_operand_scale(const float* __restrict__ partials, int n, int lane, float& scale, float& inv) {
+    h3_pow2_scale(h3_partials_max(partials, n, lane), scale, inv);
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

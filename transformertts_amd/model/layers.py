@@ -49,9 +49,9 @@ class MultiheadAttention(nn.Module):
     def self_attention(self, x: Tensor, lens: Tensor, causal: bool, residual: Tensor, out_drop: float) -> Tensor:
         """residual + drop(out_proj(attention(in_proj(x))))"""
         skip = ops.SkipToken() if residual is x else None      # the skip gradient rides in the in-projection's epilogue
-        qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias, skip_in=skip)
+        qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias, skip_in=skip, publish_amax=True)
         p = self._p()
-        ctx = ops.SelfAttentionFn.apply(qkv, lens, self.num_heads, causal, p, ops.seeds.next() if p > 0 else 0)
+        ctx = ops.self_attention(qkv, lens, self.num_heads, causal, p, ops.seeds.next() if p > 0 else 0)
         ctx._ttts_sole_consumer = True      # only the out-projection below reads it (see LinearFn.forward)
         return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, drop_p=out_drop,
                           seed=ops.seeds.next() if out_drop > 0 else 0, skip_out=skip)
@@ -60,11 +60,12 @@ class MultiheadAttention(nn.Module):
                         need_weights: bool = True):
         d = self.embed_dim
         skip = ops.SkipToken() if residual is x else None
-        q = ops.linear(x, ops.param_rows(self.in_proj_weight, 0, d), ops.param_rows(self.in_proj_bias, 0, d), skip_in=skip)
-        kv = ops.linear(mem, ops.param_rows(self.in_proj_weight, d, 3 * d), ops.param_rows(self.in_proj_bias, d, 3 * d))
+        q = ops.linear(x, ops.param_rows(self.in_proj_weight, 0, d), ops.param_rows(self.in_proj_bias, 0, d), skip_in=skip,
+                       publish_amax=True)
+        kv = ops.linear(mem, ops.param_rows(self.in_proj_weight, d, 3 * d), ops.param_rows(self.in_proj_bias, d, 3 * d),
+                        publish_amax=True)
         p = self._p()
-        ctx, attn = ops.CrossAttentionFn.apply(q, kv, mem_lens, self.num_heads, p, ops.seeds.next() if p > 0 else 0,
-                                               need_weights)
+        ctx, attn = ops.cross_attention(q, kv, mem_lens, self.num_heads, p, ops.seeds.next() if p > 0 else 0, need_weights)
         ctx._ttts_sole_consumer = True
         if not need_weights:
             attn = None
@@ -80,7 +81,7 @@ def _ffn_block(layer, x: Tensor, out_dropout: nn.Dropout) -> Tensor:
     po = out_dropout.p if layer.training else 0.0
     skip = ops.SkipToken()
     h = ops.linear(x, layer.linear1.weight, layer.linear1.bias, act=ops.ACT_RELU, drop_p=p,
-                   seed=ops.seeds.next() if p > 0 else 0, skip_in=skip)
+                   seed=ops.seeds.next() if p > 0 else 0, skip_in=skip, publish_amax=True)
     return ops.linear(h, layer.linear2.weight, layer.linear2.bias, residual=x, drop_p=po,
                       seed=ops.seeds.next() if po > 0 else 0, sole_consumer=True, skip_out=skip)   # h feeds nothing else
 

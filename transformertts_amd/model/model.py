@@ -59,7 +59,7 @@ class DecoderPreNet(nn.Module):
         p2 = self.dropout2.p if self.training else 0.0
         l1, l2 = self.linear1.linear, self.linear2.linear
         x = ops.linear(x, l1.weight, l1.bias, act=ops.ACT_RELU, drop_p=p1, seed=ops.seeds.next() if p1 > 0 else 0,
-                       row_shift=-1 if shift_right else 0, T=x.size(1))
+                       row_shift=-1 if shift_right else 0, T=x.size(1), publish_amax=True)
         return ops.linear(x, l2.weight, l2.bias, act=ops.ACT_RELU, drop_p=p2, seed=ops.seeds.next() if p2 > 0 else 0,
                           sole_consumer=True)
 
@@ -80,7 +80,7 @@ class PositionalEncoding(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         p = self.dropout.p if self.training else 0.0
-        return ops.PosEncFn.apply(x, self.pe, self.alpha, p, ops.seeds.next() if p > 0 else 0)
+        return ops.posenc(x, self.pe, self.alpha, p, ops.seeds.next() if p > 0 else 0)
 
 
 class PostNet(nn.Module):
@@ -175,7 +175,7 @@ class TransformerTTS(nn.Module):
         return src_kpm, tgt_kpm, tgt_mask
 
     def encode(self, phoneme: Tensor, phoneme_lens: Tensor) -> Tensor:
-        x = ops.EmbeddingFn.apply(phoneme, self.emb.weight)
+        x = ops.embedding(phoneme, self.emb.weight)
         x = self.pe(self.enc_prenet(x))
         return self.encoder(x, src_lens=phoneme_lens)
 
@@ -240,28 +240,34 @@ class TransformerTTS(nn.Module):
             layers = list(self.decoder.layers)
             H = layers[0].self_attn.num_heads
             # encoder memory K/V per layer, once; self-attention K/V caches (B, max_len, 2d) filled one row per step
-            mem_kv = [ops.linear(memory, ops.param_rows(l.multihead_attn.in_proj_weight, d, 3 * d), ops.param_rows(l.multihead_attn.in_proj_bias, d, 3 * d)) for l in layers]
+            mem_kv = [ops.linear(memory, ops.param_rows(l.multihead_attn.in_proj_weight, d, 3 * d),
+                                 ops.param_rows(l.multihead_attn.in_proj_bias, d, 3 * d), publish_amax=True) for l in layers]
             cache = [torch.zeros(B, max_len, 2 * d, device=dev) for _ in layers]
+            # running maxima of everything the self-attention in-projections have produced so far (the K/V caches hold a
+            # subset of it): the same zeroed slots are handed to every step's GEMM, whose atomic maxima accumulate
+            run_am = [ops._amax_slots(dev, True) for _ in layers]
             Tp = memory.size(1)
             for t in range(1, max_len):
                 x = self.dec_prenet(ys[:, t - 1:t].contiguous())
-                x = ops.PosEncFn.apply(x, self.pe.pe[t - 1:t], self.pe.alpha, 0.0, 0)
+                x = ops.posenc(x, self.pe.pe[t - 1:t], self.pe.alpha, 0.0, 0)
                 lens_t = torch.full((B,), t, dtype=torch.int64, device=dev)
-                for l, kvc, mkv in zip(layers, cache, mem_kv):
+                for l, kvc, mkv, ram in zip(layers, cache, mem_kv, run_am):
                     sa = l.self_attn
-                    qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)                    # (B,1,3d)
+                    qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias, publish_amax=ram)  # (B,1,3d)
                     kvc[:, t - 1] = qkv[:, 0, d:]
                     ctx, _, _ = ops._attn_fwd(ops._off(qkv, 0), ops._off(kvc, 0), ops._off(kvc, d), 3 * d, 2 * d, 2 * d, B, H,
-                                              1, max_len, lens_t, False, 0.0, 0, False)
+                                              1, max_len, lens_t, False, 0.0, 0, False, ram, ram, ram)
                     x = ops.layer_norm(ops.linear(ctx, sa.out_proj.weight, sa.out_proj.bias, residual=x),
                                        l.norm1.weight, l.norm1.bias, l.norm1.eps)
                     ca = l.multihead_attn
-                    q = ops.linear(x, ops.param_rows(ca.in_proj_weight, 0, d), ops.param_rows(ca.in_proj_bias, 0, d))
+                    q = ops.linear(x, ops.param_rows(ca.in_proj_weight, 0, d), ops.param_rows(ca.in_proj_bias, 0, d),
+                                   publish_amax=True)
+                    mkv_am = ops._amax(mkv)
                     ctx, _, _ = ops._attn_fwd(ops._off(q, 0), ops._off(mkv, 0), ops._off(mkv, d), d, 2 * d, 2 * d, B, H, 1, Tp,
-                                              phoneme_lens, False, 0.0, 0, False)
+                                              phoneme_lens, False, 0.0, 0, False, ops._amax(q), mkv_am, mkv_am)
                     x = ops.layer_norm(ops.linear(ctx, ca.out_proj.weight, ca.out_proj.bias, residual=x),
                                        l.norm2.weight, l.norm2.bias, l.norm2.eps)
-                    hdn = ops.linear(x, l.linear1.weight, l.linear1.bias, act=ops.ACT_RELU)
+                    hdn = ops.linear(x, l.linear1.weight, l.linear1.bias, act=ops.ACT_RELU, publish_amax=True)
                     x = ops.layer_norm(ops.linear(hdn, l.linear2.weight, l.linear2.bias, residual=x),
                                        l.norm3.weight, l.norm3.bias, l.norm3.eps)
                 mel, stop = ops.HeadsFn.apply(x, *heads)

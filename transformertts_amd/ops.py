@@ -128,9 +128,9 @@ ATTN_MODE = os.environ.get("TTTS_ATTN_MODE", GEMM_MODE)       # attention produc
 ATTN_FWD_MODE = os.environ.get("TTTS_ATTN_FWD_MODE", "h3" if ATTN_MODE == "x6" else ATTN_MODE)   # forward: "h3", "x6", "f32"
 ATTN_BWD_MODE = os.environ.get("TTTS_ATTN_BWD_MODE", "h3" if ATTN_MODE == "x6" else ATTN_MODE)   # backward: "h3", "x6", "f32"
 WGRAD_MODE = os.environ.get("TTTS_WGRAD_MODE", "h3" if GEMM_MODE == "x6" else GEMM_MODE)   # weight gradients: "h3", "x6", "f32"
-# Forward GEMMs (nn.Linear / Conv1d forward) under GEMM_MODE "x6": "h3" = fp16x3 split (three f16 MFMA terms on operands
-# pre-scaled into f16's range: O(1) activations, O(1/sqrt(fan_in)) weights; csrc/gemm_h3.hip), "x6" = bf16x6 as the
-# gradients use.  Shapes the fp16 kernel cannot take (K or channels not a multiple of 32) go to bf16x6.
+# Forward GEMMs (nn.Linear / Conv1d forward) under GEMM_MODE "x6": "h3" = fp16x3 split (three f16 MFMA terms, both operands
+# pre-scaled by powers of two taken from their MEASURED maxima, csrc/gemm_h3.hip -- no magnitude window), "x6" = bf16x6.
+# Shapes the fp16 kernel cannot take (K or channels not a multiple of 32) go to bf16x6.
 FWD_MODE = os.environ.get("TTTS_FWD_MODE", "h3")
 
 
@@ -153,15 +153,19 @@ def _amax(t: torch.Tensor) -> torch.Tensor:
     ready = getattr(t, "_ttts_amax", None)
     if ready is not None:
         return ready
+    if not t.is_contiguous():
+        t = t.contiguous()
     out = torch.empty(1024, dtype=torch.float32, device=t.device)
     _lib.check(_lib.load().ttts_amax_partials(_p(t), t.numel(), _p(out), _stream()), "ttts_amax_partials")
     return out
 
 
 class _AmaxArena:
-    """Per-device pool of 1024-float partial-maxima arrays that ONE memset zeroes for a whole backward pass.  ~20 kernels
-    of a backward pass fill such an array with atomic maxima and each would otherwise need a memset of its own."""
-    SLICES = 64
+    """Per-device pool of 1024-float partial-maxima arrays that ONE memset zeroes for a whole training step.  ~150 kernels
+    of a step (every producer of an fp16x3 operand: GEMM epilogues, LayerNorm, BatchNorm, positional encoding, attention,
+    the backward masks) fill such an array with atomic maxima and each would otherwise need a memset of its own.  Slices
+    are handed out in call order and stay valid until the next reset (a forward's maxima are read again in backward)."""
+    SLICES = 512
 
     def __init__(self, device):
         self.buf = torch.empty(self.SLICES, 1024, dtype=torch.float32, device=device)
@@ -183,7 +187,7 @@ _amax_arenas = {}
 
 
 def amax_arena_reset(device) -> None:
-    """Call once per step in front of backward (step.TrainStep does)."""
+    """Call once at the start of a step (step.TrainStep does); everything handed out before is dead by then."""
     arena = _amax_arenas.get(device)
     if arena is None:
         arena = _amax_arenas[device] = _AmaxArena(device)
@@ -191,7 +195,7 @@ def amax_arena_reset(device) -> None:
 
 
 def amax_arena_release(device) -> None:
-    """After backward: arrays handed out from here on are zeroed individually again."""
+    """At the end of the step: arrays handed out from here on are zeroed individually again."""
     arena = _amax_arenas.get(device)
     if arena is not None:
         arena.clean = False
@@ -214,50 +218,66 @@ def _amax_slots(device, zero: bool) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------------------------- deferred reductions
 # The parameter-gradient kernels end in a small reduction of their partials into the gradient sink.  With sinks (the
-# results are not read before the pass ends) those ~90 launches are queued in the library and run as two at the end of
-# the backward pass: the first deferring backward node registers a final callback with the autograd engine.
+# results are not read before the pass ends) those ~90 launches are appended to a queue that belongs to the gradient
+# bucket (`parallel.FlatGradBucket.queue`, a caller-owned `ttts_reduce_queue` of the C ABI) and run as two launches when
+# the queue is flushed: at the end of the backward pass (the first deferring node of a pass registers a final callback with
+# the autograd engine, so `p.grad` is complete when `backward()` returns -- Lightning clips gradients right there), and
+# again, defensively, before a collective over the bucket and before the optimizer reads it.  Nothing is process-global:
+# the queue and its "callback registered" flag belong to the bucket, and `FlatGradBucket.zero()` drops whatever a backward
+# pass that raised (its callback never ran) left behind.
 DEFER_REDUCE = os.environ.get("TTTS_DEFER_REDUCE", "1") == "1"
-_defer_armed = False
-_defer_keep: list = []           # workspaces the queued reductions still read
 
 
-def _defer(acc: int, ws: torch.Tensor) -> int:
-    """`accumulate` argument for a parameter-gradient entry point writing into sinks: adds the "may defer" bit and keeps
-    `ws` alive until the flush.  Only called from backward nodes (the engine's final-callback queue is open there)."""
-    global _defer_armed
-    if not DEFER_REDUCE:
-        return acc
-    if not _defer_armed:
-        _lib.check(_lib.load().ttts_reduce_defer_begin(), "ttts_reduce_defer_begin")
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred_final)
-        _defer_armed = True
-    _defer_keep.append(ws)
-    return acc | 2
+class ReduceQueue:
+    """Host-side queue of deferred second-stage reductions (include/ttts_hip.h, ttts_reduce_queue) plus the workspaces
+    the queued reductions still read."""
+
+    def __init__(self):
+        self._lib = _lib.load()
+        self.handle = c_void_p(self._lib.ttts_reduce_queue_create())
+        if not self.handle:
+            raise MemoryError("ttts_reduce_queue_create failed")
+        self.keep: list = []
+        self._armed = False         # a final callback of the running backward pass will flush
+
+    def arg(self, ws: torch.Tensor):
+        """`queue` argument for an entry point whose reduction may wait for the flush; keeps `ws` alive until then.
+        Called from backward nodes only (the engine's final-callback queue is open there)."""
+        if not self._armed:
+            torch.autograd.Variable._execution_engine.queue_callback(self._final)
+            self._armed = True
+        self.keep.append(ws)
+        return self.handle
+
+    def _final(self) -> None:
+        self._armed = False
+        self.flush()
+
+    def pending(self) -> int:
+        return int(self._lib.ttts_reduce_queue_pending(self.handle))
+
+    def flush(self) -> None:
+        """Run every queued reduction now, on the current stream."""
+        if self.keep or self.pending():
+            _lib.check(self._lib.ttts_reduce_queue_flush(self.handle, _stream()), "ttts_reduce_queue_flush")
+            self.keep.clear()
+
+    def clear(self) -> None:
+        _lib.check(self._lib.ttts_reduce_queue_clear(self.handle), "ttts_reduce_queue_clear")
+        self.keep.clear()
+        self._armed = False
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.ttts_reduce_queue_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
-def flush_deferred(final: bool = False) -> None:
-    """Run every queued reduction now (on the current stream).  Mid-pass (`final` False: e.g. before a collective over the
-    gradients finished so far) the pass keeps deferring afterwards."""
-    global _defer_armed
-    if not _defer_armed:
-        return
-    if final:
-        _defer_armed = False
-    _lib.check(_lib.load().ttts_reduce_defer_flush(0 if final else 1, _stream()), "ttts_reduce_defer_flush")
-    _defer_keep.clear()
-
-
-def _flush_deferred_final() -> None:
-    flush_deferred(True)
-
-
-def abort_deferred() -> None:
-    """Drop whatever an interrupted backward pass left queued (its final callback never ran)."""
-    global _defer_armed
-    if _defer_armed or _defer_keep:
-        _lib.check(_lib.load().ttts_reduce_defer_abort(), "ttts_reduce_defer_abort")
-        _defer_armed = False
-        _defer_keep.clear()
+def _qarg(queue: Optional[ReduceQueue], ws: torch.Tensor):
+    return queue.arg(ws) if (queue is not None and DEFER_REDUCE) else None
 
 
 def _wgrad_is_split(N: int, K: int) -> bool:
@@ -266,22 +286,24 @@ def _wgrad_is_split(N: int, K: int) -> bool:
     return (N >= 128 or N in (80, 96)) and (K >= 128 or K in (80, 96)) and (N >= 128 or K >= 128)
 
 
-def _attn_bwd(lib, do, dq_am, dkv_am, *args):
+def _attn_bwd(lib, do, dq_am, dkv_am, q_am, k_am, v_am, *args):
     """Attention backward in the configured form; `args` = every C-ABI argument up to step_seed.  dq_am / dkv_am: zeroed
-    1024-slot arrays in which the fp16x3 kernels leave max|dq| / max|dk, dv| (the in-projection gradients consume them)."""
+    1024-slot arrays in which the fp16x3 kernels leave max|dq| / max|dk, dv| (the in-projection gradients consume them);
+    q_am / k_am / v_am: the partial maxima of the forward operands (their dynamic pre-scales)."""
     if ATTN_BWD_MODE == "h3":
-        return lib.ttts_attention_bwd_h3(*args, _p(_amax(do)), _p(dq_am), _p(dkv_am), _stream())
+        return lib.ttts_attention_bwd_h3(*args, _p(_amax(do)), _p(dq_am), _p(dkv_am), _p(q_am), _p(k_am), _p(v_am), _stream())
     return (lib.ttts_attention_bwd_x6 if ATTN_BWD_MODE == "x6" else lib.ttts_attention_bwd)(*args, _stream())
 
 
-def _wgrad(lib, name: str, dy: torch.Tensor, amax, split_ok: bool, *args):
-    """Weight-gradient entry point `name` in the configured form; `args` = everything after (dy ...) up to `accumulate`.
-    The fp16x3 form takes the partial maxima of |dy| (computed here unless the caller already has them); shapes the split
-    kernels do not take (`split_ok` False) run on the fp32-MFMA kernel behind the _x6 entry point and need none."""
+def _wgrad(lib, name: str, dy: torch.Tensor, amax, x: torch.Tensor, x_amax, split_ok: bool, queue, *args):
+    """Weight-gradient entry point `name` in the configured form; `args` = everything between (dy, x) and `queue`.
+    The fp16x3 form takes the partial maxima of |dy| and |x| (computed here unless the caller already has them); shapes
+    the split kernels do not take (`split_ok` False) run on the fp32-MFMA kernel behind the _x6 entry point and need none."""
     if WGRAD_MODE == "h3" and split_ok:
         am = amax if amax is not None else _amax(dy)
-        return getattr(lib, name + "_h3")(_p(dy), *args, _p(am), _stream())
-    return getattr(lib, name + ("_x6" if WGRAD_MODE in ("x6", "h3") else ""))(_p(dy), *args, _stream())
+        xm = x_amax if x_amax is not None else _amax(x)
+        return getattr(lib, name + "_h3")(_p(dy), _p(x), *args, _p(am), _p(xm), queue, _stream())
+    return getattr(lib, name + ("_x6" if WGRAD_MODE in ("x6", "h3") else ""))(_p(dy), _p(x), *args, queue, _stream())
 
 
 _param_epoch = 0
@@ -300,39 +322,96 @@ class _PlaneEntry:
 
 _BATCHED_SPLIT = os.environ.get("TTTS_BATCHED_SPLIT", "1") == "1"
 _plane_entries: list = []        # every (weight, mode) split so far, for the one-launch refresh after an optimizer step
-_plane_table = None              # (signature, device descriptor table, pinned host copy, total blocks)
+_plane_tables: dict = {}         # flat-storage address -> (signature, device descriptor table, pinned host copy, total blocks)
 
 
-def _refresh_all_planes() -> None:
-    """Re-split every registered weight whose storage and version are unchanged (only the parameter epoch moved, i.e. an
-    optimizer stepped through raw pointers) with ONE launch instead of one per weight and mode."""
-    global _plane_table, _plane_entries
-    live, sig = [], []
+def _refresh_all_planes(storage: int) -> None:
+    """Re-split every registered weight that lives in the flat parameter storage at address `storage` (one model under
+    one FlatAdam) and whose storage and version are unchanged (only the parameter epoch moved, i.e. an optimizer stepped
+    through raw pointers) with ONE launch instead of one per weight and mode.  Weights of other models are left alone:
+    their owners may be using them on another stream."""
+    global _plane_entries
+    live, mine, sig = [], [], []
     for e in _plane_entries:
         w = e.wref()
         if w is None:
             continue
         live.append(e)
+        if w.untyped_storage().data_ptr() != storage:
+            continue
+        mine.append(e)
         if e.tag[0] == w._version and e.tag[1] == w.data_ptr() + e.off and e.tag[2] != _param_epoch:
             sig.append((e.tag[1], e.planes.data_ptr(), e.rows, e.cols, e.mode, e.c2, e.taps))
     _plane_entries = live
+    for k in [k for k in _plane_tables if not any(e.wref() is not None and e.wref().untyped_storage().data_ptr() == k for e in live)]:
+        del _plane_tables[k]
     if not sig:
         return
     sig_t = tuple(sig)
-    if _plane_table is None or _plane_table[0] != sig_t:
+    table = _plane_tables.get(storage)
+    if table is None or table[0] != sig_t:
         rows, blk = [], 0
         for s in sig:
             rows.append(list(s) + [blk])
             blk += (s[2] * s[3] + 255) // 256
         host = torch.tensor(rows, dtype=torch.int64).pin_memory()      # page-locked: the upload does not synchronise
-        _plane_table = (sig_t, host.to(live[0].planes.device, non_blocking=True), host, blk)
+        table = _plane_tables[storage] = (sig_t, host.to(mine[0].planes.device, non_blocking=True), host, blk)
     lib = _lib.load()
-    _lib.check(lib.ttts_weight_split_batched(_p(_plane_table[1]), len(sig), _plane_table[3], _stream()),
-               "ttts_weight_split_batched")
+    _lib.check(lib.ttts_weight_split_batched(_p(table[1]), len(sig), table[3], _stream()), "ttts_weight_split_batched")
     refreshed = {s[1] for s in sig}
-    for e in live:
+    for e in mine:
         if e.planes.data_ptr() in refreshed:
             e.tag = (e.tag[0], e.tag[1], _param_epoch)
+
+
+class PlaneTable:
+    """Every weight-plane image of ONE module's parameters and the descriptor table of their batched refresh.
+
+    `step.TrainStep` owns one: it refreshes the planes explicitly at the start of a step (one launch sequence, recorded in
+    the step's HIP graph) instead of relying on the lazy, process-wide refresh of `_planes`.  The table tensor, its pinned
+    host copy and (through the entries) the plane buffers are referenced from here, so a captured graph that reads them
+    stays valid for as long as its TrainStep lives, whatever other models in the process do."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.entries = []
+        seen = set()
+        for prm in module.parameters():
+            for ent in (getattr(prm, "_ttts_planes", None) or {}).values():
+                if id(ent) not in seen:
+                    seen.add(id(ent))
+                    self.entries.append((prm, ent))
+        if not self.entries:
+            raise RuntimeError("PlaneTable: the module has no weight planes yet (run one forward + backward first)")
+        rows, blk = [], 0
+        self.sig = []
+        for prm, e in self.entries:
+            src = prm.data_ptr() + e.off
+            self.sig.append((src, e.planes.data_ptr(), prm._version))
+            rows.append([src, e.planes.data_ptr(), e.rows, e.cols, e.mode, e.c2, e.taps, blk])
+            blk += (e.rows * e.cols + 255) // 256
+        self.blocks = blk
+        self.host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+        self.dev = self.host.to(self.entries[0][1].planes.device, non_blocking=True)
+
+    def valid(self) -> bool:
+        """The parameters still live where the table says (no `.to()`, no re-allocated planes, no in-place autograd edit)."""
+        return all((prm.data_ptr() + e.off, e.planes.data_ptr(), prm._version) == sg
+                   for (prm, e), sg in zip(self.entries, self.sig))
+
+    def stale(self) -> bool:
+        return any(e.tag[2] != _param_epoch for _, e in self.entries)
+
+    def refresh(self) -> None:
+        """Re-split every weight of the module with one batched launch sequence and mark the planes current."""
+        _lib.check(_lib.load().ttts_weight_split_batched(_p(self.dev), len(self.entries), self.blocks, _stream()),
+                   "ttts_weight_split_batched")
+        for prm, e in self.entries:
+            e.tag = (prm._version, prm.data_ptr() + e.off, _param_epoch)
+
+    def mark_stale(self) -> None:
+        """After a capture: the recorded refresh has not run, so the host must not believe the planes are current."""
+        for _, e in self.entries:
+            e.tag = (e.tag[0], e.tag[1], -1)
 
 
 def _planes(w: torch.Tensor, mode: int, rows: int, cols: int, c2: int = 0, taps: int = 0) -> torch.Tensor:
@@ -349,12 +428,15 @@ def _planes(w: torch.Tensor, mode: int, rows: int, cols: int, c2: int = 0, taps:
     if ent is not None:
         if ent.tag == tag:
             return ent.planes
-        if _BATCHED_SPLIT and ent.tag[0] == tag[0] and ent.tag[1] == tag[1]:   # only the epoch moved: refresh everything at once
-            _refresh_all_planes()
+        if _BATCHED_SPLIT and ent.tag[0] == tag[0] and ent.tag[1] == tag[1] and not torch.cuda.is_current_stream_capturing():
+            _refresh_all_planes(holder.untyped_storage().data_ptr())   # only the epoch moved: refresh this model at once (never inside a capture:
+            #                                       the process-wide table is not owned by the graph, see PlaneTable)
             if ent.tag == tag:
                 return ent.planes
     lib = _lib.load()
     if ent is None or ent.planes.numel() != 3 * rows * cols or ent.planes.device != w.device:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("weight planes must exist before a HIP-graph capture: run the eager warm-up steps first")
         planes = torch.empty(3 * rows * cols, dtype=torch.int16, device=w.device)
     else:
         planes = ent.planes
@@ -400,6 +482,7 @@ def param_rows(p: torch.Tensor, r0: int, r1: int) -> torch.Tensor:
     sk = _sink(p)
     if sk is not None:
         v._ttts_grad_sink = sk[r0:r1]
+        v._ttts_reduce_queue = getattr(p, "_ttts_reduce_queue", None)
     if p.dim() == 2:
         v._ttts_planes_owner = (p, r0)
     return v
@@ -413,12 +496,15 @@ def _sink(t: Optional[torch.Tensor]):
 
 
 def _sinks(*params):
-    """(list of destinations or None, accumulate flag): sinks are used only if all given parameters have one."""
+    """(list of destinations or None, accumulate flag, reduction queue or None): sinks are used only if all given
+    parameters have one; the queue is the one their bucket attached (`_ttts_reduce_queue`), when they share it."""
     live = [p for p in params if p is not None]
     sk = [_sink(p) for p in live]
     if live and all(x is not None for x in sk):
-        return [(_sink(p) if p is not None else None) for p in params], 1
-    return None, 0
+        qs = {id(getattr(p, "_ttts_reduce_queue", None)) for p in live}
+        q = getattr(live[0], "_ttts_reduce_queue", None) if len(qs) == 1 else None
+        return [(_sink(p) if p is not None else None) for p in params], 1, q
+    return None, 0, None
 
 
 # ----------------------------------------------------------------------------------------------- linear
@@ -427,7 +513,9 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out=None, tok_in=None, skip_in=None,
-                skip_out=None, tok_drop=None):
+                skip_out=None, tok_drop=None, x_amax=None, y_amax=None):
+        """x_amax: partial maxima of |x| (fp16x3 forms; None: measured here); y_amax: None, or a zeroed 1024-slot array
+        that receives max|y| (the wrapper attaches it to y for the next fp16x3 consumer)."""
         lib = _lib.load()
         x = _chk(x, "linear.x")
         w = _chk(w, "linear.weight")
@@ -443,8 +531,11 @@ class LinearFn(torch.autograd.Function):
         if r_ is not None and r_.shape != y.shape:
             raise ValueError("linear: residual shape mismatch")
         if _fwd_h3(K, N):
+            if x_amax is None:
+                x_amax = _amax(x)
             _lib.check(lib.ttts_linear_fwd_h3(_p(x), _p(_planes(w, 4, N, K)), _p(b_), _p(r_), _p(y), M, N, K, act,
-                                              float(drop_p), seed, _ss(), row_shift, T, _stream()), "ttts_linear_fwd_h3")
+                                              float(drop_p), seed, _ss(), row_shift, T, _p(x_amax), _p(y_amax), _stream()),
+                       "ttts_linear_fwd_h3")
         elif GEMM_MODE == "x6":
             _lib.check(lib.ttts_linear_fwd_x6(_p(x), _p(_planes(w, 0, N, K)), _p(b_), _p(r_), _p(y), M, N, K, act,
                                               float(drop_p), seed, _ss(), row_shift, T, _stream()), "ttts_linear_fwd_x6")
@@ -454,6 +545,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
         ctx.cfg = (act, float(drop_p), seed, row_shift, T, b is not None, residual is not None)
         ctx.sinks = _sinks(w, b)
+        ctx.x_amax = x_amax         # the weight gradient reads x again (same pre-scale)
         ctx.ss = _ss()              # backward regenerates the dropout mask under the step-state word of ITS forward
         ctx.toks = (tok_out, tok_in, skip_in, skip_out)
         ctx.tok_drop = tok_drop
@@ -527,19 +619,18 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             nbytes = lib.ttts_wgrad_workspace_bytes(M, N, K, 1)
             ws = _ws(nbytes, x.device)
-            sk, acc = ctx.sinks
+            sk, acc, queue = ctx.sinks
             if sk is not None:
                 dw_t, db_t = sk
-                acc = _defer(acc, ws)
             else:
                 dw_t = dw = torch.empty_like(w)
                 db_t = db = torch.empty(N, dtype=torch.float32, device=x.device) if has_b else None
-            _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dacc, am, _wgrad_is_split(N, K), _p(x), _p(dw_t), _p(db_t), _p(ws),
-                              ws.numel() * 4, M, N, K, row_shift, T, acc), "ttts_linear_bwd_weight")
+            _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dacc, am, x, ctx.x_amax, _wgrad_is_split(N, K), _qarg(queue, ws),
+                              _p(dw_t), _p(db_t), _p(ws), ws.numel() * 4, M, N, K, row_shift, T, acc), "ttts_linear_bwd_weight")
         dres = dy if has_r else None
         if has_r and skip_out is not None:      # hand the skip gradient to the block's first Linear instead of autograd
             skip_out.grad, dres = dy, None
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 # Test seam: called with the output of every relu-epilogue Linear, in call order (which units the HIP path gated off).
@@ -578,11 +669,20 @@ class SkipToken:
 
 
 def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_shift=0, T=0, sole_consumer=False,
-           skip_in=None, skip_out=None):
+           skip_in=None, skip_out=None, publish_amax=False):
     """`sole_consumer=True` is the caller's promise that nothing but this Linear reads `x`; if `x` came out of a
     relu(+dropout) Linear, its backward mask is then fused into this Linear's data-gradient epilogue.
-    `skip_in` / `skip_out`: see SkipToken."""
+    `skip_in` / `skip_out`: see SkipToken.
+    `publish_amax`: the output feeds another fp16x3 GEMM / attention kernel, so the epilogue leaves its partial maxima on
+    it (`y._ttts_amax`) and that consumer needs no pass of its own over y.  True, or a zeroed 1024-float array to add the
+    maxima to (a running maximum over several calls: the K/V cache of `inference`)."""
     grad_on = torch.is_grad_enabled()
+    N, K = w.shape
+    h3 = x.is_cuda and _fwd_h3(K, N)
+    x_am = _amax(x) if h3 else None
+    y_am = None
+    if h3 and publish_amax is not False and publish_amax is not None:
+        y_am = publish_amax if isinstance(publish_amax, torch.Tensor) else _amax_slots(x.device, True)
     tok_in = getattr(x, "_ttts_relu_token", None) if (sole_consumer and grad_on) else None
     tok_out = _ReluToken(1.0 / (1.0 - float(drop_p))) if act == ACT_RELU else None
     if not (grad_on and x.requires_grad):
@@ -592,7 +692,10 @@ def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_sh
     tok_drop = None
     if grad_on and act == ACT_NONE and float(drop_p) > 0.0 and residual is not None and x.is_cuda:
         tok_drop = _DropToken(float(drop_p), seed, _ss())
-    y = LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out, tok_in, skip_in, skip_out, tok_drop)
+    y = LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out, tok_in, skip_in, skip_out, tok_drop,
+                       x_am, y_am)
+    if y_am is not None:
+        y._ttts_amax = y_am
     if tok_drop is not None:
         y._ttts_drop_token = tok_drop           # picked up by layer_norm(y, ..., sole_consumer=True)
     if tok_out is not None:
@@ -615,9 +718,11 @@ class HeadsFn(torch.autograd.Function):
         mel = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
         stop = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
         w_mel = _chk(w_mel, "w_mel")
+        x_amax = None
         if _fwd_h3(K, N):
+            x_amax = _amax(x)
             _lib.check(lib.ttts_linear_fwd_h3(_p(x), _p(_planes(w_mel, 4, N, K)), _p(b_mel), None, _p(mel), M, N, K,
-                                              ACT_NONE, 0.0, 0, None, 0, 0, _stream()), "ttts_linear_fwd_h3")
+                                              ACT_NONE, 0.0, 0, None, 0, 0, _p(x_amax), None, _stream()), "ttts_linear_fwd_h3")
         elif GEMM_MODE == "x6":
             _lib.check(lib.ttts_linear_fwd_x6(_p(x), _p(_planes(w_mel, 0, N, K)), _p(b_mel), None, _p(mel), M, N, K,
                                               ACT_NONE, 0.0, 0, None, 0, 0, _stream()), "ttts_linear_fwd_x6")
@@ -628,6 +733,7 @@ class HeadsFn(torch.autograd.Function):
                    "ttts_rowdot_fwd")
         ctx.save_for_backward(x, w_mel, w_stop)
         ctx.sinks = _sinks(w_mel, b_mel, w_stop, b_stop)
+        ctx.x_amax = x_amax
         return mel, stop
 
     @staticmethod
@@ -647,21 +753,20 @@ class HeadsFn(torch.autograd.Function):
             _lib.check(lib.ttts_linear_bwd_data(_p(dmel), _p(w_mel), None, _p(dx), M, N, K, None, 1.0, _stream()),
                        "ttts_linear_bwd_data")
         ws = _ws(lib.ttts_wgrad_workspace_bytes(M, N, K, 1), x.device)
-        sk, acc = ctx.sinks
+        sk, acc, queue = ctx.sinks
         ws2 = _ws(lib.ttts_rowdot_bwd_workspace_bytes(K), x.device)
         if sk is not None:
             t_wm, t_bm, t_ws, t_bs = sk
             dw_mel = db_mel = dw_stop = db_stop = None
-            acc = _defer(_defer(acc, ws), ws2)
         else:
             t_wm = dw_mel = torch.empty_like(w_mel)
             t_bm = db_mel = torch.empty(N, dtype=torch.float32, device=x.device)
             t_ws = dw_stop = torch.empty_like(w_stop)
             t_bs = db_stop = torch.empty(1, dtype=torch.float32, device=x.device)
-        _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dmel, None, _wgrad_is_split(N, K), _p(x), _p(t_wm), _p(t_bm), _p(ws),
-                          ws.numel() * 4, M, N, K, 0, 0, acc), "ttts_linear_bwd_weight")
+        _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dmel, None, x, ctx.x_amax, _wgrad_is_split(N, K), _qarg(queue, ws),
+                          _p(t_wm), _p(t_bm), _p(ws), ws.numel() * 4, M, N, K, 0, 0, acc), "ttts_linear_bwd_weight")
         _lib.check(lib.ttts_rowdot_bwd(_p(dstop), _p(x), _p(w_stop), _p(dx), _p(t_ws), _p(t_bs), _p(ws2),
-                                       ws2.numel() * 4, M, K, acc, _stream()), "ttts_rowdot_bwd")
+                                       ws2.numel() * 4, M, K, acc, _qarg(queue, ws2), _stream()), "ttts_rowdot_bwd")
         return dx, dw_mel, db_mel, dw_stop, db_stop
 
 
@@ -671,7 +776,7 @@ class ConvBNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act,
-                drop_p, seed):
+                drop_p, seed, x_amax=None, z_amax=None):
         lib = _lib.load()
         x = _chk(x, "conv_bn.x")
         B, T, cin = x.shape
@@ -682,8 +787,10 @@ class ConvBNFn(torch.autograd.Function):
         conv_w = _chk(conv_w, "conv.weight")
         y = torch.empty(B, T, cout, dtype=torch.float32, device=dev)
         if _fwd_h3(taps * cin, cout, cin):
+            if x_amax is None:
+                x_amax = _amax(x)
             _lib.check(lib.ttts_conv1d_fwd_h3(_p(x), _p(_planes(conv_w, 6, cout, taps * cin, cin, taps)), _p(conv_b), _p(y),
-                                              B, T, cin, cout, taps, _stream()), "ttts_conv1d_fwd_h3")
+                                              B, T, cin, cout, taps, _p(x_amax), _stream()), "ttts_conv1d_fwd_h3")
         elif GEMM_MODE == "x6":
             _lib.check(lib.ttts_conv1d_fwd_x6(_p(x), _p(_planes(conv_w, 2, cout, taps * cin, cin, taps)), _p(conv_b), _p(y),
                                               B, T, cin, cout, taps, _stream()), "ttts_conv1d_fwd_x6")
@@ -706,8 +813,9 @@ class ConvBNFn(torch.autograd.Function):
                                               _stream()), "ttts_bn_eval_stats")
         z = torch.empty_like(y)
         _lib.check(lib.ttts_bn_apply_fwd(_p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(z), M, cout, act,
-                                         float(drop_p), seed, _ss(), _stream()), "ttts_bn_apply_fwd")
+                                         float(drop_p), seed, _ss(), _p(z_amax), _stream()), "ttts_bn_apply_fwd")
         ctx.save_for_backward(x, conv_w, y, mean, invstd, gamma, beta)
+        ctx.x_amax = x_amax
         ctx.cfg = (training, act, float(drop_p), seed, conv_b is not None)
         ctx.ss = _ss()
         ctx.sinks = _sinks(conv_w, conv_b, gamma, beta)
@@ -726,7 +834,7 @@ class ConvBNFn(torch.autograd.Function):
         M = B * T
         dz = _chk(dz, "conv_bn.dz")
         dy = torch.empty_like(y)
-        sk, acc = ctx.sinks
+        sk, acc, queue = ctx.sinks
         dw = db = dgamma = dbeta = None
         if sk is not None:
             t_w, t_b, t_g, t_be = sk
@@ -759,22 +867,29 @@ class ConvBNFn(torch.autograd.Function):
                 _lib.check(lib.ttts_conv1d_bwd_data(_p(dy), _p(w_bwd), _p(dx), B, T, cin, cout, taps, _stream()),
                            "ttts_conv1d_bwd_data")
         ws2 = _ws(lib.ttts_wgrad_workspace_bytes(M, cout, cin, taps), dev)
-        _lib.check(_wgrad(lib, "ttts_conv1d_bwd_weight", dy, am, _wgrad_is_split(cout, cin), _p(x), _p(t_w), _p(t_b), _p(ws2),
-                          ws2.numel() * 4, B, T, cin, cout, taps, _defer(acc, ws2) if sk is not None else acc),
-                   "ttts_conv1d_bwd_weight")
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        _lib.check(_wgrad(lib, "ttts_conv1d_bwd_weight", dy, am, x, ctx.x_amax, _wgrad_is_split(cout, cin),
+                          _qarg(queue, ws2) if sk is not None else None, _p(t_w), _p(t_b), _p(ws2), ws2.numel() * 4, B, T, cin,
+                          cout, taps, acc), "ttts_conv1d_bwd_weight")
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn(x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum=0.1, eps=1e-5,
-            act=ACT_NONE, drop_p=0.0, seed=0):
-    return ConvBNFn.apply(x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act,
-                          drop_p, seed)
+            act=ACT_NONE, drop_p=0.0, seed=0, publish_amax=True):
+    """`publish_amax`: leave the partial maxima of the output on it (`z._ttts_amax`) for the fp16x3 GEMM that reads it."""
+    cout, cin, taps = conv_w.shape
+    x_am = _amax(x) if (x.is_cuda and _fwd_h3(taps * cin, cout, cin)) else None
+    z_am = _amax_slots(x.device, True) if (publish_amax and x.is_cuda) else None
+    z = ConvBNFn.apply(x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act,
+                       drop_p, seed, x_am, z_am)
+    if z_am is not None:
+        z._ttts_amax = z_am
+    return z
 
 
 # ----------------------------------------------------------------------------------------------- layer norm
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, tok_drop=None):
+    def forward(ctx, x, gamma, beta, eps, tok_drop=None, y_amax=None):
         lib = _lib.load()
         ctx.tok_drop = tok_drop
         x = _chk(x, "layernorm.x")
@@ -784,7 +899,7 @@ class LayerNormFn(torch.autograd.Function):
         mean = torch.empty(M, dtype=torch.float32, device=x.device)
         rstd = torch.empty(M, dtype=torch.float32, device=x.device)
         _lib.check(lib.ttts_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, d, float(eps),
-                                          _stream()), "ttts_layernorm_fwd")
+                                          _p(y_amax), _stream()), "ttts_layernorm_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.sinks = _sinks(gamma, beta)
         return y
@@ -797,7 +912,7 @@ class LayerNormFn(torch.autograd.Function):
         M = x.numel() // d
         dy = _chk(dy, "layernorm.dy")
         dx = torch.empty_like(x)
-        sk, acc = ctx.sinks
+        sk, acc, queue = ctx.sinks
         dgamma = dbeta = None
         if sk is not None:
             t_g, t_b = sk
@@ -805,40 +920,58 @@ class LayerNormFn(torch.autograd.Function):
             t_g = dgamma = torch.empty_like(gamma)
             t_b = dbeta = torch.empty_like(gamma)
         ws = _ws(lib.ttts_layernorm_bwd_workspace_bytes(d), x.device)
-        accf = _defer(acc, ws) if sk is not None else acc
+        qa = _qarg(queue, ws) if sk is not None else None
         td = ctx.tok_drop
         if td is not None and d in (256, 512, 1024):
             # x is the output of a Linear with residual dropout and feeds nothing but this LayerNorm: dx is that Linear's dy
             dacc = torch.empty_like(x)
             am = _amax_slots(x.device, True)
             _lib.check(lib.ttts_layernorm_bwd_drop(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(t_g), _p(t_b),
-                                                   _p(ws), ws.numel() * 4, M, d, accf, _p(dacc), td.p, td.seed, td.ss, _p(am),
+                                                   _p(ws), ws.numel() * 4, M, d, acc, _p(dacc), td.p, td.seed, td.ss, _p(am), qa,
                                                    _stream()), "ttts_layernorm_bwd_drop")
             td.dx, td.dacc, td.amax = dx, dacc, am
         else:
             _lib.check(lib.ttts_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(t_g), _p(t_b),
-                                              _p(ws), ws.numel() * 4, M, d, accf, _stream()), "ttts_layernorm_bwd")
-        return dx, dgamma, dbeta, None, None
+                                              _p(ws), ws.numel() * 4, M, d, acc, qa, _stream()), "ttts_layernorm_bwd")
+        return dx, dgamma, dbeta, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps=1e-5, sole_consumer=False):
+def layer_norm(x, gamma, beta, eps=1e-5, sole_consumer=False, publish_amax=True):
     """`sole_consumer=True` is the caller's promise that nothing but this LayerNorm reads `x`; if `x` came out of a Linear
-    with a residual-dropout epilogue, that Linear's dropout backward is then written by this LayerNorm's backward kernel."""
+    with a residual-dropout epilogue, that Linear's dropout backward is then written by this LayerNorm's backward kernel.
+    `publish_amax`: leave the partial maxima of the output on it for the fp16x3 GEMMs that read it."""
     tok = getattr(x, "_ttts_drop_token", None) if (sole_consumer and torch.is_grad_enabled()) else None
-    return LayerNormFn.apply(x, gamma, beta, eps, tok)
+    y_am = _amax_slots(x.device, True) if (publish_amax and x.is_cuda) else None
+    y = LayerNormFn.apply(x, gamma, beta, eps, tok, y_am)
+    if y_am is not None:
+        y._ttts_amax = y_am
+    return y
 
 
 # ----------------------------------------------------------------------------------------------- attention
-def _attn_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, lens, causal, drop_p, seed, need_weights):
+def _attn_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, lens, causal, drop_p, seed, need_weights, q_am=None, k_am=None,
+              v_am=None, o_am=None):
+    """q_am / k_am / v_am: partial maxima of the operands (fp16x3 form; required there); o_am: None, or a zeroed
+    1024-slot array that receives max|o|."""
     lib = _lib.load()
     dev = lens.device
     o = torch.empty(B, Tq, H * 64, dtype=torch.float32, device=dev)
     lse = torch.empty(B, H, Tq, dtype=torch.float32, device=dev)
     attn = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=dev) if need_weights else None
-    fwd = {"h3": lib.ttts_attention_fwd_h3, "x6": lib.ttts_attention_fwd_x6}.get(ATTN_FWD_MODE, lib.ttts_attention_fwd)
-    _lib.check(fwd(q, k, v, _p(o), _p(lse), _p(attn), _p(lens), B, H, Tq, Tk, ldq, ldk, ldv, H * 64,
-                   1 if causal else 0, float(drop_p), seed, _ss(), _stream()), "ttts_attention_fwd")
+    args = (q, k, v, _p(o), _p(lse), _p(attn), _p(lens), B, H, Tq, Tk, ldq, ldk, ldv, H * 64, 1 if causal else 0,
+            float(drop_p), seed, _ss())
+    if ATTN_FWD_MODE == "h3":
+        if q_am is None or k_am is None or v_am is None:
+            raise ValueError("attention (fp16x3 form): the partial maxima of q, k and v are required")
+        _lib.check(lib.ttts_attention_fwd_h3(*args, _p(q_am), _p(k_am), _p(v_am), _p(o_am), _stream()), "ttts_attention_fwd_h3")
+    else:
+        fwd = lib.ttts_attention_fwd_x6 if ATTN_FWD_MODE == "x6" else lib.ttts_attention_fwd
+        _lib.check(fwd(*args, _stream()), "ttts_attention_fwd")
     return o, lse, attn
+
+
+def _attn_h3() -> bool:
+    return ATTN_FWD_MODE == "h3" or ATTN_BWD_MODE == "h3"
 
 
 def _off(t: torch.Tensor, col: int):
@@ -849,16 +982,19 @@ class SelfAttentionFn(torch.autograd.Function):
     """o = softmax(mask(q k^T / 8)) v over a packed in-proj output qkv (B,T,3d); heads of 64."""
 
     @staticmethod
-    def forward(ctx, qkv, lens, n_head, causal, drop_p, seed):
+    def forward(ctx, qkv, lens, n_head, causal, drop_p, seed, qkv_amax=None, o_amax=None):
         qkv = _chk(qkv, "self_attention.qkv")
         lens = _chk(lens, "self_attention.lens", torch.int64)
         B, T, d3 = qkv.shape
         d = d3 // 3
         if d != n_head * 64:
             raise ValueError(f"attention kernels need head_dim 64 (d_model {d}, heads {n_head})")
+        if qkv_amax is None and _attn_h3():
+            qkv_amax = _amax(qkv)
         o, lse, _ = _attn_fwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), d3, d3, d3, B, n_head, T, T, lens, causal,
-                              drop_p, seed, False)
+                              drop_p, seed, False, qkv_amax, qkv_amax, qkv_amax, o_amax)
         ctx.save_for_backward(qkv, o, lse, lens)
+        ctx.qkv_amax = qkv_amax
         ctx.cfg = (n_head, causal, float(drop_p), seed)
         ctx.ss = _ss()
         return o
@@ -874,19 +1010,20 @@ class SelfAttentionFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
         am = _amax_slots(qkv.device, True) if ATTN_BWD_MODE == "h3" else None     # max|dqkv| for the in-projection gradients
-        _lib.check(_attn_bwd(lib, do, am, am, _off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta),
+        qa = ctx.qkv_amax
+        _lib.check(_attn_bwd(lib, do, am, am, qa, qa, qa, _off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta),
                              _off(dqkv, 0), _off(dqkv, d), _off(dqkv, 2 * d), _p(lens), B, n_head, T, T, d3,
                              d3, d3, d, d3, d3, d3, 1 if causal else 0, drop_p, seed, ctx.ss), "ttts_attention_bwd")
         if am is not None:
             dqkv._ttts_amax = am
-        return dqkv, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None
 
 
 class CrossAttentionFn(torch.autograd.Function):
     """Encoder-decoder attention: q (B,Tq,d), packed kv (B,Tk,2d) -> o (B,Tq,d), weights (B,H,Tq,Tk) post-dropout."""
 
     @staticmethod
-    def forward(ctx, q, kv, lens, n_head, drop_p, seed, need_weights=True):
+    def forward(ctx, q, kv, lens, n_head, drop_p, seed, need_weights=True, q_amax=None, kv_amax=None, o_amax=None):
         q = _chk(q, "cross_attention.q")
         kv = _chk(kv, "cross_attention.kv")
         lens = _chk(lens, "cross_attention.lens", torch.int64)
@@ -894,9 +1031,13 @@ class CrossAttentionFn(torch.autograd.Function):
         Tk = kv.shape[1]
         if d != n_head * 64:
             raise ValueError(f"attention kernels need head_dim 64 (d_model {d}, heads {n_head})")
+        if _attn_h3():
+            q_amax = _amax(q) if q_amax is None else q_amax
+            kv_amax = _amax(kv) if kv_amax is None else kv_amax
         o, lse, attn = _attn_fwd(_off(q, 0), _off(kv, 0), _off(kv, d), d, 2 * d, 2 * d, B, n_head, Tq, Tk, lens, False,
-                                 drop_p, seed, need_weights)
+                                 drop_p, seed, need_weights, q_amax, kv_amax, kv_amax, o_amax)
         ctx.save_for_backward(q, kv, o, lse, lens)
+        ctx.amax = (q_amax, kv_amax)
         ctx.cfg = (n_head, float(drop_p), seed)
         ctx.ss = _ss()
         if attn is None:       # weights not requested: single-pass online softmax, nothing written
@@ -908,7 +1049,7 @@ class CrossAttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, do, _dattn):
         if do is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None, None
         lib = _lib.load()
         q, kv, o, lse, lens = ctx.saved_tensors
         n_head, drop_p, seed = ctx.cfg
@@ -921,24 +1062,47 @@ class CrossAttentionFn(torch.autograd.Function):
         am_q = am_kv = None
         if ATTN_BWD_MODE == "h3":
             am_q, am_kv = _amax_slots(q.device, True), _amax_slots(q.device, True)
-        _lib.check(_attn_bwd(lib, do, am_q, am_kv, _off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
+        qa, kva = ctx.amax
+        _lib.check(_attn_bwd(lib, do, am_q, am_kv, qa, kva, kva, _off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
                              _off(dq, 0), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk, d, 2 * d,
                              2 * d, d, d, 2 * d, 2 * d, 0, drop_p, seed, ctx.ss), "ttts_attention_bwd")
         if am_q is not None:
             dq._ttts_amax, dkv._ttts_amax = am_q, am_kv
-        return dq, dkv, None, None, None, None, None
+        return dq, dkv, None, None, None, None, None, None, None, None
+
+
+def self_attention(qkv, lens, n_head: int, causal: bool, drop_p: float, seed: int):
+    """Self-attention over a packed in-projection output; the partial maxima of `qkv` ride on it when its producer left
+    them (`linear(..., publish_amax=True)`), and the context leaves with its own for the out-projection."""
+    h3 = qkv.is_cuda and _attn_h3()
+    am = _amax(qkv) if h3 else None
+    o_am = _amax_slots(qkv.device, True) if (qkv.is_cuda and ATTN_FWD_MODE == "h3") else None
+    o = SelfAttentionFn.apply(qkv, lens, n_head, causal, drop_p, seed, am, o_am)
+    if o_am is not None:
+        o._ttts_amax = o_am
+    return o
+
+
+def cross_attention(q, kv, lens, n_head: int, drop_p: float, seed: int, need_weights: bool = True):
+    h3 = q.is_cuda and _attn_h3()
+    q_am, kv_am = (_amax(q), _amax(kv)) if h3 else (None, None)
+    o_am = _amax_slots(q.device, True) if (q.is_cuda and ATTN_FWD_MODE == "h3") else None
+    o, attn = CrossAttentionFn.apply(q, kv, lens, n_head, drop_p, seed, need_weights, q_am, kv_am, o_am)
+    if o_am is not None:
+        o._ttts_amax = o_am
+    return o, attn
 
 
 # ----------------------------------------------------------------------------------------------- small pieces
 class EmbeddingFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, table):
+    def forward(ctx, ids, table, out_amax=None):
         lib = _lib.load()
         ids = _chk(ids, "embedding.ids", torch.int64)
         table = _chk(table, "embedding.weight")
         vocab, d = table.shape
         out = torch.empty(*ids.shape, d, dtype=torch.float32, device=table.device)
-        _lib.check(lib.ttts_embedding_fwd(_p(ids), _p(table), _p(out), ids.numel(), vocab, d, _stream()),
+        _lib.check(lib.ttts_embedding_fwd(_p(ids), _p(table), _p(out), ids.numel(), vocab, d, _p(out_amax), _stream()),
                    "ttts_embedding_fwd")
         ctx.save_for_backward(ids)
         ctx.shape = (vocab, d)
@@ -951,7 +1115,7 @@ class EmbeddingFn(torch.autograd.Function):
         (ids,) = ctx.saved_tensors
         vocab, d = ctx.shape
         dout = _chk(dout, "embedding.dout")
-        sk, acc = ctx.sinks
+        sk, acc, _ = ctx.sinks
         dtable = None
         if sk is not None:
             t = sk[0]
@@ -959,22 +1123,30 @@ class EmbeddingFn(torch.autograd.Function):
             t = dtable = torch.empty(vocab, d, dtype=torch.float32, device=dout.device)
         _lib.check(lib.ttts_embedding_bwd(_p(ids), _p(dout), _p(t), ids.numel(), vocab, d, acc, _stream()),
                    "ttts_embedding_bwd")
-        return None, dtable
+        return None, dtable, None
+
+
+def embedding(ids, table):
+    out_am = _amax_slots(table.device, True) if table.is_cuda else None
+    out = EmbeddingFn.apply(ids, table, out_am)
+    if out_am is not None:
+        out._ttts_amax = out_am
+    return out
 
 
 class PosEncFn(torch.autograd.Function):
     """y = drop(x + alpha * pe[:T])"""
 
     @staticmethod
-    def forward(ctx, x, pe, alpha, drop_p, seed):
+    def forward(ctx, x, pe, alpha, drop_p, seed, y_amax=None):
         lib = _lib.load()
         x = _chk(x, "posenc.x")
         B, T, d = x.shape
         if T > pe.shape[0] or d != pe.shape[1]:
             raise ValueError("posenc: sequence longer than the table or width mismatch")
         y = torch.empty_like(x)
-        _lib.check(lib.ttts_posenc_fwd(_p(x), _p(pe), _p(alpha), _p(y), B, T, d, float(drop_p), seed, _ss(), _stream()),
-                   "ttts_posenc_fwd")
+        _lib.check(lib.ttts_posenc_fwd(_p(x), _p(pe), _p(alpha), _p(y), B, T, d, float(drop_p), seed, _ss(), _p(y_amax),
+                                       _stream()), "ttts_posenc_fwd")
         ctx.save_for_backward(pe)
         ctx.cfg = (float(drop_p), seed)
         ctx.ss = _ss()
@@ -989,7 +1161,7 @@ class PosEncFn(torch.autograd.Function):
         dy = _chk(dy, "posenc.dy")
         B, T, d = dy.shape
         dx = torch.empty_like(dy)
-        sk, acc = ctx.sinks
+        sk, acc, _ = ctx.sinks
         dalpha = None
         if sk is not None:
             t = sk[0]
@@ -998,7 +1170,15 @@ class PosEncFn(torch.autograd.Function):
         ws = _ws(lib.ttts_posenc_bwd_workspace_bytes(), dy.device)
         _lib.check(lib.ttts_posenc_bwd(_p(dy), _p(pe), _p(dx), _p(t), _p(ws), ws.numel() * 4, B, T, d, drop_p, seed, ctx.ss, acc,
                                        _stream()), "ttts_posenc_bwd")
-        return dx, None, dalpha, None, None
+        return dx, None, dalpha, None, None, None
+
+
+def posenc(x, pe, alpha, drop_p: float, seed: int):
+    y_am = _amax_slots(x.device, True) if x.is_cuda else None
+    y = PosEncFn.apply(x, pe, alpha, drop_p, seed, y_am)
+    if y_am is not None:
+        y._ttts_amax = y_am
+    return y
 
 
 class AddFn(torch.autograd.Function):

@@ -58,6 +58,7 @@ class FlatAdam(torch.optim.Optimizer):
         lib = _lib.load()
         g = self.param_groups[0]
         b = self.bucket
+        b.flush_reductions()        # deferred parameter-gradient reductions of the backward pass(es) land first
         self._step += 1
         n = b.flat.numel()
         norm_ptr = None

@@ -29,6 +29,13 @@ class FlatGradBucket:
             off += (n + 63) // 64 * 64
         self.flat = torch.zeros(off, dtype=dt, device=dev)
         self.views = [self.flat[o:o + n].view_as(p) for o, n, p in zip(self.offsets, sizes, self.params)]
+        # deferred second-stage reductions of the parameter-gradient kernels that write into this bucket: a queue of
+        # the C ABI owned by the bucket (device buckets only), run by flush_reductions()
+        self.queue = None
+        if self.flat.is_cuda:
+            from . import ops
+            self.queue = ops.ReduceQueue()
+        self._tail = None
         self.attach()
 
     def attach(self) -> None:
@@ -38,8 +45,19 @@ class FlatGradBucket:
         for p, v in zip(self.params, self.views):
             p.grad = v
             p._ttts_grad_sink = v
+            p._ttts_reduce_queue = self.queue
+
+    def flush_reductions(self) -> None:
+        """Run the queued parameter-gradient reductions on the current stream: after this (in stream order) the bucket
+        holds every gradient of the backward passes so far.  Called after backward, before any collective over the bucket
+        and before the optimizer reads it; cheap when nothing is queued."""
+        if self.queue is not None:
+            self.queue.flush()
 
     def zero(self) -> None:
+        if self.queue is not None:
+            self.queue.clear()       # leftovers of a backward pass that raised: their destinations are being zeroed anyway
+        self._tail = None
         if self.flat.is_cuda:        # a memset on the stream, not a fill kernel (one node of the captured step graph)
             from . import _lib, ops
             _lib.check(_lib.load().ttts_zero(ops._p(self.flat), self.flat.numel() * self.flat.element_size(), ops._stream()),
@@ -49,6 +67,7 @@ class FlatGradBucket:
         self.attach()
 
     def allreduce_mean(self, group: Optional[dist.ProcessGroup] = None, async_op: bool = False):
+        self.flush_reductions()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return None
         if dist.get_backend(group) == "gloo":   # gloo has no AVG; device buffers are staged through the host
@@ -93,6 +112,7 @@ class FlatGradBucket:
     def start_tail_allreduce(self, lo: int, group: Optional[dist.ProcessGroup] = None) -> None:
         """Begin the (asynchronous) mean all-reduce of flat[lo:].  Call it from a backward hook once every gradient in
         that range is final; every rank must call it at the same point of its step."""
+        self.flush_reductions()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
         if getattr(self, "_tail", None) is not None:
@@ -102,6 +122,7 @@ class FlatGradBucket:
     def finish_allreduce(self, group: Optional[dist.ProcessGroup] = None) -> None:
         """Reduce whatever `start_tail_allreduce` has not covered and wait for the tail: after this the whole bucket
         holds the mean gradient.  Without a started tail it is `allreduce_mean()`."""
+        self.flush_reductions()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
         tail = getattr(self, "_tail", None)
@@ -136,8 +157,8 @@ class _TailTrigger:
     positional inputs, and for a module called with keyword arguments PyTorch fires it as soon as the gradient w.r.t.
     the module's OUTPUT exists -- before any of its parameter gradients do."""
 
-    def __init__(self, boundary: torch.nn.Module, lo: int, on_ready):
-        self.lo, self.on_ready = lo, on_ready
+    def __init__(self, boundary: torch.nn.Module, lo: int, on_ready, before=None):
+        self.lo, self.on_ready, self.before = lo, on_ready, before
         self.pending = 0
         self.generation = 0
         self.fired = 0
@@ -158,8 +179,8 @@ class _TailTrigger:
                 self.pending -= 1
                 if self.pending == 0:
                     self.fired += 1
-                    from . import ops
-                    ops.flush_deferred()       # parameter-gradient reductions queued so far land in the bucket first
+                    if self.before is not None:
+                        self.before()          # parameter-gradient reductions queued so far land in the bucket first
                     self.on_ready(self.lo)
             return None
         seen = set()
@@ -204,7 +225,7 @@ def overlap_tail_with_backward(bucket: FlatGradBucket, model: torch.nn.Module, b
     if on_ready is None:
         def on_ready(lo_):
             bucket.start_tail_allreduce(lo_, group)
-    return _TailTrigger(boundary, lo, on_ready)
+    return _TailTrigger(boundary, lo, on_ready, before=bucket.flush_reductions)
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) -> None:

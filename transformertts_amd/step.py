@@ -1,21 +1,32 @@
-"""TrainStep: one optimizer step of the reference's training loop as the MI355X runs it -- optionally as ONE captured
-HIP graph.
+"""TrainStep: one optimizer step of the reference's training loop as the MI355X runs it -- as captured HIP graphs, one per
+batch shape.
 
 What a step is (reference lightning_module.py:45-86 + what its Trainer does around it, train.py:38-51):
 
-    zero gradients -> training_step (no-grad forward, scheduled-sampling mix, forward, loss) -> backward
+    zero gradients -> [training_step (no-grad forward, scheduled-sampling mix, forward, loss) -> backward] x accumulate
     -> [N > 1: gradient all-reduce (mean) over RCCL] -> global-norm clip -> Adam (lr = Noam factor) -> scheduler.step()
 
 Eagerly that is ~700 kernel launches issued one by one from Python (16 ms of host time per step, measured in round 1:
-more than the kernels need once they get faster, and already more than a batch-16 step needs).  The launch sequence of a
-step is identical from step to step for a fixed batch shape, so it is captured once into a HIP graph and replayed; the
-host then spends one small host-to-device copy plus one graph launch per step.
+more than the kernels need once they get faster, and already more than a batch-16 step needs).  The launch sequence is
+identical from step to step for a fixed batch shape, so it is captured into a HIP graph and replayed; the host then
+spends one small host-to-device copy plus one graph launch per micro-batch.
+
+Real batches vary in shape (dataset.py:71-103 pads to the batch maxima), so the graphs live in a cache keyed on the
+batch shape `(B, Tp, Tm)` and the micro-batch's role in the accumulation window; all of them share ONE memory pool (they
+never run concurrently), so the cache costs the memory of its largest member, not the sum.  `lattice=(p, m)` rounds the
+padded lengths up to multiples of p phonemes / m frames before the lookup, which bounds the number of distinct shapes
+(LJSpeech under a length-bucketed sampler: a few dozen): the extra rows are padding exactly like the reference's own
+(zero input, masked in attention and in the loss by the true lengths); like the reference's padding rows they are
+visible to BatchNorm's batch statistics and to the convolutions' receptive fields at an utterance's end, so the option
+is off by default and the parity tests run on exact shapes.
 
 Kernel arguments are frozen at capture, so everything that varies per step is read from device memory by the kernels
 (`ops.StepState`, `ttts_step_state` in include/ttts_hip.h): the dropout / sampling seed word, the learning rate, the
-Adam step count and the teacher-forcing ratio.  Dropout SITE seeds are numbered from zero at the start of every step in
-both modes, so an eager step and a replayed step with the same state block are bit-identical
-(tests/test_hip_graph.py).
+Adam step count and the teacher-forcing ratio.  Dropout SITE seeds are numbered from zero at the start of every
+micro-batch in both modes, so an eager step and a replayed step with the same state block are bit-identical
+(tests/test_hip_graph.py).  The weight planes of the split-precision GEMMs are refreshed by an explicit batched launch at
+the start of the first micro-batch after an optimizer step (`ops.PlaneTable`, owned by this object and recorded in the
+graph), never through the lazy process-wide cache.
 
 Data parallel (N > 1): the graph ends after backward; the all-reduce of the flat bucket and the optimizer kernels are
 issued eagerly behind it on the same stream (one collective + three launches).  Overlapping the tail of the bucket with
@@ -24,7 +35,7 @@ eager-mode option.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -33,6 +44,7 @@ from .optim import FlatAdam
 from .parallel import overlap_tail_with_backward
 
 _MIX = 0x9E3779B97F4A7C15
+_KEYS = ("phoneme", "melspec", "phoneme_lens", "melspec_lens")
 
 
 def _step_seed(base: int, step: int) -> int:
@@ -43,113 +55,227 @@ def _step_seed(base: int, step: int) -> int:
     return z ^ (z >> 31)
 
 
+def _round_up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+class _Slot:
+    """Static buffers of one batch shape and the graphs captured over them (one per accumulation role)."""
+    __slots__ = ("batch", "graphs", "losses", "eager_runs")
+
+    def __init__(self, batch):
+        self.batch = batch
+        self.graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+        self.losses: Dict[str, torch.Tensor] = {}
+        self.eager_runs = 0
+
+
 class TrainStep:
-    def __init__(self, lm, optimizer: FlatAdam, scheduler, batch: Dict[str, torch.Tensor], *, graph: bool = True,
-                 seed: int = 0, group=None, overlap: bool = False, eager_warmup: int = 2):
-        """`lm`: the LightningModule counterpart (training_step surface); `batch`: device tensors with the keys of the
-        reference's collate_fn -- kept as STATIC buffers: later batches of the same shape are copied into them
-        (`load`).  `graph=True` captures after `eager_warmup` eager steps.  `overlap=True` (eager mode, N > 1 only)
-        starts the all-reduce of the decoder / postnet / head gradients while backward is still in the encoder."""
+    def __init__(self, lm, optimizer: FlatAdam, scheduler, batch: Optional[Dict[str, torch.Tensor]] = None, *,
+                 graph: bool = True, seed: int = 0, group=None, overlap: bool = False, eager_warmup: int = 2,
+                 accumulate: int = 1, lattice: Optional[Tuple[int, int]] = None, max_shapes: int = 64):
+        """`lm`: the LightningModule counterpart (training_step surface).  `batch` (optional): device tensors with the keys
+        of the reference's collate_fn; its shape gets the first set of static buffers.  Later batches of any shape are
+        copied into the static buffers of THEIR shape (`__call__(batch)` / `load`), created on first sight.
+        `graph=True` captures a shape at its first use after `eager_warmup` eager micro-batches overall.
+        `accumulate=k`: gradients of k micro-batches are summed (each scaled by 1/k, as Lightning's
+        accumulate_grad_batches does, train.py:42) before the optimizer steps.  `lattice=(p, m)`: see the module text.
+        `overlap=True` (eager mode, N > 1 only) starts the all-reduce of the decoder / postnet / head gradients while
+        backward is still in the encoder."""
         if not isinstance(optimizer, FlatAdam):
             raise TypeError("TrainStep drives FlatAdam (flat parameter / gradient / moment buffers)")
         self.lm, self.opt, self.sched, self.group = lm, optimizer, scheduler, group
         self.bucket = optimizer.bucket
-        self.batch = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
         dev = self.bucket.flat.device
-        if any(v.device != dev for v in self.batch.values()):
-            raise ValueError("TrainStep: the batch must live on the model's HIP device")
+        self.device = dev
         self.state = ops.StepState(dev)
-        self._one = torch.ones((), dtype=torch.float32, device=dev)
+        self.accumulate = max(1, int(accumulate))
+        self._grad_seed = torch.full((), 1.0 / self.accumulate, dtype=torch.float32, device=dev)   # resident d(loss)
         self.base_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-        self.index = 0                       # steps taken
+        self.index = 0                       # micro-batches taken
+        self.micro = 0                       # position inside the accumulation window
         self.use_graph = bool(graph)
-        self.eager_warmup = max(2, int(eager_warmup))     # step 1 builds the weight-plane caches, step 2 their table
-        self._graph: Optional[torch.cuda.CUDAGraph] = None
-        self._loss: Optional[torch.Tensor] = None
-        self._graph_has_optimizer = False
+        self.eager_warmup = max(2, int(eager_warmup))     # micro-batch 1 builds the weight-plane caches, 2 their table
+        self.lattice = tuple(int(v) for v in lattice) if lattice else None
+        self.max_shapes = int(max_shapes)
+        self._slots: Dict[Tuple[int, int, int], _Slot] = {}
+        self._cur: Optional[_Slot] = None
+        self._pool = None                    # memory pool shared by every captured graph
+        self._planes: Optional[ops.PlaneTable] = None
         import torch.distributed as dist
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.trigger = None
         if overlap and self.world > 1 and not self.use_graph:
             self.trigger = overlap_tail_with_backward(self.bucket, lm.model, lm.model.decoder, group)
+        if batch is not None:
+            self.load(batch)
+
+    # ------------------------------------------------------------------------------------------------ batches
+    @property
+    def batch(self) -> Dict[str, torch.Tensor]:
+        """Static buffers of the current shape."""
+        if self._cur is None:
+            raise RuntimeError("TrainStep: no batch loaded yet")
+        return self._cur.batch
+
+    def _key(self, batch) -> Tuple[int, int, int]:
+        B, Tp = batch["phoneme"].shape
+        Tm = batch["melspec"].shape[1]
+        if self.lattice:
+            Tp, Tm = _round_up(Tp, self.lattice[0]), _round_up(Tm, self.lattice[1])
+        return int(B), int(Tp), int(Tm)
+
+    def load(self, batch: Dict[str, torch.Tensor]) -> None:
+        """Copy the next batch into the static buffers of its (lattice-rounded) shape, creating them on first sight."""
+        key = self._key(batch)
+        slot = self._slots.get(key)
+        if slot is None:
+            if len(self._slots) >= self.max_shapes:
+                raise RuntimeError(f"TrainStep: more than {self.max_shapes} distinct batch shapes; use `lattice` or a "
+                                   "length-bucketed sampler (dataset.BucketBatchSampler)")
+            B, Tp, Tm = key
+            src = {k: batch[k] for k in _KEYS}
+            if any(v.device != self.device for v in src.values()):
+                raise ValueError("TrainStep: the batch must live on the model's HIP device")
+            n_mels = src["melspec"].shape[2]
+            static = {"phoneme": torch.zeros(B, Tp, dtype=src["phoneme"].dtype, device=self.device),
+                      "melspec": torch.zeros(B, Tm, n_mels, dtype=src["melspec"].dtype, device=self.device),
+                      "phoneme_lens": torch.zeros(B, dtype=src["phoneme_lens"].dtype, device=self.device),
+                      "melspec_lens": torch.zeros(B, dtype=src["melspec_lens"].dtype, device=self.device)}
+            slot = self._slots[key] = _Slot(static)
+        dst = slot.batch
+        for k in _KEYS:
+            s, d = batch[k], dst[k]
+            if s.shape == d.shape:
+                d.copy_(s, non_blocking=True)
+            else:                                  # lattice padding: id 0 / 0.0 beyond the batch's own maxima
+                d.zero_()
+                d[tuple(slice(0, n) for n in s.shape)].copy_(s, non_blocking=True)
+        self._cur = slot
 
     # ------------------------------------------------------------------------------------------------ pieces
-    def load(self, batch: Dict[str, torch.Tensor]) -> None:
-        """Copy the next batch into the static buffers (same shapes; a different shape needs its own TrainStep)."""
-        for k, dst in self.batch.items():
-            src = batch[k]
-            if src.shape != dst.shape:
-                raise ValueError(f"TrainStep.load: {k} has shape {tuple(src.shape)}, the step was built for {tuple(dst.shape)}")
-            dst.copy_(src, non_blocking=True)
-
     def _push_state(self) -> None:
         self.state.push(seed=_step_seed(self.base_seed, self.index), lr=float(self.opt.param_groups[0]["lr"]),
                         p_tf=float(self.lm.teacher_forcing_ratio()), step=self.opt._step + 1)
 
-    def _forward_backward(self) -> torch.Tensor:
-        ops.seeds.counter = 0                # site seeds are numbered per step; the step's seed word makes them fresh
-        ops.abort_deferred()                 # leftovers of a backward pass that raised
-        self.opt.zero_grad()
-        loss = self.lm.training_step(self.batch, self.index)
-        dev = self.bucket.flat.device
-        ops.amax_arena_reset(dev)            # one memset for all partial-maxima arrays of this backward pass
-        loss.backward(gradient=self._one)    # a resident 1.0 instead of autograd's ones_like fill kernel
-        ops.amax_arena_release(dev)
+    def _role(self) -> str:
+        first, last = self.micro == 0, self.micro == self.accumulate - 1
+        return "full" if (first and last) else "first" if first else "last" if last else "mid"
+
+    def _forward_backward(self, role: Optional[str] = None, capturing: bool = False) -> torch.Tensor:
+        """One micro-batch: [zero-grad + weight-plane refresh] + training_step + backward + flush of the deferred
+        parameter-gradient reductions."""
+        dev = self.device
+        role = role or self._role()
+        trig = self.trigger
+        hold = trig is not None and trig.enabled and role not in ("full", "last")
+        if hold:
+            trig.enabled = False             # the exchange belongs to the window's last micro-batch only
+        ops.seeds.counter = 0                # site seeds are numbered per micro-batch; the seed word makes them fresh
+        ops.amax_arena_reset(dev)            # one memset for all partial-maxima arrays of this micro-batch
+        try:
+            if role in ("full", "first"):
+                self.opt.zero_grad()         # also drops reductions a failed backward pass left queued
+                if self._planes is not None and (capturing or self._planes.stale()):
+                    self._planes.refresh()   # the optimizer stepped: every weight is re-split by one batched launch
+            loss = self.lm.training_step(self._cur.batch, self.index)
+            loss.backward(gradient=self._grad_seed)    # a resident 1/accumulate instead of autograd's ones_like fill kernel
+            self.bucket.flush_reductions()
+        finally:
+            ops.amax_arena_release(dev)
+            if hold:
+                trig.enabled = True
         return loss
 
     def _reduce_and_update(self) -> None:
         self.bucket.finish_allreduce(self.group)     # waits for an overlapped tail and reduces the rest; no-op at N = 1
         self.opt.step()
 
+    def _ensure_planes(self) -> None:
+        if self._planes is None or not self._planes.valid():
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("TrainStep: weight planes moved during a capture")
+            self._planes = ops.PlaneTable(self.lm.model)
+
     # ------------------------------------------------------------------------------------------------ one step
     def __call__(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+        """One micro-batch; the optimizer (and the scheduler) step on every `accumulate`-th call."""
         if batch is not None:
             self.load(batch)
+        slot = self._cur
+        if slot is None:
+            raise RuntimeError("TrainStep: no batch loaded yet")
+        role = self._role()
+        last = role in ("full", "last")
         self._push_state()
-        if not self.use_graph or self.index < self.eager_warmup:
+        if self.index >= 1:
+            self._ensure_planes()
+        eager = (not self.use_graph) or self.index < self.eager_warmup
+        if eager:
             with self.state:
-                loss = self._forward_backward()
-                self._reduce_and_update()
-        else:
-            if self._graph is None:
-                self._capture()
-            self._graph.replay()
-            if self._graph_has_optimizer:
-                self.opt.note_external_step()
-            else:
-                with self.state:
+                loss = self._forward_backward(role)
+                if last:
                     self._reduce_and_update()
-            loss = self._loss
-        self.sched.step()
+            slot.eager_runs += 1
+        else:
+            if role not in slot.graphs:
+                self._capture(slot, role)
+            slot.graphs[role].replay()
+            if last:
+                if self.world == 1:
+                    self.opt.note_external_step()
+                else:
+                    with self.state:
+                        self._reduce_and_update()
+            loss = slot.losses[role]
+        if last:
+            self.sched.step()
         self.index += 1
+        self.micro = 0 if last else self.micro + 1
         return loss
 
-    def _capture(self) -> None:
-        """Record zero-grad + training_step + backward (+ clip + Adam at N = 1) of ONE step into a HIP graph.  Nothing
-        executes during capture; the caller replays it right away."""
+    def _capture(self, slot: _Slot, role: str) -> None:
+        """Record one micro-batch of `role` over the static buffers of `slot` into a HIP graph.  Nothing executes during
+        capture; the caller replays it right away."""
+        self._ensure_planes()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         step0 = self.opt._step
-        with torch.cuda.graph(g):
-            with self.state:
-                self._loss = self._forward_backward()
-                if self.world == 1:
-                    self.opt.step()
-                    self._graph_has_optimizer = True
-        self.opt._step = step0               # the capture pass ran the host bookkeeping of a step that did not execute
-        self._graph = g
+        prev = self._cur
+        self._cur = slot
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        try:
+            with torch.cuda.graph(g, pool=self._pool):
+                with self.state:
+                    slot.losses[role] = self._forward_backward(role, capturing=True)
+                    if role in ("full", "last") and self.world == 1:
+                        self.opt.step()
+        finally:
+            self._cur = prev
+            self.opt._step = step0           # the capture pass ran the host bookkeeping of a step that did not execute
+            self._planes.mark_stale()        # ... and the recorded plane refresh has not run either
+        slot.graphs[role] = g
 
     def ensure_captured(self) -> None:
-        """Capture now (outside any timed region) instead of lazily inside the first step past the eager warm-up.  Needs
-        two eager steps before it: the first creates the weight-plane caches, the second their descriptor table (pinned
-        host allocation + upload, which must not land inside a capture)."""
-        if self.use_graph and self._graph is None:
-            if self.index < 2:
-                raise RuntimeError("TrainStep.ensure_captured: run at least two (eager) steps first")
-            self._push_state()               # harmless: the next step pushes its own state again
-            self._capture()
-            self.eager_warmup = min(self.eager_warmup, self.index)
+        """Capture the current shape's graph for the role of the NEXT micro-batch now (outside any timed region) instead
+        of lazily inside the first step past the eager warm-up.  Needs two eager micro-batches before it: the first creates
+        the weight-plane caches, the second their descriptor table."""
+        if not self.use_graph:
+            return
+        slot, role = self._cur, self._role()
+        if slot is None or role in slot.graphs:
+            return
+        if self.index < 2:
+            raise RuntimeError("TrainStep.ensure_captured: run at least two (eager) steps first")
+        self._push_state()                   # harmless: the next step pushes its own state again
+        self._capture(slot, role)
+        self.eager_warmup = min(self.eager_warmup, self.index)
 
     @property
     def graphed(self) -> bool:
-        return self._graph is not None
+        return self._cur is not None and bool(self._cur.graphs)
+
+    @property
+    def n_graphs(self) -> int:
+        return sum(len(s.graphs) for s in self._slots.values())
