@@ -18,6 +18,11 @@ The step is driven by `transformertts_amd.step.TrainStep`: after two eager steps
 all-reduce + optimizer kernels follow it on the stream) and replayed.  TTTS_GRAPH=0 keeps the eager launch path
 (with TTTS_DP_OVERLAP=1 the tail of the gradient bucket is then exchanged while backward is still in the encoder).
 Other configs: --config scaled --batch 32 (BASELINE configs[4] per-GPU shard), --batch 16 (configs[1] shape, fp32).
+--ragged --cycle N: a stream of N differently shaped LJSpeech-like batches, round-robin (one graph per shape out of the
+shape-keyed cache; --lattice P,M rounds the padded lengths to multiples of P phonemes / M frames first).
+After the timed steps the same step is replayed for --sustain seconds more and the median step time of that stretch is
+reported as `sustained` (the timed region of a default run is a third of a second: too short to show the clocks the chip
+holds under sustained matrix load).
 """
 from __future__ import annotations
 
@@ -246,6 +251,10 @@ def main():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--cycle", type=int, default=1, help="number of distinct ragged batch shapes fed round-robin")
+    ap.add_argument("--lattice", default="", help="P,M: pad batches to multiples of P phonemes / M frames (graph-cache key)")
+    ap.add_argument("--accumulate", type=int, default=1, help="micro-batches per optimizer step (train.py:42 uses 4)")
+    ap.add_argument("--sustain", type=float, default=10.0, help="seconds of further replays after the timed steps (0: skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -262,7 +271,7 @@ def main():
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if world > 1 or os.environ.get("TTTS_FORCE_DIST", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -286,22 +295,33 @@ def main():
     opt_cfg = lm.configure_optimizers()          # FlatAdam: flat parameters / gradients / moments, clip folded in
     optimizer, scheduler = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
 
-    # per-rank shard of the global synthetic batch (weak scaling: args.batch utterances per GPU)
-    batch = synth_batch(args.batch, args.tp, args.tm, cfg["n_mels"], cfg["n_phon"], ragged=args.ragged, seed=1234 + rank)
-    batch = {k: v.to(dev) for k, v in batch.items()}
-    frames_rank = int(batch["melspec_lens"].sum().item())
-    flops_rank = 4.0 * sum(algorithmic_flops_forward(cfg, int(p), int(m))
-                           for p, m in zip(batch["phoneme_lens"].tolist(), batch["melspec_lens"].tolist()))
+    # per-rank shard of the global synthetic batch (weak scaling: args.batch utterances per GPU).  --cycle N: N batches whose
+    # maxima differ (as the reference's collate_fn pads each batch to its own longest utterance, dataset.py:71-103)
+    batches = []
+    for i in range(max(1, args.cycle)):
+        tp_i, tm_i = max(8, args.tp - (3 * i) % 29), max(95, args.tm - (37 * i) % 311)
+        b = synth_batch(args.batch, tp_i, tm_i, cfg["n_mels"], cfg["n_phon"], ragged=args.ragged, seed=1234 + rank + 101 * i)
+        batches.append({k: v.to(dev) for k, v in b.items()})
+    batch = batches[0]
+    frames_each = [int(b["melspec_lens"].sum().item()) for b in batches]
+    flops_each = [4.0 * sum(algorithmic_flops_forward(cfg, int(p), int(m))
+                            for p, m in zip(b["phoneme_lens"].tolist(), b["melspec_lens"].tolist())) for b in batches]
+    # work of the timed region: step i takes batch (warmup + i) mod cycle
+    frames_rank = sum(frames_each[(args.warmup + i) % len(batches)] for i in range(args.steps)) / args.steps
+    flops_rank = sum(flops_each[(args.warmup + i) % len(batches)] for i in range(args.steps)) / args.steps
 
     use_graph = os.environ.get("TTTS_GRAPH", "1") == "1"
     want_overlap = os.environ.get("TTTS_DP_OVERLAP", "1") == "1"
     # one step = zero-grad, training_step (2 forwards + loss), backward, [all-reduce], clip + Adam, scheduler.step();
     # different ranks draw different dropout masks (seed 42 + rank)
+    lattice = tuple(int(v) for v in args.lattice.split(",")) if args.lattice else None
+    force_dist = world == 1 and dist.is_initialized()      # TTTS_FORCE_DIST=1: RCCL in a one-rank group
     ts = TrainStep(lm, optimizer, scheduler, batch, graph=use_graph, seed=42 + rank, overlap=want_overlap,
-                   eager_warmup=2)
+                   eager_warmup=2, accumulate=args.accumulate, lattice=lattice, force_collective=force_dist)
+    cycling = len(batches) > 1
 
     def step(i):
-        return ts()
+        return ts(batches[i % len(batches)]) if cycling else ts()
 
     def fence():
         if world > 1:
@@ -324,8 +344,13 @@ def main():
     if use_graph:
         while ts.index < 2:
             step(ts.index)                       # --warmup < 2: the capture still needs two eager steps before it
-        ts.ensure_captured()                     # capture outside the timed region (nothing executes during capture)
-        note("step captured into a HIP graph")
+        if cycling or args.accumulate > 1:       # every shape / accumulation role is captured at its first use: do a full
+            for i in range(len(batches) * args.accumulate):          # round of them before the timed region
+                step(args.warmup + i)
+            torch.cuda.synchronize()
+        else:
+            ts.ensure_captured()                 # capture outside the timed region (nothing executes during capture)
+        note(f"step captured into HIP graphs ({ts.n_graphs})")
     gc.collect()
     gc.freeze()
     fence()
@@ -345,6 +370,31 @@ def main():
     elapsed = float(t.item())
     frames_all, flops_all = float(tot[0].item()), float(tot[1].item())
     final_loss = float(loss.item())
+
+    # sustained figure: keep stepping for args.sustain seconds, in stretches of `args.steps` steps fenced like the timed ones
+    sustained = None
+    if args.sustain > 0 and not rehearsal:
+        stretch, t_s0, k = [], time.perf_counter(), args.warmup + args.steps
+        while True:
+            fence()
+            ta = time.perf_counter()
+            for i in range(args.steps):
+                step(k + i)
+            fence()
+            tb = time.perf_counter()
+            k += args.steps
+            stretch.append((tb - ta) / args.steps * 1e3)
+            go = torch.tensor([1.0 if tb - t_s0 < args.sustain else 0.0], dtype=torch.float64, device=red_dev)
+            if world > 1:
+                dist.all_reduce(go, op=dist.ReduceOp.MIN)       # every rank leaves the loop in the same iteration
+            if go.item() == 0.0:
+                break
+        med = statistics.median(stretch)
+        sustained = {"seconds": time.perf_counter() - t_s0, "steps": len(stretch) * args.steps,
+                     "median_ms_per_step": med, "min_ms_per_step": min(stretch), "max_ms_per_step": max(stretch),
+                     "ratio_to_headline": med / (elapsed / args.steps * 1e3),
+                     "note": "rank-0 clock around fenced stretches of --steps steps each, after the timed region"}
+        note(f"sustained: median {med:.2f} ms/step over {sustained['steps']} further steps")
 
     rehearsal_check = None
     if rehearsal and world > 1:
@@ -378,13 +428,18 @@ def main():
                                    f"({'ragged' if args.ragged else 'dense'}), {args.config} config d_model {cfg['d_model']}, "
                                    f"{cfg['encoder_n_layers']}+{cfg['decoder_n_layers']} layers, dropout on, fp32",
                        "global_batch": args.batch * world, "frames_per_step": frames_all, "parallelism": f"dp{world}",
-                       "launch_path": ("one HIP graph per step (captured after the eager warm-up steps)" if ts.graphed
-                                       else "eager: one ctypes launch per kernel"),
-                       "grad_allreduce": ("none (1 GPU)" if world == 1 else
+                       "launch_path": (f"one HIP graph per step ({ts.n_graphs} captured: one per batch shape and accumulation role)"
+                                       if ts.graphed else "eager: one ctypes launch per kernel"),
+                       "batch_stream": (f"{len(batches)} distinct ragged shapes round-robin" + (f", lattice {lattice}" if lattice else "")
+                                        if cycling else "one resident batch"),
+                       "accumulate": args.accumulate,
+                       "process_group": (dist.get_backend() + f" x{world}") if dist.is_initialized() else "none",
+                       "grad_allreduce": ("none (1 GPU)" if not ts.dp else
                                           "tail overlapped with backward" if ts.trigger is not None
                                           else "one collective after backward"),
                        "final_loss": final_loss, "per_step_loss_item_sync": False},
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
+            "sustained": sustained,
             "step_algorithmic_tflops": flops_all / 1e12,
             "step_achieved_tflops_per_gpu": flops_all / world / (elapsed / args.steps) / 1e12,
         }

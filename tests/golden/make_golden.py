@@ -89,19 +89,19 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-def _grad_record(named_params):
+def _grad_record(named_params, max_samples=MAX_GRAD_SAMPLES):
     rec = {}
     for k, p in named_params:
         g = p.grad if p.grad is not None else torch.zeros_like(p)
         flat = g.flatten()
-        stride = max(1, (flat.numel() + MAX_GRAD_SAMPLES - 1) // MAX_GRAD_SAMPLES)
+        stride = max(1, (flat.numel() + max_samples - 1) // max_samples)
         rec[f"gradnorm/{k}"] = np.float64(g.double().norm().item())
         rec[f"gradsample/{k}"] = _np(flat[::stride])
         rec[f"gradstride/{k}"] = np.int64(stride)
     return rec
 
 
-def golden_model(name, cfg_name, B, Tp, Tm, w_seed, b_seed, align_stride):
+def golden_model(name, cfg_name, B, Tp, Tm, w_seed, b_seed, align_stride, max_grad_samples=MAX_GRAD_SAMPLES):
     cfg = model_config(cfg_name)
     batch = synth_batch(B, Tp, Tm, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=b_seed)
     args = (batch["phoneme"], batch["melspec"], batch["phoneme_lens"], batch["melspec_lens"])
@@ -135,7 +135,7 @@ def golden_model(name, cfg_name, B, Tp, Tm, w_seed, b_seed, align_stride):
         rec[f"train/align{i}"] = _np(a[:, :, ::align_stride])
     for k in ("total", "pred_mel", "post_mel", "stop"):
         rec[f"train/loss_{k}"] = np.float64(loss[k].item())
-    rec.update(_grad_record(m.named_parameters()))
+    rec.update(_grad_record(m.named_parameters(), max_grad_samples))
     for k, v in m.state_dict().items():
         if "running_" in k or "num_batches" in k:
             rec[f"bn/{k}"] = _np(v)
@@ -263,9 +263,18 @@ def golden_collate(name):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    golden_helpers("helpers")
-    golden_model("tiny_model", "tiny", B=3, Tp=12, Tm=40, w_seed=11, b_seed=21, align_stride=1)
-    golden_model("base_model", "base", B=2, Tp=60, Tm=300, w_seed=12, b_seed=22, align_stride=8)
-    golden_step("tiny_step", "tiny", B=3, Tp=12, Tm=40, w_seed=11, b_seed=21, epoch=120)
-    golden_collate("collate")
-    golden_inference("tiny_inference", "tiny", B=3, Tp=12, w_seed=11, b_seed=21, max_len=14)
+    only = set(sys.argv[1:])            # e.g. `make_golden.py scaled_model`: regenerate the named fixtures only
+    jobs = [
+        ("helpers", lambda: golden_helpers("helpers")),
+        ("tiny_model", lambda: golden_model("tiny_model", "tiny", B=3, Tp=12, Tm=40, w_seed=11, b_seed=21, align_stride=1)),
+        ("base_model", lambda: golden_model("base_model", "base", B=2, Tp=60, Tm=300, w_seed=12, b_seed=22, align_stride=8)),
+        # BASELINE configs[4]: d_model 512, 6+6 layers, 8 heads, d_ffn 2048 (fewer gradient samples per parameter: 282 tensors)
+        ("scaled_model", lambda: golden_model("scaled_model", "scaled", B=2, Tp=60, Tm=300, w_seed=14, b_seed=24, align_stride=8,
+                                              max_grad_samples=1024)),
+        ("tiny_step", lambda: golden_step("tiny_step", "tiny", B=3, Tp=12, Tm=40, w_seed=11, b_seed=21, epoch=120)),
+        ("collate", lambda: golden_collate("collate")),
+        ("tiny_inference", lambda: golden_inference("tiny_inference", "tiny", B=3, Tp=12, w_seed=11, b_seed=21, max_len=14)),
+    ]
+    for name, job in jobs:
+        if not only or name in only:
+            job()

@@ -150,3 +150,26 @@ def test_two_rank_rehearsal_reduces_to_the_mean_gradient(overlap):
     assert chk["tail_trigger_fired"] == (overlap == "1")
     assert chk["rel_l2_vs_mean_of_rank_gradients"] <= 1e-6, chk
     assert "Full backward hook is firing" not in r.stderr
+
+
+def test_rccl_one_rank_group_matches_the_single_process_step():
+    """RCCL itself (backend "nccl"), on the one GPU of this box: a one-rank process group launched by torch.distributed.run
+    as the driver launches bench.py.  tools/rccl_one_rank.py takes the data-parallel launch path -- graph replay, then
+    ReduceOp.AVG over the flat bucket on the same stream, then clip + Adam -- and requires the one-rank mean to leave the
+    bucket unchanged and six steps (dropout on) to end bit for bit where the single-process path ends."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "tools", "rccl_one_rank.py"), "base", "6"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", "rccl_one_rank.json"), "w") as f:
+        json.dump(out, f)
+    assert out["backend"] == "nccl" and out["world"] == 1
+    assert out["one_rank_mean_leaves_bucket_unchanged"] and out["losses_equal"] and out["state_equal"], out

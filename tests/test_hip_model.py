@@ -116,10 +116,12 @@ def test_forward_backward_vs_oracle(cfg_name, B, Tp, Tm, w_seed, b_seed):
     assert not bad, bad
 
 
-def test_golden_outputs_direct(golden_dir):
-    """HIP path against the committed reference outputs themselves (fp32 reference run), base config."""
+@pytest.mark.parametrize("fixture", ["base_model", "scaled_model"])
+def test_golden_outputs_direct(golden_dir, fixture):
+    """HIP path against the committed reference outputs themselves (fp32 reference run): base config and the scaled
+    configuration of BASELINE configs[4] (d_model 512, 6+6 layers, 8 heads, d_ffn 2048)."""
     from oracle import synth_batch
-    g = np.load(os.path.join(golden_dir, "base_model.npz"))
+    g = np.load(os.path.join(golden_dir, f"{fixture}.npz"))
     cfg, m = _build(str(g["meta/cfg_name"]), int(g["meta/w_seed"]))
     batch = synth_batch(int(g["meta/B"]), int(g["meta/Tp"]), int(g["meta/Tm"]), cfg["n_mels"], cfg["n_phon"], ragged=True,
                         seed=int(g["meta/b_seed"]))
@@ -133,14 +135,15 @@ def test_golden_outputs_direct(golden_dir):
         assert rel_l2(a[:, :, ::st], torch.from_numpy(g[f"train/align{i}"])) < GATE
 
 
-def test_golden_gradients_direct(golden_dir):
-    """HIP gradients against the reference's OWN fp32 backward (tests/golden/base_model.npz: per-parameter norms and
+@pytest.mark.parametrize("fixture", ["base_model", "scaled_model"])
+def test_golden_gradients_direct(golden_dir, fixture):
+    """HIP gradients against the reference's OWN fp32 backward (tests/golden/{base,scaled}_model.npz: per-parameter norms and
     strided samples written by make_golden.py from the imported reference).  Both sides are fp32 evaluations with their
     own ReLU gate flips against exact arithmetic (see test_gradient_gap_is_relu_gate_flips), so the gate is the sum of
     the two spreads; parameters that no flip reaches agree to ~1e-6."""
     from oracle import synth_batch
     from transformertts_amd.loss import TransformerTTSLoss
-    g = np.load(os.path.join(golden_dir, "base_model.npz"))
+    g = np.load(os.path.join(golden_dir, f"{fixture}.npz"))
     cfg, m = _build(str(g["meta/cfg_name"]), int(g["meta/w_seed"]))
     batch = synth_batch(int(g["meta/B"]), int(g["meta/Tp"]), int(g["meta/Tm"]), cfg["n_mels"], cfg["n_phon"], ragged=True,
                         seed=int(g["meta/b_seed"]))
@@ -160,15 +163,19 @@ def test_golden_gradients_direct(golden_dir):
         assert abs(float(p.grad.double().norm()) - ref_norm) < GRAD_GATE * ref_norm, name
         errs[name] = rel_l2(flat, ref)
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/parity_golden_gradients.txt", "w") as f:
+    with open(f"gpurun_out/parity_golden_gradients_{fixture}.txt", "w") as f:
         for k, v in sorted(errs.items(), key=lambda kv: -kv[1]):
             f.write(f"{v:.3e} {k}\n")
     bad = {k: v for k, v in errs.items() if not v < GRAD_GATE}
     assert not bad, bad
-    assert sorted(errs.values())[len(errs) // 2] < 1e-4        # the typical parameter is far inside the gate
+    # the typical parameter is far inside the gate (the deeper scaled stack has more units near zero: the oracle evaluated
+    # in fp32 sits at 2.6e-4 against the same fixture, tests/test_oracle_golden.py)
+    assert sorted(errs.values())[len(errs) // 2] < (1e-4 if fixture == "base_model" else 5e-4)
 
 
-def test_gradient_gap_is_relu_gate_flips():
+@pytest.mark.parametrize("cfg_name,B,Tp,Tm,w_seed,b_seed", [("base", 4, 100, 870, 13, 23), ("base", 16, 100, 870, 15, 25),
+                                                            ("scaled", 2, 60, 300, 14, 24)])
+def test_gradient_gap_is_relu_gate_flips(cfg_name, B, Tp, Tm, w_seed, b_seed):
     """Why the end-to-end gradient gate is looser than the 1e-6 every backward kernel meets on its own: a ReLU is the one
     discontinuous operation on the path.  A pre-activation within rounding distance of zero is gated differently by two
     correct evaluations in different precision, and a flipped unit perturbs its own weight gradient and everything below
@@ -177,11 +184,13 @@ def test_gradient_gap_is_relu_gate_flips():
           them has |pre-activation| < 1e-5 in fp64 (measured: 1 unit of 1.37e7);
       (2) evaluating the fp64 oracle UNDER THE HIP PATH'S GATES makes every parameter gradient agree to FLIP_FREE_GATE --
           the flips are the entire gap;
-      (3) flips aside, the HIP path's typical parameter error is of the order of stock fp32 torch's own (vs fp64)."""
+      (3) flips aside, the HIP path's typical parameter error is of the order of stock fp32 torch's own (vs fp64).
+    Run for every case of test_forward_backward_vs_oracle whose gradients are held to the loose GRAD_GATE there (base x 4,
+    base x 16 = BASELINE configs[1] shape, scaled = configs[4]): under the HIP path's gates ALL of them meet 2e-5."""
     from oracle import synth_batch, oracle_forward, oracle_loss, relu_gates
     from transformertts_amd import ops
     from transformertts_amd.loss import TransformerTTSLoss
-    cfg_name, B, Tp, Tm, w_seed, b_seed = "base", 4, 100, 870, 13, 23
+    first = (cfg_name, B) == ("base", 4)
     cfg, m = _build(cfg_name, w_seed)
     batch = synth_batch(B, Tp, Tm, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=b_seed)
     args = [batch[k].to("cuda") for k in ("phoneme", "melspec", "phoneme_lens", "melspec_lens")]
@@ -217,9 +226,9 @@ def test_gradient_gap_is_relu_gate_flips():
         units += pre.numel()
         if diff.any():
             assert float(pre[diff].abs().max()) < 1e-5, "a unit far from zero was gated differently"
-    assert flips < 200 and units > 1e7, (flips, units)
+    assert flips < 200 and units > 2e6, (flips, units)
     ggate, _ = oracle_grads(torch.float64, gates=[g.to(torch.float64) for g in hip_out])
-    g32, _ = oracle_grads(torch.float32)
+    g32 = oracle_grads(torch.float32)[0] if first else g64          # claim (3) is checked on the first case only
     FLIP_FREE_GATE = 2e-5
     rows = []
     for name, p in m.named_parameters():
@@ -227,7 +236,7 @@ def test_gradient_gap_is_relu_gate_flips():
             continue
         rows.append((name, rel_l2(p.grad, ggate[name]), rel_l2(p.grad, g64[name]), rel_l2(g32[name], g64[name])))
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/parity_gate_flips.txt", "w") as f:
+    with open(f"gpurun_out/parity_gate_flips_{cfg_name}_B{B}.txt", "w") as f:
         f.write(f"# {flips} of {units} ReLU units gated differently by the HIP path and the fp64 oracle\n")
         f.write("# hip_vs_fp64_under_hip_gates  hip_vs_fp64  oracle_fp32_vs_fp64  parameter\n")
         for name, a, b, c in sorted(rows, key=lambda r: -r[2]):
@@ -237,7 +246,45 @@ def test_gradient_gap_is_relu_gate_flips():
     # (3) with the flips taken out, the HIP path is as close to exact arithmetic as stock fp32 torch is to its own fp64
     # run (which of the two flips a unit in a given run is chance: their summation orders differ)
     med = lambda xs: sorted(xs)[len(xs) // 2]
-    assert med([a for _, a, _, _ in rows]) <= max(5.0 * med([c for _, _, _, c in rows]), 2e-6)
+    if first:
+        assert med([a for _, a, _, _ in rows]) <= max(5.0 * med([c for _, _, _, c in rows]), 2e-6)
+
+
+@pytest.mark.parametrize("mel_scale", [1e3, 1e-3])
+def test_parity_holds_for_inputs_of_any_magnitude(mel_scale):
+    """The reference runs in fp32 and has no operand-magnitude window; neither has this path: with the mel inputs (and
+    targets) 1000 x larger or smaller than the normalised features the model expects, outputs and gradients still meet
+    the gates of test_forward_backward_vs_oracle (the fp16x3 kernels take their pre-scales from measured maxima)."""
+    from oracle import synth_batch, oracle_forward, oracle_loss
+    from transformertts_amd.loss import TransformerTTSLoss
+    cfg_name, B, Tp, Tm, w_seed, b_seed = "base", 2, 60, 300, 12, 22
+    cfg, m = _build(cfg_name, w_seed)
+    batch = synth_batch(B, Tp, Tm, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=b_seed)
+    batch["melspec"] = batch["melspec"] * mel_scale
+    args = [batch[k].to("cuda") for k in ("phoneme", "melspec", "phoneme_lens", "melspec_lens")]
+    m.train()
+    out = m(*args)
+    loss = TransformerTTSLoss(8.0).to("cuda")(out, args[1], args[3])
+    loss["total"].backward()
+    sd = _oracle64(cfg, w_seed)
+    ref = oracle_forward(sd, cfg, batch["phoneme"], batch["melspec"].double(), batch["phoneme_lens"], batch["melspec_lens"],
+                         training=True, dropout=False)
+    rloss = oracle_loss(ref, batch["melspec"].double(), batch["melspec_lens"])
+    rloss["total"].backward()
+    for k in ("pred_melspec", "post_melspec", "pred_stop"):
+        assert torch.isfinite(out[k]).all() and rel_l2(out[k], ref[k]) < GATE, (k, rel_l2(out[k], ref[k]))
+    for a, r in zip(out["alignments"], ref["alignments"]):
+        assert rel_l2(a, r) < GATE
+    assert abs(loss["total"].item() - rloss["total"].item()) < 1e-5 * abs(rloss["total"].item())
+    bad = {}
+    for name, p in m.named_parameters():
+        rg = sd[name].grad
+        if rg.norm().item() < 1e-7 * max(1.0, sd[name].detach().norm().item()) * max(1.0, mel_scale ** 2):
+            continue
+        e = rel_l2(p.grad, rg)
+        if not e < GRAD_GATE:
+            bad[name] = e
+    assert not bad, bad
 
 
 def test_training_step_surface():

@@ -524,10 +524,10 @@ def test_fp16x3_attention_any_magnitude(vs, qs, ks, causal):
         assert _rel(o, o_ref) < 4 * TOL, _rel(o, o_ref)
 
 
-def _base_module(seed=5):
+def _base_module(seed=5, cfg_name="base"):
     from oracle.spec import model_config, fill_state
     from transformertts_amd.lightning_module import LightningModule
-    cfg = model_config("base")
+    cfg = model_config(cfg_name)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
               "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,
                            "sync_loss_every_step": False}}
@@ -536,16 +536,18 @@ def _base_module(seed=5):
     return cfg, lm
 
 
-def test_full_size_batch_composition_invariance():
-    """BASELINE batch (64 ragged LJSpeech-shaped utterances, eval mode): an utterance's outputs do not depend on what it
-    is batched with -- the masks, the conv / go-frame clipping at utterance ends and the padding never leak."""
+@pytest.mark.parametrize("cfg_name,B", [("base", 64), ("scaled", 32)])
+def test_full_size_batch_composition_invariance(cfg_name, B):
+    """BASELINE batch (64 ragged LJSpeech-shaped utterances; 32 for the scaled model = the per-GPU shard of configs[4];
+    eval mode): an utterance's outputs do not depend on what it is batched with -- the masks, the conv / go-frame clipping
+    at utterance ends and the padding never leak."""
     from oracle.synth import synth_batch
-    cfg, lm = _base_module()
+    cfg, lm = _base_module(cfg_name=cfg_name)
     lm.eval()
-    batch = {k: v.to(_dev()) for k, v in synth_batch(64, 100, 870, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=3).items()}
+    batch = {k: v.to(_dev()) for k, v in synth_batch(B, 100, 870, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=3).items()}
     with torch.no_grad():
         full = lm.model(batch["phoneme"], batch["melspec"], batch["phoneme_lens"], batch["melspec_lens"])
-        idx = [0, 17, 40, 63]
+        idx = [0, 17, B // 2 + 8, B - 1]
         pl, ml = batch["phoneme_lens"][idx], batch["melspec_lens"][idx]
         Tp, Tm = int(pl.max()), int(ml.max())
         sub = lm.model(batch["phoneme"][idx][:, :Tp].contiguous(), batch["melspec"][idx][:, :Tm].contiguous(), pl, ml)
@@ -560,16 +562,18 @@ def test_full_size_batch_composition_invariance():
         assert float(full["alignments"][-1][i, :, :m, p:].abs().max()) == 0.0 if p < full["alignments"][-1].size(-1) else True
 
 
-def test_full_size_training_step_is_reproducible():
+@pytest.mark.parametrize("cfg_name,B", [("base", 64), ("scaled", 32)])
+def test_full_size_training_step_is_reproducible(cfg_name, B):
     """Two BASELINE-size training steps from the same state and seeds: bit-identical loss and gradient bucket (fixed-order
-    reductions everywhere, no floating-point atomics), and a different dropout seed changes them."""
+    reductions everywhere, no floating-point atomics), and a different dropout seed changes them.  Also for the scaled
+    model at its per-GPU shard size (configs[4]: batch 32 x 870 frames, d_model 512, 6+6 layers, 8 heads)."""
     from oracle.synth import synth_batch
     from transformertts_amd import ops
     from transformertts_amd.parallel import FlatGradBucket
-    cfg, lm = _base_module()
+    cfg, lm = _base_module(cfg_name=cfg_name)
     lm.train()
     bucket = FlatGradBucket(lm.parameters())
-    batch = {k: v.to(_dev()) for k, v in synth_batch(64, 100, 870, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=4).items()}
+    batch = {k: v.to(_dev()) for k, v in synth_batch(B, 100, 870, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=4).items()}
     bn0 = {k: v.clone() for k, v in lm.state_dict().items() if "running" in k or "num_batches" in k}
 
     def run(seed):

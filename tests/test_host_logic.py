@@ -22,10 +22,42 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in ttts_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.ttts_abi_version() >= 6
+    assert lib.ttts_abi_version() >= 7
     # size queries are pure host functions: callable without a GPU
     assert lib.ttts_wgrad_workspace_bytes(55680, 256, 256, 5) > 0
     assert lib.ttts_layernorm_bwd_workspace_bytes(256) > 0
+    # so is the one host-side object of the ABI, the caller-owned reduction queue
+    q = lib.ttts_reduce_queue_create()
+    assert q and lib.ttts_reduce_queue_pending(q) == 0 and lib.ttts_reduce_queue_clear(q) == 0
+    lib.ttts_reduce_queue_destroy(q)
+
+
+def test_library_keeps_no_hidden_configuration():
+    """The product library reads no environment variables (round 2 had development knobs behind getenv) and keeps no
+    process-wide queue: checked on the sources and on the built object's imports."""
+    import glob
+    import subprocess
+    for src in glob.glob(os.path.join(REPO, "transformertts_amd", "csrc", "*")):
+        assert "getenv" not in open(src).read(), src
+    from transformertts_amd import _lib
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
+
+
+def test_bench_workload_is_the_oracles_workload():
+    """bench.py and the launchers draw configurations and synthetic batches from transformertts_amd/workload.py (the product
+    path must not import oracle/); the parity tests draw them from oracle/spec.py / oracle/synth.py.  The two copies must
+    stay the same thing."""
+    from oracle import spec, synth
+    from transformertts_amd import workload
+    for name in ("base", "scaled", "tiny"):
+        assert workload.model_config(name) == spec.model_config(name), name
+    for kw in (dict(B=4, Tp=100, Tm=870, ragged=False, seed=1234), dict(B=7, Tp=60, Tm=300, ragged=True, seed=5),
+               dict(B=3, Tp=12, Tm=40, n_mels=16, n_phon=30, ragged=True, seed=21)):
+        a, b = workload.synth_batch(**kw), synth.synth_batch(**kw)
+        assert a.keys() == b.keys()
+        for k in a:
+            assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), (kw, k)
 
 
 def test_error_path_without_gpu():

@@ -52,40 +52,55 @@ def _check_grads(g, sd, tol):
     return worst
 
 
-@pytest.mark.parametrize("name", ["tiny_model", "base_model"])
-def test_forward_eval_and_train(golden_dir, name):
+# The scaled configuration (12 layers of d_model 512, d_ffn 2048) is held against the reference with the oracle evaluated
+# in fp64: two fp32 evaluations of that depth each gate a few of their 2.5e6 ReLU units differently from exact arithmetic
+# (see tests/test_hip_model.py::test_gradient_gap_is_relu_gate_flips), so fp32-vs-fp32 gradients differ by up to 8e-4,
+# while exact arithmetic of the restatement reproduces the reference's fp32 gradients to 5.5e-5 and its outputs to
+# 2.5e-5 (the reference's own fp32 rounding through the 512-channel post-net): measured when the fixture was generated.
+@pytest.mark.parametrize("name,dtype,out_tol,grad_tol", [("tiny_model", torch.float32, OUT_TOL, GRAD_TOL),
+                                                         ("base_model", torch.float32, OUT_TOL, GRAD_TOL),
+                                                         ("scaled_model", torch.float64, 5e-5, 2e-4)])
+def test_forward_eval_and_train(golden_dir, name, dtype, out_tol, grad_tol):
     g = _load(golden_dir, name)
     cfg, sd, batch = _setup(g)
     st = int(g["meta/align_stride"])
-    args = (batch["phoneme"], batch["melspec"], batch["phoneme_lens"], batch["melspec_lens"])
+
+    def state():
+        sd_ = fill_state(cfg, int(g["meta/w_seed"]))
+        for k in list(sd_):
+            if sd_[k].is_floating_point():
+                sd_[k] = sd_[k].to(dtype)
+        return sd_
+    args = (batch["phoneme"], batch["melspec"].to(dtype), batch["phoneme_lens"], batch["melspec_lens"])
+    sd = state()
     with torch.no_grad():
         out = oracle_forward(sd, cfg, *args, training=False)
     for k in ("pred_melspec", "post_melspec", "pred_stop"):
-        assert rel_l2(out[k], torch.from_numpy(g[f"eval/{k}"])) < OUT_TOL, k
+        assert rel_l2(out[k], torch.from_numpy(g[f"eval/{k}"])) < out_tol, k
     for i, a in enumerate(out["alignments"]):
-        assert rel_l2(a[:, :, ::st], torch.from_numpy(g[f"eval/align{i}"])) < OUT_TOL
+        assert rel_l2(a[:, :, ::st], torch.from_numpy(g[f"eval/align{i}"])) < out_tol
 
-    sd = fill_state(cfg, int(g["meta/w_seed"]))
+    sd = state()
     for k, v in sd.items():
         if v.is_floating_point() and "running" not in k and k != "pe.pe":
             v.requires_grad_(True)
     out = oracle_forward(sd, cfg, *args, training=True, dropout=False)
     for k in ("pred_melspec", "post_melspec", "pred_stop"):
-        assert rel_l2(out[k], torch.from_numpy(g[f"train/{k}"])) < OUT_TOL, k
+        assert rel_l2(out[k], torch.from_numpy(g[f"train/{k}"])) < out_tol, k
     for i, a in enumerate(out["alignments"]):
-        assert rel_l2(a[:, :, ::st], torch.from_numpy(g[f"train/align{i}"])) < OUT_TOL
-    loss = oracle_loss(out, batch["melspec"], batch["melspec_lens"])
+        assert rel_l2(a[:, :, ::st], torch.from_numpy(g[f"train/align{i}"])) < out_tol
+    loss = oracle_loss(out, args[1], batch["melspec_lens"])
     for k in ("total", "pred_mel", "post_mel", "stop"):
         assert abs(loss[k].item() - float(g[f"train/loss_{k}"])) < 1e-5 * max(1.0, abs(float(g[f"train/loss_{k}"])))
     loss["total"].backward()
-    _check_grads(g, sd, GRAD_TOL)
+    _check_grads(g, sd, grad_tol)
     for k in [k for k in g.files if k.startswith("bn/")]:
         name_ = k.split("/", 1)[1]
         ref = torch.from_numpy(np.asarray(g[k]))
         if ref.dtype == torch.int64:
             assert int(sd[name_]) == int(ref)
         else:
-            assert rel_l2(sd[name_], ref) < OUT_TOL, name_
+            assert rel_l2(sd[name_], ref) < out_tol, name_
 
 
 def test_training_step(golden_dir):

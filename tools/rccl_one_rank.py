@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""RCCL on the one GPU a build box has: a ONE-rank process group over the real "nccl" backend (= RCCL on ROCm).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port P tools/rccl_one_rank.py
+
+Exercises what an 8-GPU node runs for the first time otherwise: process-group init with a device id, the broadcast of the
+module state, `ReduceOp.AVG` over the flat gradient bucket enqueued right behind a HIP-graph replay on the same stream,
+and the optimizer kernels behind the collective.  Checks (printed as one JSON line, exit code 1 on failure):
+  * a one-rank mean leaves the bucket bit for bit unchanged;
+  * N steps through the data-parallel launch path (graph = zero-grad .. backward, then collective, then clip + Adam)
+    end in exactly the parameters / moments / BatchNorm buffers of N steps through the single-process path (graph
+    including the optimizer), dropout on.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def main():
+    cfg_name = sys.argv[1] if len(sys.argv) > 1 else "base"
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=dev)
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+
+    from transformertts_amd.lightning_module import LightningModule
+    from transformertts_amd.parallel import broadcast_module_state
+    from transformertts_amd.step import TrainStep
+    from transformertts_amd.workload import model_config, synth_batch
+
+    cfg = model_config(cfg_name)
+    config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
+              "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 50,
+                           "sync_loss_every_step": False, "fused_clip_norm": 1.0}}
+    B, Tp, Tm = (4, 60, 300) if cfg_name != "tiny" else (3, 12, 40)
+    batch = {k: v.to(dev) for k, v in synth_batch(B, Tp, Tm, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=8).items()}
+    out = {"backend": dist.get_backend(), "world": dist.get_world_size(), "config": cfg_name, "steps": steps}
+    runs = []
+    for force in (False, True):
+        torch.manual_seed(42)
+        lm = LightningModule(config).to(dev)
+        lm.train()
+        broadcast_module_state(lm, force=force)            # RCCL broadcast of every parameter and buffer
+        oc = lm.configure_optimizers()
+        opt, sch = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+        ts = TrainStep(lm, opt, sch, batch, graph=True, seed=77, force_collective=force)
+        losses = [ts().detach().clone() for _ in range(steps)]
+        torch.cuda.synchronize()
+        assert ts.graphed
+        if force:
+            before = opt.bucket.flat.clone()
+            dist.all_reduce(opt.bucket.flat, op=dist.ReduceOp.AVG)
+            torch.cuda.synchronize()
+            out["one_rank_mean_leaves_bucket_unchanged"] = bool(torch.equal(before, opt.bucket.flat))
+        runs.append((losses, opt.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
+                     {k: v.clone() for k, v in lm.model.state_dict().items() if "running" in k}))
+    a, b = runs
+    out["losses_equal"] = all(torch.equal(x, y) for x, y in zip(a[0], b[0]))
+    out["state_equal"] = bool(torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+                              and all(torch.equal(a[4][k], b[4][k]) for k in a[4]))
+    out["final_loss"] = float(a[0][-1])
+    out["ok"] = bool(out["losses_equal"] and out["state_equal"] and out["one_rank_mean_leaves_bucket_unchanged"])
+    print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if out["ok"] else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -36,6 +36,9 @@ class FlatGradBucket:
             from . import ops
             self.queue = ops.ReduceQueue()
         self._tail = None
+        # True: run the collectives even in a one-rank group (rehearsing the RCCL path on a single GPU: init, AVG over
+        # the bucket behind a graph replay, the optimizer behind the collective)
+        self.force_collective = False
         self.attach()
 
     def attach(self) -> None:
@@ -66,9 +69,15 @@ class FlatGradBucket:
             self.flat.zero_()
         self.attach()
 
+    def _solo(self, group) -> bool:
+        """No exchange to do: no process group, or a group of one (unless `force_collective`)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return True
+        return dist.get_world_size(group) == 1 and not self.force_collective
+
     def allreduce_mean(self, group: Optional[dist.ProcessGroup] = None, async_op: bool = False):
         self.flush_reductions()
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if self._solo(group):
             return None
         if dist.get_backend(group) == "gloo":   # gloo has no AVG; device buffers are staged through the host
             if self.flat.is_cuda:
@@ -113,7 +122,7 @@ class FlatGradBucket:
         """Begin the (asynchronous) mean all-reduce of flat[lo:].  Call it from a backward hook once every gradient in
         that range is final; every rank must call it at the same point of its step."""
         self.flush_reductions()
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if self._solo(group):
             return
         if getattr(self, "_tail", None) is not None:
             raise RuntimeError("start_tail_allreduce: a tail reduction is already in flight")
@@ -123,7 +132,7 @@ class FlatGradBucket:
         """Reduce whatever `start_tail_allreduce` has not covered and wait for the tail: after this the whole bucket
         holds the mean gradient.  Without a started tail it is `allreduce_mean()`."""
         self.flush_reductions()
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if self._solo(group):
             return
         tail = getattr(self, "_tail", None)
         self._tail = None
@@ -228,9 +237,9 @@ def overlap_tail_with_backward(bucket: FlatGradBucket, model: torch.nn.Module, b
     return _TailTrigger(boundary, lo, on_ready, before=bucket.flush_reductions)
 
 
-def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) -> None:
-    """Make every replica start from rank `src`'s parameters and buffers."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None, force: bool = False) -> None:
+    """Make every replica start from rank `src`'s parameters and buffers (`force`: also in a one-rank group)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return
     stage = dist.get_backend(group) == "gloo"
     for t in list(module.parameters()) + list(module.buffers()):

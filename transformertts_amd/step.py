@@ -73,7 +73,8 @@ class _Slot:
 class TrainStep:
     def __init__(self, lm, optimizer: FlatAdam, scheduler, batch: Optional[Dict[str, torch.Tensor]] = None, *,
                  graph: bool = True, seed: int = 0, group=None, overlap: bool = False, eager_warmup: int = 2,
-                 accumulate: int = 1, lattice: Optional[Tuple[int, int]] = None, max_shapes: int = 64):
+                 accumulate: int = 1, lattice: Optional[Tuple[int, int]] = None, max_shapes: int = 64,
+                 force_collective: bool = False):
         """`lm`: the LightningModule counterpart (training_step surface).  `batch` (optional): device tensors with the keys
         of the reference's collate_fn; its shape gets the first set of static buffers.  Later batches of any shape are
         copied into the static buffers of THEIR shape (`__call__(batch)` / `load`), created on first sight.
@@ -81,7 +82,8 @@ class TrainStep:
         `accumulate=k`: gradients of k micro-batches are summed (each scaled by 1/k, as Lightning's
         accumulate_grad_batches does, train.py:42) before the optimizer steps.  `lattice=(p, m)`: see the module text.
         `overlap=True` (eager mode, N > 1 only) starts the all-reduce of the decoder / postnet / head gradients while
-        backward is still in the encoder."""
+        backward is still in the encoder.  `force_collective=True` takes the data-parallel path (graph ends after backward,
+        collective + optimizer behind it) in a one-rank process group too: RCCL on a single GPU."""
         if not isinstance(optimizer, FlatAdam):
             raise TypeError("TrainStep drives FlatAdam (flat parameter / gradient / moment buffers)")
         self.lm, self.opt, self.sched, self.group = lm, optimizer, scheduler, group
@@ -104,8 +106,12 @@ class TrainStep:
         self._planes: Optional[ops.PlaneTable] = None
         import torch.distributed as dist
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if force_collective and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("TrainStep(force_collective=True) needs an initialised process group")
+        self.bucket.force_collective = bool(force_collective)
+        self.dp = self.world > 1 or bool(force_collective)       # the optimizer runs behind a collective, outside the graph
         self.trigger = None
-        if overlap and self.world > 1 and not self.use_graph:
+        if overlap and self.dp and not self.use_graph:
             self.trigger = overlap_tail_with_backward(self.bucket, lm.model, lm.model.decoder, group)
         if batch is not None:
             self.load(batch)
@@ -222,7 +228,7 @@ class TrainStep:
                 self._capture(slot, role)
             slot.graphs[role].replay()
             if last:
-                if self.world == 1:
+                if not self.dp:
                     self.opt.note_external_step()
                 else:
                     with self.state:
@@ -249,7 +255,7 @@ class TrainStep:
             with torch.cuda.graph(g, pool=self._pool):
                 with self.state:
                     slot.losses[role] = self._forward_backward(role, capturing=True)
-                    if role in ("full", "last") and self.world == 1:
+                    if role in ("full", "last") and not self.dp:
                         self.opt.step()
         finally:
             self._cur = prev
