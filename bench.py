@@ -254,7 +254,7 @@ def main():
     ap.add_argument("--cycle", type=int, default=1, help="number of distinct ragged batch shapes fed round-robin")
     ap.add_argument("--lattice", default="", help="P,M: pad batches to multiples of P phonemes / M frames (graph-cache key)")
     ap.add_argument("--accumulate", type=int, default=1, help="micro-batches per optimizer step (train.py:42 uses 4)")
-    ap.add_argument("--sustain", type=float, default=10.0, help="seconds of further replays after the timed steps (0: skip)")
+    ap.add_argument("--sustain", type=float, default=float(os.environ.get("TTTS_BENCH_SUSTAIN", "10")), help="seconds of further replays after the timed steps (0: skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

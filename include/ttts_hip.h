@@ -37,6 +37,9 @@ extern "C" {
 #define TTTS_ERR_INVALID (-1) /* bad argument (shape, alignment, null pointer) */
 #define TTTS_ERR_LAUNCH (-2)  /* hipLaunchKernel reported an error */
 
+/* length of every partial-maxima array (`*_amax`, `*_amax_out`) of this header, in floats */
+#define TTTS_AMAX_SLOTS 256
+
 #define TTTS_ACT_NONE 0
 #define TTTS_ACT_RELU 1
 #define TTTS_ACT_TANH 2
@@ -112,13 +115,13 @@ int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db
  * ttts_linear_fwd_h3 / ttts_conv1d_fwd_h3 take such planes and form each product from three f16 x f16 MFMA terms
  * (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi): the same fp32-grade result (error vs fp64 a few 1e-7) for half the matrix-pipe
  * work.  f16 has no bf16-like exponent range, so the ACTIVATION operand is pre-scaled while it is staged, by the power
- * of two that puts ITS measured maximum in [2^11, 2^12): `x_amax` = 1024 partial maxima of |x| (their maximum must be
+ * of two that puts ITS measured maximum in [2^11, 2^12): `x_amax` = 256 partial maxima of |x| (their maximum must be
  * >= max|x|; ttts_amax_partials computes them with one read of x, and every kernel of this header that PRODUCES an
  * activation or a gradient can leave them behind itself: the `*_amax_out` arguments).  Every element within 2^-15 of the
  * largest keeps 22 significant bits, smaller ones an absolute error of 2^-37 * max|x| -- no assumption about the operands'
  * magnitudes is left.
- * Arrays named `*_amax_out` are filled with slot-wise atomic maxima and must be zeroed by the caller first (ttts_zero);
- * `*_amax_partials` are fully written. */
+ * Every such array has TTTS_AMAX_SLOTS floats.  Arrays named `*_amax_out` are filled with slot-wise atomic maxima and must
+ * be zeroed by the caller first (ttts_zero); only ttts_amax_partials writes its array in full. */
 size_t ttts_split_bytes(int64_t rows, int64_t cols);
 /* tile shape the forward / data-gradient dispatch uses for an M x N output with reduction length K (1: 64x64, 2: 128x128,
  * 3: 64x128, 4: 128x96; fp16x3 only: 6: 256x256 / 8 waves, 7: 256x128 / 8 waves, 8: 256x128 / 4 waves, two workgroups per
@@ -132,7 +135,7 @@ int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks,
 int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
                        int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift, int T,
                     void* stream);
-/* y_amax_out: NULL, or a caller-zeroed 1024-float array receiving max|y| (y feeds another fp16x3 GEMM / attention) */
+/* y_amax_out: NULL, or a caller-zeroed 256-float array receiving max|y| (y feeds another fp16x3 GEMM / attention) */
 int ttts_linear_fwd_h3(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
                        int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift,
                        int T, const float* x_amax, float* y_amax_out, void* stream);
@@ -140,7 +143,7 @@ int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias
                        int taps, const float* x_amax, void* stream);
 /* fp16x3 data gradients: as the forward, with the gradient as the activation operand (dy_amax: its partial maxima;
  * 1e-7 .. 1e-5 behind a mean-reduced loss, any magnitude in general).  planes: modes 5 / 7. */
-int ttts_amax_partials(const float* x, int64_t n, float* partials /* 1024 floats */, void* stream);
+int ttts_amax_partials(const float* x, int64_t n, float* partials /* TTTS_AMAX_SLOTS floats, fully written */, void* stream);
 int ttts_linear_bwd_data_h3(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
                             int K, const float* relu_out, float relu_scale, const float* dy_amax, float* dx_amax_out,
                             void* stream);
@@ -193,28 +196,28 @@ int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* runni
                         float eps, void* stream);
 int ttts_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C, float eps,
                        void* stream);
-/* z = drop(act((x - mean) * invstd * gamma + beta)); z_amax_out: NULL, or a caller-zeroed 1024-float array receiving max|z| */
+/* z = drop(act((x - mean) * invstd * gamma + beta)); z_amax_out: NULL, or a caller-zeroed 256-float array receiving max|z| */
 int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       float* z, int64_t M, int C, int act, float drop_p, uint64_t seed, const uint64_t* step_seed,
                       float* z_amax_out, void* stream);
 /* train-mode backward through drop/act/BN: dx, dgamma, dbeta from dz and the saved x, mean, invstd */
 int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float* invstd, const float* gamma,
                 const float* beta, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int C,
-                int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate, float* dx_amax_partials,
+                int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate, float* dx_amax_out,
                 void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm over the last dim (d % 64 == 0, d <= 1024)
  * Replaces nn.LayerNorm norm1/2/3 of the encoder/decoder layers (torch/nn/modules/transformer.py:951-956,
  * model/layers.py:47-50).  The residual sum is produced by the preceding GEMM's epilogue. */
 int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                       int64_t M, int d, float eps, float* y_amax_out /* NULL, or zeroed 1024 floats: max|y| */, void* stream);
+                       int64_t M, int d, float eps, float* y_amax_out /* NULL, or zeroed 256 floats: max|y| */, void* stream);
 size_t ttts_layernorm_bwd_workspace_bytes(int d);
 int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
                        int accumulate, ttts_reduce_queue* queue, void* stream);
 /* the same, and in the same pass dacc = dx * keep(seed, element) / (1 - drop_p): the gradient behind the residual dropout
  * of the sublayer whose output this LayerNorm normalised (ttts_dropout_bwd(dx) without a pass of its own; same mask as
- * the forward epilogue of that sublayer's last Linear).  dacc_amax: NULL, or a caller-zeroed 1024-float array that receives
+ * the forward epilogue of that sublayer's last Linear).  dacc_amax: NULL, or a caller-zeroed 256-float array that receives
  * partial maxima of |dacc|.  d in {256, 512, 1024}, operands 16-byte aligned. */
 int ttts_layernorm_bwd_drop(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                             float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
@@ -244,8 +247,8 @@ int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float*
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 /* fp16x3 form of the forward (three f16 MFMA terms; Q/8, K and V pre-scaled from their partial maxima q_amax / k_amax /
- * v_amax -- 1024 floats each, the same array three times for a packed projection output -- and probabilities x 2^10);
- * lse in natural units, so either backward form can follow it.  o_amax_out: NULL, or zeroed 1024 floats: max|o|. */
+ * v_amax -- 256 floats each, the same array three times for a packed projection output -- and probabilities x 2^10);
+ * lse in natural units, so either backward form can follow it.  o_amax_out: NULL, or zeroed 256 floats: max|o|. */
 int ttts_attention_fwd_h3(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* q_amax,
@@ -255,7 +258,7 @@ int ttts_attention_bwd_x6(const float* q, const float* k, const float* v, const 
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 /* fp16x3 form of the backward.  d_o is pre-scaled by the power of two that puts max|d_o| in [2^11, 2^12) (do_amax = the
- * 1024 partial maxima of ttts_amax_partials(d_o)); dS = P (dP - delta) lives in registers as a lane-local accumulator
+ * 256 partial maxima of ttts_amax_partials(d_o)); dS = P (dP - delta) lives in registers as a lane-local accumulator
  * column and gets a lane-local pre-scale that is lowered on the fly together with its accumulator. */
 int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
@@ -267,24 +270,25 @@ int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const 
 /* ------------------------------------------------------------------ small row / element-wise pieces
  * nn.Embedding gather / scatter-add (model/model.py:168,288; no padding_idx) */
 int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d,
-                       float* out_amax_out /* NULL, or zeroed 1024 floats: max|out| */, void* stream);
+                       float* out_amax_out /* NULL, or zeroed 256 floats: max|out| */, void* stream);
 int ttts_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t n, int vocab, int d, int accumulate,
                        void* stream);
 /* PositionalEncoding.forward (model/model.py:91-97): y = drop(x + alpha * pe[t]) */
 int ttts_posenc_fwd(const float* x, const float* pe, const float* alpha, float* y, int B, int T, int d, float drop_p,
-                    uint64_t seed, const uint64_t* step_seed, float* y_amax_out /* NULL, or zeroed 1024 floats */, void* stream);
+                    uint64_t seed, const uint64_t* step_seed, float* y_amax_out /* NULL, or zeroed 256 floats */, void* stream);
 size_t ttts_posenc_bwd_workspace_bytes(void);
 int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, float* ws, size_t ws_bytes, int B, int T,
                     int d, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate, void* stream);
-/* dx = dy * 1[out > 0] / (1-p): backward of drop(relu(.)) given the forward output.  amax_partials (NULL, or 1024
- * floats): also emit the partial maxima of |dx| that ttts_amax_partials(dx) would produce -- the dynamic pre-scale input of
+/* dx = dy * 1[out > 0] / (1-p): backward of drop(relu(.)) given the forward output.  dx_amax_out (NULL, or zeroed
+ * TTTS_AMAX_SLOTS floats): also leave the partial maxima of |dx| behind -- the dynamic pre-scale input of
  * the fp16x3 gradient GEMMs that consume dx -- without a second pass over it. */
-int ttts_relu_dropout_bwd(const float* dy, const float* out, float* dx, int64_t n, float drop_p, float* amax_partials,
+int ttts_relu_dropout_bwd(const float* dy, const float* out, float* dx, int64_t n, float drop_p, float* dx_amax_out,
                           void* stream);
-/* dx = dy * keep(seed, i) / (1-p); amax_partials as above */
+/* dx = dy * keep(seed, i) / (1-p); dx_amax_out as above */
 int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64_t seed, const uint64_t* step_seed,
-                     float* amax_partials, void* stream);
-/* p[0 .. nbytes) = 0, enqueued as a memset on the stream (the flat gradient bucket at the start of a step) */
+                     float* dx_amax_out, void* stream);
+/* p[0 .. nbytes) = 0 by a fill kernel on the stream (the flat gradient bucket and the partial-maxima arrays at the start of
+ * a step; p and nbytes multiples of 4).  Deliberately not hipMemsetAsync: see csrc/elementwise.hip. */
 int ttts_zero(void* p, size_t nbytes, void* stream);
 /* z = x + y */
 int ttts_add(const float* x, const float* y, float* z, int64_t n, void* stream);
@@ -320,9 +324,11 @@ int ttts_loss_bwd(const float* pred, const float* post, const float* stop, const
  * prediction when any u[t-l_bar/2 .. t-l_bar/2+l_bar-1] < 1-p_tf (max_pool1d(k=l_bar, s=1, pad=l_bar/2)[:T]), the
  * ground truth otherwise, and zero beyond lens[b].  u == NULL: the draw (torch.rand of utils/util.py:108) is generated
  * in the kernel from `seed` (a counter-based uniform per frame).  st != NULL: p_tf and the seed word of the step are
- * read from device memory when the kernel runs (p_tf by value is ignored). */
+ * read from device memory when the kernel runs (p_tf by value is ignored).
+ * out_amax_out: NULL, or a caller-zeroed 256-float array receiving max|out|. */
 int ttts_sched_sampling_mix(const float* pred, const float* mel, const float* u, const int64_t* lens, float* out, int B,
-                            int T, int C, float p_tf, int l_bar, uint64_t seed, const ttts_step_state* st, void* stream);
+                            int T, int C, float p_tf, int l_bar, uint64_t seed, const ttts_step_state* st,
+                            float* out_amax_out, void* stream);
 
 /* ------------------------------------------------------------------ optimizer over flat buffers
  * Global L2 norm of the flat gradient bucket (clip_grad_norm_, train.py:41) and one torch.optim.Adam step

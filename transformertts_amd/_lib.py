@@ -82,7 +82,7 @@ SIGNATURES = {
     "ttts_reduce_queue_pending": (L, [P]),
     "ttts_reduce_queue_flush": (I, [P, P]),
     "ttts_reduce_queue_clear": (I, [P]),
-    "ttts_sched_sampling_mix": (I, [P, P, P, P, P, I, I, I, F, I, U, P, P]),
+    "ttts_sched_sampling_mix": (I, [P, P, P, P, P, I, I, I, F, I, U, P, P, P]),
     "ttts_grad_norm_workspace_bytes": (Z, []),
     "ttts_grad_norm": (I, [P, P, P, Z, L, P]),
     "ttts_adam_step": (I, [P, P, P, P, P, L, F, F, F, F, L, F, P, P]),

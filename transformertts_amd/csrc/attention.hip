@@ -63,9 +63,9 @@ struct AttnArgs {
     int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
     float drop_scale; uint32_t thr; uint64_t seed; const uint64_t* step_seed;
     const float* do_amax; int do_amax_n;      // fp16x3 backward: partial maxima of |dout| (ttts_amax_partials)
-    float* amax_dq; float* amax_dkv;          // fp16x3 backward: NULL, or caller-zeroed 1024-slot arrays receiving max|dq| / max|dk, dv|
-    // fp16x3 forms: 1024 partial maxima of |q|, |k|, |v| each (the same array three times for a packed projection output):
-    // the operands' dynamic pre-scales.  o_amax (forward): NULL, or a caller-zeroed 1024-slot array receiving max|o|.
+    float* amax_dq; float* amax_dkv;          // fp16x3 backward: NULL, or caller-zeroed TTTS_AMAX_SLOTS-slot arrays receiving max|dq| / max|dk, dv|
+    // fp16x3 forms: TTTS_AMAX_SLOTS partial maxima of |q|, |k|, |v| each (the same array three times for a packed projection output):
+    // the operands' dynamic pre-scales.  o_amax (forward): NULL, or a caller-zeroed TTTS_AMAX_SLOTS-slot array receiving max|o|.
     const float* q_amax; const float* k_amax; const float* v_amax;
     float* o_amax;
 };
@@ -867,11 +867,15 @@ __device__ __forceinline__ float sgpr(float x) { return __uint_as_float(__builti
 __device__ __forceinline__ H3Scales attn_h3_scales(const float* q_amax, const float* k_amax, const float* v_amax, int lane) {
     H3Scales h;
     float s, i;
-    h3_pow2_scale(0.125f * h3_partials_max(q_amax, 1024, lane), s, i);   // Q is multiplied by 1/8 before it is split
+    // a packed projection output passes the same array three times: read it once (wave-uniform branches)
+    const float mq = h3_partials_max(q_amax, TTTS_AMAX_SLOTS, lane);
+    const float mk = (k_amax == q_amax) ? mq : h3_partials_max(k_amax, TTTS_AMAX_SLOTS, lane);
+    const float mv = (v_amax == k_amax) ? mk : (v_amax == q_amax) ? mq : h3_partials_max(v_amax, TTTS_AMAX_SLOTS, lane);
+    h3_pow2_scale(0.125f * mq, s, i);                                    // Q is multiplied by 1/8 before it is split
     h.sq = sgpr(s); h.inv_sq = sgpr(i);
-    h3_pow2_scale(h3_partials_max(k_amax, 1024, lane), s, i);
+    h3_pow2_scale(mk, s, i);
     h.sk = sgpr(s); h.inv_sk = sgpr(i);
-    h3_pow2_scale(h3_partials_max(v_amax, 1024, lane), s, i);
+    h3_pow2_scale(mv, s, i);
     h.sv = sgpr(s); h.inv_sv = sgpr(i);
     h.c = h.inv_sq * h.inv_sk;
     h.c2 = h.c * 1.4426950408889634f;
@@ -2219,7 +2223,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
     a.seed = seed; a.step_seed = step_seed;
     dim3 gq(B * H, cdiv(Tq, QB), 1), gk(B * H, cdiv(Tk, QB), 1);
     if (form == 2) {
-        a.do_amax = do_amax; a.do_amax_n = 1024;
+        a.do_amax = do_amax; a.do_amax_n = TTTS_AMAX_SLOTS;
         a.amax_dq = dq_amax_out; a.amax_dkv = dkv_amax_out;
         a.q_amax = q_amax; a.k_amax = k_amax; a.v_amax = v_amax;
         return causal ? launch_bwd_h3<true>(a, gq, gk, stream) : launch_bwd_h3<false>(a, gq, gk, stream);

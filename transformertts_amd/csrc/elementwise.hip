@@ -22,6 +22,36 @@ static inline int ew_grid(long n_items) {
     return (int)g;
 }
 
+// ------------------------------------------------------------------ zero fill
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, long n) {
+    // 16-byte stores over the aligned middle, dwords at the ragged ends
+    const long head = (long)(((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) >> 2) < n ? (long)(((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) >> 2) : n;
+    const long n4 = (n - head) / 4;
+    uint4* q = reinterpret_cast<uint4*>(p + head);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0) {
+        if ((long)threadIdx.x < head) p[threadIdx.x] = 0u;
+        const long tail0 = head + n4 * 4;
+        if (tail0 + threadIdx.x < n) p[tail0 + threadIdx.x] = 0u;
+    }
+}
+
+// A fill KERNEL, not hipMemsetAsync: the zeroing of the gradient bucket and of the partial-maxima arrays is part of the
+// captured step graph, and graph memset nodes proved fragile on ROCm 7 (after ANOTHER graph's memory pool had been released
+// with hipFree, replays of a surviving graph saw arrays that were not zeroed; reproduced by tools/dbg_two_models.py).
+int launch_zero(void* p, size_t nbytes, hipStream_t stream) {
+    TTTS_REQUIRE(p != nullptr || nbytes == 0, "zero: null pointer");
+    if (nbytes == 0) return TTTS_OK;
+    TTTS_REQUIRE((((uintptr_t)p) & 3) == 0 && nbytes % 4 == 0, "zero: pointer and size must be multiples of 4 bytes");
+    const long n = (long)(nbytes / 4);
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<uint32_t*>(p), n);
+    TTTS_LAUNCH_CHECK("zero_kernel");
+    return TTTS_OK;
+}
+
 // ------------------------------------------------------------------ embedding
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
                                                             float* __restrict__ out, long n, int vocab, int d4,
@@ -147,14 +177,10 @@ __global__ void scalar_reduce_kernel(const float* __restrict__ ws, float* __rest
 }
 
 // ------------------------------------------------------------------ masks
-// Both mask kernels can also emit the partial maxima of |dx| that ttts_amax_partials would compute in a separate pass
-// (amax != NULL: one entry per block; the launch then uses exactly the 1024 blocks the consumers expect).
+// Both mask kernels can also leave the partial maxima of |dx| behind (amax != NULL: a caller-zeroed TTTS_AMAX_SLOTS array,
+// slot-wise atomic maxima) and save the consumer the separate pass of ttts_amax_partials.
 __device__ __forceinline__ void block_amax_out(float m, float* __restrict__ amax) {
-    __shared__ float red[4];
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    amax_publish(m, amax, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out,
@@ -287,16 +313,7 @@ extern "C" {
 const char* ttts_last_error(void) { return ttts::g_err; }
 int ttts_abi_version(void) { return 7; }
 
-int ttts_zero(void* p, size_t nbytes, void* stream) {
-    TTTS_REQUIRE(p != nullptr || nbytes == 0, "zero: null pointer");
-    if (nbytes == 0) return TTTS_OK;
-    hipError_t e = hipMemsetAsync(p, 0, nbytes, (hipStream_t)stream);
-    if (e != hipSuccess) {
-        ::ttts::set_error("zero: hipMemsetAsync failed: %s", hipGetErrorString(e));
-        return TTTS_ERR_LAUNCH;
-    }
-    return TTTS_OK;
-}
+int ttts_zero(void* p, size_t nbytes, void* stream) { return ::ttts::launch_zero(p, nbytes, (hipStream_t)stream); }
 
 int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d, float* out_amax_out,
                        void* stream) {
@@ -358,7 +375,7 @@ int ttts_relu_dropout_bwd(const float* dy, const float* out, float* dx, int64_t 
                           void* stream) {
     TTTS_REQUIRE(dy && out && dx && n > 0 && n % 4 == 0, "relu_dropout_bwd: bad arguments (n %% 4 must be 0)");
     TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relu_dropout_bwd: bad dropout p");
-    hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(amax_partials ? 1024 : ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream,
                        dy, out, dx, (long)(n / 4), 1.f / (1.f - drop_p), amax_partials);
     TTTS_LAUNCH_CHECK("relu_dropout_bwd_kernel");
     return TTTS_OK;
@@ -368,7 +385,7 @@ int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64
                      float* amax_partials, void* stream) {
     TTTS_REQUIRE(dy && dx && n > 0 && n % 4 == 0, "dropout_bwd: bad arguments (n %% 4 must be 0)");
     TTTS_REQUIRE(drop_p > 0.f && drop_p < 1.f, "dropout_bwd: p must be in (0,1)");
-    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(amax_partials ? 1024 : ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dy,
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dy,
                        dx, (long)(n / 4), 1.f / (1.f - drop_p), drop_threshold(drop_p), seed, step_seed, amax_partials);
     TTTS_LAUNCH_CHECK("dropout_bwd_kernel");
     return TTTS_OK;

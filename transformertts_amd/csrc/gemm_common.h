@@ -45,7 +45,7 @@ struct GemmArgs {
     int a_amax_n;
     const float* b_amax;
     int b_amax_n;
-    // fp16x3 kernel: NULL, or a caller-zeroed 1024-slot array that receives max|C| (amax_publish): the output is a
+    // fp16x3 kernel: NULL, or a caller-zeroed TTTS_AMAX_SLOTS-slot array that receives max|C| (amax_publish): the output is a
     // gradient that another fp16x3 GEMM will consume
     float* c_amax;
 };
@@ -71,7 +71,7 @@ __device__ __forceinline__ void buf_store4s(__amdgpu_buffer_rsrc_t rsrc, uint32_
 
 // ---- fp16x3 ("h3") split: constants and the weight-plane image (see gemm_h3.hip)
 constexpr int HBK = 32;                 // k-tile depth
-constexpr int H3_AMAX_PARTIALS = 1024;  // length of the partial-maxima array of ttts_amax_partials
+constexpr int H3_AMAX_PARTIALS = TTTS_AMAX_SLOTS;  // length of every partial-maxima array (include/ttts_hip.h)
 
 // byte size of the fp16x3 image of a rows x cols weight: two f16 planes, then a 16-byte tail whose first float is max|w|
 // (written by the split, read by every GEMM that takes the planes: the scale the planes were written with follows from it)
@@ -98,8 +98,13 @@ __device__ __forceinline__ void weight_amax_h3_one(const float* __restrict__ w, 
     float m = (i < n) ? fabsf(w[i]) : 0.f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f)
-        atomicMax(reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(planes) + h3_plane_bytes(R, C)), __float_as_uint(m));
+    // every wave of every block of this weight aims at ONE word: look before the atomic (a stale read only costs an atomic
+    // that changes nothing) -- after the first few waves almost none is issued
+    unsigned int* tail = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(planes) + h3_plane_bytes(R, C));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) {
+        const unsigned int cur = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__float_as_uint(m) > cur) atomicMax(tail, __float_as_uint(m));
+    }
 }
 
 // B[r][c] of weight_split (gemm.hip) as two f16 planes of w * scale, stored [c/32][plane][r][c%32]; scale = the power of two

@@ -12,7 +12,7 @@
 // two (exact) taken from their measured maxima (h3_pow2_scale, gemm_common.h): the largest magnitude lands in
 // [2^11, 2^12), every element within 2^-15 of it keeps 22 significant bits, smaller ones an absolute error of 2^-37 of
 // the maximum, and the accumulator is scaled back in the epilogue.  Nothing about the operands' magnitude is assumed:
-//   * activations / gradients: 1024 partial maxima left by the kernel that produced the tensor (GEMM epilogues, LayerNorm,
+//   * activations / gradients: TTTS_AMAX_SLOTS partial maxima left by the kernel that produced the tensor (GEMM epilogues, LayerNorm,
 //     BatchNorm, positional encoding, attention, the dropout / relu backward masks ...) or by ttts_amax_partials (one read);
 //   * weights: max|w| sits in the tail of the plane image, measured by the split itself.
 // A non-finite operand gives a non-finite result, as fp32 arithmetic would.
@@ -39,15 +39,15 @@ __global__ __launch_bounds__(256) void weight_split_h3_kernel(const float* __res
 // tail = 0, max|w| into the tail, then the planes scaled by the power of two that follows from it
 void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, int mode, int c2, int taps, hipStream_t stream) {
     const long n = (long)rows * cols;
-    (void)hipMemsetAsync(reinterpret_cast<char*>(planes) + h3_plane_bytes(rows, cols), 0, 16, stream);
+    (void)launch_zero(reinterpret_cast<char*>(planes) + h3_plane_bytes(rows, cols), 16, stream);
     hipLaunchKernelGGL(weight_amax_h3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, w, (unsigned short*)planes, rows, cols);
     hipLaunchKernelGGL(weight_split_h3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, w, (unsigned short*)planes, rows,
                        cols, mode, c2, taps);
 }
 
 // partial maxima of |x|: block b writes max over its grid-stride share to out[b]; blocks past the data write 0
-__global__ __launch_bounds__(256) void amax_partials_kernel(const float* __restrict__ x, long n4, long n, float* __restrict__ out) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void amax_partials_kernel(const float* __restrict__ x, long n4, long n, float* __restrict__ out) {
+    __shared__ float red[16];
     float m = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -60,7 +60,11 @@ __global__ __launch_bounds__(256) void amax_partials_kernel(const float* __restr
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x < 64) {
+        float r = threadIdx.x < 16 ? red[threadIdx.x] : 0.f;
+        r = wave_max(r);
+        if (threadIdx.x == 0) out[blockIdx.x] = r;
+    }
 }
 
 template <int BM, int BN, int WM, int WN, bool CLIP>
@@ -811,12 +815,12 @@ int dispatch_wgrad_h3(const GemmArgs& g, int zdim, int tile, hipStream_t stream)
 }  // namespace ttts
 
 extern "C" int ttts_amax_partials(const float* x, int64_t n, float* partials, void* stream) {
-    // partials[0 .. 1023] = partial maxima of |x[0 .. n)| (the max over them is max|x|);
+    // partials[0 .. TTTS_AMAX_SLOTS) = partial maxima of |x[0 .. n)| (the max over them is max|x|);
     // feeds the dynamic pre-scale of the gradient operand of the *_h3 backward entry points
     using namespace ttts;
     TTTS_REQUIRE(x && partials && n > 0, "amax_partials: bad arguments");
     TTTS_REQUIRE((((uintptr_t)x) & 15) == 0, "amax_partials: x must be 16-byte aligned");
-    hipLaunchKernelGGL(amax_partials_kernel, dim3(H3_AMAX_PARTIALS), dim3(256), 0, (hipStream_t)stream, x, (long)(n / 4), (long)n,
+    hipLaunchKernelGGL(amax_partials_kernel, dim3(H3_AMAX_PARTIALS), dim3(1024), 0, (hipStream_t)stream, x, (long)(n / 4), (long)n,
                        partials);
     TTTS_LAUNCH_CHECK("amax_partials_kernel");
     return TTTS_OK;

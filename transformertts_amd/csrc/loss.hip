@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void sched_mix_kernel(const float* __restrict__ pred, const float* __restrict__ mel,
                                                         const float* __restrict__ u, const int64_t* __restrict__ lens,
                                                         float* __restrict__ out, int B, int T, int C, float thresh,
-                                                        int l_bar, uint64_t seed, const ttts_step_state* __restrict__ st) {
+                                                        int l_bar, uint64_t seed, const ttts_step_state* __restrict__ st,
+                                                        float* __restrict__ amax_out) {
+    float vmax = 0.f;
     if (st != nullptr) {                 // captured-graph form: this step's ratio and seed word live in device memory
         thresh = 1.0f - st->p_tf;
         seed ^= st->seed;
@@ -152,7 +154,9 @@ __global__ __launch_bounds__(256) void sched_mix_kernel(const float* __restrict_
             v = take_pred ? reinterpret_cast<const float4*>(pred)[i] : reinterpret_cast<const float4*>(mel)[i];
         }
         reinterpret_cast<float4*>(out)[i] = v;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
+    if (amax_out != nullptr) amax_publish(vmax, amax_out, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 static inline int grid_for(long n_items, int cap) {
@@ -198,11 +202,12 @@ int ttts_loss_bwd(const float* pred, const float* post, const float* stop, const
 }
 
 int ttts_sched_sampling_mix(const float* pred, const float* mel, const float* u, const int64_t* lens, float* out, int B,
-                            int T, int C, float p_tf, int l_bar, uint64_t seed, const ttts_step_state* st, void* stream) {
+                            int T, int C, float p_tf, int l_bar, uint64_t seed, const ttts_step_state* st,
+                            float* out_amax_out, void* stream) {
     TTTS_REQUIRE(pred && mel && lens && out, "sched_sampling_mix: null pointer");
     TTTS_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && l_bar > 0, "sched_sampling_mix: bad dims (C %% 4 must be 0)");
     hipLaunchKernelGGL(sched_mix_kernel, dim3(grid_for((long)B * T * (C / 4), 2048)), dim3(256), 0, (hipStream_t)stream, pred,
-                       mel, u, lens, out, B, T, C, 1.0f - p_tf, l_bar, seed, st);
+                       mel, u, lens, out, B, T, C, 1.0f - p_tf, l_bar, seed, st, out_amax_out);
     TTTS_LAUNCH_CHECK("sched_mix_kernel");
     return TTTS_OK;
 }

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // block count is fixed by the partial-sum workspace, so occupancy comes from the block size: 16 waves per CU at d = 256)
 // DROP: also write dacc = dx * keep(seed, element) / (1-p) -- the gradient behind the residual dropout of the sublayer whose
 // output this LayerNorm normalised (what ttts_dropout_bwd would compute from dx in a pass of its own) -- and publish the
-// maximum of |dacc| (atomic maxima into a caller-zeroed 1024-slot array)
+// maximum of |dacc| (atomic maxima into a caller-zeroed TTTS_AMAX_SLOTS-slot array)
 template <int NV, int NW, bool DROP>
 __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -494,13 +494,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         *reinterpret_cast<float4*>(dx + e) = make_float4(o[0], o[1], o[2], o[3]);
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
     }
-    if (amax != nullptr) {           // partial maxima of |dx|, one per block (the launch then has exactly 1024 blocks)
-        __shared__ float red[4];
-        mx = wave_max(mx);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-        __syncthreads();
-        if (threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    }
+    if (amax != nullptr) amax_publish(mx, amax, blockIdx.x * 4 + (threadIdx.x >> 6));    // max|dx| (caller-zeroed slots)
 }
 
 static int bn_blocks(long M, int* rows_per_block) {
@@ -674,7 +668,6 @@ int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float*
     long n4 = (long)M * C / 4;
     int grid = (int)((n4 + 255) / 256);
     if (grid > 4096) grid = 4096;
-    if (dx_amax_partials) grid = 1024;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, dz, x, mean, invstd, gamma, beta, sums, dx, n4,
                        C, 1.0f / (float)M, act, scale, thr, seed, step_seed, dx_amax_partials);
     TTTS_LAUNCH_CHECK("bn_bwd_apply_kernel");

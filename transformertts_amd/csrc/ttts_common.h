@@ -30,6 +30,9 @@ void set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// p[0 .. nbytes) = 0 by a fill kernel (elementwise.hip); pointer and size multiples of 4 bytes
+int launch_zero(void* p, size_t nbytes, hipStream_t stream);
+
 // out0[c] (+)= sum_r ws[r*ld + c] for c < n0, out1[c - n0] for the rest (reduce.hip); fixed summation order
 // `queue` != NULL: nothing later in the same pass reads the result (parameter gradients), so the reduction is appended to
 // the caller's queue (ttts_reduce_queue_flush runs it) instead of being launched now
@@ -131,10 +134,10 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // Publish a wave's max|value| of a gradient tensor it has just written: slot-wise atomic max on the float's bit pattern
 // (non-negative floats order like unsigned integers, so the result does not depend on arrival order).  `slots` is a
-// caller-zeroed array of 1024 floats -- the partial-maxima array the fp16x3 gradient GEMMs take as `dy_amax`.
+// caller-zeroed array of TTTS_AMAX_SLOTS floats -- the partial-maxima array the fp16x3 gradient GEMMs take as `dy_amax`.
 __device__ __forceinline__ void amax_publish(float m, float* __restrict__ slots, int slot) {
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(slots) + (slot & 1023), __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(slots) + (slot & (TTTS_AMAX_SLOTS - 1)), __float_as_uint(m));
 }
 
 // Power-of-two pre-scale of an fp16x3 operand whose largest magnitude is m: scale * m lands in [2^11, 2^12), i.e. every
@@ -152,11 +155,18 @@ __host__ __device__ __forceinline__ void h3_pow2_scale(float m, float& scale, fl
         scale = 1.0f; inv = 1.0f;
     }
 }
-// the maximum over an operand's partial maxima (1024 floats from ttts_amax_partials or a producer's `*_amax_out`; a weight
-// image carries one value); every lane of the wave gets it
+// the maximum over an operand's partial maxima (TTTS_AMAX_SLOTS floats from ttts_amax_partials or a producer's
+// `*_amax_out`; a weight image carries one value); every lane of the wave gets it.  A full array is ONE 16-byte load per
+// lane: every wave of every consumer reads it, so the array is kept to 1 KB (eight cache lines).
 __device__ __forceinline__ float h3_partials_max(const float* __restrict__ partials, int n, int lane) {
     float m = 0.f;
-    for (int i = lane; i < n; i += 64) m = fmaxf(m, partials[i]);
+    static_assert(TTTS_AMAX_SLOTS == 256, "one float4 per lane");
+    if (n == TTTS_AMAX_SLOTS && (reinterpret_cast<uintptr_t>(partials) & 15) == 0) {
+        const float4 a = reinterpret_cast<const float4*>(partials)[lane];
+        m = fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w));
+    } else {
+        for (int i = lane; i < n; i += 64) m = fmaxf(m, partials[i]);
+    }
     return wave_max(m);
 }
 __device__ __forceinline__ void h3_operand_scale(const float* __restrict__ partials, int n, int lane, float& scale, float& inv) {

@@ -203,8 +203,8 @@ class TransformerTTS(nn.Module):
         tgt_out, alignments = self.decoder(tgt, memory, tgt_is_causal=True, memory_is_causal=False,
                                            tgt_lens=melspec_lens, memory_lens=phoneme_lens,
                                            need_alignments=need_alignments)
-        pred_melspec, pred_stop = ops.HeadsFn.apply(tgt_out, self.linear1.linear.weight, self.linear1.linear.bias,
-                                                    self.linear2.linear.weight, self.linear2.linear.bias)
+        pred_melspec, pred_stop = ops.heads(tgt_out, self.linear1.linear.weight, self.linear1.linear.bias,
+                                            self.linear2.linear.weight, self.linear2.linear.bias)
         post_melspec = ops.AddFn.apply(self.postnet(pred_melspec), pred_melspec)
         return {
             'pred_melspec': pred_melspec,
@@ -270,7 +270,7 @@ class TransformerTTS(nn.Module):
                     hdn = ops.linear(x, l.linear1.weight, l.linear1.bias, act=ops.ACT_RELU, publish_amax=True)
                     x = ops.layer_norm(ops.linear(hdn, l.linear2.weight, l.linear2.bias, residual=x),
                                        l.norm3.weight, l.norm3.bias, l.norm3.eps)
-                mel, stop = ops.HeadsFn.apply(x, *heads)
+                mel, stop = ops.heads(x, *heads)
                 ys[:, t] = mel[:, 0]
                 stops.append(stop)
                 n = t
@@ -284,7 +284,7 @@ class TransformerTTS(nn.Module):
                 out, _ = self.decoder(tgt, memory, tgt_is_causal=True, tgt_lens=lens_t,
                                       memory_lens=phoneme_lens, need_alignments=False)
                 last = out[:, -1:, :].contiguous()
-                mel, stop = ops.HeadsFn.apply(last, *heads)
+                mel, stop = ops.heads(last, *heads)
                 ys[:, t] = mel[:, 0]
                 stops.append(stop)
                 n = t

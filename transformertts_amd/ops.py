@@ -17,6 +17,7 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+AMAX_SLOTS = 256          # TTTS_AMAX_SLOTS of include/ttts_hip.h: floats per partial-maxima array
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -148,27 +149,27 @@ def _bwd_h3(K: int, N: int, channels: int = 0) -> bool:
 
 
 def _amax(t: torch.Tensor) -> torch.Tensor:
-    """1024 partial maxima of |t| (device), the dynamic pre-scale input of the fp16x3 gradient GEMMs: the array the kernel
+    """AMAX_SLOTS partial maxima of |t| (device), the dynamic pre-scale input of the fp16x3 gradient GEMMs: the array the kernel
     that produced `t` left on it (`_ttts_amax`, see _amax_slots), or a separate pass over `t`."""
     ready = getattr(t, "_ttts_amax", None)
     if ready is not None:
         return ready
     if not t.is_contiguous():
         t = t.contiguous()
-    out = torch.empty(1024, dtype=torch.float32, device=t.device)
+    out = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=t.device)
     _lib.check(_lib.load().ttts_amax_partials(_p(t), t.numel(), _p(out), _stream()), "ttts_amax_partials")
     return out
 
 
 class _AmaxArena:
-    """Per-device pool of 1024-float partial-maxima arrays that ONE memset zeroes for a whole training step.  ~150 kernels
+    """Per-device pool of AMAX_SLOTS-float partial-maxima arrays that ONE memset zeroes for a whole training step.  ~150 kernels
     of a step (every producer of an fp16x3 operand: GEMM epilogues, LayerNorm, BatchNorm, positional encoding, attention,
     the backward masks) fill such an array with atomic maxima and each would otherwise need a memset of its own.  Slices
     are handed out in call order and stay valid until the next reset (a forward's maxima are read again in backward)."""
     SLICES = 512
 
     def __init__(self, device):
-        self.buf = torch.empty(self.SLICES, 1024, dtype=torch.float32, device=device)
+        self.buf = torch.empty(self.SLICES, AMAX_SLOTS, dtype=torch.float32, device=device)
         self.next = 0
         self.clean = False          # True between reset() and release(): unissued slices are known to be zero
 
@@ -202,7 +203,7 @@ def amax_arena_release(device) -> None:
 
 
 def _amax_slots(device, zero: bool) -> torch.Tensor:
-    """A 1024-float array for a gradient-producing kernel to leave the partial maxima of its output in (attached to that
+    """An AMAX_SLOTS-float array for a producing kernel to leave the partial maxima of its output in (attached to that
     output as `_ttts_amax`; a tensor attribute survives the hop to the next autograd Function, and when it does not the
     consumer simply runs the separate pass).  `zero`: the producer fills it with atomic maxima."""
     if zero:
@@ -210,9 +211,9 @@ def _amax_slots(device, zero: bool) -> torch.Tensor:
         got = arena.take() if arena is not None else None
         if got is not None:
             return got
-    a = torch.empty(1024, dtype=torch.float32, device=device)
+    a = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=device)
     if zero:
-        _lib.check(_lib.load().ttts_zero(_p(a), 4096, _stream()), "ttts_zero")
+        _lib.check(_lib.load().ttts_zero(_p(a), AMAX_SLOTS * 4, _stream()), "ttts_zero")
     return a
 
 
@@ -288,7 +289,7 @@ def _wgrad_is_split(N: int, K: int) -> bool:
 
 def _attn_bwd(lib, do, dq_am, dkv_am, q_am, k_am, v_am, *args):
     """Attention backward in the configured form; `args` = every C-ABI argument up to step_seed.  dq_am / dkv_am: zeroed
-    1024-slot arrays in which the fp16x3 kernels leave max|dq| / max|dk, dv| (the in-projection gradients consume them);
+    AMAX_SLOTS-slot arrays in which the fp16x3 kernels leave max|dq| / max|dk, dv| (the in-projection gradients consume them);
     q_am / k_am / v_am: the partial maxima of the forward operands (their dynamic pre-scales)."""
     if ATTN_BWD_MODE == "h3":
         return lib.ttts_attention_bwd_h3(*args, _p(_amax(do)), _p(dq_am), _p(dkv_am), _p(q_am), _p(k_am), _p(v_am), _stream())
@@ -514,7 +515,7 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out=None, tok_in=None, skip_in=None,
                 skip_out=None, tok_drop=None, x_amax=None, y_amax=None):
-        """x_amax: partial maxima of |x| (fp16x3 forms; None: measured here); y_amax: None, or a zeroed 1024-slot array
+        """x_amax: partial maxima of |x| (fp16x3 forms; None: measured here); y_amax: None, or a zeroed AMAX_SLOTS-slot array
         that receives max|y| (the wrapper attaches it to y for the next fp16x3 consumer)."""
         lib = _lib.load()
         x = _chk(x, "linear.x")
@@ -573,7 +574,7 @@ class LinearFn(torch.autograd.Function):
             tok_out.premasked = False
         elif act == ACT_RELU:
             dacc = torch.empty_like(dy)
-            am = torch.empty(1024, dtype=torch.float32, device=dy.device) if want_am else None
+            am = _amax_slots(dy.device, True) if want_am else None
             _lib.check(lib.ttts_relu_dropout_bwd(_p(dy), _p(y), _p(dacc), dy.numel(), drop_p, _p(am), _stream()),
                        "ttts_relu_dropout_bwd")
         elif drop_p > 0.0:
@@ -583,7 +584,7 @@ class LinearFn(torch.autograd.Function):
                 td.dx = td.dacc = td.amax = None
             else:
                 dacc = torch.empty_like(dy)
-                am = torch.empty(1024, dtype=torch.float32, device=dy.device) if want_am else None
+                am = _amax_slots(dy.device, True) if want_am else None
                 _lib.check(lib.ttts_dropout_bwd(_p(dy), _p(dacc), dy.numel(), drop_p, seed, ctx.ss, _p(am), _stream()),
                            "ttts_dropout_bwd")
         else:
@@ -674,7 +675,7 @@ def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_sh
     relu(+dropout) Linear, its backward mask is then fused into this Linear's data-gradient epilogue.
     `skip_in` / `skip_out`: see SkipToken.
     `publish_amax`: the output feeds another fp16x3 GEMM / attention kernel, so the epilogue leaves its partial maxima on
-    it (`y._ttts_amax`) and that consumer needs no pass of its own over y.  True, or a zeroed 1024-float array to add the
+    it (`y._ttts_amax`) and that consumer needs no pass of its own over y.  True, or a zeroed AMAX_SLOTS-float array to add the
     maxima to (a running maximum over several calls: the K/V cache of `inference`)."""
     grad_on = torch.is_grad_enabled()
     N, K = w.shape
@@ -710,7 +711,7 @@ class HeadsFn(torch.autograd.Function):
     """mel = x @ w_mel.T + b_mel  (B,T,n_mels);  stop = x @ w_stop.T + b_stop  (B,T)  -- one read of dx."""
 
     @staticmethod
-    def forward(ctx, x, w_mel, b_mel, w_stop, b_stop):
+    def forward(ctx, x, w_mel, b_mel, w_stop, b_stop, x_amax=None, mel_amax=None):
         lib = _lib.load()
         x = _chk(x, "heads.x")
         N, K = w_mel.shape
@@ -718,11 +719,12 @@ class HeadsFn(torch.autograd.Function):
         mel = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
         stop = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
         w_mel = _chk(w_mel, "w_mel")
-        x_amax = None
         if _fwd_h3(K, N):
-            x_amax = _amax(x)
+            if x_amax is None:
+                x_amax = _amax(x)
             _lib.check(lib.ttts_linear_fwd_h3(_p(x), _p(_planes(w_mel, 4, N, K)), _p(b_mel), None, _p(mel), M, N, K,
-                                              ACT_NONE, 0.0, 0, None, 0, 0, _p(x_amax), None, _stream()), "ttts_linear_fwd_h3")
+                                              ACT_NONE, 0.0, 0, None, 0, 0, _p(x_amax), _p(mel_amax), _stream()),
+                       "ttts_linear_fwd_h3")
         elif GEMM_MODE == "x6":
             _lib.check(lib.ttts_linear_fwd_x6(_p(x), _p(_planes(w_mel, 0, N, K)), _p(b_mel), None, _p(mel), M, N, K,
                                               ACT_NONE, 0.0, 0, None, 0, 0, _stream()), "ttts_linear_fwd_x6")
@@ -767,7 +769,20 @@ class HeadsFn(torch.autograd.Function):
                           _p(t_wm), _p(t_bm), _p(ws), ws.numel() * 4, M, N, K, 0, 0, acc), "ttts_linear_bwd_weight")
         _lib.check(lib.ttts_rowdot_bwd(_p(dstop), _p(x), _p(w_stop), _p(dx), _p(t_ws), _p(t_bs), _p(ws2),
                                        ws2.numel() * 4, M, K, acc, _qarg(queue, ws2), _stream()), "ttts_rowdot_bwd")
-        return dx, dw_mel, db_mel, dw_stop, db_stop
+        return dx, dw_mel, db_mel, dw_stop, db_stop, None, None
+
+
+def heads(x, w_mel, b_mel, w_stop, b_stop):
+    """(mel, stop) heads; x's partial maxima ride on it (LayerNorm left them), and the mel output leaves with its own for
+    the post-net's first convolution (its weight gradient reads pred_melspec as an fp16x3 operand)."""
+    N, K = w_mel.shape
+    h3 = x.is_cuda and _fwd_h3(K, N)
+    x_am = _amax(x) if h3 else None
+    mel_am = _amax_slots(x.device, True) if h3 else None
+    mel, stop = HeadsFn.apply(x, w_mel, b_mel, w_stop, b_stop, x_am, mel_am)
+    if mel_am is not None:
+        mel._ttts_amax = mel_am
+    return mel, stop
 
 
 # ----------------------------------------------------------------------------------------------- conv + BN
@@ -847,7 +862,7 @@ class ConvBNFn(torch.autograd.Function):
         # the BatchNorm backward writes dy, the gradient both conv GEMMs below consume: it leaves dy's partial maxima too
         want_am = (ctx.needs_input_grad[0] and _bwd_h3(taps * cout, cin, cout)) or \
                   (WGRAD_MODE == "h3" and _wgrad_is_split(cout, cin))
-        am = _amax_slots(dev, False) if want_am else None
+        am = _amax_slots(dev, True) if want_am else None
         _lib.check(lib.ttts_bn_bwd(_p(dz), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(t_g), _p(t_be),
                                    _p(ws), ws.numel() * 4, M, cout, act, drop_p, seed, ctx.ss, acc, _p(am), _stream()),
                    "ttts_bn_bwd")
@@ -952,7 +967,7 @@ def layer_norm(x, gamma, beta, eps=1e-5, sole_consumer=False, publish_amax=True)
 def _attn_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, lens, causal, drop_p, seed, need_weights, q_am=None, k_am=None,
               v_am=None, o_am=None):
     """q_am / k_am / v_am: partial maxima of the operands (fp16x3 form; required there); o_am: None, or a zeroed
-    1024-slot array that receives max|o|."""
+    AMAX_SLOTS-slot array that receives max|o|."""
     lib = _lib.load()
     dev = lens.device
     o = torch.empty(B, Tq, H * 64, dtype=torch.float32, device=dev)
@@ -1243,6 +1258,8 @@ def sched_sampling_mix(pred, mel, u, lens, p_tf: float, l_bar: int = 8, seed: in
     lens = _chk(lens, "mix.lens", torch.int64)
     B, T, C = pred.shape
     out = torch.empty_like(mel)
+    out_am = _amax_slots(mel.device, True)       # the decoder pre-net's weight gradient reads the mix as an fp16x3 operand
     _lib.check(lib.ttts_sched_sampling_mix(_p(pred), _p(mel), _p(u), _p(lens), _p(out), B, T, C, float(p_tf), l_bar, seed,
-                                           _ss(), _stream()), "ttts_sched_sampling_mix")
+                                           _ss(), _p(out_am), _stream()), "ttts_sched_sampling_mix")
+    out._ttts_amax = out_am
     return out
