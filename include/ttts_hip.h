@@ -38,7 +38,7 @@ extern "C" {
 #define TTTS_ERR_LAUNCH (-2)  /* hipLaunchKernel reported an error */
 
 /* length of every partial-maxima array (`*_amax`, `*_amax_out`) of this header, in floats */
-#define TTTS_AMAX_SLOTS 256
+#define TTTS_AMAX_SLOTS 1024
 
 #define TTTS_ACT_NONE 0
 #define TTTS_ACT_RELU 1
@@ -115,7 +115,7 @@ int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db
  * ttts_linear_fwd_h3 / ttts_conv1d_fwd_h3 take such planes and form each product from three f16 x f16 MFMA terms
  * (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi): the same fp32-grade result (error vs fp64 a few 1e-7) for half the matrix-pipe
  * work.  f16 has no bf16-like exponent range, so the ACTIVATION operand is pre-scaled while it is staged, by the power
- * of two that puts ITS measured maximum in [2^11, 2^12): `x_amax` = 256 partial maxima of |x| (their maximum must be
+ * of two that puts ITS measured maximum in [2^11, 2^12): `x_amax` = TTTS_AMAX_SLOTS partial maxima of |x| (their maximum must be
  * >= max|x|; ttts_amax_partials computes them with one read of x, and every kernel of this header that PRODUCES an
  * activation or a gradient can leave them behind itself: the `*_amax_out` arguments).  Every element within 2^-15 of the
  * largest keeps 22 significant bits, smaller ones an absolute error of 2^-37 * max|x| -- no assumption about the operands'
@@ -135,7 +135,7 @@ int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks,
 int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
                        int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift, int T,
                     void* stream);
-/* y_amax_out: NULL, or a caller-zeroed 256-float array receiving max|y| (y feeds another fp16x3 GEMM / attention) */
+/* y_amax_out: NULL, or a caller-zeroed TTTS_AMAX_SLOTS-float array receiving max|y| (y feeds another fp16x3 GEMM / attention) */
 int ttts_linear_fwd_h3(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
                        int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift,
                        int T, const float* x_amax, float* y_amax_out, void* stream);
@@ -196,7 +196,7 @@ int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* runni
                         float eps, void* stream);
 int ttts_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C, float eps,
                        void* stream);
-/* z = drop(act((x - mean) * invstd * gamma + beta)); z_amax_out: NULL, or a caller-zeroed 256-float array receiving max|z| */
+/* z = drop(act((x - mean) * invstd * gamma + beta)); z_amax_out: NULL, or a caller-zeroed TTTS_AMAX_SLOTS-float array receiving max|z| */
 int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       float* z, int64_t M, int C, int act, float drop_p, uint64_t seed, const uint64_t* step_seed,
                       float* z_amax_out, void* stream);
@@ -210,14 +210,14 @@ int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float*
  * Replaces nn.LayerNorm norm1/2/3 of the encoder/decoder layers (torch/nn/modules/transformer.py:951-956,
  * model/layers.py:47-50).  The residual sum is produced by the preceding GEMM's epilogue. */
 int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                       int64_t M, int d, float eps, float* y_amax_out /* NULL, or zeroed 256 floats: max|y| */, void* stream);
+                       int64_t M, int d, float eps, float* y_amax_out /* NULL, or zeroed TTTS_AMAX_SLOTS floats: max|y| */, void* stream);
 size_t ttts_layernorm_bwd_workspace_bytes(int d);
 int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
                        int accumulate, ttts_reduce_queue* queue, void* stream);
 /* the same, and in the same pass dacc = dx * keep(seed, element) / (1 - drop_p): the gradient behind the residual dropout
  * of the sublayer whose output this LayerNorm normalised (ttts_dropout_bwd(dx) without a pass of its own; same mask as
- * the forward epilogue of that sublayer's last Linear).  dacc_amax: NULL, or a caller-zeroed 256-float array that receives
+ * the forward epilogue of that sublayer's last Linear).  dacc_amax: NULL, or a caller-zeroed TTTS_AMAX_SLOTS-float array that receives
  * partial maxima of |dacc|.  d in {256, 512, 1024}, operands 16-byte aligned. */
 int ttts_layernorm_bwd_drop(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                             float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
@@ -247,8 +247,8 @@ int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float*
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 /* fp16x3 form of the forward (three f16 MFMA terms; Q/8, K and V pre-scaled from their partial maxima q_amax / k_amax /
- * v_amax -- 256 floats each, the same array three times for a packed projection output -- and probabilities x 2^10);
- * lse in natural units, so either backward form can follow it.  o_amax_out: NULL, or zeroed 256 floats: max|o|. */
+ * v_amax -- TTTS_AMAX_SLOTS floats each, the same array three times for a packed projection output -- and probabilities x 2^10);
+ * lse in natural units, so either backward form can follow it.  o_amax_out: NULL, or zeroed TTTS_AMAX_SLOTS floats: max|o|. */
 int ttts_attention_fwd_h3(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* q_amax,
@@ -258,7 +258,7 @@ int ttts_attention_bwd_x6(const float* q, const float* k, const float* v, const 
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 /* fp16x3 form of the backward.  d_o is pre-scaled by the power of two that puts max|d_o| in [2^11, 2^12) (do_amax = the
- * 256 partial maxima of ttts_amax_partials(d_o)); dS = P (dP - delta) lives in registers as a lane-local accumulator
+ * TTTS_AMAX_SLOTS partial maxima of ttts_amax_partials(d_o)); dS = P (dP - delta) lives in registers as a lane-local accumulator
  * column and gets a lane-local pre-scale that is lowered on the fly together with its accumulator. */
 int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
@@ -270,12 +270,12 @@ int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const 
 /* ------------------------------------------------------------------ small row / element-wise pieces
  * nn.Embedding gather / scatter-add (model/model.py:168,288; no padding_idx) */
 int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d,
-                       float* out_amax_out /* NULL, or zeroed 256 floats: max|out| */, void* stream);
+                       float* out_amax_out /* NULL, or zeroed TTTS_AMAX_SLOTS floats: max|out| */, void* stream);
 int ttts_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t n, int vocab, int d, int accumulate,
                        void* stream);
 /* PositionalEncoding.forward (model/model.py:91-97): y = drop(x + alpha * pe[t]) */
 int ttts_posenc_fwd(const float* x, const float* pe, const float* alpha, float* y, int B, int T, int d, float drop_p,
-                    uint64_t seed, const uint64_t* step_seed, float* y_amax_out /* NULL, or zeroed 256 floats */, void* stream);
+                    uint64_t seed, const uint64_t* step_seed, float* y_amax_out /* NULL, or zeroed TTTS_AMAX_SLOTS floats */, void* stream);
 size_t ttts_posenc_bwd_workspace_bytes(void);
 int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, float* ws, size_t ws_bytes, int B, int T,
                     int d, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate, void* stream);
@@ -325,7 +325,7 @@ int ttts_loss_bwd(const float* pred, const float* post, const float* stop, const
  * ground truth otherwise, and zero beyond lens[b].  u == NULL: the draw (torch.rand of utils/util.py:108) is generated
  * in the kernel from `seed` (a counter-based uniform per frame).  st != NULL: p_tf and the seed word of the step are
  * read from device memory when the kernel runs (p_tf by value is ignored).
- * out_amax_out: NULL, or a caller-zeroed 256-float array receiving max|out|. */
+ * out_amax_out: NULL, or a caller-zeroed TTTS_AMAX_SLOTS-float array receiving max|out|. */
 int ttts_sched_sampling_mix(const float* pred, const float* mel, const float* u, const int64_t* lens, float* out, int B,
                             int T, int C, float p_tf, int l_bar, uint64_t seed, const ttts_step_state* st,
                             float* out_amax_out, void* stream);

@@ -157,8 +157,8 @@ def test_golden_gradients_direct(golden_dir, fixture):
         ref_norm = float(g[f"gradnorm/{name}"])
         flat = p.grad.flatten()[::int(g[f"gradstride/{name}"])].cpu()
         ref = torch.from_numpy(g[f"gradsample/{name}"])
-        if ref_norm < 1e-7:                       # analytically zero (conv bias in front of BN, key bias of a softmax)
-            assert float(p.grad.norm()) < 1e-4, name
+        if ref_norm < 1e-6:                       # analytically zero (conv bias in front of BN, key bias of a softmax):
+            assert float(p.grad.norm()) < 1e-4, name      # rounding noise on both sides (2e-7 in the 512-channel post-net)
             continue
         assert abs(float(p.grad.double().norm()) - ref_norm) < GRAD_GATE * ref_norm, name
         errs[name] = rel_l2(flat, ref)
@@ -229,7 +229,13 @@ def test_gradient_gap_is_relu_gate_flips(cfg_name, B, Tp, Tm, w_seed, b_seed):
     assert flips < 200 and units > 2e6, (flips, units)
     ggate, _ = oracle_grads(torch.float64, gates=[g.to(torch.float64) for g in hip_out])
     g32 = oracle_grads(torch.float32)[0] if first else g64          # claim (3) is checked on the first case only
+    # Flip-free gate: 2e-5 on the base configuration.  Through the 12 layers of the scaled one plain fp32 rounding alone is
+    # larger than that, so there the bar is what stock fp32 torch itself achieves UNDER THE SAME GATES (the oracle evaluated
+    # in fp32 with the HIP path's gates, against its fp64 evaluation with the same gates), times 3, and never above 5e-5.
     FLIP_FREE_GATE = 2e-5
+    g32gate = None
+    if cfg_name != "base":
+        g32gate, _ = oracle_grads(torch.float32, gates=[g.to(torch.float32) for g in hip_out])
     rows = []
     for name, p in m.named_parameters():
         if g64[name].norm().item() < 1e-7 * max(1.0, p.detach().norm().item()):
@@ -241,7 +247,15 @@ def test_gradient_gap_is_relu_gate_flips(cfg_name, B, Tp, Tm, w_seed, b_seed):
         f.write("# hip_vs_fp64_under_hip_gates  hip_vs_fp64  oracle_fp32_vs_fp64  parameter\n")
         for name, a, b, c in sorted(rows, key=lambda r: -r[2]):
             f.write(f"{a:.3e} {b:.3e} {c:.3e} {name}\n")
-    bad = {n: a for n, a, _, _ in rows if not a < FLIP_FREE_GATE}
+    if g32gate is None:
+        bad = {n: a for n, a, _, _ in rows if not a < FLIP_FREE_GATE}
+    else:
+        stock = {n: rel_l2(g32gate[n], ggate[n]) for n, _, _, _ in rows}
+        with open(f"gpurun_out/parity_gate_flips_{cfg_name}_B{B}.txt", "a") as f:
+            f.write("# stock fp32 torch under the same gates vs fp64 under the same gates (worst five):\n")
+            for n, v in sorted(stock.items(), key=lambda kv: -kv[1])[:5]:
+                f.write(f"# {v:.3e} {n}\n")
+        bad = {n: (a, stock[n]) for n, a, _, _ in rows if not a < min(5e-5, max(FLIP_FREE_GATE, 3.0 * stock[n]))}
     assert not bad, bad
     # (3) with the flips taken out, the HIP path is as close to exact arithmetic as stock fp32 torch is to its own fp64
     # run (which of the two flips a unit in a given run is chance: their summation orders differ)

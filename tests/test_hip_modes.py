@@ -95,7 +95,7 @@ def test_fp16x3_forward_form_agrees_with_fp64(M, N, K):
     y, y6 = torch.empty(M, N, device=_dev()), torch.empty(M, N, device=_dev())
     assert fwd(x, pl, b, res, y) == 0
     assert _rel(y, ref + res.double()) < TOL
-    slots = torch.zeros(256, device=_dev())
+    slots = torch.zeros(1024, device=_dev())
     assert fwd(x, pl, b, None, y, act=1, y_am=slots) == 0
     assert _rel(y, torch.relu(ref)) < TOL
     assert slots.max().item() == y.abs().max().item()           # the epilogue's own maxima of y (slot-wise atomic max)
@@ -148,7 +148,7 @@ def test_fp16x3_data_gradient_with_dynamic_scale(M, N, K, mag):
     dx = torch.empty(M, K, device=_dev())
     am = ops._amax(dy)
     assert abs(am.max().item() - dy.abs().max().item()) == 0.0
-    slots = torch.zeros(256, device=_dev())
+    slots = torch.zeros(1024, device=_dev())
     assert lib.ttts_linear_bwd_data_h3(_p(dy), _p(plt), None, _p(dx), M, N, K, None, 1.0, _p(am), _p(slots), _stream()) == 0
     assert slots.max().item() == dx.abs().max().item()          # the epilogue's own maxima of dx (slot-wise atomic max)
     ref = dy.double() @ w.double()
@@ -392,7 +392,7 @@ def test_fp16x3_attention_forward(causal, Tq, Tk, lens, qk_scale):
     dq_ref = qd.grad.transpose(1, 2).reshape(B, Tq, d)
     o = torch.empty(B, Tq, d, device=_dev()); lse = torch.empty(B, H, Tq, device=_dev())
     attn = None if causal else torch.empty(B, H, Tq, Tk, device=_dev())
-    qa, kva, oslots = ops._amax(q), ops._amax(kv), torch.zeros(256, device=_dev())
+    qa, kva, oslots = ops._amax(q), ops._amax(kv), torch.zeros(1024, device=_dev())
     assert lib.ttts_attention_fwd_h3(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), _p(attn), _p(kl), B, H, Tq, Tk, d, 2 * d,
                                      2 * d, d, causal, 0.0, 0, None, _p(qa), _p(kva), _p(kva), _p(oslots), _stream()) == 0
     assert _rel(o, o_ref) < TOL, _rel(o, o_ref)
@@ -457,7 +457,7 @@ def test_fp16x3_attention_backward(causal, Tq, Tk, lens, mag, grow):
         args = (_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(kl),
                 B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, p_drop, 99, None)
         if h3:
-            sq, sk = torch.zeros(256, device=_dev()), torch.zeros(256, device=_dev())
+            sq, sk = torch.zeros(1024, device=_dev()), torch.zeros(1024, device=_dev())
             assert bwd(*args, _p(ops._amax(do)), _p(sq), _p(sk), _p(qa), _p(kva), _p(kva), _stream()) == 0
             assert sq.max().item() == dq.abs().max().item() and sk.max().item() == dkv.abs().max().item()
         else:

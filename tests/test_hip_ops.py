@@ -140,14 +140,14 @@ def test_layernorm_backward_with_fused_dropout_backward(M, d):
     x, g, dy = (_rand(M, d, seed=1) * 2 + 0.3).to(dev), (1 + _rand(d, seed=2, scale=0.2)).to(dev), _rand(M, d, seed=4).to(dev)
     b = torch.zeros(d, device=dev)
     y, mean, rstd = torch.empty_like(x), torch.empty(M, device=dev), torch.empty(M, device=dev)
-    ysl = torch.zeros(256, device=dev)
+    ysl = torch.zeros(1024, device=dev)
     assert lib.ttts_layernorm_fwd(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), M, d, 1e-5, _p(ysl), _stream()) == 0
     assert float(ysl.max()) == float(y.abs().max())              # the forward's own maxima of y (slot-wise atomic max)
     nb = lib.ttts_layernorm_bwd_workspace_bytes(d)
     outs = []
     for fused in (False, True):
         dx, dg, db, ws = torch.empty_like(x), torch.empty(d, device=dev), torch.empty(d, device=dev), ops._ws(nb, dev)
-        dacc, am = torch.empty_like(x), torch.zeros(256, device=dev)
+        dacc, am = torch.empty_like(x), torch.zeros(1024, device=dev)
         if fused:
             assert lib.ttts_layernorm_bwd_drop(_p(dy), _p(x), _p(mean), _p(rstd), _p(g), _p(dx), _p(dg), _p(db), _p(ws),
                                                ws.numel() * 4, M, d, 0, _p(dacc), 0.3, 4242, None, _p(am), None, _stream()) == 0

@@ -862,15 +862,37 @@ struct H3Scales {
     float inv_sq, inv_sk, inv_sv;
     float c;                   // accumulator units -> true score: 1 / (sq * sk)
     float c2;                  // ... -> base-2 exponent
+    float sg, inv_sg;          // backward only: dO pre-scale (max|dO| over the whole tensor -> [2^11, 2^12))
 };
 __device__ __forceinline__ float sgpr(float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); }
-__device__ __forceinline__ H3Scales attn_h3_scales(const float* q_amax, const float* k_amax, const float* v_amax, int lane) {
+// Maximum over one TTTS_AMAX_SLOTS array, read ONCE per workgroup: each of the four waves takes a quarter (one 16-byte load
+// per lane) and the quarters meet in LDS.  These kernels run thousands of small workgroups (1 792 for a cross-attention
+// forward); with every wave reading whole arrays the maxima alone were a quarter of the kernel's L2 traffic (+17 us).
+__device__ __forceinline__ float attn_wg_quarter_max(const float* __restrict__ partials, int lane, int wave) {
+    static_assert(TTTS_AMAX_SLOTS == 1024, "four waves x 64 lanes x float4");
+    const float4 a = reinterpret_cast<const float4*>(partials)[wave * 64 + lane];
+    return wave_max(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+}
+__device__ __forceinline__ H3Scales attn_h3_scales(const float* q_amax, const float* k_amax, const float* v_amax, int lane,
+                                                   const float* g_amax = nullptr) {
     H3Scales h;
     float s, i;
-    // a packed projection output passes the same array three times: read it once (wave-uniform branches)
-    const float mq = h3_partials_max(q_amax, TTTS_AMAX_SLOTS, lane);
-    const float mk = (k_amax == q_amax) ? mq : h3_partials_max(k_amax, TTTS_AMAX_SLOTS, lane);
-    const float mv = (v_amax == k_amax) ? mk : (v_amax == q_amax) ? mq : h3_partials_max(v_amax, TTTS_AMAX_SLOTS, lane);
+    __shared__ float quarter[4][4];
+    const int wave = threadIdx.x >> 6;
+    // a packed projection output passes the same array three times: read it once (block-uniform branches)
+    const bool k_own = k_amax != q_amax, v_own = v_amax != k_amax && v_amax != q_amax;
+    const float pq = attn_wg_quarter_max(q_amax, lane, wave);
+    const float pk = k_own ? attn_wg_quarter_max(k_amax, lane, wave) : 0.f;
+    const float pv = v_own ? attn_wg_quarter_max(v_amax, lane, wave) : 0.f;
+    const float pg = g_amax != nullptr ? attn_wg_quarter_max(g_amax, lane, wave) : 0.f;
+    if (lane == 0) { quarter[0][wave] = pq; quarter[1][wave] = pk; quarter[2][wave] = pv; quarter[3][wave] = pg; }
+    __syncthreads();
+    h3_pow2_scale(fmaxf(fmaxf(quarter[3][0], quarter[3][1]), fmaxf(quarter[3][2], quarter[3][3])), s, i);
+    h.sg = sgpr(s); h.inv_sg = sgpr(i);
+    const float mq = fmaxf(fmaxf(quarter[0][0], quarter[0][1]), fmaxf(quarter[0][2], quarter[0][3]));
+    const float mk = k_own ? fmaxf(fmaxf(quarter[1][0], quarter[1][1]), fmaxf(quarter[1][2], quarter[1][3])) : mq;
+    const float mv = v_own ? fmaxf(fmaxf(quarter[2][0], quarter[2][1]), fmaxf(quarter[2][2], quarter[2][3]))
+                           : (v_amax == k_amax ? mk : mq);
     h3_pow2_scale(0.125f * mq, s, i);                                    // Q is multiplied by 1/8 before it is split
     h.sq = sgpr(s); h.inv_sq = sgpr(i);
     h3_pow2_scale(mk, s, i);
@@ -1632,11 +1654,6 @@ constexpr int DKVH_DW = 4 * XPQ + 4 * XPT + 2 * RAWQ + 256;                    /
 static_assert(DKVH_DW >= SMEM_FLOATS, "per-wave fp32 scratch must fit the stage buffers");
 constexpr int DKVH_SMEM = DKVH_DW * 4;
 
-__device__ __forceinline__ void attn_h3_grad_scale(const float* __restrict__ partials, int n, int lane, float& s, float& inv_s) {
-    float s_, i_;
-    h3_operand_scale(partials, n, lane, s_, i_);           // max|dO| -> [2^11, 2^12)
-    s = sgpr(s_); inv_s = sgpr(i_);
-}
 // ds: this lane's 16 dS values of the tile (true units); sds: the lane's current pre-scale (0 = unset); acc: the
 // accumulator pair the products land in (lane-local column).  Both half-waves hold halves of the same column.
 __device__ __forceinline__ void attn_h3_track_scale(const float (&ds)[16], float& sds, f32x16 (&acc)[2]) {
@@ -1733,9 +1750,8 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
     const uint32_t rowid = (uint32_t)(arow + qg);
 
     // dO is a gradient: its pre-scale is the power of two that puts max|dO| (over the whole tensor) in [2^11, 2^12)
-    float s_g, inv_g;
-    attn_h3_grad_scale(a.do_amax, a.do_amax_n, lane, s_g, inv_g);
-    const H3Scales hs = attn_h3_scales(a.q_amax, a.k_amax, a.v_amax, lane);
+    const H3Scales hs = attn_h3_scales(a.q_amax, a.k_amax, a.v_amax, lane, a.do_amax);
+    const float s_g = hs.sg, inv_g = hs.inv_sg;
     const float H3A_C2 = hs.c2;
     f16x8v qf[4][2], gf[4][2];
     wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
@@ -1887,9 +1903,8 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
     const float* gb_ = a.dout + (long)b * a.Tq * a.ldo + h * HD;
     const long arow = ((long)(b * a.H + h) * a.Tq);
 
-    float s_g, inv_g;
-    attn_h3_grad_scale(a.do_amax, a.do_amax_n, lane, s_g, inv_g);
-    const H3Scales hs = attn_h3_scales(a.q_amax, a.k_amax, a.v_amax, lane);
+    const H3Scales hs = attn_h3_scales(a.q_amax, a.k_amax, a.v_amax, lane, a.do_amax);
+    const float s_g = hs.sg, inv_g = hs.inv_sg;
     const float H3A_C2 = hs.c2;
     f16x8v kf[4][2], vf[4][2];
     wave_stage_tile(kb_, kw0, a.Tk, a.ldk, lane, scratch, 1.f);

@@ -98,12 +98,16 @@ __device__ __forceinline__ void weight_amax_h3_one(const float* __restrict__ w, 
     float m = (i < n) ? fabsf(w[i]) : 0.f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    // every wave of every block of this weight aims at ONE word: look before the atomic (a stale read only costs an atomic
-    // that changes nothing) -- after the first few waves almost none is issued
-    unsigned int* tail = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(planes) + h3_plane_bytes(R, C));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) {
-        const unsigned int cur = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__float_as_uint(m) > cur) atomicMax(tail, __float_as_uint(m));
+    // every block of this weight aims at ONE word: reduce over the block first, then look before the atomic (a stale read
+    // only costs an atomic that changes nothing) -- after the first few blocks almost none is issued
+    __shared__ float wred[4];
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+        unsigned int* tail = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(planes) + h3_plane_bytes(R, C));
+        if (m > 0.f && __float_as_uint(m) > __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(tail, __float_as_uint(m));
     }
 }
 

@@ -135,6 +135,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // Publish a wave's max|value| of a gradient tensor it has just written: slot-wise atomic max on the float's bit pattern
 // (non-negative floats order like unsigned integers, so the result does not depend on arrival order).  `slots` is a
 // caller-zeroed array of TTTS_AMAX_SLOTS floats -- the partial-maxima array the fp16x3 gradient GEMMs take as `dy_amax`.
+// (Measured on the element-wise producers, 14 000 - 16 000 waves per launch: 1024 slots and a plain no-return atomic per wave
+// cost a LayerNorm +1 us; 256 slots +5 us, and a look-before-you-add load in front of the atomic +10 us -- the slots'
+// cache lines become the bottleneck either way.  So: many slots, fire and forget.)
 __device__ __forceinline__ void amax_publish(float m, float* __restrict__ slots, int slot) {
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(slots) + (slot & (TTTS_AMAX_SLOTS - 1)), __float_as_uint(m));
@@ -156,14 +159,17 @@ __host__ __device__ __forceinline__ void h3_pow2_scale(float m, float& scale, fl
     }
 }
 // the maximum over an operand's partial maxima (TTTS_AMAX_SLOTS floats from ttts_amax_partials or a producer's
-// `*_amax_out`; a weight image carries one value); every lane of the wave gets it.  A full array is ONE 16-byte load per
-// lane: every wave of every consumer reads it, so the array is kept to 1 KB (eight cache lines).
+// `*_amax_out`; a weight image carries one value); every lane of the wave gets it.  A full array is four independent
+// 16-byte loads per lane (one L2 round trip), not sixteen dword loads.  Kernels with thousands of small workgroups share
+// the read between their waves instead (attention.hip).
 __device__ __forceinline__ float h3_partials_max(const float* __restrict__ partials, int n, int lane) {
     float m = 0.f;
-    static_assert(TTTS_AMAX_SLOTS == 256, "one float4 per lane");
+    static_assert(TTTS_AMAX_SLOTS == 1024, "four float4 per lane");
     if (n == TTTS_AMAX_SLOTS && (reinterpret_cast<uintptr_t>(partials) & 15) == 0) {
-        const float4 a = reinterpret_cast<const float4*>(partials)[lane];
-        m = fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w));
+        const float4* p4 = reinterpret_cast<const float4*>(partials);
+        const float4 a = p4[lane], b = p4[lane + 64], c = p4[lane + 128], d = p4[lane + 192];
+        m = fmaxf(fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))),
+                  fmaxf(fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w)), fmaxf(fmaxf(d.x, d.y), fmaxf(d.z, d.w))));
     } else {
         for (int i = lane; i < n; i += 64) m = fmaxf(m, partials[i]);
     }

@@ -17,7 +17,7 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
-AMAX_SLOTS = 256          # TTTS_AMAX_SLOTS of include/ttts_hip.h: floats per partial-maxima array
+AMAX_SLOTS = 1024         # TTTS_AMAX_SLOTS of include/ttts_hip.h: floats per partial-maxima array
 
 
 def _p(t: Optional[torch.Tensor]):
