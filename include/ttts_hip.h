@@ -248,11 +248,16 @@ int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float*
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 /* fp16x3 form of the forward (three f16 MFMA terms; Q/8, K and V pre-scaled from their partial maxima q_amax / k_amax /
  * v_amax -- TTTS_AMAX_SLOTS floats each, the same array three times for a packed projection output -- and probabilities x 2^10);
- * lse in natural units, so either backward form can follow it.  o_amax_out: NULL, or zeroed TTTS_AMAX_SLOTS floats: max|o|. */
+ * lse in natural units, so either backward form can follow it.  o_amax_out: NULL, or zeroed TTTS_AMAX_SLOTS floats: max|o|.
+ * rowstat_out: NULL, or (2, B, H, Tq) floats: per query row the maximum of the score ACCUMULATOR (the float the softmax
+ * subtracted, in the kernel's own pre-scaled units) and log2 of the row sum -- what ttts_attention_bwd_h3 needs to
+ * recompute the probabilities EXACTLY as the forward formed them (it re-forms bit-identical accumulators, so s - max is an
+ * exact difference whatever the scores' magnitude; from lse alone the probabilities are only good to ulp(lse), i.e. 6 % at
+ * scores of 1e6, where torch -- which keeps the probabilities -- is still accurate). */
 int ttts_attention_fwd_h3(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* q_amax,
-                          const float* k_amax, const float* v_amax, float* o_amax_out, void* stream);
+                          const float* k_amax, const float* v_amax, float* o_amax_out, float* rowstat_out, void* stream);
 int ttts_attention_bwd_x6(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
@@ -265,7 +270,7 @@ int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const 
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
                           float* dq_amax_out, float* dkv_amax_out, const float* q_amax, const float* k_amax,
-                          const float* v_amax, void* stream);
+                          const float* v_amax, const float* rowstat /* of the h3 forward, or NULL: use lse */, void* stream);
 
 /* ------------------------------------------------------------------ small row / element-wise pieces
  * nn.Embedding gather / scatter-add (model/model.py:168,288; no padding_idx) */

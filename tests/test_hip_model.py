@@ -290,15 +290,34 @@ def test_parity_holds_for_inputs_of_any_magnitude(mel_scale):
     for a, r in zip(out["alignments"], ref["alignments"]):
         assert rel_l2(a, r) < GATE
     assert abs(loss["total"].item() - rloss["total"].item()) < 1e-5 * abs(rloss["total"].item())
-    bad = {}
+    # Gradients: inputs 1000 x off the normalised features make the step itself ill-conditioned in fp32 (the decoder's first
+    # residual sums add O(1) attention outputs to O(1000) pre-net activations), so the yardstick is what stock fp32 torch
+    # achieves on the same inputs: the oracle evaluated in fp32 against its own fp64 evaluation.
+    from oracle import fill_state
+    sd32 = fill_state(cfg, w_seed)
+    for k, v in sd32.items():
+        if v.is_floating_point() and "running" not in k and k != "pe.pe":
+            v.requires_grad_(True)
+    ref32 = oracle_forward(sd32, cfg, batch["phoneme"], batch["melspec"], batch["phoneme_lens"], batch["melspec_lens"],
+                           training=True, dropout=False)
+    oracle_loss(ref32, batch["melspec"], batch["melspec_lens"])["total"].backward()
+    rows, bad = [], {}
     for name, p in m.named_parameters():
         rg = sd[name].grad
         if rg.norm().item() < 1e-7 * max(1.0, sd[name].detach().norm().item()) * max(1.0, mel_scale ** 2):
             continue
-        e = rel_l2(p.grad, rg)
-        if not e < GRAD_GATE:
-            bad[name] = e
+        e, e32 = rel_l2(p.grad, rg), rel_l2(sd32[name].grad, rg)
+        rows.append((e, e32, name))
+        if not e < max(GRAD_GATE, 3.0 * e32):
+            bad[name] = (e, e32)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/parity_mel_x{mel_scale:g}.txt", "w") as f:
+        f.write("# hip_vs_fp64  stock_fp32_vs_fp64  parameter (gradients)\n")
+        for e, e32, name in sorted(rows, reverse=True):
+            f.write(f"{e:.3e} {e32:.3e} {name}\n")
     assert not bad, bad
+    med = lambda xs: sorted(xs)[len(xs) // 2]
+    assert med([r[0] for r in rows]) <= max(3.0 * med([r[1] for r in rows]), 1e-5)
 
 
 def test_training_step_surface():

@@ -59,10 +59,10 @@ SIGNATURES = {
     "ttts_layernorm_bwd_drop": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P, F, U, P, P, P, P]),
     "ttts_attention_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P, P]),
     "ttts_attention_fwd_x6": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P, P]),
-    "ttts_attention_fwd_h3": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P, P, P, P, P, P]),
+    "ttts_attention_fwd_h3": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P, P, P, P, P, P, P]),
     "ttts_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P, P]),
     "ttts_attention_bwd_x6": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P, P]),
-    "ttts_attention_bwd_h3": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P, P, P, P, P, P, P, P]),
+    "ttts_attention_bwd_h3": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P, P, P, P, P, P, P, P, P]),
     "ttts_embedding_fwd": (I, [P, P, P, L, I, I, P, P]),
     "ttts_embedding_bwd": (I, [P, P, P, L, I, I, I, P]),
     "ttts_posenc_fwd": (I, [P, P, P, P, I, I, I, F, U, P, P, P]),

@@ -68,6 +68,11 @@ struct AttnArgs {
     // the operands' dynamic pre-scales.  o_amax (forward): NULL, or a caller-zeroed TTTS_AMAX_SLOTS-slot array receiving max|o|.
     const float* q_amax; const float* k_amax; const float* v_amax;
     float* o_amax;
+    // fp16x3 forms: per-row softmax statistics in the forward's own units, (2, B, H, Tq): plane 0 = the row maximum of the
+    // score ACCUMULATOR (exactly the float the forward subtracted), plane 1 = log2 of the row sum.  The backward recomputes
+    // P = exp2((s - m) c2 - log2 l) from bit-identical accumulators, so the difference s - m is exact whatever the scores'
+    // magnitude; from lse (one float, natural units) it is only good to ulp(lse): 6 % in P at scores of 1e6.
+    float* rowstat;
 };
 
 // ---- cooperative staging (256 threads): KB rows x 64 floats from global straight into LDS; rows beyond
@@ -1188,6 +1193,12 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
         lse_v = ((m == NEG_INF) ? 0.f : m) * H3A_C + __logf(lt > 0.f ? lt * (1.0f / H3A_P) : 1.f);
     }
     if (a.lse != nullptr && half == 0 && qg < a.Tq) a.lse[arow + qg] = lse_v;
+    const float lsum = WRITE_A ? l : (l + __shfl_xor(l, 32, 64)) * (1.0f / H3A_P);
+    if (a.rowstat != nullptr && half == 0 && qg < a.Tq) {
+        const long plane = (long)a.B * a.H * a.Tq;
+        a.rowstat[arow + qg] = WRITE_A ? m_fin : ((m == NEG_INF) ? 0.f : m);
+        a.rowstat[plane + arow + qg] = lsum > 0.f ? __log2f(lsum) : 0.f;
+    }
     float omax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1650,7 +1661,7 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
 #define TTTS_DKVH_W 2
 #endif
 constexpr int DQH_SMEM = ((6 * XP > SMEM_FLOATS) ? 6 * XP : SMEM_FLOATS) * 4;   // K rows, V rows, K^T: 2 planes each (48 KB)
-constexpr int DKVH_DW = 4 * XPQ + 4 * XPT + 2 * RAWQ + 256;                    // planes 32 KB + raw Q, dO 16 KB + stats
+constexpr int DKVH_DW = 4 * XPQ + 4 * XPT + 2 * RAWQ + 384;                    // planes 32 KB + raw Q, dO 16 KB + stats
 static_assert(DKVH_DW >= SMEM_FLOATS, "per-wave fp32 scratch must fit the stage buffers");
 constexpr int DKVH_SMEM = DKVH_DW * 4;
 
@@ -1772,7 +1783,16 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
     delta += __shfl_xor(delta, 32, 64);
     load_lane_frags_h3(scratch, l31, half, s_g, gf);
     if (half == 0 && qg < a.Tq) a.delta[arow + qg] = delta;
-    const float lse_q2 = ((qg < a.Tq) ? a.lse[arow + qg] : 0.f) * 1.4426950408889634f;
+    // row statistics of this query: accumulator-unit maximum and log2 of the row sum (rowstat), or lse alone
+    float m_q = 0.f, l2_q = 0.f;
+    if (qg < a.Tq) {
+        if (a.rowstat != nullptr) {
+            m_q = a.rowstat[arow + qg];
+            l2_q = a.rowstat[(long)a.B * a.H * a.Tq + arow + qg];
+        } else {
+            l2_q = a.lse[arow + qg] * 1.4426950408889634f;
+        }
+    }
     const float dp_unscale = inv_g * hs.inv_sv * a.drop_scale;   // dP accumulator units -> true dP, times the 1/(1-p) of kept weights
     float sds = 0.f;                              // this query's dS pre-scale (power of two), set / lowered on the fly
 
@@ -1826,7 +1846,7 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int kg = key_g + e;
-                    float p = fast_exp2(__builtin_fmaf(s[r + e], H3A_C2, -lse_q2));
+                    float p = fast_exp2(__builtin_fmaf(s[r + e] - m_q, H3A_C2, -l2_q));
                     if (!full) p = (kg < klen && (!CAUSAL || kg <= qg)) ? p : 0.f;
                     float g = dp[r + e] * dp_unscale;
                     if (a.thr != 0u) g = attn_keep_word(qh, attn_drop_mult(e), thr16) ? g : 0.f;
@@ -1882,7 +1902,7 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
     uint32_t* Gt = xs + 4 * XPQ + 2 * XPT;
     uint32_t* rawQ = xs + 4 * XPQ + 4 * XPT;   // [32][64] fp32, filled by DMA
     uint32_t* rawG = rawQ + RAWQ;
-    float* stat_s = reinterpret_cast<float*>(rawG + RAWQ);  // [2 buffers][lse 64 | delta 64] (32 of each 64 used)
+    float* stat_s = reinterpret_cast<float*>(rawG + RAWQ);  // [2 buffers][m or lse 64 | log2 l 64 | delta 64] (32 of each 64 used)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -1935,14 +1955,17 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar copy: the DMA destinations must not cost VGPRs
     const int dma_row = 8 * wave + (lane >> 4);
     const uint32_t dma_col = (uint32_t)(lane & 15) * 16u;
-    const float* lse_b = a.lse + arow;
+    const bool has_rs = a.rowstat != nullptr;       // row statistics in accumulator units (see AttnArgs), else lse alone
+    const float* lse_b = (has_rs ? a.rowstat : a.lse) + arow;
+    const float* l2_b = has_rs ? a.rowstat + (long)a.B * a.H * a.Tq + arow : a.lse + arow;
     const float* delta_b = a.delta + arow;
     auto fetch = [&](int qt0, int sb) {
         if (wave_u == 0) {     // first: whatever the allocator does to this address must not wait on the big requests
             int q = qt0 + l31;
             if (q > a.Tq - 1) q = a.Tq - 1;
-            dma4(lse_b, (uint32_t)q * 4u, reinterpret_cast<uint32_t*>(stat_s + sb * 128));
-            dma4(delta_b, (uint32_t)q * 4u, reinterpret_cast<uint32_t*>(stat_s + sb * 128 + 64));
+            dma4(lse_b, (uint32_t)q * 4u, reinterpret_cast<uint32_t*>(stat_s + sb * 192));
+            dma4(l2_b, (uint32_t)q * 4u, reinterpret_cast<uint32_t*>(stat_s + sb * 192 + 64));
+            dma4(delta_b, (uint32_t)q * 4u, reinterpret_cast<uint32_t*>(stat_s + sb * 192 + 128));
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1975,8 +1998,9 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
             if (st_q) patch_split_store_h3<true, 32>(v, rq, dqd, qpos, Qr, XPQ, Qt, XPT);
             else patch_split_store_h3<true, 32>(v, rq, dqd, qpos, Gr, XPQ, Gt, XPT);
         }
-        const float* lse_s = stat_s + (qs & 1) * 128;
-        const float* delta_s = lse_s + 64;
+        const float* lse_s = stat_s + (qs & 1) * 192;
+        const float* l2_s = lse_s + 64;
+        const float* delta_s = lse_s + 128;
         __syncthreads();
         if (qs + 1 < nqs) fetch(qt0 + QS, (qs + 1) & 1);   // in flight while this stage is multiplied
         if (CAUSAL && qt0 + 31 < kw0) continue;     // every query of the stage precedes this wave's keys (wave-uniform)
@@ -1990,14 +2014,20 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
             f16x8v qfr[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) qfr[p] = *reinterpret_cast<const f16x8v*>(Qr + p * XPQ + xsw(l31, 2 * st + half));
-            mfma_h3(s, qfr, kf[st]);
+            // the same three products in the same order as the forward formed them (there K was the first operand): the
+            // accumulators are then bit-identical to the forward's and s - m below is exact
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr[0], kf[st][1], s, 0, 0, 0);      // q_hi k_lo
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr[1], kf[st][0], s, 0, 0, 0);      // q_lo k_hi
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr[0], kf[st][0], s, 0, 0, 0);
         }
         float pd[16];
         const bool full = (kw0 + 32 <= klen) && (!CAUSAL || kw0 + 31 <= qt0) && (qt0 + QS <= a.Tq);   // wave-uniform
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q_g = qt0 + acc_row(r, half);
-            float p = fast_exp2(__builtin_fmaf(s[r], H3A_C2, -lse_s[acc_row(r, half)] * 1.4426950408889634f));
+            const float mq = has_rs ? lse_s[acc_row(r, half)] : 0.f;
+            const float l2 = has_rs ? l2_s[acc_row(r, half)] : l2_s[acc_row(r, half)] * 1.4426950408889634f;
+            float p = fast_exp2(__builtin_fmaf(s[r] - mq, H3A_C2, -l2));
             if (!full) p = (kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq) ? p : 0.f;
             pd[r] = p;
         }
@@ -2143,7 +2173,7 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, fl
                               const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                               int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, int form, void* stream_,
                               const float* q_amax = nullptr, const float* k_amax = nullptr, const float* v_amax = nullptr,
-                              float* o_amax_out = nullptr) {
+                              float* o_amax_out = nullptr, float* rowstat_out = nullptr) {
     // form: 0 = fp32 MFMA, 1 = bf16x6, 2 = fp16x3 (needs the partial maxima of q, k, v)
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(q && k && v && o && key_lens, "attention_fwd: null pointer");
@@ -2159,7 +2189,7 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, fl
     a.thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     a.drop_scale = 1.f / (1.f - drop_p);
     a.seed = seed; a.step_seed = step_seed;
-    a.q_amax = q_amax; a.k_amax = k_amax; a.v_amax = v_amax; a.o_amax = o_amax_out;
+    a.q_amax = q_amax; a.k_amax = k_amax; a.v_amax = v_amax; a.o_amax = o_amax_out; a.rowstat = rowstat_out;
     dim3 grid(B * H, cdiv(Tq, QB), 1);
     if (form == 2) {
         if (causal)
@@ -2206,9 +2236,9 @@ int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float*
 int ttts_attention_fwd_h3(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* q_amax,
-                          const float* k_amax, const float* v_amax, float* o_amax_out, void* stream) {
+                          const float* k_amax, const float* v_amax, float* o_amax_out, float* rowstat_out, void* stream) {
     return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, step_seed, 2,
-                              stream, q_amax, k_amax, v_amax, o_amax_out);
+                              stream, q_amax, k_amax, v_amax, o_amax_out, rowstat_out);
 }
 
 static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* do_,
@@ -2216,7 +2246,8 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
                               int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                               int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, int form, void* stream_,
                               const float* do_amax = nullptr, float* dq_amax_out = nullptr, float* dkv_amax_out = nullptr,
-                              const float* q_amax = nullptr, const float* k_amax = nullptr, const float* v_amax = nullptr) {
+                              const float* q_amax = nullptr, const float* k_amax = nullptr, const float* v_amax = nullptr,
+                              const float* rowstat = nullptr) {
     // form: 0 = fp32 MFMA, 1 = bf16x6, 2 = fp16x3 (needs do_amax and the partial maxima of q, k, v)
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(q && k && v && o && do_ && lse && delta && dq && dk && dv && key_lens, "attention_bwd: null pointer");
@@ -2241,6 +2272,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
         a.do_amax = do_amax; a.do_amax_n = TTTS_AMAX_SLOTS;
         a.amax_dq = dq_amax_out; a.amax_dkv = dkv_amax_out;
         a.q_amax = q_amax; a.k_amax = k_amax; a.v_amax = v_amax;
+        a.rowstat = const_cast<float*>(rowstat);
         return causal ? launch_bwd_h3<true>(a, gq, gk, stream) : launch_bwd_h3<false>(a, gq, gk, stream);
     }
     if (form == 1) return causal ? launch_bwd_x6<true>(a, gq, gk, stream) : launch_bwd_x6<false>(a, gq, gk, stream);
@@ -2276,10 +2308,10 @@ int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const 
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                           int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
                           float* dq_amax_out, float* dkv_amax_out, const float* q_amax, const float* k_amax,
-                          const float* v_amax, void* stream) {
+                          const float* v_amax, const float* rowstat, void* stream) {
     return attention_bwd_impl(q, k, v, o, d_o, lse, delta, dq, dk, dv, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk,
                               lddv, causal, drop_p, seed, step_seed, 2, stream, do_amax, dq_amax_out, dkv_amax_out, q_amax, k_amax,
-                              v_amax);
+                              v_amax, rowstat);
 }
 
 }  // extern "C"

@@ -287,12 +287,13 @@ def _wgrad_is_split(N: int, K: int) -> bool:
     return (N >= 128 or N in (80, 96)) and (K >= 128 or K in (80, 96)) and (N >= 128 or K >= 128)
 
 
-def _attn_bwd(lib, do, dq_am, dkv_am, q_am, k_am, v_am, *args):
+def _attn_bwd(lib, do, dq_am, dkv_am, q_am, k_am, v_am, rowstat, *args):
     """Attention backward in the configured form; `args` = every C-ABI argument up to step_seed.  dq_am / dkv_am: zeroed
     AMAX_SLOTS-slot arrays in which the fp16x3 kernels leave max|dq| / max|dk, dv| (the in-projection gradients consume them);
     q_am / k_am / v_am: the partial maxima of the forward operands (their dynamic pre-scales)."""
     if ATTN_BWD_MODE == "h3":
-        return lib.ttts_attention_bwd_h3(*args, _p(_amax(do)), _p(dq_am), _p(dkv_am), _p(q_am), _p(k_am), _p(v_am), _stream())
+        return lib.ttts_attention_bwd_h3(*args, _p(_amax(do)), _p(dq_am), _p(dkv_am), _p(q_am), _p(k_am), _p(v_am), _p(rowstat),
+                                         _stream())
     return (lib.ttts_attention_bwd_x6 if ATTN_BWD_MODE == "x6" else lib.ttts_attention_bwd)(*args, _stream())
 
 
@@ -971,18 +972,21 @@ def _attn_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, lens, causal, drop_p, seed, 
     lib = _lib.load()
     dev = lens.device
     o = torch.empty(B, Tq, H * 64, dtype=torch.float32, device=dev)
-    lse = torch.empty(B, H, Tq, dtype=torch.float32, device=dev)
+    # lse (natural units) and, in the fp16x3 form, the row statistics in the kernel's own units behind it: rows 1-2 of `stat`
+    stat = torch.empty(3 if ATTN_FWD_MODE == "h3" else 1, B, H, Tq, dtype=torch.float32, device=dev)
+    lse = stat[0]
     attn = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=dev) if need_weights else None
     args = (q, k, v, _p(o), _p(lse), _p(attn), _p(lens), B, H, Tq, Tk, ldq, ldk, ldv, H * 64, 1 if causal else 0,
             float(drop_p), seed, _ss())
     if ATTN_FWD_MODE == "h3":
         if q_am is None or k_am is None or v_am is None:
             raise ValueError("attention (fp16x3 form): the partial maxima of q, k and v are required")
-        _lib.check(lib.ttts_attention_fwd_h3(*args, _p(q_am), _p(k_am), _p(v_am), _p(o_am), _stream()), "ttts_attention_fwd_h3")
+        _lib.check(lib.ttts_attention_fwd_h3(*args, _p(q_am), _p(k_am), _p(v_am), _p(o_am), _p(stat[1:]), _stream()),
+                   "ttts_attention_fwd_h3")
     else:
         fwd = lib.ttts_attention_fwd_x6 if ATTN_FWD_MODE == "x6" else lib.ttts_attention_fwd
         _lib.check(fwd(*args, _stream()), "ttts_attention_fwd")
-    return o, lse, attn
+    return o, stat, attn
 
 
 def _attn_h3() -> bool:
@@ -1006,9 +1010,9 @@ class SelfAttentionFn(torch.autograd.Function):
             raise ValueError(f"attention kernels need head_dim 64 (d_model {d}, heads {n_head})")
         if qkv_amax is None and _attn_h3():
             qkv_amax = _amax(qkv)
-        o, lse, _ = _attn_fwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), d3, d3, d3, B, n_head, T, T, lens, causal,
-                              drop_p, seed, False, qkv_amax, qkv_amax, qkv_amax, o_amax)
-        ctx.save_for_backward(qkv, o, lse, lens)
+        o, stat, _ = _attn_fwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), d3, d3, d3, B, n_head, T, T, lens, causal,
+                               drop_p, seed, False, qkv_amax, qkv_amax, qkv_amax, o_amax)
+        ctx.save_for_backward(qkv, o, stat, lens)
         ctx.qkv_amax = qkv_amax
         ctx.cfg = (n_head, causal, float(drop_p), seed)
         ctx.ss = _ss()
@@ -1017,16 +1021,17 @@ class SelfAttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, do):
         lib = _lib.load()
-        qkv, o, lse, lens = ctx.saved_tensors
+        qkv, o, stat, lens = ctx.saved_tensors
+        lse, rowstat = stat[0], (stat[1:] if stat.shape[0] == 3 else None)
         n_head, causal, drop_p, seed = ctx.cfg
         B, T, d3 = qkv.shape
         d = d3 // 3
         do = _chk(do, "self_attention.do")
         dqkv = torch.empty_like(qkv)
-        delta = torch.empty_like(lse)
+        delta = torch.empty(lse.shape, dtype=torch.float32, device=lse.device)
         am = _amax_slots(qkv.device, True) if ATTN_BWD_MODE == "h3" else None     # max|dqkv| for the in-projection gradients
         qa = ctx.qkv_amax
-        _lib.check(_attn_bwd(lib, do, am, am, qa, qa, qa, _off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta),
+        _lib.check(_attn_bwd(lib, do, am, am, qa, qa, qa, rowstat, _off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta),
                              _off(dqkv, 0), _off(dqkv, d), _off(dqkv, 2 * d), _p(lens), B, n_head, T, T, d3,
                              d3, d3, d, d3, d3, d3, 1 if causal else 0, drop_p, seed, ctx.ss), "ttts_attention_bwd")
         if am is not None:
@@ -1049,9 +1054,9 @@ class CrossAttentionFn(torch.autograd.Function):
         if _attn_h3():
             q_amax = _amax(q) if q_amax is None else q_amax
             kv_amax = _amax(kv) if kv_amax is None else kv_amax
-        o, lse, attn = _attn_fwd(_off(q, 0), _off(kv, 0), _off(kv, d), d, 2 * d, 2 * d, B, n_head, Tq, Tk, lens, False,
-                                 drop_p, seed, need_weights, q_amax, kv_amax, kv_amax, o_amax)
-        ctx.save_for_backward(q, kv, o, lse, lens)
+        o, stat, attn = _attn_fwd(_off(q, 0), _off(kv, 0), _off(kv, d), d, 2 * d, 2 * d, B, n_head, Tq, Tk, lens, False,
+                                  drop_p, seed, need_weights, q_amax, kv_amax, kv_amax, o_amax)
+        ctx.save_for_backward(q, kv, o, stat, lens)
         ctx.amax = (q_amax, kv_amax)
         ctx.cfg = (n_head, float(drop_p), seed)
         ctx.ss = _ss()
@@ -1066,7 +1071,8 @@ class CrossAttentionFn(torch.autograd.Function):
         if do is None:
             return None, None, None, None, None, None, None, None, None, None
         lib = _lib.load()
-        q, kv, o, lse, lens = ctx.saved_tensors
+        q, kv, o, stat, lens = ctx.saved_tensors
+        lse, rowstat = stat[0], (stat[1:] if stat.shape[0] == 3 else None)
         n_head, drop_p, seed = ctx.cfg
         B, Tq, d = q.shape
         Tk = kv.shape[1]
@@ -1078,7 +1084,7 @@ class CrossAttentionFn(torch.autograd.Function):
         if ATTN_BWD_MODE == "h3":
             am_q, am_kv = _amax_slots(q.device, True), _amax_slots(q.device, True)
         qa, kva = ctx.amax
-        _lib.check(_attn_bwd(lib, do, am_q, am_kv, qa, kva, kva, _off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
+        _lib.check(_attn_bwd(lib, do, am_q, am_kv, qa, kva, kva, rowstat, _off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
                              _off(dq, 0), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk, d, 2 * d,
                              2 * d, d, d, 2 * d, 2 * d, 0, drop_p, seed, ctx.ss), "ttts_attention_bwd")
         if am_q is not None:
