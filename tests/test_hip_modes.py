@@ -521,8 +521,15 @@ def test_fp16x3_attention_any_magnitude(vs, qs, ks, causal):
                                      _off(dkv, d), _p(kl), B, H, T, T, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, 0.0, 0, None,
                                      _p(ops._amax(do)), None, None, _p(qa), _p(ka), _p(va), _p(rowstat), _stream()) == 0
     assert torch.isfinite(dq).all() and torch.isfinite(dkv).all()
-    assert _rel(dq, dq_ref) < TOL and _rel(dkv[..., :d], dk_ref) < TOL and _rel(dkv[..., d:], dv_ref) < TOL, \
-        (_rel(dq, dq_ref), _rel(dkv[..., :d], dk_ref), _rel(dkv[..., d:], dv_ref))
+    assert _rel(dkv[..., d:], dv_ref) < TOL, _rel(dkv[..., d:], dv_ref)
+    if qs * ks < 100:
+        assert _rel(dq, dq_ref) < TOL and _rel(dkv[..., :d], dk_ref) < TOL, (_rel(dq, dq_ref), _rel(dkv[..., :d], dk_ref))
+    else:
+        # scores of +-1e6: every softmax row is exactly one-hot, the true dQ and dK are exactly zero, and what a recomputing
+        # backward returns is the rounding of dS = P (dP - delta): 2^-22 |dO| |V| per weight, times |K| (resp. |Q|) / 8
+        noise = 2.0 ** -20 * float(do.abs().max()) * float(kv[..., d:].abs().max()) * 8.0
+        assert float(dq_ref.abs().max()) == 0.0
+        assert float(dq.abs().max()) < noise * float(kv[..., :d].abs().max()) and float(dkv[..., :d].abs().max()) < noise * float(q.abs().max())
     # one shared array for a packed projection whose parts differ by 1e3 .. 1e8 still works (graceful: the small part
     # keeps an absolute error of 2^-37 of the largest element)
     am_all = torch.maximum(torch.maximum(qa, ka), va)

@@ -68,10 +68,11 @@ struct AttnArgs {
     // the operands' dynamic pre-scales.  o_amax (forward): NULL, or a caller-zeroed TTTS_AMAX_SLOTS-slot array receiving max|o|.
     const float* q_amax; const float* k_amax; const float* v_amax;
     float* o_amax;
-    // fp16x3 forms: per-row softmax statistics in the forward's own units, (2, B, H, Tq): plane 0 = the row maximum of the
-    // score ACCUMULATOR (exactly the float the forward subtracted), plane 1 = log2 of the row sum.  The backward recomputes
-    // P = exp2((s - m) c2 - log2 l) from bit-identical accumulators, so the difference s - m is exact whatever the scores'
-    // magnitude; from lse (one float, natural units) it is only good to ulp(lse): 6 % in P at scores of 1e6.
+    // fp16x3 forms: per-row softmax statistics in the forward's own units, (2, B, H, Tq): plane 0 = the subtrahend mcs of the
+    // weights' exponents fma(s, c2, -mcs) exactly as the forward used it with the final row maximum (one rounded product
+    // per row), plane 1 = log2 of the row sum of those weights.  The backward re-forms bit-identical score accumulators s and
+    // the same exponents, so its probabilities ARE the forward's whatever the scores' magnitude; from lse (one float,
+    // natural units) they are only good to ulp(lse): 6 % at scores of 1e6.
     float* rowstat;
 };
 
@@ -1096,6 +1097,11 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
 
     const float m_fin = (m == NEG_INF) ? 0.f : m;
     const float inv_l = (l > 0.f) ? 1.f / l : 0.f;
+    // The exponent of a weight is fma(s, c2, -mcs) with mcs = fl(max * c2): ONE rounded product per row, kept as it is
+    // (rowstat) so that the backward forms the very same exponents.  Its rounding error is the same for every key of the
+    // row and cancels against the row sum -- here and there -- whatever the scores' magnitude.
+    const float mcs_fin = m_fin * H3A_C2;
+    float mcs_last = 0.f;        // online form: the subtrahend of the last tile (= of the final maximum)
 
     // ---------------- main pass
     for (int t = 0; t < nst; ++t) {
@@ -1115,7 +1121,7 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
             if (WRITE_A) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    p[r] = alive(key0 + acc_row(r, half)) ? fast_exp2(__builtin_fmaf(s[r], H3A_C2, -m_fin * H3A_C2)) * inv_l : 0.f;
+                    p[r] = alive(key0 + acc_row(r, half)) ? fast_exp2(__builtin_fmaf(s[r], H3A_C2, -mcs_fin)) * inv_l : 0.f;
             } else {
                 float mx = NEG_INF;
                 if (full) {
@@ -1133,7 +1139,8 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
                 float m_use = (m_new == NEG_INF) ? 0.f : m_new;
                 float alpha = fast_exp2((m - m_use) * H3A_C2);
                 // the weights are born pre-scaled by 2^10 (the f16 split scale rides in the exponent): l sums them scaled
-                const float mc = m_use * H3A_C2 - 10.f;
+                const float mc = __builtin_fmaf(m_use, H3A_C2, -10.f);
+                mcs_last = mc;
                 float ps = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(__builtin_fmaf(s[r], H3A_C2, -mc)); ps += p[r]; }
@@ -1193,12 +1200,15 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
         lse_v = ((m == NEG_INF) ? 0.f : m) * H3A_C + __logf(lt > 0.f ? lt * (1.0f / H3A_P) : 1.f);
     }
     if (a.lse != nullptr && half == 0 && qg < a.Tq) a.lse[arow + qg] = lse_v;
-    const float lsum = WRITE_A ? l : (l + __shfl_xor(l, 32, 64)) * (1.0f / H3A_P);
+    // row statistics for the backward: the subtrahend the weights were formed with and log2 of their sum (in the online form
+    // both carry the 2^10 the weights are born with; a row whose last tile did not move the maximum used the same value)
+    const float lsum = WRITE_A ? l : (l + __shfl_xor(l, 32, 64));
     if (a.rowstat != nullptr && half == 0 && qg < a.Tq) {
         const long plane = (long)a.B * a.H * a.Tq;
-        a.rowstat[arow + qg] = WRITE_A ? m_fin : ((m == NEG_INF) ? 0.f : m);
+        a.rowstat[arow + qg] = WRITE_A ? mcs_fin : ((m == NEG_INF) ? -10.f : __builtin_fmaf(m, H3A_C2, -10.f));
         a.rowstat[plane + arow + qg] = lsum > 0.f ? __log2f(lsum) : 0.f;
     }
+    (void)mcs_last;
     float omax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1783,7 +1793,7 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
     delta += __shfl_xor(delta, 32, 64);
     load_lane_frags_h3(scratch, l31, half, s_g, gf);
     if (half == 0 && qg < a.Tq) a.delta[arow + qg] = delta;
-    // row statistics of this query: accumulator-unit maximum and log2 of the row sum (rowstat), or lse alone
+    // row statistics of this query: the forward's exponent subtrahend and log2 of its row sum (rowstat), or lse alone
     float m_q = 0.f, l2_q = 0.f;
     if (qg < a.Tq) {
         if (a.rowstat != nullptr) {
@@ -1846,7 +1856,7 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int kg = key_g + e;
-                    float p = fast_exp2(__builtin_fmaf(s[r + e] - m_q, H3A_C2, -l2_q));
+                    float p = fast_exp2(__builtin_fmaf(s[r + e], H3A_C2, -m_q) - l2_q);
                     if (!full) p = (kg < klen && (!CAUSAL || kg <= qg)) ? p : 0.f;
                     float g = dp[r + e] * dp_unscale;
                     if (a.thr != 0u) g = attn_keep_word(qh, attn_drop_mult(e), thr16) ? g : 0.f;
@@ -2027,7 +2037,7 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
             const int q_g = qt0 + acc_row(r, half);
             const float mq = has_rs ? lse_s[acc_row(r, half)] : 0.f;
             const float l2 = has_rs ? l2_s[acc_row(r, half)] : l2_s[acc_row(r, half)] * 1.4426950408889634f;
-            float p = fast_exp2(__builtin_fmaf(s[r] - mq, H3A_C2, -l2));
+            float p = fast_exp2(__builtin_fmaf(s[r], H3A_C2, -mq) - l2);
             if (!full) p = (kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq) ? p : 0.f;
             pd[r] = p;
         }
