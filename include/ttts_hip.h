@@ -139,8 +139,13 @@ int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, 
 int ttts_linear_fwd_h3(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
                        int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift,
                        int T, const float* x_amax, float* y_amax_out, void* stream);
+/* bn_partials: NULL, or the workspace of ttts_bn_train_stats (ttts_bn_workspace_bytes): the epilogue then leaves BatchNorm's
+ * row-chunk partials (count, mean, M2 per output channel and chunk, [nblk][3][cout]) behind and
+ * ttts_bn_train_stats_from_partials finishes the statistics without a pass over y.  nblk = ttts_conv1d_fwd_h3_bn_blocks(...);
+ * 0 means this shape's tile cannot emit them (pass NULL and use ttts_bn_train_stats). */
+int ttts_conv1d_fwd_h3_bn_blocks(int B, int T, int cin, int cout, int taps);
 int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
-                       int taps, const float* x_amax, void* stream);
+                       int taps, const float* x_amax, float* bn_partials, void* stream);
 /* fp16x3 data gradients: as the forward, with the gradient as the activation operand (dy_amax: its partial maxima;
  * 1e-7 .. 1e-5 behind a mean-reduced loss, any magnitude in general).  planes: modes 5 / 7. */
 int ttts_amax_partials(const float* x, int64_t n, float* partials /* TTTS_AMAX_SLOTS floats, fully written */, void* stream);
@@ -194,6 +199,9 @@ size_t ttts_bn_workspace_bytes(int64_t M, int C);
 int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, float* ws, size_t ws_bytes, int64_t M, int C, float momentum,
                         float eps, void* stream);
+int ttts_bn_train_stats_from_partials(const float* partials, int nblk, float* mean, float* invstd, float* running_mean,
+                                      float* running_var, int64_t* num_batches_tracked, int C, float momentum, float eps,
+                                      void* stream);
 int ttts_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C, float eps,
                        void* stream);
 /* z = drop(act((x - mean) * invstd * gamma + beta)); z_amax_out: NULL, or a caller-zeroed TTTS_AMAX_SLOTS-float array receiving max|z| */

@@ -243,12 +243,58 @@ def test_fp16x3_conv_forward_agrees_with_fp64(B, T, cin, cout):
     ref = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), b.double(), padding=2).transpose(1, 2)
     y = torch.empty(B, T, cout, device=_dev())
     pl = ops._planes(w, 6, cout, 5 * cin, cin, 5)
-    assert lib.ttts_conv1d_fwd_h3(_p(x), _p(pl), _p(b), _p(y), B, T, cin, cout, 5, _p(ops._amax(x)), _stream()) == 0
+    assert lib.ttts_conv1d_fwd_h3(_p(x), _p(pl), _p(b), _p(y), B, T, cin, cout, 5, _p(ops._amax(x)), None, _stream()) == 0
     assert _rel(y, ref) < TOL, _rel(y, ref)
     x2 = x * 1e5                                                    # any magnitude
-    assert lib.ttts_conv1d_fwd_h3(_p(x2), _p(pl), _p(b), _p(y), B, T, cin, cout, 5, _p(ops._amax(x2)), _stream()) == 0
+    assert lib.ttts_conv1d_fwd_h3(_p(x2), _p(pl), _p(b), _p(y), B, T, cin, cout, 5, _p(ops._amax(x2)), None, _stream()) == 0
     ref2 = torch.nn.functional.conv1d(x2.double().transpose(1, 2), w.double(), b.double(), padding=2).transpose(1, 2)
     assert torch.isfinite(y).all() and _rel(y, ref2) < TOL
+
+
+@pytest.mark.parametrize("B,T,cin,cout,offset", [(3, 50, 128, 256, 0.0), (7, 333, 256, 256, 0.0), (2, 7, 256, 128, 40.0),
+                                                 (30, 870, 256, 256, 3.0), (5, 97, 64, 64, 0.0)])
+def test_batchnorm_statistics_from_the_conv_epilogue(B, T, cin, cout, offset):
+    """The fp16x3 convolution leaves BatchNorm's row-chunk partials (count, mean, M2 per channel) behind in its epilogue and
+    ttts_bn_train_stats_from_partials merges them: same mean / invstd / running statistics as the separate two-pass
+    statistics kernel and as fp64, also for ragged row counts (rows past M do not count) and for a channel offset 40 x
+    the spread (sums are taken about each slab's first row, so nothing cancels)."""
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    M = B * T
+    x, w = _rand(B, T, cin, seed=1), _rand(cout, cin, 5, seed=2, scale=(5 * cin) ** -0.5)
+    b = _rand(cout, seed=3) + offset
+    nblk = lib.ttts_conv1d_fwd_h3_bn_blocks(B, T, cin, cout, 5)
+    assert 0 < nblk <= 512
+    y = torch.empty(B, T, cout, device=_dev())
+    ws = ops._ws(lib.ttts_bn_workspace_bytes(M, cout), _dev())
+    pl = ops._planes(w, 6, cout, 5 * cin, cin, 5)
+    assert lib.ttts_conv1d_fwd_h3(_p(x), _p(pl), _p(b), _p(y), B, T, cin, cout, 5, _p(ops._amax(x)), _p(ws), _stream()) == 0
+    res = []
+    for fused in (True, False):
+        mean, invstd = torch.empty(cout, device=_dev()), torch.empty(cout, device=_dev())
+        rm, rv, nbt = torch.zeros(cout, device=_dev()), torch.ones(cout, device=_dev()), torch.zeros((), dtype=torch.int64, device=_dev())
+        if fused:
+            assert lib.ttts_bn_train_stats_from_partials(_p(ws), nblk, _p(mean), _p(invstd), _p(rm), _p(rv), _p(nbt), cout, 0.1, 1e-5,
+                                                         _stream()) == 0
+        else:
+            ws2 = ops._ws(lib.ttts_bn_workspace_bytes(M, cout), _dev())
+            assert lib.ttts_bn_train_stats(_p(y), _p(mean), _p(invstd), _p(rm), _p(rv), _p(nbt), _p(ws2), ws2.numel() * 4, M, cout,
+                                           0.1, 1e-5, _stream()) == 0
+        res.append((mean, invstd, rm, rv, int(nbt)))
+    yd = y.double().view(M, cout)
+    mean64, var64 = yd.mean(0), yd.var(0, unbiased=False)
+    inv64 = 1.0 / torch.sqrt(var64 + 1e-5)
+    for mean, invstd, rm, rv, n in res:
+        assert n == 1
+        assert float((mean.double() - mean64).abs().max()) < 2e-6 * (1.0 + abs(offset)) and _rel(invstd, inv64) < 2e-6, \
+            (float((mean.double() - mean64).abs().max()), _rel(invstd, inv64))
+        assert _rel(rv, 0.9 + 0.1 * yd.var(0, unbiased=True)) < 2e-6
+    assert _rel(res[0][1], res[1][1]) < 1e-6 and _rel(res[0][0], res[1][0]) < 1e-6
+    # the plain forward (no partials) writes the same y
+    y2 = torch.empty_like(y)
+    assert lib.ttts_conv1d_fwd_h3(_p(x), _p(pl), _p(b), _p(y2), B, T, cin, cout, 5, _p(ops._amax(x)), None, _stream()) == 0
+    assert torch.equal(y, y2)
 
 
 @pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128)])

@@ -435,12 +435,12 @@ __global__ __launch_bounds__(256) void weight_tail_zero_batched_kernel(const lon
         if (d[4] >= 4) *reinterpret_cast<float*>(reinterpret_cast<char*>(d[1]) + h3_plane_bytes(d[2], d[3])) = 0.f;
     }
 }
-__global__ __launch_bounds__(256) void weight_amax_batched_kernel(const long* __restrict__ descs, int n) {
+__global__ __launch_bounds__(64) void weight_amax_batched_kernel(const long* __restrict__ descs, int n) {
     const long blk = blockIdx.x;
     const long* d = batched_desc(descs, n, blk);
     if (d[4] >= 4)
         weight_amax_h3_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
-                           (blk - d[7]) * 256 + threadIdx.x);
+                           (blk - d[7]) * 256);
 }
 
 __global__ __launch_bounds__(256) void weight_split_batched_kernel(const long* __restrict__ descs, int n) {
@@ -928,7 +928,7 @@ static GemmArgs base_args() {
     g.bias = nullptr; g.act = 0; g.drop_scale = 1.f; g.drop_thr = 0; g.seed = 0; g.step_seed = nullptr;
     g.residual = nullptr; g.ldr = 0; g.colsum = nullptr; g.a_bytes = 0; g.b_bytes = 0;
     g.relu_out = nullptr; g.relu_scale = 1.f;
-    g.a_amax = nullptr; g.a_amax_n = 0; g.b_amax = nullptr; g.b_amax_n = 0; g.c_amax = nullptr;
+    g.a_amax = nullptr; g.a_amax_n = 0; g.b_amax = nullptr; g.b_amax_n = 0; g.c_amax = nullptr; g.bn_ws = nullptr;
     return g;
 }
 
@@ -1227,7 +1227,7 @@ int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks,
     TTTS_REQUIRE(descs && n > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "weight_split_batched: bad arguments");
     hipLaunchKernelGGL(weight_tail_zero_batched_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const long*>(descs), n);
-    hipLaunchKernelGGL(weight_amax_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(weight_amax_batched_kernel, dim3((unsigned)total_blocks), dim3(64), 0, (hipStream_t)stream,
                        reinterpret_cast<const long*>(descs), n);
     hipLaunchKernelGGL(weight_split_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const long*>(descs), n);
@@ -1281,8 +1281,12 @@ int ttts_linear_fwd_h3(const float* x, const void* w_planes, const float* bias, 
     return dispatch_h3(g, (hipStream_t)stream);
 }
 
+int ttts_conv1d_fwd_h3_bn_blocks(int B, int T, int cin, int cout, int taps) {
+    return h3_bn_blocks((long)B * T, cout, (long)taps * cin);
+}
+
 int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
-                       int taps, const float* x_amax, void* stream) {
+                       int taps, const float* x_amax, float* bn_partials, void* stream) {
     TTTS_REQUIRE(x && planes_fwd && y && x_amax, "conv1d_fwd_h3: null pointer (x_amax, the partial maxima of |x|, is required)");
     TTTS_REQUIRE(B > 0 && T > 0 && cin > 0 && cout > 0 && taps > 0 && (taps & 1), "conv1d_fwd_h3: bad dims");
     TTTS_REQUIRE(cin % HBK == 0 && cout % 4 == 0, "conv1d_fwd_h3: cin=%d must be a multiple of %d and cout=%d of 4", cin, HBK, cout);
@@ -1296,6 +1300,8 @@ int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias
     g.bias = bias;
     g.a_amax = x_amax; g.a_amax_n = H3_AMAX_PARTIALS;
     g.b_amax = h3_plane_tail(planes_fwd, cout, (long)taps * cin); g.b_amax_n = 1;
+    TTTS_REQUIRE(bn_partials == nullptr || (((uintptr_t)bn_partials) & 15) == 0, "conv1d_fwd_h3: bn_partials must be 16-byte aligned");
+    g.bn_ws = bn_partials;
     return dispatch_h3(g, (hipStream_t)stream);
 }
 

@@ -45,6 +45,11 @@ struct GemmArgs {
     int a_amax_n;
     const float* b_amax;
     int b_amax_n;
+    // fp16x3 forward of a convolution that feeds BatchNorm: NULL, or the workspace of ttts_bn_train_stats.  Every wave
+    // leaves, per output column, the (count, mean, M2) of the rows of its wave tile at bn_ws[((tile_row * WM + wave_m) * 3
+    // + {0,1,2}) * N + column] -- the row-chunk partials bn_stats_final_kernel merges -- so the statistics cost no pass
+    // over y.  Only tiles whose lanes keep one column group (h3_bn_blocks() > 0).
+    float* bn_ws;
     // fp16x3 kernel: NULL, or a caller-zeroed TTTS_AMAX_SLOTS-slot array that receives max|C| (amax_publish): the output is a
     // gradient that another fp16x3 GEMM will consume
     float* c_amax;
@@ -91,23 +96,26 @@ __device__ __forceinline__ void split2_pair(f32x2 x, uint32_t& hi, uint32_t& lo)
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
 }
 
-// |w| maximum of one weight into the tail of its plane image (atomic max on the bit pattern; the tail was zeroed first)
+// |w| maximum of one weight into the tail of its plane image (atomic max on the bit pattern; the tail was zeroed first).
+// Called by ONE wave per 256 elements (blockDim 64): a float4 per lane, a wave reduction, and a look at the tail before the
+// atomic -- every wave of a weight aims at the same word, and after the first few arrivals almost none has anything to add.
 __device__ __forceinline__ void weight_amax_h3_one(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
-                                                   int C, long i) {
+                                                   int C, long i0) {
     const long n = (long)R * C;
-    float m = (i < n) ? fabsf(w[i]) : 0.f;
+    const long i = i0 + 4 * (long)(threadIdx.x & 63);
+    float m = 0.f;
+    if (i + 3 < n && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(w + i);
+        m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    } else {
+        for (int e = 0; e < 4; ++e)
+            if (i + e < n) m = fmaxf(m, fabsf(w[i + e]));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    // every block of this weight aims at ONE word: reduce over the block first, then look before the atomic (a stale read
-    // only costs an atomic that changes nothing) -- after the first few blocks almost none is issued
-    __shared__ float wred[4];
-    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) {
         unsigned int* tail = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(planes) + h3_plane_bytes(R, C));
-        if (m > 0.f && __float_as_uint(m) > __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(tail, __float_as_uint(m));
+        if (__float_as_uint(m) > __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(tail, __float_as_uint(m));
     }
 }
 
@@ -146,6 +154,8 @@ bool h3_supports(const GemmArgs& g);
 int h3_tile_choice(long M, long N, long K);
 void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, int mode, int c2, int taps, hipStream_t stream);
 int dispatch_h3(const GemmArgs& g, hipStream_t stream);
+// row-chunk partials the fp16x3 forward writes into GemmArgs::bn_ws for an M x N x K problem (0: its tile shape cannot)
+int h3_bn_blocks(long M, long N, long K);
 int dispatch_wgrad_h3(const GemmArgs& g, int zdim, int tile, hipStream_t stream);
 
 }  // namespace ttts

@@ -27,9 +27,9 @@
 
 namespace ttts {
 
-__global__ __launch_bounds__(256) void weight_amax_h3_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
-                                                             int R, int C) {
-    weight_amax_h3_one(w, planes, R, C, (long)blockIdx.x * blockDim.x + threadIdx.x);
+__global__ __launch_bounds__(64) void weight_amax_h3_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
+                                                            int R, int C) {
+    weight_amax_h3_one(w, planes, R, C, (long)blockIdx.x * 256);
 }
 __global__ __launch_bounds__(256) void weight_split_h3_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
                                                               int R, int C, int mode, int c2, int taps) {
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void weight_split_h3_kernel(const float* __res
 void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, int mode, int c2, int taps, hipStream_t stream) {
     const long n = (long)rows * cols;
     (void)launch_zero(reinterpret_cast<char*>(planes) + h3_plane_bytes(rows, cols), 16, stream);
-    hipLaunchKernelGGL(weight_amax_h3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, w, (unsigned short*)planes, rows, cols);
+    hipLaunchKernelGGL(weight_amax_h3_kernel, dim3(cdiv(n, 256)), dim3(64), 0, stream, w, (unsigned short*)planes, rows, cols);
     hipLaunchKernelGGL(weight_split_h3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, w, (unsigned short*)planes, rows,
                        cols, mode, c2, taps);
 }
@@ -328,9 +328,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
         const float relu_lo = (g.act == 1) ? 0.f : -__builtin_inff();
         // rows / columns past the matrix edge exist only in edge tiles: everywhere else the running maximum needs no test
         const bool tile_full = m0 + BM <= g.M && n0 + BN <= g.N;
-        auto run = [&](auto has_res_c, auto has_gate_c, auto drop_c) {
+        auto run = [&](auto has_res_c, auto has_gate_c, auto drop_c, auto stats_c) {
             constexpr bool HAS_RES = decltype(has_res_c)::value, HAS_GATE = decltype(has_gate_c)::value;
-            constexpr bool DROP = decltype(drop_c)::value;
+            constexpr bool DROP = decltype(drop_c)::value, STATS = decltype(stats_c)::value;
+            // BatchNorm partials of this wave tile (STATS): per column (n, mean, M2), merged slab by slab
+            float bn_n = 0.f, bn_mean[4] = {0.f, 0.f, 0.f, 0.f}, bn_m2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -343,6 +345,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 constexpr int GR = (NIT % 4 == 0) ? 4 : NIT;
+                // STATS: sums are taken about the slab's first row (shift[]), so that sum((v - shift)^2) - sum(v - shift)^2 / n
+                // does not cancel: the shift is within the column's spread of its mean
+                float shift[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+                const long slab_row0 = (long)m0 + wm * WTM + i * 32;
+                const int slab_rows = (int)(g.M - slab_row0 < 32 ? (g.M - slab_row0 > 0 ? g.M - slab_row0 : 0) : 32);
+                if (STATS) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(slab + 4 * c4);
+                    shift[0] = __builtin_fmaf(a0.x, out_scale, bias_fixed.x); shift[1] = __builtin_fmaf(a0.y, out_scale, bias_fixed.y);
+                    shift[2] = __builtin_fmaf(a0.z, out_scale, bias_fixed.z); shift[3] = __builtin_fmaf(a0.w, out_scale, bias_fixed.w);
+                }
 #pragma unroll
                 for (int g0 = 0; g0 < NIT; g0 += GR) {
                     float4 r4[HAS_RES ? GR : 1], g4[HAS_GATE ? GR : 1];
@@ -373,6 +385,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
                         }
                         if (HAS_RES) { v[0] += r4[u].x; v[1] += r4[u].y; v[2] += r4[u].z; v[3] += r4[u].w; }
                         buf_store4s(rsrcC, offC, (uint32_t)(rg * g.ldc * 4), make_float4(v[0], v[1], v[2], v[3]));
+                        if (STATS) {
+                            const bool live = (g0 + u) * RPI + rsub < slab_rows;          // rows past M are not statistics
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float dlt = live ? v[e] - shift[e] : 0.f;
+                                s1[e] += dlt;
+                                s2[e] = __builtin_fmaf(dlt, dlt, s2[e]);
+                            }
+                        }
                         if (want_max) {
                             if (tile_full)
                                 cmax = fmaxf(fmaxf(fmaxf(cmax, fabsf(v[0])), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -381,21 +402,49 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
                         }
                     }
                 }
+                if (STATS && slab_rows > 0) {
+                    // the slab's rows of one column group sit in the lanes c4, c4 + C4, ...: fold them, then merge the slab
+                    // (n_s, mean_s, M2_s) into the running partial (Chan et al.); every lane of a group ends with the same values
+#pragma unroll
+                    for (int o = C4; o < 64; o <<= 1)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+                    const float ns = (float)slab_rows, ntot = bn_n + ns;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float mean_s = shift[e] + s1[e] / ns;
+                        const float m2_s = s2[e] - s1[e] * s1[e] / ns;
+                        const float dm = mean_s - bn_mean[e];
+                        bn_mean[e] += dm * (ns / ntot);
+                        bn_m2[e] += m2_s + dm * dm * (bn_n * ns / ntot);
+                    }
+                    bn_n = ntot;
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
+            if (STATS && rsub == 0 && col_ok) {
+                float* w = g.bn_ws + ((long)(ty * WM + wm) * 3) * g.N + col;
+                *reinterpret_cast<float4*>(w) = make_float4(bn_n, bn_n, bn_n, bn_n);
+                *reinterpret_cast<float4*>(w + g.N) = make_float4(bn_mean[0], bn_mean[1], bn_mean[2], bn_mean[3]);
+                *reinterpret_cast<float4*>(w + 2 * (long)g.N) = make_float4(fmaxf(bn_m2[0], 0.f), fmaxf(bn_m2[1], 0.f), fmaxf(bn_m2[2], 0.f),
+                                                                            fmaxf(bn_m2[3], 0.f));
+            }
         };
-        // (a gate operand belongs to data gradients, which have no dropout of their own)
-        if (has_gate) {
-            if (has_res) run(std::true_type{}, std::true_type{}, std::false_type{});
-            else run(std::false_type{}, std::true_type{}, std::false_type{});
+        // (a gate operand belongs to data gradients, which have no dropout of their own; BatchNorm partials belong to a
+        // convolution's forward, which has a bias and nothing else)
+        if (g.bn_ws != nullptr) {
+            run(std::false_type{}, std::false_type{}, std::false_type{}, std::true_type{});
+        } else if (has_gate) {
+            if (has_res) run(std::true_type{}, std::true_type{}, std::false_type{}, std::false_type{});
+            else run(std::false_type{}, std::true_type{}, std::false_type{}, std::false_type{});
         } else if (do_drop) {
-            if (has_res) run(std::true_type{}, std::false_type{}, std::true_type{});
-            else run(std::false_type{}, std::false_type{}, std::true_type{});
+            if (has_res) run(std::true_type{}, std::false_type{}, std::true_type{}, std::false_type{});
+            else run(std::false_type{}, std::false_type{}, std::true_type{}, std::false_type{});
         } else {
-            if (has_res) run(std::true_type{}, std::false_type{}, std::false_type{});
-            else run(std::false_type{}, std::false_type{}, std::false_type{});
+            if (has_res) run(std::true_type{}, std::false_type{}, std::false_type{}, std::false_type{});
+            else run(std::false_type{}, std::false_type{}, std::false_type{}, std::false_type{});
         }
     } else {
     #pragma unroll
@@ -509,7 +558,31 @@ int h3_tile_choice(long M, long N, long K) {
     return best;
 }
 
+// tile geometry of a tile code: rows per tile, waves along the rows; even = its lanes keep one column group (the fast epilogue)
+static bool h3_tile_geometry(int tile, int& bm, int& wm) {
+    switch (tile) {
+        case H3_TILE_256: bm = 256; wm = 2; return true;
+        case H3_TILE_256x128: bm = 256; wm = 4; return true;
+        case H3_TILE_256x128_PAIR: bm = 256; wm = 2; return true;
+        case TILE_64x128: bm = 64; wm = 2; return true;
+        case TILE_64: bm = 64; wm = 2; return true;
+        case TILE_128x96: bm = 128; wm = 4; return false;          // 96-wide wave tile: generic epilogue
+        default: bm = 128; wm = 2; return true;                    // 128 x 128
+    }
+}
+
+int h3_bn_blocks(long M, long N, long K) {
+    int bm, wm;
+    if (!h3_tile_geometry(h3_tile_choice(M, N, K), bm, wm)) return 0;
+    const long nb = (long)cdiv(M, bm) * wm;
+    return (nb <= 512 && N % 4 == 0 && (long)(M + 256) * N * 4 < (1L << 32)) ? (int)nb : 0;   // 512 = BN_MAXBLK of norm.hip
+}
+
 int dispatch_h3(const GemmArgs& g, hipStream_t stream) {
+    if (g.bn_ws != nullptr && (h3_bn_blocks(g.M, g.N, g.K) == 0 || g.residual || g.relu_out || g.drop_thr || g.act)) {
+        set_error("fp16x3 GEMM: BatchNorm partials were requested for a shape / epilogue that cannot emit them");
+        return TTTS_ERR_INVALID;
+    }
     // the epilogue addresses the output, the residual and the gate operand with 32-bit byte offsets (buffer instructions)
     const long ldmax = g.ldc > g.ldr ? g.ldc : g.ldr;
     if (((long)g.M + 256) * ldmax * 4 >= (1L << 32)) {

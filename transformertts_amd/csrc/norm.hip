@@ -619,6 +619,19 @@ int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* runni
     return TTTS_OK;
 }
 
+int ttts_bn_train_stats_from_partials(const float* partials, int nblk, float* mean, float* invstd, float* running_mean,
+                                      float* running_var, int64_t* num_batches_tracked, int C, float momentum, float eps,
+                                      void* stream) {
+    // the second half of ttts_bn_train_stats on row-chunk partials [nblk][3][C] = (count, mean, M2) that somebody else wrote
+    // (the fp16x3 convolution's epilogue: ttts_conv1d_fwd_h3 with bn_partials)
+    TTTS_REQUIRE(partials && mean && invstd, "bn_train_stats_from_partials: null pointer");
+    TTTS_REQUIRE(nblk > 0 && nblk <= BN_MAXBLK && C > 0, "bn_train_stats_from_partials: nblk=%d must be in 1..%d", nblk, BN_MAXBLK);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, mean, invstd,
+                       running_mean, running_var, num_batches_tracked, nblk, C, momentum, eps);
+    TTTS_LAUNCH_CHECK("bn_stats_final_kernel");
+    return TTTS_OK;
+}
+
 int ttts_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C, float eps,
                        void* stream) {
     TTTS_REQUIRE(running_mean && running_var && mean && invstd && C > 0, "bn_eval_stats: bad arguments");

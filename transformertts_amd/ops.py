@@ -802,11 +802,18 @@ class ConvBNFn(torch.autograd.Function):
         dev = x.device
         conv_w = _chk(conv_w, "conv.weight")
         y = torch.empty(B, T, cout, dtype=torch.float32, device=dev)
+        M = B * T
+        bn_nblk, bn_ws = 0, None
         if _fwd_h3(taps * cin, cout, cin):
             if x_amax is None:
                 x_amax = _amax(x)
+            if training and M > 1:
+                # the convolution's epilogue leaves BatchNorm's row-chunk partials behind: no statistics pass over y
+                bn_nblk = lib.ttts_conv1d_fwd_h3_bn_blocks(B, T, cin, cout, taps)
+                if bn_nblk > 0:
+                    bn_ws = _ws(lib.ttts_bn_workspace_bytes(M, cout), dev)
             _lib.check(lib.ttts_conv1d_fwd_h3(_p(x), _p(_planes(conv_w, 6, cout, taps * cin, cin, taps)), _p(conv_b), _p(y),
-                                              B, T, cin, cout, taps, _p(x_amax), _stream()), "ttts_conv1d_fwd_h3")
+                                              B, T, cin, cout, taps, _p(x_amax), _p(bn_ws), _stream()), "ttts_conv1d_fwd_h3")
         elif GEMM_MODE == "x6":
             _lib.check(lib.ttts_conv1d_fwd_x6(_p(x), _p(_planes(conv_w, 2, cout, taps * cin, cin, taps)), _p(conv_b), _p(y),
                                               B, T, cin, cout, taps, _stream()), "ttts_conv1d_fwd_x6")
@@ -818,8 +825,11 @@ class ConvBNFn(torch.autograd.Function):
                        "ttts_conv1d_fwd")
         mean = torch.empty(cout, dtype=torch.float32, device=dev)
         invstd = torch.empty(cout, dtype=torch.float32, device=dev)
-        M = B * T
-        if training:
+        if training and bn_ws is not None:
+            _lib.check(lib.ttts_bn_train_stats_from_partials(_p(bn_ws), bn_nblk, _p(mean), _p(invstd), _p(running_mean),
+                                                             _p(running_var), _p(nbt), cout, float(momentum), float(eps),
+                                                             _stream()), "ttts_bn_train_stats_from_partials")
+        elif training:
             ws = _ws(lib.ttts_bn_workspace_bytes(M, cout), dev)
             _lib.check(lib.ttts_bn_train_stats(_p(y), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(nbt),
                                                _p(ws), ws.numel() * 4, M, cout, float(momentum), float(eps), _stream()),
