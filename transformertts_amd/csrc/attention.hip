@@ -2032,11 +2032,23 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
         }
         float pd[16];
         const bool full = (kw0 + 32 <= klen) && (!CAUSAL || kw0 + 31 <= qt0) && (qt0 + QS <= a.Tq);   // wave-uniform
+        // the row statistics of this lane's 16 queries: registers 4g .. 4g+3 are four consecutive rows, so each array is four
+        // 16-byte LDS reads (broadcast within a half-wave), not sixteen dword reads
+        float mq_r[16], l2_r[16], dl_r[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 m4 = *reinterpret_cast<const float4*>(lse_s + 8 * g4 + 4 * half);
+            const float4 l4 = *reinterpret_cast<const float4*>(l2_s + 8 * g4 + 4 * half);
+            const float4 d4 = *reinterpret_cast<const float4*>(delta_s + 8 * g4 + 4 * half);
+            mq_r[4 * g4] = m4.x; mq_r[4 * g4 + 1] = m4.y; mq_r[4 * g4 + 2] = m4.z; mq_r[4 * g4 + 3] = m4.w;
+            l2_r[4 * g4] = l4.x; l2_r[4 * g4 + 1] = l4.y; l2_r[4 * g4 + 2] = l4.z; l2_r[4 * g4 + 3] = l4.w;
+            dl_r[4 * g4] = d4.x; dl_r[4 * g4 + 1] = d4.y; dl_r[4 * g4 + 2] = d4.z; dl_r[4 * g4 + 3] = d4.w;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q_g = qt0 + acc_row(r, half);
-            const float mq = has_rs ? lse_s[acc_row(r, half)] : 0.f;
-            const float l2 = has_rs ? l2_s[acc_row(r, half)] : l2_s[acc_row(r, half)] * 1.4426950408889634f;
+            const float mq = has_rs ? mq_r[r] : 0.f;
+            const float l2 = has_rs ? l2_r[r] : l2_r[r] * 1.4426950408889634f;
             float p = fast_exp2(__builtin_fmaf(s[r], H3A_C2, -mq) - l2);
             if (!full) p = (kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq) ? p : 0.f;
             pd[r] = p;
@@ -2072,7 +2084,7 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
                     g = keep ? g : 0.f;                  // the 1/(1-p) factors ride in dp_unscale and in dv's final scale
                     pk = keep ? pk : 0.f;
                 }
-                ds[r + e] = pd[r + e] * (g - delta_s[acc_row(r + e, half)]);
+                ds[r + e] = pd[r + e] * (g - dl_r[r + e]);
                 pd[r + e] = pk;
             }
         }

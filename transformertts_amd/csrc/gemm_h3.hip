@@ -434,8 +434,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
         };
         // (a gate operand belongs to data gradients, which have no dropout of their own; BatchNorm partials belong to a
         // convolution's forward, which has a bias and nothing else)
-        if (g.bn_ws != nullptr) {
-            run(std::false_type{}, std::false_type{}, std::false_type{}, std::true_type{});
+        bool stats_done = false;
+        if constexpr (CLIP) {          // (only the convolution instantiations carry the statistics code: it costs registers)
+            if (g.bn_ws != nullptr) {
+                run(std::false_type{}, std::false_type{}, std::false_type{}, std::true_type{});
+                stats_done = true;
+            }
+        }
+        if (stats_done) {
         } else if (has_gate) {
             if (has_res) run(std::true_type{}, std::true_type{}, std::false_type{}, std::false_type{});
             else run(std::false_type{}, std::true_type{}, std::false_type{}, std::false_type{});
@@ -579,7 +585,7 @@ int h3_bn_blocks(long M, long N, long K) {
 }
 
 int dispatch_h3(const GemmArgs& g, hipStream_t stream) {
-    if (g.bn_ws != nullptr && (h3_bn_blocks(g.M, g.N, g.K) == 0 || g.residual || g.relu_out || g.drop_thr || g.act)) {
+    if (g.bn_ws != nullptr && (g.T <= 0 || h3_bn_blocks(g.M, g.N, g.K) == 0 || g.residual || g.relu_out || g.drop_thr || g.act)) {
         set_error("fp16x3 GEMM: BatchNorm partials were requested for a shape / epilogue that cannot emit them");
         return TTTS_ERR_INVALID;
     }

@@ -175,8 +175,13 @@ __device__ __forceinline__ float h3_partials_max(const float* __restrict__ parti
     }
     return wave_max(m);
 }
+// (the result is wave-uniform: handed back in scalar registers, it costs the kernels no VGPRs)
+__device__ __forceinline__ float h3_uniform(float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); }
 __device__ __forceinline__ void h3_operand_scale(const float* __restrict__ partials, int n, int lane, float& scale, float& inv) {
-    h3_pow2_scale(h3_partials_max(partials, n, lane), scale, inv);
+    float s, i;
+    h3_pow2_scale(h3_partials_max(partials, n, lane), s, i);
+    scale = h3_uniform(s);
+    inv = h3_uniform(i);
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
