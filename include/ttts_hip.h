@@ -208,13 +208,14 @@ int ttts_bn_eval_stats(const float* running_mean, const float* running_var, floa
 int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       float* z, int64_t M, int C, int act, float drop_p, uint64_t seed, const uint64_t* step_seed,
                       float* z_amax_out, void* stream);
-/* train-mode backward through drop/act/BN: dx, dgamma, dbeta from dz and the saved x, mean, invstd */
+/* backward through drop/act/BN: dx, dgamma, dbeta from dz and the saved x, mean, invstd.  batch_stats = 1: train mode (mean /
+ * invstd are the batch statistics of x, whose derivative dx carries); 0: eval mode (running statistics, constants). */
 int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float* invstd, const float* gamma,
                 const float* beta, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int C,
                 int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate, float* dx_amax_out,
-                void* stream);
+                int batch_stats, void* stream);
 
-/* ------------------------------------------------------------------ LayerNorm over the last dim (d % 64 == 0, d <= 1024)
+/* ------------------------------------------------------------------ LayerNorm over the last dim (1 <= d <= 1024)
  * Replaces nn.LayerNorm norm1/2/3 of the encoder/decoder layers (torch/nn/modules/transformer.py:951-956,
  * model/layers.py:47-50).  The residual sum is produced by the preceding GEMM's epilogue. */
 int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
@@ -232,28 +233,35 @@ int ttts_layernorm_bwd_drop(const float* dy, const float* x, const float* mean, 
                             int accumulate, float* dacc, float drop_p, uint64_t seed, const uint64_t* step_seed,
                             float* dacc_amax, ttts_reduce_queue* queue, void* stream);
 
-/* ------------------------------------------------------------------ attention (head_dim = 64)
+/* ------------------------------------------------------------------ attention (64 columns per head)
  * Scaled dot-product attention with masks computed from lengths in-kernel (no mask tensors):
- * key j of batch b is dead when j >= key_lens[b], or (causal) j > i.  q is scaled by sqrt(1/64) before
- * q.k^T exactly as torch does (torch/nn/functional.py:6578).  q/k/v/o are addressed as
- * ptr[(b*T + t)*ld + h*64 + c], so packed in-proj outputs are consumed in place.
+ * key j of batch b is dead when j >= key_lens[b], or (causal) j > i.  q is multiplied by q_scale before q.k^T exactly as
+ * torch does (q * sqrt(1 / head_dim), torch/nn/functional.py:6578): 0.125 for head_dim 64.  q/k/v/o are addressed as
+ * ptr[(b*T + t)*ld + h*64 + c], so packed in-proj outputs of 64-wide heads are consumed in place; narrower heads
+ * (head_dim < 64) are zero-padded to 64 columns by ttts_heads_pad (zeros add nothing to q.k^T and produce zero output
+ * columns) and passed with q_scale = sqrt(1 / head_dim).
  * Replaces: encoder self-attention and decoder `_sa_block` (torch/nn/modules/transformer.py:961-978,
  * 1158-1175 -> F.scaled_dot_product_attention, torch/nn/functional.py:6629) and the decoder's
  * `_mha_block` cross-attention with need_weights=True, average_attn_weights=False
  * (model/layers.py:54-74; torch/nn/functional.py:6576-6610).
  * attn (optional) receives the per-head, post-dropout weights (B,H,Tq,Tk); lse (B,H,Tq) is saved for backward. */
+/* head_dim < 64: dst (rows, H*64) = the H heads of src (rows x ld_src, head h at column h*head_dim) zero-padded to 64
+ * columns each; ttts_heads_unpad writes the first head_dim columns of every 64-wide head of src (rows, H*64) back to
+ * dst (rows x ld_dst, head h at column h*head_dim), leaving the other columns of dst untouched. */
+int ttts_heads_pad(const float* src, int64_t ld_src, float* dst, int64_t rows, int H, int head_dim, void* stream);
+int ttts_heads_unpad(const float* src, float* dst, int64_t ld_dst, int64_t rows, int H, int head_dim, void* stream);
 int ttts_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                        const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                       int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
+                       int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 /* dq, dk, dv from do_ (recomputes the probabilities from q, k and lse); delta (B,H,Tq) is scratch */
 int ttts_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* do_,
                        const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                        int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                       int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
+                       int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 /* Split-precision forms of the two entry points above (bf16x6 MFMA products, fp32-grade results; same arguments). */
 int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
+                          int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 /* fp16x3 form of the forward (three f16 MFMA terms; Q/8, K and V pre-scaled from their partial maxima q_amax / k_amax /
  * v_amax -- TTTS_AMAX_SLOTS floats each, the same array three times for a packed projection output -- and probabilities x 2^10);
  * lse in natural units, so either backward form can follow it.  o_amax_out: NULL, or zeroed TTTS_AMAX_SLOTS floats: max|o|.
@@ -264,19 +272,19 @@ int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float*
  * are only good to ulp(lse), i.e. 6 % at scores of 1e6, where torch -- which keeps the probabilities -- is still accurate). */
 int ttts_attention_fwd_h3(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* q_amax,
+                          int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* q_amax,
                           const float* k_amax, const float* v_amax, float* o_amax_out, float* rowstat_out, void* stream);
 int ttts_attention_bwd_x6(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
+                          int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream);
 /* fp16x3 form of the backward.  d_o is pre-scaled by the power of two that puts max|d_o| in [2^11, 2^12) (do_amax = the
  * TTTS_AMAX_SLOTS partial maxima of ttts_amax_partials(d_o)); dS = P (dP - delta) lives in registers as a lane-local accumulator
  * column and gets a lane-local pre-scale that is lowered on the fly together with its accumulator. */
 int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
+                          int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
                           float* dq_amax_out, float* dkv_amax_out, const float* q_amax, const float* k_amax,
                           const float* v_amax, const float* rowstat /* of the h3 forward, or NULL: use lse */, void* stream);
 

@@ -268,6 +268,8 @@ if __name__ == "__main__":
         ("helpers", lambda: golden_helpers("helpers")),
         ("tiny_model", lambda: golden_model("tiny_model", "tiny", B=3, Tp=12, Tm=40, w_seed=11, b_seed=21, align_stride=1)),
         ("base_model", lambda: golden_model("base_model", "base", B=2, Tp=60, Tm=300, w_seed=12, b_seed=22, align_stride=8)),
+        # SURVEY 8c's tiny-golden plan: d_model 32, 2 heads (head_dim 16), 1+1 layers, B = 3 ragged, Tp <= 12, Tm <= 40
+        ("micro_model", lambda: golden_model("micro_model", "micro", B=3, Tp=12, Tm=40, w_seed=16, b_seed=26, align_stride=1)),
         # BASELINE configs[4]: d_model 512, 6+6 layers, 8 heads, d_ffn 2048 (fewer gradient samples per parameter: 282 tensors)
         ("scaled_model", lambda: golden_model("scaled_model", "scaled", B=2, Tp=60, Tm=300, w_seed=14, b_seed=24, align_stride=8,
                                               max_grad_samples=1024)),

@@ -56,7 +56,8 @@ def _oracle64(cfg, w_seed):
 
 @pytest.mark.parametrize("cfg_name,B,Tp,Tm,w_seed,b_seed", [("tiny", 3, 12, 40, 11, 21), ("base", 2, 60, 300, 12, 22),
                                                             ("base", 4, 100, 870, 13, 23), ("scaled", 2, 60, 300, 14, 24),
-                                                            ("base", 16, 100, 870, 15, 25)])
+                                                            ("base", 16, 100, 870, 15, 25),
+                                                            ("micro", 3, 12, 40, 16, 26)])      # d_model 32, head_dim 16
 def test_forward_backward_vs_oracle(cfg_name, B, Tp, Tm, w_seed, b_seed):
     from oracle import synth_batch, oracle_forward, oracle_loss
     from transformertts_amd.loss import TransformerTTSLoss
@@ -111,12 +112,12 @@ def test_forward_backward_vs_oracle(cfg_name, B, Tp, Tm, w_seed, b_seed):
         for k, v in sorted({**errs, **{"grad/" + k: v for k, v in gerrs.items()}}.items(), key=lambda kv: -kv[1]):
             f.write(f"{v:.3e} {k}\n")
     bad = {k: v for k, v in errs.items() if not v < GATE}
-    gate = GRAD_GATE_TINY if cfg_name == "tiny" else GRAD_GATE
+    gate = GRAD_GATE_TINY if cfg_name in ("tiny", "micro") else GRAD_GATE
     bad.update({k: v for k, v in gerrs.items() if not v < gate})
     assert not bad, bad
 
 
-@pytest.mark.parametrize("fixture", ["base_model", "scaled_model"])
+@pytest.mark.parametrize("fixture", ["base_model", "scaled_model", "micro_model"])
 def test_golden_outputs_direct(golden_dir, fixture):
     """HIP path against the committed reference outputs themselves (fp32 reference run): base config and the scaled
     configuration of BASELINE configs[4] (d_model 512, 6+6 layers, 8 heads, d_ffn 2048)."""
@@ -422,3 +423,118 @@ def test_inference_kv_cache_vs_recompute_vs_oracle(golden_dir):
     # early stop: a threshold every item passes at once ends the loop after the first frame
     one = m.inference(ph, pl, max_len=L, stop_threshold=0.0)
     assert one["pred_melspec"].shape[1] == 1 and one["pred_stop"].shape[1] == 1
+
+
+@pytest.mark.parametrize("which", ["decoder", "encoder"])
+def test_pre_norm_layers_match_torch(which):
+    """norm_first=True (the other branch of the reference's decoder layer, model/layers.py:41-45, and of torch's encoder
+    layer): output and gradients against torch's own layers evaluated in fp64 on the CPU with the same weights and masks."""
+    from transformertts_amd.model.layers import TransformerDecoderLayer, TransformerEncoderLayer
+    torch.manual_seed(3)
+    d, H, dff, B, Tm, Tp = 128, 2, 256, 3, 50, 17
+    x = torch.randn(B, Tm, d)
+    mem = torch.randn(B, Tp, d)
+    tl, ml = torch.tensor([50, 31, 8]), torch.tensor([17, 9, 3])
+    gout = torch.randn(B, Tm, d)
+    if which == "decoder":
+        ours = TransformerDecoderLayer(d, H, dff, dropout=0.0, norm_first=True).to("cuda")
+        ref = torch.nn.TransformerDecoderLayer(d, H, dff, dropout=0.0, norm_first=True, batch_first=True).double()
+    else:
+        ours = TransformerEncoderLayer(d, H, dff, dropout=0.0, norm_first=True).to("cuda")
+        ref = torch.nn.TransformerEncoderLayer(d, H, dff, dropout=0.0, norm_first=True, batch_first=True).double()
+    with torch.no_grad():
+        for p in ours.parameters():
+            p.copy_(torch.randn(p.shape) * (0.3 if p.dim() > 1 else 0.1) + (1.0 if "norm" in "" else 0.0))
+    ref.load_state_dict({k: v.detach().cpu().double() for k, v in ours.state_dict().items()}, strict=True)
+    ours.train(); ref.train()
+    xg = x.to("cuda").requires_grad_()
+    xr = x.double().requires_grad_()
+    kpm = torch.arange(Tm)[None, :] >= tl[:, None]
+    if which == "decoder":
+        out, _ = ours(xg, mem.to("cuda"), tgt_lens=tl.to("cuda"), memory_lens=ml.to("cuda"), tgt_is_causal=True)
+        causal = torch.triu(torch.ones(Tm, Tm), 1).bool()
+        mkpm = torch.arange(Tp)[None, :] >= ml[:, None]
+        want = ref(xr, mem.double(), tgt_mask=causal, tgt_key_padding_mask=kpm, memory_key_padding_mask=mkpm)
+    else:
+        out = ours(xg, tl.to("cuda"))
+        want = ref(xr, src_key_padding_mask=kpm)
+    valid = (~kpm).unsqueeze(-1)                      # rows past an utterance's length are padding on both sides
+    out.backward(gout.to("cuda") * valid.to("cuda"))
+    want.backward(gout.double() * valid)
+    assert rel_l2(out * valid.to("cuda"), want * valid) < 1e-5, rel_l2(out * valid.to("cuda"), want * valid)
+    assert rel_l2(xg.grad, xr.grad) < 1e-5, rel_l2(xg.grad, xr.grad)
+    for (n, p), (_, q) in zip(ours.named_parameters(), ref.named_parameters()):
+        if q.grad is None or q.grad.norm() < 1e-9:
+            continue
+        assert rel_l2(p.grad, q.grad) < 1e-4, (n, rel_l2(p.grad, q.grad))
+
+
+def test_eval_mode_backward_through_batchnorm():
+    """ConvNormBN in eval mode (running statistics are constants of the graph) is differentiable like the reference's: the
+    gradients of the input, the convolution and the affine parameters against torch in fp64."""
+    from transformertts_amd.model.module import ConvNormBN
+    torch.manual_seed(5)
+    B, T, cin, cout = 3, 41, 64, 96
+    m = ConvNormBN(cin, cout, 5, activation="tanh").to("cuda")
+    with torch.no_grad():
+        m.bn.running_mean.copy_(torch.randn(cout) * 0.3)
+        m.bn.running_var.copy_(torch.rand(cout) + 0.5)
+        m.bn.weight.copy_(1 + 0.2 * torch.randn(cout)); m.bn.bias.copy_(0.1 * torch.randn(cout))
+    m.eval()
+    x = torch.randn(B, T, cin)
+    xg = x.to("cuda").requires_grad_()
+    g = torch.randn(B, T, cout)
+    z = m.fused(xg, 2, 0.0)            # tanh epilogue
+    z.backward(g.to("cuda"))
+    conv = torch.nn.Conv1d(cin, cout, 5, padding=2).double()
+    bn = torch.nn.BatchNorm1d(cout).double()
+    conv.load_state_dict({k: v.detach().cpu().double() for k, v in m.conv.state_dict().items()})
+    bn.load_state_dict({k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in m.bn.state_dict().items()})
+    conv.eval(); bn.eval()
+    xr = x.double().requires_grad_()
+    zr = torch.tanh(bn(conv(xr.transpose(1, 2)))).transpose(1, 2)
+    zr.backward(g.double())
+    assert rel_l2(z, zr) < 1e-5 and rel_l2(xg.grad, xr.grad) < 1e-5
+    assert rel_l2(m.conv.weight.grad, conv.weight.grad) < 1e-5 and rel_l2(m.conv.bias.grad, conv.bias.grad) < 1e-5
+    assert rel_l2(m.bn.weight.grad, bn.weight.grad) < 1e-5 and rel_l2(m.bn.bias.grad, bn.bias.grad) < 1e-5
+    assert int(m.bn.num_batches_tracked) == 0
+
+
+@pytest.mark.parametrize("d,H", [(96, 3), (64, 4), (48, 1)])
+def test_attention_heads_narrower_than_64(d, H):
+    """head_dim 32 / 16 / 48: the kernels work on 64-column heads, narrower ones are zero-padded copies; q is scaled by
+    sqrt(1 / head_dim) as torch does.  Self- (causal) and cross-attention with weights against fp64."""
+    import math
+    from transformertts_amd import ops
+    torch.manual_seed(1)
+    B, T, Tk, hd = 2, 70, 23, d // H
+    qkv = torch.randn(B, T, 3 * d)
+    lens = torch.tensor([70, 33])
+    do = torch.randn(B, T, d)
+
+    def ref(q, k, v, kl, causal):
+        q = q.double().view(B, -1, H, hd).transpose(1, 2); k = k.double().view(B, -1, H, hd).transpose(1, 2)
+        v = v.double().view(B, -1, H, hd).transpose(1, 2)
+        s = (q * math.sqrt(1.0 / hd)) @ k.transpose(-1, -2)
+        mask = torch.arange(k.shape[2])[None, None, None, :] >= kl[:, None, None, None]
+        if causal:
+            mask = mask | (torch.arange(k.shape[2])[None, :] > torch.arange(q.shape[2])[:, None])
+        p = torch.softmax(s.masked_fill(mask, float("-inf")), -1)
+        return (p @ v).transpose(1, 2).reshape(B, -1, d), p
+    qg = qkv.to("cuda").requires_grad_()
+    o = ops.self_attention(qg, lens.to("cuda"), H, True, 0.0, 0)
+    o.backward(do.to("cuda"))
+    qr = qkv.double().requires_grad_()
+    orf, _ = ref(qr[..., :d], qr[..., d:2 * d], qr[..., 2 * d:], lens, True)
+    orf.backward(do.double())
+    assert rel_l2(o, orf) < 5e-6 and rel_l2(qg.grad, qr.grad) < 2e-5, (rel_l2(o, orf), rel_l2(qg.grad, qr.grad))
+    q, kv = torch.randn(B, T, d), torch.randn(B, Tk, 2 * d)
+    kl = torch.tensor([23, 7])
+    q1, kv1 = q.to("cuda").requires_grad_(), kv.to("cuda").requires_grad_()
+    o2, attn = ops.cross_attention(q1, kv1, kl.to("cuda"), H, 0.0, 0, True)
+    o2.backward(do.to("cuda"))
+    q2, kv2 = q.double().requires_grad_(), kv.double().requires_grad_()
+    o2r, pr = ref(q2, kv2[..., :d], kv2[..., d:], kl, False)
+    o2r.backward(do.double())
+    assert rel_l2(o2, o2r) < 5e-6 and rel_l2(attn, pr) < 5e-6
+    assert rel_l2(q1.grad, q2.grad) < 2e-5 and rel_l2(kv1.grad, kv2.grad) < 2e-5

@@ -50,7 +50,7 @@ def test_bench_workload_is_the_oracles_workload():
     stay the same thing."""
     from oracle import spec, synth
     from transformertts_amd import workload
-    for name in ("base", "scaled", "tiny"):
+    for name in ("base", "scaled", "tiny", "micro"):
         assert workload.model_config(name) == spec.model_config(name), name
     for kw in (dict(B=4, Tp=100, Tm=870, ragged=False, seed=1234), dict(B=7, Tp=60, Tm=300, ragged=True, seed=5),
                dict(B=3, Tp=12, Tm=40, n_mels=16, n_phon=30, ragged=True, seed=21)):
@@ -80,7 +80,7 @@ def test_state_dict_contract_and_ctor_signature():
     import inspect
     from oracle.spec import model_config, state_spec
     from transformertts_amd.model import TransformerTTS
-    for name in ("base", "tiny", "scaled"):
+    for name in ("base", "tiny", "scaled", "micro"):
         cfg = model_config(name)
         m = TransformerTTS(**cfg, device="cpu")
         sd, spec = m.state_dict(), state_spec(cfg)

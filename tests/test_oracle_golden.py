@@ -58,6 +58,7 @@ def _check_grads(g, sd, tol):
 # while exact arithmetic of the restatement reproduces the reference's fp32 gradients to 5.5e-5 and its outputs to
 # 2.5e-5 (the reference's own fp32 rounding through the 512-channel post-net): measured when the fixture was generated.
 @pytest.mark.parametrize("name,dtype,out_tol,grad_tol", [("tiny_model", torch.float32, OUT_TOL, GRAD_TOL),
+                                                         ("micro_model", torch.float32, OUT_TOL, GRAD_TOL),
                                                          ("base_model", torch.float32, OUT_TOL, GRAD_TOL),
                                                          ("scaled_model", torch.float64, 5e-5, 2e-4)])
 def test_forward_eval_and_train(golden_dir, name, dtype, out_tol, grad_tol):

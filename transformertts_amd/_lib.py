@@ -54,17 +54,19 @@ SIGNATURES = {
     "ttts_bn_train_stats": (I, [P, P, P, P, P, P, P, Z, L, I, F, F, P]),
     "ttts_bn_eval_stats": (I, [P, P, P, P, I, F, P]),
     "ttts_bn_apply_fwd": (I, [P, P, P, P, P, P, L, I, I, F, U, P, P, P]),
-    "ttts_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, Z, L, I, I, F, U, P, I, P, P]),
+    "ttts_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, Z, L, I, I, F, U, P, I, P, I, P]),
     "ttts_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P, P]),
     "ttts_layernorm_bwd_workspace_bytes": (Z, [I]),
     "ttts_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P, P]),
     "ttts_layernorm_bwd_drop": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P, F, U, P, P, P, P]),
-    "ttts_attention_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P, P]),
-    "ttts_attention_fwd_x6": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P, P]),
-    "ttts_attention_fwd_h3": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U, P, P, P, P, P, P, P]),
-    "ttts_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P, P]),
-    "ttts_attention_bwd_x6": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P, P]),
-    "ttts_attention_bwd_h3": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, U, P, P, P, P, P, P, P, P, P]),
+    "ttts_attention_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U, P, P]),
+    "ttts_attention_fwd_x6": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U, P, P]),
+    "ttts_attention_fwd_h3": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U, P, P, P, P, P, P, P]),
+    "ttts_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, P]),
+    "ttts_attention_bwd_x6": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, P]),
+    "ttts_attention_bwd_h3": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, P, P, P, P, P, P, P, P]),
+    "ttts_heads_pad": (I, [P, L, P, L, I, I, P]),
+    "ttts_heads_unpad": (I, [P, P, L, L, I, I, P]),
     "ttts_embedding_fwd": (I, [P, P, P, L, I, I, P, P]),
     "ttts_embedding_bwd": (I, [P, P, P, L, I, I, I, P]),
     "ttts_posenc_fwd": (I, [P, P, P, P, I, I, I, F, U, P, P, P]),

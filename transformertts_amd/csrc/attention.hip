@@ -61,6 +61,7 @@ struct AttnArgs {
     const int64_t* key_lens;
     int B, H, Tq, Tk;
     int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    float qscale;                             // q is multiplied by this before q.k^T: sqrt(1 / head_dim) (torch/nn/functional.py:6578)
     float drop_scale; uint32_t thr; uint64_t seed; const uint64_t* step_seed;
     const float* do_amax; int do_amax_n;      // fp16x3 backward: partial maxima of |dout| (ttts_amax_partials)
     float* amax_dq; float* amax_dkv;          // fp16x3 backward: NULL, or caller-zeroed TTTS_AMAX_SLOTS-slot arrays receiving max|dq| / max|dk, dv|
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256, TTTS_FWD_W) void attn_fwd_kernel(AttnArgs a) {
 
     // Q fragment: lane (query l31, half) holds Q[q][2j+half] * sqrt(1/64)
     float qreg[32];
-    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
+    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, a.qscale);
     wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < 32; ++j) qreg[j] = scratch[l31 * KT_LD + 2 * j + half];
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256, TTTS_DQ_W) void attn_bwd_dq_kernel(AttnArgs a)
     const uint32_t rowid = (uint32_t)(arow + qg);
 
     float qreg[32], greg[32];
-    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
+    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, a.qscale);
     wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < 32; ++j) qreg[j] = scratch[l31 * KT_LD + 2 * j + half];
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256, TTTS_DQ_W) void attn_bwd_dq_kernel(AttnArgs a)
         }
     }
     __syncthreads();
-    wave_store_rows(dq, scratch, a.dq + (long)b * a.Tq * a.lddq + h * HD, qw0, a.Tq, a.lddq, lane, 0.125f);
+    wave_store_rows(dq, scratch, a.dq + (long)b * a.Tq * a.lddq + h * HD, qw0, a.Tq, a.lddq, lane, a.qscale);
 }
 
 // =====================================================================================  backward: dK, dV
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(256, TTTS_DKV_W) void attn_bwd_dkv_kernel(AttnArgs 
 
     for (int qs = qs_begin; qs < nqs; ++qs) {
         __syncthreads();
-        stage_rows<true>(qb_, (long)qs * KB, a.Tq, a.ldq, tid, Qs, 0.125f);
+        stage_rows<true>(qb_, (long)qs * KB, a.Tq, a.ldq, tid, Qs, a.qscale);
         stage_rows<true>(gb_, (long)qs * KB, a.Tq, a.ldo, tid, Gs, 1.f);
         if (tid < KB) {
             int q = qs * KB + tid;
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDX_W) void attn_fwd_x6_ke
 
     // Q fragments: lane (query l31, half) holds Q[q][16 s + 8 half + 0..7] / 8 for the four d-steps s, split in three
     bf16x8 qf[4][3];
-    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
+    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, a.qscale);
     wave_lds_sync();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -880,7 +881,7 @@ __device__ __forceinline__ float attn_wg_quarter_max(const float* __restrict__ p
     return wave_max(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
 }
 __device__ __forceinline__ H3Scales attn_h3_scales(const float* q_amax, const float* k_amax, const float* v_amax, int lane,
-                                                   const float* g_amax = nullptr) {
+                                                   float qscale, const float* g_amax = nullptr) {
     H3Scales h;
     float s, i;
     __shared__ float quarter[4][4];
@@ -899,7 +900,7 @@ __device__ __forceinline__ H3Scales attn_h3_scales(const float* q_amax, const fl
     const float mk = k_own ? fmaxf(fmaxf(quarter[1][0], quarter[1][1]), fmaxf(quarter[1][2], quarter[1][3])) : mq;
     const float mv = v_own ? fmaxf(fmaxf(quarter[2][0], quarter[2][1]), fmaxf(quarter[2][2], quarter[2][3]))
                            : (v_amax == k_amax ? mk : mq);
-    h3_pow2_scale(0.125f * mq, s, i);                                    // Q is multiplied by 1/8 before it is split
+    h3_pow2_scale(qscale * mq, s, i);                                    // Q is multiplied by qscale before it is split
     h.sq = sgpr(s); h.inv_sq = sgpr(i);
     h3_pow2_scale(mk, s, i);
     h.sk = sgpr(s); h.inv_sk = sgpr(i);
@@ -1013,12 +1014,12 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
     const float* qb_ = a.q + (long)b * a.Tq * a.ldq + h * HD;
     const float* kb_ = a.k + (long)b * a.Tk * a.ldk + h * HD;
     const float* vb_ = a.v + (long)b * a.Tk * a.ldv + h * HD;
-    const H3Scales hs = attn_h3_scales(a.q_amax, a.k_amax, a.v_amax, lane);
+    const H3Scales hs = attn_h3_scales(a.q_amax, a.k_amax, a.v_amax, lane, a.qscale);
     const float H3A_C = hs.c, H3A_C2 = hs.c2;
 
     // Q fragments: lane (query l31, half) holds Q[q][16 s + 8 half + 0..7] / 8 * sq for the four d-steps s, split in two
     f16x8v qf[4][2];
-    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
+    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, a.qscale);
     wave_lds_sync();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -1328,7 +1329,7 @@ __global__ __launch_bounds__(256, TTTS_DQX_W) void attn_bwd_dq_x6_kernel(AttnArg
     const uint32_t rowid = (uint32_t)(arow + qg);
 
     bf16x8 qf[4][3], gf[4][3];
-    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
+    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, a.qscale);
     wave_lds_sync();
     load_lane_frags(scratch, l31, half, qf);
     wave_lds_sync();
@@ -1425,7 +1426,7 @@ __global__ __launch_bounds__(256, TTTS_DQX_W) void attn_bwd_dq_x6_kernel(AttnArg
         }
     }
     __syncthreads();
-    wave_store_rows(dq, scratch, a.dq + (long)b * a.Tq * a.lddq + h * HD, qw0, a.Tq, a.lddq, lane, 0.125f);
+    wave_store_rows(dq, scratch, a.dq + (long)b * a.Tq * a.lddq + h * HD, qw0, a.Tq, a.lddq, lane, a.qscale);
 }
 
 // dK, dV: key on the lane; one stage = 32 queries in both orientations (Q, dO row-major for S / dP, transposed for dK / dV).
@@ -1547,7 +1548,7 @@ __global__ __launch_bounds__(256, TTTS_DKVX_W) void attn_bwd_dkv_x6_kernel(AttnA
         __syncthreads();                                    // ... and everybody else's; previous planes are free
         {
             const uint32_t* raw = st_q ? rawQ : rawG;
-            const float sc = st_q ? 0.125f : 1.f;
+            const float sc = st_q ? a.qscale : 1.f;
             float4 v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1771,11 +1772,11 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
     const uint32_t rowid = (uint32_t)(arow + qg);
 
     // dO is a gradient: its pre-scale is the power of two that puts max|dO| (over the whole tensor) in [2^11, 2^12)
-    const H3Scales hs = attn_h3_scales(a.q_amax, a.k_amax, a.v_amax, lane, a.do_amax);
+    const H3Scales hs = attn_h3_scales(a.q_amax, a.k_amax, a.v_amax, lane, a.qscale, a.do_amax);
     const float s_g = hs.sg, inv_g = hs.inv_sg;
     const float H3A_C2 = hs.c2;
     f16x8v qf[4][2], gf[4][2];
-    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, 0.125f);
+    wave_stage_tile(qb_, qw0, a.Tq, a.ldq, lane, scratch, a.qscale);
     wave_lds_sync();
     load_lane_frags_h3(scratch, l31, half, hs.sq, qf);
     wave_lds_sync();
@@ -1887,7 +1888,7 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
     }
     __syncthreads();
     {
-        const float fin = (sds > 0.f) ? 0.125f * hs.inv_sk / sds : 0.f;    // accumulator units -> dQ (incl. the 1/8 of q / 8)
+        const float fin = (sds > 0.f) ? a.qscale * hs.inv_sk / sds : 0.f;    // accumulator units -> dQ (incl. the 1/8 of q / 8)
         float mx = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1933,7 +1934,7 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
     const float* gb_ = a.dout + (long)b * a.Tq * a.ldo + h * HD;
     const long arow = ((long)(b * a.H + h) * a.Tq);
 
-    const H3Scales hs = attn_h3_scales(a.q_amax, a.k_amax, a.v_amax, lane, a.do_amax);
+    const H3Scales hs = attn_h3_scales(a.q_amax, a.k_amax, a.v_amax, lane, a.qscale, a.do_amax);
     const float s_g = hs.sg, inv_g = hs.inv_sg;
     const float H3A_C2 = hs.c2;
     f16x8v kf[4][2], vf[4][2];
@@ -1995,7 +1996,7 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
         __syncthreads();                                    // ... and everybody else's; previous planes are free
         {
             const uint32_t* raw = st_q ? rawQ : rawG;
-            const float sc = st_q ? 0.125f * hs.sq : s_g;
+            const float sc = st_q ? a.qscale * hs.sq : s_g;
             float4 v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -2193,7 +2194,7 @@ extern "C" {
 
 static int attention_fwd_impl(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                               const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                              int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, int form, void* stream_,
+                              int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, int form, void* stream_,
                               const float* q_amax = nullptr, const float* k_amax = nullptr, const float* v_amax = nullptr,
                               float* o_amax_out = nullptr, float* rowstat_out = nullptr) {
     // form: 0 = fp32 MFMA, 1 = bf16x6, 2 = fp16x3 (needs the partial maxima of q, k, v)
@@ -2210,6 +2211,7 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, fl
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     a.drop_scale = 1.f / (1.f - drop_p);
+    a.qscale = q_scale;
     a.seed = seed; a.step_seed = step_seed;
     a.q_amax = q_amax; a.k_amax = k_amax; a.v_amax = v_amax; a.o_amax = o_amax_out; a.rowstat = rowstat_out;
     dim3 grid(B * H, cdiv(Tq, QB), 1);
@@ -2245,28 +2247,28 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, fl
 
 int ttts_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                        const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                       int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
-    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, step_seed, 0,
+                       int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
+    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, q_scale, drop_p, seed, step_seed, 0,
                               stream);
 }
 int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
-    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, step_seed, 1,
+                          int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
+    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, q_scale, drop_p, seed, step_seed, 1,
                               stream);
 }
 int ttts_attention_fwd_h3(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* q_amax,
+                          int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* q_amax,
                           const float* k_amax, const float* v_amax, float* o_amax_out, float* rowstat_out, void* stream) {
-    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, drop_p, seed, step_seed, 2,
+    return attention_fwd_impl(q, k, v, o, lse, attn, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, q_scale, drop_p, seed, step_seed, 2,
                               stream, q_amax, k_amax, v_amax, o_amax_out, rowstat_out);
 }
 
 static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* do_,
                               const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                               int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                              int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, int form, void* stream_,
+                              int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, int form, void* stream_,
                               const float* do_amax = nullptr, float* dq_amax_out = nullptr, float* dkv_amax_out = nullptr,
                               const float* q_amax = nullptr, const float* k_amax = nullptr, const float* v_amax = nullptr,
                               const float* rowstat = nullptr) {
@@ -2288,6 +2290,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
     a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     a.drop_scale = 1.f / (1.f - drop_p);
+    a.qscale = q_scale;
     a.seed = seed; a.step_seed = step_seed;
     dim3 gq(B * H, cdiv(Tq, QB), 1), gk(B * H, cdiv(Tk, QB), 1);
     if (form == 2) {
@@ -2314,25 +2317,25 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
 int ttts_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* do_,
                        const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                        int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                       int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
+                       int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
     return attention_bwd_impl(q, k, v, o, do_, lse, delta, dq, dk, dv, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk,
-                              lddv, causal, drop_p, seed, step_seed, 0, stream);
+                              lddv, causal, q_scale, drop_p, seed, step_seed, 0, stream);
 }
 int ttts_attention_bwd_x6(const float* q, const float* k, const float* v, const float* o, const float* do_,
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
+                          int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, void* stream) {
     return attention_bwd_impl(q, k, v, o, do_, lse, delta, dq, dk, dv, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk,
-                              lddv, causal, drop_p, seed, step_seed, 1, stream);
+                              lddv, causal, q_scale, drop_p, seed, step_seed, 1, stream);
 }
 int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                           const float* lse, float* delta, float* dq, float* dk, float* dv, const int64_t* key_lens, int B,
                           int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                          int causal, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
+                          int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
                           float* dq_amax_out, float* dkv_amax_out, const float* q_amax, const float* k_amax,
                           const float* v_amax, const float* rowstat, void* stream) {
     return attention_bwd_impl(q, k, v, o, d_o, lse, delta, dq, dk, dv, key_lens, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk,
-                              lddv, causal, drop_p, seed, step_seed, 2, stream, do_amax, dq_amax_out, dkv_amax_out, q_amax, k_amax,
+                              lddv, causal, q_scale, drop_p, seed, step_seed, 2, stream, do_amax, dq_amax_out, dkv_amax_out, q_amax, k_amax,
                               v_amax, rowstat);
 }
 

@@ -52,6 +52,24 @@ int launch_zero(void* p, size_t nbytes, hipStream_t stream) {
     return TTTS_OK;
 }
 
+// ------------------------------------------------------------------ head padding (attention for head_dim < 64)
+// dst[r][h*64 + c] = c < hd ? src[r*ld_src + h*hd + c] : 0   (pad)      dst[r*ld_dst + h*hd + c] = src[r][h*64 + c]   (unpad)
+__global__ __launch_bounds__(256) void heads_pad_kernel(const float* __restrict__ src, long ld_src, float* __restrict__ dst,
+                                                        long rows, int H, int hd, int unpad, long ld_dst) {
+    const long n = rows * H * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 63);
+        const long rh = i >> 6;
+        const int h = (int)(rh % H);
+        const long r = rh / H;
+        if (unpad) {
+            if (c < hd) dst[r * ld_dst + h * hd + c] = src[i];
+        } else {
+            dst[i] = c < hd ? src[r * ld_src + h * hd + c] : 0.f;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ embedding
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
                                                             float* __restrict__ out, long n, int vocab, int d4,
@@ -314,6 +332,24 @@ const char* ttts_last_error(void) { return ttts::g_err; }
 int ttts_abi_version(void) { return 7; }
 
 int ttts_zero(void* p, size_t nbytes, void* stream) { return ::ttts::launch_zero(p, nbytes, (hipStream_t)stream); }
+
+int ttts_heads_pad(const float* src, int64_t ld_src, float* dst, int64_t rows, int H, int head_dim, void* stream) {
+    TTTS_REQUIRE(src && dst && rows > 0 && H > 0 && head_dim > 0 && head_dim <= 64 && ld_src >= (int64_t)H * head_dim,
+                 "heads_pad: bad arguments (head_dim %d must be in 1..64)", head_dim);
+    hipLaunchKernelGGL(heads_pad_kernel, dim3(ew_grid(rows * H * 64)), dim3(256), 0, (hipStream_t)stream, src, (long)ld_src, dst,
+                       (long)rows, H, head_dim, 0, 0L);
+    TTTS_LAUNCH_CHECK("heads_pad_kernel");
+    return TTTS_OK;
+}
+
+int ttts_heads_unpad(const float* src, float* dst, int64_t ld_dst, int64_t rows, int H, int head_dim, void* stream) {
+    TTTS_REQUIRE(src && dst && rows > 0 && H > 0 && head_dim > 0 && head_dim <= 64 && ld_dst >= (int64_t)H * head_dim,
+                 "heads_unpad: bad arguments (head_dim %d must be in 1..64)", head_dim);
+    hipLaunchKernelGGL(heads_pad_kernel, dim3(ew_grid(rows * H * 64)), dim3(256), 0, (hipStream_t)stream, src, 0L, dst, (long)rows,
+                       H, head_dim, 1, (long)ld_dst);
+    TTTS_LAUNCH_CHECK("heads_pad_kernel");
+    return TTTS_OK;
+}
 
 int ttts_embedding_fwd(const int64_t* ids, const float* table, float* out, int64_t n, int vocab, int d, float* out_amax_out,
                        void* stream) {

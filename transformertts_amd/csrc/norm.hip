@@ -17,26 +17,26 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const long row = (long)blockIdx.x * 4 + wave;
     if (row >= M) return;
     float ymax = 0.f;
-    const int nper = d >> 6;
     const float* xr = x + row * d;
     float v[LN_MAXPER];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXPER; ++i) {
-        if (i < nper) { v[i] = xr[lane + 64 * i]; s += v[i]; }
+        v[i] = 0.f;
+        if (lane + 64 * i < d) { v[i] = xr[lane + 64 * i]; s += v[i]; }          // any width up to 64 * LN_MAXPER
     }
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXPER; ++i) {
-        if (i < nper) { float c = v[i] - mean; q += c * c; }
+        if (lane + 64 * i < d) { float c = v[i] - mean; q += c * c; }
     }
     const float var = wave_sum(q) / (float)d;
     const float rstd = 1.0f / sqrtf(var + eps);
     float* yr = y + row * d;
 #pragma unroll
     for (int i = 0; i < LN_MAXPER; ++i) {
-        if (i < nper) {
+        if (lane + 64 * i < d) {
             int c = lane + 64 * i;
             const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
             yr[c] = o;
@@ -115,15 +115,16 @@ template <int NPER>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
-                                                            float* __restrict__ ws, long M) {
-    constexpr int d = NPER * 64;
-    __shared__ float red[4][2][d];
+                                                            float* __restrict__ ws, long M, int d) {
+    // d <= NPER * 64 (any width: the columns past d of the last 64-column group are skipped)
+    constexpr int DP = NPER * 64;
+    __shared__ float red[4][2][DP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float g[NPER], accg[NPER], accb[NPER];
 #pragma unroll
     for (int i = 0; i < NPER; ++i) {
         accg[i] = 0.f; accb[i] = 0.f;
-        g[i] = gamma[lane + 64 * i];
+        g[i] = (lane + 64 * i < d) ? gamma[lane + 64 * i] : 0.f;
     }
     for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
@@ -134,8 +135,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < NPER; ++i) {
             int c = lane + 64 * i;
-            float dyv = dr[c];
-            xh[i] = (xr[c] - mu) * rs;
+            const bool in = c < d;
+            float dyv = in ? dr[c] : 0.f;
+            xh[i] = in ? (xr[c] - mu) * rs : 0.f;
             gd[i] = dyv * g[i];
             s1 += gd[i];
             s2 += gd[i] * xh[i];
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         s2 = wave_sum(s2) / (float)d;
         float* dxr = dx + row * d;
 #pragma unroll
-        for (int i = 0; i < NPER; ++i) dxr[lane + 64 * i] = rs * (gd[i] - s1 - xh[i] * s2);
+        for (int i = 0; i < NPER; ++i)
+            if (lane + 64 * i < d) dxr[lane + 64 * i] = rs * (gd[i] - s1 - xh[i] * s2);
     }
 #pragma unroll
     for (int i = 0; i < NPER; ++i) {
@@ -515,8 +518,7 @@ extern "C" {
 int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                        int64_t M, int d, float eps, float* y_amax_out, void* stream) {
     TTTS_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
-    TTTS_REQUIRE(M > 0 && d > 0 && d % 64 == 0 && d <= 64 * LN_MAXPER, "layernorm_fwd: d=%d must be a multiple of 64, <= %d",
-                 d, 64 * LN_MAXPER);
+    TTTS_REQUIRE(M > 0 && d > 0 && d <= 64 * LN_MAXPER, "layernorm_fwd: d=%d must be in 1..%d", d, 64 * LN_MAXPER);
     const bool v4 = (d == 256 || d == 512 || d == 1024) &&
                     ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0;
     if (v4 && d == 256)
@@ -542,7 +544,7 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* mean
                               int accumulate, float* dacc, float drop_p, uint64_t seed, const uint64_t* step_seed,
                               float* dacc_amax, ttts_reduce_queue* queue, hipStream_t stream) {
     TTTS_REQUIRE(dy && x && mean && rstd && gamma && dx && ws, "layernorm_bwd: null pointer");
-    TTTS_REQUIRE(M > 0 && d > 0 && d % 64 == 0 && d <= 64 * LN_MAXPER, "layernorm_bwd: bad d=%d", d);
+    TTTS_REQUIRE(M > 0 && d > 0 && d <= 64 * LN_MAXPER, "layernorm_bwd: d=%d must be in 1..%d", d, 64 * LN_MAXPER);
     TTTS_REQUIRE(ws_bytes >= ttts_layernorm_bwd_workspace_bytes(d), "layernorm_bwd: workspace too small");
     int nblk = LN_BWD_BLOCKS;
     if ((long)nblk * 4 > M) nblk = cdiv(M, 4);
@@ -566,15 +568,13 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* mean
     }
 #define TTTS_LN_BWD(NPER)                                                                                         \
     hipLaunchKernelGGL((layernorm_bwd_kernel<NPER>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, \
-                       (long)M)
-    switch (d / 64) {
-        case 1: TTTS_LN_BWD(1); break;
-        case 2: TTTS_LN_BWD(2); break;
-        case 4: TTTS_LN_BWD(4); break;
-        case 8: TTTS_LN_BWD(8); break;
-        case 16: TTTS_LN_BWD(16); break;
-        default: TTTS_REQUIRE(false, "layernorm_bwd: d=%d must be 64, 128, 256, 512 or 1024", d);
-    }
+                       (long)M, d)
+    const int groups = (d + 63) / 64;          // the instantiation with the next power of two of 64-column groups
+    if (groups <= 1) TTTS_LN_BWD(1);
+    else if (groups <= 2) TTTS_LN_BWD(2);
+    else if (groups <= 4) TTTS_LN_BWD(4);
+    else if (groups <= 8) TTTS_LN_BWD(8);
+    else TTTS_LN_BWD(16);
 #undef TTTS_LN_BWD
     TTTS_LAUNCH_CHECK("layernorm_bwd_kernel");
     return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate != 0, stream, queue);
@@ -661,7 +661,9 @@ int ttts_bn_apply_fwd(const float* x, const float* mean, const float* invstd, co
 int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float* invstd, const float* gamma,
                 const float* beta, float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int C,
                 int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate,
-                float* dx_amax_partials, void* stream_) {
+                float* dx_amax_partials, int batch_stats, void* stream_) {
+    // batch_stats = 1: train-mode BatchNorm (mean / invstd are statistics of x itself, so dx carries their derivative);
+    // 0: eval mode (running statistics are constants of the graph: dx = gamma * invstd * g)
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dz && x && mean && invstd && gamma && beta && dx && ws, "bn_bwd: null pointer");
     TTTS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd: C=%d must be a multiple of 4", C);
@@ -682,7 +684,7 @@ int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float*
     int grid = (int)((n4 + 255) / 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, dz, x, mean, invstd, gamma, beta, sums, dx, n4,
-                       C, 1.0f / (float)M, act, scale, thr, seed, step_seed, dx_amax_partials);
+                       C, batch_stats ? 1.0f / (float)M : 0.0f, act, scale, thr, seed, step_seed, dx_amax_partials);
     TTTS_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return TTTS_OK;
 }

@@ -7,7 +7,8 @@ Class names, constructor signatures and parameter names follow the reference's
   * masks never exist as tensors: the stacks take per-utterance lengths (`*_lens`, int64 on the
     device) and the attention kernels derive key-padding and causal masks from them;
     `*_key_padding_mask` / `tgt_mask` arguments are still accepted and converted (prefix masks only);
-  * post-norm only (`norm_first=False`, the reference's configuration), batch-first only, relu FFN;
+  * post-norm (`norm_first=False`, the reference's configuration) and pre-norm (`norm_first=True`, the other branch of
+    model/layers.py:41-50); batch-first only, relu FFN;
   * residual adds, biases, relu and dropout live in GEMM epilogues, not in separate ops.
 """
 from __future__ import annotations
@@ -29,12 +30,13 @@ def _lens_from_kpm(kpm: Optional[Tensor], B: int, T: int, device) -> Tensor:
 
 
 class MultiheadAttention(nn.Module):
-    """Parameter layout of nn.MultiheadAttention (packed in-proj, `out_proj` sub-module); head_dim must be 64."""
+    """Parameter layout of nn.MultiheadAttention (packed in-proj, `out_proj` sub-module); head_dim <= 64."""
 
     def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0.0):
         super().__init__()
-        if embed_dim != num_heads * 64:
-            raise ValueError("MultiheadAttention: the gfx950 attention kernels are specialised for head_dim 64")
+        if num_heads <= 0 or embed_dim % num_heads != 0 or embed_dim // num_heads > 64:
+            raise ValueError("MultiheadAttention: embed_dim must be divisible by num_heads with head_dim <= 64 (the gfx950 "
+                             "attention kernels work on 64-column heads; narrower heads are zero-padded)")
         self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
         self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
         self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))
@@ -74,15 +76,16 @@ class MultiheadAttention(nn.Module):
         return out, attn
 
 
-def _ffn_block(layer, x: Tensor, out_dropout: nn.Dropout) -> Tensor:
-    """x + drop_out(W2 . drop(relu(W1 x))): relu+dropout ride in the first GEMM's epilogue, dropout+residual in
-    the second's (torch `_ff_block`, torch/nn/modules/transformer.py:980-982,1197-1199)."""
+def _ffn_block(layer, x: Tensor, out_dropout: nn.Dropout, residual: Optional[Tensor] = None) -> Tensor:
+    """residual + drop_out(W2 . drop(relu(W1 x))), residual = x unless given (pre-norm: x is the normalised copy): relu+dropout
+    ride in the first GEMM's epilogue, dropout+residual in the second's (torch `_ff_block`,
+    torch/nn/modules/transformer.py:980-982,1197-1199)."""
     p = layer.dropout.p if layer.training else 0.0
     po = out_dropout.p if layer.training else 0.0
-    skip = ops.SkipToken()
+    skip = ops.SkipToken() if residual is None else None      # the skip gradient rides in the first GEMM's epilogue
     h = ops.linear(x, layer.linear1.weight, layer.linear1.bias, act=ops.ACT_RELU, drop_p=p,
                    seed=ops.seeds.next() if p > 0 else 0, skip_in=skip, publish_amax=True)
-    return ops.linear(h, layer.linear2.weight, layer.linear2.bias, residual=x, drop_p=po,
+    return ops.linear(h, layer.linear2.weight, layer.linear2.bias, residual=x if residual is None else residual, drop_p=po,
                       seed=ops.seeds.next() if po > 0 else 0, sole_consumer=True, skip_out=skip)   # h feeds nothing else
 
 
@@ -90,8 +93,9 @@ class TransformerEncoderLayer(nn.Module):
     def __init__(self, d_model: int, nhead: int, dim_feedforward: int = 2048, dropout: float = 0.1,
                  activation: str = 'relu', batch_first: bool = True, norm_first: bool = False):
         super().__init__()
-        if activation != 'relu' or not batch_first or norm_first:
-            raise ValueError("TransformerEncoderLayer: relu, batch_first, post-norm only (the reference's configuration)")
+        if activation != 'relu' or not batch_first:
+            raise ValueError("TransformerEncoderLayer: relu activation and batch_first only (the reference's configuration)")
+        self.norm_first = norm_first
         self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.dropout = nn.Dropout(dropout)
@@ -103,6 +107,11 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward(self, src: Tensor, src_lens: Tensor) -> Tensor:
         p1 = self.dropout1.p if self.training else 0.0
+        if self.norm_first:      # torch/nn/modules/transformer.py:944-950: x + SA(LN1(x)), then x + FF(LN2(x))
+            x1 = ops.layer_norm(src, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            s = self.self_attn.self_attention(x1, src_lens, False, residual=src, out_drop=p1)
+            x2 = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            return _ffn_block(self, x2, self.dropout2, residual=s)
         s = self.self_attn.self_attention(src, src_lens, False, residual=src, out_drop=p1)
         x = ops.layer_norm(s, self.norm1.weight, self.norm1.bias, self.norm1.eps, sole_consumer=True)
         x = ops.layer_norm(_ffn_block(self, x, self.dropout2), self.norm2.weight, self.norm2.bias, self.norm2.eps,
@@ -139,8 +148,8 @@ class TransformerDecoderLayer(nn.Module):
     def __init__(self, d_model: int, nhead: int, dim_feedforward: int = 2048, dropout: float = 0.1,
                  norm_first: bool = False, batch_first: bool = True):
         super().__init__()
-        if norm_first or not batch_first:
-            raise ValueError("TransformerDecoderLayer: batch_first, post-norm only (the reference's configuration)")
+        if not batch_first:
+            raise ValueError("TransformerDecoderLayer: batch_first only (the reference's configuration)")
         self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
         self.multihead_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
@@ -168,6 +177,15 @@ class TransformerDecoderLayer(nn.Module):
             memory_lens = _lens_from_kpm(memory_key_padding_mask, B, memory.size(1), tgt.device)
         causal = bool(tgt_is_causal) or tgt_mask is not None
         tr = self.training
+        if self.norm_first:      # reference model/layers.py:41-45
+            x1 = ops.layer_norm(tgt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            s = self.self_attn.self_attention(x1, tgt_lens, causal, residual=tgt, out_drop=self.dropout1.p if tr else 0.0)
+            x2 = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            s2, alignments = self.multihead_attn.cross_attention(x2, memory, memory_lens, residual=s,
+                                                                 out_drop=self.dropout2.p if tr else 0.0,
+                                                                 need_weights=need_alignments)
+            x3 = ops.layer_norm(s2, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+            return _ffn_block(self, x3, self.dropout3, residual=s2), alignments
         s = self.self_attn.self_attention(tgt, tgt_lens, causal, residual=tgt, out_drop=self.dropout1.p if tr else 0.0)
         x = ops.layer_norm(s, self.norm1.weight, self.norm1.bias, self.norm1.eps, sole_consumer=True)
         s, alignments = self.multihead_attn.cross_attention(x, memory, memory_lens, residual=x,

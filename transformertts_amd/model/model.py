@@ -235,6 +235,8 @@ class TransformerTTS(nn.Module):
         stops = []
         n = 0
         heads = (self.linear1.linear.weight, self.linear1.linear.bias, self.linear2.linear.weight, self.linear2.linear.bias)
+        if use_kv_cache and memory.size(-1) // self.decoder.layers[0].self_attn.num_heads != 64:
+            use_kv_cache = False          # the incremental kernels read 64-wide heads in place; others take the recompute loop
         if use_kv_cache:
             d = memory.size(-1)
             layers = list(self.decoder.layers)

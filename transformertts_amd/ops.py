@@ -852,8 +852,6 @@ class ConvBNFn(torch.autograd.Function):
         lib = _lib.load()
         x, conv_w, y, mean, invstd, gamma, beta = ctx.saved_tensors
         training, act, drop_p, seed, has_b = ctx.cfg
-        if not training:
-            raise RuntimeError("conv_bn: backward is implemented for train-mode BatchNorm only")
         B, T, cin = x.shape
         cout, _, taps = conv_w.shape
         dev = x.device
@@ -875,8 +873,8 @@ class ConvBNFn(torch.autograd.Function):
                   (WGRAD_MODE == "h3" and _wgrad_is_split(cout, cin))
         am = _amax_slots(dev, True) if want_am else None
         _lib.check(lib.ttts_bn_bwd(_p(dz), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(t_g), _p(t_be),
-                                   _p(ws), ws.numel() * 4, M, cout, act, drop_p, seed, ctx.ss, acc, _p(am), _stream()),
-                   "ttts_bn_bwd")
+                                   _p(ws), ws.numel() * 4, M, cout, act, drop_p, seed, ctx.ss, acc, _p(am), 1 if training else 0,
+                                   _stream()), "ttts_bn_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -976,7 +974,7 @@ def layer_norm(x, gamma, beta, eps=1e-5, sole_consumer=False, publish_amax=True)
 
 # ----------------------------------------------------------------------------------------------- attention
 def _attn_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, lens, causal, drop_p, seed, need_weights, q_am=None, k_am=None,
-              v_am=None, o_am=None):
+              v_am=None, o_am=None, q_scale: float = 0.125):
     """q_am / k_am / v_am: partial maxima of the operands (fp16x3 form; required there); o_am: None, or a zeroed
     AMAX_SLOTS-slot array that receives max|o|."""
     lib = _lib.load()
@@ -987,7 +985,7 @@ def _attn_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, lens, causal, drop_p, seed, 
     lse = stat[0]
     attn = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=dev) if need_weights else None
     args = (q, k, v, _p(o), _p(lse), _p(attn), _p(lens), B, H, Tq, Tk, ldq, ldk, ldv, H * 64, 1 if causal else 0,
-            float(drop_p), seed, _ss())
+            float(q_scale), float(drop_p), seed, _ss())
     if ATTN_FWD_MODE == "h3":
         if q_am is None or k_am is None or v_am is None:
             raise ValueError("attention (fp16x3 form): the partial maxima of q, k and v are required")
@@ -1007,8 +1005,30 @@ def _off(t: torch.Tensor, col: int):
     return c_void_p(t.data_ptr() + 4 * col)
 
 
+def _head_dim(d: int, n_head: int) -> int:
+    """Columns per head; the kernels work on 64-column heads and narrower ones are zero-padded to 64 (`_pad_heads`)."""
+    if n_head <= 0 or d % n_head != 0:
+        raise ValueError(f"attention: d_model {d} is not divisible by {n_head} heads")
+    hd = d // n_head
+    if hd > 64:
+        raise ValueError(f"attention kernels take head_dim <= 64 (d_model {d}, heads {n_head}: head_dim {hd})")
+    return hd
+
+
+def _pad_heads(src: torch.Tensor, col0: int, ld: int, rows: int, H: int, hd: int) -> torch.Tensor:
+    """(rows, H*64): the H heads of `src` (row stride ld floats, head h at column col0 + h*hd) zero-padded to 64 columns."""
+    dst = torch.empty(rows, H * 64, dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().ttts_heads_pad(_off(src, col0), ld, _p(dst), rows, H, hd, _stream()), "ttts_heads_pad")
+    return dst
+
+
+def _unpad_heads(src: torch.Tensor, dst: torch.Tensor, col0: int, ld: int, rows: int, H: int, hd: int) -> None:
+    _lib.check(_lib.load().ttts_heads_unpad(_p(src), _off(dst, col0), ld, rows, H, hd, _stream()), "ttts_heads_unpad")
+
+
 class SelfAttentionFn(torch.autograd.Function):
-    """o = softmax(mask(q k^T / 8)) v over a packed in-proj output qkv (B,T,3d); heads of 64."""
+    """o = softmax(mask(q k^T / sqrt(head_dim))) v over a packed in-proj output qkv (B,T,3d); head_dim <= 64 (heads of 64 are
+    read in place, narrower ones through zero-padded copies)."""
 
     @staticmethod
     def forward(ctx, qkv, lens, n_head, causal, drop_p, seed, qkv_amax=None, o_amax=None):
@@ -1016,24 +1036,34 @@ class SelfAttentionFn(torch.autograd.Function):
         lens = _chk(lens, "self_attention.lens", torch.int64)
         B, T, d3 = qkv.shape
         d = d3 // 3
-        if d != n_head * 64:
-            raise ValueError(f"attention kernels need head_dim 64 (d_model {d}, heads {n_head})")
+        hd = _head_dim(d, n_head)
         if qkv_amax is None and _attn_h3():
             qkv_amax = _amax(qkv)
-        o, stat, _ = _attn_fwd(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), d3, d3, d3, B, n_head, T, T, lens, causal,
-                               drop_p, seed, False, qkv_amax, qkv_amax, qkv_amax, o_amax)
-        ctx.save_for_backward(qkv, o, stat, lens)
+        pads = None
+        if hd == 64:
+            ptrs, ld = (_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d)), d3
+        else:
+            pads = tuple(_pad_heads(qkv, c, d3, B * T, n_head, hd) for c in (0, d, 2 * d))
+            ptrs, ld = tuple(_p(t) for t in pads), n_head * 64
+        o64, stat, _ = _attn_fwd(*ptrs, ld, ld, ld, B, n_head, T, T, lens, causal, drop_p, seed, False, qkv_amax, qkv_amax,
+                                 qkv_amax, o_amax, q_scale=hd ** -0.5)
+        if hd == 64:
+            o = o64
+        else:
+            o = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
+            _unpad_heads(o64, o, 0, d, B * T, n_head, hd)
+        ctx.save_for_backward(qkv, o64, stat, lens, *(pads or ()))
         ctx.qkv_amax = qkv_amax
-        ctx.cfg = (n_head, causal, float(drop_p), seed)
+        ctx.cfg = (n_head, causal, float(drop_p), seed, hd)
         ctx.ss = _ss()
         return o
 
     @staticmethod
     def backward(ctx, do):
         lib = _lib.load()
-        qkv, o, stat, lens = ctx.saved_tensors
+        qkv, o64, stat, lens, *pads = ctx.saved_tensors
         lse, rowstat = stat[0], (stat[1:] if stat.shape[0] == 3 else None)
-        n_head, causal, drop_p, seed = ctx.cfg
+        n_head, causal, drop_p, seed, hd = ctx.cfg
         B, T, d3 = qkv.shape
         d = d3 // 3
         do = _chk(do, "self_attention.do")
@@ -1041,9 +1071,20 @@ class SelfAttentionFn(torch.autograd.Function):
         delta = torch.empty(lse.shape, dtype=torch.float32, device=lse.device)
         am = _amax_slots(qkv.device, True) if ATTN_BWD_MODE == "h3" else None     # max|dqkv| for the in-projection gradients
         qa = ctx.qkv_amax
-        _lib.check(_attn_bwd(lib, do, am, am, qa, qa, qa, rowstat, _off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(delta),
-                             _off(dqkv, 0), _off(dqkv, d), _off(dqkv, 2 * d), _p(lens), B, n_head, T, T, d3,
-                             d3, d3, d, d3, d3, d3, 1 if causal else 0, drop_p, seed, ctx.ss), "ttts_attention_bwd")
+        if hd == 64:
+            ins, ld, do64 = (_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d)), d3, do
+            outs, ldg = (_off(dqkv, 0), _off(dqkv, d), _off(dqkv, 2 * d)), d3
+        else:
+            ins, ld = tuple(_p(t) for t in pads), n_head * 64
+            do64 = _pad_heads(do, 0, d, B * T, n_head, hd)
+            grads = tuple(torch.empty(B * T, n_head * 64, dtype=torch.float32, device=qkv.device) for _ in range(3))
+            outs, ldg = tuple(_p(t) for t in grads), n_head * 64
+        _lib.check(_attn_bwd(lib, do64, am, am, qa, qa, qa, rowstat, *ins, _p(o64), _p(do64), _p(lse), _p(delta), *outs, _p(lens),
+                             B, n_head, T, T, ld, ld, ld, n_head * 64, ldg, ldg, ldg, 1 if causal else 0, hd ** -0.5, drop_p,
+                             seed, ctx.ss), "ttts_attention_bwd")
+        if hd != 64:
+            for g, c in zip(grads, (0, d, 2 * d)):
+                _unpad_heads(g, dqkv, c, d3, B * T, n_head, hd)
         if am is not None:
             dqkv._ttts_amax = am
         return dqkv, None, None, None, None, None, None, None
@@ -1059,16 +1100,27 @@ class CrossAttentionFn(torch.autograd.Function):
         lens = _chk(lens, "cross_attention.lens", torch.int64)
         B, Tq, d = q.shape
         Tk = kv.shape[1]
-        if d != n_head * 64:
-            raise ValueError(f"attention kernels need head_dim 64 (d_model {d}, heads {n_head})")
+        hd = _head_dim(d, n_head)
         if _attn_h3():
             q_amax = _amax(q) if q_amax is None else q_amax
             kv_amax = _amax(kv) if kv_amax is None else kv_amax
-        o, stat, attn = _attn_fwd(_off(q, 0), _off(kv, 0), _off(kv, d), d, 2 * d, 2 * d, B, n_head, Tq, Tk, lens, False,
-                                  drop_p, seed, need_weights, q_amax, kv_amax, kv_amax, o_amax)
-        ctx.save_for_backward(q, kv, o, stat, lens)
+        pads = None
+        if hd == 64:
+            ptrs, lds = (_off(q, 0), _off(kv, 0), _off(kv, d)), (d, 2 * d, 2 * d)
+        else:
+            pads = (_pad_heads(q, 0, d, B * Tq, n_head, hd), _pad_heads(kv, 0, 2 * d, B * Tk, n_head, hd),
+                    _pad_heads(kv, d, 2 * d, B * Tk, n_head, hd))
+            ptrs, lds = tuple(_p(t) for t in pads), (n_head * 64,) * 3
+        o64, stat, attn = _attn_fwd(*ptrs, *lds, B, n_head, Tq, Tk, lens, False, drop_p, seed, need_weights, q_amax, kv_amax,
+                                    kv_amax, o_amax, q_scale=hd ** -0.5)
+        if hd == 64:
+            o = o64
+        else:
+            o = torch.empty(B, Tq, d, dtype=torch.float32, device=q.device)
+            _unpad_heads(o64, o, 0, d, B * Tq, n_head, hd)
+        ctx.save_for_backward(q, kv, o64, stat, lens, *(pads or ()))
         ctx.amax = (q_amax, kv_amax)
-        ctx.cfg = (n_head, float(drop_p), seed)
+        ctx.cfg = (n_head, float(drop_p), seed, hd)
         ctx.ss = _ss()
         if attn is None:       # weights not requested: single-pass online softmax, nothing written
             attn = torch.empty(0, dtype=torch.float32, device=q.device)
@@ -1081,22 +1133,36 @@ class CrossAttentionFn(torch.autograd.Function):
         if do is None:
             return None, None, None, None, None, None, None, None, None, None
         lib = _lib.load()
-        q, kv, o, stat, lens = ctx.saved_tensors
+        q, kv, o64, stat, lens, *pads = ctx.saved_tensors
         lse, rowstat = stat[0], (stat[1:] if stat.shape[0] == 3 else None)
-        n_head, drop_p, seed = ctx.cfg
+        n_head, drop_p, seed, hd = ctx.cfg
         B, Tq, d = q.shape
         Tk = kv.shape[1]
         do = _chk(do, "cross_attention.do")
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
-        delta = torch.empty_like(lse)
+        delta = torch.empty(lse.shape, dtype=torch.float32, device=lse.device)
         am_q = am_kv = None
         if ATTN_BWD_MODE == "h3":
             am_q, am_kv = _amax_slots(q.device, True), _amax_slots(q.device, True)
         qa, kva = ctx.amax
-        _lib.check(_attn_bwd(lib, do, am_q, am_kv, qa, kva, kva, rowstat, _off(q, 0), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta),
-                             _off(dq, 0), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk, d, 2 * d,
-                             2 * d, d, d, 2 * d, 2 * d, 0, drop_p, seed, ctx.ss), "ttts_attention_bwd")
+        if hd == 64:
+            ins, lds, do64 = (_off(q, 0), _off(kv, 0), _off(kv, d)), (d, 2 * d, 2 * d), do
+            outs, ldg = (_off(dq, 0), _off(dkv, 0), _off(dkv, d)), (d, 2 * d, 2 * d)
+        else:
+            ins, lds = tuple(_p(t) for t in pads), (n_head * 64,) * 3
+            do64 = _pad_heads(do, 0, d, B * Tq, n_head, hd)
+            grads = (torch.empty(B * Tq, n_head * 64, dtype=torch.float32, device=q.device),
+                     torch.empty(B * Tk, n_head * 64, dtype=torch.float32, device=q.device),
+                     torch.empty(B * Tk, n_head * 64, dtype=torch.float32, device=q.device))
+            outs, ldg = tuple(_p(t) for t in grads), (n_head * 64,) * 3
+        _lib.check(_attn_bwd(lib, do64, am_q, am_kv, qa, kva, kva, rowstat, *ins, _p(o64), _p(do64), _p(lse), _p(delta), *outs,
+                             _p(lens), B, n_head, Tq, Tk, *lds, n_head * 64, *ldg, 0, hd ** -0.5, drop_p, seed, ctx.ss),
+                   "ttts_attention_bwd")
+        if hd != 64:
+            _unpad_heads(grads[0], dq, 0, d, B * Tq, n_head, hd)
+            _unpad_heads(grads[1], dkv, 0, 2 * d, B * Tk, n_head, hd)
+            _unpad_heads(grads[2], dkv, d, 2 * d, B * Tk, n_head, hd)
         if am_q is not None:
             dq._ttts_amax, dkv._ttts_amax = am_q, am_kv
         return dq, dkv, None, None, None, None, None, None, None, None
