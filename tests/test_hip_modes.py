@@ -383,10 +383,10 @@ def test_attention_forms_agree(causal, Tq, Tk, lens):
             o = torch.empty(B, Tq, d, device=_dev()); lse = torch.empty(B, H, Tq, device=_dev())
             attn = None if causal else torch.empty(B, H, Tq, Tk, device=_dev())
             assert fwd(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), _p(attn), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d,
-                       causal, p_drop, 99, None, _stream()) == 0
+                       causal, 0.125, p_drop, 99, None, _stream()) == 0
             dq, dkv, delta = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(lse)
             assert bwd(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d),
-                       _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, p_drop, 99, None, _stream()) == 0
+                       _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, 0.125, p_drop, 99, None, _stream()) == 0
             outs[(name, p_drop)] = (o, attn, dq, dkv)
             if p_drop == 0.0:
                 assert _rel(o, o_ref) < TOL and _rel(dq, dq_ref) < TOL and _rel(dkv, dkv_ref) < TOL
@@ -440,7 +440,7 @@ def test_fp16x3_attention_forward(causal, Tq, Tk, lens, qk_scale):
     attn = None if causal else torch.empty(B, H, Tq, Tk, device=_dev())
     qa, kva, oslots = ops._amax(q), ops._amax(kv), torch.zeros(1024, device=_dev())
     assert lib.ttts_attention_fwd_h3(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), _p(attn), _p(kl), B, H, Tq, Tk, d, 2 * d,
-                                     2 * d, d, causal, 0.0, 0, None, _p(qa), _p(kva), _p(kva), _p(oslots), None, _stream()) == 0
+                                     2 * d, d, causal, 0.125, 0.0, 0, None, _p(qa), _p(kva), _p(kva), _p(oslots), None, _stream()) == 0
     assert _rel(o, o_ref) < TOL, _rel(o, o_ref)
     assert oslots.max().item() == o.abs().max().item()
     if attn is not None:
@@ -448,14 +448,14 @@ def test_fp16x3_attention_forward(causal, Tq, Tk, lens, qk_scale):
         assert float(attn.sum(-1).sub(1).abs().max()) < 1e-5
     dq, dkv, delta = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(lse)
     assert lib.ttts_attention_bwd_x6(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _off(dkv, 0),
-                                     _off(dkv, d), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, 0.0, 0, None,
+                                     _off(dkv, d), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, 0.125, 0.0, 0, None,
                                      _stream()) == 0
     if qk_scale == 1.0:                                                 # the backward recomputes P from this forward's lse
         assert _rel(dq, dq_ref) < TOL
     o6 = torch.empty_like(o); a6 = None if causal else torch.empty_like(attn); l6 = torch.empty_like(lse)
     for f, oo, aa, ll, extra in ((lib.ttts_attention_fwd_h3, o, attn, lse, (_p(qa), _p(kva), _p(kva), None, None)),
                                  (lib.ttts_attention_fwd_x6, o6, a6, l6, ())):
-        assert f(_p(q), _off(kv, 0), _off(kv, d), _p(oo), _p(ll), _p(aa), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, causal, 0.25,
+        assert f(_p(q), _off(kv, 0), _off(kv, d), _p(oo), _p(ll), _p(aa), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, causal, 0.125, 0.25,
                  99, None, *extra, _stream()) == 0
     assert _rel(o, o6) < TOL and _rel(lse, l6) < TOL
     if attn is not None and qk_scale == 1.0:       # (peaked softmaxes underflow to 0 at slightly different places)
@@ -499,10 +499,10 @@ def test_fp16x3_attention_backward(causal, Tq, Tk, lens, mag, grow):
         rowstat = torch.empty(2, B, H, Tq, device=_dev())
         extra = (_p(qa), _p(kva), _p(kva), None, _p(rowstat)) if h3 else ()
         assert fwd(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), None, _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, causal,
-                   p_drop, 99, None, *extra, _stream()) == 0
+                   0.125, p_drop, 99, None, *extra, _stream()) == 0
         dq, dkv, delta = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(lse)
         args = (_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(kl),
-                B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, p_drop, 99, None)
+                B, H, Tq, Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, 0.125, p_drop, 99, None)
         if h3:
             sq, sk = torch.zeros(1024, device=_dev()), torch.zeros(1024, device=_dev())
             assert bwd(*args, _p(ops._amax(do)), _p(sq), _p(sk), _p(qa), _p(kva), _p(kva), _p(rowstat), _stream()) == 0
@@ -560,11 +560,11 @@ def test_fp16x3_attention_any_magnitude(vs, qs, ks, causal):
     o, lse = torch.empty(B, T, d, device=_dev()), torch.empty(B, H, T, device=_dev())
     rowstat = torch.empty(2, B, H, T, device=_dev())
     assert lib.ttts_attention_fwd_h3(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), None, _p(kl), B, H, T, T, d, 2 * d, 2 * d,
-                                     d, causal, 0.0, 0, None, _p(qa), _p(ka), _p(va), None, _p(rowstat), _stream()) == 0
+                                     d, causal, 0.125, 0.0, 0, None, _p(qa), _p(ka), _p(va), None, _p(rowstat), _stream()) == 0
     assert torch.isfinite(o).all() and _rel(o, o_ref) < TOL, _rel(o, o_ref)
     dq, dkv, delta = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(lse)
     assert lib.ttts_attention_bwd_h3(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _off(dkv, 0),
-                                     _off(dkv, d), _p(kl), B, H, T, T, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, 0.0, 0, None,
+                                     _off(dkv, d), _p(kl), B, H, T, T, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, 0.125, 0.0, 0, None,
                                      _p(ops._amax(do)), None, None, _p(qa), _p(ka), _p(va), _p(rowstat), _stream()) == 0
     assert torch.isfinite(dq).all() and torch.isfinite(dkv).all()
     assert _rel(dkv[..., d:], dv_ref) < TOL, _rel(dkv[..., d:], dv_ref)
@@ -581,7 +581,7 @@ def test_fp16x3_attention_any_magnitude(vs, qs, ks, causal):
     am_all = torch.maximum(torch.maximum(qa, ka), va)
     if max(vs, qs, ks) / min(vs, qs, ks) <= 1e4:
         assert lib.ttts_attention_fwd_h3(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), None, _p(kl), B, H, T, T, d, 2 * d,
-                                         2 * d, d, causal, 0.0, 0, None, _p(am_all), _p(am_all), _p(am_all), None, None,
+                                         2 * d, d, causal, 0.125, 0.0, 0, None, _p(am_all), _p(am_all), _p(am_all), None, None,
                                          _stream()) == 0
         assert _rel(o, o_ref) < 4 * TOL, _rel(o, o_ref)
 

@@ -449,7 +449,7 @@ int ttts_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx_a
                     size_t ws_bytes, int64_t M, int d, int accumulate, ttts_reduce_queue* queue, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(dy && x && w && ws, "rowdot_bwd: null pointer");
-    TTTS_REQUIRE(M > 0 && d > 0 && d % 64 == 0 && d <= 1024, "rowdot_bwd: d=%d must be a multiple of 64, <= 1024", d);
+    TTTS_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 1024, "rowdot_bwd: d=%d must be a multiple of 4, <= 1024", d);
     TTTS_REQUIRE(ws_bytes >= ttts_rowdot_bwd_workspace_bytes(d), "rowdot_bwd: workspace too small");
     int nblk = RD_BWD_BLOCKS;
     if ((long)nblk * 4 > M) nblk = (int)((M + 3) / 4);
