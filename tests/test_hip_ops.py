@@ -347,6 +347,27 @@ def test_scheduled_sampling_mix_kernel(golden_dir):
         assert torch.equal(out.cpu(), torch.from_numpy(g[f"ss/mixed_{p_tf}"])), p_tf
 
 
+def test_block_mask_shim_matches_reference_windowing():
+    """`utils.util.block_mask` (reference utils/util.py:103-111) for an injected draw: the (B,T,1) bool mask equals the
+    max-pool dilation of (u < 1 - p_tf), window L_bar with padding L_bar // 2, cut to T frames."""
+    import torch.nn.functional as F
+    import transformertts_amd.utils.util as U
+    g = torch.Generator().manual_seed(5)
+    B, T = 3, 53
+    u = torch.rand(B, 1, T, generator=g)
+    mel = torch.zeros(B, T, 16, device=_dev())
+    U._uniform_draw = lambda b, t, device: u.to(device)
+    try:
+        for p_tf, l_bar in ((0.9, 8), (0.5, 8), (0.8, 4)):
+            got = U.block_mask(mel, p_tf, l_bar)
+            want = F.max_pool1d((u < (1 - p_tf)).float(), kernel_size=l_bar, stride=1, padding=l_bar // 2)
+            want = want.squeeze(1).bool().unsqueeze(-1)[:, :T, :]
+            assert got.dtype == torch.bool and got.shape == (B, T, 1) and torch.equal(got.cpu(), want), (p_tf, l_bar)
+    finally:
+        U._uniform_draw = None
+    assert not bool(U.block_mask(mel, 1.0, 8).any())         # p_tf = 1: pure teacher forcing, in-kernel draw
+
+
 def test_loss_kernel_matches_reference_fixture(golden_dir):
     """The fused loss against the values the reference's own TransformerTTSLoss produced (tests/golden/helpers.npz)."""
     import os

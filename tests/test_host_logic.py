@@ -150,12 +150,23 @@ def test_reference_import_lines_bind_to_this_package(tmp_path):
         "from dataset import DataModule\n"
         "from lightning_module import LightningModule\n"
         "from utils.util import increment_path, setup_logger\n"
+        "from utils.plot import (plot_mels_batch, plot_mels_single, plot_mels_scheduled, plot_alignments_batch,"
+        " plot_alignment_single)\n"
         "from model.layers import TransformerDecoderLayer, TransformerDecoder\n"
         "from model.module import ConvNormBN, LinearNorm\n"
         "import transformertts_amd.model as m, transformertts_amd.loss as l\n"
         "assert TransformerTTS is m.TransformerTTS and TransformerTTSLoss is l.TransformerTTSLoss\n"
         f"p = increment_path(r'{tmp_path}'); import os; assert os.path.isdir(os.path.join(p, 'mels_scheduled'))\n"
         f"q = increment_path(r'{tmp_path}'); assert os.path.basename(q).startswith('exp_2_')\n"
+        "import torch\n"
+        "a = [torch.rand(3, 2, 12, 7).softmax(-1) for _ in range(2)]\n"
+        "w = [plot_mels_batch(torch.rand(3, 12, 16), torch.rand(3, 10, 16), 1, p),"
+        " plot_mels_scheduled(torch.rand(3, 12, 16), torch.rand(3, 12, 16), 1, p),"
+        " plot_mels_single(torch.rand(12, 16), torch.rand(9, 16), 1, p),"
+        " plot_alignments_batch(a, 1, p), plot_alignment_single(a, 2, 1, p)]\n"
+        "names = ['mels_batch/valid_epoch_1.png', 'mels_scheduled/scheduled_epoch_1.png', 'mels_single/infer_epoch_1.png',"
+        " 'align_batch/valid_align_batch_epoch_1.png', 'align_single/valid_align_2_epoch_1.png']\n"
+        "assert all(x is None or (os.path.getsize(x) > 0 and x == os.path.join(p, n)) for x, n in zip(w, names)), w\n"
         "print('ok')\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]

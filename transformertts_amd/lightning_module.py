@@ -47,6 +47,10 @@ class LightningModule(_Base):
         self.example_batch = None
         self.log_interval = config['training'].get('log_interval', 100)
         self.sync_loss = config['training'].get('sync_loss_every_step', True)
+        # dropout / scheduled-sampling draws follow torch's process seed and the data-parallel rank (the reference draws
+        # them from torch's global generator, which `seed_everything` seeds per rank)
+        from . import ops
+        ops.seeds.seed_from_torch()
 
     def forward(self, phoneme, melspec, phoneme_lens, melspec_lens, **kwargs):
         return self.model(phoneme, melspec, phoneme_lens, melspec_lens, **kwargs)

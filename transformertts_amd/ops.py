@@ -59,6 +59,14 @@ class _SeedStream:
         self.base = int(seed) & 0xFFFFFFFFFFFF
         self.counter = 0
 
+    def seed_from_torch(self, rank: int = None) -> None:
+        """Base = torch's process seed (so `torch.manual_seed` / Lightning's `seed_everything` decide the masks, as they
+        do in the reference) folded with the data-parallel rank, so that replicas draw different masks."""
+        if rank is None:
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.manual_seed((torch.initial_seed() ^ (0x9E3779B9 * (int(rank) + 1))) & 0xFFFFFFFFFFFF)
+
     def next(self) -> int:
         self.counter += 1
         return ((self.base * 0x9E3779B97F4A7C15) ^ (self.counter * 0xD1B54A32D192ED03)) & 0xFFFFFFFFFFFFFFFF

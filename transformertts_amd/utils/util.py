@@ -90,6 +90,19 @@ def prepare_batch(batch: Dict[str, Tensor], device) -> Tuple[Tensor, ...]:
 _uniform_draw = None
 
 
+def block_mask(mel: Tensor, p_tf: float, L_bar: int) -> Tensor:
+    """(B,T,1) bool mask of the frames that take the model's own prediction (utils/util.py:103-111): frame t is set when
+    any uniform draw in its `L_bar`-frame window falls below 1 - p_tf.  Same kernel as `apply_teacher_forcing`, asked
+    to mix a plane of ones into a plane of zeros; the training step itself never materialises the mask."""
+    from .. import ops
+    B, T, _ = mel.shape
+    one = torch.ones(B, T, 4, dtype=torch.float32, device=mel.device)
+    u = _uniform_draw(B, T, mel.device).reshape(B, T).contiguous() if _uniform_draw is not None else None
+    full = torch.full((B,), T, dtype=torch.int64, device=mel.device)
+    mix = ops.sched_sampling_mix(one, torch.zeros_like(one), u, full, p_tf, L_bar, seed=ops.seeds.next())
+    return mix[:, :, :1] > 0.5
+
+
 def apply_teacher_forcing(pred_melspec: Tensor, melspec: Tensor, melspec_lens: Tensor, p_tf: float, device=None) -> Tensor:
     """`block_mask` + `apply_teacher_forcing` of the reference (utils/util.py:103-120) as ONE fused HIP kernel: frame t
     takes the model's own prediction when any uniform draw in its 8-frame window falls below 1 - p_tf, the ground truth
