@@ -45,7 +45,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense
 
 
-TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")     # newest first; see tools/collect_traffic.py
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")     # newest first; see tools/collect_traffic.py
 
 
 def measured_traffic(kernel: str):

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-2 evidence run on the GPU box: bench lines of the three workloads, rocprofv3 kernel stats of the default bench
+# Per-round evidence run on the GPU box: bench lines of the three workloads, rocprofv3 kernel stats of the default bench
 # command, and the two --pmc passes (FETCH_SIZE / WRITE_SIZE) the HBM-traffic table is built from.  Everything lands in
-# gpurun_out/r02/; the files to keep are then copied into profiles/.   usage: bash tools/collect_r02.sh <tag>
+# gpurun_out/r02/; the files to keep are then copied into profiles/.   usage: bash tools/collect_round.sh <tag>
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -15,6 +15,12 @@ python3 bench.py --steps 10 --warmup 4 --config scaled --batch 32 --no-cpu-basel
 echo "scaled b32 done"
 python3 bench.py --steps 20 --warmup 5 --ragged --no-cpu-baseline > $out/bench_base_b64_ragged.json 2> $out/bench_base_b64_ragged.err || exit 1
 echo "ragged done"
+python3 bench.py --steps 32 --warmup 16 --ragged --cycle 16 --no-cpu-baseline > $out/bench_base_b64_cycle16.json 2> $out/bench_base_b64_cycle16.err || exit 1
+echo "cycle16 (16 distinct ragged batches, shape-keyed graph cache) done"
+python3 bench.py --steps 16 --warmup 4 --batch 16 --accumulate 4 --no-cpu-baseline > $out/bench_base_b16_acc4.json 2> $out/bench_base_b16_acc4.err || exit 1
+echo "accumulate 4 x 16 done"
+MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 python3 tools/rccl_one_rank.py > $out/rccl_one_rank.json 2> $out/rccl_one_rank.err || exit 1
+echo "rccl one-rank done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-probe > $out/stats.log 2>&1 || exit 1
 echo "stats done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/traf_fetch -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-probe > $out/traf_fetch.log 2>&1 || exit 1
