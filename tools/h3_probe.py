@@ -9,6 +9,8 @@ M, N, K = (int(a) for a in sys.argv[1:4]); reps = int(sys.argv[4]) if len(sys.ar
 lib = _lib.load(); dev = torch.device("cuda:0")
 x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev)
 y = torch.empty(M, N, device=dev); pl = ops._planes(w, 4, N, K)
+xa = torch.zeros(ops.AMAX_SLOTS, device=dev)
+lib.ttts_amax_partials(_p(x), x.numel(), _p(xa), _stream())
 for _ in range(reps):
-    lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _stream())
+    lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _p(xa), None, _stream())
 torch.cuda.synchronize()

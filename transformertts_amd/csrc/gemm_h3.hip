@@ -67,216 +67,17 @@ __global__ __launch_bounds__(1024) void amax_partials_kernel(const float* __rest
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool CLIP>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
-    const uint64_t seed_eff = site_seed(g.seed, g.step_seed);
-    constexpr int NT = WM * WN * 64;                            // threads per workgroup (4 or 8 waves)
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue of the fp16x3 forward / data-gradient kernels (shared by the 8-wave and the one-wave-per-SIMD kernel): the wave's
+// accumulator tiles leave through `slab_base` (LDS, (WM * WN) * 32 * EP_LD floats, free at this point).
+template <int BM, int BN, int WM, int WN, bool CLIP, bool SWZ>
+__device__ __forceinline__ void h3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* slab_base,
+                                            const int lane, const int wave, const int m0, const int n0, const int ty,
+                                            const int bid, const float out_scale, const uint64_t seed_eff) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
-    static_assert((BM * 8) % NT == 0, "every thread stages whole float4s of the A tile");
-    constexpr int A_PLANE = BM * 16, B_PLANE = BN * 16;         // dwords per plane (64-byte rows)
-    constexpr int STAGE = 2 * (A_PLANE + B_PLANE);
-    // A 4-wave workgroup on a 256-row tile keeps ONE LDS stage (48 KB) so that two workgroups share a CU: a wave cannot
-    // run loads past its own outstanding stores (vmcnt is one in-order counter for both), so the 10 us store burst of a
-    // K = 256 tile can only drain under ANOTHER workgroup's main loop.
-    constexpr bool SINGLE = (NT == 256 && BM == 256);
-    constexpr int NSTAGE = SINGLE ? 1 : 2;
-    constexpr int NLA = BM * 8 / NT;                            // float4 loads per thread for the A tile (8 per row)
-    constexpr int NLB = (BN * 4 + NT - 1) / NT;                 // 16-byte pieces per thread and plane for the B tile (4 per row)
-    constexpr bool B_ALL = (BN * 4) % NT == 0;
-    constexpr int NTILE = 2 * TM * TN;                          // accumulator-tile visits per k-tile (two MFMA k-steps)
-
-    __shared__ __attribute__((aligned(16))) uint32_t lds[NSTAGE * STAGE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int nkt = g.K / HBK;
-    float a_scale, out_scale;
-    {
-        float a_inv, w_scale, w_inv;
-        h3_operand_scale(g.a_amax, g.a_amax_n, lane, a_scale, a_inv);
-        h3_operand_scale(g.b_amax, g.b_amax_n, lane, w_scale, w_inv);      // the planes already carry w_scale
-        out_scale = a_inv * w_inv;
-    }
-    // Persistent tile loop: the grid is (at most) as many workgroups as the chip holds at once and each walks over tiles
-    // bid, bid + gridDim.x, ...  A workgroup that has issued the stores of one tile goes straight on to the loads of the next,
-    // so the output burst drains from L2 to HBM under the next tile's main loop instead of in front of a new workgroup's
-    // start.  XCD-aware numbering (as the bf16x6 kernel): workgroups are dealt round-robin to the 8 XCDs, so virtual block
-    // ids that are equal mod 8 share an L2, and the column blocks of one A row panel get consecutive ids of one XCD.
-    const int nx = (g.N + BN - 1) / BN;
-    const int ntiles = nx * ((g.M + BM - 1) / BM);
-    for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int per = ntiles >> 3, rem = ntiles & 7;
-    const int t = xcd * per + min(xcd, rem) + slot;
-    const int ty = t / nx, tx = t - ty * nx;
-    const int m0 = ty * BM, n0 = tx * BN;
-
-    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
-    const uint32_t b_plane_bytes = (uint32_t)g.N * 64u;            // one plane of one k-tile: N rows of 32 f16
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float4 ra[NLA];
-    u32x4 rb[2][NLB];
-
-    // A: thread -> (row = idx >> 3, float4 chunk = idx & 7) for idx = tid + i*NT; rows past M fall outside the buffer
-    // descriptor (hardware zero), shifted rows outside their utterance are clipped on the offset (CLIP).  Per-thread
-    // offsets are loop-invariant VGPRs; the k position travels in SGPRs (the loads' scalar offset), so advancing k costs
-    // no vector instruction.
-    int a_t[NLA];
-    uint32_t a_off[NLA], a_lds[NLA];
-#pragma unroll
-    for (int i = 0; i < NLA; ++i) {
-        const int idx = tid + i * NT;
-        const int row = idx >> 3, ch = idx & 7;
-        const int m = m0 + row;
-        a_off[i] = (uint32_t)(((long)m * g.lda + ch * 4) * 4);
-        a_t[i] = CLIP ? (m % g.T) : 0;
-        a_lds[i] = (uint32_t)(row * 16 + (((ch >> 1) ^ ((row >> 2) & 3)) * 4) + (ch & 1) * 2);
-    }
-    // B: piece idx = tid + j*NT -> (row = idx >> 2, 16-byte chunk = idx & 3) of each plane
-    uint32_t b_off[NLB], b_lds[NLB];
-#pragma unroll
-    for (int j = 0; j < NLB; ++j) {
-        const int idx = tid + j * NT;
-        const int row = idx >> 2, c = idx & 3;
-        b_off[j] = (uint32_t)((n0 + row) * 64 + c * 16);
-        b_lds[j] = (uint32_t)(row * 16 + ((c ^ ((row >> 2) & 3)) * 4));
-    }
-    uint32_t b_cur = 0;                                            // scalar: byte offset of the current k-tile's planes
-    int k_c0 = 0, k_shift = g.shift0;
-    uint32_t k_off = (uint32_t)((long)g.shift0 * g.lda * 4);       // scalar: byte offset of the current k position in a row
-    const uint32_t tap_step = (uint32_t)(((long)g.shift_step * g.lda - g.cin) * 4);
-
-    auto load_a_piece = [&](int i) {
-        if (CLIP) {
-            uint32_t off = a_off[i] + k_off;
-            off = ((unsigned)(a_t[i] + k_shift) < (unsigned)g.T) ? off : OOB;
-            ra[i] = buf_load4(rsrcA, off);
-        } else {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (int)a_off[i], (int)k_off, 0);
-            ra[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-        }
-    };
-    auto advance_a = [&]() {
-        k_c0 += HBK;
-        k_off += HBK * 4;
-        if (k_c0 == g.cin) { k_c0 = 0; k_shift += g.shift_step; k_off += tap_step; }
-    };
-    auto load_b_piece = [&](int j) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-            rb[p][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)b_off[j], (int)(b_cur + p * b_plane_bytes), 0);
-    };
-    auto advance_b = [&]() { b_cur += 2u * b_plane_bytes; };
-    auto store_a_piece = [&](int buf, int i) {
-        uint32_t* as = lds + buf * STAGE;
-        uint2 hi, lo;
-        split2_pair(f32x2{ra[i].x, ra[i].y} * a_scale, hi.x, lo.x);
-        split2_pair(f32x2{ra[i].z, ra[i].w} * a_scale, hi.y, lo.y);
-        *reinterpret_cast<uint2*>(as + a_lds[i]) = hi;
-        *reinterpret_cast<uint2*>(as + A_PLANE + a_lds[i]) = lo;
-    };
-    auto store_b_piece = [&](int buf, int j) {
-        uint32_t* bs = lds + buf * STAGE + 2 * A_PLANE;
-        if (B_ALL || (tid + j * NT) < BN * 4) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(bs + p * B_PLANE + b_lds[j]) = rb[p][j];
-        }
-    };
-    // All staging of a k-tile in one block: write the registers (tile kt+1, requested a whole k-tile ago, so the single
-    // s_waitcnt vmcnt(0) in front of it is free) to LDS[buf^1], then re-use them at once to request tile kt+2.  Spreading
-    // the pieces over the MFMA gaps does not work with hipcc: every piece then waits vmcnt(0), i.e. for the loads issued
-    // a few instructions earlier (measured: 0.65x).
-    auto stage_all = [&](int buf, bool stage, bool fetch) {
-        if (stage) {
-#pragma unroll
-            for (int i = 0; i < NLA; ++i) store_a_piece(buf ^ 1, i);
-#pragma unroll
-            for (int j = 0; j < NLB; ++j) store_b_piece(buf ^ 1, j);
-        }
-        if (fetch) {
-#pragma unroll
-            for (int i = 0; i < NLA; ++i) load_a_piece(i);
-            advance_a();
-#pragma unroll
-            for (int j = 0; j < NLB; ++j) load_b_piece(j);
-            advance_b();
-        }
-    };
-
-    // One 32-deep k-tile = two MFMA k-steps over the wave's TM x TN accumulator tiles.  LDS[buf] holds tile kt, the staging
-    // registers tile kt+1.  The staging block sits behind the first accumulator-tile visit in the first half of the waves
-    // and behind the middle visit in the second half: the two waves that share a SIMD in an 8-wave workgroup run the same
-    // program in lockstep (one barrier per k-tile), and offsetting their VALU-heavy staging blocks lets one wave's MFMAs
-    // run under the other's staging.
-    const bool late = (NT == 512) && wave >= (NT / 128);
-    auto step = [&](int buf, bool stage, bool fetch) {
-        const uint32_t* as = lds + buf * STAGE;
-        const uint32_t* bs = as + 2 * A_PLANE;
-        const int sw = (l31 >> 2) & 3;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int cw = ((s * 2 + half) ^ sw) * 4;            // swizzled 16-byte chunk of this lane's 8 k values
-            f16x8 a[2][TM], b[2][TN];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    a[p][i] = *reinterpret_cast<const f16x8*>(as + p * A_PLANE + (wm * WTM + i * 32 + l31) * 16 + cw);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    b[p][j] = *reinterpret_cast<const f16x8*>(bs + p * B_PLANE + (wn * WTN + j * 32 + l31) * 16 + cw);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f32x16 c = acc[i][j];
-                    // the WEIGHT fragment is the MFMA's first operand: the accumulator tile is C^T (lane = output row m,
-                    // registers 4g..4g+3 = four consecutive output columns), so the epilogue moves float4s
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[0][j], a[1][i], c, 0, 0, 0);   // small terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[1][j], a[0][i], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[0][j], a[0][i], c, 0, 0, 0);
-                    acc[i][j] = c;
-                    const int visit = (s * TM + i) * TN + j;
-                    if (visit == 0 && !late) stage_all(buf, stage, fetch);
-                    if (NT == 512 && visit == NTILE / 2 && late) stage_all(buf, stage, fetch);
-                }
-        }
-    };
-
-    if (SINGLE) {
-        if (nkt > 0) stage_all(1, false, true);                 // request tile 0
-        for (int kt = 0; kt < nkt; ++kt) {
-            stage_all(1, true, kt + 1 < nkt);                   // registers (tile kt) -> LDS[0], request tile kt+1
-            __syncthreads();
-            step(0, false, false);                              // products only
-            __syncthreads();                                    // LDS[0] free again
-        }
-    } else if (nkt > 0) {
-        stage_all(1, false, true);              // request tile 0
-        stage_all(1, true, nkt > 1);            // stage tile 0 into LDS[0], request tile 1
-        __syncthreads();
-        int buf = 0;
-        for (int kt = 0; kt < nkt; ++kt) {
-            step(buf, kt + 1 < nkt, kt + 2 < nkt);
-            __syncthreads();
-            buf ^= 1;
-        }
-    }
-
     // ---------------- epilogue.  Accumulator tile (i, j) holds C[m][n] for m = row0 + l31 (the lane) and, in registers
     // 4q .. 4q+3, four consecutive columns.  Written from that layout a wave-store touches 32 rows x 32 bytes -- a quarter
     // of 32 different 128-byte lines -- and the output burst of a tile (256 KB per workgroup, every CU at the same time) ran
@@ -294,12 +95,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
         const_cast<float*>(has_res ? g.residual : g.A), 0, has_res ? (uint32_t)((long)g.M * g.ldr * 4) : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcBias = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(g.bias != nullptr ? g.bias : g.A), 0, g.bias != nullptr ? (uint32_t)g.N * 4u : 0u, 0x00020000);
-    constexpr int EP_LD = WTN + 4;                        // floats per slab row (+16 B: conflict-free float4 column writes)
+    // floats per slab row: +16 B makes the float4 column writes conflict-free; SWZ: no padding (the four 128 x 128 slabs of the
+    // one-wave-per-SIMD kernel fill one 64 KB LDS stage exactly), the 16-byte chunk index is XORed with the row instead
+    constexpr int EP_LD = SWZ ? WTN : WTN + 4;
     constexpr int C4 = WTN / 4;                           // float4 per slab row
     constexpr int NIT = (32 * C4 + 63) / 64;              // float4 per lane and slab
     constexpr bool EVEN = (32 * C4) % 64 == 0 && 64 % C4 == 0;   // every lane keeps ONE column group for the whole tile
-    static_assert((WM * WN) * 32 * EP_LD <= NSTAGE * STAGE, "epilogue slabs must fit the staging buffers");
-    float* slab = reinterpret_cast<float*>(lds) + wave * (32 * EP_LD);
+    static_assert(!SWZ || (EVEN && (C4 & (C4 - 1)) == 0), "the swizzled slab exists for the even layout only");
+    float* slab = slab_base + wave * (32 * EP_LD);
     const int col_base = n0 + wn * WTN;
     // vmcnt is an in-order counter shared by loads and stores: a load issued behind a slab's stores cannot be waited for
     // without waiting for those stores to complete.  The bias of a lane's (fixed) column group is therefore read once per
@@ -326,8 +129,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
         const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(C, 0, (uint32_t)((long)g.M * g.ldc * 4), 0x00020000);
         const bool want_max = g.c_amax != nullptr;
         const float relu_lo = (g.act == 1) ? 0.f : -__builtin_inff();
-        // rows / columns past the matrix edge exist only in edge tiles: everywhere else the running maximum needs no test
-        const bool tile_full = m0 + BM <= g.M && n0 + BN <= g.N;
+        // rows of this lane's first slab row group that lie inside the matrix (none in a column group past N): the running
+        // maximum of what is stored (published when g.c_amax is set) takes a slab row group rg only when rg < rows_left
+        const long left_l = (long)g.M - row_l;
+        const int rows_left = col_ok ? (int)(left_l < 0 ? 0 : (left_l > BM ? BM : left_l)) : 0;
         auto run = [&](auto has_res_c, auto has_gate_c, auto drop_c, auto stats_c) {
             constexpr bool HAS_RES = decltype(has_res_c)::value, HAS_GATE = decltype(has_gate_c)::value;
             constexpr bool DROP = decltype(drop_c)::value, STATS = decltype(stats_c)::value;
@@ -339,12 +144,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<float4*>(slab + l31 * EP_LD + j * 32 + 8 * q + 4 * half) =
+                        *reinterpret_cast<float4*>(slab + l31 * EP_LD + 4 * ((j * 8 + 2 * q + half) ^ (SWZ ? (l31 & (C4 - 1)) : 0))) =
                             make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 constexpr int GR = (NIT % 4 == 0) ? 4 : NIT;
+                float4 a4_ahead = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (SWZ) a4_ahead = *reinterpret_cast<const float4*>(slab + rsub * EP_LD + 4 * (c4 ^ (rsub & (C4 - 1))));
                 // STATS: sums are taken about the slab's first row (shift[]), so that sum((v - shift)^2) - sum(v - shift)^2 / n
                 // does not cancel: the shift is within the column's spread of its mean
                 float shift[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -367,7 +174,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
 #pragma unroll
                     for (int u = 0; u < GR; ++u) {
                         const int rg = i * 32 + (g0 + u) * RPI;
-                        const float4 a4 = *reinterpret_cast<const float4*>(slab + ((g0 + u) * RPI + rsub) * EP_LD + 4 * c4);
+                        // (one wave per SIMD: nothing else covers the LDS latency, so the float4 of the NEXT store is requested
+                        // before this one is worked on; the 8-wave kernel has neither the registers nor the need)
+                        const int srow = (g0 + u) * RPI + rsub;
+                        float4 a4;
+                        if (SWZ) {
+                            a4 = a4_ahead;
+                            const int nrow = (g0 + u + 1) * RPI + rsub;
+                            if (g0 + u + 1 < NIT)
+                                a4_ahead = *reinterpret_cast<const float4*>(slab + nrow * EP_LD + 4 * (c4 ^ (nrow & (C4 - 1))));
+                        } else {
+                            a4 = *reinterpret_cast<const float4*>(slab + srow * EP_LD + 4 * c4);
+                        }
                         float v[4] = {__builtin_fmaf(a4.x, out_scale, bias_fixed.x), __builtin_fmaf(a4.y, out_scale, bias_fixed.y),
                                       __builtin_fmaf(a4.z, out_scale, bias_fixed.z), __builtin_fmaf(a4.w, out_scale, bias_fixed.w)};
 #pragma unroll
@@ -394,12 +212,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
                                 s2[e] = __builtin_fmaf(dlt, dlt, s2[e]);
                             }
                         }
-                        if (want_max) {
-                            if (tile_full)
-                                cmax = fmaxf(fmaxf(fmaxf(cmax, fabsf(v[0])), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-                            else if (col_ok && row_l + rg < g.M)
-                                cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                        if (want_max) {   // running maximum, branch-free (two v_max3 + compare + select): rows / columns past the matrix
+                            // edge exist only in edge tiles, where rows_left cuts them off
+                            float mx = fmaxf(fmaxf(cmax, fabsf(v[0])), fabsf(v[1]));
+                            mx = fmaxf(fmaxf(mx, fabsf(v[2])), fabsf(v[3]));
+                            cmax = rg < rows_left ? mx : cmax;
                         }
+                        // one float4 at a time: without the fence the scheduler pulls the LDS reads and scalar offsets of the
+                        // whole slab to the front and the kernel (at the 256-register limit) spills into its main loop
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 if (STATS && slab_rows > 0) {
@@ -516,8 +337,488 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
         }
     }
     if (g.c_amax != nullptr) amax_publish(cmax, g.c_amax, bid);
+}
+
+#ifdef TTTS_EXP_STAMPS
+__device__ unsigned long long ttts_dbg_stamps[512 * 8 * 6 * 8];
+#endif
+
+template <int BM, int BN, int WM, int WN, bool CLIP>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
+    const uint64_t seed_eff = site_seed(g.seed, g.step_seed);
+    constexpr int NT = WM * WN * 64;                            // threads per workgroup (4 or 8 waves)
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
+    static_assert((BM * 8) % NT == 0, "every thread stages whole float4s of the A tile");
+    constexpr int A_PLANE = BM * 16, B_PLANE = BN * 16;         // dwords per plane (64-byte rows)
+    constexpr int STAGE = 2 * (A_PLANE + B_PLANE);
+    // A 4-wave workgroup on a 256-row tile keeps ONE LDS stage (48 KB) so that two workgroups share a CU: a wave cannot
+    // run loads past its own outstanding stores (vmcnt is one in-order counter for both), so the 10 us store burst of a
+    // K = 256 tile can only drain under ANOTHER workgroup's main loop.
+    constexpr bool SINGLE = (NT == 256 && BM == 256 && BN == 128);
+    constexpr int NSTAGE = SINGLE ? 1 : 2;
+    constexpr int NLA = BM * 8 / NT;                            // float4 loads per thread for the A tile (8 per row)
+    constexpr int NLB = (BN * 4 + NT - 1) / NT;                 // 16-byte pieces per thread and plane for the B tile (4 per row)
+    constexpr bool B_ALL = (BN * 4) % NT == 0;
+    constexpr int NTILE = 2 * TM * TN;                          // accumulator-tile visits per k-tile (two MFMA k-steps)
+
+    __shared__ __attribute__((aligned(16))) uint32_t lds[NSTAGE * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    // the wave index as a SCALAR: everything derived from it (wm, wn, the staging slot `late`) is then uniform for the
+    // compiler too -- with a VGPR wave index the k offsets updated inside `if (late)` became divergent values and every
+    // buffer load of the main loop was wrapped in a readfirstlane waterfall loop
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nkt = g.K / HBK;
+    float a_scale, out_scale;
+    {
+        float a_inv, w_scale, w_inv;
+        h3_operand_scale(g.a_amax, g.a_amax_n, lane, a_scale, a_inv);
+        h3_operand_scale(g.b_amax, g.b_amax_n, lane, w_scale, w_inv);      // the planes already carry w_scale
+        out_scale = a_inv * w_inv;
+    }
+    // Persistent tile loop: the grid is (at most) as many workgroups as the chip holds at once and each walks over tiles
+    // bid, bid + gridDim.x, ...  A workgroup that has issued the stores of one tile goes straight on to the loads of the next,
+    // so the output burst drains from L2 to HBM under the next tile's main loop instead of in front of a new workgroup's
+    // start.  XCD-aware numbering (as the bf16x6 kernel): workgroups are dealt round-robin to the 8 XCDs, so virtual block
+    // ids that are equal mod 8 share an L2, and the column blocks of one A row panel get consecutive ids of one XCD.
+    const int nx = (g.N + BN - 1) / BN;
+    const int ntiles = nx * ((g.M + BM - 1) / BM);
+#ifdef TTTS_EXP_STAMPS
+    int dbg_iter = 0;
+#define STAMP(ph) do { if (BM == 256 && BN == 256 && (threadIdx.x & 63) == 0 && dbg_iter < 6) \
+        ttts_dbg_stamps[((blockIdx.x * 8 + (threadIdx.x >> 6)) * 6 + dbg_iter) * 8 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+    STAMP(7);
+#else
+#define STAMP(ph)
+#endif
+    for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
+    STAMP(0);
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int per = ntiles >> 3, rem = ntiles & 7;
+    const int t = xcd * per + min(xcd, rem) + slot;
+    const int ty = t / nx, tx = t - ty * nx;
+    const int m0 = ty * BM, n0 = tx * BN;
+
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
+    const uint32_t b_plane_bytes = (uint32_t)g.N * 64u;            // one plane of one k-tile: N rows of 32 f16
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[NLA];
+    u32x4 rb[2][NLB];
+
+    // A: thread -> (row = idx >> 3, float4 chunk = idx & 7) for idx = tid + i*NT; rows past M fall outside the buffer
+    // descriptor (hardware zero), shifted rows outside their utterance are clipped on the offset (CLIP).  Per-thread
+    // offsets are loop-invariant VGPRs; the k position travels in SGPRs (the loads' scalar offset), so advancing k costs
+    // no vector instruction.
+    // Piece i of a thread sits 64 (A: NT / 8) resp. NT / 4 (B) rows below piece 0 -- same chunk, same swizzle term -- so ONE
+    // global offset and ONE LDS offset per operand live in VGPRs (the kernel sits at the 256-register limit of two waves
+    // per SIMD); the distance to piece i is a constant in LDS and a scalar in the loads' soffset.
+    constexpr int A_ROWS_PER_PIECE = NT / 8, B_ROWS_PER_PIECE = NT / 4;
+    static_assert(A_ROWS_PER_PIECE % 16 == 0 && B_ROWS_PER_PIECE % 16 == 0, "pieces keep their swizzle term");
+    const int a_row0 = tid >> 3, a_ch = tid & 7;
+    const uint32_t a_off0 = (uint32_t)(((long)(m0 + a_row0) * g.lda + a_ch * 4) * 4);
+    const uint32_t a_piece_step = (uint32_t)((long)A_ROWS_PER_PIECE * g.lda * 4);          // scalar
+    const uint32_t a_lds0 = (uint32_t)(a_row0 * 16 + (((a_ch >> 1) ^ ((a_row0 >> 2) & 3)) * 4) + (a_ch & 1) * 2);
+    int a_t[CLIP ? NLA : 1];
+    if (CLIP) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) a_t[i] = (m0 + a_row0 + i * A_ROWS_PER_PIECE) % g.T;
+    }
+    // B: piece idx = tid + j*NT -> (row = idx >> 2, 16-byte chunk = idx & 3) of each plane
+    const int b_row0 = tid >> 2, b_c = tid & 3;
+    const uint32_t b_off0 = (uint32_t)((n0 + b_row0) * 64 + b_c * 16);
+    const uint32_t b_lds0 = (uint32_t)(b_row0 * 16 + ((b_c ^ ((b_row0 >> 2) & 3)) * 4));
+    uint32_t b_cur = 0;                                            // scalar: byte offset of the current k-tile's planes
+    int k_c0 = 0, k_shift = g.shift0;
+    uint32_t k_off = (uint32_t)((long)g.shift0 * g.lda * 4);       // scalar: byte offset of the current k position in a row
+    const uint32_t tap_step = (uint32_t)(((long)g.shift_step * g.lda - g.cin) * 4);
+
+    auto load_a_piece = [&](int i) {
+        if (CLIP) {
+            uint32_t off = a_off0 + k_off + i * a_piece_step;
+            off = ((unsigned)(a_t[i] + k_shift) < (unsigned)g.T) ? off : OOB;
+            ra[i] = buf_load4(rsrcA, off);
+        } else {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (int)a_off0, (int)(k_off + i * a_piece_step), 0);
+            ra[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+    };
+    auto advance_a = [&]() {
+        k_c0 += HBK;
+        k_off += HBK * 4;
+        if (k_c0 == g.cin) { k_c0 = 0; k_shift += g.shift_step; k_off += tap_step; }
+    };
+    auto load_b_piece = [&](int j) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            rb[p][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)b_off0,
+                                                             (int)(b_cur + p * b_plane_bytes + j * (B_ROWS_PER_PIECE * 64)), 0);
+    };
+    auto advance_b = [&]() { b_cur += 2u * b_plane_bytes; };
+    auto store_a_piece = [&](int buf, int i) {
+        uint32_t* as = lds + buf * STAGE;
+        uint2 hi, lo;
+        split2_pair(f32x2{ra[i].x, ra[i].y} * a_scale, hi.x, lo.x);
+        split2_pair(f32x2{ra[i].z, ra[i].w} * a_scale, hi.y, lo.y);
+        *reinterpret_cast<uint2*>(as + a_lds0 + i * (A_ROWS_PER_PIECE * 16)) = hi;
+        *reinterpret_cast<uint2*>(as + A_PLANE + a_lds0 + i * (A_ROWS_PER_PIECE * 16)) = lo;
+    };
+    auto store_b_piece = [&](int buf, int j) {
+        uint32_t* bs = lds + buf * STAGE + 2 * A_PLANE;
+        if (B_ALL || (tid + j * NT) < BN * 4) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                *reinterpret_cast<u32x4*>(bs + p * B_PLANE + b_lds0 + j * (B_ROWS_PER_PIECE * 16)) = rb[p][j];
+        }
+    };
+    // All staging of a k-tile in one block: write the registers (tile kt+1, requested a whole k-tile ago, so the single
+    // s_waitcnt vmcnt(0) in front of it is free) to LDS[buf^1], then re-use them at once to request tile kt+2.  Spreading
+    // the pieces over the MFMA gaps does not work with hipcc: every piece then waits vmcnt(0), i.e. for the loads issued
+    // a few instructions earlier (measured: 0.65x).
+    auto stage_all = [&](int buf, bool stage, bool fetch) {
+        if (stage) {
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) store_a_piece(buf ^ 1, i);
+#pragma unroll
+            for (int j = 0; j < NLB; ++j) store_b_piece(buf ^ 1, j);
+        }
+        if (fetch) {
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) load_a_piece(i);
+            advance_a();
+#pragma unroll
+            for (int j = 0; j < NLB; ++j) load_b_piece(j);
+            advance_b();
+        }
+    };
+
+    // One 32-deep k-tile = two MFMA k-steps over the wave's TM x TN accumulator tiles.  LDS[buf] holds tile kt, the staging
+    // registers tile kt+1.  The staging block sits behind the first accumulator-tile visit in the first half of the waves
+    // and behind the middle visit in the second half: the two waves that share a SIMD in an 8-wave workgroup run the same
+    // program in lockstep (one barrier per k-tile), and offsetting their VALU-heavy staging blocks lets one wave's MFMAs
+    // run under the other's staging.
+    const bool late = (NT == 512) && wave >= (NT / 128);
+    auto step = [&](int buf, bool stage, bool fetch) {
+        const uint32_t* as = lds + buf * STAGE;
+        const uint32_t* bs = as + 2 * A_PLANE;
+        const int sw = (l31 >> 2) & 3;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int cw = ((s * 2 + half) ^ sw) * 4;            // swizzled 16-byte chunk of this lane's 8 k values
+            f16x8 a[2][TM], b[2][TN];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[p][i] = *reinterpret_cast<const f16x8*>(as + p * A_PLANE + (wm * WTM + i * 32 + l31) * 16 + cw);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[p][j] = *reinterpret_cast<const f16x8*>(bs + p * B_PLANE + (wn * WTN + j * 32 + l31) * 16 + cw);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    // the WEIGHT fragment is the MFMA's first operand: the accumulator tile is C^T (lane = output row m,
+                    // registers 4g..4g+3 = four consecutive output columns), so the epilogue moves float4s
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[0][j], a[1][i], c, 0, 0, 0);   // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[1][j], a[0][i], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[0][j], a[0][i], c, 0, 0, 0);
+                    acc[i][j] = c;
+                    const int visit = (s * TM + i) * TN + j;
+                    if (visit == 0 && !late) stage_all(buf, stage, fetch);
+                    if (NT == 512 && visit == NTILE / 2 && late) stage_all(buf, stage, fetch);
+                }
+        }
+    };
+
+    if (SINGLE) {
+        if (nkt > 0) stage_all(1, false, true);                 // request tile 0
+        for (int kt = 0; kt < nkt; ++kt) {
+            stage_all(1, true, kt + 1 < nkt);                   // registers (tile kt) -> LDS[0], request tile kt+1
+            __syncthreads();
+            step(0, false, false);                              // products only
+            __syncthreads();                                    // LDS[0] free again
+        }
+    } else if (nkt > 0) {
+        stage_all(1, false, true);              // request tile 0
+        STAMP(1);
+        stage_all(1, true, nkt > 1);            // stage tile 0 into LDS[0], request tile 1
+        STAMP(2);
+        __syncthreads();
+        STAMP(3);
+        int buf = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+            step(buf, kt + 1 < nkt, kt + 2 < nkt);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    STAMP(4);
+
+    static_assert((WM * WN) * 32 * (WTN + 4) <= NSTAGE * STAGE, "epilogue slabs must fit the staging buffers");
+    h3_epilogue<BM, BN, WM, WN, CLIP, false>(g, acc, reinterpret_cast<float*>(lds), lane, wave, m0, n0, ty, bid, out_scale, seed_eff);
+    STAMP(5);
     __syncthreads();        // the slabs alias the staging buffers the next tile's prologue writes
+    STAMP(6);
+#ifdef TTTS_EXP_STAMPS
+    ++dbg_iter;
+#endif
     }   // persistent tile loop
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The 256 x 256 tile with ONE wave per SIMD: 4 waves, 128 x 128 per wave (256 accumulator registers of the wave's 512).
+// Nothing else on the SIMD covers a wait, so the wave covers its own, and the source order below IS the schedule (a
+// scheduling fence after every MFMA slot):
+//   * two fragment sets -- while the 48 MFMAs of one k-step run, the LDS reads of the next step land in the other set, so the
+//     one barrier per k-tile (between its two k-steps, where the second step's fragments are already in registers) is not
+//     followed by a dependent LDS wait;
+//   * every MFMA is followed by ONE piece of side work that runs while the matrix pipe is busy with it: a fragment read, half
+//     of the split of an A piece (~7 VALU) and its LDS write, a B plane piece's LDS write, a global load;
+//   * the operand stream does not stop at a tile boundary: the last two k-tiles of a tile request, and the last one stages,
+//     the first k-tiles of the workgroup's NEXT tile, so a tile's epilogue (whose slabs use the LDS stage the last k-step
+//     freed, swizzled instead of padded: 4 x 16 KB) is followed at once by MFMAs; the next tile's loads are older than the
+//     epilogue's stores, so waiting for them does not wait for the store burst (vmcnt is one in-order counter).
+// Measured at M = 55 680, K = 256 (s_memtime, tools/h3_stamps.py): main loop 32.7k ticks per tile against 36.7k of the
+// 8-wave kernel (MFMA-bound: 22.1k); K >= 1024 and the convolutions gain 7-9 % per launch.
+// Requires K >= 96 (three k-tiles) and T == 0 or T >= 32.
+template <bool CLIP>
+__global__ __launch_bounds__(256, 1) void gemm_h3_wide_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 2, NT = 256;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    constexpr int A_PLANE = BM * 16, B_PLANE = BN * 16, STAGE = 2 * (A_PLANE + B_PLANE);      // dwords
+    constexpr int NLA = BM * 8 / NT, NLB = BN * 4 / NT;
+    constexpr int A_ROWS_PER_PIECE = NT / 8, B_ROWS_PER_PIECE = NT / 4;
+    static_assert((WM * WN) * 32 * WTN <= STAGE, "the four swizzled epilogue slabs fill one LDS stage");
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE];
+
+    const uint64_t seed_eff = site_seed(g.seed, g.step_seed);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nkt = g.K / HBK;
+    float a_scale, out_scale;
+    {
+        float a_inv, w_scale, w_inv;
+        h3_operand_scale(g.a_amax, g.a_amax_n, lane, a_scale, a_inv);
+        h3_operand_scale(g.b_amax, g.b_amax_n, lane, w_scale, w_inv);      // the planes already carry w_scale
+        out_scale = a_inv * w_inv;
+    }
+    const int nx = (g.N + BN - 1) / BN;
+    const int ntiles = nx * ((g.M + BM - 1) / BM);
+#ifdef TTTS_EXP_STAMPS
+    int dbg_iter = 0;
+#define WSTAMP(ph) do { if ((threadIdx.x & 63) == 0 && dbg_iter < 6) \
+        ttts_dbg_stamps[((blockIdx.x * 8 + (threadIdx.x >> 6)) * 6 + dbg_iter) * 8 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WSTAMP(ph)
+#endif
+    // XCD-aware tile numbering of gemm_h3_kernel
+    auto tile_coords = [&](int bid, int& m0, int& n0, int& ty) {
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int per = ntiles >> 3, rem = ntiles & 7;
+        const int t = xcd * per + min(xcd, rem) + slot;
+        ty = t / nx;
+        m0 = ty * BM;
+        n0 = (t - ty * nx) * BN;
+    };
+    // (the loader's descriptors: empty once the workgroup has no further tile -- its loads then return zeros without touching
+    // memory, and the k-tile loop needs no variant that stops staging)
+    __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
+    const uint32_t b_plane_bytes = (uint32_t)g.N * 64u;            // one plane of one k-tile: N rows of 32 f16
+    const uint32_t a_piece_step = (uint32_t)((long)A_ROWS_PER_PIECE * g.lda * 4);
+    const uint32_t tap_step = (uint32_t)(((long)g.shift_step * g.lda - g.cin) * 4);
+    // staging layout of gemm_h3_kernel: one global / LDS offset per operand, piece i a constant number of rows further down
+    const int a_row0 = tid >> 3, a_ch = tid & 7;
+    const uint32_t a_lds0 = (uint32_t)(a_row0 * 16 + (((a_ch >> 1) ^ ((a_row0 >> 2) & 3)) * 4) + (a_ch & 1) * 2);
+    const int b_row0 = tid >> 2, b_c = tid & 3;
+    const uint32_t b_lds0 = (uint32_t)(b_row0 * 16 + ((b_c ^ ((b_row0 >> 2) & 3)) * 4));
+    // ---- the loader's position: a tile (possibly the one AFTER the tile being computed) and a k-tile within it
+    uint32_t a_off0 = 0, b_off0 = 0, b_cur = 0, k_off = 0;
+    int a_t[CLIP ? NLA : 1];
+    int k_c0 = 0, k_shift = 0;
+    auto set_loader_tile = [&](int bid) {
+        const bool live = bid < ntiles;
+        rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, live ? g.a_bytes : 0u, 0x00020000);
+        rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, live ? g.b_bytes : 0u, 0x00020000);
+        int m0, n0, ty;
+        tile_coords(live ? bid : 0, m0, n0, ty);
+        a_off0 = (uint32_t)(((long)(m0 + a_row0) * g.lda + a_ch * 4) * 4);
+        b_off0 = (uint32_t)((n0 + b_row0) * 64 + b_c * 16);
+        if (CLIP) {                                                // frame index of every piece's row (T >= 32: one wrap per piece)
+            int t = (m0 + a_row0) % g.T;
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) {
+                a_t[i] = t;
+                t += A_ROWS_PER_PIECE;
+                t -= t >= g.T ? g.T : 0;
+            }
+        }
+        b_cur = 0;
+        k_c0 = 0;
+        k_shift = g.shift0;
+        k_off = (uint32_t)((long)g.shift0 * g.lda * 4);
+    };
+    float4 ra[NLA];
+    u32x4 rb[2][NLB];
+    auto load_a_piece = [&](int i) {
+        if (CLIP) {
+            uint32_t off = a_off0 + k_off + i * a_piece_step;
+            off = ((unsigned)(a_t[i] + k_shift) < (unsigned)g.T) ? off : OOB;
+            ra[i] = buf_load4(rsrcA, off);
+        } else {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (int)a_off0, (int)(k_off + i * a_piece_step), 0);
+            ra[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+    };
+    auto advance_a = [&]() {
+        k_c0 += HBK;
+        k_off += HBK * 4;
+        if (k_c0 == g.cin) { k_c0 = 0; k_shift += g.shift_step; k_off += tap_step; }
+    };
+    auto load_b_piece = [&](int w) {                               // w -> (plane w & 1, piece w >> 1)
+        rb[w & 1][w >> 1] = __builtin_amdgcn_raw_buffer_load_b128(
+            rsrcB, (int)b_off0, (int)(b_cur + (w & 1) * b_plane_bytes + (w >> 1) * (B_ROWS_PER_PIECE * 64)), 0);
+    };
+    auto advance_b = [&]() { b_cur += 2u * b_plane_bytes; };
+    auto store_b_piece = [&](int buf, int w) {
+        uint32_t* bs = lds + buf * STAGE + 2 * A_PLANE;
+        *reinterpret_cast<u32x4*>(bs + (w & 1) * B_PLANE + b_lds0 + (w >> 1) * (B_ROWS_PER_PIECE * 16)) = rb[w & 1][w >> 1];
+    };
+    uint32_t pend_hi = 0, pend_lo = 0;                             // first half of the A piece being split
+    auto split_a_half = [&](int buf, int i, int h) {
+        if (h == 0) {
+            split2_pair(f32x2{ra[i].x, ra[i].y} * a_scale, pend_hi, pend_lo);
+        } else {
+            uint2 hi, lo;
+            hi.x = pend_hi; lo.x = pend_lo;
+            split2_pair(f32x2{ra[i].z, ra[i].w} * a_scale, hi.y, lo.y);
+            uint32_t* as = lds + buf * STAGE;
+            *reinterpret_cast<uint2*>(as + a_lds0 + i * (A_ROWS_PER_PIECE * 16)) = hi;
+            *reinterpret_cast<uint2*>(as + A_PLANE + a_lds0 + i * (A_ROWS_PER_PIECE * 16)) = lo;
+        }
+    };
+    // ---- fragments and products
+    f32x16 acc[TM][TN];
+    f16x8 fa[2][2][TM], fb[2][2][TN];                              // [set][plane][tile]
+    const int sw = (l31 >> 2) & 3;
+    constexpr int NMF = 3 * TM * TN;                               // MFMAs per k-step
+    constexpr int NFR = 2 * (TM + TN);                             // fragment reads per k-step
+    static_assert(NFR + 2 * NLA + 2 * NLB <= NMF, "one piece of side work per MFMA slot");
+    auto read_frag = [&](int set, int buf, int s, int r) {         // r -> plane r / (TM + TN), then the A tiles, then the B tiles
+        const uint32_t* as = lds + buf * STAGE;
+        const uint32_t* bs = as + 2 * A_PLANE;
+        const int cw = ((s * 2 + half) ^ sw) * 4;
+        const int p = r / (TM + TN), q = r % (TM + TN);
+        if (q < TM) fa[set][p][q] = *reinterpret_cast<const f16x8*>(as + p * A_PLANE + (wm * WTM + q * 32 + l31) * 16 + cw);
+        else fb[set][p][q - TM] = *reinterpret_cast<const f16x8*>(bs + p * B_PLANE + (wn * WTN + (q - TM) * 32 + l31) * 16 + cw);
+    };
+    // m -> (term, i, j), term-major: consecutive MFMAs never wait for one another's result, and every accumulator still sees
+    // its three terms in the order of the 8-wave kernel (small terms first: b_hi a_lo, b_lo a_hi, b_hi a_hi) -- same bits
+    auto mfma_one = [&](int set, int m) {
+        const int t = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
+        const int pb = t == 1 ? 1 : 0, pa = t == 0 ? 1 : 0;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[set][pb][j], fa[set][pa][i], acc[i][j], 0, 0, 0);
+    };
+    // One k-tile.  On entry LDS[buf] holds it, fragment set 0 its first k-step, the staging registers the k-tile after it (of
+    // this tile or of the workgroup's next one).  Stages the registers to LDS[buf ^ 1], requests the k-tile after that, and
+    // leaves in set 0 the first fragments of LDS[buf ^ 1].  ONE instantiation for every k-tile of every tile: variants that skip
+    // the staging at the end of the tile list would each want the 256 accumulators in their own registers.
+    auto body = [&](int buf) {
+        constexpr int S_SPLIT = NFR, S_BW = S_SPLIT + 2 * NLA, S_END = S_BW + 2 * NLB;
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+            mfma_one(0, m);
+            if (m < S_SPLIT) {
+                read_frag(1, buf, 1, m);
+            } else if (m < S_BW) {                                 // an A piece in two halves; its register is re-requested at once
+                const int i = (m - S_SPLIT) >> 1, h = (m - S_SPLIT) & 1;
+                split_a_half(buf ^ 1, i, h);
+                if (h == 1) load_a_piece(i);
+                if (m == S_BW - 1) advance_a();
+            } else if (m < S_END) {
+                store_b_piece(buf ^ 1, m - S_BW);
+                load_b_piece(m - S_BW);
+                if (m == S_END - 1) advance_b();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();              // LDS[buf ^ 1] complete, every wave has its last fragments of LDS[buf]
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+            mfma_one(1, m);
+            if (m < NFR) read_frag(0, buf ^ 1, 0, m);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    int bid = blockIdx.x;                                          // the grid never exceeds the number of tiles
+    set_loader_tile(bid);
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) load_a_piece(i);
+    advance_a();
+#pragma unroll
+    for (int w = 0; w < 2 * NLB; ++w) load_b_piece(w);
+    advance_b();
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) { split_a_half(0, i, 0); split_a_half(0, i, 1); }
+#pragma unroll
+    for (int w = 0; w < 2 * NLB; ++w) store_b_piece(0, w);
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) load_a_piece(i);
+    advance_a();
+#pragma unroll
+    for (int w = 0; w < 2 * NLB; ++w) load_b_piece(w);
+    advance_b();
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NFR; ++r) read_frag(0, 0, 0, r);
+    int buf = 0;
+    for (; bid < ntiles; bid += gridDim.x) {
+        WSTAMP(3);
+        int m0, n0, ty;
+        tile_coords(bid, m0, n0, ty);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            // two k-tiles before the end the loader moves on to the workgroup's next tile (none left: empty descriptors)
+            if (kt == nkt - 2) set_loader_tile(bid + gridDim.x);
+            body(buf);
+            buf ^= 1;
+        }
+        WSTAMP(4);
+        // LDS[buf] now holds the next tile's first k-tile; the stage the last k-step ran on is free for the slabs
+        h3_epilogue<BM, BN, WM, WN, CLIP, true>(g, acc, reinterpret_cast<float*>(lds + (buf ^ 1) * STAGE), lane, wave, m0, n0, ty, bid,
+                                                out_scale, seed_eff);
+        WSTAMP(5);
+        __syncthreads();              // the slabs are free again: the next tile's first k-tile stages into them
+        WSTAMP(6);
+#ifdef TTTS_EXP_STAMPS
+        ++dbg_iter;
+#endif
+    }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -531,6 +832,19 @@ static int launch_h3(const GemmArgs& g, hipStream_t stream) {
     else
         hipLaunchKernelGGL((gemm_h3_kernel<BM, BN, WM, WN, false>), grid, dim3(WM * WN * 64), 0, stream, g);
     TTTS_LAUNCH_CHECK("gemm_h3_kernel");
+    return TTTS_OK;
+}
+
+static bool h3_wide_supports(const GemmArgs& g) { return g.K >= 3 * HBK && (g.T <= 0 || g.T >= 32); }
+
+static int launch_h3_wide(const GemmArgs& g, hipStream_t stream) {
+    const long ntiles = (long)cdiv(g.N, 256) * cdiv(g.M, 256);
+    dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256), 1, 1);                // one workgroup per CU
+    if (g.T > 0)
+        hipLaunchKernelGGL((gemm_h3_wide_kernel<true>), grid, dim3(256), 0, stream, g);
+    else
+        hipLaunchKernelGGL((gemm_h3_wide_kernel<false>), grid, dim3(256), 0, stream, g);
+    TTTS_LAUNCH_CHECK("gemm_h3_wide_kernel");
     return TTTS_OK;
 }
 
@@ -596,7 +910,7 @@ int dispatch_h3(const GemmArgs& g, hipStream_t stream) {
         return TTTS_ERR_INVALID;
     }
     switch (h3_tile_choice(g.M, g.N, g.K)) {
-        case H3_TILE_256: return launch_h3<256, 256, 2, 4>(g, stream);
+        case H3_TILE_256: return h3_wide_supports(g) ? launch_h3_wide(g, stream) : launch_h3<256, 256, 2, 4>(g, stream);
         case H3_TILE_256x128: return launch_h3<256, 128, 4, 2>(g, stream);
         case H3_TILE_256x128_PAIR: return launch_h3<256, 128, 2, 2>(g, stream);
         case TILE_64x128: return launch_h3<64, 128, 2, 2>(g, stream);
@@ -904,3 +1218,13 @@ extern "C" int ttts_amax_partials(const float* x, int64_t n, float* partials, vo
     TTTS_LAUNCH_CHECK("amax_partials_kernel");
     return TTTS_OK;
 }
+
+#ifdef TTTS_EXP_STAMPS
+extern "C" int ttts_dbg_read_stamps(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ttts::ttts_dbg_stamps), n * sizeof(unsigned long long));
+}
+extern "C" int ttts_dbg_clear_stamps() {
+    static unsigned long long z[512 * 8 * 6 * 8];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(ttts::ttts_dbg_stamps), z, sizeof(z));
+}
+#endif
