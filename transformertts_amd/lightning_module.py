@@ -69,8 +69,11 @@ class LightningModule(_Base):
                                         need_alignments=False)['pred_melspec']
         p_tf = self.teacher_forcing_ratio()
         mel_mixed = apply_teacher_forcing(pred_melspec, melspec, melspec_lens, p_tf, self.device)
-        # forward #2 (with grad) on the mixed input, loss against the ground truth
-        output = self.forward(phoneme, mel_mixed, phoneme_lens, melspec_lens)
+        # forward #2 (with grad) on the mixed input, loss against the ground truth.  The loss reads the three prediction tensors
+        # only (lightning_module.py:78-79 of the reference discards the alignments of its output dict as well), so the per-head
+        # attention maps are not written here either; `validation_step` / `forward()` return them as the reference does.
+        output = self.forward(phoneme, mel_mixed, phoneme_lens, melspec_lens,
+                              need_alignments=self.config['training'].get('train_step_alignments', False))
         loss = self.criterion(output, melspec, melspec_lens)
         if self.sync_loss:
             self.train_losses.append(loss['total'].item())
