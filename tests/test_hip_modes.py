@@ -64,6 +64,48 @@ def test_linear_forms_agree_with_fp64(M, N, K):
         assert rc == 0 and _rel(dw, 2 * dw_ref) < TOL and _rel(db, 2 * db_ref) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(70001, 768, 96), (66000, 768, 256), (41000, 1024, 128)])
+def test_fp16x3_one_wave_per_simd_tile_streams_across_tiles(M, N, K):
+    """Shapes the dispatch gives to gemm_h3_wide_kernel (256 x 256 tile, 4 waves; csrc/gemm_h3.hip) with MORE tiles than
+    workgroups, so every workgroup runs several tiles back to back -- the operand stream continues across the tile boundary,
+    the last tile of a workgroup loads through empty descriptors -- with a ragged last row block, the minimum of three
+    k-tiles, and the epilogues of the step (bias + relu + maxima, residual, relu gate of a data gradient): against fp64 on
+    sampled rows and bit for bit against a second run (no dependence on what the staging buffers held before)."""
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    assert lib.ttts_gemm_tile_choice(M, N, K, 2) == 6               # H3_TILE_256
+    x, w, b = _rand(M, K, seed=11), _rand(N, K, seed=12, scale=K ** -0.5), _rand(N, seed=13)
+    res = _rand(M, N, seed=14)
+    pl = ops._planes(w, 4, N, K)
+    xa = ops._amax(x)
+    rows = torch.cat([torch.arange(0, 300, device=_dev()), torch.randint(0, M, (700,), device=_dev()),
+                      torch.arange(M - 300, M, device=_dev())])
+    ref = x[rows].double() @ w.double().t() + b.double()
+    y = torch.full((M, N), float("nan"), device=_dev())
+    slots = torch.zeros(ops.AMAX_SLOTS, device=_dev())
+    assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 1, 0.0, 0, None, 0, 0, _p(xa), _p(slots), _stream()) == 0
+    assert torch.isfinite(y).all() and _rel(y[rows], torch.relu(ref)) < TOL
+    assert slots.max().item() == y.abs().max().item()
+    y2 = torch.full((M, N), 3.0, device=_dev())
+    torch.randn(1 << 22, device=_dev())                              # something else through the caches in between
+    assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), None, _p(y2), M, N, K, 1, 0.0, 0, None, 0, 0, _p(xa), None, _stream()) == 0
+    assert torch.equal(y, y2)
+    assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), _p(res), _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _p(xa), None, _stream()) == 0
+    assert _rel(y[rows], ref + res[rows].double()) < TOL
+    # data gradient of the same layer: dy (M x N) . W -> dx (M x K) is a K-wide output; the gated form through W^T instead:
+    # dh (M x K2) = dy2 (M x K) . Wt with the relu gate of h -- an N-wide output with the gate operand read in the epilogue
+    dy2 = _rand(M, K, seed=15) * 1e-5
+    hgate = torch.relu(_rand(M, N, seed=16))
+    plt = ops._planes(w.t().contiguous(), 5, N, K)                   # weight (K, N) of a Linear N -> K, data-gradient planes
+    dh = torch.empty(M, N, device=_dev())
+    dslots = torch.zeros(ops.AMAX_SLOTS, device=_dev())
+    assert lib.ttts_linear_bwd_data_h3(_p(dy2), _p(plt), None, _p(dh), M, K, N, _p(hgate), 1.25, _p(ops._amax(dy2)), _p(dslots),
+                                       _stream()) == 0
+    dref = (dy2[rows].double() @ w.double().t()) * (hgate[rows] > 0).double() * 1.25
+    assert _rel(dh[rows], dref) < TOL and dslots.max().item() == dh.abs().max().item()
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1024, 256), (777, 256, 1024), (129, 80, 256), (64, 96, 32)])
 def test_fp16x3_forward_form_agrees_with_fp64(M, N, K):
     """The fp16x3 forward kernel (three f16 MFMA terms, both operands pre-scaled from their measured maxima,
