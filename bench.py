@@ -84,7 +84,7 @@ class GemmProbe:
     instantiation with the largest total time = the dominant kernel of the step."""
 
     TILES = {1: "64,64,2,2", 2: "128,128,2,2", 3: "64,128,2,2", 4: "128,96,4,1", 6: "256,256,2,4", 7: "256,128,4,2",
-             8: "256,128,2,2"}
+             8: "256,128,2,2", 9: "wide 256,256,2,2"}
     # name -> (x6?, extractor of (M, N, K) from the C-ABI argument tuple)
     CALLS = {
         "ttts_linear_fwd": (0, lambda a: (a[5], a[6], a[7])),
@@ -112,6 +112,8 @@ class GemmProbe:
             def wrapped(*a, _fn=fn, _x6=x6, _dims=dims):
                 M, N, K = _dims(a)
                 tile = self.lib.ttts_gemm_tile_choice(M, N, K, _x6)
+                if _x6 == 2 and tile == 6 and K >= 96:
+                    tile = 9        # the 256 x 256 tile runs on gemm_h3_wide_kernel (one wave per SIMD) from three k-tiles on
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = _fn(*a)
@@ -142,7 +144,7 @@ class GemmProbe:
         n, ms, fl, nbytes = groups[key]
         x6, tile = key
         name = (f"gemm_f32_kernel<{self.TILES[tile]},true,*>", f"gemm_bf16x6_kernel<{self.TILES[tile]}>",
-                f"gemm_h3_kernel<{self.TILES[tile]}>")[x6]
+                "gemm_h3_wide_kernel" if tile == 9 else f"gemm_h3_kernel<{self.TILES[tile]}>")[x6]
         others = {(f"{('f32', 'bf16x6', 'h3')[k[0]]}<{self.TILES[k[1]]}>"): {"launches": v[0], "total_ms": v[1],
                                                                               "tflops": v[2] / (v[1] * 1e-3) / 1e12}
                   for k, v in groups.items()}

@@ -22,6 +22,8 @@ def short(name):
     if not m:
         return None
     args = m.group(2).replace(" ", "")
+    if m.group(1) == "gemm_h3_wide_kernel":
+        return m.group(1)                              # clipped / unclipped loaders are one line
     if m.group(1) in ("gemm_bf16x6_kernel", "gemm_h3_kernel"):
         args = ",".join(args.split(",")[:4])          # clipped / unclipped loaders of one tile are one line
     if m.group(1) == "gemm_f32_kernel":
