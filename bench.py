@@ -109,11 +109,14 @@ class GemmProbe:
             fn = getattr(self.lib, n)
             self.orig[n] = fn
 
-            def wrapped(*a, _fn=fn, _x6=x6, _dims=dims):
+            def wrapped(*a, _fn=fn, _x6=x6, _dims=dims, _name=n):
+                # unshifted operands only: T > 0 (argument 13 of the linear forward: the go-frame shift) and convolutions go
+                # through the clipping loader of the 8-wave kernel
+                _plain = _name == "ttts_linear_bwd_data_h3" or (_name == "ttts_linear_fwd_h3" and a[13] <= 0)
                 M, N, K = _dims(a)
                 tile = self.lib.ttts_gemm_tile_choice(M, N, K, _x6)
-                if _x6 == 2 and tile == 6 and K >= 96:
-                    tile = 9        # the 256 x 256 tile runs on gemm_h3_wide_kernel (one wave per SIMD) from three k-tiles on
+                if _x6 == 2 and tile == 6 and K >= 96 and _plain:
+                    tile = 9        # unshifted operands on the 256 x 256 tile run on gemm_h3_wide_kernel (one wave per SIMD)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = _fn(*a)

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
 //     epilogue's stores, so waiting for them does not wait for the store burst (vmcnt is one in-order counter).
 // Measured at M = 55 680, K = 256 (s_memtime, tools/h3_stamps.py): main loop 32.7k ticks per tile against 36.7k of the
 // 8-wave kernel (MFMA-bound: 22.1k); K >= 1024 and the convolutions gain 7-9 % per launch.
-// Requires K >= 96 (three k-tiles) and T == 0 or T >= 32.
+// Requires K >= 96 (three k-tiles); dispatched for unshifted operands (T == 0) only, see h3_wide_supports.
 template <bool CLIP>
 __global__ __launch_bounds__(256, 1) void gemm_h3_wide_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256, WM = 2, WN = 2, NT = 256;
@@ -614,13 +614,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h3_wide_kernel(GemmArgs g) {
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int nkt = g.K / HBK;
-    float a_scale, out_scale;
-    {
-        float a_inv, w_scale, w_inv;
-        h3_operand_scale(g.a_amax, g.a_amax_n, lane, a_scale, a_inv);
-        h3_operand_scale(g.b_amax, g.b_amax_n, lane, w_scale, w_inv);      // the planes already carry w_scale
-        out_scale = a_inv * w_inv;
-    }
+    float a_scale = 1.f, out_scale = 1.f;          // set once the first k-tile has been requested (below)
     const int nx = (g.N + BN - 1) / BN;
     const int ntiles = nx * ((g.M + BM - 1) / BM);
 #ifdef TTTS_EXP_STAMPS
@@ -778,6 +772,13 @@ __global__ __launch_bounds__(256, 1) void gemm_h3_wide_kernel(GemmArgs g) {
 #pragma unroll
     for (int w = 0; w < 2 * NLB; ++w) load_b_piece(w);
     advance_b();
+    {   // the operands' measured maxima -> power-of-two scales: read while the first k-tile is on its way (1024 floats from L2
+        // and a wave reduction: ~1.5 us that used to sit in front of the first load of every launch)
+        float a_inv, w_scale, w_inv;
+        h3_operand_scale(g.a_amax, g.a_amax_n, lane, a_scale, a_inv);
+        h3_operand_scale(g.b_amax, g.b_amax_n, lane, w_scale, w_inv);      // the planes already carry w_scale
+        out_scale = a_inv * w_inv;
+    }
 #pragma unroll
     for (int i = 0; i < NLA; ++i) { split_a_half(0, i, 0); split_a_half(0, i, 1); }
 #pragma unroll
@@ -835,15 +836,15 @@ static int launch_h3(const GemmArgs& g, hipStream_t stream) {
     return TTTS_OK;
 }
 
-static bool h3_wide_supports(const GemmArgs& g) { return g.K >= 3 * HBK && (g.T <= 0 || g.T >= 32); }
+// (row-shifted / utterance-clipped operands -- convolutions, the go-frame shift -- stay on the 8-wave kernel: with the clip
+// arithmetic and the BatchNorm-partials epilogue the 512-register kernel spills, and measured in the step its convolution
+// launches took 124.7 us against 119.7)
+static bool h3_wide_supports(const GemmArgs& g) { return g.K >= 3 * HBK && g.T <= 0; }
 
 static int launch_h3_wide(const GemmArgs& g, hipStream_t stream) {
     const long ntiles = (long)cdiv(g.N, 256) * cdiv(g.M, 256);
     dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256), 1, 1);                // one workgroup per CU
-    if (g.T > 0)
-        hipLaunchKernelGGL((gemm_h3_wide_kernel<true>), grid, dim3(256), 0, stream, g);
-    else
-        hipLaunchKernelGGL((gemm_h3_wide_kernel<false>), grid, dim3(256), 0, stream, g);
+    hipLaunchKernelGGL((gemm_h3_wide_kernel<false>), grid, dim3(256), 0, stream, g);
     TTTS_LAUNCH_CHECK("gemm_h3_wide_kernel");
     return TTTS_OK;
 }
