@@ -123,6 +123,11 @@ int ttts_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db
  * Every such array has TTTS_AMAX_SLOTS floats.  Arrays named `*_amax_out` are filled with slot-wise atomic maxima and must
  * be zeroed by the caller first (ttts_zero); only ttts_amax_partials writes its array in full. */
 size_t ttts_split_bytes(int64_t rows, int64_t cols);
+/* bytes of the image ttts_weight_split writes in `mode`.  Modes 4-7 (fp16x3) pad the channels of a tap -- all columns of a
+ * linear weight -- with zeros to the next multiple of 32, so that the 32-deep k-tiles of the GEMM never straddle a tap; a
+ * channel count that is no multiple of 32 (the 80-channel mel side) therefore needs no other kernel: the loader reads the
+ * activation row's neighbour against zero weight columns.  Channel counts must be multiples of 4. */
+size_t ttts_split_image_bytes(int64_t rows, int64_t cols, int mode, int channels_per_tap, int taps);
 /* tile shape the forward / data-gradient dispatch uses for an M x N output with reduction length K (1: 64x64, 2: 128x128,
  * 3: 64x128, 4: 128x96; fp16x3 only: 6: 256x256 / 8 waves, 7: 256x128 / 8 waves, 8: 256x128 / 4 waves, two workgroups per
  * CU); x6 = 0: fp32-MFMA kernel, 1: bf16x6 kernel, 2: fp16x3 kernel.  A profiling aid (bench.py attributes launches). */

@@ -93,6 +93,14 @@ def test_fp16x3_one_wave_per_simd_tile_streams_across_tiles(M, N, K):
     assert torch.equal(y, y2)
     assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), _p(res), _p(y), M, N, K, 0, 0.0, 0, None, 0, 0, _p(xa), None, _stream()) == 0
     assert _rel(y[rows], ref + res[rows].double()) < TOL
+    # dropout: the counter-based mask of the bf16x6 kernel, element for element
+    y6 = torch.empty(M, N, device=_dev())
+    assert lib.ttts_linear_fwd_h3(_p(x), _p(pl), _p(b), None, _p(y), M, N, K, 0, 0.3, 4321, None, 0, 0, _p(xa), None, _stream()) == 0
+    assert lib.ttts_linear_fwd_x6(_p(x), _p(ops._planes(w, 0, N, K)), _p(b), None, _p(y6), M, N, K, 0, 0.3, 4321, None, 0, 0, _stream()) == 0
+    differ = (y == 0) != (y6 == 0)              # the same mask; a sum that cancels to exactly 0 in one form only is no mask bit
+    assert int(differ.sum()) <= 8 and float(torch.maximum(y.abs(), y6.abs())[differ].max() if differ.any() else 0.0) < 1e-5
+    assert abs(float((y == 0).float().mean()) - 0.3) < 1e-3 and _rel(y[rows], y6[rows]) < TOL
+    del y6, differ
     # data gradient of the same layer: dy (M x N) . W -> dx (M x K) is a K-wide output; the gated form through W^T instead:
     # dh (M x K2) = dy2 (M x K) . Wt with the relu gate of h -- an N-wide output with the gate operand read in the epilogue
     dy2 = _rand(M, K, seed=15) * 1e-5
@@ -106,7 +114,8 @@ def test_fp16x3_one_wave_per_simd_tile_streams_across_tiles(M, N, K):
     assert _rel(dh[rows], dref) < TOL and dslots.max().item() == dh.abs().max().item()
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1024, 256), (777, 256, 1024), (129, 80, 256), (64, 96, 32)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1024, 256), (777, 256, 1024), (129, 80, 256), (64, 96, 32), (530, 256, 80),
+                                   (70, 64, 48)])
 def test_fp16x3_forward_form_agrees_with_fp64(M, N, K):
     """The fp16x3 forward kernel (three f16 MFMA terms, both operands pre-scaled from their measured maxima,
     csrc/gemm_h3.hip) against fp64: same gate as the bf16x6 and fp32-MFMA forms, with every epilogue (bias, relu, residual,
@@ -173,7 +182,7 @@ def test_fp16x3_forward_form_agrees_with_fp64(M, N, K):
     assert _rel(y, b.double().expand(M, N)) < TOL
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1024, 256), (777, 256, 1024), (129, 96, 80)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1024, 256), (777, 256, 1024), (129, 96, 80), (530, 80, 256), (70, 20, 64)])
 @pytest.mark.parametrize("mag", [1.0, 3e-7, 1e-12, 1e6])
 def test_fp16x3_data_gradient_with_dynamic_scale(M, N, K, mag):
     """dx = dy . w in the fp16x3 form for gradients of ANY magnitude (3e-7 is what a mean-reduced loss produces): the
@@ -260,7 +269,8 @@ def test_fp16x3_conv_weight_gradient(B, T, cin, cout):
     assert _rel(dw, wd.grad) < TOL and _rel(db, bd.grad) < TOL, (_rel(dw, wd.grad), _rel(db, bd.grad))
 
 
-@pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128), (4, 33, 80, 64)])
+@pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128), (4, 33, 80, 64), (6, 41, 512, 80),
+                                          (3, 870, 256, 80), (2, 9, 64, 20)])
 def test_fp16x3_conv_data_gradient(B, T, cin, cout):
     from transformertts_amd import _lib, ops
     from transformertts_amd.ops import _p, _stream
@@ -276,7 +286,8 @@ def test_fp16x3_conv_data_gradient(B, T, cin, cout):
     assert _rel(dx, xd.grad) < TOL, _rel(dx, xd.grad)
 
 
-@pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128), (4, 33, 64, 80)])
+@pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128), (4, 33, 64, 80), (6, 41, 80, 512),
+                                          (3, 870, 80, 256), (2, 9, 20, 64)])
 def test_fp16x3_conv_forward_agrees_with_fp64(B, T, cin, cout):
     from transformertts_amd import _lib, ops
     from transformertts_amd.ops import _p, _stream
@@ -365,10 +376,15 @@ def test_weight_split_batched_equals_single():
              (_rand(64, 32, 5, seed=3), 64, 160, 2, 32, 5), (_rand(64, 32, 5, seed=4), 32, 320, 3, 64, 5),
              # fp16x3 images: two f16 planes + a tail holding max|w| (the pre-scale follows from it)
              (_rand(256, 128, seed=5) * 40.0, 256, 128, 4, 0, 0), (_rand(256, 128, seed=6) * 1e-5, 128, 256, 5, 0, 0),
-             (_rand(64, 32, 5, seed=7), 64, 160, 6, 32, 5), (_rand(64, 64, 5, seed=8), 64, 320, 7, 64, 5)]
+             (_rand(64, 32, 5, seed=7), 64, 160, 6, 32, 5), (_rand(64, 64, 5, seed=8), 64, 320, 7, 64, 5),
+             # channel counts that are no multiple of 32: the image pads every tap (every row of a linear weight) with zeros
+             (_rand(256, 80, seed=9), 256, 80, 4, 0, 0), (_rand(80, 256, seed=10), 256, 80, 5, 0, 0),
+             (_rand(64, 80, 5, seed=11), 64, 400, 6, 80, 5), (_rand(80, 64, 5, seed=12), 64, 400, 7, 80, 5)]
     single, batched, rows, blk = [], [], [], 0
     for w, R, C, mode, c2, taps in specs:
-        a = torch.zeros(3 * R * C, dtype=torch.int16, device=_dev())
+        nbytes = lib.ttts_split_image_bytes(R, C, mode, c2, taps)
+        assert nbytes == (6 * R * C if mode < 4 else 4 * R * (taps * ((c2 + 31) // 32 * 32) if mode >= 6 else (C + 31) // 32 * 32) + 16)
+        a = torch.full(((nbytes + 1) // 2,), 0x7e00, dtype=torch.int16, device=_dev())      # (f16 NaN: the padding must be WRITTEN)
         b = torch.zeros_like(a)
         assert lib.ttts_weight_split(_p(w), _p(a), R, C, mode, c2, taps, _stream()) == 0
         single.append(a); batched.append(b)
@@ -394,6 +410,16 @@ def test_weight_split_batched_equals_single():
     pl = img[: 2 * R * C].view(torch.float16).view(C // 32, 2, R, 32).double().sum(1).permute(1, 0, 2).reshape(R, C)
     assert 2048.0 <= tail.item() * sc < 4096.0
     assert (pl / sc - w.double()).abs().max().item() <= 2.0 ** -21 * w.abs().max().item()
+    # padded images: conv (cout 64, cin 80, 5 taps) -> [5 * 96 / 32][2][64][32]; channels 80..95 of every tap are exact zeros
+    w, R = specs[10][0], 64
+    img = single[10]
+    Cp = 5 * 96
+    tail = img.view(torch.uint8)[R * Cp * 4: R * Cp * 4 + 4].view(torch.float32)
+    assert tail.item() == w.abs().max().item()
+    sc = 2.0 ** (11 - int(np.floor(np.log2(tail.item()))))
+    pl = img[: 2 * R * Cp].view(torch.float16).view(Cp // 32, 2, R, 32).double().sum(1).permute(1, 0, 2).reshape(R, 5, 96)
+    assert torch.equal(pl[:, :, 80:], torch.zeros_like(pl[:, :, 80:]))
+    assert (pl[:, :, :80] / sc - w.double().permute(0, 2, 1)).abs().max().item() <= 2.0 ** -21 * w.abs().max().item()
 
 
 @pytest.mark.parametrize("causal,Tq,Tk,lens", [(1, 200, 200, [200, 131, 64]), (0, 150, 70, [70, 33, 1]), (0, 33, 129, [129, 128, 5])])

@@ -27,6 +27,7 @@ SIGNATURES = {
     "ttts_wgrad_workspace_bytes": (Z, [L, I, I, I]),
     "ttts_linear_bwd_weight": (I, [P, P, P, P, P, Z, L, I, I, I, I, I, P, P]),
     "ttts_split_bytes": (Z, [L, L]),
+    "ttts_split_image_bytes": (Z, [L, L, I, I, I]),
     "ttts_gemm_tile_choice": (I, [L, I, I, I]),
     "ttts_weight_split": (I, [P, P, I, I, I, I, I, P]),
     "ttts_weight_split_batched": (I, [P, I, L, P]),

@@ -432,7 +432,9 @@ __device__ __forceinline__ const long* batched_desc(const long* __restrict__ des
 __global__ __launch_bounds__(256) void weight_tail_zero_batched_kernel(const long* __restrict__ descs, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const long* d = descs + i * 8;
-        if (d[4] >= 4) *reinterpret_cast<float*>(reinterpret_cast<char*>(d[1]) + h3_plane_bytes(d[2], d[3])) = 0.f;
+        if (d[4] >= 4)
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(d[1]) +
+                                      h3_plane_bytes(d[2], h3_image_cols(d[3], d[4] >= 6 ? (int)d[5] : 0, d[4] >= 6 ? (int)d[6] : 0))) = 0.f;
     }
 }
 __global__ __launch_bounds__(64) void weight_amax_batched_kernel(const long* __restrict__ descs, int n) {
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(64) void weight_amax_batched_kernel(const long* __r
     const long* d = batched_desc(descs, n, blk);
     if (d[4] >= 4)
         weight_amax_h3_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
-                           (blk - d[7]) * 256);
+                           h3_image_cols(d[3], d[4] >= 6 ? (int)d[5] : 0, d[4] >= 6 ? (int)d[6] : 0), (blk - d[7]) * 256);
 }
 
 __global__ __launch_bounds__(256) void weight_split_batched_kernel(const long* __restrict__ descs, int n) {
@@ -1200,16 +1202,26 @@ int ttts_gemm_tile_choice(int64_t M, int N, int K, int x6) {
 
 size_t ttts_split_bytes(int64_t rows, int64_t cols) { return (size_t)3 * (size_t)rows * (size_t)cols * 2; }
 
+size_t ttts_split_image_bytes(int64_t rows, int64_t cols, int mode, int channels_per_tap, int taps) {
+    // bytes of the image ttts_weight_split writes in `mode`: three bf16 planes (modes 0-3), or two f16 planes of the
+    // channel-padded image plus the 16-byte tail (modes 4-7)
+    if (mode < 4) return ttts_split_bytes(rows, cols);
+    const bool conv = (mode & 3) >= 2;
+    return h3_plane_bytes(rows, h3_image_cols(cols, conv ? channels_per_tap : 0, conv ? taps : 0)) + 16;
+}
+
 int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode, int channels_per_tap, int taps,
                       void* stream) {
     // planes[3][rows][cols] bf16 (hi, mid, lo) of a weight re-laid as the K-contiguous B operand; modes in gemm.hip
     TTTS_REQUIRE(w && planes && rows > 0 && cols > 0, "weight_split: bad arguments");
     TTTS_REQUIRE(mode >= 0 && mode <= 7, "weight_split: mode must be 0..7");
-    TTTS_REQUIRE(cols % (mode >= 4 ? HBK : BK) == 0, "weight_split: cols=%d must be a multiple of %d", cols, mode >= 4 ? HBK : BK);
+    TTTS_REQUIRE(cols % (mode >= 4 ? 4 : BK) == 0, "weight_split: cols=%d must be a multiple of %d", cols, mode >= 4 ? 4 : BK);
     TTTS_REQUIRE((mode & 3) < 2 || (channels_per_tap > 0 && taps > 0 && cols == channels_per_tap * taps),
                  "weight_split: conv modes need cols == channels_per_tap * taps");
     if (mode >= 4) {
-        TTTS_REQUIRE((mode & 3) < 2 || channels_per_tap % HBK == 0, "weight_split: fp16x3 conv image needs channels %% 32 == 0");
+        // (the fp16x3 image pads the channels of a tap -- all columns of a linear weight -- to a multiple of 32 with zeros:
+        // size it with ttts_split_image_bytes)
+        TTTS_REQUIRE((mode & 3) < 2 || channels_per_tap % 4 == 0, "weight_split: fp16x3 conv image needs channels %% 4 == 0");
         launch_weight_split_h3(w, planes, rows, cols, mode - 4, channels_per_tap, taps, (hipStream_t)stream);
         TTTS_LAUNCH_CHECK("weight_split_h3_kernel");
         return TTTS_OK;
@@ -1261,45 +1273,49 @@ int ttts_linear_fwd_h3(const float* x, const void* w_planes, const float* bias, 
                        int T, const float* x_amax, float* y_amax_out, void* stream) {
     TTTS_REQUIRE(x && w_planes && y && x_amax, "linear_fwd_h3: null pointer (x_amax, the partial maxima of |x|, is required)");
     TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_fwd_h3: bad dims");
-    TTTS_REQUIRE(K % HBK == 0 && N % 4 == 0, "linear_fwd_h3: K=%d must be a multiple of %d and N=%d of 4", K, HBK, N);
+    TTTS_REQUIRE(K % 4 == 0 && N % 4 == 0, "linear_fwd_h3: K=%d and N=%d must be multiples of 4", K, N);
     TTTS_REQUIRE(aligned16(x) && aligned16(w_planes), "linear_fwd_h3: x / planes must be 16-byte aligned");
     TTTS_REQUIRE(act == 0 || act == 1, "linear_fwd_h3: act must be 0 (none) or 1 (relu)");
     TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "linear_fwd_h3: dropout p out of [0,1)");
     TTTS_REQUIRE(row_shift == 0 || (T > 0 && M % T == 0), "linear_fwd_h3: row_shift needs T>0 and M %% T == 0");
     TTTS_REQUIRE((uint64_t)M * K * 4 < (1ull << 32) && (uint64_t)N * K * 4 < (1ull << 32), "linear_fwd_h3: operand larger than 4 GiB");
     GemmArgs g = base_args();
-    g.A = x; g.B = (const float*)w_planes; g.C = y; g.M = (int)M; g.N = N; g.K = K;
-    g.lda = K; g.ldb = K; g.ldc = N;
-    g.a_bytes = (uint32_t)((uint64_t)M * K * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 4);
-    g.cin = K; g.shift0 = row_shift; g.T = (row_shift != 0) ? T : 0;
+    // (K is padded to the image's 32-deep k-tiles: the loader reads up to 28 floats past a row's end -- the next row, or
+    // zeros past the buffer -- against zero weight columns)
+    const int Kp = h3_pad32(K);
+    g.A = x; g.B = (const float*)w_planes; g.C = y; g.M = (int)M; g.N = N; g.K = Kp;
+    g.lda = K; g.ldb = Kp; g.ldc = N;
+    g.a_bytes = (uint32_t)((uint64_t)M * K * 4); g.b_bytes = (uint32_t)((uint64_t)N * Kp * 4);
+    g.cin = Kp; g.shift0 = row_shift; g.T = (row_shift != 0) ? T : 0;
     g.bias = bias; g.act = act;
     if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; g.step_seed = step_seed; }
     g.residual = residual; g.ldr = N;
     g.a_amax = x_amax; g.a_amax_n = H3_AMAX_PARTIALS;
-    g.b_amax = h3_plane_tail(w_planes, N, K); g.b_amax_n = 1;
+    g.b_amax = h3_plane_tail(w_planes, N, Kp); g.b_amax_n = 1;
     g.c_amax = y_amax_out;
     return dispatch_h3(g, (hipStream_t)stream);
 }
 
 int ttts_conv1d_fwd_h3_bn_blocks(int B, int T, int cin, int cout, int taps) {
-    return h3_bn_blocks((long)B * T, cout, (long)taps * cin);
+    return h3_bn_blocks((long)B * T, cout, (long)taps * h3_pad32(cin));
 }
 
 int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
                        int taps, const float* x_amax, float* bn_partials, void* stream) {
     TTTS_REQUIRE(x && planes_fwd && y && x_amax, "conv1d_fwd_h3: null pointer (x_amax, the partial maxima of |x|, is required)");
     TTTS_REQUIRE(B > 0 && T > 0 && cin > 0 && cout > 0 && taps > 0 && (taps & 1), "conv1d_fwd_h3: bad dims");
-    TTTS_REQUIRE(cin % HBK == 0 && cout % 4 == 0, "conv1d_fwd_h3: cin=%d must be a multiple of %d and cout=%d of 4", cin, HBK, cout);
+    TTTS_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "conv1d_fwd_h3: cin=%d and cout=%d must be multiples of 4", cin, cout);
     TTTS_REQUIRE((uint64_t)B * T * cin * 4 < (1ull << 32), "conv1d_fwd_h3: activation larger than 4 GiB");
     TTTS_REQUIRE(aligned16(x) && aligned16(planes_fwd), "conv1d_fwd_h3: pointers must be 16-byte aligned");
     GemmArgs g = base_args();
-    g.A = x; g.B = (const float*)planes_fwd; g.C = y; g.M = B * T; g.N = cout; g.K = taps * cin;
-    g.lda = cin; g.ldb = (long)taps * cin; g.ldc = cout;
-    g.a_bytes = (uint32_t)((uint64_t)B * T * cin * 4); g.b_bytes = (uint32_t)((uint64_t)cout * taps * cin * 4);
-    g.T = T; g.cin = cin; g.shift0 = -((taps - 1) / 2); g.shift_step = 1;
+    const int cinp = h3_pad32(cin);                  // channels per tap of the padded image (see ttts_linear_fwd_h3)
+    g.A = x; g.B = (const float*)planes_fwd; g.C = y; g.M = B * T; g.N = cout; g.K = taps * cinp;
+    g.lda = cin; g.ldb = (long)taps * cinp; g.ldc = cout;
+    g.a_bytes = (uint32_t)((uint64_t)B * T * cin * 4); g.b_bytes = (uint32_t)((uint64_t)cout * taps * cinp * 4);
+    g.T = T; g.cin = cinp; g.shift0 = -((taps - 1) / 2); g.shift_step = 1;
     g.bias = bias;
     g.a_amax = x_amax; g.a_amax_n = H3_AMAX_PARTIALS;
-    g.b_amax = h3_plane_tail(planes_fwd, cout, (long)taps * cin); g.b_amax_n = 1;
+    g.b_amax = h3_plane_tail(planes_fwd, cout, (long)taps * cinp); g.b_amax_n = 1;
     TTTS_REQUIRE(bn_partials == nullptr || (((uintptr_t)bn_partials) & 15) == 0, "conv1d_fwd_h3: bn_partials must be 16-byte aligned");
     g.bn_ws = bn_partials;
     return dispatch_h3(g, (hipStream_t)stream);
@@ -1312,17 +1328,18 @@ int ttts_linear_bwd_data_h3(const float* dy, const void* wt_planes, const float*
     // dy_amax = the partial maxima of |dy| written by ttts_amax_partials (the dynamic pre-scale of the gradient operand)
     TTTS_REQUIRE(dy && wt_planes && dx && dy_amax, "linear_bwd_data_h3: null pointer");
     TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_bwd_data_h3: bad dims");
-    TTTS_REQUIRE(N % HBK == 0 && K % 4 == 0, "linear_bwd_data_h3: N=%d must be a multiple of %d and K=%d of 4", N, HBK, K);
+    TTTS_REQUIRE(N % 4 == 0 && K % 4 == 0, "linear_bwd_data_h3: N=%d and K=%d must be multiples of 4", N, K);
     TTTS_REQUIRE(aligned16(dy) && aligned16(wt_planes), "linear_bwd_data_h3: pointers must be 16-byte aligned");
     TTTS_REQUIRE((uint64_t)M * N * 4 < (1ull << 32) && (uint64_t)N * K * 4 < (1ull << 32), "linear_bwd_data_h3: operand larger than 4 GiB");
     GemmArgs g = base_args();
-    g.A = dy; g.B = (const float*)wt_planes; g.C = dx; g.M = (int)M; g.N = K; g.K = N;
-    g.lda = N; g.ldb = N; g.ldc = K; g.cin = N;
-    g.a_bytes = (uint32_t)((uint64_t)M * N * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 4);
+    const int Np = h3_pad32(N);                      // reduction depth of the padded image (see ttts_linear_fwd_h3)
+    g.A = dy; g.B = (const float*)wt_planes; g.C = dx; g.M = (int)M; g.N = K; g.K = Np;
+    g.lda = N; g.ldb = Np; g.ldc = K; g.cin = Np;
+    g.a_bytes = (uint32_t)((uint64_t)M * N * 4); g.b_bytes = (uint32_t)((uint64_t)Np * K * 4);
     g.residual = residual; g.ldr = K;
     g.relu_out = relu_out; g.relu_scale = relu_scale;
     g.a_amax = dy_amax; g.a_amax_n = H3_AMAX_PARTIALS;
-    g.b_amax = h3_plane_tail(wt_planes, K, N); g.b_amax_n = 1;
+    g.b_amax = h3_plane_tail(wt_planes, K, Np); g.b_amax_n = 1;
     g.c_amax = dx_amax_out;
     return dispatch_h3(g, (hipStream_t)stream);
 }
@@ -1331,16 +1348,17 @@ int ttts_conv1d_bwd_data_h3(const float* dy, const void* planes_bwd, float* dx, 
                             const float* dy_amax, void* stream) {
     TTTS_REQUIRE(dy && planes_bwd && dx && dy_amax, "conv1d_bwd_data_h3: null pointer");
     TTTS_REQUIRE(B > 0 && T > 0 && cin > 0 && cout > 0 && taps > 0 && (taps & 1), "conv1d_bwd_data_h3: bad dims");
-    TTTS_REQUIRE(cout % HBK == 0 && cin % 4 == 0, "conv1d_bwd_data_h3: cout=%d must be a multiple of %d and cin=%d of 4", cout, HBK, cin);
+    TTTS_REQUIRE(cout % 4 == 0 && cin % 4 == 0, "conv1d_bwd_data_h3: cout=%d and cin=%d must be multiples of 4", cout, cin);
     TTTS_REQUIRE((uint64_t)B * T * cout * 4 < (1ull << 32), "conv1d_bwd_data_h3: activation larger than 4 GiB");
     TTTS_REQUIRE(aligned16(dy) && aligned16(planes_bwd), "conv1d_bwd_data_h3: pointers must be 16-byte aligned");
     GemmArgs g = base_args();
-    g.A = dy; g.B = (const float*)planes_bwd; g.C = dx; g.M = B * T; g.N = cin; g.K = taps * cout;
-    g.lda = cout; g.ldb = (long)taps * cout; g.ldc = cin;
-    g.a_bytes = (uint32_t)((uint64_t)B * T * cout * 4); g.b_bytes = (uint32_t)((uint64_t)cin * taps * cout * 4);
-    g.T = T; g.cin = cout; g.shift0 = (taps - 1) / 2; g.shift_step = -1;
+    const int coutp = h3_pad32(cout);                // channels per tap of the padded image (see ttts_linear_fwd_h3)
+    g.A = dy; g.B = (const float*)planes_bwd; g.C = dx; g.M = B * T; g.N = cin; g.K = taps * coutp;
+    g.lda = cout; g.ldb = (long)taps * coutp; g.ldc = cin;
+    g.a_bytes = (uint32_t)((uint64_t)B * T * cout * 4); g.b_bytes = (uint32_t)((uint64_t)cin * taps * coutp * 4);
+    g.T = T; g.cin = coutp; g.shift0 = (taps - 1) / 2; g.shift_step = -1;
     g.a_amax = dy_amax; g.a_amax_n = H3_AMAX_PARTIALS;
-    g.b_amax = h3_plane_tail(planes_bwd, cin, (long)taps * cout); g.b_amax_n = 1;
+    g.b_amax = h3_plane_tail(planes_bwd, cin, (long)taps * coutp); g.b_amax_n = 1;
     return dispatch_h3(g, (hipStream_t)stream);
 }
 

@@ -80,9 +80,16 @@ constexpr int H3_AMAX_PARTIALS = TTTS_AMAX_SLOTS;  // length of every partial-ma
 
 // byte size of the fp16x3 image of a rows x cols weight: two f16 planes, then a 16-byte tail whose first float is max|w|
 // (written by the split, read by every GEMM that takes the planes: the scale the planes were written with follows from it)
-__host__ __device__ __forceinline__ size_t h3_plane_bytes(long rows, long cols) { return (size_t)rows * cols * 4; }
-__host__ __device__ __forceinline__ const float* h3_plane_tail(const void* planes, long rows, long cols) {
-    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(planes) + h3_plane_bytes(rows, cols));
+// The image is cut in 32-deep k-tiles that must not straddle a convolution tap, so the channels of a tap (all `cols` of a
+// linear weight) are PADDED with zeros to the next multiple of 32: the 80-channel mel side runs as 96 channels whose last
+// 16 multiply whatever the activation row's neighbour holds by zero (h3_image_cols = the padded column count).
+__host__ __device__ __forceinline__ int h3_pad32(int c) { return (c + HBK - 1) / HBK * HBK; }
+__host__ __device__ __forceinline__ long h3_image_cols(long cols, int c2, int taps) {
+    return (c2 > 0 && taps > 0) ? (long)taps * h3_pad32(c2) : (long)h3_pad32((int)cols);
+}
+__host__ __device__ __forceinline__ size_t h3_plane_bytes(long rows, long image_cols) { return (size_t)rows * image_cols * 4; }
+__host__ __device__ __forceinline__ const float* h3_plane_tail(const void* planes, long rows, long image_cols) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(planes) + h3_plane_bytes(rows, image_cols));
 }
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -100,7 +107,7 @@ __device__ __forceinline__ void split2_pair(f32x2 x, uint32_t& hi, uint32_t& lo)
 // Called by ONE wave per 256 elements (blockDim 64): a float4 per lane, a wave reduction, and a look at the tail before the
 // atomic -- every wave of a weight aims at the same word, and after the first few arrivals almost none has anything to add.
 __device__ __forceinline__ void weight_amax_h3_one(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
-                                                   int C, long i0) {
+                                                   int C, long image_cols, long i0) {
     const long n = (long)R * C;
     const long i = i0 + 4 * (long)(threadIdx.x & 63);
     float m = 0.f;
@@ -114,34 +121,45 @@ __device__ __forceinline__ void weight_amax_h3_one(const float* __restrict__ w, 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.f) {
-        unsigned int* tail = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(planes) + h3_plane_bytes(R, C));
+        unsigned int* tail = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(planes) + h3_plane_bytes(R, image_cols));
         if (__float_as_uint(m) > __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(tail, __float_as_uint(m));
     }
 }
 
-// B[r][c] of weight_split (gemm.hip) as two f16 planes of w * scale, stored [c/32][plane][r][c%32]; scale = the power of two
-// of h3_pow2_scale(max|w|), max|w| read from the tail (weight_amax_h3_one has run)
+// B[r][c] of weight_split (gemm.hip) as two f16 planes of w * scale, stored [c'/32][plane][r][c'%32] with c' = the column
+// in the padded image (tap * pad32(c2) + channel; c for a linear weight); scale = the power of two of h3_pow2_scale(max|w|),
+// max|w| read from the tail (weight_amax_h3_one has run).  Thread i takes SOURCE element i; the thread of a tap's last
+// channel also writes that tap's zero padding.
 __device__ __forceinline__ void weight_split_h3_one(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
                                                     int C, int mode, int c2, int taps, long i) {
     const long n = (long)R * C;
     if (i >= n) return;
+    const long Cp = h3_image_cols(C, mode >= 2 ? c2 : 0, mode >= 2 ? taps : 0);
     float w_scale, w_inv;
-    h3_pow2_scale(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(planes) + h3_plane_bytes(R, C)), w_scale, w_inv);
+    h3_pow2_scale(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(planes) + h3_plane_bytes(R, Cp)), w_scale, w_inv);
     const int r = (int)(i / C), c = (int)(i % C);
     float v;
+    int cp = c, npad = 0;                                   // column in the padded image; zeros to write behind it
     if (mode == 0) v = w[i];
     else if (mode == 1) v = w[(long)c * R + r];
     else {
         const int tap = c / c2, ch = c % c2;
         if (mode == 2) v = w[((long)r * c2 + ch) * taps + tap];
         else v = w[((long)ch * R + r) * taps + tap];
+        cp = tap * h3_pad32(c2) + ch;
+        if (ch == c2 - 1) npad = h3_pad32(c2) - c2;
     }
+    if (mode < 2 && c == C - 1) npad = (int)(Cp - C);
     v *= w_scale;
     const _Float16 h = (_Float16)v;
     const _Float16 l = (_Float16)(v - (float)h);
-    const long o = ((long)(c >> 5) * 2 * R + r) * 32 + (c & 31);
+    const long o = ((long)(cp >> 5) * 2 * R + r) * 32 + (cp & 31);
     planes[o] = __builtin_bit_cast(unsigned short, h);
     planes[o + (long)R * 32] = __builtin_bit_cast(unsigned short, l);
+    for (int e = 1; e <= npad; ++e) {                       // (cp + e stays inside the k-tile of cp: the pad ends on a multiple of 32)
+        planes[o + e] = 0;
+        planes[o + e + (long)R * 32] = 0;
+    }
 }
 
 enum { TILE_AUTO = 0, TILE_64 = 1, TILE_128 = 2, TILE_64x128 = 3, TILE_128x96 = 4, TILE_96x128 = 5,

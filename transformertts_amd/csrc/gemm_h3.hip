@@ -28,8 +28,8 @@
 namespace ttts {
 
 __global__ __launch_bounds__(64) void weight_amax_h3_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
-                                                            int R, int C) {
-    weight_amax_h3_one(w, planes, R, C, (long)blockIdx.x * 256);
+                                                            int R, int C, long image_cols) {
+    weight_amax_h3_one(w, planes, R, C, image_cols, (long)blockIdx.x * 256);
 }
 __global__ __launch_bounds__(256) void weight_split_h3_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
                                                               int R, int C, int mode, int c2, int taps) {
@@ -39,8 +39,10 @@ __global__ __launch_bounds__(256) void weight_split_h3_kernel(const float* __res
 // tail = 0, max|w| into the tail, then the planes scaled by the power of two that follows from it
 void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, int mode, int c2, int taps, hipStream_t stream) {
     const long n = (long)rows * cols;
-    (void)launch_zero(reinterpret_cast<char*>(planes) + h3_plane_bytes(rows, cols), 16, stream);
-    hipLaunchKernelGGL(weight_amax_h3_kernel, dim3(cdiv(n, 256)), dim3(64), 0, stream, w, (unsigned short*)planes, rows, cols);
+    const long image_cols = h3_image_cols(cols, mode >= 2 ? c2 : 0, mode >= 2 ? taps : 0);
+    (void)launch_zero(reinterpret_cast<char*>(planes) + h3_plane_bytes(rows, image_cols), 16, stream);
+    hipLaunchKernelGGL(weight_amax_h3_kernel, dim3(cdiv(n, 256)), dim3(64), 0, stream, w, (unsigned short*)planes, rows, cols,
+                       image_cols);
     hipLaunchKernelGGL(weight_split_h3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, w, (unsigned short*)planes, rows,
                        cols, mode, c2, taps);
 }
@@ -850,8 +852,9 @@ static int launch_h3_wide(const GemmArgs& g, hipStream_t stream) {
 }
 
 bool h3_supports(const GemmArgs& g) {
-    // 32-deep k-tiles must not straddle a conv tap; B rows are addressed as 64-byte pieces
-    return g.K % HBK == 0 && g.cin % HBK == 0 && g.N % 4 == 0 && (uint64_t)g.N * g.K * 4 < (1ull << 32);
+    // 32-deep k-tiles must not straddle a conv tap (the entry points pad K / cin to the image's, h3_image_cols); B rows are
+    // addressed as 64-byte pieces; activation rows as float4s
+    return g.K % HBK == 0 && g.cin % HBK == 0 && g.N % 4 == 0 && g.lda % 4 == 0 && (uint64_t)g.N * g.K * 4 < (1ull << 32);
 }
 
 

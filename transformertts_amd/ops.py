@@ -139,7 +139,7 @@ ATTN_BWD_MODE = os.environ.get("TTTS_ATTN_BWD_MODE", "h3" if ATTN_MODE == "x6" e
 WGRAD_MODE = os.environ.get("TTTS_WGRAD_MODE", "h3" if GEMM_MODE == "x6" else GEMM_MODE)   # weight gradients: "h3", "x6", "f32"
 # Forward GEMMs (nn.Linear / Conv1d forward) under GEMM_MODE "x6": "h3" = fp16x3 split (three f16 MFMA terms, both operands
 # pre-scaled by powers of two taken from their MEASURED maxima, csrc/gemm_h3.hip -- no magnitude window), "x6" = bf16x6.
-# Shapes the fp16 kernel cannot take (K or channels not a multiple of 32) go to bf16x6.
+# Shapes the fp16 kernel cannot take (K or channels not a multiple of 4) go to bf16x6.
 FWD_MODE = os.environ.get("TTTS_FWD_MODE", "h3")
 
 
@@ -148,12 +148,13 @@ BWD_MODE = os.environ.get("TTTS_BWD_MODE", "h3")
 
 
 def _fwd_h3(K: int, N: int, channels: int = 0) -> bool:
-    """fp16x3 takes reduction depths (and conv channel counts) that are multiples of 32 and output widths % 4 == 0."""
-    return GEMM_MODE == "x6" and FWD_MODE == "h3" and K % 32 == 0 and channels % 32 == 0 and N % 4 == 0
+    """fp16x3 takes reduction depths, conv channel counts and output widths that are multiples of 4 (the weight image pads
+    the channels of a tap to a multiple of 32 with zeros: ttts_split_image_bytes)."""
+    return GEMM_MODE == "x6" and FWD_MODE == "h3" and K % 4 == 0 and channels % 4 == 0 and N % 4 == 0
 
 
 def _bwd_h3(K: int, N: int, channels: int = 0) -> bool:
-    return GEMM_MODE == "x6" and BWD_MODE == "h3" and K % 32 == 0 and channels % 32 == 0 and N % 4 == 0
+    return GEMM_MODE == "x6" and BWD_MODE == "h3" and K % 4 == 0 and channels % 4 == 0 and N % 4 == 0
 
 
 def _amax(t: torch.Tensor) -> torch.Tensor:
@@ -444,10 +445,11 @@ def _planes(w: torch.Tensor, mode: int, rows: int, cols: int, c2: int = 0, taps:
             if ent.tag == tag:
                 return ent.planes
     lib = _lib.load()
-    if ent is None or ent.planes.numel() != 3 * rows * cols or ent.planes.device != w.device:
+    nwords = (int(lib.ttts_split_image_bytes(rows, cols, mode, c2, taps)) + 1) // 2      # (fp16x3 images pad channels to 32)
+    if ent is None or ent.planes.numel() != nwords or ent.planes.device != w.device:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("weight planes must exist before a HIP-graph capture: run the eager warm-up steps first")
-        planes = torch.empty(3 * rows * cols, dtype=torch.int16, device=w.device)
+        planes = torch.empty(nwords, dtype=torch.int16, device=w.device)
     else:
         planes = ent.planes
     _lib.check(lib.ttts_weight_split(_p(w), _p(planes), rows, cols, mode, c2, taps, _stream()), "ttts_weight_split")
