@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes for the self-attention kernels (development aid).  usage: tools/pmc_attn.sh <outdir>   (MODE=h3|x6|f32)
+# PMC passes for the self-attention kernels (development aid).  usage: tools/pmc_attn.sh <outdir>
 out=$1
 mkdir -p $out
 i=0

@@ -23,11 +23,12 @@ def lin(M, N, K):
     dw = torch.empty(N, K, device=dev); db = torch.empty(N, device=dev)
     ws = torch.empty(lib.ttts_wgrad_workspace_bytes(M, N, K, 1) // 4, device=dev)
     out = []
-    am = torch.empty(1024, device=dev)
+    am, xm = torch.empty(1024, device=dev), torch.empty(1024, device=dev)
     lib.ttts_amax_partials(_p(dy), dy.numel(), _p(am), _stream())
+    lib.ttts_amax_partials(_p(x), x.numel(), _p(xm), _stream())
     for name in ("ttts_linear_bwd_weight", "ttts_linear_bwd_weight_x6", "ttts_linear_bwd_weight_h3"):
         f = getattr(lib, name)
-        tail = (_p(am), _stream()) if name.endswith("h3") else (_stream(),)
+        tail = (_p(am), _p(xm), None, _stream()) if name.endswith("h3") else (None, _stream())
         us = timeit(lambda: f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 0, *tail))
         out.append(f"{us:7.1f}us {2.0 * M * N * K / us / 1e6:6.1f}TF")
     print(f"linear M={M} N={N} K={K}:".ljust(36), " | ".join(out))
@@ -39,11 +40,12 @@ def conv(B, T, cin, cout):
     dw = torch.empty(cout, cin, 5, device=dev); db = torch.empty(cout, device=dev)
     ws = torch.empty(lib.ttts_wgrad_workspace_bytes(M, cout, cin, 5) // 4, device=dev)
     out = []
-    am = torch.empty(1024, device=dev)
+    am, xm = torch.empty(1024, device=dev), torch.empty(1024, device=dev)
     lib.ttts_amax_partials(_p(dy), dy.numel(), _p(am), _stream())
+    lib.ttts_amax_partials(_p(x), x.numel(), _p(xm), _stream())
     for name in ("ttts_conv1d_bwd_weight", "ttts_conv1d_bwd_weight_x6", "ttts_conv1d_bwd_weight_h3"):
         f = getattr(lib, name)
-        tail = (_p(am), _stream()) if name.endswith("h3") else (_stream(),)
+        tail = (_p(am), _p(xm), None, _stream()) if name.endswith("h3") else (None, _stream())
         us = timeit(lambda: f(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, B, T, cin, cout, 5, 0, *tail))
         out.append(f"{us:7.1f}us {2.0 * M * cin * cout * 5 / us / 1e6:6.1f}TF")
     print(f"conv B={B} T={T} {cin}->{cout}:".ljust(36), " | ".join(out))

@@ -10,10 +10,10 @@ lib = _lib.load(); dev = torch.device("cuda:0")
 x = torch.randn(M, K, device=dev); dy = torch.randn(M, N, device=dev) * 1e-6
 dw = torch.empty(N, K, device=dev); db = torch.empty(N, device=dev)
 ws = torch.empty(lib.ttts_wgrad_workspace_bytes(M, N, K, 1) // 4, device=dev)
-am = ops._amax(dy)
+am, xm = ops._amax(dy), ops._amax(x)
 for _ in range(reps):
     if form == "h3":
-        lib.ttts_linear_bwd_weight_h3(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 0, _p(am), _stream())
+        lib.ttts_linear_bwd_weight_h3(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 0, _p(am), _p(xm), None, _stream())
     else:
-        lib.ttts_linear_bwd_weight_x6(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 0, _stream())
+        lib.ttts_linear_bwd_weight_x6(_p(dy), _p(x), _p(dw), _p(db), _p(ws), ws.numel() * 4, M, N, K, 0, 0, 0, None, _stream())
 torch.cuda.synchronize()
