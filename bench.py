@@ -478,7 +478,7 @@ def main():
                                            "algorithmic_bytes_per_launch": probe["avg_bytes"],
                                            "bytes_are": "4 * (M*K + M*N + N*K) per launch: activation read, output write, weights"}
             out["roofline"]["gemm_kernels"] = probe["all"]
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # (rank 0 at N = 1 only: the other ranks would wait for it)
             out["cpu_baseline"] = cpu_baseline(cfg, args.tp, args.config)
         print(json.dumps(out), flush=True)
     if world > 1:
