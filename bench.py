@@ -48,12 +48,14 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense
 TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")     # newest first; see tools/collect_traffic.py
 
 
-def measured_traffic(kernel: str):
+def measured_traffic(kernel: str, workload: str = "base_b64"):
     """(HBM bytes per launch of `kernel`, source file) from the committed PMC collection -- separate rocprofv3
     `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command, FETCH_SIZE doubled per the gfx950 note of
     MI355X_MICROARCH.md -- or (None, None).  PMC passes cannot run inside the timed bench, so the figure is a stamped
-    reading of the build named in the file, not of this run."""
-    for name in TRAFFIC_FILES:
+    reading of the build named in the file, not of this run.  A workload other than the default one has its own file
+    (`r03_traffic_<workload>.json`) or no figure: the default workload's bytes per launch are not its bytes."""
+    files = TRAFFIC_FILES if workload == "base_b64" else (f"r03_traffic_{workload}.json",)
+    for name in files:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
@@ -455,7 +457,7 @@ def main():
             # unit that bounds it is the bf16 matrix pipe: its ceiling in algorithmic (fp32-equivalent) FLOP/s is the dense
             # bf16 peak / 6.  `frac` is priced against THAT ceiling; the fp32-MFMA peak (157.3 TF, what a plain
             # v_mfma_f32 kernel is bound by, and the peak of the dtype) is reported beside it as a floor the kernel beats.
-            traffic, traffic_src = measured_traffic(probe["kernel"])
+            traffic, traffic_src = measured_traffic(probe["kernel"], f"{args.config}_b{args.batch}")
             terms = (0, 6, 3)[probe["form"]]
             if terms:
                 peak = PEAK_BF16_MFMA_TFLOPS / terms
