@@ -758,7 +758,12 @@ class HeadsFn(torch.autograd.Function):
         dmel = _chk(dmel, "heads.dmel")
         dstop = _chk(dstop, "heads.dstop")
         dx = torch.empty_like(x)
-        if GEMM_MODE == "x6":
+        dmel_am = None
+        if _bwd_h3(N, K):
+            dmel_am = _amax(dmel)                  # (shared with the weight gradient below)
+            _lib.check(lib.ttts_linear_bwd_data_h3(_p(dmel), _p(_planes(w_mel, 5, K, N)), None, _p(dx), M, N, K, None, 1.0,
+                                                   _p(dmel_am), None, _stream()), "ttts_linear_bwd_data_h3")
+        elif GEMM_MODE == "x6":
             _lib.check(lib.ttts_linear_bwd_data_x6(_p(dmel), _p(_planes(w_mel, 1, K, N)), None, _p(dx), M, N, K, None, 1.0,
                                                    _stream()),
                        "ttts_linear_bwd_data_x6")
@@ -776,7 +781,7 @@ class HeadsFn(torch.autograd.Function):
             t_bm = db_mel = torch.empty(N, dtype=torch.float32, device=x.device)
             t_ws = dw_stop = torch.empty_like(w_stop)
             t_bs = db_stop = torch.empty(1, dtype=torch.float32, device=x.device)
-        _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dmel, None, x, ctx.x_amax, _wgrad_is_split(N, K), _qarg(queue, ws),
+        _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dmel, dmel_am, x, ctx.x_amax, _wgrad_is_split(N, K), _qarg(queue, ws),
                           _p(t_wm), _p(t_bm), _p(ws), ws.numel() * 4, M, N, K, 0, 0, acc), "ttts_linear_bwd_weight")
         _lib.check(lib.ttts_rowdot_bwd(_p(dstop), _p(x), _p(w_stop), _p(dx), _p(t_ws), _p(t_bs), _p(ws2),
                                        ws2.numel() * 4, M, K, acc, _qarg(queue, ws2), _stream()), "ttts_rowdot_bwd")
