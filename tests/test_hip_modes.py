@@ -64,6 +64,47 @@ def test_linear_forms_agree_with_fp64(M, N, K):
         assert rc == 0 and _rel(dw, 2 * dw_ref) < TOL and _rel(db, 2 * db_ref) < TOL
 
 
+def test_fp16x3_gemms_on_random_shapes():
+    """Seeded random shapes through every fp16x3 forward-type entry point (nn.Linear forward / data gradient, Conv1d forward
+    / data gradient): row counts with ragged last tiles, widths and depths that are multiples of 4 but not of 32 (padded
+    weight images), one to seven taps, utterance lengths down to 1 -- each against fp64, whichever tile the dispatch picks."""
+    import random
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    rng = random.Random(20260904)
+    for case in range(24):
+        M = rng.choice([1, 7, 33, 255, 257, 1000, 4099, 20011])
+        N = 4 * rng.randint(1, 130)
+        K = 4 * rng.randint(1, 130)
+        x, w, b = _rand(M, K, seed=case), _rand(N, K, seed=100 + case, scale=K ** -0.5), _rand(N, seed=200 + case)
+        y = torch.full((M, N), float("nan"), device=_dev())
+        assert lib.ttts_linear_fwd_h3(_p(x), _p(ops._planes(w, 4, N, K)), _p(b), None, _p(y), M, N, K, 0, 0.0, 0, None, 0, 0,
+                                      _p(ops._amax(x)), None, _stream()) == 0, (M, N, K)
+        assert _rel(y, x.double() @ w.double().t() + b.double()) < TOL, ("linear fwd", M, N, K)
+        dy = _rand(M, N, seed=300 + case) * 1e-4
+        dx = torch.full((M, K), float("nan"), device=_dev())
+        assert lib.ttts_linear_bwd_data_h3(_p(dy), _p(ops._planes(w, 5, K, N)), None, _p(dx), M, N, K, None, 1.0, _p(ops._amax(dy)),
+                                           None, _stream()) == 0, (M, N, K)
+        assert _rel(dx, dy.double() @ w.double()) < TOL, ("linear dgrad", M, N, K)
+    for case in range(16):
+        B, T = rng.choice([(1, 1), (2, 5), (3, 64), (5, 131), (2, 870)])
+        cin, cout, taps = 4 * rng.randint(1, 70), 4 * rng.randint(1, 70), rng.choice([1, 3, 5, 7])
+        x, w, b = _rand(B, T, cin, seed=case), _rand(cout, cin, taps, seed=400 + case, scale=(taps * cin) ** -0.5), _rand(cout, seed=500 + case)
+        ref = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), b.double(), padding=taps // 2).transpose(1, 2)
+        y = torch.full((B, T, cout), float("nan"), device=_dev())
+        assert lib.ttts_conv1d_fwd_h3(_p(x), _p(ops._planes(w, 6, cout, taps * cin, cin, taps)), _p(b), _p(y), B, T, cin, cout, taps,
+                                      _p(ops._amax(x)), None, _stream()) == 0, (B, T, cin, cout, taps)
+        assert _rel(y, ref) < TOL, ("conv fwd", B, T, cin, cout, taps)
+        dy = _rand(B, T, cout, seed=600 + case) * 1e-4
+        xd = torch.zeros(B, T, cin, dtype=torch.float64, device=_dev(), requires_grad=True)
+        torch.nn.functional.conv1d(xd.transpose(1, 2), w.double(), None, padding=taps // 2).transpose(1, 2).backward(dy.double())
+        dx = torch.full((B, T, cin), float("nan"), device=_dev())
+        assert lib.ttts_conv1d_bwd_data_h3(_p(dy), _p(ops._planes(w, 7, cin, taps * cout, cout, taps)), _p(dx), B, T, cin, cout, taps,
+                                           _p(ops._amax(dy)), _stream()) == 0, (B, T, cin, cout, taps)
+        assert _rel(dx, xd.grad) < TOL, ("conv dgrad", B, T, cin, cout, taps)
+
+
 @pytest.mark.parametrize("M,N,K", [(70001, 768, 96), (66000, 768, 256), (41000, 1024, 128)])
 def test_fp16x3_one_wave_per_simd_tile_streams_across_tiles(M, N, K):
     """Shapes the dispatch gives to gemm_h3_wide_kernel (256 x 256 tile, 4 waves; csrc/gemm_h3.hip) with MORE tiles than
