@@ -125,7 +125,11 @@ class GemmProbe:
                 e1.record()
                 # compulsory HBM bytes of the launch: the activation read once, the output written once, the weights once
                 # (residual / gate operands of some epilogues not counted)
-                self.records.append((e0, e1, 2.0 * M * N * K, (_x6, tile), 4.0 * (M * K + M * N + N * K)))
+                # bytes that cross the CUs' global-memory paths on a 256 x 256 tiling (any form of the 256-wide kernels): every
+                # tile loads its 256 x K activation block and its 256 x K weight block (re-reads come from L2, but through the same
+                # per-CU path) and stores 256 x 256 outputs
+                cu_bytes = (-(-M // 256)) * (-(-N // 256)) * (2.0 * 256 * K * 4) + 4.0 * M * N
+                self.records.append((e0, e1, 2.0 * M * N * K, (_x6, tile), 4.0 * (M * K + M * N + N * K), cu_bytes))
                 return rc
             setattr(self.lib, n, wrapped)
         return self
@@ -137,16 +141,17 @@ class GemmProbe:
     def summary(self):
         torch.cuda.synchronize()
         groups = {}
-        for e0, e1, fl, key, nbytes in self.records:
-            g = groups.setdefault(key, [0, 0.0, 0.0, 0.0])
+        for e0, e1, fl, key, nbytes, cu_bytes in self.records:
+            g = groups.setdefault(key, [0, 0.0, 0.0, 0.0, 0.0])
             g[0] += 1
             g[1] += e0.elapsed_time(e1)
             g[2] += fl
             g[3] += nbytes
+            g[4] += cu_bytes
         if not groups:
             return None
         key = max(groups, key=lambda k: groups[k][1])
-        n, ms, fl, nbytes = groups[key]
+        n, ms, fl, nbytes, cu_bytes = groups[key]
         x6, tile = key
         name = (f"gemm_f32_kernel<{self.TILES[tile]},true,*>", f"gemm_bf16x6_kernel<{self.TILES[tile]}>",
                 "gemm_h3_wide_kernel" if tile == 9 else f"gemm_h3_kernel<{self.TILES[tile]}>")[x6]
@@ -155,7 +160,8 @@ class GemmProbe:
                   for k, v in groups.items()}
         return {"kernel": name, "form": x6, "launches": n, "avg_ms": ms / n, "avg_flops": fl / n,
                 "tflops": fl / (ms * 1e-3) / 1e12, "total_ms": ms, "all": others, "avg_bytes": nbytes / n,
-                "gbps": nbytes / (ms * 1e-3) / 1e9}
+                "gbps": nbytes / (ms * 1e-3) / 1e9, "cu_gbps": cu_bytes / (ms * 1e-3) / 1e9, "avg_cu_bytes": cu_bytes / n,
+                "tile256": tile in (6, 9)}
 
 
 def usable_cores() -> int:
@@ -479,6 +485,17 @@ def main():
                                            "frac": probe["gbps"] / 8000.0,
                                            "algorithmic_bytes_per_launch": probe["avg_bytes"],
                                            "bytes_are": "4 * (M*K + M*N + N*K) per launch: activation read, output write, weights"}
+            if probe["tile256"]:
+                # ... and against the ceiling that actually binds a 256 x 256 tiling at K = 256: a CU's global-memory path streams
+                # ~10 B per cycle (MI355X_MICROARCH.md, cycle constants: `global_load_dwordx4` HBM-bound; 11-13 measured for
+                # mixed / LDS-DMA prologues), and a tile moves 2 * 256 * K * 4 B of operands + 256 KB of output through it
+                # for 2 * 256 * 256 * K * 3 MFMA flops -- 128 flop/B at K = 256, where the matrix pipe would need 407
+                cu_peak = 256 * 10.0 * 2.4
+                out["roofline"]["cu_path_view"] = {"achieved": probe["cu_gbps"], "peak": cu_peak, "unit": "GB/s",
+                                                   "frac": probe["cu_gbps"] / cu_peak,
+                                                   "bytes_per_launch": probe["avg_cu_bytes"],
+                                                   "bytes_are": "per 256 x 256 tile: activation block + weight block loaded, output stored",
+                                                   "peak_is": "256 CUs x ~10 B/cycle/CU x 2.4 GHz (global_load_dwordx4, HBM-bound); L2 hits can exceed it"}
             out["roofline"]["gemm_kernels"] = probe["all"]
         if not args.no_cpu_baseline and world == 1:          # (rank 0 at N = 1 only: the other ranks would wait for it)
             out["cpu_baseline"] = cpu_baseline(cfg, args.tp, args.config)
