@@ -227,6 +227,55 @@ def test_cross_attention(B, H, Tq, Tk, lens):
     assert rel_l2(out2, ref) < TOL and rel_l2(q2.grad, qd.grad) < TOL and rel_l2(kv2.grad, kvd.grad) < TOL
 
 
+def test_attention_on_random_shapes():
+    """Seeded random batch sizes, head counts, lengths (tile edges at 32 / 64 / 128 and ragged key lengths down to 1), causal
+    and not, with and without the returned weights: forward, weights and every gradient against fp64."""
+    import random
+    from transformertts_amd import ops
+    rng = random.Random(20260905)
+    dev = _dev()
+    for case in range(14):
+        B, H = rng.choice([1, 2, 3]), rng.choice([1, 2, 4, 8])
+        T = rng.choice([1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 333])
+        causal = rng.random() < 0.5
+        lens = [T] + [rng.randint(1, T) for _ in range(B - 1)]
+        d = H * 64
+        qkv, do = _rand(B, T, 3 * d, seed=case), _rand(B, T, d, seed=100 + case)
+        lens_t = torch.tensor(lens, dtype=torch.int64)
+        qd = qkv.double().requires_grad_()
+        q, k, v = [t.view(B, T, H, 64).transpose(1, 2) for t in qd.split(d, dim=-1)]
+        ref = _ref_attention(q, k, v, lens_t, causal)[0].transpose(1, 2).reshape(B, T, d)
+        ref.backward(do.double())
+        qg = _g(qkv)
+        out = ops.self_attention(qg, lens_t.to(dev), H, causal, 0.0, 0)
+        out.backward(do.to(dev))
+        assert rel_l2(out, ref) < TOL and rel_l2(qg.grad, qd.grad) < TOL, ("self", B, H, T, causal, lens)
+    for case in range(12):
+        B, H = rng.choice([1, 2, 3]), rng.choice([1, 2, 4])
+        Tq, Tk = rng.choice([1, 33, 64, 130, 257]), rng.choice([1, 17, 64, 100, 129, 190])
+        lens = [Tk] + [rng.randint(1, Tk) for _ in range(B - 1)]
+        d = H * 64
+        q_, kv_, do = _rand(B, Tq, d, seed=200 + case), _rand(B, Tk, 2 * d, seed=300 + case), _rand(B, Tq, d, seed=400 + case)
+        lens_t = torch.tensor(lens, dtype=torch.int64)
+        qd, kvd = q_.double().requires_grad_(), kv_.double().requires_grad_()
+        qq = qd.view(B, Tq, H, 64).transpose(1, 2)
+        kk, vv = [t.view(B, Tk, H, 64).transpose(1, 2) for t in kvd.split(d, dim=-1)]
+        o, a = _ref_attention(qq, kk, vv, lens_t, False)
+        ref = o.transpose(1, 2).reshape(B, Tq, d)
+        ref.backward(do.double())
+        for need_w in (True, False):
+            qg, kvg = _g(q_), _g(kv_)
+            out, attn = ops.cross_attention(qg, kvg, lens_t.to(dev), H, 0.0, 0, need_w)
+            out.backward(do.to(dev))
+            assert rel_l2(out, ref) < TOL and rel_l2(kvg.grad, kvd.grad) < TOL, ("cross", B, H, Tq, Tk, lens, need_w)
+            if Tk == 1:     # one key: the weights are constant 1 and dq is exactly zero in fp64 -- absolute bound instead
+                assert qg.grad.abs().max().item() < 1e-6 * do.abs().max().item()
+            else:
+                assert rel_l2(qg.grad, qd.grad) < TOL, ("cross dq", B, H, Tq, Tk, lens, need_w)
+            if need_w:
+                assert rel_l2(attn, a) < TOL
+
+
 def test_embedding_posenc_heads_add():
     from transformertts_amd import ops
     dev = _dev()
