@@ -135,7 +135,11 @@ int ttts_gemm_tile_choice(int64_t M, int N, int K, int x6);
 int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode, int channels_per_tap, int taps,
                       void* stream);
 /* all weights in one launch: descs (device memory) = n x 8 int64 {w, planes, rows, cols, mode, channels_per_tap, taps,
- * first_block}, first_block = running sum of ceil(rows*cols/256), total_blocks = the final sum */
+ * first_block}, first_block = running sum of ttts_weight_split_units(rows, cols, mode, channels_per_tap) over the entries
+ * before this one, total_blocks = the final sum.  (A unit is one workgroup: 256 elements of a bf16x6 image; a 32-row x
+ * 32-channel tile, all taps of it, of an fp16x3 image -- read in the order the source is contiguous in and written as whole
+ * 2 KB runs of the planes.) */
+int64_t ttts_weight_split_units(int64_t rows, int64_t cols, int mode, int channels_per_tap);
 int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks, void* stream);
 int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
                        int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed, int row_shift, int T,

@@ -430,7 +430,7 @@ def test_weight_split_batched_equals_single():
         assert lib.ttts_weight_split(_p(w), _p(a), R, C, mode, c2, taps, _stream()) == 0
         single.append(a); batched.append(b)
         rows.append([w.data_ptr(), b.data_ptr(), R, C, mode, c2, taps, blk])
-        blk += (R * C + 255) // 256
+        blk += lib.ttts_weight_split_units(R, C, mode, c2)
     table = torch.tensor(rows, dtype=torch.int64).to(_dev())
     assert lib.ttts_weight_split_batched(_p(table), len(rows), blk, _stream()) == 0
     torch.cuda.synchronize()
@@ -461,6 +461,64 @@ def test_weight_split_batched_equals_single():
     pl = img[: 2 * R * Cp].view(torch.float16).view(Cp // 32, 2, R, 32).double().sum(1).permute(1, 0, 2).reshape(R, 5, 96)
     assert torch.equal(pl[:, :, 80:], torch.zeros_like(pl[:, :, 80:]))
     assert (pl[:, :, :80] / sc - w.double().permute(0, 2, 1)).abs().max().item() <= 2.0 ** -21 * w.abs().max().item()
+
+
+def _h3_image_ref(w, mode, scale_exp):
+    """The fp16x3 image of ttts_weight_split modes 4-7 in torch: B[r][c'] (c' in the tap-padded image) as hi / lo f16 planes
+    of w * 2^k laid [c'/32][plane][r][32].  Bit-exact restatement (float32 arithmetic, round-to-nearest f16 casts)."""
+    if mode == 4: B = w[:, None, :]                          # (N, K) -> rows N, one tap, channels K
+    elif mode == 5: B = w.t()[:, None, :]                    # rows K, channels N
+    elif mode == 6: B = w.permute(0, 2, 1)                   # (co, ci, tap) -> rows co, taps, channels ci
+    else: B = w.permute(1, 2, 0)                             # rows ci, taps, channels co
+    R, taps, ch = B.shape
+    pad = (ch + 31) // 32 * 32
+    img = torch.zeros(R, taps, pad, device=w.device)
+    img[:, :, :ch] = B * (2.0 ** scale_exp)
+    img = img.reshape(R, taps * pad)
+    hi = img.half()
+    lo = (img - hi.float()).half()
+    planes = torch.stack([hi, lo], 0).view(2, R, taps * pad // 32, 32).permute(2, 0, 1, 3).contiguous()
+    return planes.view(torch.int16).flatten(), R, taps * pad
+
+
+def test_fp16x3_weight_images_bit_exact():
+    """Every mode of the tiled split (32-row x 32-channel tiles through LDS) against the torch restatement: rows and channels
+    that are no multiples of 32, a 9-tap kernel (two passes of 8 taps), a source that is only 4-byte aligned, tiny and
+    large magnitudes; single and batched entry points."""
+    from transformertts_amd import _lib
+    from transformertts_amd.ops import _p, _stream
+    lib = _lib.load()
+    big = _rand(4 * 1024 * 80 + 1, seed=77)
+    specs = [(_rand(256, 128, seed=1) * 40.0, 4), (_rand(1024, 256, seed=2) * 1e-5, 5), (_rand(80, 256, seed=3), 4),
+             (_rand(80, 256, seed=4), 5), (_rand(256, 80, seed=5), 4), (_rand(256, 80, seed=6), 5), (_rand(36, 44, seed=7), 4),
+             (_rand(36, 44, seed=8), 5), (_rand(256, 256, 5, seed=9), 6), (_rand(256, 256, 5, seed=10), 7),
+             (_rand(80, 256, 5, seed=11), 6), (_rand(80, 256, 5, seed=12), 7), (_rand(256, 80, 5, seed=13), 6),
+             (_rand(256, 80, 5, seed=14), 7), (_rand(48, 36, 9, seed=15) * 3e4, 6), (_rand(48, 36, 9, seed=16), 7),
+             (_rand(40, 12, 3, seed=17), 6), (_rand(40, 12, 1, seed=18), 7),
+             (big[1:].view(1024, 320), 4), (big[1:].view(1024, 64, 5), 7)]          # data_ptr % 16 == 4
+    imgs, rows, blk = [], [], 0
+    for w, mode in specs:
+        if mode == 4: R, C, c2, taps = w.shape[0], w.shape[1], 0, 0
+        elif mode == 5: R, C, c2, taps = w.shape[1], w.shape[0], 0, 0
+        elif mode == 6: R, C, c2, taps = w.shape[0], w.shape[1] * w.shape[2], w.shape[1], w.shape[2]
+        else: R, C, c2, taps = w.shape[1], w.shape[0] * w.shape[2], w.shape[0], w.shape[2]
+        amax = w.abs().max().item()
+        k = 11 - int(np.floor(np.log2(amax)))
+        ref, Rr, Cp = _h3_image_ref(w, mode, k)
+        assert Rr == R and lib.ttts_split_image_bytes(R, C, mode, c2, taps) == 4 * R * Cp + 16
+        a = torch.full((2 * R * Cp + 8,), 0x7e00, dtype=torch.int16, device=_dev())
+        b = torch.full_like(a, 0x7e00)
+        assert lib.ttts_weight_split(_p(w), _p(a), R, C, mode, c2, taps, _stream()) == 0
+        rows.append([w.data_ptr(), b.data_ptr(), R, C, mode, c2, taps, blk])
+        blk += lib.ttts_weight_split_units(R, C, mode, c2)
+        imgs.append((a, b, ref, amax, (tuple(w.shape), mode)))
+    table = torch.tensor(rows, dtype=torch.int64).to(_dev())
+    assert lib.ttts_weight_split_batched(_p(table), len(rows), blk, _stream()) == 0
+    torch.cuda.synchronize()
+    for a, b, ref, amax, what in imgs:
+        for img in (a, b):
+            assert torch.equal(img[: ref.numel()], ref), what
+            assert img[ref.numel():ref.numel() + 2].view(torch.float32).item() == amax, what
 
 
 @pytest.mark.parametrize("causal,Tq,Tk,lens", [(1, 200, 200, [200, 131, 64]), (0, 150, 70, [70, 33, 1]), (0, 33, 129, [129, 128, 5])])

@@ -30,6 +30,7 @@ SIGNATURES = {
     "ttts_split_image_bytes": (Z, [L, L, I, I, I]),
     "ttts_gemm_tile_choice": (I, [L, I, I, I]),
     "ttts_weight_split": (I, [P, P, I, I, I, I, I, P]),
+    "ttts_weight_split_units": (L, [L, L, I, I]),
     "ttts_weight_split_batched": (I, [P, I, L, P]),
     "ttts_linear_fwd_x6": (I, [P, P, P, P, P, L, I, I, I, F, U, P, I, I, P]),
     "ttts_linear_fwd_h3": (I, [P, P, P, P, P, L, I, I, I, F, U, P, I, I, P, P, P]),

@@ -437,20 +437,22 @@ __global__ __launch_bounds__(256) void weight_tail_zero_batched_kernel(const lon
                                       h3_plane_bytes(d[2], h3_image_cols(d[3], d[4] >= 6 ? (int)d[5] : 0, d[4] >= 6 ? (int)d[6] : 0))) = 0.f;
     }
 }
-__global__ __launch_bounds__(64) void weight_amax_batched_kernel(const long* __restrict__ descs, int n) {
+__global__ __launch_bounds__(256) void weight_amax_batched_kernel(const long* __restrict__ descs, int n) {
     const long blk = blockIdx.x;
     const long* d = batched_desc(descs, n, blk);
     if (d[4] >= 4)
-        weight_amax_h3_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
-                           h3_image_cols(d[3], d[4] >= 6 ? (int)d[5] : 0, d[4] >= 6 ? (int)d[6] : 0), (blk - d[7]) * 256);
+        weight_amax_h3_unit(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
+                            h3_image_cols(d[3], d[4] >= 6 ? (int)d[5] : 0, d[4] >= 6 ? (int)d[6] : 0), blk - d[7],
+                            h3_split_units(d[2], d[3], (int)d[4], (int)d[5]));
 }
 
 __global__ __launch_bounds__(256) void weight_split_batched_kernel(const long* __restrict__ descs, int n) {
+    __shared__ float t[H3_SPLIT_TAPS][32][33];
     const long blk = blockIdx.x;
     const long* d = batched_desc(descs, n, blk);
-    if (d[4] >= 4)      // modes 4-7: the fp16x3 image of modes 0-3 (block-uniform branch)
-        weight_split_h3_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2],
-                            (int)d[3], (int)d[4] - 4, (int)d[5], (int)d[6], (blk - d[7]) * 256 + threadIdx.x);
+    if (d[4] >= 4)      // modes 4-7: the fp16x3 image of modes 0-3 (block-uniform branch), a 32 x 32 tile per workgroup
+        weight_split_h3_tile(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2],
+                             (int)d[3], (int)d[4] - 4, (int)d[5], (int)d[6], blk - d[7], t);
     else
         weight_split_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
                          (int)d[4], (int)d[5], (int)d[6], (blk - d[7]) * 256 + threadIdx.x);
@@ -1233,13 +1235,19 @@ int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode
     return TTTS_OK;
 }
 
+int64_t ttts_weight_split_units(int64_t rows, int64_t cols, int mode, int channels_per_tap) {
+    // workgroups an entry of ttts_weight_split_batched takes: 256 elements each (bf16x6 images), a 32-row x 32-channel
+    // tile over all taps each (fp16x3 images)
+    return mode >= 4 ? h3_split_units(rows, cols, mode, channels_per_tap) : (rows * cols + 255) / 256;
+}
+
 int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks, void* stream) {
     // descs (device): n x 8 int64 {w, planes, rows, cols, mode, channels_per_tap, taps, first_block}; first_block are the
-    // prefix sums of ceil(rows*cols / 256); the caller guarantees the per-entry constraints of ttts_weight_split
+    // prefix sums of ttts_weight_split_units(); the caller guarantees the per-entry constraints of ttts_weight_split
     TTTS_REQUIRE(descs && n > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "weight_split_batched: bad arguments");
     hipLaunchKernelGGL(weight_tail_zero_batched_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const long*>(descs), n);
-    hipLaunchKernelGGL(weight_amax_batched_kernel, dim3((unsigned)total_blocks), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(weight_amax_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const long*>(descs), n);
     hipLaunchKernelGGL(weight_split_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const long*>(descs), n);

@@ -103,20 +103,34 @@ __device__ __forceinline__ void split2_pair(f32x2 x, uint32_t& hi, uint32_t& lo)
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
 }
 
+// ---- the split of one weight into its fp16x3 image, in WORK UNITS of one 256-thread workgroup each: unit u is the 32-row x
+// 32-channel tile (row block u / channel blocks, channel block u % channel blocks) of the weight, all taps of it.
+// h3_split_units = how many an entry has (host and device agree: the prefix sums of the batched table are built from it).
+constexpr int H3_SPLIT_TAPS = 8;        // taps staged per pass of a tile (longer kernels take several passes)
+__host__ __device__ __forceinline__ long h3_split_units(long R, long C, int mode, int c2) {
+    const long chans = (mode & 3) >= 2 ? c2 : C;
+    return ((R + 31) / 32) * ((chans + 31) / 32);
+}
+
 // |w| maximum of one weight into the tail of its plane image (atomic max on the bit pattern; the tail was zeroed first).
-// Called by ONE wave per 256 elements (blockDim 64): a float4 per lane, a wave reduction, and a look at the tail before the
-// atomic -- every wave of a weight aims at the same word, and after the first few arrivals almost none has anything to add.
-__device__ __forceinline__ void weight_amax_h3_one(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
-                                                   int C, long image_cols, long i0) {
+// The source is R * C contiguous floats whatever the mode: unit u of `units` takes the u-th chunk of it, a float4 per lane
+// and trip.  One atomic per wave, behind a look at the tail -- every wave of a weight aims at the same word, and after the
+// first few arrivals almost none has anything to add.
+__device__ __forceinline__ void weight_amax_h3_unit(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
+                                                    int C, long image_cols, long unit, long units) {
     const long n = (long)R * C;
-    const long i = i0 + 4 * (long)(threadIdx.x & 63);
+    const long chunk = ((n + units - 1) / units + 3) & ~3L;
+    const long i0 = unit * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
     float m = 0.f;
-    if (i + 3 < n && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
-        const float4 v = *reinterpret_cast<const float4*>(w + i);
-        m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        long i = i0 + 4 * (long)threadIdx.x;
+        for (; i + 3 < i1; i += 4 * (long)blockDim.x) {
+            const float4 v = *reinterpret_cast<const float4*>(w + i);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        for (; i < i1; ++i) m = fmaxf(m, fabsf(w[i]));      // (at most one lane: the last 1-3 elements of the weight)
     } else {
-        for (int e = 0; e < 4; ++e)
-            if (i + e < n) m = fmaxf(m, fabsf(w[i + e]));
+        for (long i = i0 + threadIdx.x; i < i1; i += blockDim.x) m = fmaxf(m, fabsf(w[i]));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -128,37 +142,65 @@ __device__ __forceinline__ void weight_amax_h3_one(const float* __restrict__ w, 
 
 // B[r][c] of weight_split (gemm.hip) as two f16 planes of w * scale, stored [c'/32][plane][r][c'%32] with c' = the column
 // in the padded image (tap * pad32(c2) + channel; c for a linear weight); scale = the power of two of h3_pow2_scale(max|w|),
-// max|w| read from the tail (weight_amax_h3_one has run).  Thread i takes SOURCE element i; the thread of a tap's last
-// channel also writes that tap's zero padding.
-__device__ __forceinline__ void weight_split_h3_one(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
-                                                    int C, int mode, int c2, int taps, long i) {
-    const long n = (long)R * C;
-    if (i >= n) return;
-    const long Cp = h3_image_cols(C, mode >= 2 ? c2 : 0, mode >= 2 ? taps : 0);
+// max|w| read from the tail (weight_amax_h3_unit has run).  One workgroup of 256 threads per unit: the tile is read in the
+// order the SOURCE is contiguous in (rows of channels, columns of rows, or a row's / a channel's run over all taps), goes
+// through LDS (t: H3_SPLIT_TAPS x 32 x 33 floats) and leaves as 2 KB runs of each plane -- one k-tile's 32 rows, 8 bytes per
+// lane.  Channels past the tap's last one are staged as zeros, which writes the image's padding.
+__device__ __forceinline__ void weight_split_h3_tile(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
+                                                     int C, int mode, int c2, int taps, long unit, float (*t)[32][33]) {
+    const int chans = mode >= 2 ? c2 : C;
+    if (mode < 2) taps = 1;
+    const int ngc = (chans + 31) / 32;
+    const int r0 = (int)(unit / ngc) * 32, ch0 = (int)(unit % ngc) * 32;
+    const int nr = min(32, R - r0), nc = min(32, chans - ch0);
+    const int padc = h3_pad32(chans);
     float w_scale, w_inv;
-    h3_pow2_scale(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(planes) + h3_plane_bytes(R, Cp)), w_scale, w_inv);
-    const int r = (int)(i / C), c = (int)(i % C);
-    float v;
-    int cp = c, npad = 0;                                   // column in the padded image; zeros to write behind it
-    if (mode == 0) v = w[i];
-    else if (mode == 1) v = w[(long)c * R + r];
-    else {
-        const int tap = c / c2, ch = c % c2;
-        if (mode == 2) v = w[((long)r * c2 + ch) * taps + tap];
-        else v = w[((long)ch * R + r) * taps + tap];
-        cp = tap * h3_pad32(c2) + ch;
-        if (ch == c2 - 1) npad = h3_pad32(c2) - c2;
-    }
-    if (mode < 2 && c == C - 1) npad = (int)(Cp - C);
-    v *= w_scale;
-    const _Float16 h = (_Float16)v;
-    const _Float16 l = (_Float16)(v - (float)h);
-    const long o = ((long)(cp >> 5) * 2 * R + r) * 32 + (cp & 31);
-    planes[o] = __builtin_bit_cast(unsigned short, h);
-    planes[o + (long)R * 32] = __builtin_bit_cast(unsigned short, l);
-    for (int e = 1; e <= npad; ++e) {                       // (cp + e stays inside the k-tile of cp: the pad ends on a multiple of 32)
-        planes[o + e] = 0;
-        planes[o + e + (long)R * 32] = 0;
+    h3_pow2_scale(*h3_plane_tail(planes, R, (long)taps * padc), w_scale, w_inv);
+    const int tid = threadIdx.x;
+    for (int tc0 = 0; tc0 < taps; tc0 += H3_SPLIT_TAPS) {
+        const int tcn = min(H3_SPLIT_TAPS, taps - tc0), run = 32 * tcn;
+        if (mode == 0) {
+            for (int idx = tid; idx < 1024; idx += 256) {
+                const int rr = idx >> 5, cc = idx & 31;
+                t[0][rr][cc] = (rr < nr && cc < nc) ? w[(long)(r0 + rr) * C + ch0 + cc] : 0.f;
+            }
+        } else if (mode == 1) {
+            for (int idx = tid; idx < 1024; idx += 256) {
+                const int cc = idx >> 5, rr = idx & 31;
+                t[0][rr][cc] = (rr < nr && cc < nc) ? w[(long)(ch0 + cc) * R + r0 + rr] : 0.f;
+            }
+        } else if (mode == 2) {                             // w[co][ci][tap]: a row's channels x taps are one run
+            for (int idx = tid; idx < 32 * run; idx += 256) {
+                const int rr = idx / run, j = idx - rr * run, cc = j / tcn, tt = j - cc * tcn;
+                t[tt][rr][cc] = (rr < nr && cc < nc) ? w[((long)(r0 + rr) * c2 + ch0 + cc) * taps + tc0 + tt] : 0.f;
+            }
+        } else {                                            // w[co][ci][tap] read as [ci] rows: a channel's rows x taps are one run
+            for (int idx = tid; idx < 32 * run; idx += 256) {
+                const int cc = idx / run, j = idx - cc * run, rr = j / tcn, tt = j - rr * tcn;
+                t[tt][rr][cc] = (rr < nr && cc < nc) ? w[((long)(ch0 + cc) * R + r0 + rr) * taps + tc0 + tt] : 0.f;
+            }
+        }
+        __syncthreads();
+        const int rr = tid >> 3, q = (tid & 7) * 4;
+        if (rr < nr) {
+            for (int tt = 0; tt < tcn; ++tt) {
+                const int cp = (mode >= 2 ? (tc0 + tt) * padc : 0) + ch0 + q;
+                unsigned short h[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = t[tt][rr][q + e] * w_scale;
+                    const _Float16 hh = (_Float16)v;
+                    const _Float16 ll = (_Float16)(v - (float)hh);
+                    h[e] = __builtin_bit_cast(unsigned short, hh);
+                    l[e] = __builtin_bit_cast(unsigned short, ll);
+                }
+                const long o = ((long)(cp >> 5) * 2 * R + r0 + rr) * 32 + (cp & 31);
+                *reinterpret_cast<uint2*>(planes + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+                *reinterpret_cast<uint2*>(planes + o + (long)R * 32) =
+                    make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+            }
+        }
+        __syncthreads();
     }
 }
 

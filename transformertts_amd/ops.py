@@ -362,9 +362,10 @@ def _refresh_all_planes(storage: int) -> None:
     table = _plane_tables.get(storage)
     if table is None or table[0] != sig_t:
         rows, blk = [], 0
+        units = _lib.load().ttts_weight_split_units
         for s in sig:
             rows.append(list(s) + [blk])
-            blk += (s[2] * s[3] + 255) // 256
+            blk += units(s[2], s[3], s[4], s[5])
         host = torch.tensor(rows, dtype=torch.int64).pin_memory()      # page-locked: the upload does not synchronise
         table = _plane_tables[storage] = (sig_t, host.to(mine[0].planes.device, non_blocking=True), host, blk)
     lib = _lib.load()
@@ -395,11 +396,12 @@ class PlaneTable:
             raise RuntimeError("PlaneTable: the module has no weight planes yet (run one forward + backward first)")
         rows, blk = [], 0
         self.sig = []
+        units = _lib.load().ttts_weight_split_units
         for prm, e in self.entries:
             src = prm.data_ptr() + e.off
             self.sig.append((src, e.planes.data_ptr(), prm._version))
             rows.append([src, e.planes.data_ptr(), e.rows, e.cols, e.mode, e.c2, e.taps, blk])
-            blk += (e.rows * e.cols + 255) // 256
+            blk += units(e.rows, e.cols, e.mode, e.c2)
         self.blocks = blk
         self.host = torch.tensor(rows, dtype=torch.int64).pin_memory()
         self.dev = self.host.to(self.entries[0][1].planes.device, non_blocking=True)
