@@ -92,28 +92,59 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __res
     if (amax_out != nullptr) amax_publish(m, amax_out, blockIdx.x * 4 + wave);
 }
 
-// one workgroup per vocabulary row.  Positions holding this id are compacted IN ORDER into LDS, 256 ids per step
-// (wave ballots + prefix counts), then the matching gradient rows are summed in that fixed order: deterministic.
+// one workgroup per vocabulary row.  Positions holding this id are compacted IN ORDER into LDS, 1024 ids per step (four
+// independent id loads per lane, wave ballots + prefix counts), then the matching gradient rows are summed in that fixed
+// order: deterministic.
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
                                                             float* __restrict__ dtable, long n, int d, int accumulate) {
-    __shared__ int list[256];
-    __shared__ int wcount[4];
+    constexpr int PER = 4;                                  // ids per lane and step
+    __shared__ int list[256 * PER];
+    __shared__ int wcount[PER][4];
     const int v = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int MAXPER = 4;   // d <= 1024
     float acc[MAXPER] = {0.f, 0.f, 0.f, 0.f};
-    for (long base = 0; base < n; base += 256) {
-        const long i = base + tid;
-        const bool hit = (i < n) && (ids[i] == v);
-        const unsigned long long m = __ballot(hit);
-        if (lane == 0) wcount[wave] = __popcll(m);
+    for (long base = 0; base < n; base += 256 * PER) {
+        bool hit[PER];
+        unsigned long long m[PER];
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {                     // position base + 256 p + tid: ordered by (p, wave, lane)
+            const long i = base + 256 * p + tid;
+            hit[p] = (i < n) && (ids[i] == v);
+        }
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            m[p] = __ballot(hit[p]);
+            if (lane == 0) wcount[p][wave] = __popcll(m[p]);
+        }
         __syncthreads();
-        int off = 0;
-        for (int w = 0; w < wave; ++w) off += wcount[w];
-        const int total = wcount[0] + wcount[1] + wcount[2] + wcount[3];
-        if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)(i - base);
+        int total = 0;
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            int off = total;
+            for (int w = 0; w < wave; ++w) off += wcount[p][w];
+            if (hit[p]) list[off + __popcll(m[p] & ((1ull << lane) - 1ull))] = 256 * p + tid;
+            total += wcount[p][0] + wcount[p][1] + wcount[p][2] + wcount[p][3];
+        }
         __syncthreads();
-        for (int k = 0; k < total; ++k) {
+        int k = 0;
+        for (; k + 8 <= total; k += 8) {                    // eight rows in flight, added in list order
+            float g[8][MAXPER];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long row = base + list[k + u];
+#pragma unroll
+                for (int j = 0; j < MAXPER; ++j) {
+                    const int c = tid + 256 * j;
+                    g[u][j] = c < d ? dout[row * d + c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < MAXPER; ++j) acc[j] += g[u][j];
+        }
+        for (; k < total; ++k) {
             const long row = base + list[k];
 #pragma unroll
             for (int j = 0; j < MAXPER; ++j) {

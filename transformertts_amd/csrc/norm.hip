@@ -450,22 +450,19 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     }
 }
 
-// dgamma / dbeta (+)= the reduced sums
-__global__ void bn_param_grad_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                     int C, int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sums[c] : sums[c];
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sums[C + c] : sums[C + c];
-}
-
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ sums, float* __restrict__ dx, long n4,
                                                            int C, float inv_m, int act, float drop_scale, uint32_t thr,
-                                                           uint64_t seed, const uint64_t* step_seed, float* __restrict__ amax) {
+                                                           uint64_t seed, const uint64_t* step_seed, float* __restrict__ amax,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
     seed = site_seed(seed, step_seed);
+    if (blockIdx.x == 0)                                    // dgamma / dbeta (+)= the reduced sums (no launch of their own)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sums[c] : sums[c];
+            if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sums[C + c] : sums[C + c];
+        }
     float mx = 0.f;
     const float dsc = thr != 0u ? drop_scale : 1.0f;
     // per-channel vectors as 16-byte loads when every one of them is 16-byte aligned (parameters may sit at any 4-byte
@@ -678,13 +675,12 @@ int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float*
     TTTS_LAUNCH_CHECK("bn_bwd_partial_kernel");
     int rc = launch_reduce_rows(ws, 2 * C, nb, 2 * C, sums, 2 * C, nullptr, 0, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, sums, dgamma, dbeta, C, accumulate);
-    TTTS_LAUNCH_CHECK("bn_param_grad_kernel");
     long n4 = (long)M * C / 4;
     int grid = (int)((n4 + 255) / 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, dz, x, mean, invstd, gamma, beta, sums, dx, n4,
-                       C, batch_stats ? 1.0f / (float)M : 0.0f, act, scale, thr, seed, step_seed, dx_amax_partials);
+                       C, batch_stats ? 1.0f / (float)M : 0.0f, act, scale, thr, seed, step_seed, dx_amax_partials, dgamma, dbeta,
+                       accumulate);
     TTTS_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return TTTS_OK;
 }
