@@ -846,7 +846,13 @@ static bool h3_wide_supports(const GemmArgs& g) { return g.K >= 3 * HBK && g.T <
 
 static int launch_h3_wide(const GemmArgs& g, hipStream_t stream) {
     const long ntiles = (long)cdiv(g.N, 256) * cdiv(g.M, 256);
-    dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256), 1, 1);                // one workgroup per CU
+    // one workgroup per CU, and no more of them than level rounds need: 872 tiles are four rounds on 256 workgroups (104 busy
+    // in the last) and four on 224 (200 busy in the last) -- the same rounds with fewer CUs pulling on L2 / HBM at a time
+    // (1-5 % per launch, same-box A/B).  A multiple of 8, so that virtual ids keep their XCD from tile to tile.
+    const long rounds = (ntiles + 255) / 256;
+    long gsz = ((ntiles + rounds - 1) / rounds + 7) / 8 * 8;
+    if (gsz > 256) gsz = 256;
+    dim3 grid((unsigned)(ntiles < 256 ? ntiles : gsz), 1, 1);
     hipLaunchKernelGGL((gemm_h3_wide_kernel<false>), grid, dim3(256), 0, stream, g);
     TTTS_LAUNCH_CHECK("gemm_h3_wide_kernel");
     return TTTS_OK;
