@@ -459,10 +459,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
             ra[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
     };
+    // Order of the k-tiles.  A shifted operand (CLIP: a convolution, K = taps x cin) walks TAPS INNERMOST: the `taps`
+    // k-tiles of one 32-channel block follow each other, so the rows a tap reads are the rows the previous tap read, one
+    // further down -- re-reads that hit L1 / L2.  Taps outermost (the order of the weight image) brought a row back after a
+    // whole pass over the channels, by which time the 32 workgroups of an XCD had pushed it out of L2: the 256-channel
+    // convolutions fetched 5.2 x their activation bytes from beyond L2 (profiles/r03_traffic.json).  Only the sequence of
+    // (tap, channel block) changes; the image keeps its layout and is addressed tile by tile.
+    const int taps = CLIP ? g.K / g.cin : 1;
+    const uint32_t row_step = (uint32_t)((long)g.shift_step * g.lda * 4);                 // one tap further: shift_step rows
+    const uint32_t b_tap_step = (uint32_t)(g.cin / HBK) * 2u * b_plane_bytes;             // ... and cin / 32 k-tiles of the image
+    const uint32_t a_wrap = HBK * 4 - (uint32_t)(taps - 1) * row_step;                    // last tap -> first tap of the next block
+    const uint32_t b_wrap = 2u * b_plane_bytes - (uint32_t)(taps - 1) * b_tap_step;
+    int tap_i = 0;
     auto advance_a = [&]() {
-        k_c0 += HBK;
-        k_off += HBK * 4;
-        if (k_c0 == g.cin) { k_c0 = 0; k_shift += g.shift_step; k_off += tap_step; }
+        if (CLIP) {
+            const bool wrap = tap_i + 1 == taps;
+            k_shift = wrap ? g.shift0 : k_shift + g.shift_step;
+            k_off += wrap ? a_wrap : row_step;
+        } else {
+            k_c0 += HBK;
+            k_off += HBK * 4;
+            if (k_c0 == g.cin) { k_c0 = 0; k_shift += g.shift_step; k_off += tap_step; }
+        }
     };
     auto load_b_piece = [&](int j) {
 #pragma unroll
@@ -470,7 +488,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
             rb[p][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)b_off0,
                                                              (int)(b_cur + p * b_plane_bytes + j * (B_ROWS_PER_PIECE * 64)), 0);
     };
-    auto advance_b = [&]() { b_cur += 2u * b_plane_bytes; };
+    auto advance_b = [&]() {                                       // (always called right behind advance_a)
+        if (CLIP) {
+            const bool wrap = tap_i + 1 == taps;
+            b_cur += wrap ? b_wrap : b_tap_step;
+            tap_i = wrap ? 0 : tap_i + 1;
+        } else {
+            b_cur += 2u * b_plane_bytes;
+        }
+    };
     auto store_a_piece = [&](int buf, int i) {
         uint32_t* as = lds + buf * STAGE;
         uint2 hi, lo;
