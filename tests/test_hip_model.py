@@ -57,7 +57,10 @@ def _oracle64(cfg, w_seed):
 @pytest.mark.parametrize("cfg_name,B,Tp,Tm,w_seed,b_seed", [("tiny", 3, 12, 40, 11, 21), ("base", 2, 60, 300, 12, 22),
                                                             ("base", 4, 100, 870, 13, 23), ("scaled", 2, 60, 300, 14, 24),
                                                             ("base", 16, 100, 870, 15, 25),
-                                                            ("micro", 3, 12, 40, 16, 26)])      # d_model 32, head_dim 16
+                                                            ("micro", 3, 12, 40, 16, 26),       # d_model 32, head_dim 16
+                                                            # utterances far beyond LJSpeech's longest (870 frames): 24
+                                                            # query blocks, 47 key tiles, 3000 rows of the 5000-row pe table
+                                                            ("base", 2, 200, 3000, 17, 27)])
 def test_forward_backward_vs_oracle(cfg_name, B, Tp, Tm, w_seed, b_seed):
     from oracle import synth_batch, oracle_forward, oracle_loss
     from transformertts_amd.loss import TransformerTTSLoss
