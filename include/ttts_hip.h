@@ -322,6 +322,9 @@ int ttts_dropout_bwd(const float* dy, float* dx, int64_t n, float drop_p, uint64
 int ttts_zero(void* p, size_t nbytes, void* stream);
 /* z = x + y */
 int ttts_add(const float* x, const float* y, float* z, int64_t n, void* stream);
+/* z = (x + y) + w: the gradient of a tensor with three consumers in one pass (autograd's own accumulation is one add per
+ * extra consumer); n % 4 == 0 */
+int ttts_add3(const float* x, const float* y, const float* w, float* z, int64_t n, void* stream);
 /* ---- input side: device-side padding of a ragged batch --------------------------------------
  * Replaces the host loop of collate_fn (dataset.py:76-91) and the per-sample transpose of __getitem__
  * (dataset.py:64).  `ragged` holds the B utterances back to back, each in its on-disk (n_mels, len_b) row-major

@@ -276,6 +276,29 @@ def test_attention_on_random_shapes():
                 assert rel_l2(attn, a) < TOL
 
 
+def test_fanout_sums_consumer_gradients_in_one_launch():
+    """ops.fanout: n aliases whose gradients meet in one ttts_add / ttts_add3 launch -- autograd's own accumulation up to
+    the association order of a three-term fp32 sum --, also with an unused handle and without gradient tracking."""
+    from transformertts_amd import ops
+    x = _rand(7, 33, 64, seed=1)
+    w = [_rand(7, 33, 64, seed=10 + i) for i in range(3)]
+    for n in (2, 3):
+        ref = _g(x)
+        sum((ref * w[i].to(_dev())).sum() * (i + 1.0) for i in range(n)).backward()
+        xg = _g(x)
+        hs = ops.fanout(xg, n)
+        assert len(hs) == n and all(h.data_ptr() == xg.data_ptr() for h in hs)
+        sum((hs[i] * w[i].to(_dev())).sum() * (i + 1.0) for i in range(n)).backward()
+        assert rel_l2(xg.grad, ref.grad) < 1e-7 and (xg.grad - ref.grad).abs().max().item() <= 4e-7 * ref.grad.abs().max().item()
+    xg = _g(x)
+    a, b, c = ops.fanout(xg, 3)
+    ((a * 2.0).sum() + (c * 3.0).sum()).backward()              # the middle handle has no consumer
+    assert torch.equal(xg.grad, torch.full_like(xg, 5.0))
+    with torch.no_grad():
+        hs = ops.fanout(_g(x), 3)
+    assert all(not h.requires_grad or h.grad_fn is None for h in hs)
+
+
 def test_embedding_posenc_heads_add():
     from transformertts_amd import ops
     dev = _dev()

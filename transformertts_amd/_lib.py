@@ -77,6 +77,7 @@ SIGNATURES = {
     "ttts_relu_dropout_bwd": (I, [P, P, P, L, F, P, P]),
     "ttts_dropout_bwd": (I, [P, P, L, F, U, P, P, P]),
     "ttts_add": (I, [P, P, P, L, P]),
+    "ttts_add3": (I, [P, P, P, P, L, P]),
     "ttts_collate_melspec": (I, [P, P, P, I, I, I, P]),
     "ttts_collate_phoneme": (I, [P, P, P, I, I, P]),
     "ttts_loss_workspace_bytes": (Z, []),

@@ -278,6 +278,16 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ x, c
     }
 }
 
+__global__ __launch_bounds__(256) void add3_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                   const float* __restrict__ w, float* __restrict__ z, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 a = reinterpret_cast<const float4*>(x)[i];
+        const float4 b = reinterpret_cast<const float4*>(y)[i];
+        const float4 c = reinterpret_cast<const float4*>(w)[i];
+        reinterpret_cast<float4*>(z)[i] = make_float4((a.x + b.x) + c.x, (a.y + b.y) + c.y, (a.z + b.z) + c.z, (a.w + b.w) + c.w);
+    }
+}
+
 // ------------------------------------------------------------------ stop-token head (N = 1)
 __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ b, float* __restrict__ y, long M, int d) {
@@ -462,6 +472,13 @@ int ttts_add(const float* x, const float* y, float* z, int64_t n, void* stream) 
     TTTS_REQUIRE(x && y && z && n > 0 && n % 4 == 0, "add: bad arguments (n %% 4 must be 0)");
     hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y, z, (long)(n / 4));
     TTTS_LAUNCH_CHECK("add_kernel");
+    return TTTS_OK;
+}
+
+int ttts_add3(const float* x, const float* y, const float* w, float* z, int64_t n, void* stream) {
+    TTTS_REQUIRE(x && y && w && z && n > 0 && n % 4 == 0, "add3: bad arguments (n %% 4 must be 0)");
+    hipLaunchKernelGGL(add3_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y, w, z, (long)(n / 4));
+    TTTS_LAUNCH_CHECK("add3_kernel");
     return TTTS_OK;
 }
 

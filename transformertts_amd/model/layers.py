@@ -219,7 +219,8 @@ class TransformerDecoder(nn.Module):
         if memory_lens is None:
             memory_lens = _lens_from_kpm(memory_key_padding_mask, B, memory.size(1), tgt.device)
         alignments = []
-        for layer in self.layers:
+        memories = ops.fanout(memory, len(self.layers))     # one handle per layer: their gradients meet in one launch
+        for layer, memory in zip(self.layers, memories):
             tgt, alignment = layer(tgt, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
                                    tgt_is_causal=True if tgt_is_causal is None else tgt_is_causal,
                                    memory_is_causal=bool(memory_is_causal), tgt_lens=tgt_lens,

@@ -205,7 +205,9 @@ class TransformerTTS(nn.Module):
                                            need_alignments=need_alignments)
         pred_melspec, pred_stop = ops.heads(tgt_out, self.linear1.linear.weight, self.linear1.linear.bias,
                                             self.linear2.linear.weight, self.linear2.linear.bias)
-        post_melspec = ops.AddFn.apply(self.postnet(pred_melspec), pred_melspec)
+        # three consumers of the prediction (the loss, the post-net, its residual): one handle each
+        pred_melspec, pred_in, pred_res = ops.fanout(pred_melspec, 3)
+        post_melspec = ops.AddFn.apply(self.postnet(pred_in), pred_res)
         return {
             'pred_melspec': pred_melspec,
             'post_melspec': post_melspec,

@@ -1310,6 +1310,41 @@ class AddFn(torch.autograd.Function):
         return dz, dz
 
 
+class FanoutFn(torch.autograd.Function):
+    """n aliases of x for n consumers.  Autograd would add their gradients with one stock `aten::add_` per extra consumer;
+    here they meet in ONE launch (two or three consumers: the encoder memory under three decoder layers, the mel prediction
+    under the loss, the post-net and its residual)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        lib = _lib.load()
+        gs = [_chk(g, "fanout.grad") for g in gs if g is not None]
+        if not gs:
+            return None, None
+        while len(gs) > 1:
+            out = torch.empty_like(gs[0])
+            if len(gs) >= 3 and out.numel() % 4 == 0:
+                _lib.check(lib.ttts_add3(_p(gs[0]), _p(gs[1]), _p(gs[2]), _p(out), out.numel(), _stream()), "ttts_add3")
+                gs = [out] + gs[3:]
+            elif out.numel() % 4 == 0:
+                _lib.check(lib.ttts_add(_p(gs[0]), _p(gs[1]), _p(out), out.numel(), _stream()), "ttts_add")
+                gs = [out] + gs[2:]
+            else:
+                gs = [gs[0] + gs[1]] + gs[2:]
+        return gs[0], None
+
+
+def fanout(x: torch.Tensor, n: int):
+    """n handles on x, one per consumer (see FanoutFn); plain aliases when no gradient will flow."""
+    if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * max(n, 1)
+    return FanoutFn.apply(x, n)
+
+
 # ----------------------------------------------------------------------------------------------- loss / mix
 class TTSLossFn(torch.autograd.Function):
     """(total, pred_mel, post_mel, stop) of TransformerTTSLoss in one streaming reduction (no boolean-index gathers).  The
