@@ -11,7 +11,7 @@ lib = _lib.load()
 dev = torch.device("cuda:0")
 ONLY_H3 = len(sys.argv) > 1 and sys.argv[1] == "h3"
 SHAPES = [("ffn1 256->1024", 55680, 1024, 256), ("ffn2 1024->256", 55680, 256, 1024), ("inproj 256->768", 55680, 768, 256),
-          ("outproj 256->256", 55680, 256, 256), ("enc ffn1", 6400, 1024, 256), ("scaled ffn1 512->2048", 27840, 2048, 512),
+          ("outproj 256->256", 55680, 256, 256), ("enc ffn1", 6400, 1024, 256), ("enc ffn2", 6400, 256, 1024), ("enc outproj", 6400, 256, 256), ("enc inproj", 6400, 768, 256), ("scaled ffn1 512->2048", 27840, 2048, 512),
           ("scaled ffn2 2048->512", 27840, 512, 2048)]
 CONV = [("postnet conv 256->256 k5", 64, 870, 256, 256), ("enc conv 256->256 k5", 64, 100, 256, 256)]
 
