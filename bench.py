@@ -2,6 +2,7 @@
 """bench.py -- mel frames/sec of one teacher-forced Transformer-TTS training step on N MI355X.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          (N > 1 with no launcher: starts the line below as a child)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -38,6 +39,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+
+def self_launch(argv) -> int | None:
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process
+    (never exec: see the environment notes on replacing a process; nothing here has touched the GPU -- torch is not even
+    imported yet), relay its stdout / stderr and return its exit code.  Returns None when this process is itself a rank
+    (RANK / WORLD_SIZE set by a launcher) or N == 1.  The reference has no counterpart (train.py:38-51 is devices=1)."""
+    import socket
+    import subprocess
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return None
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = str(sock.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"[bench] --gpus {n} without a launcher: starting {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+if __name__ == "__main__":
+    _rc = self_launch(sys.argv[1:])
+    if _rc is not None:
+        raise SystemExit(_rc)
+
 import torch
 import torch.distributed as dist
 
@@ -45,7 +82,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense
 
 
-TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")     # newest first; see tools/collect_traffic.py
+TRAFFIC_FILES = ("r04_traffic.json",)     # see tools/collect_traffic.py; round 3's file mis-normalised WRITE_SIZE (x1.9) and is not read
 
 
 def measured_traffic(kernel: str, workload: str = "base_b64"):
@@ -54,7 +91,7 @@ def measured_traffic(kernel: str, workload: str = "base_b64"):
     MI355X_MICROARCH.md -- or (None, None).  PMC passes cannot run inside the timed bench, so the figure is a stamped
     reading of the build named in the file, not of this run.  A workload other than the default one has its own file
     (`r03_traffic_<workload>.json`) or no figure: the default workload's bytes per launch are not its bytes."""
-    files = TRAFFIC_FILES if workload == "base_b64" else (f"r03_traffic_{workload}.json",)
+    files = TRAFFIC_FILES if workload == "base_b64" else (f"r04_traffic_{workload}.json",)
     for name in files:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -242,6 +279,32 @@ def rehearsal_gradient_check(ts, rank: int, world: int) -> dict:
             "tail_trigger_fired": bool(ts.trigger is not None and ts.trigger.fired == fired0 + 1)}
 
 
+def launch_check(args, world: int, rank: int):
+    """--launch-check: what the driver's N-rank command exercises around the measured step, with the step left out --
+    rendezvous on 127.0.0.1, one barrier on each side of a (trivial) timed region, MAX of the ranks' clocks, SUM of the
+    ranks' unit counts, ONE JSON line from rank 0.  Runs on a box without a GPU (gloo); tests/test_host_logic.py starts it
+    through `self_launch`.  The line says `launch_check: true` and carries no metric value."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    units = torch.tensor([float(args.batch * args.tm)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(units, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "frames_per_step": float(units.item()), "max_rank_seconds": float(t.item()), "value": None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def workload_name(args) -> str:
     if args.config == "base" and args.batch == 64:
         return "BASELINE configs[2] (batch 64, 1 GPU; per-GPU shard of configs[3])"
@@ -267,6 +330,13 @@ def main():
     ap.add_argument("--cycle", type=int, default=1, help="number of distinct ragged batch shapes fed round-robin")
     ap.add_argument("--lattice", default="", help="P,M: pad batches to multiples of P phonemes / M frames (graph-cache key)")
     ap.add_argument("--accumulate", type=int, default=1, help="micro-batches per optimizer step (train.py:42 uses 4)")
+    ap.add_argument("--alignments", action="store_true",
+                    help="the grad forward of every timed step also writes the per-head cross-attention maps (B,H,Tm,Tp) as the "
+                         "reference's forward does (model/layers.py:68-73); the step's results do not depend on them")
+    ap.add_argument("--no-alignments-figure", action="store_true", help="skip the secondary figure taken with --alignments semantics")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="exercise the launcher protocol only (process group, barrier, MAX-over-ranks clock, rank-0 JSON line) "
+                         "over gloo on the host: no model, no GPU, not a measurement")
     ap.add_argument("--sustain", type=float, default=float(os.environ.get("TTTS_BENCH_SUSTAIN", "10")), help="seconds of further replays after the timed steps (0: skip)")
     args = ap.parse_args()
 
@@ -275,6 +345,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.launch_check:
+        return launch_check(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     # Rehearsal mode for a one-GPU box (TTTS_BENCH_REHEARSAL=1): every rank uses cuda:0 and the collectives run over
@@ -300,7 +372,8 @@ def main():
     cfg = model_config(args.config)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
               "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,
-                           "sync_loss_every_step": False, "fused_clip_norm": 1.0}}
+                           "sync_loss_every_step": False, "fused_clip_norm": 1.0,
+                           "train_step_alignments": bool(args.alignments)}}
     torch.manual_seed(42)
     lm = LightningModule(config).to(dev)
     lm.train()
@@ -409,6 +482,34 @@ def main():
                      "note": "rank-0 clock around fenced stretches of --steps steps each, after the timed region"}
         note(f"sustained: median {med:.2f} ms/step over {sustained['steps']} further steps")
 
+    # Secondary figure: the same step with the grad forward WRITING the attention maps (the reference's forward always
+    # materialises them, model/layers.py:68-73; its training_step then drops them, lightning_module.py:78-79).  The default
+    # step does not write them -- `config.alignments_written` says which -- so the <WRITE_A> cross-attention kernel gets its
+    # driver-visible time here.
+    with_alignments = None
+    if (not args.alignments and not args.no_alignments_figure and world == 1 and not cycling and args.accumulate == 1
+            and use_graph and not rehearsal):
+        lm.config["training"]["train_step_alignments"] = True
+        ts2 = TrainStep(lm, optimizer, scheduler, batch, graph=True, seed=42 + rank, eager_warmup=2)
+        for _ in range(2):
+            ts2()
+        ts2.ensure_captured()
+        ts2()
+        fence()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            ts2()
+        fence()
+        ms2 = (time.perf_counter() - ta) / args.steps * 1e3
+        lm.config["training"]["train_step_alignments"] = False
+        maps_mb = cfg["decoder_n_layers"] * args.batch * cfg["decoder_n_head"] * args.tm * args.tp * 4 / 1e6
+        with_alignments = {"ms_per_step": ms2, "value": frames_all / (ms2 * 1e-3), "steps": args.steps,
+                           "alignment_bytes_written_per_step": maps_mb * 1e6,
+                           "note": "same step, grad forward writes the per-head cross-attention maps "
+                                   f"({maps_mb:.0f} MB); the no-grad forward needs none"}
+        note(f"with attention maps written: {ms2:.2f} ms/step")
+        del ts2
+
     rehearsal_check = None
     if rehearsal and world > 1:
         rehearsal_check = rehearsal_gradient_check(ts, rank, world)
@@ -450,9 +551,11 @@ def main():
                        "grad_allreduce": ("none (1 GPU)" if not ts.dp else
                                           "tail overlapped with backward" if ts.trigger is not None
                                           else "one collective after backward"),
+                       "alignments_written": bool(args.alignments),
                        "final_loss": final_loss, "per_step_loss_item_sync": False},
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "sustained": sustained,
+            "with_alignments": with_alignments,
             "step_algorithmic_tflops": flops_all / 1e12,
             "step_achieved_tflops_per_gpu": flops_all / world / (elapsed / args.steps) / 1e12,
         }

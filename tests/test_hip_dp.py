@@ -130,21 +130,19 @@ def test_weight_planes_follow_raw_data_writes_after_epoch_bump():
 @pytest.mark.parametrize("overlap", ["1", "0"])
 def test_two_rank_rehearsal_reduces_to_the_mean_gradient(overlap):
     """bench.py in rehearsal mode (two gloo ranks sharing cuda:0): the reduced bucket must equal the mean of the two
-    ranks' single-process gradients (rel-L2 <= 1e-6), with the overlapped tail exchange on and off."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    ranks' single-process gradients (rel-L2 <= 1e-6), with the overlapped tail exchange on and off.  The command is the
+    bare `python bench.py --gpus 2 ...`: bench.py starts its own torch.distributed.run child (bench.self_launch)."""
     env = dict(os.environ, TTTS_BENCH_REHEARSAL="1", TTTS_DP_OVERLAP=overlap, TTTS_GRAPH="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2",
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--batch", "4", "--tm", "160", "--tp", "40", "--ragged", "--no-cpu-baseline", "--no-probe"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
+    assert out["n_gpus"] == 2
     chk = out["config"]["rehearsal_gradient_check"]
     assert chk["overlap_requested"] == (overlap == "1")
     assert chk["tail_trigger_fired"] == (overlap == "1")

@@ -284,3 +284,28 @@ def test_data_parallel_bucket_gloo_world2():
     ret = mgr.dict()
     mp.spawn(_dp_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment (how a driver that only knows the 1-GPU command
+    shape would call it) must start `torch.distributed.run --nproc-per-node 2` as a child, and rank 0 must print exactly ONE
+    JSON line with n_gpus = 2.  --launch-check keeps the model and the GPU out of it (gloo on the host): the protocol around
+    the step -- rendezvous on 127.0.0.1, barriers, MAX-over-ranks clock, SUM of units -- is what runs.  The same bare command
+    with the real step is covered on the GPU box by test_two_rank_rehearsal_reduces_to_the_mean_gradient."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--launch-check"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["launch_check"] is True and out["steps"] == 3
+    assert out["frames_per_step"] == 2 * 64 * 870          # SUM over ranks (weak scaling: 64 utterances per rank)
+    # a failing child must fail the parent: an unknown flag makes every rank exit 2
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--no-such-flag"], env=env, capture_output=True,
+                       text=True, timeout=300, cwd=repo)
+    assert r.returncode != 0

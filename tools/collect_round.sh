@@ -3,7 +3,7 @@
 # command, and the two --pmc passes (FETCH_SIZE / WRITE_SIZE) the HBM-traffic table is built from.  Everything lands in
 # gpurun_out/r02/; the files to keep are then copied into profiles/.   usage: bash tools/collect_round.sh <tag>
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -21,11 +21,11 @@ python3 bench.py --steps 16 --warmup 4 --batch 16 --accumulate 4 --no-cpu-baseli
 echo "accumulate 4 x 16 done"
 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 python3 tools/rccl_one_rank.py > $out/rccl_one_rank.json 2> $out/rccl_one_rank.err || exit 1
 echo "rccl one-rank done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-probe > $out/stats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 8 --warmup 3 --sustain 3 --no-cpu-baseline --no-probe > $out/stats.log 2>&1 || exit 1
 echo "stats done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/traf_fetch -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-probe > $out/traf_fetch.log 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/traf_write -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-probe > $out/traf_write.log 2>&1 || exit 1
-python3 tools/collect_traffic.py $out/traf_fetch $out/traf_write $out/traffic.json "$tag build, bench.py --steps 3 --warmup 3, separate --pmc FETCH_SIZE / WRITE_SIZE passes" > /dev/null || exit 1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/traf_fetch -- python3 bench.py --steps 3 --warmup 3 --sustain 0 --no-cpu-baseline --no-probe > $out/traf_fetch.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/traf_write -- python3 bench.py --steps 3 --warmup 3 --sustain 0 --no-cpu-baseline --no-probe > $out/traf_write.log 2>&1 || exit 1
+python3 tools/collect_traffic.py $out/traf_fetch $out/traf_write $out/traffic.json "$tag build, bench.py --steps 3 --warmup 3 --sustain 0, separate --pmc FETCH_SIZE / WRITE_SIZE passes" > /dev/null || exit 1
 cp $out/stats/*/*kernel_stats.csv $out/kernel_stats.csv
 rm -rf $out/traf_fetch $out/traf_write
 echo "traffic done"
