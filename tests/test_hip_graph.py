@@ -343,3 +343,81 @@ def test_two_host_threads_on_two_streams_run_backward_concurrently():
     assert not errs, errs
     for i in range(2):
         assert _same(_state(models[i][0], models[i][1]), serial[i])
+
+
+def test_mid_and_last_graphs_record_no_weight_splits(monkeypatch):
+    """accumulate > 1: only the window's FIRST micro-batch refreshes the weight planes (one batched launch).  The graphs of
+    the later micro-batches must not carry per-weight `ttts_weight_split` launches (round 3 baked ~200 of them into every
+    mid / last graph: after any capture the host-side plane tags read 'stale', and inside a capture the batched refresh is
+    refused).  Counted at the C ABI while the graphs are being captured."""
+    from transformertts_amd import _lib
+    from transformertts_amd.step import TrainStep
+    from transformertts_amd.workload import synth_batch
+    cfg, lm, opt, sch = _setup("tiny", 5, 0)
+    batch = {k: v.to("cuda") for k, v in synth_batch(3, 12, 40, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=8).items()}
+    ts = TrainStep(lm, opt, sch, batch, graph=True, seed=3, accumulate=3)
+    lib = _lib.load()
+    calls = {"single": 0, "batched": 0}
+    single, batched = lib.ttts_weight_split, lib.ttts_weight_split_batched
+
+    def count_single(*a):
+        if torch.cuda.is_current_stream_capturing():
+            calls["single"] += 1
+        return single(*a)
+
+    def count_batched(*a):
+        if torch.cuda.is_current_stream_capturing():
+            calls["batched"] += 1
+        return batched(*a)
+
+    monkeypatch.setattr(lib, "ttts_weight_split", count_single)
+    monkeypatch.setattr(lib, "ttts_weight_split_batched", count_batched)
+    for _ in range(9):
+        ts()
+    torch.cuda.synchronize()
+    assert ts.n_graphs == 3
+    assert calls == {"single": 0, "batched": 1}, calls
+
+
+def test_load_state_dict_on_a_live_trainstep_drops_its_graphs():
+    """A parameter edited behind the plane table (load_state_dict bumps the version counters) invalidates the table whose
+    device descriptors the captured graphs recorded: the graphs must be dropped and re-captured against the new table, and the
+    run must continue exactly as an eager run that loads the same state at the same step."""
+    from oracle import fill_state
+    from transformertts_amd.step import TrainStep
+    from transformertts_amd.workload import synth_batch
+    outs = []
+    for graph in (False, True):
+        cfg, lm, opt, sch = _setup("tiny", 5, 0)
+        batch = {k: v.to("cuda") for k, v in synth_batch(3, 12, 40, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=8).items()}
+        ts = TrainStep(lm, opt, sch, batch, graph=graph, seed=3)
+        for _ in range(4):
+            ts()
+        lm.model.load_state_dict(fill_state(cfg, 11), strict=True)
+        losses = [ts().detach().clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        if graph:
+            assert ts.recaptures == 1 and ts.n_graphs == 1
+        outs.append((losses, _state(lm, opt)))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
+    assert _same(outs[0][1], outs[1][1])
+
+
+def test_graph_cache_evicts_the_least_recently_used_shape():
+    """max_shapes = 2 and three shapes round-robin: every new shape evicts the least recently used one (graphs destroyed,
+    static buffers freed) instead of aborting training; the arithmetic stays that of the eager run."""
+    from transformertts_amd.step import TrainStep
+    from transformertts_amd.workload import synth_batch
+    outs = []
+    for graph in (False, True):
+        cfg, lm, opt, sch = _setup("tiny", 5, 0)
+        mk = lambda tm, seed: {k: v.to("cuda") for k, v in synth_batch(3, 12, tm, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=seed).items()}
+        batches = [mk(40, 1), mk(36, 2), mk(44, 3)]
+        ts = TrainStep(lm, opt, sch, batches[0], graph=graph, seed=3, max_shapes=2)
+        losses = [ts(batches[i % 3]).detach().clone() for i in range(9)]
+        torch.cuda.synchronize()
+        if graph:
+            assert ts.evictions >= 6 and len(ts._slots) == 2
+        outs.append((losses, _state(lm, opt)))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
+    assert _same(outs[0][1], outs[1][1])

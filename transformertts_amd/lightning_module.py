@@ -47,10 +47,9 @@ class LightningModule(_Base):
         self.example_batch = None
         self.log_interval = config['training'].get('log_interval', 100)
         self.sync_loss = config['training'].get('sync_loss_every_step', True)
-        # dropout / scheduled-sampling draws follow torch's process seed and the data-parallel rank (the reference draws
-        # them from torch's global generator, which `seed_everything` seeds per rank)
-        from . import ops
-        ops.seeds.seed_from_torch()
+        # dropout / scheduled-sampling draws follow torch's process seed folded with the data-parallel rank (the reference
+        # draws them from torch's global generator; replicas there differ because their generators advance differently).
+        # Derived at the first training_step, not here: Lightning constructs the module before torch.distributed exists.
 
     def forward(self, phoneme, melspec, phoneme_lens, melspec_lens, **kwargs):
         return self.model(phoneme, melspec, phoneme_lens, melspec_lens, **kwargs)
@@ -62,6 +61,8 @@ class LightningModule(_Base):
                                          mode=self.config['training']['teacher_forcing_mode'], cycles=1)
 
     def training_step(self, batch, batch_idx):
+        from . import ops
+        ops.seeds.ensure_seeded()
         phoneme, melspec, phoneme_lens, melspec_lens = prepare_batch(batch, self.device)
         # forward #1 (no grad, train mode: dropout on, BN statistics updated) -> the model's own prediction
         with torch.no_grad():   # only pred_melspec is used: do not materialise the attention maps

@@ -54,10 +54,13 @@ class _SeedStream:
     def __init__(self, base: int = 0x5EED5EED):
         self.base = base
         self.counter = 0
+        self.explicit = False          # manual_seed() was called: the stream no longer follows torch's seed
+        self._derived_from = None      # (torch seed, rank) the base was last derived from
 
     def manual_seed(self, seed: int) -> None:
         self.base = int(seed) & 0xFFFFFFFFFFFF
         self.counter = 0
+        self.explicit = True
 
     def seed_from_torch(self, rank: int = None) -> None:
         """Base = torch's process seed (so `torch.manual_seed` / Lightning's `seed_everything` decide the masks, as they
@@ -65,7 +68,20 @@ class _SeedStream:
         if rank is None:
             import torch.distributed as dist
             rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
-        self.manual_seed((torch.initial_seed() ^ (0x9E3779B9 * (int(rank) + 1))) & 0xFFFFFFFFFFFF)
+        self.base = (torch.initial_seed() ^ (0x9E3779B9 * (int(rank) + 1))) & 0xFFFFFFFFFFFF
+        self.counter = 0
+        self._derived_from = (torch.initial_seed(), int(rank))
+
+    def ensure_seeded(self) -> None:
+        """Called at the first use of a step (training_step / TrainStep), i.e. when the process group exists -- Lightning
+        builds the module BEFORE it initialises torch.distributed, so the rank read in a constructor is 0 on every replica.
+        Derives the base from (torch seed, rank) whenever that pair changed; does nothing after an explicit manual_seed()."""
+        if self.explicit:
+            return
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        if self._derived_from != (torch.initial_seed(), int(rank)):
+            self.seed_from_torch(rank)
 
     def next(self) -> int:
         self.counter += 1
@@ -418,6 +434,12 @@ class PlaneTable:
         """Re-split every weight of the module with one batched launch sequence and mark the planes current."""
         _lib.check(_lib.load().ttts_weight_split_batched(_p(self.dev), len(self.entries), self.blocks, _stream()),
                    "ttts_weight_split_batched")
+        for prm, e in self.entries:
+            e.tag = (prm._version, prm.data_ptr() + e.off, _param_epoch)
+
+    def mark_current(self) -> None:
+        """Before capturing a micro-batch that does NOT begin an accumulation window: the window's first graph refreshes the
+        planes when it replays, so the launches recorded here must use them as they are (no per-weight re-split nodes)."""
         for prm, e in self.entries:
             e.tag = (prm._version, prm.data_ptr() + e.off, _param_epoch)
 
@@ -1342,7 +1364,12 @@ def fanout(x: torch.Tensor, n: int):
     """n handles on x, one per consumer (see FanoutFn); plain aliases when no gradient will flow."""
     if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
         return (x,) * max(n, 1)
-    return FanoutFn.apply(x, n)
+    outs = FanoutFn.apply(x, n)
+    amax = getattr(x, "_ttts_amax", None)
+    if amax is not None:               # the producer's partial maxima describe every alias: consumers need no amax pass
+        for o in outs:
+            o._ttts_amax = amax
+    return outs
 
 
 # ----------------------------------------------------------------------------------------------- loss / mix

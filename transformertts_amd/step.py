@@ -61,13 +61,18 @@ def _round_up(n: int, m: int) -> int:
 
 class _Slot:
     """Static buffers of one batch shape and the graphs captured over them (one per accumulation role)."""
-    __slots__ = ("batch", "graphs", "losses", "eager_runs")
+    __slots__ = ("batch", "graphs", "losses", "eager_runs", "used")
 
     def __init__(self, batch):
         self.batch = batch
         self.graphs: Dict[str, torch.cuda.CUDAGraph] = {}
         self.losses: Dict[str, torch.Tensor] = {}
         self.eager_runs = 0
+        self.used = 0                        # TrainStep.index at the last use (LRU eviction)
+
+    def drop_graphs(self) -> None:
+        self.graphs.clear()
+        self.losses.clear()
 
 
 class TrainStep:
@@ -101,6 +106,8 @@ class TrainStep:
         self.lattice = tuple(int(v) for v in lattice) if lattice else None
         self.max_shapes = int(max_shapes)
         self._slots: Dict[Tuple[int, int, int], _Slot] = {}
+        self.evictions = 0
+        self.recaptures = 0                  # times a moved / edited parameter invalidated the captured graphs
         self._cur: Optional[_Slot] = None
         self._pool = None                    # memory pool shared by every captured graph
         self._planes: Optional[ops.PlaneTable] = None
@@ -137,8 +144,16 @@ class TrainStep:
         slot = self._slots.get(key)
         if slot is None:
             if len(self._slots) >= self.max_shapes:
-                raise RuntimeError(f"TrainStep: more than {self.max_shapes} distinct batch shapes; use `lattice` or a "
-                                   "length-bucketed sampler (dataset.BucketBatchSampler)")
+                # least-recently-used shape leaves: its graphs are destroyed, its static buffers freed.  (Graphs hold kernel
+                # nodes only -- `ttts_zero` is a fill kernel -- so a pool-mate's survival does not depend on this one's memory,
+                # DESIGN 9.2.)  Never evict inside an accumulation window: the window's graphs belong to the current shape.
+                victim = min((k for k, v in self._slots.items() if v is not self._cur), key=lambda k: self._slots[k].used,
+                             default=None)
+                if victim is None:
+                    raise RuntimeError("TrainStep: max_shapes must be at least 2")
+                torch.cuda.synchronize()     # the victim's last replay may still be running
+                self._slots.pop(victim).drop_graphs()
+                self.evictions += 1
             B, Tp, Tm = key
             src = {k: batch[k] for k in _KEYS}
             if any(v.device != self.device for v in src.values()):
@@ -157,6 +172,7 @@ class TrainStep:
             else:                                  # lattice padding: id 0 / 0.0 beyond the batch's own maxima
                 d.zero_()
                 d[tuple(slice(0, n) for n in s.shape)].copy_(s, non_blocking=True)
+        slot.used = self.index
         self._cur = slot
 
     # ------------------------------------------------------------------------------------------------ pieces
@@ -201,6 +217,17 @@ class TrainStep:
         if self._planes is None or not self._planes.valid():
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("TrainStep: weight planes moved during a capture")
+            if self._planes is not None:
+                # A parameter moved or was edited behind the table (load_state_dict, broadcast_module_state, .to()): every
+                # graph captured so far recorded `ttts_weight_split_batched` over the OLD table's device descriptors, which
+                # die with the old table.  Drop those graphs (they are re-captured at their next use) BEFORE the table goes.
+                torch.cuda.synchronize()
+                for slot in self._slots.values():
+                    slot.drop_graphs()
+                self.recaptures += 1
+                self._planes = ops.PlaneTable(self.lm.model)
+                self._planes.refresh()       # whatever edited the parameters: the planes follow now, wherever the window stands
+                return
             self._planes = ops.PlaneTable(self.lm.model)
 
     # ------------------------------------------------------------------------------------------------ one step
@@ -211,6 +238,8 @@ class TrainStep:
         slot = self._cur
         if slot is None:
             raise RuntimeError("TrainStep: no batch loaded yet")
+        slot.used = self.index
+        ops.seeds.ensure_seeded()
         role = self._role()
         last = role in ("full", "last")
         self._push_state()
@@ -245,6 +274,8 @@ class TrainStep:
         capture; the caller replays it right away."""
         self._ensure_planes()
         torch.cuda.synchronize()
+        if role not in ("full", "first"):
+            self._planes.mark_current()      # the window's first graph refreshes the planes at replay: record no re-splits here
         g = torch.cuda.CUDAGraph()
         step0 = self.opt._step
         prev = self._cur
