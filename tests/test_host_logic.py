@@ -42,6 +42,12 @@ def test_library_keeps_no_hidden_configuration():
     from transformertts_amd import _lib
     syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "getenv" not in syms
+    # ... and neither does the Python layer select arithmetic from the process environment (round 3 read TTTS_*_MODE at import
+    # time): the only environment reads of the package are the library path of a development A/B build and the compiler name.
+    allowed = {("_lib.py", "TTTS_LIB"), ("build.py", "HIPCC")}
+    for path in glob.glob(os.path.join(REPO, "transformertts_amd", "**", "*.py"), recursive=True):
+        for m in re.finditer(r"os\.environ(?:\.get\(|\[)\s*[\"']([A-Z_0-9]+)", open(path).read()):
+            assert (os.path.basename(path), m.group(1)) in allowed, (path, m.group(1))
 
 
 def test_bench_workload_is_the_oracles_workload():

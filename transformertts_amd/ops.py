@@ -148,19 +148,50 @@ def _ss():
 # Forward / data-gradient GEMMs and convolutions: "x6" = fp32-accurate split-precision products on the bf16 MFMA
 # (3-way bf16 split, six MFMA terms, fp32 accumulate; error 1.1e-7 vs 2.9e-7 for the plain fp32 MFMA chain),
 # "f32" = the plain v_mfma_f32_32x32x2_f32 kernel.  Weight gradients always use the fp32 kernel.
-GEMM_MODE = os.environ.get("TTTS_GEMM_MODE", "x6")
-ATTN_MODE = os.environ.get("TTTS_ATTN_MODE", GEMM_MODE)       # attention products (backward; forward unless ATTN_FWD_MODE): "x6" or "f32"
-ATTN_FWD_MODE = os.environ.get("TTTS_ATTN_FWD_MODE", "h3" if ATTN_MODE == "x6" else ATTN_MODE)   # forward: "h3", "x6", "f32"
-ATTN_BWD_MODE = os.environ.get("TTTS_ATTN_BWD_MODE", "h3" if ATTN_MODE == "x6" else ATTN_MODE)   # backward: "h3", "x6", "f32"
-WGRAD_MODE = os.environ.get("TTTS_WGRAD_MODE", "h3" if GEMM_MODE == "x6" else GEMM_MODE)   # weight gradients: "h3", "x6", "f32"
+GEMM_MODE = "x6"
+ATTN_MODE = GEMM_MODE       # attention products (backward; forward unless ATTN_FWD_MODE): "x6" or "f32"
+ATTN_FWD_MODE = "h3"   # forward: "h3", "x6", "f32"
+ATTN_BWD_MODE = "h3"   # backward: "h3", "x6", "f32"
+WGRAD_MODE = "h3"   # weight gradients: "h3", "x6", "f32"
 # Forward GEMMs (nn.Linear / Conv1d forward) under GEMM_MODE "x6": "h3" = fp16x3 split (three f16 MFMA terms, both operands
 # pre-scaled by powers of two taken from their MEASURED maxima, csrc/gemm_h3.hip -- no magnitude window), "x6" = bf16x6.
 # Shapes the fp16 kernel cannot take (K or channels not a multiple of 4) go to bf16x6.
-FWD_MODE = os.environ.get("TTTS_FWD_MODE", "h3")
+FWD_MODE = "h3"
 
 
 # Data-gradient GEMMs: "h3" = fp16x3 with a dynamic pre-scale of the gradient operand (one amax pass over dy), "x6".
-BWD_MODE = os.environ.get("TTTS_BWD_MODE", "h3")
+BWD_MODE = "h3"
+
+
+class cross_check_forms:
+    """TEST / TOOL API, not configuration: the product path always runs the fp16x3 forms and reads no environment
+    variable.  `with ops.cross_check_forms(gemm="f32")` (or fwd= / bwd= / wgrad= / attn_fwd= / attn_bwd= "x6") routes the
+    launches made inside the block to the bf16x6 / fp32-MFMA forms the library keeps as numerical cross-checks
+    (tests/test_hip_modes.py holds all forms to the same fp64 references); `defer_reduce=False` runs every column reduction
+    as it occurs instead of batching them at the end of backward."""
+
+    _NAMES = {"gemm": "GEMM_MODE", "fwd": "FWD_MODE", "bwd": "BWD_MODE", "wgrad": "WGRAD_MODE", "attn": "ATTN_MODE",
+              "attn_fwd": "ATTN_FWD_MODE", "attn_bwd": "ATTN_BWD_MODE", "defer_reduce": "DEFER_REDUCE"}
+
+    def __init__(self, **forms):
+        unknown = set(forms) - set(self._NAMES)
+        if unknown:
+            raise TypeError(f"cross_check_forms: unknown form(s) {sorted(unknown)}")
+        if forms.get("gemm") == "f32":         # the fp32-MFMA form of everything, as the old process-wide switch meant it
+            forms = dict({"attn": "f32", "attn_fwd": "f32", "attn_bwd": "f32", "wgrad": "f32"}, **forms)
+        self.forms, self.saved = forms, {}
+
+    def __enter__(self):
+        g = globals()
+        for k, v in self.forms.items():
+            self.saved[k] = g[self._NAMES[k]]
+            g[self._NAMES[k]] = v
+        return self
+
+    def __exit__(self, *exc):
+        g = globals()
+        for k, v in self.saved.items():
+            g[self._NAMES[k]] = v
 
 
 def _fwd_h3(K: int, N: int, channels: int = 0) -> bool:
@@ -251,7 +282,7 @@ def _amax_slots(device, zero: bool) -> torch.Tensor:
 # again, defensively, before a collective over the bucket and before the optimizer reads it.  Nothing is process-global:
 # the queue and its "callback registered" flag belong to the bucket, and `FlatGradBucket.zero()` drops whatever a backward
 # pass that raised (its callback never ran) left behind.
-DEFER_REDUCE = os.environ.get("TTTS_DEFER_REDUCE", "1") == "1"
+DEFER_REDUCE = True          # tests flip it through `cross_check_forms(defer_reduce=False)`
 
 
 class ReduceQueue:
@@ -347,7 +378,7 @@ class _PlaneEntry:
     __slots__ = ("wref", "off", "mode", "rows", "cols", "c2", "taps", "planes", "tag")
 
 
-_BATCHED_SPLIT = os.environ.get("TTTS_BATCHED_SPLIT", "1") == "1"
+_BATCHED_SPLIT = True
 _plane_entries: list = []        # every (weight, mode) split so far, for the one-launch refresh after an optimizer step
 _plane_tables: dict = {}         # flat-storage address -> (signature, device descriptor table, pinned host copy, total blocks)
 
