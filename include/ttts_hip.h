@@ -161,6 +161,24 @@ int ttts_amax_partials(const float* x, int64_t n, float* partials /* TTTS_AMAX_S
 int ttts_linear_bwd_data_h3(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
                             int K, const float* relu_out, float relu_scale, const float* dy_amax, float* dx_amax_out,
                             void* stream);
+/* ---- fp16x3 with an IMAGE activation operand (ABI v10; transformertts_amd/csrc/gemm_h3i.hip).  The kernels above split
+ * the fp32 activation while they stage it (registers, 3.5 VALU instructions per MFMA, one k-tile of requests in flight per
+ * CU).  Here the producer of the activation writes it already split: an IMAGE is row-major, a row of K values is K/16
+ * groups of 64 bytes = {16 f16 "hi", 16 f16 "lo"} of x * 2^e_row (4 bytes per element, as fp32) with a PER-ROW power of two
+ * that puts the row's maximum in [2^11, 2^12); row_inv[row] = 2^-e_row.  A row scale of the left operand factors out of the
+ * output row, so the GEMM undoes it in its epilogue.  Both operands are then staged by LDS-DMA (no staging registers), on a
+ * 128 x 256 tile with two workgroups per CU.  ttts_act_image makes an image from fp32 (K % 16 == 0, K <= 1024);
+ * ttts_layernorm_fwd / _bwd emit one next to their fp32 output (their *_image_out arguments).  Replaces the same call
+ * sites as ttts_linear_fwd_h3 / ttts_linear_bwd_data_h3 (torch F.linear inside nn.MultiheadAttention / _ff_block,
+ * torch/nn/modules/transformer.py:951-982,1158-1199, reached from model/model.py:189-213 and model/layers.py:29-74);
+ * no row shift, K % 32 == 0, N % 4 == 0. */
+int ttts_act_image(const float* x, void* image, float* row_inv, int64_t M, int K, void* stream);
+int ttts_linear_fwd_h3i(const void* x_image, const float* x_row_inv, const void* w_planes, const float* bias,
+                        const float* residual, float* y, int64_t M, int N, int K, int act, float drop_p, uint64_t seed,
+                        const uint64_t* step_seed, float* y_amax_out, void* stream);
+int ttts_linear_bwd_data_h3i(const void* dy_image, const float* dy_row_inv, const void* wt_planes, const float* residual,
+                             float* dx, int64_t M, int N, int K, const float* relu_out, float relu_scale,
+                             float* dx_amax_out, void* stream);
 int ttts_conv1d_bwd_data_h3(const float* dy, const void* planes_bwd, float* dx, int B, int T, int cin, int cout, int taps,
                             const float* dy_amax, void* stream);
 int ttts_linear_bwd_data_x6(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,

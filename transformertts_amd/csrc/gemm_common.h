@@ -53,6 +53,9 @@ struct GemmArgs {
     // fp16x3 kernel: NULL, or a caller-zeroed TTTS_AMAX_SLOTS-slot array that receives max|C| (amax_publish): the output is a
     // gradient that another fp16x3 GEMM will consume
     float* c_amax;
+    // image-operand kernel (gemm_h3i.hip) only: A is an activation IMAGE (rows of K/16 groups {16 f16 hi, 16 f16 lo} of
+    // x * 2^e_row) and a_row_inv[row] = 2^-e_row, the factor its output row is scaled back by; NULL for every other kernel
+    const float* a_row_inv;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -217,5 +220,8 @@ int dispatch_h3(const GemmArgs& g, hipStream_t stream);
 // row-chunk partials the fp16x3 forward writes into GemmArgs::bn_ws for an M x N x K problem (0: its tile shape cannot)
 int h3_bn_blocks(long M, long N, long K);
 int dispatch_wgrad_h3(const GemmArgs& g, int zdim, int tile, hipStream_t stream);
+// image-operand fp16x3 GEMM (gemm_h3i.hip): both operands staged by LDS-DMA, 128 x 256 tile, two workgroups per CU
+bool h3i_supports(const GemmArgs& g);
+int dispatch_h3i(const GemmArgs& g, hipStream_t stream);
 
 }  // namespace ttts

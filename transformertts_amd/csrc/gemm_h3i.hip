@@ -1,0 +1,402 @@
+// fp16x3 GEMM whose ACTIVATION operand arrives already split ("image" operand): gemm_h3i_kernel.
+//
+// gemm_h3.hip splits the fp32 activation while it stages it: the operand has to pass through registers (3.5 VALU
+// instructions per MFMA in the loader, 64 KB of staging registers per workgroup, ONE k-tile of requests in flight per CU),
+// and DESIGN.md section 9.7 shows the three costs of a K = 256 tile -- operand round trips, MFMAs, the 256 KB store burst --
+// running one after the other.  Here both operands are bytes:
+//   * the activation is an IMAGE written by its producer (LayerNorm forward / backward, ttts_act_image): row-major, a row of
+//     K values is K/16 groups of 64 bytes = 16 f16 "hi" then 16 f16 "lo" of x * 2^e_row -- the same 4 bytes per element
+//     as fp32 -- with a PER-ROW power-of-two scale (the row's maximum lands in [2^11, 2^12)); 2^-e_row sits in a float per
+//     row.  A row scale of A factors out of C's row, so it is undone where the accumulator leaves the registers (in the
+//     transposed accumulator layout a lane IS an output row);
+//   * the weight planes are the fp16x3 image of gemm_h3.hip, unchanged ([K/32][plane][N][32]);
+//   * both are staged by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no VALU), three 16-deep k-tiles in an
+//     LDS ring (3 x 24 KB), two k-tiles in flight behind a COUNTED s_waitcnt vmcnt and one raw s_barrier per k-tile;
+//   * the tile is 128 x 256 with 4 waves (64 x 128 per wave, 128 accumulator registers), so TWO workgroups share a CU:
+//     one's store burst and LDS turn run under the other's MFMAs -- the overlap a single 256 x 256 workgroup per CU cannot
+//     have (vmcnt is one in-order counter per wave: a wave cannot wait for loads issued behind its own stores);
+//   * the operand stream does not stop at a tile boundary: the first two k-tiles of the workgroup's next tile are requested
+//     before the epilogue's stores, so they are older than the stores in the counter and the next tile starts on landed data.
+// N = 256 outputs (out-projection, FFN2) keep whole rows inside one tile.
+//
+// LDS stage (24 KB): activation rows [128][64 B] then weight rows [256][64 B]; a row's 64 bytes are four 16-byte chunks
+// {hi k0-7, hi k8-15, lo k0-7, lo k8-15}, chunk index XORed with (row >> 2) & 3 -- the DMA writes lane-linearly, so the
+// permutation is applied to the SOURCE address of each lane and again by the fragment reads (conflict-free ds_read_b128).
+#include "gemm_common.h"
+
+namespace ttts {
+
+constexpr int IBM = 128, IBN = 256, IBK = 16, INST = 3;
+constexpr int I_A_BYTES = IBM * 64, I_B_BYTES = IBN * 64, I_STAGE = I_A_BYTES + I_B_BYTES;
+constexpr int I_LOADS = 6;              // LDS-DMA instructions per wave and k-tile: 2 activation + 4 weight pieces of 1 KB
+constexpr int I_EP_STORES = 32;         // store instructions per wave and tile: 8 accumulator blocks x 4, all unconditional
+
+__device__ __forceinline__ uint32_t lds_addr_i(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// 64 lanes x 16 bytes from (descriptor, per-lane byte offset + scalar byte offset) to LDS at lds_dst + 16 * lane.  Inline
+// assembly: outside hipcc's counter bookkeeping (with the builtin it drains vmcnt(0) before the next LDS read of any address);
+// the kernel counts its own.  M0 = LDS destination base, saved and restored inside the statement.
+__device__ __forceinline__ void dma16b(u32x4 rsrc, uint32_t voff, uint32_t soff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(N) : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[INST * I_STAGE / 4];
+    const uint64_t seed_eff = site_seed(g.seed, g.step_seed);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nkt = g.K / IBK;
+    const int nx = (g.N + IBN - 1) / IBN;
+    const int ntiles = nx * ((g.M + IBM - 1) / IBM);
+    float w_inv;
+    {
+        float w_scale;
+        h3_operand_scale(g.b_amax, g.b_amax_n, lane, w_scale, w_inv);       // the planes already carry w_scale
+        asm volatile("" :: "s"(w_inv));     // the wait for this load sits HERE, in front of the first DMA, not in the first epilogue
+    }
+    auto tile_coords = [&](int bid, int& m0, int& n0) {     // XCD-aware numbering of gemm_h3_kernel: column tiles of a row panel share an L2
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int per = ntiles >> 3, rem = ntiles & 7;
+        const int t = xcd * per + min(xcd, rem) + slot;
+        const int ty = t / nx;
+        m0 = ty * IBM;
+        n0 = (t - ty * nx) * IBN;
+    };
+    // ---- loader: lane -> (row r16 of a 16-row piece, LDS chunk slot); the chunk it FETCHES is slot ^ swizzle(row)
+    const int r16 = lane >> 2, c = (lane & 3) ^ ((r16 >> 2) & 3);
+    const uint32_t a_row_bytes = (uint32_t)g.lda * 4u;
+    const uint32_t a_voff = (uint32_t)r16 * a_row_bytes + (uint32_t)c * 16u;
+    const uint32_t b_plane = (uint32_t)g.N * 64u;           // one plane of one 32-deep k-tile of the weight image
+    const uint32_t b_voff = (uint32_t)r16 * 64u + (uint32_t)(c >> 1) * b_plane + (uint32_t)(c & 1) * 16u;
+    const uint32_t lds0 = lds_addr_i(lds);
+    const uint64_t a_base = reinterpret_cast<uint64_t>(g.A), b_base = reinterpret_cast<uint64_t>(g.B);
+    int ld_bid = blockIdx.x, ld_kt = 0, ld_stage = 0;
+    uint32_t ld_a0 = 0, ld_b0 = 0, ld_abytes = 0, ld_bbytes = 0;
+    auto set_ld_tile = [&](int bid) {       // (no tile left: empty descriptors -- the loads return without touching memory, and the
+        const bool live = bid < ntiles;     //  k-tile loop needs no variant that stops requesting)
+        int m0, n0;
+        tile_coords(live ? bid : 0, m0, n0);
+        ld_a0 = (uint32_t)((long)(m0 + wave * 32) * a_row_bytes);
+        ld_b0 = (uint32_t)(n0 + wave * 64) * 64u;
+        ld_abytes = live ? g.a_bytes : 0u;
+        ld_bbytes = live ? g.b_bytes : 0u;
+    };
+    auto issue = [&]() {
+        const u32x4 rsrcA = {(uint32_t)a_base, (uint32_t)(a_base >> 32) & 0xffffu, ld_abytes, 0x00020000u};
+        const u32x4 rsrcB = {(uint32_t)b_base, (uint32_t)(b_base >> 32) & 0xffffu, ld_bbytes, 0x00020000u};
+        const uint32_t dst = lds0 + (uint32_t)ld_stage * I_STAGE;
+        const uint32_t a_s = ld_a0 + (uint32_t)ld_kt * 64u;
+        const uint32_t b_s = ld_b0 + (uint32_t)(ld_kt >> 1) * 2u * b_plane + (uint32_t)(ld_kt & 1) * 32u;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            dma16b(rsrcA, a_voff, __builtin_amdgcn_readfirstlane(a_s + e * 16u * a_row_bytes),
+                   __builtin_amdgcn_readfirstlane(dst + (uint32_t)(2 * wave + e) * 1024u));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            dma16b(rsrcB, b_voff, __builtin_amdgcn_readfirstlane(b_s + e * 1024u),
+                   __builtin_amdgcn_readfirstlane(dst + I_A_BYTES + (uint32_t)(4 * wave + e) * 1024u));
+        ld_stage = ld_stage == INST - 1 ? 0 : ld_stage + 1;
+        if (++ld_kt == nkt) {
+            ld_kt = 0;
+            ld_bid += gridDim.x;
+            set_ld_tile(ld_bid);
+        }
+    };
+    // ---- fragments: lane -> row l31 of a 32-row block, chunk (plane * 2 + half) ^ swizzle
+    const int sw = (l31 >> 2) & 3;
+    const uint32_t ch_hi = (uint32_t)((half ^ sw) * 16), ch_lo = (uint32_t)(((2 + half) ^ sw) * 16);
+    const uint32_t fa_off = (uint32_t)(wm * 64 + l31) * 64u;
+    const uint32_t fb_off = I_A_BYTES + (uint32_t)(wn * 128 + l31) * 64u;
+    f32x16 acc[2][4];
+    auto compute = [&](int stage) {
+        const char* st = reinterpret_cast<const char*>(lds) + stage * I_STAGE;
+        f16x8 fa[2][2], fb[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[0][i] = *reinterpret_cast<const f16x8*>(st + fa_off + i * 2048 + ch_hi);
+            fa[1][i] = *reinterpret_cast<const f16x8*>(st + fa_off + i * 2048 + ch_lo);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fb[0][j] = *reinterpret_cast<const f16x8*>(st + fb_off + j * 2048 + ch_hi);
+            fb[1][j] = *reinterpret_cast<const f16x8*>(st + fb_off + j * 2048 + ch_lo);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // the WEIGHT fragment is the MFMA's first operand: the accumulator block is C^T (lane = output row, registers
+                // 4q .. 4q+3 = four consecutive output columns); small terms first, as gemm_h3_kernel
+                f32x16 cc = acc[i][j];
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[0][j], fa[1][i], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[1][j], fa[0][i], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[0][j], fa[0][i], cc, 0, 0, 0);
+                acc[i][j] = cc;
+            }
+    };
+
+    set_ld_tile(ld_bid);
+    issue();                        // k-tiles 0 and 1 of the first tile (K >= 32)
+    issue();
+    int cstage = 0;
+    bool after_ep = false;
+    for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
+        int m0, n0;
+        tile_coords(bid, m0, n0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            // k-tile kt has landed when all but the requests BEHIND it have: the next k-tile's I_LOADS and -- for the two k-tiles
+            // requested before the previous tile's epilogue -- that epilogue's stores (a lower bound of what was issued since is
+            // what makes the count safe: every store of the epilogue is unconditional)
+            if (after_ep && kt < 2) wait_vm_barrier<I_LOADS + I_EP_STORES>();
+            else wait_vm_barrier<I_LOADS>();
+            // behind the barrier every wave has finished the products of k-tile kt-1 (or the epilogue's slabs): that stage is free
+            issue();
+            compute(cstage);
+            cstage = cstage == INST - 1 ? 0 : cstage + 1;
+        }
+        asm volatile("s_barrier" ::: "memory");          // every wave has its last fragments: the stage becomes the epilogue's slabs
+        const int ep_stage = cstage == 0 ? INST - 1 : cstage - 1;
+
+        // ---------------- epilogue: each 32 x 32 accumulator block is scaled by its lane's row factor, turned through a 4 KB slab
+        // (row-major, 16-byte chunk ^= row & 7: conflict-free both ways) and leaves as whole 128-byte lines
+        {
+            float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + ep_stage * I_STAGE) + wave * 1024;
+            const int rsub = lane >> 3, ch = lane & 7;
+            const int col0 = n0 + wn * 128 + ch * 4;
+            const bool has_res = g.residual != nullptr, has_gate = g.relu_out != nullptr, do_drop = g.drop_thr != 0u;
+            const bool want_max = g.c_amax != nullptr;
+            const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (uint32_t)((long)g.M * g.ldc * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(has_res ? g.residual : g.A), 0, has_res ? (uint32_t)((long)g.M * g.ldr * 4) : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(has_gate ? g.relu_out : g.A), 0, has_gate ? (uint32_t)((long)g.M * g.ldc * 4) : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsrcBias = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(g.bias != nullptr ? g.bias : g.A), 0, g.bias != nullptr ? (uint32_t)g.N * 4u : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.a_row_inv), 0,
+                                                                                  (uint32_t)g.M * 4u, 0x00020000);
+            float rs[2];
+            float4 bias4[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                rs[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcS, (m0 + wm * 64 + i * 32 + l31) * 4, 0, 0)) * w_inv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias4[j] = buf_load4(rsrcBias, (col0 + j * 32 < g.N) ? (uint32_t)(col0 + j * 32) * 4u : OOB);
+            const float relu_lo = (g.act == 1) ? 0.f : -__builtin_inff();
+            float cmax = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const long row_blk = (long)m0 + wm * 64 + i * 32;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = col0 + j * 32;
+                    const bool col_ok = col < g.N;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(slab + l31 * 32 + (((2 * q + half) ^ (l31 & 7)) * 4)) =
+                            make_float4(acc[i][j][4 * q] * rs[i], acc[i][j][4 * q + 1] * rs[i], acc[i][j][4 * q + 2] * rs[i],
+                                        acc[i][j][4 * q + 3] * rs[i]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    float4 r4[4], g4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const long row = row_blk + u * 8 + rsub;
+                        if (has_res) r4[u] = buf_load4(rsrcR, col_ok ? (uint32_t)((row * g.ldr + col) * 4) : OOB);
+                        if (has_gate) g4[u] = buf_load4(rsrcG, col_ok ? (uint32_t)((row * g.ldc + col) * 4) : OOB);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int srow = u * 8 + rsub;
+                        const long row = row_blk + srow;
+                        const float4 a4 = *reinterpret_cast<const float4*>(slab + srow * 32 + ((ch ^ (srow & 7)) * 4));
+                        float v[4] = {a4.x + bias4[j].x, a4.y + bias4[j].y, a4.z + bias4[j].z, a4.w + bias4[j].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_lo);
+                        if (do_drop) {
+                            bool kp[4];
+                            keep_quad(seed_eff, (uint64_t)row * (uint64_t)g.N + (uint64_t)col, g.drop_thr, kp);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = kp[e] ? v[e] * g.drop_scale : 0.f;
+                        }
+                        if (has_gate) {
+                            const float gg[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gg[e] > 0.f ? v[e] * g.relu_scale : 0.f;
+                        }
+                        if (has_res) { v[0] += r4[u].x; v[1] += r4[u].y; v[2] += r4[u].z; v[3] += r4[u].w; }
+                        // unconditional: a row past M lies beyond the descriptor, a column group past N gets the out-of-range offset
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsrcC,
+                            col_ok ? (int)(uint32_t)((row * g.ldc + col) * 4) : (int)OOB, 0, 0);
+                        if (want_max) {
+                            float mx = fmaxf(fmaxf(cmax, fabsf(v[0])), fabsf(v[1]));
+                            mx = fmaxf(fmaxf(mx, fabsf(v[2])), fabsf(v[3]));
+                            cmax = (col_ok && row < g.M) ? mx : cmax;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+            }
+            if (want_max) amax_publish(cmax, g.c_amax, bid);
+        }
+        after_ep = true;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // requests made for a tile that does not exist must not outlive the wave
+}
+
+bool h3i_supports(const GemmArgs& g) {
+    return g.a_row_inv != nullptr && g.K % 32 == 0 && g.K >= 32 && g.N % 4 == 0 && g.T <= 0 && g.bn_ws == nullptr &&
+           (uint64_t)g.N * g.K * 4 < (1ull << 32);
+}
+
+int dispatch_h3i(const GemmArgs& g, hipStream_t stream) {
+    const long ldmax = g.ldc > g.ldr ? g.ldc : g.ldr;
+    if (((long)g.M + 256) * ldmax * 4 >= (1L << 32)) {
+        set_error("fp16x3 GEMM (image operand): output larger than 4 GiB (M=%d, row stride %ld)", g.M, ldmax);
+        return TTTS_ERR_INVALID;
+    }
+    if (!h3i_supports(g)) {
+        set_error("fp16x3 GEMM (image operand): unsupported shape M=%d N=%d K=%d", g.M, g.N, g.K);
+        return TTTS_ERR_INVALID;
+    }
+    const long ntiles = (long)cdiv(g.N, IBN) * cdiv(g.M, IBM);
+    // two workgroups per CU, and no more of them than level rounds need (a multiple of 8: virtual ids keep their XCD)
+    const long rounds = (ntiles + 511) / 512;
+    long gsz = ((ntiles + rounds - 1) / rounds + 7) / 8 * 8;
+    if (gsz > 512) gsz = 512;
+    dim3 grid((unsigned)(ntiles < 512 ? ntiles : gsz), 1, 1);
+    hipLaunchKernelGGL(gemm_h3i_kernel, grid, dim3(256), 0, stream, g);
+    TTTS_LAUNCH_CHECK("gemm_h3i_kernel");
+    return TTTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 (M x K) -> activation image + per-row inverse scale.  One wave per row, a lane owns NV float4 (K = 256 NV' or any
+// multiple of 16 up to 1024: lanes past the row's end idle).  The stand-alone form of what the producers do in their epilogues.
+template <int NV>
+__global__ __launch_bounds__(256) void act_image_kernel(const float* __restrict__ x, unsigned short* __restrict__ img,
+                                                        float* __restrict__ row_inv, long M, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    float4 v[NV];
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c4 = lane + 64 * k;
+        v[k] = (c4 * 4 < K) ? reinterpret_cast<const float4*>(x + row * K)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[k].x), fabsf(v[k].y))), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
+    }
+    m = wave_max(m);
+    float sc, inv;
+    h3_pow2_scale(m, sc, inv);
+    unsigned short* out = img + row * (long)K * 2;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c4 = lane + 64 * k;
+        if (c4 * 4 < K) {
+            uint2 hi, lo;
+            split2_pair(f32x2{v[k].x, v[k].y} * sc, hi.x, lo.x);
+            split2_pair(f32x2{v[k].z, v[k].w} * sc, hi.y, lo.y);
+            const int kk = c4 * 4;                                  // group kk / 16: 32 halfwords, hi at +0, lo at +16
+            unsigned short* p = out + (kk >> 4) * 32 + (kk & 15);
+            *reinterpret_cast<uint2*>(p) = hi;
+            *reinterpret_cast<uint2*>(p + 16) = lo;
+        }
+    }
+    if (lane == 0) row_inv[row] = inv;
+}
+
+static GemmArgs h3i_base_args() {
+    GemmArgs g;
+    g.A = g.B = nullptr; g.C = nullptr;
+    g.M = g.N = g.K = 0; g.lda = g.ldb = g.ldc = 0;
+    g.T = 0; g.cin = 1; g.shift0 = 0; g.shift_step = 0; g.ztaps = 1;
+    g.kt_per_split = 1 << 30; g.c_zstride = 0;
+    g.bias = nullptr; g.act = 0; g.drop_scale = 1.f; g.drop_thr = 0; g.seed = 0; g.step_seed = nullptr;
+    g.residual = nullptr; g.ldr = 0; g.colsum = nullptr; g.a_bytes = 0; g.b_bytes = 0;
+    g.relu_out = nullptr; g.relu_scale = 1.f;
+    g.a_amax = nullptr; g.a_amax_n = 0; g.b_amax = nullptr; g.b_amax_n = 0; g.c_amax = nullptr; g.bn_ws = nullptr;
+    g.a_row_inv = nullptr;
+    return g;
+}
+
+}  // namespace ttts
+
+using namespace ttts;
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int ttts_act_image(const float* x, void* image, float* row_inv, int64_t M, int K, void* stream) {
+    TTTS_REQUIRE(x && image && row_inv, "act_image: null pointer");
+    TTTS_REQUIRE(M > 0 && K > 0 && K % 16 == 0 && K <= 1024, "act_image: K=%d must be a multiple of 16, at most 1024", K);
+    TTTS_REQUIRE(al16(x) && al16(image), "act_image: pointers must be 16-byte aligned");
+    const dim3 grid((unsigned)cdiv(M, 4));
+    if (K <= 256) hipLaunchKernelGGL((act_image_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)image, row_inv, (long)M, K);
+    else if (K <= 512) hipLaunchKernelGGL((act_image_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)image, row_inv, (long)M, K);
+    else hipLaunchKernelGGL((act_image_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)image, row_inv, (long)M, K);
+    TTTS_LAUNCH_CHECK("act_image_kernel");
+    return TTTS_OK;
+}
+
+extern "C" int ttts_linear_fwd_h3i(const void* x_image, const float* x_row_inv, const void* w_planes, const float* bias,
+                                   const float* residual, float* y, int64_t M, int N, int K, int act, float drop_p, uint64_t seed,
+                                   const uint64_t* step_seed, float* y_amax_out, void* stream) {
+    TTTS_REQUIRE(x_image && x_row_inv && w_planes && y, "linear_fwd_h3i: null pointer");
+    TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_fwd_h3i: bad dims");
+    TTTS_REQUIRE(K % 32 == 0 && N % 4 == 0, "linear_fwd_h3i: K=%d must be a multiple of 32 and N=%d of 4", K, N);
+    TTTS_REQUIRE(al16(x_image) && al16(w_planes) && al16(y), "linear_fwd_h3i: pointers must be 16-byte aligned");
+    TTTS_REQUIRE(act == 0 || act == 1, "linear_fwd_h3i: act must be 0 (none) or 1 (relu)");
+    TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "linear_fwd_h3i: dropout p out of [0,1)");
+    TTTS_REQUIRE((uint64_t)M * K * 4 < (1ull << 32) && (uint64_t)N * K * 4 < (1ull << 32), "linear_fwd_h3i: operand larger than 4 GiB");
+    GemmArgs g = h3i_base_args();
+    g.A = (const float*)x_image; g.B = (const float*)w_planes; g.C = y; g.M = (int)M; g.N = N; g.K = K;
+    g.lda = K; g.ldb = K; g.ldc = N;
+    g.a_bytes = (uint32_t)((uint64_t)M * K * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 4);
+    g.cin = K;
+    g.bias = bias; g.act = act;
+    if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; g.step_seed = step_seed; }
+    g.residual = residual; g.ldr = N;
+    g.a_row_inv = x_row_inv;
+    g.b_amax = h3_plane_tail(w_planes, N, K); g.b_amax_n = 1;
+    g.c_amax = y_amax_out;
+    return dispatch_h3i(g, (hipStream_t)stream);
+}
+
+extern "C" int ttts_linear_bwd_data_h3i(const void* dy_image, const float* dy_row_inv, const void* wt_planes, const float* residual,
+                                        float* dx, int64_t M, int N, int K, const float* relu_out, float relu_scale,
+                                        float* dx_amax_out, void* stream) {
+    // dx[M,K] = dy[M,N] . w[N,K] (+ residual): the gradient is the image operand; wt_planes = weight_split mode 5 (w^T)
+    TTTS_REQUIRE(dy_image && dy_row_inv && wt_planes && dx, "linear_bwd_data_h3i: null pointer");
+    TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_bwd_data_h3i: bad dims");
+    TTTS_REQUIRE(N % 32 == 0 && K % 4 == 0, "linear_bwd_data_h3i: N=%d must be a multiple of 32 and K=%d of 4", N, K);
+    TTTS_REQUIRE(al16(dy_image) && al16(wt_planes) && al16(dx), "linear_bwd_data_h3i: pointers must be 16-byte aligned");
+    TTTS_REQUIRE((uint64_t)M * N * 4 < (1ull << 32) && (uint64_t)N * K * 4 < (1ull << 32), "linear_bwd_data_h3i: operand larger than 4 GiB");
+    GemmArgs g = h3i_base_args();
+    g.A = (const float*)dy_image; g.B = (const float*)wt_planes; g.C = dx; g.M = (int)M; g.N = K; g.K = N;
+    g.lda = N; g.ldb = N; g.ldc = K; g.cin = N;
+    g.a_bytes = (uint32_t)((uint64_t)M * N * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 4);
+    g.residual = residual; g.ldr = K;
+    g.relu_out = relu_out; g.relu_scale = relu_scale;
+    g.a_row_inv = dy_row_inv;
+    g.b_amax = h3_plane_tail(wt_planes, K, N); g.b_amax_n = 1;
+    g.c_amax = dx_amax_out;
+    return dispatch_h3i(g, (hipStream_t)stream);
+}

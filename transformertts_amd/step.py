@@ -154,6 +154,7 @@ class TrainStep:
                 torch.cuda.synchronize()     # the victim's last replay may still be running
                 self._slots.pop(victim).drop_graphs()
                 self.evictions += 1
+                self._pool_check()
             B, Tp, Tm = key
             src = {k: batch[k] for k in _KEYS}
             if any(v.device != self.device for v in src.values()):
@@ -213,6 +214,12 @@ class TrainStep:
         self.bucket.finish_allreduce(self.group)     # waits for an overlapped tail and reduces the rest; no-op at N = 1
         self.opt.step()
 
+    def _pool_check(self) -> None:
+        """The shared capture pool lives as long as one graph captured into it does: with the last graph gone the handle
+        is stale (the allocator asserts on it), so the next capture starts a new pool."""
+        if not any(s.graphs for s in self._slots.values()):
+            self._pool = None
+
     def _ensure_planes(self) -> None:
         if self._planes is None or not self._planes.valid():
             if torch.cuda.is_current_stream_capturing():
@@ -225,6 +232,7 @@ class TrainStep:
                 for slot in self._slots.values():
                     slot.drop_graphs()
                 self.recaptures += 1
+                self._pool_check()
                 self._planes = ops.PlaneTable(self.lm.model)
                 self._planes.refresh()       # whatever edited the parameters: the planes follow now, wherever the window stands
                 return
