@@ -432,18 +432,22 @@ __device__ __forceinline__ const long* batched_desc(const long* __restrict__ des
 __global__ __launch_bounds__(256) void weight_tail_zero_batched_kernel(const long* __restrict__ descs, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const long* d = descs + i * 8;
-        if (d[4] >= 4)
+        if (d[4] >= 4) {
+            const bool conv = h3_mode_base(d[4]) >= 2;
             *reinterpret_cast<float*>(reinterpret_cast<char*>(d[1]) +
-                                      h3_plane_bytes(d[2], h3_image_cols(d[3], d[4] >= 6 ? (int)d[5] : 0, d[4] >= 6 ? (int)d[6] : 0))) = 0.f;
+                                      h3_plane_bytes(d[2], h3_image_cols(d[3], conv ? (int)d[5] : 0, conv ? (int)d[6] : 0))) = 0.f;
+        }
     }
 }
 __global__ __launch_bounds__(256) void weight_amax_batched_kernel(const long* __restrict__ descs, int n) {
     const long blk = blockIdx.x;
     const long* d = batched_desc(descs, n, blk);
-    if (d[4] >= 4)
+    if (d[4] >= 4) {
+        const bool conv = h3_mode_base(d[4]) >= 2;
         weight_amax_h3_unit(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
-                            h3_image_cols(d[3], d[4] >= 6 ? (int)d[5] : 0, d[4] >= 6 ? (int)d[6] : 0), blk - d[7],
-                            h3_split_units(d[2], d[3], (int)d[4], (int)d[5]));
+                            h3_image_cols(d[3], conv ? (int)d[5] : 0, conv ? (int)d[6] : 0), blk - d[7],
+                            h3_split_units(d[2], d[3], h3_mode_base(d[4]), (int)d[5]));
+    }
 }
 
 __global__ __launch_bounds__(256) void weight_split_batched_kernel(const long* __restrict__ descs, int n) {
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(256) void weight_split_batched_kernel(const long* _
     const long* d = batched_desc(descs, n, blk);
     if (d[4] >= 4)      // modes 4-7: the fp16x3 image of modes 0-3 (block-uniform branch), a 32 x 32 tile per workgroup
         weight_split_h3_tile(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2],
-                             (int)d[3], (int)d[4] - 4, (int)d[5], (int)d[6], blk - d[7], t);
+                             (int)d[3], h3_mode_base(d[4]), (int)d[5], (int)d[6], blk - d[7], t, h3_mode_k16(d[4]));
     else
         weight_split_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
                          (int)d[4], (int)d[5], (int)d[6], (blk - d[7]) * 256 + threadIdx.x);
@@ -1209,7 +1213,7 @@ size_t ttts_split_image_bytes(int64_t rows, int64_t cols, int mode, int channels
     // bytes of the image ttts_weight_split writes in `mode`: three bf16 planes (modes 0-3), or two f16 planes of the
     // channel-padded image plus the 16-byte tail (modes 4-7)
     if (mode < 4) return ttts_split_bytes(rows, cols);
-    const bool conv = (mode & 3) >= 2;
+    const bool conv = h3_mode_base(mode) >= 2;
     return h3_plane_bytes(rows, h3_image_cols(cols, conv ? channels_per_tap : 0, conv ? taps : 0)) + 16;
 }
 
@@ -1217,15 +1221,15 @@ int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode
                       void* stream) {
     // planes[3][rows][cols] bf16 (hi, mid, lo) of a weight re-laid as the K-contiguous B operand; modes in gemm.hip
     TTTS_REQUIRE(w && planes && rows > 0 && cols > 0, "weight_split: bad arguments");
-    TTTS_REQUIRE(mode >= 0 && mode <= 7, "weight_split: mode must be 0..7");
+    TTTS_REQUIRE(mode >= 0 && mode <= 11, "weight_split: mode must be 0..11");
     TTTS_REQUIRE(cols % (mode >= 4 ? 4 : BK) == 0, "weight_split: cols=%d must be a multiple of %d", cols, mode >= 4 ? 4 : BK);
-    TTTS_REQUIRE((mode & 3) < 2 || (channels_per_tap > 0 && taps > 0 && cols == channels_per_tap * taps),
+    TTTS_REQUIRE((mode < 4 ? mode : h3_mode_base(mode)) < 2 || (channels_per_tap > 0 && taps > 0 && cols == channels_per_tap * taps),
                  "weight_split: conv modes need cols == channels_per_tap * taps");
     if (mode >= 4) {
         // (the fp16x3 image pads the channels of a tap -- all columns of a linear weight -- to a multiple of 32 with zeros:
         // size it with ttts_split_image_bytes)
-        TTTS_REQUIRE((mode & 3) < 2 || channels_per_tap % 4 == 0, "weight_split: fp16x3 conv image needs channels %% 4 == 0");
-        launch_weight_split_h3(w, planes, rows, cols, mode - 4, channels_per_tap, taps, (hipStream_t)stream);
+        TTTS_REQUIRE(h3_mode_base(mode) < 2 || channels_per_tap % 4 == 0, "weight_split: fp16x3 conv image needs channels %% 4 == 0");
+        launch_weight_split_h3(w, planes, rows, cols, h3_mode_base(mode), channels_per_tap, taps, (hipStream_t)stream, h3_mode_k16(mode));
         TTTS_LAUNCH_CHECK("weight_split_h3_kernel");
         return TTTS_OK;
     }
@@ -1239,7 +1243,7 @@ int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode
 int64_t ttts_weight_split_units(int64_t rows, int64_t cols, int mode, int channels_per_tap) {
     // workgroups an entry of ttts_weight_split_batched takes: 256 elements each (bf16x6 images), a 32-row x 32-channel
     // tile over all taps each (fp16x3 images)
-    return mode >= 4 ? h3_split_units(rows, cols, mode, channels_per_tap) : (rows * cols + 255) / 256;
+    return mode >= 4 ? h3_split_units(rows, cols, h3_mode_base(mode), channels_per_tap) : (rows * cols + 255) / 256;
 }
 
 int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks, void* stream) {

@@ -109,6 +109,9 @@ __device__ __forceinline__ void split2_pair(f32x2 x, uint32_t& hi, uint32_t& lo)
 // ---- the split of one weight into its fp16x3 image, in WORK UNITS of one 256-thread workgroup each: unit u is the 32-row x
 // 32-channel tile (row block u / channel blocks, channel block u % channel blocks) of the weight, all taps of it.
 // h3_split_units = how many an entry has (host and device agree: the prefix sums of the batched table are built from it).
+// ttts_weight_split modes 4-7 and 8-11 are the fp16x3 images of modes 0-3: base = which matrix, k16 = which layout
+__host__ __device__ __forceinline__ int h3_mode_base(long mode) { return (int)((mode - 4) & 3); }
+__host__ __device__ __forceinline__ bool h3_mode_k16(long mode) { return mode >= 8; }
 constexpr int H3_SPLIT_TAPS = 8;        // taps staged per pass of a tile (longer kernels take several passes)
 __host__ __device__ __forceinline__ long h3_split_units(long R, long C, int mode, int c2) {
     const long chans = (mode & 3) >= 2 ? c2 : C;
@@ -149,8 +152,12 @@ __device__ __forceinline__ void weight_amax_h3_unit(const float* __restrict__ w,
 // order the SOURCE is contiguous in (rows of channels, columns of rows, or a row's / a channel's run over all taps), goes
 // through LDS (t: H3_SPLIT_TAPS x 32 x 33 floats) and leaves as 2 KB runs of each plane -- one k-tile's 32 rows, 8 bytes per
 // lane.  Channels past the tap's last one are staged as zeros, which writes the image's padding.
+// k16 = true (modes 8-11 of ttts_weight_split): the K16-MAJOR image the image-operand kernel (gemm_h3i.hip) stages by LDS-DMA --
+// [c'/16][r][{16 f16 hi, 16 f16 lo}], i.e. one 64-byte group per (16-deep k-tile, row) and the 16 KB a 256-row tile needs per
+// k-tile in ONE contiguous run of whole 128-byte lines.  Same bytes, same padding, same tail.
 __device__ __forceinline__ void weight_split_h3_tile(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
-                                                     int C, int mode, int c2, int taps, long unit, float (*t)[32][33]) {
+                                                     int C, int mode, int c2, int taps, long unit, float (*t)[32][33],
+                                                     bool k16 = false) {
     const int chans = mode >= 2 ? c2 : C;
     if (mode < 2) taps = 1;
     const int ngc = (chans + 31) / 32;
@@ -197,9 +204,9 @@ __device__ __forceinline__ void weight_split_h3_tile(const float* __restrict__ w
                     h[e] = __builtin_bit_cast(unsigned short, hh);
                     l[e] = __builtin_bit_cast(unsigned short, ll);
                 }
-                const long o = ((long)(cp >> 5) * 2 * R + r0 + rr) * 32 + (cp & 31);
+                const long o = k16 ? ((long)(cp >> 4) * R + r0 + rr) * 32 + (cp & 15) : ((long)(cp >> 5) * 2 * R + r0 + rr) * 32 + (cp & 31);
                 *reinterpret_cast<uint2*>(planes + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
-                *reinterpret_cast<uint2*>(planes + o + (long)R * 32) =
+                *reinterpret_cast<uint2*>(planes + o + (k16 ? 16L : (long)R * 32)) =
                     make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
             }
         }
@@ -215,7 +222,8 @@ enum { TILE_AUTO = 0, TILE_64 = 1, TILE_128 = 2, TILE_64x128 = 3, TILE_128x96 = 
 // k-tiles); the caller falls back to the bf16x6 kernel otherwise
 bool h3_supports(const GemmArgs& g);
 int h3_tile_choice(long M, long N, long K);
-void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, int mode, int c2, int taps, hipStream_t stream);
+void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, int mode, int c2, int taps, hipStream_t stream,
+                            bool k16 = false);
 int dispatch_h3(const GemmArgs& g, hipStream_t stream);
 // row-chunk partials the fp16x3 forward writes into GemmArgs::bn_ws for an M x N x K problem (0: its tile shape cannot)
 int h3_bn_blocks(long M, long N, long K);

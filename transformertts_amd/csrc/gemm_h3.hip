@@ -32,20 +32,21 @@ __global__ __launch_bounds__(256) void weight_amax_h3_kernel(const float* __rest
     weight_amax_h3_unit(w, planes, R, C, image_cols, blockIdx.x, gridDim.x);
 }
 __global__ __launch_bounds__(256) void weight_split_h3_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
-                                                              int R, int C, int mode, int c2, int taps) {
+                                                              int R, int C, int mode, int c2, int taps, bool k16) {
     __shared__ float t[H3_SPLIT_TAPS][32][33];
-    weight_split_h3_tile(w, planes, R, C, mode, c2, taps, blockIdx.x, t);
+    weight_split_h3_tile(w, planes, R, C, mode, c2, taps, blockIdx.x, t, k16);
 }
 
 // tail = 0, max|w| into the tail, then the planes scaled by the power of two that follows from it
-void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, int mode, int c2, int taps, hipStream_t stream) {
+void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, int mode, int c2, int taps, hipStream_t stream,
+                            bool k16) {
     const long units = h3_split_units(rows, cols, mode, c2);
     const long image_cols = h3_image_cols(cols, mode >= 2 ? c2 : 0, mode >= 2 ? taps : 0);
     (void)launch_zero(reinterpret_cast<char*>(planes) + h3_plane_bytes(rows, image_cols), 16, stream);
     hipLaunchKernelGGL(weight_amax_h3_kernel, dim3((unsigned)units), dim3(256), 0, stream, w, (unsigned short*)planes, rows,
                        cols, image_cols);
     hipLaunchKernelGGL(weight_split_h3_kernel, dim3((unsigned)units), dim3(256), 0, stream, w, (unsigned short*)planes, rows,
-                       cols, mode, c2, taps);
+                       cols, mode, c2, taps, k16);
 }
 
 // partial maxima of |x|: block b writes max over its grid-stride share to out[b]; blocks past the data write 0

@@ -4,12 +4,14 @@
 // instructions per MFMA in the loader, 64 KB of staging registers per workgroup, ONE k-tile of requests in flight per CU),
 // and DESIGN.md section 9.7 shows the three costs of a K = 256 tile -- operand round trips, MFMAs, the 256 KB store burst --
 // running one after the other.  Here both operands are bytes:
-//   * the activation is an IMAGE written by its producer (LayerNorm forward / backward, ttts_act_image): row-major, a row of
-//     K values is K/16 groups of 64 bytes = 16 f16 "hi" then 16 f16 "lo" of x * 2^e_row -- the same 4 bytes per element
-//     as fp32 -- with a PER-ROW power-of-two scale (the row's maximum lands in [2^11, 2^12)); 2^-e_row sits in a float per
-//     row.  A row scale of A factors out of C's row, so it is undone where the accumulator leaves the registers (in the
-//     transposed accumulator layout a lane IS an output row);
-//   * the weight planes are the fp16x3 image of gemm_h3.hip, unchanged ([K/32][plane][N][32]);
+//   * the activation is an IMAGE written by its producer (LayerNorm forward / backward, ttts_act_image): K16-MAJOR,
+//     [K/16][M][64 B], the 64 bytes of (k-tile, row) being 16 f16 "hi" then 16 f16 "lo" of x * 2^e_row -- the same 4 bytes
+//     per element as fp32 -- with a PER-ROW power-of-two scale (the row's maximum lands in [2^11, 2^12)); 2^-e_row sits in a
+//     float per row.  A row scale of A factors out of C's row, so it is undone where the accumulator leaves the registers (in
+//     the transposed accumulator layout a lane IS an output row);
+//   * the weight image has the same layout ([K/16][N][64 B]: ttts_weight_split modes 8-11), so every LDS-DMA instruction of
+//     either operand moves ONE contiguous KB = eight whole 128-byte lines (a first version read 64-byte pieces of row-major
+//     activations and 32-byte pieces of the [K/32][plane][N][32] planes: twice the lines per byte, and no faster than gemm_h3);
 //   * both are staged by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no VALU), three 16-deep k-tiles in an
 //     LDS ring (3 x 24 KB), two k-tiles in flight behind a COUNTED s_waitcnt vmcnt and one raw s_barrier per k-tile;
 //   * the tile is 128 x 256 with 4 waves (64 x 128 per wave, 128 accumulator registers), so TWO workgroups share a CU:
@@ -23,6 +25,7 @@
 // {hi k0-7, hi k8-15, lo k0-7, lo k8-15}, chunk index XORed with (row >> 2) & 3 -- the DMA writes lane-linearly, so the
 // permutation is applied to the SOURCE address of each lane and again by the fragment reads (conflict-free ds_read_b128).
 #include "gemm_common.h"
+#include <type_traits>
 
 namespace ttts {
 
@@ -46,7 +49,28 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(N) : "memory");
 }
 
+#ifdef TTTS_H3I_STAMPS
+// development aid (tools/h3i_stamps.py; never defined in the product build): per (workgroup, wave) sums of s_memtime ticks spent
+// 0 waiting for a k-tile (vmcnt + barrier), 1 issuing the next k-tile's DMAs, 2 fragment reads + products, 3 epilogue,
+// 4 whole kernel, 5 tiles done, 6 k-tiles done, 7 the wait of each tile's FIRST k-tile
+__device__ unsigned long long ttts_h3i_stamps[512 * 4 * 8];
+#define ISTAMP() __builtin_amdgcn_s_memtime()
+#define IACC(slot, v) do { if ((threadIdx.x & 63) == 0) st_acc[slot] += (v); } while (0)
+#else
+#define ISTAMP() 0ull
+#define IACC(slot, v)
+#endif
+
+// HAS_RES / HAS_GATE / DROP: the epilogue's optional operands are TEMPLATE parameters of the kernel, not branches inside it.  With
+// the six variants behind run-time branches in one kernel, hipcc's s_waitcnt insertion merged their counter states at the tile
+// loop's head and put `s_waitcnt vmcnt(0)` in front of the main loop's first fragment read -- a wait for the DMAs issued a
+// few instructions earlier, i.e. no prefetch at all (2.2k instead of 1.1k cycles per k-tile).
+template <bool HAS_RES, bool HAS_GATE, bool DROP>
 __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
+#ifdef TTTS_H3I_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_begin = ISTAMP();
+#endif
     __shared__ __attribute__((aligned(16))) uint32_t lds[INST * I_STAGE / 4];
     const uint64_t seed_eff = site_seed(g.seed, g.step_seed);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -71,11 +95,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
         n0 = (t - ty * nx) * IBN;
     };
     // ---- loader: lane -> (row r16 of a 16-row piece, LDS chunk slot); the chunk it FETCHES is slot ^ swizzle(row)
+    // Both images are K16-MAJOR: [k / 16][row][64 B], so the 16 rows of a piece are ONE contiguous KB (eight whole lines).
     const int r16 = lane >> 2, c = (lane & 3) ^ ((r16 >> 2) & 3);
-    const uint32_t a_row_bytes = (uint32_t)g.lda * 4u;
-    const uint32_t a_voff = (uint32_t)r16 * a_row_bytes + (uint32_t)c * 16u;
-    const uint32_t b_plane = (uint32_t)g.N * 64u;           // one plane of one 32-deep k-tile of the weight image
-    const uint32_t b_voff = (uint32_t)r16 * 64u + (uint32_t)(c >> 1) * b_plane + (uint32_t)(c & 1) * 16u;
+    const uint32_t lane_off = (uint32_t)r16 * 64u + (uint32_t)c * 16u;
+    const uint32_t a_kstep = (uint32_t)g.M * 64u, b_kstep = (uint32_t)g.N * 64u;     // one k-tile further
     const uint32_t lds0 = lds_addr_i(lds);
     const uint64_t a_base = reinterpret_cast<uint64_t>(g.A), b_base = reinterpret_cast<uint64_t>(g.B);
     int ld_bid = blockIdx.x, ld_kt = 0, ld_stage = 0;
@@ -84,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
         const bool live = bid < ntiles;     //  k-tile loop needs no variant that stops requesting)
         int m0, n0;
         tile_coords(live ? bid : 0, m0, n0);
-        ld_a0 = (uint32_t)((long)(m0 + wave * 32) * a_row_bytes);
+        ld_a0 = (uint32_t)(m0 + wave * 32) * 64u;
         ld_b0 = (uint32_t)(n0 + wave * 64) * 64u;
         ld_abytes = live ? g.a_bytes : 0u;
         ld_bbytes = live ? g.b_bytes : 0u;
@@ -93,15 +116,15 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
         const u32x4 rsrcA = {(uint32_t)a_base, (uint32_t)(a_base >> 32) & 0xffffu, ld_abytes, 0x00020000u};
         const u32x4 rsrcB = {(uint32_t)b_base, (uint32_t)(b_base >> 32) & 0xffffu, ld_bbytes, 0x00020000u};
         const uint32_t dst = lds0 + (uint32_t)ld_stage * I_STAGE;
-        const uint32_t a_s = ld_a0 + (uint32_t)ld_kt * 64u;
-        const uint32_t b_s = ld_b0 + (uint32_t)(ld_kt >> 1) * 2u * b_plane + (uint32_t)(ld_kt & 1) * 32u;
+        const uint32_t a_s = ld_a0 + (uint32_t)ld_kt * a_kstep;
+        const uint32_t b_s = ld_b0 + (uint32_t)ld_kt * b_kstep;
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-            dma16b(rsrcA, a_voff, __builtin_amdgcn_readfirstlane(a_s + e * 16u * a_row_bytes),
+            dma16b(rsrcA, lane_off, __builtin_amdgcn_readfirstlane(a_s + e * 1024u),
                    __builtin_amdgcn_readfirstlane(dst + (uint32_t)(2 * wave + e) * 1024u));
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            dma16b(rsrcB, b_voff, __builtin_amdgcn_readfirstlane(b_s + e * 1024u),
+            dma16b(rsrcB, lane_off, __builtin_amdgcn_readfirstlane(b_s + e * 1024u),
                    __builtin_amdgcn_readfirstlane(dst + I_A_BYTES + (uint32_t)(4 * wave + e) * 1024u));
         ld_stage = ld_stage == INST - 1 ? 0 : ld_stage + 1;
         if (++ld_kt == nkt) {
@@ -161,29 +184,34 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
             // k-tile kt has landed when all but the requests BEHIND it have: the next k-tile's I_LOADS and -- for the two k-tiles
             // requested before the previous tile's epilogue -- that epilogue's stores (a lower bound of what was issued since is
             // what makes the count safe: every store of the epilogue is unconditional)
+            [[maybe_unused]] const unsigned long long s0 = ISTAMP();
             if (after_ep && kt < 2) wait_vm_barrier<I_LOADS + I_EP_STORES>();
             else wait_vm_barrier<I_LOADS>();
+            [[maybe_unused]] const unsigned long long s1 = ISTAMP();
             // behind the barrier every wave has finished the products of k-tile kt-1 (or the epilogue's slabs): that stage is free
             issue();
+            [[maybe_unused]] const unsigned long long s2 = ISTAMP();
             compute(cstage);
             cstage = cstage == INST - 1 ? 0 : cstage + 1;
+            IACC(0, s1 - s0); IACC(1, s2 - s1); IACC(2, ISTAMP() - s2); IACC(6, 1);
+            if (kt == 0) IACC(7, s1 - s0);
         }
+        [[maybe_unused]] const unsigned long long s3 = ISTAMP();
         asm volatile("s_barrier" ::: "memory");          // every wave has its last fragments: the stage becomes the epilogue's slabs
         const int ep_stage = cstage == 0 ? INST - 1 : cstage - 1;
 
         // ---------------- epilogue: each 32 x 32 accumulator block is scaled by its lane's row factor, turned through a 4 KB slab
-        // (row-major, 16-byte chunk ^= row & 7: conflict-free both ways) and leaves as whole 128-byte lines
+        // (row-major, 16-byte chunk ^= row & 7: conflict-free both ways) and leaves as whole 128-byte lines.
+        // vmcnt is ONE in-order counter for loads and stores: a block's auxiliary operands (residual, relu gate) are requested
+        // BEFORE the previous block's stores, so the wait in front of their first use counts those stores as younger and does not
+        // wait for them (a first version requested them behind the stores: every block then waited a full store round trip,
+        // 16.5k of a tile's 42k cycles); the variants without auxiliary operands issue no load at all.
         {
             float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + ep_stage * I_STAGE) + wave * 1024;
             const int rsub = lane >> 3, ch = lane & 7;
             const int col0 = n0 + wn * 128 + ch * 4;
-            const bool has_res = g.residual != nullptr, has_gate = g.relu_out != nullptr, do_drop = g.drop_thr != 0u;
             const bool want_max = g.c_amax != nullptr;
             const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (uint32_t)((long)g.M * g.ldc * 4), 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(has_res ? g.residual : g.A), 0, has_res ? (uint32_t)((long)g.M * g.ldr * 4) : 0u, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(has_gate ? g.relu_out : g.A), 0, has_gate ? (uint32_t)((long)g.M * g.ldc * 4) : 0u, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsrcBias = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(g.bias != nullptr ? g.bias : g.A), 0, g.bias != nullptr ? (uint32_t)g.N * 4u : 0u, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.a_row_inv), 0,
@@ -197,68 +225,107 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
             for (int j = 0; j < 4; ++j) bias4[j] = buf_load4(rsrcBias, (col0 + j * 32 < g.N) ? (uint32_t)(col0 + j * 32) * 4u : OOB);
             const float relu_lo = (g.act == 1) ? 0.f : -__builtin_inff();
             float cmax = 0.f;
+            // Addressing as gemm_h3's fast epilogue: ONE per-lane 32-bit byte offset per column group (out of range when the group
+            // lies past N) plus a wave-uniform scalar offset per row group -- rows past M fall outside the descriptors, so there
+            // is no row test, no 64-bit arithmetic and no branch around a load or a store (output, residual and gate operand
+            // share the row stride: ldr == ldc at both entry points).
+            const int row_l = m0 + wm * 64 + rsub;                       // this lane's row in row group 0
+            const int left = g.M - row_l;
+            const int rows_left = left < 0 ? 0 : (left > IBM ? IBM : left);
+            uint32_t offC[4];
+            int live_rows[4];                                            // row groups rg < live_rows[j] hold stored values
+            uint64_t idx0[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const long row_blk = (long)m0 + wm * 64 + i * 32;
+            for (int j = 0; j < 4; ++j) {
+                const int col = col0 + j * 32;
+                const bool ok = col < g.N;
+                offC[j] = ok ? (uint32_t)(((long)row_l * g.ldc + col) * 4) : OOB;
+                live_rows[j] = ok ? rows_left : 0;
+                idx0[j] = (uint64_t)row_l * (uint64_t)g.N + (uint64_t)col;
+            }
+            const uint32_t row_step = (uint32_t)g.ldc * 4u;
+            {
+                const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(HAS_RES ? g.residual : g.A), 0, HAS_RES ? (uint32_t)((long)g.M * g.ldr * 4) : 0u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(HAS_GATE ? g.relu_out : g.A), 0, HAS_GATE ? (uint32_t)((long)g.M * g.ldc * 4) : 0u, 0x00020000);
+                float4 r4[HAS_RES ? 4 : 1], g4[HAS_GATE ? 4 : 1];
+                auto load_aux = [&](int blk) {
+                    const int i = blk >> 2, j = blk & 3;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = col0 + j * 32;
-                    const bool col_ok = col < g.N;
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t soff = (uint32_t)(i * 32 + u * 8) * row_step;
+                        if (HAS_RES) r4[u] = buf_load4s(rsrcR, offC[j], soff);
+                        if (HAS_GATE) g4[u] = buf_load4s(rsrcG, offC[j], soff);
+                    }
+                };
+                if (HAS_RES || HAS_GATE) load_aux(0);
+#pragma unroll
+                for (int blk = 0; blk < 8; ++blk) {
+                    const int i = blk >> 2, j = blk & 3;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         *reinterpret_cast<float4*>(slab + l31 * 32 + (((2 * q + half) ^ (l31 & 7)) * 4)) =
                             make_float4(acc[i][j][4 * q] * rs[i], acc[i][j][4 * q + 1] * rs[i], acc[i][j][4 * q + 2] * rs[i],
                                         acc[i][j][4 * q + 3] * rs[i]);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    // (LDS instructions of one wave execute in order: no wait between its writes and its reads, only the
+                    // compiler must keep them in order)
                     __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    float4 r4[4], g4[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const long row = row_blk + u * 8 + rsub;
-                        if (has_res) r4[u] = buf_load4(rsrcR, col_ok ? (uint32_t)((row * g.ldr + col) * 4) : OOB);
-                        if (has_gate) g4[u] = buf_load4(rsrcG, col_ok ? (uint32_t)((row * g.ldc + col) * 4) : OOB);
-                    }
+                    asm volatile("" ::: "memory");
+                    float v[4][4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int srow = u * 8 + rsub;
-                        const long row = row_blk + srow;
+                        const int rg = i * 32 + u * 8;                   // row group, wave-uniform
                         const float4 a4 = *reinterpret_cast<const float4*>(slab + srow * 32 + ((ch ^ (srow & 7)) * 4));
-                        float v[4] = {a4.x + bias4[j].x, a4.y + bias4[j].y, a4.z + bias4[j].z, a4.w + bias4[j].w};
+                        v[u][0] = a4.x + bias4[j].x; v[u][1] = a4.y + bias4[j].y; v[u][2] = a4.z + bias4[j].z; v[u][3] = a4.w + bias4[j].w;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_lo);
-                        if (do_drop) {
+                        for (int e = 0; e < 4; ++e) v[u][e] = fmaxf(v[u][e], relu_lo);
+                        if (DROP) {
                             bool kp[4];
-                            keep_quad(seed_eff, (uint64_t)row * (uint64_t)g.N + (uint64_t)col, g.drop_thr, kp);
+                            keep_quad(seed_eff, idx0[j] + (uint64_t)rg * (uint64_t)g.N, g.drop_thr, kp);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = kp[e] ? v[e] * g.drop_scale : 0.f;
+                            for (int e = 0; e < 4; ++e) v[u][e] *= kp[e] ? g.drop_scale : 0.f;        // (a product, as torch's dropout)
                         }
-                        if (has_gate) {
-                            const float gg[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
+                        if (HAS_GATE) {
+                            const float4 gq = g4[HAS_GATE ? u : 0];
+                            const float gg[4] = {gq.x, gq.y, gq.z, gq.w};
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = gg[e] > 0.f ? v[e] * g.relu_scale : 0.f;
+                            for (int e = 0; e < 4; ++e) v[u][e] *= gg[e] > 0.f ? g.relu_scale : 0.f;
                         }
-                        if (has_res) { v[0] += r4[u].x; v[1] += r4[u].y; v[2] += r4[u].z; v[3] += r4[u].w; }
-                        // unconditional: a row past M lies beyond the descriptor, a column group past N gets the out-of-range offset
-                        __builtin_amdgcn_raw_buffer_store_b128(
-                            u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsrcC,
-                            col_ok ? (int)(uint32_t)((row * g.ldc + col) * 4) : (int)OOB, 0, 0);
-                        if (want_max) {
-                            float mx = fmaxf(fmaxf(cmax, fabsf(v[0])), fabsf(v[1]));
-                            mx = fmaxf(fmaxf(mx, fabsf(v[2])), fabsf(v[3]));
-                            cmax = (col_ok && row < g.M) ? mx : cmax;
+                        if (HAS_RES) {
+                            const float4 rq = r4[HAS_RES ? u : 0];
+                            v[u][0] += rq.x; v[u][1] += rq.y; v[u][2] += rq.z; v[u][3] += rq.w;
+                        }
+                        if (want_max) {          // branch-free: two v_max3, a compare and a select
+                            float mx = fmaxf(fmaxf(cmax, fabsf(v[u][0])), fabsf(v[u][1]));
+                            mx = fmaxf(fmaxf(mx, fabsf(v[u][2])), fabsf(v[u][3]));
+                            cmax = rg < live_rows[j] ? mx : cmax;
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the next block's auxiliary operands go out BEFORE this block's stores (their registers are free now)
+                    if ((HAS_RES || HAS_GATE) && blk + 1 < 8) load_aux(blk + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)      // unconditional: see the addressing note above
+                        buf_store4s(rsrcC, offC[j], (uint32_t)(i * 32 + u * 8) * row_step, make_float4(v[u][0], v[u][1], v[u][2], v[u][3]));
                     __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (want_max) amax_publish(cmax, g.c_amax, bid);
         }
         after_ep = true;
+        IACC(3, ISTAMP() - s3); IACC(5, 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // requests made for a tile that does not exist must not outlive the wave
+#ifdef TTTS_H3I_STAMPS
+    st_acc[4] = ISTAMP() - st_begin;
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 512)
+        for (int i = 0; i < 8; ++i) ttts_h3i_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i] = st_acc[i];
+#endif
 }
 
 bool h3i_supports(const GemmArgs& g) {
@@ -282,7 +349,16 @@ int dispatch_h3i(const GemmArgs& g, hipStream_t stream) {
     long gsz = ((ntiles + rounds - 1) / rounds + 7) / 8 * 8;
     if (gsz > 512) gsz = 512;
     dim3 grid((unsigned)(ntiles < 512 ? ntiles : gsz), 1, 1);
-    hipLaunchKernelGGL(gemm_h3i_kernel, grid, dim3(256), 0, stream, g);
+    const bool res = g.residual != nullptr, gate = g.relu_out != nullptr, drop = g.drop_thr != 0u;
+    if (gate && drop) {
+        set_error("fp16x3 GEMM (image operand): a relu gate (data gradient) cannot be combined with dropout");
+        return TTTS_ERR_INVALID;
+    }
+#define TTTS_H3I(R, G, D) hipLaunchKernelGGL((gemm_h3i_kernel<R, G, D>), grid, dim3(256), 0, stream, g)
+    if (gate) { if (res) TTTS_H3I(true, true, false); else TTTS_H3I(false, true, false); }
+    else if (drop) { if (res) TTTS_H3I(true, false, true); else TTTS_H3I(false, false, true); }
+    else { if (res) TTTS_H3I(true, false, false); else TTTS_H3I(false, false, false); }
+#undef TTTS_H3I
     TTTS_LAUNCH_CHECK("gemm_h3i_kernel");
     return TTTS_OK;
 }
@@ -307,7 +383,6 @@ __global__ __launch_bounds__(256) void act_image_kernel(const float* __restrict_
     m = wave_max(m);
     float sc, inv;
     h3_pow2_scale(m, sc, inv);
-    unsigned short* out = img + row * (long)K * 2;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int c4 = lane + 64 * k;
@@ -315,8 +390,8 @@ __global__ __launch_bounds__(256) void act_image_kernel(const float* __restrict_
             uint2 hi, lo;
             split2_pair(f32x2{v[k].x, v[k].y} * sc, hi.x, lo.x);
             split2_pair(f32x2{v[k].z, v[k].w} * sc, hi.y, lo.y);
-            const int kk = c4 * 4;                                  // group kk / 16: 32 halfwords, hi at +0, lo at +16
-            unsigned short* p = out + (kk >> 4) * 32 + (kk & 15);
+            const int kk = c4 * 4;                                  // k-tile kk / 16, row: 32 halfwords, hi at +0, lo at +16
+            unsigned short* p = img + ((long)(kk >> 4) * M + row) * 32 + (kk & 15);
             *reinterpret_cast<uint2*>(p) = hi;
             *reinterpret_cast<uint2*>(p + 16) = lo;
         }
@@ -341,6 +416,12 @@ static GemmArgs h3i_base_args() {
 }  // namespace ttts
 
 using namespace ttts;
+
+#ifdef TTTS_H3I_STAMPS
+extern "C" int ttts_dbg_h3i_read_stamps(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ttts::ttts_h3i_stamps), n * sizeof(unsigned long long));
+}
+#endif
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
