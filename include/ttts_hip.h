@@ -245,12 +245,17 @@ int ttts_bn_bwd(const float* dz, const float* x, const float* mean, const float*
 /* ------------------------------------------------------------------ LayerNorm over the last dim (1 <= d <= 1024)
  * Replaces nn.LayerNorm norm1/2/3 of the encoder/decoder layers (torch/nn/modules/transformer.py:951-956,
  * model/layers.py:47-50).  The residual sum is produced by the preceding GEMM's epilogue. */
+/* y_image_out / y_row_inv_out (ABI v10): NULL, or the activation image of y and its per-row inverse scales for the GEMMs that read
+ * y (ttts_linear_fwd_h3i; M * d * 4 bytes and M floats; d in {256, 512, 1024}): the row is complete in the kernel's registers,
+ * so the split costs one extra write and no pass. */
 int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                       int64_t M, int d, float eps, float* y_amax_out /* NULL, or zeroed TTTS_AMAX_SLOTS floats: max|y| */, void* stream);
+                       int64_t M, int d, float eps, float* y_amax_out /* NULL, or zeroed TTTS_AMAX_SLOTS floats: max|y| */,
+                       void* y_image_out, float* y_row_inv_out, void* stream);
 size_t ttts_layernorm_bwd_workspace_bytes(int d);
 int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
-                       int accumulate, ttts_reduce_queue* queue, void* stream);
+                       int accumulate, void* dx_image_out /* NULL, or the image of dx (ttts_linear_bwd_data_h3i) */,
+                       float* dx_row_inv_out, ttts_reduce_queue* queue, void* stream);
 /* the same, and in the same pass dacc = dx * keep(seed, element) / (1 - drop_p): the gradient behind the residual dropout
  * of the sublayer whose output this LayerNorm normalised (ttts_dropout_bwd(dx) without a pass of its own; same mask as
  * the forward epilogue of that sublayer's last Linear).  dacc_amax: NULL, or a caller-zeroed TTTS_AMAX_SLOTS-float array that receives
@@ -258,7 +263,8 @@ int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const
 int ttts_layernorm_bwd_drop(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                             float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
                             int accumulate, float* dacc, float drop_p, uint64_t seed, const uint64_t* step_seed,
-                            float* dacc_amax, ttts_reduce_queue* queue, void* stream);
+                            float* dacc_amax, void* dacc_image_out /* NULL, or the image of dacc */, float* dacc_row_inv_out,
+                            ttts_reduce_queue* queue, void* stream);
 
 /* ------------------------------------------------------------------ attention (64 columns per head)
  * Scaled dot-product attention with masks computed from lengths in-kernel (no mask tensors):

@@ -821,3 +821,58 @@ def test_full_size_training_step_is_reproducible(cfg_name, B):
     assert torch.isfinite(l1) and torch.equal(l1, l2) and torch.equal(g1, g2)
     assert not torch.equal(g1, g3)
     assert float(g1.abs().max()) > 0
+
+
+@pytest.mark.parametrize("M,N,K,scale", [(300, 96, 64, 1.0), (129, 256, 256, 1e-4), (1000, 768, 256, 30.0), (257, 1024, 256, 1.0),
+                                         (515, 256, 1024, 1.0), (1157, 260, 512, 1.0)])
+def test_image_operand_gemm_agrees_with_fp64(M, N, K, scale):
+    """ttts_linear_fwd_h3i / ttts_linear_bwd_data_h3i through the C ABI: the activation arrives as an image (f16 hi / lo planes,
+    K16-major, per-ROW power-of-two scale: ttts_act_image), the weight as the K16-major fp16x3 image (ttts_weight_split modes
+    8 / 9), both staged by LDS-DMA.  Rows of very different magnitude (x 1e3, all zero) must come out as accurate as their
+    neighbours -- that is what the per-row scale is for; ragged M / N edges, every epilogue (bias, residual, relu + dropout,
+    relu gate, published maxima)."""
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib, dev = _lib.load(), _dev()
+    x = _rand(M, K, seed=1)* scale
+    x[3] *= 1e3
+    x[5] = 0.0
+    w, b, res = _rand(N, K, seed=2) * K ** -0.5, _rand(N, seed=3), _rand(M, N, seed=4)
+
+    def image_of(t):
+        m, k = t.shape
+        img, inv = torch.empty(m * k * 2, dtype=torch.int16, device=dev), torch.empty(m, device=dev)
+        _lib.check(lib.ttts_act_image(_p(t), _p(img), _p(inv), m, k, _stream()), "act_image")
+        return img, inv
+
+    img, inv = image_of(x)
+    y = torch.full((M, N), float("nan"), device=dev)
+    am = torch.zeros(ops.AMAX_SLOTS, device=dev)
+    _lib.check(lib.ttts_linear_fwd_h3i(_p(img), _p(inv), _p(ops._planes(w, 8, N, K)), _p(b), _p(res), _p(y), M, N, K, 0, 0.0, 0, None,
+                                       _p(am), _stream()), "fwd_h3i")
+    ref = x.double() @ w.double().t() + b.double() + res.double()
+    assert _rel(y, ref) < 1e-6
+    rows = (y.double() - ref).norm(dim=1) / ref.norm(dim=1)
+    assert float(rows.max()) < 1e-6, float(rows.max())                       # the x 1e3 row, the zero row, their neighbours
+    assert float(am.max()) == float(y.abs().max())
+    # relu + dropout: the mask is a function of (seed, element index) only -- the same as the fp32-operand kernel draws
+    y1, y2 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    xa = torch.zeros(ops.AMAX_SLOTS, device=dev)
+    _lib.check(lib.ttts_amax_partials(_p(x), x.numel(), _p(xa), _stream()), "amax")
+    _lib.check(lib.ttts_linear_fwd_h3i(_p(img), _p(inv), _p(ops._planes(w, 8, N, K)), _p(b), None, _p(y1), M, N, K, 1, 0.1, 77, None,
+                                       None, _stream()), "fwd_h3i")
+    _lib.check(lib.ttts_linear_fwd_h3(_p(x), _p(ops._planes(w, 4, N, K)), _p(b), None, _p(y2), M, N, K, 1, 0.1, 77, None, 0, 0,
+                                      _p(xa), None, _stream()), "fwd_h3")
+    refr = torch.relu(x.double() @ w.double().t() + b.double())
+    live = (refr.abs() > 1e-4 * refr.abs().max())                            # away from the relu's kink both kernels agree on the mask
+    assert torch.equal((y1 == 0)[live], (y2 == 0)[live])
+    kept = live & (y1 != 0)
+    assert _rel(y1[kept], (refr / 0.9)[kept]) < 1e-6
+    if N % 32 == 0:      # data gradient dx[m, k] = dy[m, n] . w[n, k] with the relu gate of the layer below and a skip gradient
+        dy, h, skip = _rand(M, N, seed=5) * 1e-5, torch.relu(_rand(M, K, seed=6)), _rand(M, K, seed=7) * 1e-5
+        dimg, dinv = image_of(dy)
+        dx = torch.empty(M, K, device=dev)
+        _lib.check(lib.ttts_linear_bwd_data_h3i(_p(dimg), _p(dinv), _p(ops._planes(w, 9, K, N)), _p(skip), _p(dx), M, N, K, _p(h),
+                                                1.0 / 0.9, None, _stream()), "bwd_h3i")
+        refd = (dy.double() @ w.double()) * (h > 0).double() / 0.9 + skip.double()
+        assert _rel(dx, refd) < 1e-6

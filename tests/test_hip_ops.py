@@ -129,6 +129,13 @@ def test_layernorm(M, d):
     assert rel_l2(bg.grad, bd.grad) < TOL
 
 
+def _image_decode(img, inv, M, K):
+    """activation image (int16 [K/16][M][32]: 16 f16 hi, 16 f16 lo per (k-tile, row)) and per-row inverse scales -> fp64 (M, K)"""
+    h = img.view(torch.float16).view(K // 16, M, 2, 16).double()
+    v = (h[:, :, 0, :] + h[:, :, 1, :]).permute(1, 0, 2).reshape(M, K)
+    return v * inv.double().view(M, 1)
+
+
 @pytest.mark.parametrize("M,d", [(777, 256), (130, 512), (65, 1024)])
 def test_layernorm_backward_with_fused_dropout_backward(M, d):
     """ttts_layernorm_bwd_drop == ttts_layernorm_bwd followed by ttts_dropout_bwd on its dx, bit for bit (dx, the dropped
@@ -141,20 +148,30 @@ def test_layernorm_backward_with_fused_dropout_backward(M, d):
     b = torch.zeros(d, device=dev)
     y, mean, rstd = torch.empty_like(x), torch.empty(M, device=dev), torch.empty(M, device=dev)
     ysl = torch.zeros(1024, device=dev)
-    assert lib.ttts_layernorm_fwd(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), M, d, 1e-5, _p(ysl), _stream()) == 0
+    yimg, yinv = torch.empty(M * d * 2, dtype=torch.int16, device=dev), torch.empty(M, device=dev)
+    assert lib.ttts_layernorm_fwd(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), M, d, 1e-5, _p(ysl), _p(yimg), _p(yinv), _stream()) == 0
     assert float(ysl.max()) == float(y.abs().max())              # the forward's own maxima of y (slot-wise atomic max)
+    # the image operand the forward leaves for the GEMMs that read y: hi + lo reproduce y to 22 bits of each ROW's maximum
+    dec = _image_decode(yimg, yinv, M, d)
+    assert float(((dec - y.double()).abs().max(dim=1).values / y.double().abs().max(dim=1).values).max()) < 2.0 ** -21
     nb = lib.ttts_layernorm_bwd_workspace_bytes(d)
     outs = []
     for fused in (False, True):
         dx, dg, db, ws = torch.empty_like(x), torch.empty(d, device=dev), torch.empty(d, device=dev), ops._ws(nb, dev)
         dacc, am = torch.empty_like(x), torch.zeros(1024, device=dev)
+        gimg, ginv = torch.empty(M * d * 2, dtype=torch.int16, device=dev), torch.empty(M, device=dev)
         if fused:
             assert lib.ttts_layernorm_bwd_drop(_p(dy), _p(x), _p(mean), _p(rstd), _p(g), _p(dx), _p(dg), _p(db), _p(ws),
-                                               ws.numel() * 4, M, d, 0, _p(dacc), 0.3, 4242, None, _p(am), None, _stream()) == 0
+                                               ws.numel() * 4, M, d, 0, _p(dacc), 0.3, 4242, None, _p(am), _p(gimg), _p(ginv), None,
+                                               _stream()) == 0
         else:
             assert lib.ttts_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(g), _p(dx), _p(dg), _p(db), _p(ws),
-                                          ws.numel() * 4, M, d, 0, None, _stream()) == 0
+                                          ws.numel() * 4, M, d, 0, _p(gimg), _p(ginv), None, _stream()) == 0
             assert lib.ttts_dropout_bwd(_p(dx), _p(dacc), dx.numel(), 0.3, 4242, None, None, _stream()) == 0
+        # the image is that of the tensor the producing Linear's backward consumes: dacc behind a residual dropout, dx without
+        want = (dacc if fused else dx).double()
+        err = (_image_decode(gimg, ginv, M, d) - want).abs().max(dim=1).values / want.abs().max(dim=1).values.clamp_min(1e-300)
+        assert float(err.max()) < 2.0 ** -21
         outs.append((dx, dg, db, dacc, am))
     for a, c in zip(outs[0][:4], outs[1][:4]):
         assert torch.equal(a, c)

@@ -37,5 +37,5 @@ for i, nm in enumerate(names):
     per = st[:, :, i].mean()
     print(f"  {nm:32s} {per:9.0f} ticks per wave = {per / st[:, :, 4].mean() * 100:5.1f} %   per k-tile {per / kts:7.1f}" if i < 3 else
           f"  {nm:32s} {per:9.0f} ticks per wave = {per / st[:, :, 4].mean() * 100:5.1f} %   per tile {per / tiles:7.1f}")
-print(f"  wait of each tile's first k-tile: {st[:, :, 7].mean() / tiles:.1f} ticks per tile")
+pass
 print("  by wave (wait, issue, compute, epilogue):", [[int(st[:, wv, i].mean()) for i in range(4)] for wv in range(4)])

@@ -60,10 +60,10 @@ SIGNATURES = {
     "ttts_bn_eval_stats": (I, [P, P, P, P, I, F, P]),
     "ttts_bn_apply_fwd": (I, [P, P, P, P, P, P, L, I, I, F, U, P, P, P]),
     "ttts_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, Z, L, I, I, F, U, P, I, P, I, P]),
-    "ttts_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P, P]),
+    "ttts_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P, P, P, P]),
     "ttts_layernorm_bwd_workspace_bytes": (Z, [I]),
-    "ttts_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P, P]),
-    "ttts_layernorm_bwd_drop": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P, F, U, P, P, P, P]),
+    "ttts_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P, P, P, P]),
+    "ttts_layernorm_bwd_drop": (I, [P, P, P, P, P, P, P, P, P, Z, L, I, I, P, F, U, P, P, P, P, P, P]),
     "ttts_attention_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U, P, P]),
     "ttts_attention_fwd_x6": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U, P, P]),
     "ttts_attention_fwd_h3": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U, P, P, P, P, P, P, P]),

@@ -106,6 +106,36 @@ __device__ __forceinline__ void split2_pair(f32x2 x, uint32_t& hi, uint32_t& lo)
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
 }
 
+// ---- activation IMAGE (the operand format of gemm_h3i.hip): K16-major [K/16][M][{16 f16 hi, 16 f16 lo}] of x * 2^e_row with a
+// per-row power of two (the row's maximum lands in [2^11, 2^12)); row_inv[row] = 2^-e_row.  One wave holds one row, a lane NV
+// float4 (columns 4 * (lane + 64 v) ..): the producers (LayerNorm forward / backward, ttts_act_image) call this with the row
+// they have just computed.  `live`: the lane's v-th float4 lies inside the row.
+template <int NV>
+__device__ __forceinline__ void image_emit_row(const float4 (&o)[NV], int lane, long row, long M, int K,
+                                               unsigned short* __restrict__ img, float* __restrict__ row_inv) {
+    float m = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        if ((lane + 64 * v) * 4 < K) m = fmaxf(fmaxf(m, fmaxf(fabsf(o[v].x), fabsf(o[v].y))), fmaxf(fabsf(o[v].z), fabsf(o[v].w)));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float sc, inv;
+    h3_pow2_scale(m, sc, inv);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int kk = (lane + 64 * v) * 4;
+        if (kk < K) {
+            uint2 hi, lo;
+            split2_pair(f32x2{o[v].x, o[v].y} * sc, hi.x, lo.x);
+            split2_pair(f32x2{o[v].z, o[v].w} * sc, hi.y, lo.y);
+            unsigned short* p = img + ((long)(kk >> 4) * M + row) * 32 + (kk & 15);
+            *reinterpret_cast<uint2*>(p) = hi;
+            *reinterpret_cast<uint2*>(p + 16) = lo;
+        }
+    }
+    if (lane == 0) row_inv[row] = inv;
+}
+
 // ---- the split of one weight into its fp16x3 image, in WORK UNITS of one 256-thread workgroup each: unit u is the 32-row x
 // 32-channel tile (row block u / channel blocks, channel block u % channel blocks) of the weight, all taps of it.
 // h3_split_units = how many an entry has (host and device agree: the prefix sums of the batched table are built from it).

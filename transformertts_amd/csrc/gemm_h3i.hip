@@ -139,38 +139,68 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
     const uint32_t fa_off = (uint32_t)(wm * 64 + l31) * 64u;
     const uint32_t fb_off = I_A_BYTES + (uint32_t)(wn * 128 + l31) * 64u;
     f32x16 acc[2][4];
-    auto compute = [&](int stage) {
+    // Two fragment sets: while the products of k-tile t run from one set, the fragments of k-tile t+1 are read into the other, so
+    // a wave has no LDS latency in front of its first MFMA and a workgroup that is ALONE on the matrix pipe (its partner is in
+    // its epilogue) still keeps it busy.  One iteration:
+    //     request k-tile t+2  ->  first half of the products of t  ->  wait: t+1 has landed (counted vmcnt) + barrier
+    //     ->  read the fragments of t+1  ->  second half of the products of t (the reads land under them).
+    // The barrier sits between every wave's last read of stage (t-1) % 3 (issued an iteration ago, retired by the lgkmcnt(0) in
+    // front of it) and the next iteration's request that overwrites that stage.
+    f16x8 fa[2][2][2], fb[2][2][4];                                 // [set][plane][block]
+    auto read_frags = [&](int set, int stage) {
         const char* st = reinterpret_cast<const char*>(lds) + stage * I_STAGE;
-        f16x8 fa[2][2], fb[2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            fa[0][i] = *reinterpret_cast<const f16x8*>(st + fa_off + i * 2048 + ch_hi);
-            fa[1][i] = *reinterpret_cast<const f16x8*>(st + fa_off + i * 2048 + ch_lo);
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            fb[0][j] = *reinterpret_cast<const f16x8*>(st + fb_off + j * 2048 + ch_hi);
-            fb[1][j] = *reinterpret_cast<const f16x8*>(st + fb_off + j * 2048 + ch_lo);
+            fb[set][0][j] = *reinterpret_cast<const f16x8*>(st + fb_off + j * 2048 + ch_hi);
+            fb[set][1][j] = *reinterpret_cast<const f16x8*>(st + fb_off + j * 2048 + ch_lo);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            fa[set][0][i] = *reinterpret_cast<const f16x8*>(st + fa_off + i * 2048 + ch_hi);
+            fa[set][1][i] = *reinterpret_cast<const f16x8*>(st + fa_off + i * 2048 + ch_lo);
+        }
+    };
+    auto products = [&](int set, int i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // the WEIGHT fragment is the MFMA's first operand: the accumulator block is C^T (lane = output row, registers
-                // 4q .. 4q+3 = four consecutive output columns); small terms first, as gemm_h3_kernel
-                f32x16 cc = acc[i][j];
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[0][j], fa[1][i], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[1][j], fa[0][i], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[0][j], fa[0][i], cc, 0, 0, 0);
-                acc[i][j] = cc;
-            }
+        for (int j = 0; j < 4; ++j) {
+            // the WEIGHT fragment is the MFMA's first operand: the accumulator block is C^T (lane = output row, registers
+            // 4q .. 4q+3 = four consecutive output columns); small terms first, as gemm_h3_kernel
+            f32x16 cc = acc[i][j];
+            cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[set][0][j], fa[set][1][i], cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[set][1][j], fa[set][0][i], cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[set][0][j], fa[set][0][i], cc, 0, 0, 0);
+            acc[i][j] = cc;
+        }
+    };
+    int cstage = 0;                 // stage of the k-tile whose fragments sit in set 0 at the top of an (even) iteration
+    bool after_ep = false;
+    // one k-tile: `set` holds its fragments (compile-time), the other set receives the next k-tile's
+    auto ktile = [&](auto set_c, bool first_after_ep) {
+        constexpr int SET = decltype(set_c)::value;
+        [[maybe_unused]] const unsigned long long s0 = ISTAMP();
+        if (first_after_ep) asm volatile("s_barrier" ::: "memory");     // every wave has left its epilogue slab (this request's target)
+        issue();
+        [[maybe_unused]] const unsigned long long s1 = ISTAMP();
+        products(SET, 0);
+        [[maybe_unused]] const unsigned long long s2 = ISTAMP();
+        // k-tile t+1 has landed when all but the requests BEHIND it have: the I_LOADS just issued and -- for the k-tile requested
+        // before the previous tile's epilogue -- that epilogue's stores (a LOWER bound of what was issued since keeps the count
+        // safe: every store of the epilogue is unconditional)
+        if (first_after_ep) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "i"(I_LOADS + I_EP_STORES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "i"(I_LOADS) : "memory");
+        [[maybe_unused]] const unsigned long long s3 = ISTAMP();
+        const int nstage = cstage == INST - 1 ? 0 : cstage + 1;
+        read_frags(SET ^ 1, nstage);
+        products(SET, 1);
+        cstage = nstage;
+        IACC(0, s3 - s2); IACC(1, s1 - s0); IACC(2, (s2 - s1) + (ISTAMP() - s3)); IACC(6, 1);
     };
 
     set_ld_tile(ld_bid);
     issue();                        // k-tiles 0 and 1 of the first tile (K >= 32)
     issue();
-    int cstage = 0;
-    bool after_ep = false;
+    wait_vm_barrier<I_LOADS>();
+    read_frags(0, 0);
     for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
         int m0, n0;
         tile_coords(bid, m0, n0);
@@ -180,24 +210,13 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int kt = 0; kt < nkt; ++kt) {
-            // k-tile kt has landed when all but the requests BEHIND it have: the next k-tile's I_LOADS and -- for the two k-tiles
-            // requested before the previous tile's epilogue -- that epilogue's stores (a lower bound of what was issued since is
-            // what makes the count safe: every store of the epilogue is unconditional)
-            [[maybe_unused]] const unsigned long long s0 = ISTAMP();
-            if (after_ep && kt < 2) wait_vm_barrier<I_LOADS + I_EP_STORES>();
-            else wait_vm_barrier<I_LOADS>();
-            [[maybe_unused]] const unsigned long long s1 = ISTAMP();
-            // behind the barrier every wave has finished the products of k-tile kt-1 (or the epilogue's slabs): that stage is free
-            issue();
-            [[maybe_unused]] const unsigned long long s2 = ISTAMP();
-            compute(cstage);
-            cstage = cstage == INST - 1 ? 0 : cstage + 1;
-            IACC(0, s1 - s0); IACC(1, s2 - s1); IACC(2, ISTAMP() - s2); IACC(6, 1);
-            if (kt == 0) IACC(7, s1 - s0);
+        for (int kt = 0; kt < nkt; kt += 2) {                        // (K % 32 == 0: an even number of k-tiles)
+            ktile(std::integral_constant<int, 0>{}, after_ep && kt == 0);
+            ktile(std::integral_constant<int, 1>{}, false);
         }
         [[maybe_unused]] const unsigned long long s3 = ISTAMP();
-        asm volatile("s_barrier" ::: "memory");          // every wave has its last fragments: the stage becomes the epilogue's slabs
+        // cstage holds the NEXT tile's first k-tile (its fragments are in set 0 already), the stage behind it the second; the
+        // stage before it is the one the last products ran on: every wave passed the last barrier after reading it -> the slabs
         const int ep_stage = cstage == 0 ? INST - 1 : cstage - 1;
 
         // ---------------- epilogue: each 32 x 32 accumulator block is scaled by its lane's row factor, turned through a 4 KB slab
@@ -373,30 +392,12 @@ __global__ __launch_bounds__(256) void act_image_kernel(const float* __restrict_
     const long row = (long)blockIdx.x * 4 + wave;
     if (row >= M) return;
     float4 v[NV];
-    float m = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int c4 = lane + 64 * k;
         v[k] = (c4 * 4 < K) ? reinterpret_cast<const float4*>(x + row * K)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[k].x), fabsf(v[k].y))), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
     }
-    m = wave_max(m);
-    float sc, inv;
-    h3_pow2_scale(m, sc, inv);
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int c4 = lane + 64 * k;
-        if (c4 * 4 < K) {
-            uint2 hi, lo;
-            split2_pair(f32x2{v[k].x, v[k].y} * sc, hi.x, lo.x);
-            split2_pair(f32x2{v[k].z, v[k].w} * sc, hi.y, lo.y);
-            const int kk = c4 * 4;                                  // k-tile kk / 16, row: 32 halfwords, hi at +0, lo at +16
-            unsigned short* p = img + ((long)(kk >> 4) * M + row) * 32 + (kk & 15);
-            *reinterpret_cast<uint2*>(p) = hi;
-            *reinterpret_cast<uint2*>(p + 16) = lo;
-        }
-    }
-    if (lane == 0) row_inv[row] = inv;
+    image_emit_row<NV>(v, lane, row, M, K, img, row_inv);
 }
 
 static GemmArgs h3i_base_args() {

@@ -1,7 +1,7 @@
 // LayerNorm and BatchNorm1d (train / eval) forward + backward for (rows, channels) fp32 activations.
 // HBM-bound: every kernel streams rows with coalesced accesses across channels, reduces with
 // wave shuffles / fixed-order partials (bitwise reproducible, no atomics).
-#include "ttts_common.h"
+#include "gemm_common.h"
 
 namespace ttts {
 
@@ -57,7 +57,8 @@ template <int NV, int ROWS>
 __global__ __launch_bounds__(256) void layernorm_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ y,
                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                               long M, float eps, float* __restrict__ amax_out) {
+                                                               long M, float eps, float* __restrict__ amax_out,
+                                                               unsigned short* __restrict__ img, float* __restrict__ row_inv) {
     constexpr int d = 256 * NV;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long row0 = ((long)blockIdx.x * 4 + wave) * ROWS;
@@ -91,13 +92,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_v4_kernel(const float* __re
         }
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
         if (row0 + r < M) {
+            float4 ov[NV];
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const float4 o = make_float4((v[r][k].x - mean) * rstd * ga[k].x + be[k].x, (v[r][k].y - mean) * rstd * ga[k].y + be[k].y,
                                              (v[r][k].z - mean) * rstd * ga[k].z + be[k].z, (v[r][k].w - mean) * rstd * ga[k].w + be[k].w);
                 reinterpret_cast<float4*>(y + (row0 + r) * d)[lane + 64 * k] = o;
                 ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+                ov[k] = o;
             }
+            // the image operand of the GEMMs that read y (gemm_h3i.hip): the row is complete in this wave's registers
+            if (img != nullptr) image_emit_row<NV>(ov, lane, row0 + r, M, d, img, row_inv);
             if (lane == 0) {
                 if (mean_out) mean_out[row0 + r] = mean;
                 if (rstd_out) rstd_out[row0 + r] = rstd;
@@ -175,7 +180,8 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const float* 
                                                                const float* __restrict__ gamma, float* __restrict__ dx,
                                                                float* __restrict__ ws, long M, float* __restrict__ dacc,
                                                                float drop_scale, uint32_t thr, uint64_t seed,
-                                                               const uint64_t* step_seed, float* __restrict__ dacc_amax) {
+                                                               const uint64_t* step_seed, float* __restrict__ dacc_amax,
+                                                               unsigned short* __restrict__ img, float* __restrict__ row_inv) {
     constexpr int d = 256 * NV;
     __shared__ float red[NW][2][d];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -221,11 +227,13 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const float* 
             }
             s1 = wave_sum(s1) / (float)d;
             s2 = wave_sum(s2) / (float)d;
+            float4 ov[NV];
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const float4 o = make_float4(rs[u] * (gd[k].x - s1 - xh[k].x * s2), rs[u] * (gd[k].y - s1 - xh[k].y * s2),
                                              rs[u] * (gd[k].z - s1 - xh[k].z * s2), rs[u] * (gd[k].w - s1 - xh[k].w * s2));
                 reinterpret_cast<float4*>(dx + r * d)[lane + 64 * k] = o;
+                ov[k] = o;
                 if (DROP) {
                     bool kp[4];
                     keep_quad(seed_eff, (uint64_t)(r * d + 4 * (lane + 64 * k)), thr, kp);
@@ -233,8 +241,11 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const float* 
                                                   kp[2] ? o.z * drop_scale : 0.f, kp[3] ? o.w * drop_scale : 0.f);
                     reinterpret_cast<float4*>(dacc + r * d)[lane + 64 * k] = da;
                     amx = fmaxf(fmaxf(amx, fmaxf(fabsf(da.x), fabsf(da.y))), fmaxf(fabsf(da.z), fabsf(da.w)));
+                    ov[k] = da;
                 }
             }
+            // image of what the producing Linear's backward takes as its dy: dacc with a residual dropout, dx without
+            if (img != nullptr) image_emit_row<NV>(ov, lane, r, M, d, img, row_inv);
         }
     }
     if (DROP && dacc_amax != nullptr) amax_publish(amx, dacc_amax, blockIdx.x * NW + wave);
@@ -513,23 +524,27 @@ using namespace ttts;
 extern "C" {
 
 int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                       int64_t M, int d, float eps, float* y_amax_out, void* stream) {
+                       int64_t M, int d, float eps, float* y_amax_out, void* y_image_out, float* y_row_inv_out, void* stream) {
     TTTS_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
+    TTTS_REQUIRE((y_image_out == nullptr) == (y_row_inv_out == nullptr), "layernorm_fwd: image and row_inv come together");
+    unsigned short* img = reinterpret_cast<unsigned short*>(y_image_out);
     TTTS_REQUIRE(M > 0 && d > 0 && d <= 64 * LN_MAXPER, "layernorm_fwd: d=%d must be in 1..%d", d, 64 * LN_MAXPER);
     const bool v4 = (d == 256 || d == 512 || d == 1024) &&
                     ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0;
     if (v4 && d == 256)
         hipLaunchKernelGGL((layernorm_fwd_v4_kernel<1, 4>), dim3(cdiv(M, 16)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                           mean, rstd, (long)M, eps, y_amax_out);
+                           mean, rstd, (long)M, eps, y_amax_out, img, y_row_inv_out);
     else if (v4 && d == 512)
         hipLaunchKernelGGL((layernorm_fwd_v4_kernel<2, 2>), dim3(cdiv(M, 8)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                           mean, rstd, (long)M, eps, y_amax_out);
+                           mean, rstd, (long)M, eps, y_amax_out, img, y_row_inv_out);
     else if (v4)
         hipLaunchKernelGGL((layernorm_fwd_v4_kernel<4, 1>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                           mean, rstd, (long)M, eps, y_amax_out);
-    else
+                           mean, rstd, (long)M, eps, y_amax_out, img, y_row_inv_out);
+    else {
+        TTTS_REQUIRE(img == nullptr, "layernorm_fwd: an image output needs d in {256, 512, 1024} and 16-byte aligned operands");
         hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
                            rstd, (long)M, d, eps, y_amax_out);
+    }
     TTTS_LAUNCH_CHECK("layernorm_fwd_kernel");
     return TTTS_OK;
 }
@@ -539,7 +554,9 @@ size_t ttts_layernorm_bwd_workspace_bytes(int d) { return (size_t)LN_BWD_BLOCKS 
 static int layernorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                               float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
                               int accumulate, float* dacc, float drop_p, uint64_t seed, const uint64_t* step_seed,
-                              float* dacc_amax, ttts_reduce_queue* queue, hipStream_t stream) {
+                              float* dacc_amax, void* image_out, float* row_inv_out, ttts_reduce_queue* queue, hipStream_t stream) {
+    TTTS_REQUIRE((image_out == nullptr) == (row_inv_out == nullptr), "layernorm_bwd: image and row_inv come together");
+    unsigned short* img = reinterpret_cast<unsigned short*>(image_out);
     TTTS_REQUIRE(dy && x && mean && rstd && gamma && dx && ws, "layernorm_bwd: null pointer");
     TTTS_REQUIRE(M > 0 && d > 0 && d <= 64 * LN_MAXPER, "layernorm_bwd: d=%d must be in 1..%d", d, 64 * LN_MAXPER);
     TTTS_REQUIRE(ws_bytes >= ttts_layernorm_bwd_workspace_bytes(d), "layernorm_bwd: workspace too small");
@@ -553,7 +570,7 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* mean
         const float sc = 1.f / (1.f - drop_p);
 #define TTTS_LN_BWD4(NV, NW, DROP)                                                                                          \
         hipLaunchKernelGGL((layernorm_bwd_v4_kernel<NV, NW, DROP>), dim3(nblk), dim3(64 * NW), 0, stream, dy, x, mean, rstd, \
-                           gamma, dx, ws, (long)M, dacc, sc, thr, seed, step_seed, dacc_amax)
+                           gamma, dx, ws, (long)M, dacc, sc, thr, seed, step_seed, dacc_amax, img, row_inv_out)
         if (dacc) {
             if (d == 256) TTTS_LN_BWD4(1, 16, true); else if (d == 512) TTTS_LN_BWD4(2, 8, true); else TTTS_LN_BWD4(4, 4, true);
         } else {
@@ -563,6 +580,7 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* mean
         TTTS_LAUNCH_CHECK("layernorm_bwd_v4_kernel");
         return launch_reduce_rows(ws, 2 * d, nblk, 2 * d, dgamma, d, dbeta, accumulate != 0, stream, queue);
     }
+    TTTS_REQUIRE(img == nullptr, "layernorm_bwd: an image output needs d in {256, 512, 1024} and 16-byte aligned operands");
 #define TTTS_LN_BWD(NPER)                                                                                         \
     hipLaunchKernelGGL((layernorm_bwd_kernel<NPER>), dim3(nblk), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dx, ws, \
                        (long)M, d)
@@ -579,19 +597,20 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* mean
 
 int ttts_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
-                       int accumulate, ttts_reduce_queue* queue, void* stream) {
+                       int accumulate, void* dx_image_out, float* dx_row_inv_out, ttts_reduce_queue* queue, void* stream) {
     return layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, ws_bytes, M, d, accumulate, nullptr, 0.f, 0,
-                              nullptr, nullptr, queue, (hipStream_t)stream);
+                              nullptr, nullptr, dx_image_out, dx_row_inv_out, queue, (hipStream_t)stream);
 }
 
 int ttts_layernorm_bwd_drop(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                             float* dx, float* dgamma, float* dbeta, float* ws, size_t ws_bytes, int64_t M, int d,
                             int accumulate, float* dacc, float drop_p, uint64_t seed, const uint64_t* step_seed,
-                            float* dacc_amax, ttts_reduce_queue* queue, void* stream) {
+                            float* dacc_amax, void* dacc_image_out, float* dacc_row_inv_out, ttts_reduce_queue* queue,
+                            void* stream) {
     TTTS_REQUIRE(dacc, "layernorm_bwd_drop: dacc is required");
     TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd_drop: bad dropout p");
     return layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, ws_bytes, M, d, accumulate, dacc, drop_p, seed,
-                              step_seed, dacc_amax, queue, (hipStream_t)stream);
+                              step_seed, dacc_amax, dacc_image_out, dacc_row_inv_out, queue, (hipStream_t)stream);
 }
 
 size_t ttts_bn_workspace_bytes(int64_t M, int C) {

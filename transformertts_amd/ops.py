@@ -575,14 +575,35 @@ def _sinks(*params):
 
 
 # ----------------------------------------------------------------------------------------------- linear
+# Image operands (csrc/gemm_h3i.hip): a producer whose kernel holds whole rows (LayerNorm forward / backward) leaves, next to its
+# fp32 output, the activation already split into f16 hi / lo with a per-row power-of-two scale -- `t._ttts_image = (image,
+# row_inv)` -- and the GEMM that reads it stages both operands by LDS-DMA on 128 x 256 tiles, two workgroups per CU.  Pays from
+# a few thousand rows on (512 resident workgroups) and for outputs at least half a tile wide.
+IMAGE_MIN_ROWS = 8192
+
+
+def _image_rows_ok(M: int, d: int) -> bool:
+    return M >= IMAGE_MIN_ROWS and d in (256, 512, 1024)
+
+
+def _image_shape_ok(M: int, red: int, out: int) -> bool:
+    """M rows, reduction depth `red`, output width `out`"""
+    return M >= IMAGE_MIN_ROWS and red % 32 == 0 and red >= 32 and out >= 128 and out % 4 == 0
+
+
+def _new_image(M: int, d: int, device):
+    return (torch.empty(M * d * 2, dtype=torch.int16, device=device), torch.empty(M, dtype=torch.float32, device=device))
+
+
 class LinearFn(torch.autograd.Function):
     """y = drop(act(x @ w.T + b)) + residual, rows optionally shifted by `row_shift` inside each utterance."""
 
     @staticmethod
     def forward(ctx, x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out=None, tok_in=None, skip_in=None,
-                skip_out=None, tok_drop=None, x_amax=None, y_amax=None):
+                skip_out=None, tok_drop=None, x_amax=None, y_amax=None, x_image=None):
         """x_amax: partial maxima of |x| (fp16x3 forms; None: measured here); y_amax: None, or a zeroed AMAX_SLOTS-slot array
-        that receives max|y| (the wrapper attaches it to y for the next fp16x3 consumer)."""
+        that receives max|y| (the wrapper attaches it to y for the next fp16x3 consumer); x_image: None, or (image, row_inv) of
+        x left by its producer -- the GEMM then takes the image-operand kernel (ttts_linear_fwd_h3i)."""
         lib = _lib.load()
         x = _chk(x, "linear.x")
         w = _chk(w, "linear.weight")
@@ -597,7 +618,10 @@ class LinearFn(torch.autograd.Function):
         r_ = _chk(residual, "linear.residual") if residual is not None else None
         if r_ is not None and r_.shape != y.shape:
             raise ValueError("linear: residual shape mismatch")
-        if _fwd_h3(K, N):
+        if x_image is not None and _fwd_h3(K, N) and row_shift == 0:
+            _lib.check(lib.ttts_linear_fwd_h3i(_p(x_image[0]), _p(x_image[1]), _p(_planes(w, 8, N, K)), _p(b_), _p(r_), _p(y), M, N, K,
+                                               act, float(drop_p), seed, _ss(), _p(y_amax), _stream()), "ttts_linear_fwd_h3i")
+        elif _fwd_h3(K, N):
             if x_amax is None:
                 x_amax = _amax(x)
             _lib.check(lib.ttts_linear_fwd_h3(_p(x), _p(_planes(w, 4, N, K)), _p(b_), _p(r_), _p(y), M, N, K, act,
@@ -635,6 +659,7 @@ class LinearFn(torch.autograd.Function):
         want_am = (ctx.needs_input_grad[0] and _bwd_h3(N, K)) or \
                   (ctx.needs_input_grad[1] and WGRAD_MODE == "h3" and _wgrad_is_split(N, K))
         am = None
+        dacc_image = None
         if act == ACT_RELU and tok_out is not None and tok_out.premasked:
             dacc = dy                    # the consumer's data-gradient epilogue already applied the relu / dropout mask
             tok_out.premasked = False
@@ -647,7 +672,8 @@ class LinearFn(torch.autograd.Function):
             td = ctx.tok_drop
             if td is not None and td.dacc is not None and td.dx is dy:
                 dacc, am = td.dacc, td.amax          # written by the LayerNorm backward that produced dy
-                td.dx = td.dacc = td.amax = None
+                dacc_image = td.image                # ... with its image operand, when the shape takes the image kernel
+                td.dx = td.dacc = td.amax = td.image = None
             else:
                 dacc = torch.empty_like(dy)
                 am = _amax_slots(dy.device, True) if want_am else None
@@ -655,6 +681,7 @@ class LinearFn(torch.autograd.Function):
                            "ttts_dropout_bwd")
         else:
             dacc = dy
+            dacc_image = getattr(dy, "_ttts_image", None)     # a LayerNorm backward without residual dropout left it on its dx
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if row_shift != 0:
@@ -667,12 +694,17 @@ class LinearFn(torch.autograd.Function):
                 if skip.shape != x.shape or not skip.is_contiguous():
                     raise RuntimeError("linear: skip-connection gradient does not match the block input")
             if _bwd_h3(N, K):
-                am = am if am is not None else _amax(dacc)
                 # dx with the producer's relu mask applied here is exactly the `dacc` of that producer's backward: leave its
                 # maxima on it
                 dx_am = _amax_slots(dx.device, True) if (tok_in is not None or ctx.sole_consumer) else None
-                _lib.check(lib.ttts_linear_bwd_data_h3(_p(dacc), _p(_planes(w, 5, K, N)), _p(skip), _p(dx), M, N, K,
-                                                       _p(gate), gscale, _p(am), _p(dx_am), _stream()), "ttts_linear_bwd_data_h3")
+                if dacc_image is not None and _image_shape_ok(M, N, K):
+                    _lib.check(lib.ttts_linear_bwd_data_h3i(_p(dacc_image[0]), _p(dacc_image[1]), _p(_planes(w, 9, K, N)), _p(skip),
+                                                            _p(dx), M, N, K, _p(gate), gscale, _p(dx_am), _stream()),
+                               "ttts_linear_bwd_data_h3i")
+                else:
+                    am = am if am is not None else _amax(dacc)
+                    _lib.check(lib.ttts_linear_bwd_data_h3(_p(dacc), _p(_planes(w, 5, K, N)), _p(skip), _p(dx), M, N, K,
+                                                           _p(gate), gscale, _p(am), _p(dx_am), _stream()), "ttts_linear_bwd_data_h3")
                 if dx_am is not None:
                     dx._ttts_amax = dx_am
             elif GEMM_MODE == "x6":
@@ -697,7 +729,7 @@ class LinearFn(torch.autograd.Function):
         dres = dy if has_r else None
         if has_r and skip_out is not None:      # hand the skip gradient to the block's first Linear instead of autograd
             skip_out.grad, dres = dy, None
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 # Test seam: called with the output of every relu-epilogue Linear, in call order (which units the HIP path gated off).
@@ -717,11 +749,11 @@ class _DropToken:
     """Handshake between a Linear with a residual-dropout epilogue (y = drop(x W + b) + residual) and the LayerNorm that is
     the ONLY reader of y: the LayerNorm's backward kernel writes, next to its dx, the dropped copy the Linear's backward
     would compute from dx in a pass of its own (`ttts_dropout_bwd`), with its partial maxima."""
-    __slots__ = ("p", "seed", "ss", "dx", "dacc", "amax")
+    __slots__ = ("p", "seed", "ss", "dx", "dacc", "amax", "image")
 
     def __init__(self, p: float, seed: int, ss):
         self.p, self.seed, self.ss = p, seed, ss
-        self.dx = self.dacc = self.amax = None
+        self.dx = self.dacc = self.amax = self.image = None
 
 
 class SkipToken:
@@ -759,8 +791,11 @@ def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_sh
     tok_drop = None
     if grad_on and act == ACT_NONE and float(drop_p) > 0.0 and residual is not None and x.is_cuda:
         tok_drop = _DropToken(float(drop_p), seed, _ss())
+    x_img = getattr(x, "_ttts_image", None) if (h3 and row_shift == 0) else None
+    if x_img is not None and not _image_shape_ok(x.numel() // K, K, N):
+        x_img = None
     y = LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out, tok_in, skip_in, skip_out, tok_drop,
-                       x_am, y_am)
+                       x_am, y_am, x_img)
     if y_am is not None:
         y._ttts_amax = y_am
     if tok_drop is not None:
@@ -983,17 +1018,21 @@ def conv_bn(x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, trai
 # ----------------------------------------------------------------------------------------------- layer norm
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, tok_drop=None, y_amax=None):
+    def forward(ctx, x, gamma, beta, eps, tok_drop=None, y_amax=None, y_image=None, bwd_image=False):
+        """y_image: None, or (image, row_inv) buffers the kernel fills with the image operand of y; bwd_image: the backward leaves
+        the image of the gradient it hands to the Linear that produced x (on the drop token, or on dx)."""
         lib = _lib.load()
         ctx.tok_drop = tok_drop
+        ctx.bwd_image = bool(bwd_image)
         x = _chk(x, "layernorm.x")
         d = x.shape[-1]
         M = x.numel() // d
         y = torch.empty_like(x)
         mean = torch.empty(M, dtype=torch.float32, device=x.device)
         rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        yi, yv = y_image if y_image is not None else (None, None)
         _lib.check(lib.ttts_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, d, float(eps),
-                                          _p(y_amax), _stream()), "ttts_layernorm_fwd")
+                                          _p(y_amax), _p(yi), _p(yv), _stream()), "ttts_layernorm_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.sinks = _sinks(gamma, beta)
         return y
@@ -1016,29 +1055,41 @@ class LayerNormFn(torch.autograd.Function):
         ws = _ws(lib.ttts_layernorm_bwd_workspace_bytes(d), x.device)
         qa = _qarg(queue, ws) if sk is not None else None
         td = ctx.tok_drop
+        img = _new_image(M, d, x.device) if (ctx.bwd_image and _image_rows_ok(M, d)) else (None, None)
         if td is not None and d in (256, 512, 1024):
             # x is the output of a Linear with residual dropout and feeds nothing but this LayerNorm: dx is that Linear's dy
             dacc = torch.empty_like(x)
             am = _amax_slots(x.device, True)
             _lib.check(lib.ttts_layernorm_bwd_drop(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(t_g), _p(t_b),
-                                                   _p(ws), ws.numel() * 4, M, d, acc, _p(dacc), td.p, td.seed, td.ss, _p(am), qa,
-                                                   _stream()), "ttts_layernorm_bwd_drop")
+                                                   _p(ws), ws.numel() * 4, M, d, acc, _p(dacc), td.p, td.seed, td.ss, _p(am),
+                                                   _p(img[0]), _p(img[1]), qa, _stream()), "ttts_layernorm_bwd_drop")
             td.dx, td.dacc, td.amax = dx, dacc, am
+            td.image = img if img[0] is not None else None
         else:
             _lib.check(lib.ttts_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(t_g), _p(t_b),
-                                              _p(ws), ws.numel() * 4, M, d, acc, qa, _stream()), "ttts_layernorm_bwd")
-        return dx, dgamma, dbeta, None, None, None
+                                              _p(ws), ws.numel() * 4, M, d, acc, _p(img[0]), _p(img[1]), qa, _stream()),
+                       "ttts_layernorm_bwd")
+            if img[0] is not None:
+                dx._ttts_image = img
+        return dx, dgamma, dbeta, None, None, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps=1e-5, sole_consumer=False, publish_amax=True):
+def layer_norm(x, gamma, beta, eps=1e-5, sole_consumer=False, publish_amax=True, emit_image=True):
     """`sole_consumer=True` is the caller's promise that nothing but this LayerNorm reads `x`; if `x` came out of a Linear
     with a residual-dropout epilogue, that Linear's dropout backward is then written by this LayerNorm's backward kernel.
     `publish_amax`: leave the partial maxima of the output on it for the fp16x3 GEMMs that read it."""
     tok = getattr(x, "_ttts_drop_token", None) if (sole_consumer and torch.is_grad_enabled()) else None
     y_am = _amax_slots(x.device, True) if (publish_amax and x.is_cuda) else None
-    y = LayerNormFn.apply(x, gamma, beta, eps, tok, y_am)
+    d = x.shape[-1]
+    M = x.numel() // d
+    # the image operand of y for the GEMMs that read it (in-projections, FFN1), and -- when x is the output of a Linear nobody
+    # else reads -- of the gradient that Linear's backward consumes
+    y_img = _new_image(M, d, x.device) if (emit_image and x.is_cuda and _image_rows_ok(M, d)) else None
+    y = LayerNormFn.apply(x, gamma, beta, eps, tok, y_am, y_img, bool(emit_image and sole_consumer))
     if y_am is not None:
         y._ttts_amax = y_am
+    if y_img is not None:
+        y._ttts_image = y_img
     return y
 
 
