@@ -334,6 +334,9 @@ def main():
                     help="the grad forward of every timed step also writes the per-head cross-attention maps (B,H,Tm,Tp) as the "
                          "reference's forward does (model/layers.py:68-73); the step's results do not depend on them")
     ap.add_argument("--no-alignments-figure", action="store_true", help="skip the secondary figure taken with --alignments semantics")
+    ap.add_argument("--no-image-operands", action="store_true",
+                    help="A/B aid: keep every GEMM on the kernels that split the fp32 activation in their loader (gemm_h3) instead of "
+                         "the image-operand kernel behind LayerNorm (gemm_h3i)")
     ap.add_argument("--launch-check", action="store_true",
                     help="exercise the launcher protocol only (process group, barrier, MAX-over-ranks clock, rank-0 JSON line) "
                          "over gloo on the host: no model, no GPU, not a measurement")
@@ -369,6 +372,8 @@ def main():
     from transformertts_amd.step import TrainStep
     from transformertts_amd.workload import model_config, synth_batch
 
+    if args.no_image_operands:
+        ops.IMAGE_MIN_ROWS = 1 << 62
     cfg = model_config(args.config)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
               "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,
@@ -552,6 +557,7 @@ def main():
                                           "tail overlapped with backward" if ts.trigger is not None
                                           else "one collective after backward"),
                        "alignments_written": bool(args.alignments),
+                       "image_operands": not args.no_image_operands,
                        "final_loss": final_loss, "per_step_loss_item_sync": False},
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "sustained": sustained,

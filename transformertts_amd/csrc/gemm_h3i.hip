@@ -18,7 +18,7 @@
 //     one's store burst and LDS turn run under the other's MFMAs -- the overlap a single 256 x 256 workgroup per CU cannot
 //     have (vmcnt is one in-order counter per wave: a wave cannot wait for loads issued behind its own stores);
 //   * the operand stream does not stop at a tile boundary: the first two k-tiles of the workgroup's next tile are requested
-//     before the epilogue's stores, so they are older than the stores in the counter and the next tile starts on landed data.
+//     (and the first one is read into registers) before the epilogue, so the next tile starts on landed data.
 // N = 256 outputs (out-projection, FFN2) keep whole rows inside one tile.
 //
 // LDS stage (24 KB): activation rows [128][64 B] then weight rows [256][64 B]; a row's 64 bytes are four 16-byte chunks
@@ -32,7 +32,6 @@ namespace ttts {
 constexpr int IBM = 128, IBN = 256, IBK = 16, INST = 3;
 constexpr int I_A_BYTES = IBM * 64, I_B_BYTES = IBN * 64, I_STAGE = I_A_BYTES + I_B_BYTES;
 constexpr int I_LOADS = 6;              // LDS-DMA instructions per wave and k-tile: 2 activation + 4 weight pieces of 1 KB
-constexpr int I_EP_STORES = 32;         // store instructions per wave and tile: 8 accumulator blocks x 4, all unconditional
 
 __device__ __forceinline__ uint32_t lds_addr_i(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
@@ -183,10 +182,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
         [[maybe_unused]] const unsigned long long s1 = ISTAMP();
         products(SET, 0);
         [[maybe_unused]] const unsigned long long s2 = ISTAMP();
-        // k-tile t+1 has landed when all but the requests BEHIND it have: the I_LOADS just issued and -- for the k-tile requested
-        // before the previous tile's epilogue -- that epilogue's stores (a LOWER bound of what was issued since keeps the count
-        // safe: every store of the epilogue is unconditional)
-        if (first_after_ep) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "i"(I_LOADS + I_EP_STORES) : "memory");
+        // k-tile t+1 has landed when all but the I_LOADS requests behind it have: LDS-DMAs complete in the order they were issued
+        // AMONG THEMSELVES, so "at most I_LOADS operations outstanding" implies it whatever else (stores) is still in flight.
+        // The first k-tile after an epilogue needs no count at all: the epilogue began with vmcnt(0) (see there).
+        if (first_after_ep) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "i"(I_LOADS) : "memory");
         [[maybe_unused]] const unsigned long long s3 = ISTAMP();
         const int nstage = cstage == INST - 1 ? 0 : cstage + 1;
@@ -218,6 +217,12 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
         // cstage holds the NEXT tile's first k-tile (its fragments are in set 0 already), the stage behind it the second; the
         // stage before it is the one the last products ran on: every wave passed the last barrier after reading it -> the slabs
         const int ep_stage = cstage == 0 ? INST - 1 : cstage - 1;
+        // LDS-DMAs and ordinary loads / stores do NOT complete in one common order (measured: with the next tile's k-tile still
+        // in flight, hipcc's counted `s_waitcnt vmcnt(4)` in front of a residual / gate operand -- correct if everything retired
+        // in issue order -- let the operand be read before it had arrived: a few hundred wrong elements per launch, only where a
+        // workgroup has a next tile).  So no DMA is in flight while the epilogue's own loads and stores are counted: this wait,
+        // for a k-tile requested a whole k-tile ago, costs little; the next tile's first k-tile is in registers already.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         // ---------------- epilogue: each 32 x 32 accumulator block is scaled by its lane's row factor, turned through a 4 KB slab
         // (row-major, 16-byte chunk ^= row & 7: conflict-free both ways) and leaves as whole 128-byte lines.
@@ -268,70 +273,75 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
                     const_cast<float*>(HAS_RES ? g.residual : g.A), 0, HAS_RES ? (uint32_t)((long)g.M * g.ldr * 4) : 0u, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float*>(HAS_GATE ? g.relu_out : g.A), 0, HAS_GATE ? (uint32_t)((long)g.M * g.ldc * 4) : 0u, 0x00020000);
-                float4 r4[HAS_RES ? 4 : 1], g4[HAS_GATE ? 4 : 1];
-                auto load_aux = [&](int blk) {
-                    const int i = blk >> 2, j = blk & 3;
+                // Auxiliary operands (residual, relu gate) are requested block by block, behind the previous block's stores, and
+                // waited for with everything older.  Requesting them AHEAD of those stores and counting the stores as
+                // "younger" (`s_waitcnt vmcnt(4)`, which is what hipcc emits for that order) is not safe on this chip: stores
+                // retire ahead of older loads under load -- measured, a few hundred operands per launch read before they had
+                // arrived (tools/h3i_repro.py) -- so a count can only be trusted to mean "everything older than the stores".
+                constexpr int GB = 1;                    // blocks per group (two: 32 more registers per operand kind -> spills)
+                float4 r4[HAS_RES ? 4 * GB : 1], g4[HAS_GATE ? 4 * GB : 1];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t soff = (uint32_t)(i * 32 + u * 8) * row_step;
-                        if (HAS_RES) r4[u] = buf_load4s(rsrcR, offC[j], soff);
-                        if (HAS_GATE) g4[u] = buf_load4s(rsrcG, offC[j], soff);
+                for (int pair = 0; pair < 8 / GB; ++pair) {
+                    const int i = (pair * GB) >> 2;
+                    if (HAS_RES || HAS_GATE) {
+#pragma unroll
+                        for (int b2 = 0; b2 < GB; ++b2)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int j = (pair * GB + b2) & 3;
+                                const uint32_t soff = (uint32_t)(i * 32 + u * 8) * row_step;
+                                if (HAS_RES) r4[b2 * 4 + u] = buf_load4s(rsrcR, offC[j], soff);
+                                if (HAS_GATE) g4[b2 * 4 + u] = buf_load4s(rsrcG, offC[j], soff);
+                            }
                     }
-                };
-                if (HAS_RES || HAS_GATE) load_aux(0);
 #pragma unroll
-                for (int blk = 0; blk < 8; ++blk) {
-                    const int i = blk >> 2, j = blk & 3;
+                    for (int b2 = 0; b2 < GB; ++b2) {
+                        const int j = (pair * GB + b2) & 3;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<float4*>(slab + l31 * 32 + (((2 * q + half) ^ (l31 & 7)) * 4)) =
-                            make_float4(acc[i][j][4 * q] * rs[i], acc[i][j][4 * q + 1] * rs[i], acc[i][j][4 * q + 2] * rs[i],
-                                        acc[i][j][4 * q + 3] * rs[i]);
-                    // (LDS instructions of one wave execute in order: no wait between its writes and its reads, only the
-                    // compiler must keep them in order)
-                    __builtin_amdgcn_wave_barrier();
-                    asm volatile("" ::: "memory");
-                    float v[4][4];
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<float4*>(slab + l31 * 32 + (((2 * q + half) ^ (l31 & 7)) * 4)) =
+                                make_float4(acc[i][j][4 * q] * rs[i], acc[i][j][4 * q + 1] * rs[i], acc[i][j][4 * q + 2] * rs[i],
+                                            acc[i][j][4 * q + 3] * rs[i]);
+                        // (LDS instructions of one wave execute in order: no wait between its writes and its reads, only the
+                        // compiler must keep them in order)
+                        __builtin_amdgcn_wave_barrier();
+                        asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int srow = u * 8 + rsub;
-                        const int rg = i * 32 + u * 8;                   // row group, wave-uniform
-                        const float4 a4 = *reinterpret_cast<const float4*>(slab + srow * 32 + ((ch ^ (srow & 7)) * 4));
-                        v[u][0] = a4.x + bias4[j].x; v[u][1] = a4.y + bias4[j].y; v[u][2] = a4.z + bias4[j].z; v[u][3] = a4.w + bias4[j].w;
+                        for (int u = 0; u < 4; ++u) {
+                            const int srow = u * 8 + rsub;
+                            const int rg = i * 32 + u * 8;                   // row group, wave-uniform
+                            const float4 a4 = *reinterpret_cast<const float4*>(slab + srow * 32 + ((ch ^ (srow & 7)) * 4));
+                            float v[4] = {a4.x + bias4[j].x, a4.y + bias4[j].y, a4.z + bias4[j].z, a4.w + bias4[j].w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[u][e] = fmaxf(v[u][e], relu_lo);
-                        if (DROP) {
-                            bool kp[4];
-                            keep_quad(seed_eff, idx0[j] + (uint64_t)rg * (uint64_t)g.N, g.drop_thr, kp);
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_lo);
+                            if (DROP) {
+                                bool kp[4];
+                                keep_quad(seed_eff, idx0[j] + (uint64_t)rg * (uint64_t)g.N, g.drop_thr, kp);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[u][e] *= kp[e] ? g.drop_scale : 0.f;        // (a product, as torch's dropout)
+                                for (int e = 0; e < 4; ++e) v[e] *= kp[e] ? g.drop_scale : 0.f;        // (a product, as torch's dropout)
+                            }
+                            if (HAS_GATE) {
+                                const float4 gq = g4[HAS_GATE ? b2 * 4 + u : 0];
+                                const float gg[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] *= gg[e] > 0.f ? g.relu_scale : 0.f;
+                            }
+                            if (HAS_RES) {
+                                const float4 rq = r4[HAS_RES ? b2 * 4 + u : 0];
+                                v[0] += rq.x; v[1] += rq.y; v[2] += rq.z; v[3] += rq.w;
+                            }
+                            if (want_max) {          // branch-free: two v_max3, a compare and a select
+                                float mx = fmaxf(fmaxf(cmax, fabsf(v[0])), fabsf(v[1]));
+                                mx = fmaxf(fmaxf(mx, fabsf(v[2])), fabsf(v[3]));
+                                cmax = rg < live_rows[j] ? mx : cmax;
+                            }
+                            // unconditional: see the addressing note above
+                            buf_store4s(rsrcC, offC[j], (uint32_t)rg * row_step, make_float4(v[0], v[1], v[2], v[3]));
                         }
-                        if (HAS_GATE) {
-                            const float4 gq = g4[HAS_GATE ? u : 0];
-                            const float gg[4] = {gq.x, gq.y, gq.z, gq.w};
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[u][e] *= gg[e] > 0.f ? g.relu_scale : 0.f;
-                        }
-                        if (HAS_RES) {
-                            const float4 rq = r4[HAS_RES ? u : 0];
-                            v[u][0] += rq.x; v[u][1] += rq.y; v[u][2] += rq.z; v[u][3] += rq.w;
-                        }
-                        if (want_max) {          // branch-free: two v_max3, a compare and a select
-                            float mx = fmaxf(fmaxf(cmax, fabsf(v[u][0])), fabsf(v[u][1]));
-                            mx = fmaxf(fmaxf(mx, fabsf(v[u][2])), fabsf(v[u][3]));
-                            cmax = rg < live_rows[j] ? mx : cmax;
-                        }
+                        __builtin_amdgcn_wave_barrier();
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // the next block's auxiliary operands go out BEFORE this block's stores (their registers are free now)
-                    if ((HAS_RES || HAS_GATE) && blk + 1 < 8) load_aux(blk + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)      // unconditional: see the addressing note above
-                        buf_store4s(rsrcC, offC[j], (uint32_t)(i * 32 + u * 8) * row_step, make_float4(v[u][0], v[u][1], v[u][2], v[u][3]));
-                    __builtin_amdgcn_wave_barrier();
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (want_max) amax_publish(cmax, g.c_amax, bid);
