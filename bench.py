@@ -335,8 +335,11 @@ def main():
                          "reference's forward does (model/layers.py:68-73); the step's results do not depend on them")
     ap.add_argument("--no-alignments-figure", action="store_true", help="skip the secondary figure taken with --alignments semantics")
     ap.add_argument("--no-image-operands", action="store_true",
-                    help="A/B aid: keep every GEMM on the kernels that split the fp32 activation in their loader (gemm_h3) instead of "
-                         "the image-operand kernel behind LayerNorm (gemm_h3i)")
+                    help="A/B aid: keep every GEMM on the kernels that split the fp32 activation in their loader (gemm_h3): no launch "
+                         "of the LDS-DMA kernel (gemm_h3i)")
+    ap.add_argument("--layernorm-images", action="store_true",
+                    help="A/B aid: LayerNorm forward / backward also write the image operand of their output and the GEMMs behind "
+                         "them take it (measured slower over the step: transformertts_amd/ops.py, LAYERNORM_IMAGES)")
     ap.add_argument("--launch-check", action="store_true",
                     help="exercise the launcher protocol only (process group, barrier, MAX-over-ranks clock, rank-0 JSON line) "
                          "over gloo on the host: no model, no GPU, not a measurement")
@@ -373,7 +376,9 @@ def main():
     from transformertts_amd.workload import model_config, synth_batch
 
     if args.no_image_operands:
-        ops.IMAGE_MIN_ROWS = 1 << 62
+        ops.DMA_GEMMS = False
+    if args.layernorm_images:
+        ops.LAYERNORM_IMAGES = True
     cfg = model_config(args.config)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
               "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,
@@ -557,7 +562,7 @@ def main():
                                           "tail overlapped with backward" if ts.trigger is not None
                                           else "one collective after backward"),
                        "alignments_written": bool(args.alignments),
-                       "image_operands": not args.no_image_operands,
+                       "dma_gemms": not args.no_image_operands, "layernorm_images": bool(args.layernorm_images),
                        "final_loss": final_loss, "per_step_loss_item_sync": False},
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "sustained": sustained,

@@ -179,6 +179,15 @@ int ttts_linear_fwd_h3i(const void* x_image, const float* x_row_inv, const void*
 int ttts_linear_bwd_data_h3i(const void* dy_image, const float* dy_row_inv, const void* wt_planes, const float* residual,
                              float* dx, int64_t M, int N, int K, const float* relu_out, float relu_scale,
                              float* dx_amax_out, void* stream);
+/* the same kernel on a plain fp32 activation (per-tensor scale from x_amax, as ttts_linear_fwd_h3): the raw k-tile is staged by
+ * LDS-DMA and split in place in LDS, so no producer has to write an image; weight planes = modes 8 / 9.  Arguments as
+ * ttts_linear_fwd_h3 / ttts_linear_bwd_data_h3 (no row shift; K resp. N a multiple of 32). */
+int ttts_linear_fwd_h3d(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
+                        int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed,
+                        const float* x_amax, float* y_amax_out, void* stream);
+int ttts_linear_bwd_data_h3d(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
+                             int K, const float* relu_out, float relu_scale, const float* dy_amax, float* dx_amax_out,
+                             void* stream);
 int ttts_conv1d_bwd_data_h3(const float* dy, const void* planes_bwd, float* dx, int B, int T, int cin, int cout, int taps,
                             const float* dy_amax, void* stream);
 int ttts_linear_bwd_data_x6(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,

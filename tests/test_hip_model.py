@@ -565,6 +565,7 @@ def test_image_operand_path_on_small_shapes(monkeypatch, cfg_name, B, Tp, Tm, w_
     test_forward_backward_vs_oracle[base-16-100-870] and the batch-64 property tests.)"""
     from transformertts_amd import ops
     monkeypatch.setattr(ops, "IMAGE_MIN_ROWS", 1)
+    monkeypatch.setattr(ops, "LAYERNORM_IMAGES", True)
     calls = {"fwd": 0, "bwd": 0}
     from transformertts_amd import _lib
     lib = _lib.load()
@@ -572,4 +573,19 @@ def test_image_operand_path_on_small_shapes(monkeypatch, cfg_name, B, Tp, Tm, w_
     monkeypatch.setattr(lib, "ttts_linear_fwd_h3i", lambda *a: (calls.__setitem__("fwd", calls["fwd"] + 1), f0(*a))[1])
     monkeypatch.setattr(lib, "ttts_linear_bwd_data_h3i", lambda *a: (calls.__setitem__("bwd", calls["bwd"] + 1), b0(*a))[1])
     test_forward_backward_vs_oracle(cfg_name, B, Tp, Tm, w_seed, b_seed)
+    assert calls["fwd"] > 0 and calls["bwd"] > 0, calls
+
+
+def test_dma_gemm_on_plain_fp32_operands_on_small_shapes(monkeypatch):
+    """ttts_linear_fwd_h3d / ttts_linear_bwd_data_h3d -- the LDS-DMA kernel on a plain fp32 activation (raw k-tile staged by DMA,
+    split in place in LDS) -- are what the step uses for the 256 -> 256 projections and the gated data gradients from 8 192 rows
+    on; with the threshold lowered the whole base model runs through them against the fp64 oracle."""
+    from transformertts_amd import _lib, ops
+    monkeypatch.setattr(ops, "IMAGE_MIN_ROWS", 1)
+    calls = {"fwd": 0, "bwd": 0}
+    lib = _lib.load()
+    f0, b0 = lib.ttts_linear_fwd_h3d, lib.ttts_linear_bwd_data_h3d
+    monkeypatch.setattr(lib, "ttts_linear_fwd_h3d", lambda *a: (calls.__setitem__("fwd", calls["fwd"] + 1), f0(*a))[1])
+    monkeypatch.setattr(lib, "ttts_linear_bwd_data_h3d", lambda *a: (calls.__setitem__("bwd", calls["bwd"] + 1), b0(*a))[1])
+    test_forward_backward_vs_oracle("base", 2, 60, 300, 12, 22)
     assert calls["fwd"] > 0 and calls["bwd"] > 0, calls

@@ -70,6 +70,12 @@ for (m, n, k, scale) in [(300, 96, 64, 1.0), (129, 256, 256, 1e-4), (1000, 768, 
     print(f"fwd  M={m} N={n} K={k} scale={scale:g}: rel-L2 {e:.2e} worst row {rows:.2e} amax ok {ok_amax}", flush=True)
     worst = max(worst, e, rows if torch.isfinite(torch.tensor(rows)) else 1.0)
     assert ok_amax
+    yd_ = torch.full((m, n), float("nan"), device=dev)
+    _lib.check(lib.ttts_linear_fwd_h3d(_p(x), _p(ops._planes(w, 8, n, k)), _p(b), _p(res), _p(yd_), m, n, k, 0, 0.0, 0, None,
+                                       _p(amax_of(x)), None, _stream()), "fwd_h3d")
+    e = rel(yd_, ref)
+    print(f"h3d  M={m} N={n} K={k}: rel-L2 {e:.2e}", flush=True)
+    worst = max(worst, e)
     # relu + dropout epilogue: same mask as the fp32-operand kernel (the mask is a function of seed and element index)
     y1, y2 = torch.empty(m, n, device=dev), torch.empty(m, n, device=dev)
     _lib.check(lib.ttts_linear_fwd_h3i(_p(img), _p(inv), _p(ops._planes(w, 8, n, k)), _p(b), None, _p(y1), m, n, k, 1, 0.1, 77, None,
@@ -88,6 +94,12 @@ for (m, n, k, scale) in [(300, 96, 64, 1.0), (129, 256, 256, 1e-4), (1000, 768, 
         refd = (dy.double() @ w.double()) * (h > 0).double() / 0.9
         e = rel(dx, refd)
         print(f"dgrad M={m} N={n} K={k}: rel-L2 {e:.2e}", flush=True)
+        worst = max(worst, e)
+        dx2 = torch.empty(m, k, device=dev)
+        _lib.check(lib.ttts_linear_bwd_data_h3d(_p(dy), _p(ops._planes(w, 9, k, n)), None, _p(dx2), m, n, k, _p(h), 1.0 / 0.9,
+                                                _p(amax_of(dy)), None, _stream()), "bwd_h3d")
+        e = rel(dx2, refd)
+        print(f"dgrad h3d M={m} N={n} K={k}: rel-L2 {e:.2e}", flush=True)
         worst = max(worst, e)
 torch.cuda.synchronize()
 print(f"worst rel-L2 {worst:.2e}")
@@ -114,31 +126,39 @@ scr_i, scr_v = torch.empty_like(xi), torch.empty_like(xv)
 cases = [
     ("ffn1 fwd  relu+drop+amax  N=1024 K=256", 2.0 * M * f * d,
      lambda: lib.ttts_linear_fwd_h3(_p(x), _p(p1), _p(b1), None, _p(yf), M, f, d, 1, 0.1, 77, None, 0, 0, _p(xa), _p(am), _stream()),
-     lambda: lib.ttts_linear_fwd_h3i(_p(xi), _p(xv), _p(k1), _p(b1), None, _p(yf), M, f, d, 1, 0.1, 77, None, _p(am), _stream())),
+     lambda: lib.ttts_linear_fwd_h3i(_p(xi), _p(xv), _p(k1), _p(b1), None, _p(yf), M, f, d, 1, 0.1, 77, None, _p(am), _stream()),
+     lambda: lib.ttts_linear_fwd_h3d(_p(x), _p(k1), _p(b1), None, _p(yf), M, f, d, 1, 0.1, 77, None, _p(xa), _p(am), _stream())),
     ("inproj fwd bias+amax      N=768 K=256", 2.0 * M * 3 * d * d,
      lambda: lib.ttts_linear_fwd_h3(_p(x), _p(pq), _p(bq), None, _p(yq), M, 3 * d, d, 0, 0.0, 0, None, 0, 0, _p(xa), _p(am), _stream()),
-     lambda: lib.ttts_linear_fwd_h3i(_p(xi), _p(xv), _p(kq), _p(bq), None, _p(yq), M, 3 * d, d, 0, 0.0, 0, None, _p(am), _stream())),
+     lambda: lib.ttts_linear_fwd_h3i(_p(xi), _p(xv), _p(kq), _p(bq), None, _p(yq), M, 3 * d, d, 0, 0.0, 0, None, _p(am), _stream()),
+     lambda: lib.ttts_linear_fwd_h3d(_p(x), _p(kq), _p(bq), None, _p(yq), M, 3 * d, d, 0, 0.0, 0, None, _p(xa), _p(am), _stream())),
     ("outproj fwd res+drop      N=256 K=256", 2.0 * M * d * d,
      lambda: lib.ttts_linear_fwd_h3(_p(x), _p(po), _p(b2), _p(skip), _p(yd), M, d, d, 0, 0.1, 79, None, 0, 0, _p(xa), None, _stream()),
-     lambda: lib.ttts_linear_fwd_h3i(_p(xi), _p(xv), _p(ko), _p(b2), _p(skip), _p(yd), M, d, d, 0, 0.1, 79, None, None, _stream())),
+     lambda: lib.ttts_linear_fwd_h3i(_p(xi), _p(xv), _p(ko), _p(b2), _p(skip), _p(yd), M, d, d, 0, 0.1, 79, None, None, _stream()),
+     lambda: lib.ttts_linear_fwd_h3d(_p(x), _p(ko), _p(b2), _p(skip), _p(yd), M, d, d, 0, 0.1, 79, None, _p(xa), None, _stream())),
     ("ffn2 fwd  res+drop        N=256 K=1024", 2.0 * M * f * d,
      lambda: lib.ttts_linear_fwd_h3(_p(h), _p(p2), _p(b2), _p(skip), _p(yd), M, d, f, 0, 0.1, 78, None, 0, 0, _p(ha), None, _stream()),
-     lambda: lib.ttts_linear_fwd_h3i(_p(hi), _p(hv), _p(k2), _p(b2), _p(skip), _p(yd), M, d, f, 0, 0.1, 78, None, None, _stream())),
+     lambda: lib.ttts_linear_fwd_h3i(_p(hi), _p(hv), _p(k2), _p(b2), _p(skip), _p(yd), M, d, f, 0, 0.1, 78, None, None, _stream()),
+     lambda: lib.ttts_linear_fwd_h3d(_p(h), _p(k2), _p(b2), _p(skip), _p(yd), M, d, f, 0, 0.1, 78, None, _p(ha), None, _stream())),
     ("ffn2 dgrad gate+amax      N=1024 K=256", 2.0 * M * f * d,
      lambda: lib.ttts_linear_bwd_data_h3(_p(dy), _p(p2t), None, _p(yf), M, d, f, _p(h), 1.0 / 0.9, _p(dya), _p(am), _stream()),
-     lambda: lib.ttts_linear_bwd_data_h3i(_p(dyi), _p(dyv), _p(k2t), None, _p(yf), M, d, f, _p(h), 1.0 / 0.9, _p(am), _stream())),
+     lambda: lib.ttts_linear_bwd_data_h3i(_p(dyi), _p(dyv), _p(k2t), None, _p(yf), M, d, f, _p(h), 1.0 / 0.9, _p(am), _stream()),
+     lambda: lib.ttts_linear_bwd_data_h3d(_p(dy), _p(k2t), None, _p(yf), M, d, f, _p(h), 1.0 / 0.9, _p(dya), _p(am), _stream())),
     ("ffn1 dgrad residual       N=256 K=1024", 2.0 * M * f * d,
      lambda: lib.ttts_linear_bwd_data_h3(_p(dh), _p(p1t), _p(skip), _p(yd), M, f, d, None, 1.0, _p(dha), None, _stream()),
-     lambda: lib.ttts_linear_bwd_data_h3i(_p(dhi), _p(dhv), _p(k1t), _p(skip), _p(yd), M, f, d, None, 1.0, None, _stream())),
+     lambda: lib.ttts_linear_bwd_data_h3i(_p(dhi), _p(dhv), _p(k1t), _p(skip), _p(yd), M, f, d, None, 1.0, None, _stream()),
+     lambda: lib.ttts_linear_bwd_data_h3d(_p(dh), _p(k1t), _p(skip), _p(yd), M, f, d, None, 1.0, _p(dha), None, _stream())),
 ]
 res = {}
 for rnd in range(3):
-    for name, fl, fa, fb in cases:
-        res.setdefault(name, [[], []])
+    for name, fl, fa, fb, fc in cases:
+        res.setdefault(name, [[], [], []])
         res[name][0].append(timeit(fa))
         res[name][1].append(timeit(fb))
-for name, fl, fa, fb in cases:
-    a, b = min(res[name][0]), min(res[name][1])
-    print(f"{name:42s} h3 {a:7.1f} us {fl / a / 1e6:6.1f} TF | h3i {b:7.1f} us {fl / b / 1e6:6.1f} TF  ({a / b:.2f}x)", flush=True)
+        res[name][2].append(timeit(fc))
+for name, fl, fa, fb, fc in cases:
+    a, b, c = min(res[name][0]), min(res[name][1]), min(res[name][2])
+    print(f"{name:38s} h3 {a:6.1f} us {fl / a / 1e6:5.0f} TF | image {b:6.1f} us {fl / b / 1e6:5.0f} TF ({a / b:.2f}x) | "
+          f"fp32 by DMA {c:6.1f} us {fl / c / 1e6:5.0f} TF ({a / c:.2f}x)", flush=True)
 t = timeit(lambda: lib.ttts_act_image(_p(x), _p(scr_i), _p(scr_v), M, d, _stream()))
 print(f"act_image {M} x {d}: {t:.1f} us")

@@ -42,6 +42,8 @@ SIGNATURES = {
     "ttts_act_image": (I, [P, P, P, L, I, P]),
     "ttts_linear_fwd_h3i": (I, [P, P, P, P, P, P, L, I, I, I, F, U, P, P, P]),
     "ttts_linear_bwd_data_h3i": (I, [P, P, P, P, P, L, I, I, P, F, P, P]),
+    "ttts_linear_fwd_h3d": (I, [P, P, P, P, P, L, I, I, I, F, U, P, P, P, P]),
+    "ttts_linear_bwd_data_h3d": (I, [P, P, P, P, L, I, I, P, F, P, P, P]),
     "ttts_conv1d_bwd_data_h3": (I, [P, P, P, I, I, I, I, I, P, P]),
     "ttts_linear_bwd_data_x6": (I, [P, P, P, P, L, I, I, P, F, P]),
     "ttts_conv1d_fwd_x6": (I, [P, P, P, P, I, I, I, I, I, P]),

@@ -64,7 +64,13 @@ __device__ unsigned long long ttts_h3i_stamps[512 * 4 * 8];
 // the six variants behind run-time branches in one kernel, hipcc's s_waitcnt insertion merged their counter states at the tile
 // loop's head and put `s_waitcnt vmcnt(0)` in front of the main loop's first fragment read -- a wait for the DMAs issued a
 // few instructions earlier, i.e. no prefetch at all (2.2k instead of 1.1k cycles per k-tile).
-template <bool HAS_RES, bool HAS_GATE, bool DROP>
+// A_RAW: the activation is plain fp32 (row-major, row stride lda) with a per-TENSOR scale from its partial maxima, as gemm_h3
+// takes it -- no producer has to write an image.  The raw 16-deep k-tile (128 rows x 64 B) is DMA'd into the stage's activation
+// area exactly like an image k-tile; the wave that requested a 32-row piece converts it IN PLACE once its own requests have
+// landed (two 16-byte reads per lane, the split, two 16-byte writes: the raw row and its {hi, lo} planes are the same 64 bytes),
+// in front of the k-tile's barrier.  ~1.3 VALU instructions per MFMA instead of the 3.5 of gemm_h3's loader, no staging
+// registers, and everything global still moves by LDS-DMA, so the counted waits stay within one completion order.
+template <bool A_RAW, bool HAS_RES, bool HAS_GATE, bool DROP>
 __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
 #ifdef TTTS_H3I_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -79,11 +85,12 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
     const int nkt = g.K / IBK;
     const int nx = (g.N + IBN - 1) / IBN;
     const int ntiles = nx * ((g.M + IBM - 1) / IBM);
-    float w_inv;
+    float w_inv, a_scale = 1.f, a_inv = 1.f;
     {
         float w_scale;
         h3_operand_scale(g.b_amax, g.b_amax_n, lane, w_scale, w_inv);       // the planes already carry w_scale
-        asm volatile("" :: "s"(w_inv));     // the wait for this load sits HERE, in front of the first DMA, not in the first epilogue
+        if (A_RAW) h3_operand_scale(g.a_amax, g.a_amax_n, lane, a_scale, a_inv);
+        asm volatile("" :: "s"(w_inv), "s"(a_scale));     // the wait for these loads sits HERE, in front of the first DMA
     }
     auto tile_coords = [&](int bid, int& m0, int& n0) {     // XCD-aware numbering of gemm_h3_kernel: column tiles of a row panel share an L2
         const int xcd = bid & 7, slot = bid >> 3;
@@ -97,7 +104,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
     // Both images are K16-MAJOR: [k / 16][row][64 B], so the 16 rows of a piece are ONE contiguous KB (eight whole lines).
     const int r16 = lane >> 2, c = (lane & 3) ^ ((r16 >> 2) & 3);
     const uint32_t lane_off = (uint32_t)r16 * 64u + (uint32_t)c * 16u;
-    const uint32_t a_kstep = (uint32_t)g.M * 64u, b_kstep = (uint32_t)g.N * 64u;     // one k-tile further
+    // (A_RAW: fp32 rows of lda floats, the lane's chunk unswizzled -- the in-place conversion applies the swizzle)
+    const uint32_t a_row_bytes = (uint32_t)g.lda * 4u;
+    const uint32_t a_lane_off = A_RAW ? (uint32_t)r16 * a_row_bytes + (uint32_t)(lane & 3) * 16u : lane_off;
+    const uint32_t a_kstep = A_RAW ? 64u : (uint32_t)g.M * 64u, b_kstep = (uint32_t)g.N * 64u;     // one k-tile further
     const uint32_t lds0 = lds_addr_i(lds);
     const uint64_t a_base = reinterpret_cast<uint64_t>(g.A), b_base = reinterpret_cast<uint64_t>(g.B);
     int ld_bid = blockIdx.x, ld_kt = 0, ld_stage = 0;
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
         const bool live = bid < ntiles;     //  k-tile loop needs no variant that stops requesting)
         int m0, n0;
         tile_coords(live ? bid : 0, m0, n0);
-        ld_a0 = (uint32_t)(m0 + wave * 32) * 64u;
+        ld_a0 = A_RAW ? (uint32_t)((long)(m0 + wave * 32) * a_row_bytes) : (uint32_t)(m0 + wave * 32) * 64u;
         ld_b0 = (uint32_t)(n0 + wave * 64) * 64u;
         ld_abytes = live ? g.a_bytes : 0u;
         ld_bbytes = live ? g.b_bytes : 0u;
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
         const uint32_t b_s = ld_b0 + (uint32_t)ld_kt * b_kstep;
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-            dma16b(rsrcA, lane_off, __builtin_amdgcn_readfirstlane(a_s + e * 1024u),
+            dma16b(rsrcA, a_lane_off, __builtin_amdgcn_readfirstlane(a_s + e * (A_RAW ? 16u * a_row_bytes : 1024u)),
                    __builtin_amdgcn_readfirstlane(dst + (uint32_t)(2 * wave + e) * 1024u));
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -171,6 +181,22 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
             acc[i][j] = cc;
         }
     };
+    // A_RAW: lane -> (row 32 * wave + lane / 2, k-half lane & 1) of the wave's own piece: raw chunks 2h, 2h+1 -> chunks h (hi), 2 + h (lo)
+    auto convert_rows = [&](int stage) {
+        const int row = wave * 32 + (lane >> 1), h = lane & 1, swr = (row >> 2) & 3;
+        char* p = reinterpret_cast<char*>(lds) + stage * I_STAGE + row * 64;
+        const float4 x0 = *reinterpret_cast<const float4*>(p + h * 32), x1 = *reinterpret_cast<const float4*>(p + h * 32 + 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every lane has its raw values before any lane overwrites the row
+        __builtin_amdgcn_wave_barrier();
+        u32x4 hi, lo;
+        uint32_t hh, ll;
+        split2_pair(f32x2{x0.x, x0.y} * a_scale, hh, ll); hi.x = hh; lo.x = ll;
+        split2_pair(f32x2{x0.z, x0.w} * a_scale, hh, ll); hi.y = hh; lo.y = ll;
+        split2_pair(f32x2{x1.x, x1.y} * a_scale, hh, ll); hi.z = hh; lo.z = ll;
+        split2_pair(f32x2{x1.z, x1.w} * a_scale, hh, ll); hi.w = hh; lo.w = ll;
+        *reinterpret_cast<u32x4*>(p + ((h ^ swr) * 16)) = hi;
+        *reinterpret_cast<u32x4*>(p + (((2 + h) ^ swr) * 16)) = lo;
+    };
     int cstage = 0;                 // stage of the k-tile whose fragments sit in set 0 at the top of an (even) iteration
     bool after_ep = false;
     // one k-tile: `set` holds its fragments (compile-time), the other set receives the next k-tile's
@@ -185,7 +211,12 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
         // k-tile t+1 has landed when all but the I_LOADS requests behind it have: LDS-DMAs complete in the order they were issued
         // AMONG THEMSELVES, so "at most I_LOADS operations outstanding" implies it whatever else (stores) is still in flight.
         // The first k-tile after an epilogue needs no count at all: the epilogue began with vmcnt(0) (see there).
-        if (first_after_ep) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (A_RAW) {
+            // this wave's own requests for k-tile t+1 have landed: convert its 32 raw rows in place, then meet the others
+            if (!first_after_ep) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(I_LOADS) : "memory");
+            convert_rows(cstage == INST - 1 ? 0 : cstage + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else if (first_after_ep) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "i"(I_LOADS) : "memory");
         [[maybe_unused]] const unsigned long long s3 = ISTAMP();
         const int nstage = cstage == INST - 1 ? 0 : cstage + 1;
@@ -198,7 +229,13 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
     set_ld_tile(ld_bid);
     issue();                        // k-tiles 0 and 1 of the first tile (K >= 32)
     issue();
-    wait_vm_barrier<I_LOADS>();
+    if (A_RAW) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(I_LOADS) : "memory");
+        convert_rows(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+        wait_vm_barrier<I_LOADS>();
+    }
     read_frags(0, 0);
     for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
         int m0, n0;
@@ -238,13 +275,14 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
             const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (uint32_t)((long)g.M * g.ldc * 4), 0x00020000);
             const __amdgpu_buffer_rsrc_t rsrcBias = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(g.bias != nullptr ? g.bias : g.A), 0, g.bias != nullptr ? (uint32_t)g.N * 4u : 0u, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.a_row_inv), 0,
-                                                                                  (uint32_t)g.M * 4u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(A_RAW ? g.A : g.a_row_inv), 0, A_RAW ? 0u : (uint32_t)g.M * 4u, 0x00020000);
             float rs[2];
             float4 bias4[4];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                rs[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcS, (m0 + wm * 64 + i * 32 + l31) * 4, 0, 0)) * w_inv;
+                rs[i] = A_RAW ? a_inv * w_inv
+                              : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcS, (m0 + wm * 64 + i * 32 + l31) * 4, 0, 0)) * w_inv;
 #pragma unroll
             for (int j = 0; j < 4; ++j) bias4[j] = buf_load4(rsrcBias, (col0 + j * 32 < g.N) ? (uint32_t)(col0 + j * 32) * 4u : OOB);
             const float relu_lo = (g.act == 1) ? 0.f : -__builtin_inff();
@@ -358,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
 }
 
 bool h3i_supports(const GemmArgs& g) {
-    return g.a_row_inv != nullptr && g.K % 32 == 0 && g.K >= 32 && g.N % 4 == 0 && g.T <= 0 && g.bn_ws == nullptr &&
+    return (g.a_row_inv != nullptr || g.a_amax != nullptr) && g.K % 32 == 0 && g.K >= 32 && g.N % 4 == 0 && g.T <= 0 && g.bn_ws == nullptr &&
            (uint64_t)g.N * g.K * 4 < (1ull << 32);
 }
 
@@ -383,7 +421,11 @@ int dispatch_h3i(const GemmArgs& g, hipStream_t stream) {
         set_error("fp16x3 GEMM (image operand): a relu gate (data gradient) cannot be combined with dropout");
         return TTTS_ERR_INVALID;
     }
-#define TTTS_H3I(R, G, D) hipLaunchKernelGGL((gemm_h3i_kernel<R, G, D>), grid, dim3(256), 0, stream, g)
+#define TTTS_H3I(R, G, D)                                                                                   \
+    do {                                                                                                    \
+        if (g.a_row_inv != nullptr) hipLaunchKernelGGL((gemm_h3i_kernel<false, R, G, D>), grid, dim3(256), 0, stream, g); \
+        else hipLaunchKernelGGL((gemm_h3i_kernel<true, R, G, D>), grid, dim3(256), 0, stream, g);          \
+    } while (0)
     if (gate) { if (res) TTTS_H3I(true, true, false); else TTTS_H3I(false, true, false); }
     else if (drop) { if (res) TTTS_H3I(true, false, true); else TTTS_H3I(false, false, true); }
     else { if (res) TTTS_H3I(true, false, false); else TTTS_H3I(false, false, false); }
@@ -488,6 +530,52 @@ extern "C" int ttts_linear_bwd_data_h3i(const void* dy_image, const float* dy_ro
     g.residual = residual; g.ldr = K;
     g.relu_out = relu_out; g.relu_scale = relu_scale;
     g.a_row_inv = dy_row_inv;
+    g.b_amax = h3_plane_tail(wt_planes, K, N); g.b_amax_n = 1;
+    g.c_amax = dx_amax_out;
+    return dispatch_h3i(g, (hipStream_t)stream);
+}
+
+/* fp32 activation (per-tensor scale from its partial maxima) on the LDS-DMA kernel: the weight image is the K16-major one
+ * (ttts_weight_split modes 8 / 9); arguments otherwise as ttts_linear_fwd_h3 / ttts_linear_bwd_data_h3 without a row shift */
+extern "C" int ttts_linear_fwd_h3d(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
+                                   int64_t M, int N, int K, int act, float drop_p, uint64_t seed, const uint64_t* step_seed,
+                                   const float* x_amax, float* y_amax_out, void* stream) {
+    TTTS_REQUIRE(x && w_planes && y && x_amax, "linear_fwd_h3d: null pointer (x_amax, the partial maxima of |x|, is required)");
+    TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_fwd_h3d: bad dims");
+    TTTS_REQUIRE(K % 32 == 0 && N % 4 == 0, "linear_fwd_h3d: K=%d must be a multiple of 32 and N=%d of 4", K, N);
+    TTTS_REQUIRE(al16(x) && al16(w_planes) && al16(y), "linear_fwd_h3d: pointers must be 16-byte aligned");
+    TTTS_REQUIRE(act == 0 || act == 1, "linear_fwd_h3d: act must be 0 (none) or 1 (relu)");
+    TTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "linear_fwd_h3d: dropout p out of [0,1)");
+    TTTS_REQUIRE((uint64_t)M * K * 4 < (1ull << 32) && (uint64_t)N * K * 4 < (1ull << 32), "linear_fwd_h3d: operand larger than 4 GiB");
+    GemmArgs g = h3i_base_args();
+    g.A = x; g.B = (const float*)w_planes; g.C = y; g.M = (int)M; g.N = N; g.K = K;
+    g.lda = K; g.ldb = K; g.ldc = N;
+    g.a_bytes = (uint32_t)((uint64_t)M * K * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 4);
+    g.cin = K;
+    g.bias = bias; g.act = act;
+    if (drop_p > 0.f) { g.drop_thr = drop_threshold(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.seed = seed; g.step_seed = step_seed; }
+    g.residual = residual; g.ldr = N;
+    g.a_amax = x_amax; g.a_amax_n = H3_AMAX_PARTIALS;
+    g.b_amax = h3_plane_tail(w_planes, N, K); g.b_amax_n = 1;
+    g.c_amax = y_amax_out;
+    return dispatch_h3i(g, (hipStream_t)stream);
+}
+
+extern "C" int ttts_linear_bwd_data_h3d(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
+                                        int K, const float* relu_out, float relu_scale, const float* dy_amax, float* dx_amax_out,
+                                        void* stream) {
+    TTTS_REQUIRE(dy && wt_planes && dx && dy_amax, "linear_bwd_data_h3d: null pointer");
+    TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_bwd_data_h3d: bad dims");
+    TTTS_REQUIRE(N % 32 == 0 && K % 4 == 0, "linear_bwd_data_h3d: N=%d must be a multiple of 32 and K=%d of 4", N, K);
+    TTTS_REQUIRE(al16(dy) && al16(wt_planes) && al16(dx), "linear_bwd_data_h3d: pointers must be 16-byte aligned");
+    TTTS_REQUIRE((uint64_t)M * N * 4 < (1ull << 32) && (uint64_t)N * K * 4 < (1ull << 32), "linear_bwd_data_h3d: operand larger than 4 GiB");
+    GemmArgs g = h3i_base_args();
+    g.A = dy; g.B = (const float*)wt_planes; g.C = dx; g.M = (int)M; g.N = K; g.K = N;
+    g.lda = N; g.ldb = N; g.ldc = K; g.cin = N;
+    g.a_bytes = (uint32_t)((uint64_t)M * N * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 4);
+    g.residual = residual; g.ldr = K;
+    g.relu_out = relu_out; g.relu_scale = relu_scale;
+    g.a_amax = dy_amax; g.a_amax_n = H3_AMAX_PARTIALS;
     g.b_amax = h3_plane_tail(wt_planes, K, N); g.b_amax_n = 1;
     g.c_amax = dx_amax_out;
     return dispatch_h3i(g, (hipStream_t)stream);

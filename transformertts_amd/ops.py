@@ -580,6 +580,12 @@ def _sinks(*params):
 # row_inv)` -- and the GEMM that reads it stages both operands by LDS-DMA on 128 x 256 tiles, two workgroups per CU.  Pays from
 # a few thousand rows on (512 resident workgroups) and for outputs at least half a tile wide.
 IMAGE_MIN_ROWS = 8192
+# Measured in the training step (same-box A/B, profiles/r04_image_ab.txt): per launch the image kernel is 1.06-1.26x faster than
+# gemm_h3, but the image is 4 more bytes per element for its producer to write (LayerNorm forward 16.6 -> 26.1 us, backward 26.9 ->
+# 38.4 us at 55 680 x 256) and every LayerNorm of this model feeds exactly ONE large GEMM: the step came out 0.3 ms SLOWER.  So
+# LayerNorm leaves images only when asked (tests, `layer_norm(..., emit_image=True)`); what the step uses by default is the same
+# kernel on the plain fp32 operand (`_dma_shape_ok`), where it needs no producer and still wins.
+LAYERNORM_IMAGES = False
 
 
 def _image_rows_ok(M: int, d: int) -> bool:
@@ -589,6 +595,17 @@ def _image_rows_ok(M: int, d: int) -> bool:
 def _image_shape_ok(M: int, red: int, out: int) -> bool:
     """M rows, reduction depth `red`, output width `out`"""
     return M >= IMAGE_MIN_ROWS and red % 32 == 0 and red >= 32 and out >= 128 and out % 4 == 0
+
+
+def _dma_shape_ok(M: int, red: int, out: int, gate: bool) -> bool:
+    """shapes on which the LDS-DMA kernel beats gemm_h3 with a plain fp32 activation (ttts_linear_*_h3d; tools/h3i_bench.py at
+    M = 55 680: data gradients with a relu gate into 1024 columns 1.15x, 256 -> 256 projections 1.07x; level or slower elsewhere)"""
+    if not (DMA_GEMMS and M >= IMAGE_MIN_ROWS and red % 32 == 0 and out % 4 == 0):
+        return False
+    return (gate and red <= 512 and out >= 512) or (red == 256 and out == 256)
+
+
+DMA_GEMMS = True
 
 
 def _new_image(M: int, d: int, device):
@@ -624,9 +641,13 @@ class LinearFn(torch.autograd.Function):
         elif _fwd_h3(K, N):
             if x_amax is None:
                 x_amax = _amax(x)
-            _lib.check(lib.ttts_linear_fwd_h3(_p(x), _p(_planes(w, 4, N, K)), _p(b_), _p(r_), _p(y), M, N, K, act,
-                                              float(drop_p), seed, _ss(), row_shift, T, _p(x_amax), _p(y_amax), _stream()),
-                       "ttts_linear_fwd_h3")
+            if row_shift == 0 and _dma_shape_ok(M, K, N, False):
+                _lib.check(lib.ttts_linear_fwd_h3d(_p(x), _p(_planes(w, 8, N, K)), _p(b_), _p(r_), _p(y), M, N, K, act,
+                                                   float(drop_p), seed, _ss(), _p(x_amax), _p(y_amax), _stream()), "ttts_linear_fwd_h3d")
+            else:
+                _lib.check(lib.ttts_linear_fwd_h3(_p(x), _p(_planes(w, 4, N, K)), _p(b_), _p(r_), _p(y), M, N, K, act,
+                                                  float(drop_p), seed, _ss(), row_shift, T, _p(x_amax), _p(y_amax), _stream()),
+                           "ttts_linear_fwd_h3")
         elif GEMM_MODE == "x6":
             _lib.check(lib.ttts_linear_fwd_x6(_p(x), _p(_planes(w, 0, N, K)), _p(b_), _p(r_), _p(y), M, N, K, act,
                                               float(drop_p), seed, _ss(), row_shift, T, _stream()), "ttts_linear_fwd_x6")
@@ -703,8 +724,14 @@ class LinearFn(torch.autograd.Function):
                                "ttts_linear_bwd_data_h3i")
                 else:
                     am = am if am is not None else _amax(dacc)
-                    _lib.check(lib.ttts_linear_bwd_data_h3(_p(dacc), _p(_planes(w, 5, K, N)), _p(skip), _p(dx), M, N, K,
-                                                           _p(gate), gscale, _p(am), _p(dx_am), _stream()), "ttts_linear_bwd_data_h3")
+                    if _dma_shape_ok(M, N, K, gate is not None) and not (gate is not None and skip is not None):
+                        _lib.check(lib.ttts_linear_bwd_data_h3d(_p(dacc), _p(_planes(w, 9, K, N)), _p(skip), _p(dx), M, N, K,
+                                                                _p(gate), gscale, _p(am), _p(dx_am), _stream()),
+                                   "ttts_linear_bwd_data_h3d")
+                    else:
+                        _lib.check(lib.ttts_linear_bwd_data_h3(_p(dacc), _p(_planes(w, 5, K, N)), _p(skip), _p(dx), M, N, K,
+                                                               _p(gate), gscale, _p(am), _p(dx_am), _stream()),
+                                   "ttts_linear_bwd_data_h3")
                 if dx_am is not None:
                     dx._ttts_amax = dx_am
             elif GEMM_MODE == "x6":
@@ -1074,7 +1101,7 @@ class LayerNormFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps=1e-5, sole_consumer=False, publish_amax=True, emit_image=True):
+def layer_norm(x, gamma, beta, eps=1e-5, sole_consumer=False, publish_amax=True, emit_image=None):
     """`sole_consumer=True` is the caller's promise that nothing but this LayerNorm reads `x`; if `x` came out of a Linear
     with a residual-dropout epilogue, that Linear's dropout backward is then written by this LayerNorm's backward kernel.
     `publish_amax`: leave the partial maxima of the output on it for the fp16x3 GEMMs that read it."""
@@ -1084,6 +1111,8 @@ def layer_norm(x, gamma, beta, eps=1e-5, sole_consumer=False, publish_amax=True,
     M = x.numel() // d
     # the image operand of y for the GEMMs that read it (in-projections, FFN1), and -- when x is the output of a Linear nobody
     # else reads -- of the gradient that Linear's backward consumes
+    if emit_image is None:
+        emit_image = LAYERNORM_IMAGES
     y_img = _new_image(M, d, x.device) if (emit_image and x.is_cuda and _image_rows_ok(M, d)) else None
     y = LayerNormFn.apply(x, gamma, beta, eps, tok, y_am, y_img, bool(emit_image and sole_consumer))
     if y_am is not None:
