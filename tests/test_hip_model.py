@@ -12,25 +12,32 @@ from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
 GATE = 1e-4        # outputs: north_star's stated fp32 tolerance (measured 1e-6 .. 5e-6)
-# Gradients: every backward kernel is individually within 1e-6 of fp64 (tests/test_hip_ops.py), but a full
-# backward in fp32 vs the fp64 oracle contains DISCRETE events: a ReLU pre-activation within rounding distance of
-# zero gates differently in fp32 and fp64 ("gate flip"), which perturbs that unit's gradient and everything below it.
-# Measured on the base config: all gradients above the first flipped FFN layer agree to 5e-7, everything below it
-# to 3e-5 .. 6e-4 (pe.alpha and dec_prenet.linear1.weight, both cancellation-heavy sums, are the worst; which
-# units flip depends on the rounding of the particular GEMM kernel in use).
-GRAD_GATE = 2e-3       # base config, flips included (3e7 ReLU units: a few flip in every run; asserted to be the whole
-#                        gap in test_gradient_gap_is_relu_gate_flips, where the flip-free gate is 2e-5)
-GRAD_GATE_TINY = 1e-4  # tiny config (no flip observed): the tight end-to-end gradient check
-# pe.alpha is ONE scalar whose gradient sums alpha's effect over every position of both streams with heavy cancellation
-# (|g| ~ 0.02 on the scaled case): a single flipped ReLU unit moves it by up to 5e-3 relative, and which units flip changes
-# with the summation order of any GEMM (seen: 2.8e-4 with one build, 5.1e-3 with the next, both with 2 flipped units of
-# 9.5e6).  Under the HIP path's own gates it agrees with fp64 to 2.6e-6 (test_gradient_gap_is_relu_gate_flips holds it to
-# 2e-5 / 5e-5): that is the precision claim; the raw comparisons below only bound the effect of the flips.
-PE_ALPHA_FLIP_GATE = 2e-2
+# Gradients: every backward kernel is individually within 1e-6 of fp64 (tests/test_hip_ops.py), but a full backward vs the
+# fp64 oracle contains DISCRETE events: a ReLU pre-activation within rounding distance of zero gates differently in two correct
+# evaluations ("gate flip"), which perturbs that unit's gradient and everything below it (one flipped unit of 9.5e6 has moved
+# pe.alpha -- one scalar, summed over every position with heavy cancellation -- by 5e-3).  The end-to-end gradient gates are
+# therefore CONTINUOUS comparisons: the fp64 oracle is evaluated under the HIP path's own ReLU gates (oracle.relu_gates), and
+# every parameter of every case is held to the flip-free gate.  Raw comparisons are reports (gpurun_out/parity_*.txt).
+FLIP_FREE_GATE = 2e-5          # gradients vs the fp64 oracle under the HIP path's own ReLU gates (measured <= 1.4e-5)
+FLIP_FREE_GATE_SCALED = 5e-5   # ... through the 12 layers of the scaled model (stock fp32 torch under the same gates: 3e-5)
+GRAD_GATE = 2e-3               # the tiny training_step surface test only (flips included; no flip observed there)
 
 
-def _grad_gate(name, gate):
-    return PE_ALPHA_FLIP_GATE if (name == "pe.alpha" and gate == GRAD_GATE) else gate
+def _oracle_gated_grads(cfg, w_seed, batch, gates, dtype=torch.float64):
+    """parameter gradients (and the loss) of the oracle evaluated in `dtype` with its ReLUs replaced by the given 0/1 gates"""
+    from oracle import fill_state, oracle_forward, oracle_loss, relu_gates
+    sd = fill_state(cfg, w_seed)
+    for k in list(sd):
+        if sd[k].is_floating_point():
+            sd[k] = sd[k].to(dtype)
+            if "running" not in k and k != "pe.pe":
+                sd[k].requires_grad_(True)
+    with relu_gates(gates=[g.to(dtype) for g in gates]):
+        ref = oracle_forward(sd, cfg, batch["phoneme"], batch["melspec"].to(dtype), batch["phoneme_lens"], batch["melspec_lens"],
+                             training=True, dropout=False)
+    loss = oracle_loss(ref, batch["melspec"].to(dtype), batch["melspec_lens"])
+    loss["total"].backward()
+    return {k: v.grad for k, v in sd.items() if v.requires_grad}, loss
 
 
 def _no_dropout(m):
@@ -92,41 +99,61 @@ def test_forward_backward_vs_oracle(cfg_name, B, Tp, Tm, w_seed, b_seed):
     for a, r in zip(out["alignments"], ref["alignments"]):
         assert rel_l2(a, r) < GATE
 
-    # train forward + loss + backward
+    # train forward + loss + backward; the HIP path's ReLU decisions are recorded (ops._relu_observer)
+    from transformertts_amd import ops
     m.train()
-    out = m(*args)
+    hip_gates = []
+    ops._relu_observer = lambda y: hip_gates.append((y.detach() > 0).cpu())
+    try:
+        out = m(*args)
+    finally:
+        ops._relu_observer = None
     crit = TransformerTTSLoss(8.0).to(dev)
     loss = crit(out, args[1], args[3])
     loss["total"].backward()
+    # outputs: against the fp64 oracle as it stands (its own gates)
+    big = B * Tm > 6000                      # the raw-gradient report costs a second fp64 backward: small cases only
     ref = oracle_forward(sd, cfg, batch["phoneme"], batch["melspec"].double(), batch["phoneme_lens"],
                          batch["melspec_lens"], training=True, dropout=False)
     rloss = oracle_loss(ref, batch["melspec"].double(), batch["melspec_lens"])
-    rloss["total"].backward()
+    if not big:
+        rloss["total"].backward()
     errs = {}
     for k in ("pred_melspec", "post_melspec", "pred_stop"):
         errs[k] = rel_l2(out[k], ref[k])
     for i, (a, r) in enumerate(zip(out["alignments"], ref["alignments"])):
         errs[f"align{i}"] = rel_l2(a, r)
     errs["loss"] = abs(loss["total"].item() - rloss["total"].item()) / abs(rloss["total"].item())
-    gerrs = {}
-    for name, p in m.named_parameters():
-        rg = sd[name].grad
-        if rg.norm().item() < 1e-7 * max(1.0, sd[name].detach().norm().item()):   # analytically-zero grads (conv bias before BN)
-            assert p.grad.abs().max().item() < 1e-4, name
-            continue
-        gerrs[name] = rel_l2(p.grad, rg)
     for name, buf in m.named_buffers():
         if "running_" in name:
             errs[name] = rel_l2(buf, sd[name])
         if "num_batches" in name:
             assert int(buf.item()) == int(sd[name])
+    # gradients: against the fp64 oracle evaluated UNDER THE HIP PATH'S GATES.  A ReLU is the one discontinuity of the path: a
+    # pre-activation within rounding distance of zero is gated differently by two correct evaluations, and a flipped unit moves
+    # every gradient below it by far more than any rounding does (test_gradient_gap_is_relu_gate_flips shows that the units that
+    # differ are a handful, all with |pre-activation| < 1e-5).  With the gates fixed the comparison is continuous, and it is held
+    # to the flip-free gate for EVERY parameter of EVERY case -- no per-parameter allowance.
+    gated, gloss = _oracle_gated_grads(cfg, w_seed, batch, hip_gates)
+    gerrs, raw = {}, {}
+    for name, p in m.named_parameters():
+        rg = gated[name]
+        if rg.norm().item() < 1e-7 * max(1.0, sd[name].detach().norm().item()):   # analytically-zero grads (conv bias before BN)
+            assert p.grad.abs().max().item() < 1e-4, name
+            continue
+        gerrs[name] = rel_l2(p.grad, rg)
+        if not big:
+            raw[name] = rel_l2(p.grad, sd[name].grad)
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/parity_{cfg_name}_B{B}_Tm{Tm}.txt", "w") as f:
-        for k, v in sorted({**errs, **{"grad/" + k: v for k, v in gerrs.items()}}.items(), key=lambda kv: -kv[1]):
+        f.write("# outputs vs the fp64 oracle; grad/: vs the fp64 oracle under the HIP path's ReLU gates [raw: vs its own gates]\n")
+        for k, v in sorted(errs.items(), key=lambda kv: -kv[1]):
             f.write(f"{v:.3e} {k}\n")
+        for k, v in sorted(gerrs.items(), key=lambda kv: -kv[1]):
+            f.write(f"{v:.3e} grad/{k}" + (f"  [raw {raw[k]:.3e}]" if k in raw else "") + "\n")
     bad = {k: v for k, v in errs.items() if not v < GATE}
-    gate = GRAD_GATE_TINY if cfg_name in ("tiny", "micro") else GRAD_GATE
-    bad.update({k: v for k, v in gerrs.items() if not v < _grad_gate(k, gate)})
+    gate = FLIP_FREE_GATE_SCALED if cfg_name == "scaled" else FLIP_FREE_GATE
+    bad.update({k: v for k, v in gerrs.items() if not v < gate})
     assert not bad, bad
 
 
@@ -152,45 +179,57 @@ def test_golden_outputs_direct(golden_dir, fixture):
 @pytest.mark.parametrize("fixture", ["base_model", "scaled_model"])
 def test_golden_gradients_direct(golden_dir, fixture):
     """HIP gradients against the reference's OWN fp32 backward (tests/golden/{base,scaled}_model.npz: per-parameter norms and
-    strided samples written by make_golden.py from the imported reference).  Both sides are fp32 evaluations with their
-    own ReLU gate flips against exact arithmetic (see test_gradient_gap_is_relu_gate_flips), so the gate is the sum of
-    the two spreads; parameters that no flip reaches agree to ~1e-6."""
+    strided samples written by make_golden.py from the imported reference).  The reference's gradients are an fp32 evaluation
+    with its own ReLU gate decisions, so a raw comparison measures which units two evaluations happened to gate differently
+    (it is written to the report).  What is ASSERTED is continuous: (1) the HIP gradients equal exact arithmetic under the HIP
+    path's gates to the flip-free gate, and (2) they are as close to the reference's numbers as that exact evaluation is --
+    whatever separates them from the fixture is the fixture's own distance from exact arithmetic, not this path's."""
     from oracle import synth_batch
+    from transformertts_amd import ops
     from transformertts_amd.loss import TransformerTTSLoss
     g = np.load(os.path.join(golden_dir, f"{fixture}.npz"))
-    cfg, m = _build(str(g["meta/cfg_name"]), int(g["meta/w_seed"]))
+    cfg_name, w_seed = str(g["meta/cfg_name"]), int(g["meta/w_seed"])
+    cfg, m = _build(cfg_name, w_seed)
     batch = synth_batch(int(g["meta/B"]), int(g["meta/Tp"]), int(g["meta/Tm"]), cfg["n_mels"], cfg["n_phon"], ragged=True,
                         seed=int(g["meta/b_seed"]))
     args = [batch[k].to("cuda") for k in ("phoneme", "melspec", "phoneme_lens", "melspec_lens")]
     m.train()
-    loss = TransformerTTSLoss(8.0).to("cuda")(m(*args), args[1], args[3])
+    hip_gates = []
+    ops._relu_observer = lambda y: hip_gates.append((y.detach() > 0).cpu())
+    try:
+        out = m(*args)
+    finally:
+        ops._relu_observer = None
+    loss = TransformerTTSLoss(8.0).to("cuda")(out, args[1], args[3])
     assert abs(loss["total"].item() - float(g["train/loss_total"])) < 1e-5 * abs(float(g["train/loss_total"]))
     loss["total"].backward()
-    errs = {}
+    exact, _ = _oracle_gated_grads(cfg, w_seed, batch, hip_gates)
+    gate = FLIP_FREE_GATE_SCALED if cfg_name == "scaled" else FLIP_FREE_GATE
+    rows, bad = [], {}
     for name, p in m.named_parameters():
         ref_norm = float(g[f"gradnorm/{name}"])
-        flat = p.grad.flatten()[::int(g[f"gradstride/{name}"])].cpu()
+        stride = int(g[f"gradstride/{name}"])
         ref = torch.from_numpy(g[f"gradsample/{name}"])
         if ref_norm < 1e-6:                       # analytically zero (conv bias in front of BN, key bias of a softmax):
             assert float(p.grad.norm()) < 1e-4, name      # rounding noise on both sides (2e-7 in the 512-channel post-net)
             continue
-        assert abs(float(p.grad.double().norm()) - ref_norm) < _grad_gate(name, GRAD_GATE) * ref_norm, name
-        errs[name] = rel_l2(flat, ref)
+        e_exact_hip = rel_l2(p.grad, exact[name])
+        e_hip = rel_l2(p.grad.flatten()[::stride].cpu(), ref)
+        e_exact = rel_l2(exact[name].flatten()[::stride], ref)
+        rows.append((e_hip, e_exact, e_exact_hip, name))
+        if not e_exact_hip < gate:
+            bad[name] = ("vs exact arithmetic under the same gates", e_exact_hip)
+        elif not e_hip <= e_exact + 2.0 * gate:
+            bad[name] = ("farther from the reference's fp32 gradients than exact arithmetic is", e_hip, e_exact)
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/parity_golden_gradients_{fixture}.txt", "w") as f:
-        for k, v in sorted(errs.items(), key=lambda kv: -kv[1]):
-            f.write(f"{v:.3e} {k}\n")
-    bad = {k: v for k, v in errs.items() if not v < _grad_gate(k, GRAD_GATE)}
+        f.write("# hip_vs_reference_fp32  exact(fp64, hip gates)_vs_reference_fp32  hip_vs_exact  parameter\n")
+        for e_hip, e_exact, e_eh, name in sorted(rows, reverse=True):
+            f.write(f"{e_hip:.3e} {e_exact:.3e} {e_eh:.3e} {name}\n")
     assert not bad, bad
-    # the typical parameter is inside the gate with room to spare (the deeper scaled stack has more units near zero: the
-    # oracle evaluated in fp32 sits at 2.6e-4 against the same fixture, tests/test_oracle_golden.py; a flip in an EARLY
-    # encoder layer reaches most parameters of the model at once -- 6.5e-4 on every encoder tensor with the build that walks
-    # convolution taps innermost, 1.4e-4 with the one before, 2 flipped units of 9.5e6 both times)
-    assert sorted(errs.values())[len(errs) // 2] < (1e-4 if fixture == "base_model" else 1e-3)
 
 
-@pytest.mark.parametrize("cfg_name,B,Tp,Tm,w_seed,b_seed", [("base", 4, 100, 870, 13, 23), ("base", 16, 100, 870, 15, 25),
-                                                            ("scaled", 2, 60, 300, 14, 24)])
+@pytest.mark.parametrize("cfg_name,B,Tp,Tm,w_seed,b_seed", [("base", 4, 100, 870, 13, 23), ("scaled", 2, 60, 300, 14, 24)])
 def test_gradient_gap_is_relu_gate_flips(cfg_name, B, Tp, Tm, w_seed, b_seed):
     """Why the end-to-end gradient gate is looser than the 1e-6 every backward kernel meets on its own: a ReLU is the one
     discontinuous operation on the path.  A pre-activation within rounding distance of zero is gated differently by two
@@ -201,8 +240,8 @@ def test_gradient_gap_is_relu_gate_flips(cfg_name, B, Tp, Tm, w_seed, b_seed):
       (2) evaluating the fp64 oracle UNDER THE HIP PATH'S GATES makes every parameter gradient agree to FLIP_FREE_GATE --
           the flips are the entire gap;
       (3) flips aside, the HIP path's typical parameter error is of the order of stock fp32 torch's own (vs fp64).
-    Run for every case of test_forward_backward_vs_oracle whose gradients are held to the loose GRAD_GATE there (base x 4,
-    base x 16 = BASELINE configs[1] shape, scaled = configs[4]): under the HIP path's gates ALL of them meet 2e-5."""
+    (2) is what test_forward_backward_vs_oracle asserts for every one of its cases; here it is shown together with (1) and (3)
+    on the full-length base case and the scaled one."""
     from oracle import synth_batch, oracle_forward, oracle_loss, relu_gates
     from transformertts_amd import ops
     from transformertts_amd.loss import TransformerTTSLoss
@@ -293,55 +332,46 @@ def test_parity_holds_for_inputs_of_any_magnitude(mel_scale):
     batch = synth_batch(B, Tp, Tm, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=b_seed)
     batch["melspec"] = batch["melspec"] * mel_scale
     args = [batch[k].to("cuda") for k in ("phoneme", "melspec", "phoneme_lens", "melspec_lens")]
+    from transformertts_amd import ops
     m.train()
-    out = m(*args)
+    hip_gates = []
+    ops._relu_observer = lambda y: hip_gates.append((y.detach() > 0).cpu())
+    try:
+        out = m(*args)
+    finally:
+        ops._relu_observer = None
     loss = TransformerTTSLoss(8.0).to("cuda")(out, args[1], args[3])
     loss["total"].backward()
     sd = _oracle64(cfg, w_seed)
-    ref = oracle_forward(sd, cfg, batch["phoneme"], batch["melspec"].double(), batch["phoneme_lens"], batch["melspec_lens"],
-                         training=True, dropout=False)
-    rloss = oracle_loss(ref, batch["melspec"].double(), batch["melspec_lens"])
-    rloss["total"].backward()
+    with torch.no_grad():
+        ref = oracle_forward(sd, cfg, batch["phoneme"], batch["melspec"].double(), batch["phoneme_lens"], batch["melspec_lens"],
+                             training=True, dropout=False)
+        rloss = oracle_loss(ref, batch["melspec"].double(), batch["melspec_lens"])
     for k in ("pred_melspec", "post_melspec", "pred_stop"):
         assert torch.isfinite(out[k]).all() and rel_l2(out[k], ref[k]) < GATE, (k, rel_l2(out[k], ref[k]))
     for a, r in zip(out["alignments"], ref["alignments"]):
         assert rel_l2(a, r) < GATE
     assert abs(loss["total"].item() - rloss["total"].item()) < 1e-5 * abs(rloss["total"].item())
-    # Gradients: inputs 1000 x off the normalised features make the step itself ill-conditioned in fp32 (the decoder's first
-    # residual sums add O(1) attention outputs to O(1000) pre-net activations), so the yardstick is what stock fp32 torch
-    # achieves on the same inputs: the oracle evaluated in fp32 against its own fp64 evaluation.
-    from oracle import fill_state
-    sd32 = fill_state(cfg, w_seed)
-    for k, v in sd32.items():
-        if v.is_floating_point() and "running" not in k and k != "pe.pe":
-            v.requires_grad_(True)
-    ref32 = oracle_forward(sd32, cfg, batch["phoneme"], batch["melspec"], batch["phoneme_lens"], batch["melspec_lens"],
-                           training=True, dropout=False)
-    oracle_loss(ref32, batch["melspec"], batch["melspec_lens"])["total"].backward()
-    # One documented exception (known limits): with the inputs 1000 x too large the un-normalised input of decoder
-    # layer 0 drives its self-attention scores to +-1e6 and the softmax to exact one-hot rows.  torch keeps the probabilities
-    # and its softmax backward is then EXACTLY zero; a backward that recomputes them (this one, and any flash-style one) forms
-    # dS = P (dP - delta) with delta = rowsum(dO * O), whose rounding (2^-22 |dO| |V|) does not cancel against dP's.  That
-    # noise reaches the Q / K thirds of that layer's in-projection and the pre-net below it, nothing else.
-    saturated = ("decoder.layers.0.self_attn.in_proj_", "dec_prenet.") if mel_scale > 100 else ()
+    # Gradients, gate-controlled (see test_forward_backward_vs_oracle): fp64 under the HIP path's ReLU gates is the reference.
+    # Inputs 1000 x off the normalised features make the step itself ill-conditioned in fp32 (the decoder's first residual sums
+    # add O(1) attention outputs to O(1000) pre-net activations), so next to the flip-free gate the yardstick is what stock
+    # fp32 torch achieves on the same inputs under the same gates.  No parameter is exempt: at x 1000 decoder layer 0's
+    # self-attention softmax saturates to exact one-hot rows, whose backward this path now takes as the exact zero torch gets
+    # (csrc/attention.hip, `saturated`); round 3 waived 15 % on that layer's in-projection and on the pre-net.
+    exact, _ = _oracle_gated_grads(cfg, w_seed, batch, hip_gates)
+    stock, _ = _oracle_gated_grads(cfg, w_seed, batch, hip_gates, dtype=torch.float32)
     rows, bad = [], {}
     for name, p in m.named_parameters():
-        rg = sd[name].grad
-        if rg.norm().item() < 1e-7 * max(1.0, sd[name].detach().norm().item()) * max(1.0, mel_scale ** 2):
+        rg = exact[name]
+        if rg.norm().item() < 1e-7 * max(1.0, p.detach().norm().item()) * max(1.0, mel_scale ** 2):
             continue
-        e, e32 = rel_l2(p.grad, rg), rel_l2(sd32[name].grad, rg)
+        e, e32 = rel_l2(p.grad, rg), rel_l2(stock[name], rg)
         rows.append((e, e32, name))
-        limit = 0.15 if name.startswith(saturated) and saturated else max(GRAD_GATE, 3.0 * e32)
-        if not e < limit:
+        if not e < max(FLIP_FREE_GATE, 3.0 * e32):
             bad[name] = (e, e32)
-    if saturated:       # ... and the V third of that in-projection, which does not pass through the softmax backward, is exact
-        d = cfg["d_model"]
-        name = "decoder.layers.0.self_attn.in_proj_weight"
-        gv, rv = dict(m.named_parameters())[name].grad[2 * d:], sd[name].grad[2 * d:]
-        assert rel_l2(gv, rv) < GRAD_GATE, rel_l2(gv, rv)
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/parity_mel_x{mel_scale:g}.txt", "w") as f:
-        f.write("# hip_vs_fp64  stock_fp32_vs_fp64  parameter (gradients)\n")
+        f.write("# gradients under the HIP path's ReLU gates: hip_vs_fp64  stock_fp32_vs_fp64  parameter\n")
         for e, e32, name in sorted(rows, reverse=True):
             f.write(f"{e:.3e} {e32:.3e} {name}\n")
     assert not bad, bad

@@ -1793,17 +1793,26 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
     for (int j = 0; j < 32; ++j) delta += scratch[l31 * KT_LD + 2 * j + half] * orow[j];
     delta += __shfl_xor(delta, 32, 64);
     load_lane_frags_h3(scratch, l31, half, s_g, gf);
-    if (half == 0 && qg < a.Tq) a.delta[arow + qg] = delta;
     // row statistics of this query: the forward's exponent subtrahend and log2 of its row sum (rowstat), or lse alone
     float m_q = 0.f, l2_q = 0.f;
+    bool saturated = false;
     if (qg < a.Tq) {
         if (a.rowstat != nullptr) {
             m_q = a.rowstat[arow + qg];
             l2_q = a.rowstat[(long)a.B * a.H * a.Tq + arow + qg];
+            // A row whose sum is exactly its largest term (log2 = 0: every other exponential vanished in fp32) is ONE-HOT.
+            // torch keeps the probabilities and its softmax backward is then exactly zero (1 * (dP_k - dP_k)); a backward that
+            // recomputes P forms P (dP - delta) with delta = rowsum(dO * O), two roundings of the same number that do not
+            // cancel -- 2^-22 |dO| |V| of noise on a gradient that should vanish, multiplied by |K|, |Q| (scores ~1e6 come
+            // from inputs ~1e3: 4-5 % of the pre-net's whole gradient).  Such a row's dS is taken as the exact zero it is; the
+            // dK / dV kernel learns of it through a sentinel in `delta` (-0.0: a genuine delta of that value belongs to a row
+            // whose dS is zero anyway).
+            saturated = (l2_q == 0.f);
         } else {
             l2_q = a.lse[arow + qg] * 1.4426950408889634f;
         }
     }
+    if (half == 0 && qg < a.Tq) a.delta[arow + qg] = saturated ? -0.f : delta;
     const float dp_unscale = inv_g * hs.inv_sv * a.drop_scale;   // dP accumulator units -> true dP, times the 1/(1-p) of kept weights
     float sds = 0.f;                              // this query's dS pre-scale (power of two), set / lowered on the fly
 
@@ -1861,7 +1870,7 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
                     if (!full) p = (kg < klen && (!CAUSAL || kg <= qg)) ? p : 0.f;
                     float g = dp[r + e] * dp_unscale;
                     if (a.thr != 0u) g = attn_keep_word(qh, attn_drop_mult(e), thr16) ? g : 0.f;
-                    ds[r + e] = p * (g - delta);
+                    ds[r + e] = saturated ? 0.f : p * (g - delta);
                 }
             }
             // dQ^T[d][q] += K^T[d][key] dS^T[key][q].  dS is the lane's own column (its query), so its f16 pre-scale is
@@ -2085,7 +2094,8 @@ __global__ __launch_bounds__(256, TTTS_DKVH_W) void attn_bwd_dkv_h3_kernel(AttnA
                     g = keep ? g : 0.f;                  // the 1/(1-p) factors ride in dp_unscale and in dv's final scale
                     pk = keep ? pk : 0.f;
                 }
-                ds[r + e] = pd[r + e] * (g - dl_r[r + e]);
+                // (one-hot row: exact zero, flagged by the dQ kernel's -0.0 sentinel in delta -- see there)
+                ds[r + e] = (__float_as_uint(dl_r[r + e]) == 0x80000000u) ? 0.f : pd[r + e] * (g - dl_r[r + e]);
                 pd[r + e] = pk;
             }
         }
