@@ -307,11 +307,14 @@ int ttts_attention_fwd_x6(const float* q, const float* k, const float* v, float*
 /* fp16x3 form of the forward (three f16 MFMA terms; Q/8, K and V pre-scaled from their partial maxima q_amax / k_amax /
  * v_amax -- TTTS_AMAX_SLOTS floats each, the same array three times for a packed projection output -- and probabilities x 2^10);
  * lse in natural units, so either backward form can follow it.  o_amax_out: NULL, or zeroed TTTS_AMAX_SLOTS floats: max|o|.
- * rowstat_out: NULL, or (2, B, H, Tq) floats: per query row the subtrahend of the weights' exponents exactly as the kernel
- * used it with the final row maximum (one rounded product, in the kernel's own pre-scaled units) and log2 of the row sum of
- * those weights -- what ttts_attention_bwd_h3 needs to form the very probabilities the forward formed (it re-creates
- * bit-identical score accumulators and the same exponents, whatever the scores' magnitude; from lse alone the probabilities
- * are only good to ulp(lse), i.e. 6 % at scores of 1e6, where torch -- which keeps the probabilities -- is still accurate). */
+ * rowstat_out: NULL, or (3, B, H, Tq) floats (ABI v10: a third plane): per query row the subtrahend of the weights' exponents
+ * exactly as the kernel used it with the final row maximum (one rounded product, in the kernel's own pre-scaled units), log2
+ * of the row sum of those weights -- what ttts_attention_bwd_h3 needs to form the very probabilities the forward formed (it
+ * re-creates bit-identical score accumulators and the same exponents, whatever the scores' magnitude; from lse alone the
+ * probabilities are only good to ulp(lse), i.e. 6 % at scores of 1e6, where torch -- which keeps the probabilities -- is
+ * still accurate) -- and 1.0 / 0.0: the row is ONE-HOT in fp32 (its sum is its largest term).  torch's softmax backward of
+ * such a row is exactly zero; a backward that recomputes the probabilities would return the rounding of delta against dP
+ * instead, so ttts_attention_bwd_h3 takes the row's score gradient as zero. */
 int ttts_attention_fwd_h3(const float* q, const float* k, const float* v, float* o, float* lse, float* attn,
                           const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                           int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* q_amax,

@@ -663,7 +663,7 @@ def test_fp16x3_attention_backward(causal, Tq, Tk, lens, mag, grow):
 
     def run(fwd, bwd, p_drop, h3):
         o = torch.empty(B, Tq, d, device=_dev()); lse = torch.empty(B, H, Tq, device=_dev())
-        rowstat = torch.empty(2, B, H, Tq, device=_dev())
+        rowstat = torch.empty(3, B, H, Tq, device=_dev())
         extra = (_p(qa), _p(kva), _p(kva), None, _p(rowstat)) if h3 else ()
         assert fwd(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), None, _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, causal,
                    0.125, p_drop, 99, None, *extra, _stream()) == 0
@@ -725,7 +725,7 @@ def test_fp16x3_attention_any_magnitude(vs, qs, ks, causal):
     # q and kv come from different producers in cross-attention; in self-attention one array covers all three
     qa, ka, va = ops._amax(q), ops._amax(kv[..., :d].contiguous()), ops._amax(kv[..., d:].contiguous())
     o, lse = torch.empty(B, T, d, device=_dev()), torch.empty(B, H, T, device=_dev())
-    rowstat = torch.empty(2, B, H, T, device=_dev())
+    rowstat = torch.empty(3, B, H, T, device=_dev())
     assert lib.ttts_attention_fwd_h3(_p(q), _off(kv, 0), _off(kv, d), _p(o), _p(lse), None, _p(kl), B, H, T, T, d, 2 * d, 2 * d,
                                      d, causal, 0.125, 0.0, 0, None, _p(qa), _p(ka), _p(va), None, _p(rowstat), _stream()) == 0
     assert torch.isfinite(o).all() and _rel(o, o_ref) < TOL, _rel(o, o_ref)

@@ -1206,8 +1206,15 @@ __global__ __launch_bounds__(256, WRITE_A ? 2 : TTTS_FWDH_W) void attn_fwd_h3_ke
     const float lsum = WRITE_A ? l : (l + __shfl_xor(l, 32, 64));
     if (a.rowstat != nullptr && half == 0 && qg < a.Tq) {
         const long plane = (long)a.B * a.H * a.Tq;
-        a.rowstat[arow + qg] = WRITE_A ? mcs_fin : ((m == NEG_INF) ? -10.f : __builtin_fmaf(m, H3A_C2, -10.f));
+        const float mcs_w = WRITE_A ? mcs_fin : ((m == NEG_INF) ? -10.f : __builtin_fmaf(m, H3A_C2, -10.f));
+        a.rowstat[arow + qg] = mcs_w;
         a.rowstat[plane + arow + qg] = lsum > 0.f ? __log2f(lsum) : 0.f;
+        // third plane: 1 for a ONE-HOT row -- its sum IS its largest term (the same instruction, on the same operands, that
+        // formed the maximum's own term in the loop: the running maximum is one of the scores, and the subtrahend of every
+        // later tile is the one it set), i.e. every other exponential vanished in fp32.  The backward takes such a row's
+        // softmax gradient as the exact zero it is (attn_bwd_dq_h3_kernel, `saturated`).
+        const float top = (m == NEG_INF) ? 0.f : fast_exp2(__builtin_fmaf(m, H3A_C2, -(WRITE_A ? mcs_fin : mcs_w)));
+        a.rowstat[2 * plane + arow + qg] = (lsum > 0.f && lsum == top) ? 1.f : 0.f;
     }
     (void)mcs_last;
     float omax = 0.f;
@@ -1800,14 +1807,14 @@ __global__ __launch_bounds__(256, TTTS_DQH_W) void attn_bwd_dq_h3_kernel(AttnArg
         if (a.rowstat != nullptr) {
             m_q = a.rowstat[arow + qg];
             l2_q = a.rowstat[(long)a.B * a.H * a.Tq + arow + qg];
-            // A row whose sum is exactly its largest term (log2 = 0: every other exponential vanished in fp32) is ONE-HOT.
+            // A row whose sum is exactly its largest term (every other exponential vanished in fp32) is ONE-HOT.
             // torch keeps the probabilities and its softmax backward is then exactly zero (1 * (dP_k - dP_k)); a backward that
             // recomputes P forms P (dP - delta) with delta = rowsum(dO * O), two roundings of the same number that do not
             // cancel -- 2^-22 |dO| |V| of noise on a gradient that should vanish, multiplied by |K|, |Q| (scores ~1e6 come
             // from inputs ~1e3: 4-5 % of the pre-net's whole gradient).  Such a row's dS is taken as the exact zero it is; the
             // dK / dV kernel learns of it through a sentinel in `delta` (-0.0: a genuine delta of that value belongs to a row
             // whose dS is zero anyway).
-            saturated = (l2_q == 0.f);
+            saturated = a.rowstat[2 * (long)a.B * a.H * a.Tq + arow + qg] != 0.f;     // the forward's verdict: sum == largest term
         } else {
             l2_q = a.lse[arow + qg] * 1.4426950408889634f;
         }

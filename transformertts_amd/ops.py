@@ -1130,8 +1130,8 @@ def _attn_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, lens, causal, drop_p, seed, 
     lib = _lib.load()
     dev = lens.device
     o = torch.empty(B, Tq, H * 64, dtype=torch.float32, device=dev)
-    # lse (natural units) and, in the fp16x3 form, the row statistics in the kernel's own units behind it: rows 1-2 of `stat`
-    stat = torch.empty(3 if ATTN_FWD_MODE == "h3" else 1, B, H, Tq, dtype=torch.float32, device=dev)
+    # lse (natural units) and, in the fp16x3 form, the row statistics in the kernel's own units behind it: rows 1-3 of `stat`
+    stat = torch.empty(4 if ATTN_FWD_MODE == "h3" else 1, B, H, Tq, dtype=torch.float32, device=dev)
     lse = stat[0]
     attn = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=dev) if need_weights else None
     args = (q, k, v, _p(o), _p(lse), _p(attn), _p(lens), B, H, Tq, Tk, ldq, ldk, ldv, H * 64, 1 if causal else 0,
@@ -1212,7 +1212,7 @@ class SelfAttentionFn(torch.autograd.Function):
     def backward(ctx, do):
         lib = _lib.load()
         qkv, o64, stat, lens, *pads = ctx.saved_tensors
-        lse, rowstat = stat[0], (stat[1:] if stat.shape[0] == 3 else None)
+        lse, rowstat = stat[0], (stat[1:] if stat.shape[0] == 4 else None)
         n_head, causal, drop_p, seed, hd = ctx.cfg
         B, T, d3 = qkv.shape
         d = d3 // 3
@@ -1284,7 +1284,7 @@ class CrossAttentionFn(torch.autograd.Function):
             return None, None, None, None, None, None, None, None, None, None
         lib = _lib.load()
         q, kv, o64, stat, lens, *pads = ctx.saved_tensors
-        lse, rowstat = stat[0], (stat[1:] if stat.shape[0] == 3 else None)
+        lse, rowstat = stat[0], (stat[1:] if stat.shape[0] == 4 else None)
         n_head, drop_p, seed, hd = ctx.cfg
         B, Tq, d = q.shape
         Tk = kv.shape[1]
