@@ -127,17 +127,18 @@ def test_weight_planes_follow_raw_data_writes_after_epoch_bump():
     assert rel_l2(y0, ref) > 1e-2          # the first result was computed with the old weights
 
 
-@pytest.mark.parametrize("overlap", ["1", "0"])
-def test_two_rank_rehearsal_reduces_to_the_mean_gradient(overlap):
+@pytest.mark.parametrize("overlap,graph", [("1", "0"), ("0", "0"), ("1", "1")])
+def test_two_rank_rehearsal_reduces_to_the_mean_gradient(overlap, graph):
     """bench.py in rehearsal mode (two gloo ranks sharing cuda:0): the reduced bucket must equal the mean of the two
     ranks' single-process gradients (rel-L2 <= 1e-6), with the overlapped tail exchange on and off.  The command is the
     bare `python bench.py --gpus 2 ...`: bench.py starts its own torch.distributed.run child (bench.self_launch)."""
-    env = dict(os.environ, TTTS_BENCH_REHEARSAL="1", TTTS_DP_OVERLAP=overlap, TTTS_GRAPH="0",
+    env = dict(os.environ, TTTS_BENCH_REHEARSAL="1", TTTS_DP_OVERLAP=overlap, TTTS_GRAPH=graph,
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--batch", "4", "--tm", "160", "--tp", "40", "--ragged", "--no-cpu-baseline", "--no-probe"]
+           "--warmup", "3" if graph == "1" else "1", "--batch", "4", "--tm", "160", "--tp", "40", "--ragged", "--no-cpu-baseline",
+           "--no-probe"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -171,3 +172,6 @@ def test_rccl_one_rank_group_matches_the_single_process_step():
         json.dump(out, f)
     assert out["backend"] == "nccl" and out["world"] == 1
     assert out["one_rank_mean_leaves_bucket_unchanged"] and out["losses_equal"] and out["state_equal"], out
+    # ... and with the exchange overlapped on the FAST path: the step captured as two graphs cut where backward leaves the decoder,
+    # the tail's all-reduce (RCCL, asynchronous) started between their replays -- same bits again
+    assert out["split_graphs"] == 1 and out["overlap_losses_equal"] and out["overlap_state_equal"], out

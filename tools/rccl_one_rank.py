@@ -9,7 +9,9 @@ and the optimizer kernels behind the collective.  Checks (printed as one JSON li
   * a one-rank mean leaves the bucket bit for bit unchanged;
   * N steps through the data-parallel launch path (graph = zero-grad .. backward, then collective, then clip + Adam)
     end in exactly the parameters / moments / BatchNorm buffers of N steps through the single-process path (graph
-    including the optimizer), dropout on.
+    including the optimizer), dropout on;
+  * the same with the exchange overlapped: the step captured as TWO graphs cut where backward leaves the decoder, the tail's
+    all-reduce started between their replays (step.TrainStep, overlap=True).
 """
 import json
 import os
@@ -45,30 +47,36 @@ def main():
     batch = {k: v.to(dev) for k, v in synth_batch(B, Tp, Tm, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=8).items()}
     out = {"backend": dist.get_backend(), "world": dist.get_world_size(), "config": cfg_name, "steps": steps}
     runs = []
-    for force in (False, True):
+    for force, overlap in ((False, False), (True, False), (True, True)):
         torch.manual_seed(42)
         lm = LightningModule(config).to(dev)
         lm.train()
         broadcast_module_state(lm, force=force)            # RCCL broadcast of every parameter and buffer
         oc = lm.configure_optimizers()
         opt, sch = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
-        ts = TrainStep(lm, opt, sch, batch, graph=True, seed=77, force_collective=force)
+        ts = TrainStep(lm, opt, sch, batch, graph=True, seed=77, force_collective=force, overlap=overlap)
         losses = [ts().detach().clone() for _ in range(steps)]
         torch.cuda.synchronize()
         assert ts.graphed
-        if force:
+        if overlap:
+            out["split_graphs"] = sum(len(sl.tails) for sl in ts._slots.values())
+            out["tail_trigger_fired"] = ts.trigger.fired if ts.trigger is not None else 0
+        if force and not overlap:
             before = opt.bucket.flat.clone()
             dist.all_reduce(opt.bucket.flat, op=dist.ReduceOp.AVG)
             torch.cuda.synchronize()
             out["one_rank_mean_leaves_bucket_unchanged"] = bool(torch.equal(before, opt.bucket.flat))
         runs.append((losses, opt.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
                      {k: v.clone() for k, v in lm.model.state_dict().items() if "running" in k}))
-    a, b = runs
-    out["losses_equal"] = all(torch.equal(x, y) for x, y in zip(a[0], b[0]))
-    out["state_equal"] = bool(torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
-                              and all(torch.equal(a[4][k], b[4][k]) for k in a[4]))
+    a = runs[0]
+    same = lambda b: (all(torch.equal(x, y) for x, y in zip(a[0], b[0])),
+                      bool(torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+                           and all(torch.equal(a[4][k], b[4][k]) for k in a[4])))
+    out["losses_equal"], out["state_equal"] = same(runs[1])
+    out["overlap_losses_equal"], out["overlap_state_equal"] = same(runs[2])
     out["final_loss"] = float(a[0][-1])
-    out["ok"] = bool(out["losses_equal"] and out["state_equal"] and out["one_rank_mean_leaves_bucket_unchanged"])
+    out["ok"] = bool(out["losses_equal"] and out["state_equal"] and out["one_rank_mean_leaves_bucket_unchanged"]
+                     and out["overlap_losses_equal"] and out["overlap_state_equal"] and out["split_graphs"] == 1)
     print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -29,9 +29,12 @@ the start of the first micro-batch after an optimizer step (`ops.PlaneTable`, ow
 graph), never through the lazy process-wide cache.
 
 Data parallel (N > 1): the graph ends after backward; the all-reduce of the flat bucket and the optimizer kernels are
-issued eagerly behind it on the same stream (one collective + three launches).  Overlapping the tail of the bucket with
-the rest of backward (parallel.overlap_tail_with_backward) needs a host hook inside backward and is therefore an
-eager-mode option.
+issued eagerly behind it on the same stream.  With `overlap=True` the exchange is split where backward leaves the decoder
+(parallel.overlap_tail_with_backward: decoder, post-net and head gradients, 55 % of the bucket, are final there): eagerly a
+host hook inside backward starts the tail's all-reduce; in graph mode the step is captured as TWO graphs cut at that hook
+(the capture runs autograd on the calling thread so that the hook can end one capture and begin the next), and a replay is
+graph A -> start the tail's all-reduce (RCCL's own stream, behind A) -> graph B (the encoder's backward, beside the exchange)
+-> the head's all-reduce -> clip + Adam.  The collectives themselves are never captured.
 """
 from __future__ import annotations
 
@@ -61,17 +64,19 @@ def _round_up(n: int, m: int) -> int:
 
 class _Slot:
     """Static buffers of one batch shape and the graphs captured over them (one per accumulation role)."""
-    __slots__ = ("batch", "graphs", "losses", "eager_runs", "used")
+    __slots__ = ("batch", "graphs", "tails", "losses", "eager_runs", "used")
 
     def __init__(self, batch):
         self.batch = batch
         self.graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+        self.tails: Dict[str, torch.cuda.CUDAGraph] = {}      # second half of a step cut at the data-parallel tail trigger
         self.losses: Dict[str, torch.Tensor] = {}
         self.eager_runs = 0
         self.used = 0                        # TrainStep.index at the last use (LRU eviction)
 
     def drop_graphs(self) -> None:
         self.graphs.clear()
+        self.tails.clear()
         self.losses.clear()
 
 
@@ -86,8 +91,9 @@ class TrainStep:
         `graph=True` captures a shape at its first use after `eager_warmup` eager micro-batches overall.
         `accumulate=k`: gradients of k micro-batches are summed (each scaled by 1/k, as Lightning's
         accumulate_grad_batches does, train.py:42) before the optimizer steps.  `lattice=(p, m)`: see the module text.
-        `overlap=True` (eager mode, N > 1 only) starts the all-reduce of the decoder / postnet / head gradients while
-        backward is still in the encoder.  `force_collective=True` takes the data-parallel path (graph ends after backward,
+        `overlap=True` (N > 1 only) starts the all-reduce of the decoder / postnet / head gradients while backward is still
+        in the encoder -- from a host hook inside backward in eager mode, between the two graphs of a step cut at that hook in
+        graph mode.  `force_collective=True` takes the data-parallel path (graph ends after backward,
         collective + optimizer behind it) in a one-rank process group too: RCCL on a single GPU."""
         if not isinstance(optimizer, FlatAdam):
             raise TypeError("TrainStep drives FlatAdam (flat parameter / gradient / moment buffers)")
@@ -118,8 +124,9 @@ class TrainStep:
         self.bucket.force_collective = bool(force_collective)
         self.dp = self.world > 1 or bool(force_collective)       # the optimizer runs behind a collective, outside the graph
         self.trigger = None
-        if overlap and self.dp and not self.use_graph:
-            self.trigger = overlap_tail_with_backward(self.bucket, lm.model, lm.model.decoder, group)
+        self._cut = None                     # during a split capture: callable that ends graph A and begins graph B
+        if overlap and self.dp:
+            self.trigger = overlap_tail_with_backward(self.bucket, lm.model, lm.model.decoder, group, on_ready=self._tail_ready)
         if batch is not None:
             self.load(batch)
 
@@ -210,6 +217,15 @@ class TrainStep:
                 trig.enabled = True
         return loss
 
+    def _tail_ready(self, lo: int) -> None:
+        """The tail trigger fired: backward has left the decoder, bucket.flat[lo:] is final (its queued reductions have been
+        flushed by the trigger).  Eager step: start the tail's all-reduce beside the rest of backward.  Capture: cut the graph
+        here -- the collective is issued between the two replays, never recorded."""
+        if self._cut is not None:
+            self._cut()
+        else:
+            self.bucket.start_tail_allreduce(lo, self.group)
+
     def _reduce_and_update(self) -> None:
         self.bucket.finish_allreduce(self.group)     # waits for an overlapped tail and reduces the rest; no-op at N = 1
         self.opt.step()
@@ -264,6 +280,9 @@ class TrainStep:
             if role not in slot.graphs:
                 self._capture(slot, role)
             slot.graphs[role].replay()
+            if role in slot.tails:           # the step was cut at the tail trigger: exchange the tail beside graph B
+                self.bucket.start_tail_allreduce(self.trigger.lo, self.group)
+                slot.tails[role].replay()
             if last:
                 if not self.dp:
                     self.opt.note_external_step()
@@ -290,17 +309,46 @@ class TrainStep:
         self._cur = slot
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
+        split = self.trigger is not None and role in ("full", "last")
+        g_tail = None
         try:
-            with torch.cuda.graph(g, pool=self._pool):
-                with self.state:
-                    slot.losses[role] = self._forward_backward(role, capturing=True)
-                    if role in ("full", "last") and not self.dp:
-                        self.opt.step()
+            if not split:
+                with torch.cuda.graph(g, pool=self._pool):
+                    with self.state:
+                        slot.losses[role] = self._forward_backward(role, capturing=True)
+                        if role in ("full", "last") and not self.dp:
+                            self.opt.step()
+            else:
+                # Two graphs cut where the tail trigger fires.  The hook runs inside backward, so autograd must run on THIS thread
+                # (a stream capture is ended by the thread that began it); everything is recorded on one side stream.
+                tail = torch.cuda.CUDAGraph()
+                cut = {"done": False}
+
+                def cut_here():
+                    g.capture_end()
+                    tail.capture_begin(pool=self._pool)
+                    cut["done"] = True
+                cap = torch.cuda.Stream()
+                cap.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cap), torch.autograd.set_multithreading_enabled(False):
+                    g.capture_begin(pool=self._pool)
+                    self._cut = cut_here
+                    try:
+                        with self.state:
+                            slot.losses[role] = self._forward_backward(role, capturing=True)
+                    finally:
+                        self._cut = None
+                        (tail if cut["done"] else g).capture_end()
+                torch.cuda.current_stream().wait_stream(cap)
+                if cut["done"]:
+                    g_tail = tail
         finally:
             self._cur = prev
             self.opt._step = step0           # the capture pass ran the host bookkeeping of a step that did not execute
             self._planes.mark_stale()        # ... and the recorded plane refresh has not run either
         slot.graphs[role] = g
+        if g_tail is not None:
+            slot.tails[role] = g_tail
 
     def ensure_captured(self) -> None:
         """Capture the current shape's graph for the role of the NEXT micro-batch now (outside any timed region) instead
