@@ -614,7 +614,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # (rank 0 at N = 1 only: the other ranks would wait for it)
             out["cpu_baseline"] = cpu_baseline(cfg, args.tp, args.config)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or dist.is_initialized():
+        # captured graphs and everything else that holds device work go BEFORE the process group does
+        for sl in ts._slots.values():
+            sl.drop_graphs()
+        del ts
+        gc.collect()
+        torch.cuda.synchronize()
         dist.barrier()
         dist.destroy_process_group()
 

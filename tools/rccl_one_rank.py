@@ -68,6 +68,11 @@ def main():
             out["one_rank_mean_leaves_bucket_unchanged"] = bool(torch.equal(before, opt.bucket.flat))
         runs.append((losses, opt.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
                      {k: v.clone() for k, v in lm.model.state_dict().items() if "running" in k}))
+        # captured graphs go before the process group does (and before the next run re-uses the allocator's pools)
+        for sl in ts._slots.values():
+            sl.drop_graphs()
+        del ts
+        torch.cuda.synchronize()
     a = runs[0]
     same = lambda b: (all(torch.equal(x, y) for x, y in zip(a[0], b[0])),
                       bool(torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
@@ -78,6 +83,9 @@ def main():
     out["ok"] = bool(out["losses_equal"] and out["state_equal"] and out["one_rank_mean_leaves_bucket_unchanged"]
                      and out["overlap_losses_equal"] and out["overlap_state_equal"] and out["split_graphs"] == 1)
     print(json.dumps(out), flush=True)
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if out["ok"] else 1)
