@@ -138,7 +138,16 @@ class GemmProbe:
         "ttts_conv1d_fwd_x6": (1, lambda a: (a[4] * a[5], a[7], a[6] * a[8])),
         "ttts_conv1d_bwd_data": (0, lambda a: (a[3] * a[4], a[5], a[6] * a[7])),
         "ttts_conv1d_bwd_data_x6": (1, lambda a: (a[3] * a[4], a[5], a[6] * a[7])),
+        # LDS-DMA kernel (gemm_h3i.hip): image operand / raw fp32 operand
+        "ttts_linear_fwd_h3i": (2, lambda a: (a[6], a[7], a[8])),
+        "ttts_linear_bwd_data_h3i": (2, lambda a: (a[5], a[7], a[6])),
+        "ttts_linear_fwd_h3d": (2, lambda a: (a[5], a[6], a[7])),
+        "ttts_linear_bwd_data_h3d": (2, lambda a: (a[4], a[6], a[5])),
     }
+    # gemm_h3i_kernel<A_RAW, HAS_RES, HAS_GATE, DROP> as dispatch_h3i instantiates it: name -> argument positions of
+    # (residual, relu gate or None, dropout probability or None)
+    DMA = {"ttts_linear_fwd_h3i": (False, 4, None, 10), "ttts_linear_bwd_data_h3i": (False, 3, 8, None),
+           "ttts_linear_fwd_h3d": (True, 3, None, 9), "ttts_linear_bwd_data_h3d": (True, 2, 7, None)}
 
     def __init__(self, lib):
         self.lib, self.records, self.orig = lib, [], {}
@@ -156,6 +165,11 @@ class GemmProbe:
                 tile = self.lib.ttts_gemm_tile_choice(M, N, K, _x6)
                 if _x6 == 2 and tile == 6 and K >= 96 and _plain:
                     tile = 9        # unshifted operands on the 256 x 256 tile run on gemm_h3_wide_kernel (one wave per SIMD)
+                if _name in self.DMA:
+                    raw, i_res, i_gate, i_p = self.DMA[_name]
+                    flag = lambda v: "true" if v else "false"      # noqa: E731
+                    tile = "gemm_h3i_kernel<%s,%s,%s,%s>" % (flag(raw), flag(a[i_res]), flag(i_gate is not None and a[i_gate]),
+                                                             flag(i_p is not None and a[i_p] > 0))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = _fn(*a)
@@ -166,6 +180,8 @@ class GemmProbe:
                 # tile loads its 256 x K activation block and its 256 x K weight block (re-reads come from L2, but through the same
                 # per-CU path) and stores 256 x 256 outputs
                 cu_bytes = (-(-M // 256)) * (-(-N // 256)) * (2.0 * 256 * K * 4) + 4.0 * M * N
+                if isinstance(tile, str):       # 128 x 256 tiles
+                    cu_bytes = (-(-M // 128)) * (-(-N // 256)) * ((128 + 256) * K * 4.0) + 4.0 * M * N
                 self.records.append((e0, e1, 2.0 * M * N * K, (_x6, tile), 4.0 * (M * K + M * N + N * K), cu_bytes))
                 return rc
             setattr(self.lib, n, wrapped)
@@ -190,15 +206,19 @@ class GemmProbe:
         key = max(groups, key=lambda k: groups[k][1])
         n, ms, fl, nbytes, cu_bytes = groups[key]
         x6, tile = key
-        name = (f"gemm_f32_kernel<{self.TILES[tile]},true,*>", f"gemm_bf16x6_kernel<{self.TILES[tile]}>",
-                "gemm_h3_wide_kernel" if tile == 9 else f"gemm_h3_kernel<{self.TILES[tile]}>")[x6]
-        others = {(f"{('f32', 'bf16x6', 'h3')[k[0]]}<{self.TILES[k[1]]}>"): {"launches": v[0], "total_ms": v[1],
-                                                                              "tflops": v[2] / (v[1] * 1e-3) / 1e12}
+
+        def label(k):
+            return k[1] if isinstance(k[1], str) else f"{('f32', 'bf16x6', 'h3')[k[0]]}<{self.TILES[k[1]]}>"
+
+        name = tile if isinstance(tile, str) else (
+            f"gemm_f32_kernel<{self.TILES[tile]},true,*>", f"gemm_bf16x6_kernel<{self.TILES[tile]}>",
+            "gemm_h3_wide_kernel" if tile == 9 else f"gemm_h3_kernel<{self.TILES[tile]}>")[x6]
+        others = {label(k): {"launches": v[0], "total_ms": v[1], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
                   for k, v in groups.items()}
         return {"kernel": name, "form": x6, "launches": n, "avg_ms": ms / n, "avg_flops": fl / n,
                 "tflops": fl / (ms * 1e-3) / 1e12, "total_ms": ms, "all": others, "avg_bytes": nbytes / n,
                 "gbps": nbytes / (ms * 1e-3) / 1e9, "cu_gbps": cu_bytes / (ms * 1e-3) / 1e9, "avg_cu_bytes": cu_bytes / n,
-                "tile256": tile in (6, 9)}
+                "tile256": tile in (6, 9) or isinstance(tile, str)}
 
 
 def usable_cores() -> int:
@@ -608,7 +628,7 @@ def main():
                 out["roofline"]["cu_path_view"] = {"achieved": probe["cu_gbps"], "peak": cu_peak, "unit": "GB/s",
                                                    "frac": probe["cu_gbps"] / cu_peak,
                                                    "bytes_per_launch": probe["avg_cu_bytes"],
-                                                   "bytes_are": "per 256 x 256 tile: activation block + weight block loaded, output stored",
+                                                   "bytes_are": "per output tile (256 x 256; 128 x 256 for gemm_h3i): activation block + weight block loaded, output stored",
                                                    "peak_is": "256 CUs x ~10 B/cycle/CU x 2.4 GHz (global_load_dwordx4, HBM-bound); L2 hits can exceed it"}
             out["roofline"]["gemm_kernels"] = probe["all"]
         if not args.no_cpu_baseline and world == 1:          # (rank 0 at N = 1 only: the other ranks would wait for it)
