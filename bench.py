@@ -150,7 +150,7 @@ class GemmProbe:
            "ttts_linear_fwd_h3d": (True, 3, None, 9), "ttts_linear_bwd_data_h3d": (True, 2, 7, None)}
 
     def __init__(self, lib):
-        self.lib, self.records, self.orig = lib, [], {}
+        self.lib, self.records, self.orig, self.shapes = lib, [], {}, []
 
     def __enter__(self):
         for n, (x6, dims) in self.CALLS.items():
@@ -183,6 +183,7 @@ class GemmProbe:
                 if isinstance(tile, str):       # 128 x 256 tiles
                     cu_bytes = (-(-M // 128)) * (-(-N // 256)) * ((128 + 256) * K * 4.0) + 4.0 * M * N
                 self.records.append((e0, e1, 2.0 * M * N * K, (_x6, tile), 4.0 * (M * K + M * N + N * K), cu_bytes))
+                self.shapes.append((_name, int(M), int(N), int(K)))
                 return rc
             setattr(self.lib, n, wrapped)
         return self
@@ -190,6 +191,18 @@ class GemmProbe:
     def __exit__(self, *exc):
         for n, fn in self.orig.items():
             setattr(self.lib, n, fn)
+
+    def shape_table(self):
+        """per (entry point, M, N, K): launches, mean us, TF -- development aid (`--gemm-shapes`)"""
+        torch.cuda.synchronize()
+        t = {}
+        for (e0, e1, fl, key, _, _), sh in zip(self.records, self.shapes):
+            g = t.setdefault((sh, key[1] if isinstance(key[1], str) else self.TILES[key[1]]), [0, 0.0, fl])
+            g[0] += 1
+            g[1] += e0.elapsed_time(e1)
+        rows = sorted(t.items(), key=lambda kv: -kv[1][1])
+        return [f"{v[1] * 1e3:8.1f} us total  {v[0]:3d} x {v[1] / v[0] * 1e3:7.1f} us  {v[2] / (v[1] / v[0] * 1e-3) / 1e12:6.1f} TF  "
+                f"{k[0][0]:28s} M={k[0][1]:6d} N={k[0][2]:5d} K={k[0][3]:5d}  [{k[1]}]" for k, v in rows]
 
     def summary(self):
         torch.cuda.synchronize()
@@ -347,6 +360,7 @@ def main():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--gemm-shapes", action="store_true", help="print the instrumented step's per-shape GEMM table to stderr")
     ap.add_argument("--cycle", type=int, default=1, help="number of distinct ragged batch shapes fed round-robin")
     ap.add_argument("--lattice", default="", help="P,M: pad batches to multiples of P phonemes / M frames (graph-cache key)")
     ap.add_argument("--accumulate", type=int, default=1, help="micro-batches per optimizer step (train.py:42 uses 4)")
@@ -556,6 +570,8 @@ def main():
                 step(args.warmup + args.steps)
             probe = gp.summary()
             note("instrumented step done")
+            if args.gemm_shapes:
+                print("\n".join(gp.shape_table()), file=sys.stderr, flush=True)
         else:
             step(args.warmup + args.steps)
     fence()

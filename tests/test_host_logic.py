@@ -315,3 +315,26 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--no-such-flag"], env=env, capture_output=True,
                        text=True, timeout=300, cwd=repo)
     assert r.returncode != 0
+
+
+def test_no_sgpr_hazard_in_front_of_inline_assembly_memory_instructions():
+    """hipcc's hazard recogniser does not look inside inline assembly: a vector-memory instruction in an `asm` block that reads
+    an SGPR a VALU instruction wrote fewer than 5 wait states earlier reads a stale value (tools/isa_hazard_scan.py).  Scans the
+    gfx950 ISA of every kernel file that carries inline assembly (cross-compiles here, no GPU)."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which(os.environ.get("HIPCC", "hipcc")) is None:
+        pytest.skip("hipcc not on PATH")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "isa_hazard_scan.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # and the scanner does find the pattern when it is there
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    try:
+        import isa_hazard_scan
+    finally:
+        sys.path.pop(0)
+    isa = ["\tv_readlane_b32 s6, v137, 11", "\t;;#ASMSTART", "\tbuffer_load_dwordx4 v[46:49], v82, s[28:31], s6 offen", "\t;;#ASMEND"]
+    assert len(isa_hazard_scan.scan(isa)) == 1
+    isa.insert(1, "\ts_nop 4")
+    assert isa_hazard_scan.scan(isa) == []
