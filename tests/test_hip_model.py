@@ -616,10 +616,12 @@ def test_image_operand_path_on_small_shapes(monkeypatch, cfg_name, B, Tp, Tm, w_
 
 def test_dma_gemm_on_plain_fp32_operands_on_small_shapes(monkeypatch):
     """ttts_linear_fwd_h3d / ttts_linear_bwd_data_h3d -- the LDS-DMA kernel on a plain fp32 activation (raw k-tile staged by DMA,
-    split in place in LDS) -- are what the step uses for the 256 -> 256 projections and the gated data gradients from 8 192 rows
-    on; with the threshold lowered the whole base model runs through them against the fp64 oracle."""
+    split in place in LDS) -- are what the step uses for the gated data gradients from 8 192 rows on and for the square projections
+    whose tiles fill the chip (ops._dma_shape_ok); with the thresholds lowered the whole base model runs through them against
+    the fp64 oracle."""
     from transformertts_amd import _lib, ops
     monkeypatch.setattr(ops, "IMAGE_MIN_ROWS", 1)
+    monkeypatch.setattr(ops, "DMA_MIN_TILES", 0)
     calls = {"fwd": 0, "bwd": 0}
     lib = _lib.load()
     f0, b0 = lib.ttts_linear_fwd_h3d, lib.ttts_linear_bwd_data_h3d

@@ -598,13 +598,19 @@ def _image_shape_ok(M: int, red: int, out: int) -> bool:
 
 
 def _dma_shape_ok(M: int, red: int, out: int, gate: bool) -> bool:
-    """shapes on which the LDS-DMA kernel beats gemm_h3 with a plain fp32 activation (ttts_linear_*_h3d; tools/h3i_bench.py at
-    M = 55 680: data gradients with a relu gate into 1024 columns 1.15x, 256 -> 256 projections 1.07x; level or slower elsewhere)"""
+    """shapes on which the LDS-DMA kernel beats gemm_h3 with a plain fp32 activation (ttts_linear_*_h3d; tools/h3i_bench.py,
+    h3 time / DMA time): data gradients with a relu gate, 256 -> 1024 columns: 1.09x at M = 13 920, 1.12x at 27 840, 1.15x at
+    55 680 (512 -> 2048 at 27 840: 0.99x, not taken); square projections when their 128 x 256 tiles fill the chip: 256 -> 256
+    0.72x at M = 13 920, 0.95x at 27 840, 1.04x at 41 760 (326 tiles), 1.07x at 55 680; 512 -> 512 1.11x at 27 840 (436 tiles).
+    Level or slower elsewhere (K = 1024: 0.9x)."""
     if not (DMA_GEMMS and M >= IMAGE_MIN_ROWS and red % 32 == 0 and out % 4 == 0):
         return False
-    return (gate and red <= 512 and out >= 512) or (red == 256 and out == 256)
+    if gate and red <= 256 and out >= 512:
+        return True
+    return red == out and out in (256, 512) and -(-M // 128) * -(-out // 256) >= DMA_MIN_TILES
 
 
+DMA_MIN_TILES = 320
 DMA_GEMMS = True
 
 
