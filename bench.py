@@ -588,14 +588,16 @@ def main():
                                    f"({'ragged' if args.ragged else 'dense'}), {args.config} config d_model {cfg['d_model']}, "
                                    f"{cfg['encoder_n_layers']}+{cfg['decoder_n_layers']} layers, dropout on, fp32",
                        "global_batch": args.batch * world, "frames_per_step": frames_all, "parallelism": f"dp{world}",
-                       "launch_path": (f"one HIP graph per step ({ts.n_graphs} captured: one per batch shape and accumulation role)"
-                                       if ts.graphed else "eager: one ctypes launch per kernel"),
+                       "launch_path": ((f"one HIP graph per step ({ts.n_graphs} captured: one per batch shape and accumulation role)"
+                                        if ts.graphed else "eager: one ctypes launch per kernel")
+                                       + (f" [{ts.capture_fallback}]" if ts.capture_fallback else "")),
                        "batch_stream": (f"{len(batches)} distinct ragged shapes round-robin" + (f", lattice {lattice}" if lattice else "")
                                         if cycling else "one resident batch"),
                        "accumulate": args.accumulate,
                        "process_group": (dist.get_backend() + f" x{world}") if dist.is_initialized() else "none",
                        "grad_allreduce": ("none (1 GPU)" if not ts.dp else
-                                          "tail overlapped with backward" if ts.trigger is not None
+                                          "tail overlapped with backward" if ts.trigger is not None and (
+                                              not ts.graphed or any(sl.tails for sl in ts._slots.values()))
                                           else "one collective after backward"),
                        "alignments_written": bool(args.alignments),
                        "dma_gemms": not args.no_image_operands, "layernorm_images": bool(args.layernorm_images),

@@ -11,7 +11,9 @@ and the optimizer kernels behind the collective.  Checks (printed as one JSON li
     end in exactly the parameters / moments / BatchNorm buffers of N steps through the single-process path (graph
     including the optimizer), dropout on;
   * the same with the exchange overlapped: the step captured as TWO graphs cut where backward leaves the decoder, the tail's
-    all-reduce started between their replays (step.TrainStep, overlap=True).
+    all-reduce started between their replays (step.TrainStep, overlap=True);
+  * the same with the second graph's `capture_begin` made to FAIL: TrainStep must say so, fall back to one graph per step
+    (whole bucket exchanged after backward) and still end in the same bits (`_capture_guarded`).
 """
 import json
 import os
@@ -47,7 +49,7 @@ def main():
     batch = {k: v.to(dev) for k, v in synth_batch(B, Tp, Tm, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=8).items()}
     out = {"backend": dist.get_backend(), "world": dist.get_world_size(), "config": cfg_name, "steps": steps}
     runs = []
-    for force, overlap in ((False, False), (True, False), (True, True)):
+    for force, overlap, sabotage in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
         torch.manual_seed(42)
         lm = LightningModule(config).to(dev)
         lm.train()
@@ -55,10 +57,26 @@ def main():
         oc = lm.configure_optimizers()
         opt, sch = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
         ts = TrainStep(lm, opt, sch, batch, graph=True, seed=77, force_collective=force, overlap=overlap)
-        losses = [ts().detach().clone() for _ in range(steps)]
+        begin = torch.cuda.CUDAGraph.capture_begin
+        if sabotage:
+            calls = {"n": 0}
+
+            def failing_begin(self, *a, **k):             # the SECOND capture_begin of a step is the tail graph's
+                calls["n"] += 1
+                if calls["n"] == 2:
+                    raise RuntimeError("sabotaged capture_begin (tools/rccl_one_rank.py)")
+                return begin(self, *a, **k)
+            torch.cuda.CUDAGraph.capture_begin = failing_begin
+        try:
+            losses = [ts().detach().clone() for _ in range(steps)]
+        finally:
+            torch.cuda.CUDAGraph.capture_begin = begin
         torch.cuda.synchronize()
         assert ts.graphed
-        if overlap:
+        if sabotage:
+            out["fallback"] = ts.capture_fallback
+            out["fallback_split_graphs"] = sum(len(sl.tails) for sl in ts._slots.values())
+        elif overlap:
             out["split_graphs"] = sum(len(sl.tails) for sl in ts._slots.values())
             out["tail_trigger_fired"] = ts.trigger.fired if ts.trigger is not None else 0
         if force and not overlap:
@@ -79,9 +97,12 @@ def main():
                            and all(torch.equal(a[4][k], b[4][k]) for k in a[4])))
     out["losses_equal"], out["state_equal"] = same(runs[1])
     out["overlap_losses_equal"], out["overlap_state_equal"] = same(runs[2])
+    out["fallback_losses_equal"], out["fallback_state_equal"] = same(runs[3])
     out["final_loss"] = float(a[0][-1])
     out["ok"] = bool(out["losses_equal"] and out["state_equal"] and out["one_rank_mean_leaves_bucket_unchanged"]
-                     and out["overlap_losses_equal"] and out["overlap_state_equal"] and out["split_graphs"] == 1)
+                     and out["overlap_losses_equal"] and out["overlap_state_equal"] and out["split_graphs"] == 1
+                     and out["fallback_losses_equal"] and out["fallback_state_equal"] and out["fallback_split_graphs"] == 0
+                     and bool(out["fallback"]))
     print(json.dumps(out), flush=True)
     import gc
     gc.collect()

@@ -114,6 +114,8 @@ class TrainStep:
         self._slots: Dict[Tuple[int, int, int], _Slot] = {}
         self.evictions = 0
         self.recaptures = 0                  # times a moved / edited parameter invalidated the captured graphs
+        self.split_capture = True            # cut the captured step at the tail trigger (two graphs) when there is a trigger
+        self.capture_fallback = None         # what _capture_guarded had to give up, if anything
         self._cur: Optional[_Slot] = None
         self._pool = None                    # memory pool shared by every captured graph
         self._planes: Optional[ops.PlaneTable] = None
@@ -223,6 +225,8 @@ class TrainStep:
         here -- the collective is issued between the two replays, never recorded."""
         if self._cut is not None:
             self._cut()
+        elif torch.cuda.is_current_stream_capturing():
+            return          # one-graph capture (the fallback of _capture_guarded): the whole bucket is exchanged after the replay
         else:
             self.bucket.start_tail_allreduce(lo, self.group)
 
@@ -278,7 +282,9 @@ class TrainStep:
             slot.eager_runs += 1
         else:
             if role not in slot.graphs:
-                self._capture(slot, role)
+                self._capture_guarded(slot, role)
+            if not self.use_graph:               # the capture could not be made (see _capture_guarded): this step runs eagerly
+                return self.__call__()
             slot.graphs[role].replay()
             if role in slot.tails:           # the step was cut at the tail trigger: exchange the tail beside graph B
                 self.bucket.start_tail_allreduce(self.trigger.lo, self.group)
@@ -296,6 +302,41 @@ class TrainStep:
         self.micro = 0 if last else self.micro + 1
         return loss
 
+    def _capture_guarded(self, slot: _Slot, role: str) -> None:
+        """`_capture`, with a way out for the one form that depends on the process group's behaviour under stream capture: if
+        the TWO-graph capture (cut at the tail trigger, `split_capture`) raises, say so on stderr, capture the step as one
+        graph (the whole bucket is then exchanged after backward, as before round 4), and if that fails too run without
+        graphs.  `capture_fallback` records what happened (bench.py puts it in `config.launch_path`).  A failure of the
+        ONE-graph capture with no split attempted is a defect and propagates."""
+        attempted_split = self.trigger is not None and self.split_capture and role in ("full", "last")
+        try:
+            self._capture(slot, role)
+            return
+        except Exception as e:  # noqa: BLE001
+            if not attempted_split:
+                raise
+            import sys
+            print(f"[TrainStep] two-graph capture failed ({type(e).__name__}: {e}); falling back to one graph per step",
+                  file=sys.stderr, flush=True)
+            self.capture_fallback = f"two-graph capture failed ({type(e).__name__}); one graph per step"
+        self.split_capture = False
+        slot.drop_graphs()
+        import gc
+        gc.collect()                             # the half-made graph objects release their share of the pool
+        try:
+            torch.cuda.synchronize()
+            self._pool_check()                   # (the first graph of the pool died with the attempt: start a new pool)
+            self._capture(slot, role)
+        except Exception as e:  # noqa: BLE001
+            import sys
+            print(f"[TrainStep] one-graph capture failed as well ({type(e).__name__}: {e}); running without graphs",
+                  file=sys.stderr, flush=True)
+            self.capture_fallback = f"graph capture failed ({type(e).__name__}); eager launches"
+            for sl in self._slots.values():
+                sl.drop_graphs()
+            self._pool_check()
+            self.use_graph = False
+
     def _capture(self, slot: _Slot, role: str) -> None:
         """Record one micro-batch of `role` over the static buffers of `slot` into a HIP graph.  Nothing executes during
         capture; the caller replays it right away."""
@@ -309,7 +350,7 @@ class TrainStep:
         self._cur = slot
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
-        split = self.trigger is not None and role in ("full", "last")
+        split = self.trigger is not None and self.split_capture and role in ("full", "last")
         g_tail = None
         try:
             if not split:
@@ -333,12 +374,18 @@ class TrainStep:
                 with torch.cuda.stream(cap), torch.autograd.set_multithreading_enabled(False):
                     g.capture_begin(pool=self._pool)
                     self._cut = cut_here
+                    completed = False
                     try:
                         with self.state:
                             slot.losses[role] = self._forward_backward(role, capturing=True)
+                        completed = True
                     finally:
                         self._cut = None
-                        (tail if cut["done"] else g).capture_end()
+                        try:
+                            (tail if cut["done"] else g).capture_end()
+                        except Exception:  # noqa: BLE001
+                            if completed:    # (after a failure inside the pass its own exception is the one to report)
+                                raise
                 torch.cuda.current_stream().wait_stream(cap)
                 if cut["done"]:
                     g_tail = tail
@@ -362,7 +409,7 @@ class TrainStep:
         if self.index < 2:
             raise RuntimeError("TrainStep.ensure_captured: run at least two (eager) steps first")
         self._push_state()                   # harmless: the next step pushes its own state again
-        self._capture(slot, role)
+        self._capture_guarded(slot, role)
         self.eager_warmup = min(self.eager_warmup, self.index)
 
     @property
