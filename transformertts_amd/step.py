@@ -46,6 +46,12 @@ from . import ops
 from .optim import FlatAdam
 from .parallel import overlap_tail_with_backward
 
+# Stream-capture mode of every graph this module records.  The default ("global") makes a HIP call that is illegal during capture
+# an error in ANY thread of the process -- including ProcessGroupNCCL's watchdog thread, which polls the events of earlier
+# collectives with hipEventQuery: one capture in ten of a data-parallel run died with "operation not permitted when stream is
+# capturing" raised in the watchdog (SIGABRT; found by looping tools/rccl_one_rank.py).  "thread_local" confines the check to
+# the capturing thread; launches that other threads (autograd's) put on the capturing stream are recorded either way.
+_CAPTURE_MODE = "thread_local"
 _MIX = 0x9E3779B97F4A7C15
 _KEYS = ("phoneme", "melspec", "phoneme_lens", "melspec_lens")
 
@@ -354,7 +360,7 @@ class TrainStep:
         g_tail = None
         try:
             if not split:
-                with torch.cuda.graph(g, pool=self._pool):
+                with torch.cuda.graph(g, pool=self._pool, capture_error_mode=_CAPTURE_MODE):
                     with self.state:
                         slot.losses[role] = self._forward_backward(role, capturing=True)
                         if role in ("full", "last") and not self.dp:
@@ -367,12 +373,12 @@ class TrainStep:
 
                 def cut_here():
                     g.capture_end()
-                    tail.capture_begin(pool=self._pool)
+                    tail.capture_begin(pool=self._pool, capture_error_mode=_CAPTURE_MODE)
                     cut["done"] = True
                 cap = torch.cuda.Stream()
                 cap.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(cap), torch.autograd.set_multithreading_enabled(False):
-                    g.capture_begin(pool=self._pool)
+                    g.capture_begin(pool=self._pool, capture_error_mode=_CAPTURE_MODE)
                     self._cut = cut_here
                     completed = False
                     try:
