@@ -179,3 +179,23 @@ def test_rccl_one_rank_group_matches_the_single_process_step():
     # so on stderr and in `capture_fallback`, same bits
     assert out["fallback"] and out["fallback_split_graphs"] == 0 and out["fallback_losses_equal"] and out["fallback_state_equal"], out
     assert "two-graph capture failed" in r.stderr, r.stderr[-2000:]
+
+
+def test_bench_runs_under_a_one_rank_rccl_group():
+    """bench.py itself on the data-parallel launch path over the real backend: RANK / WORLD_SIZE = 1 with TTTS_FORCE_DIST=1 makes
+    it initialise "nccl" (RCCL), broadcast the module state, capture the step as two graphs cut at the tail trigger and
+    exchange the bucket every step -- what every rank of an N-GPU run does, minus the other ranks."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", TTTS_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "6", "--warmup", "3", "--sustain", "0", "--batch", "16",
+                        "--no-cpu-baseline", "--no-alignments-figure"], env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["process_group"].startswith("nccl")
+    assert out["config"]["grad_allreduce"] == "tail overlapped with backward", out["config"]
+    assert "failed" not in out["config"]["launch_path"], out["config"]["launch_path"]
