@@ -40,6 +40,8 @@ __global__ __launch_bounds__(64) void k(unsigned* out, unsigned seed, long long*
 #define CMP(i) asm volatile("v_cmp_le_u32 vcc, %0, %1" : : "v"(v[i]), "v"(c) : "vcc");
 #define FMA(i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[i]) : "v"(c));
 #define MFMA(i) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+v"(acc[i & 3]) : "v"(frag));
+#define MFMA1(i) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+v"(acc[0]) : "v"(frag));
+#define MFMA2(i) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+v"(acc[i & 1]) : "v"(frag));
         if (OP == 0) { REP8(MULLO) }
         if (OP == 1) { REP8(MULHI) }
         if (OP == 2) { REP8(MUL24) }
@@ -62,6 +64,8 @@ __global__ __launch_bounds__(64) void k(unsigned* out, unsigned seed, long long*
         if (OP == 19) { REP8(CMP) }
         if (OP == 20) { REP8(FMA) }
         if (OP == 21) { REP8(MFMA) }
+        if (OP == 22) { REP8(MFMA1) }
+        if (OP == 23) { REP8(MFMA2) }
     }
     long long t1 = __builtin_readcyclecounter();
     unsigned s = 0;
@@ -87,5 +91,6 @@ int main() {
     run<15>("v_pk_add_f32", out, cyc); run<16>("v_pk_fma_f32", out, cyc); run<17>("v_max3_f32", out, cyc);
     run<18>("v_cndmask_b32", out, cyc); run<19>("v_cmp_le_u32", out, cyc); run<20>("v_fma_f32", out, cyc);
     run<21>("v_mfma_32x32x16_f16", out, cyc);
+    run<22>("mfma 32x32x16, ONE accumulator chain", out, cyc); run<23>("mfma 32x32x16, two accumulators", out, cyc);
     return 0;
 }
