@@ -421,3 +421,38 @@ def test_graph_cache_evicts_the_least_recently_used_shape():
         outs.append((losses, _state(lm, opt)))
     assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
     assert _same(outs[0][1], outs[1][1])
+
+
+def test_graphs_of_shapes_on_either_side_of_a_kernel_routing_threshold(monkeypatch):
+    """Which GEMM kernel a Linear takes depends on the batch's row count (ops._dma_shape_ok: the LDS-DMA kernel when its tiles fill
+    the chip), and the two kernels read different weight images.  A shape met for the first time AFTER the eager warm-up is
+    captured at once, so the image its routing needs must already exist: the eager steps make both images of every weight whose
+    dimensions are eligible (ops._both_images).  Thresholds lowered so that base-model shapes of a few hundred rows straddle
+    them; a graph step on either side is bit for bit the eager step."""
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.step import TrainStep
+    from transformertts_amd.workload import synth_batch
+    monkeypatch.setattr(ops, "IMAGE_MIN_ROWS", 700)        # gated data gradients: DMA kernel from 700 rows on
+    monkeypatch.setattr(ops, "DMA_MIN_TILES", 8)           # 256 -> 256 projections: from 8 tiles (897 rows) on
+    shapes = [(3, 20, 320), (3, 20, 200), (3, 20, 260), (3, 20, 320), (3, 20, 200)]    # 960, 600, 780 rows
+    lib = _lib.load()
+    runs = []
+    for graph in (False, True):
+        cfg, lm, opt, sch = _setup("base", 5, 0)
+        batches = [{k: v.to("cuda") for k, v in synth_batch(B, Tp, Tm, cfg["n_mels"], cfg["n_phon"], ragged=False, seed=40 + i).items()}
+                   for i, (B, Tp, Tm) in enumerate(shapes)]
+        calls = {"h3d": 0, "h3": 0}
+        f_d, f_3 = lib.ttts_linear_fwd_h3d, lib.ttts_linear_fwd_h3
+        monkeypatch.setattr(lib, "ttts_linear_fwd_h3d", lambda *a: (calls.__setitem__("h3d", calls["h3d"] + 1), f_d(*a))[1])
+        monkeypatch.setattr(lib, "ttts_linear_fwd_h3", lambda *a: (calls.__setitem__("h3", calls["h3"] + 1), f_3(*a))[1])
+        ts = TrainStep(lm, opt, sch, graph=graph, seed=13)
+        losses = [ts(batches[i % len(batches)]).detach().clone() for i in range(8)]
+        torch.cuda.synchronize()
+        monkeypatch.setattr(lib, "ttts_linear_fwd_h3d", f_d)
+        monkeypatch.setattr(lib, "ttts_linear_fwd_h3", f_3)
+        assert calls["h3d"] > 0 and calls["h3"] > 0, calls           # both kernels were in use
+        if graph:
+            assert ts.n_graphs == 3 and ts.capture_fallback is None
+        runs.append((losses, _state(lm, opt)))
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][0], runs[1][0]))
+    assert _same(runs[0][1], runs[1][1])

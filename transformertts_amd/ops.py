@@ -611,6 +611,20 @@ def _dma_shape_ok(M: int, red: int, out: int, gate: bool) -> bool:
 
 
 DMA_MIN_TILES = 320
+
+
+def _dma_dims(red: int, out: int) -> bool:
+    """could `_dma_shape_ok` say yes for SOME row count?  The choice between the two kernels (and so between the two weight
+    images, modes 4 / 8 resp. 5 / 9) depends on the batch's row count, and a captured graph can only use images that exist:
+    `_both_images` makes both in the eager steps whenever the dimensions are eligible, whatever the current row count."""
+    return DMA_GEMMS and red % 32 == 0 and out % 4 == 0 and ((red <= 256 and out >= 512) or (red == out and out in (256, 512)))
+
+
+def _both_images(w: torch.Tensor, used: int, other: int, rows: int, cols: int) -> torch.Tensor:
+    """planes of `w` in mode `used`; outside a capture also make sure its sibling image (`other`) exists"""
+    if not torch.cuda.is_current_stream_capturing():
+        _planes(w, other, rows, cols)
+    return _planes(w, used, rows, cols)
 DMA_GEMMS = True
 
 
@@ -647,11 +661,14 @@ class LinearFn(torch.autograd.Function):
         elif _fwd_h3(K, N):
             if x_amax is None:
                 x_amax = _amax(x)
+            both = row_shift == 0 and _dma_dims(K, N)
             if row_shift == 0 and _dma_shape_ok(M, K, N, False):
-                _lib.check(lib.ttts_linear_fwd_h3d(_p(x), _p(_planes(w, 8, N, K)), _p(b_), _p(r_), _p(y), M, N, K, act,
+                _lib.check(lib.ttts_linear_fwd_h3d(_p(x), _p(_both_images(w, 8, 4, N, K) if both else _planes(w, 8, N, K)), _p(b_), _p(r_),
+                                                   _p(y), M, N, K, act,
                                                    float(drop_p), seed, _ss(), _p(x_amax), _p(y_amax), _stream()), "ttts_linear_fwd_h3d")
             else:
-                _lib.check(lib.ttts_linear_fwd_h3(_p(x), _p(_planes(w, 4, N, K)), _p(b_), _p(r_), _p(y), M, N, K, act,
+                _lib.check(lib.ttts_linear_fwd_h3(_p(x), _p(_both_images(w, 4, 8, N, K) if both else _planes(w, 4, N, K)), _p(b_), _p(r_),
+                                                  _p(y), M, N, K, act,
                                                   float(drop_p), seed, _ss(), row_shift, T, _p(x_amax), _p(y_amax), _stream()),
                            "ttts_linear_fwd_h3")
         elif GEMM_MODE == "x6":
@@ -730,12 +747,15 @@ class LinearFn(torch.autograd.Function):
                                "ttts_linear_bwd_data_h3i")
                 else:
                     am = am if am is not None else _amax(dacc)
+                    both = _dma_dims(N, K)
                     if _dma_shape_ok(M, N, K, gate is not None) and not (gate is not None and skip is not None):
-                        _lib.check(lib.ttts_linear_bwd_data_h3d(_p(dacc), _p(_planes(w, 9, K, N)), _p(skip), _p(dx), M, N, K,
+                        _lib.check(lib.ttts_linear_bwd_data_h3d(_p(dacc), _p(_both_images(w, 9, 5, K, N) if both else _planes(w, 9, K, N)),
+                                                                _p(skip), _p(dx), M, N, K,
                                                                 _p(gate), gscale, _p(am), _p(dx_am), _stream()),
                                    "ttts_linear_bwd_data_h3d")
                     else:
-                        _lib.check(lib.ttts_linear_bwd_data_h3(_p(dacc), _p(_planes(w, 5, K, N)), _p(skip), _p(dx), M, N, K,
+                        _lib.check(lib.ttts_linear_bwd_data_h3(_p(dacc), _p(_both_images(w, 5, 9, K, N) if both else _planes(w, 5, K, N)),
+                                                               _p(skip), _p(dx), M, N, K,
                                                                _p(gate), gscale, _p(am), _p(dx_am), _stream()),
                                    "ttts_linear_bwd_data_h3")
                 if dx_am is not None:
