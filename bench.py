@@ -364,10 +364,12 @@ def main():
     ap.add_argument("--cycle", type=int, default=1, help="number of distinct ragged batch shapes fed round-robin")
     ap.add_argument("--lattice", default="", help="P,M: pad batches to multiples of P phonemes / M frames (graph-cache key)")
     ap.add_argument("--accumulate", type=int, default=1, help="micro-batches per optimizer step (train.py:42 uses 4)")
-    ap.add_argument("--alignments", action="store_true",
-                    help="the grad forward of every timed step also writes the per-head cross-attention maps (B,H,Tm,Tp) as the "
+    ap.add_argument("--alignments", dest="alignments", action="store_true", default=True,
+                    help="(default) the grad forward of every timed step writes the per-head cross-attention maps (B,H,Tm,Tp) as the "
                          "reference's forward does (model/layers.py:68-73); the step's results do not depend on them")
-    ap.add_argument("--no-alignments-figure", action="store_true", help="skip the secondary figure taken with --alignments semantics")
+    ap.add_argument("--no-alignments", dest="alignments", action="store_false",
+                    help="the timed step skips the maps training_step() discards (lightning_module.py:78-79): the secondary figure as the headline")
+    ap.add_argument("--no-alignments-figure", action="store_true", help="skip the secondary figure taken with the other --alignments setting")
     ap.add_argument("--no-image-operands", action="store_true",
                     help="A/B aid: keep every GEMM on the kernels that split the fp32 activation in their loader (gemm_h3): no launch "
                          "of the LDS-DMA kernel (gemm_h3i)")
@@ -526,14 +528,14 @@ def main():
                      "note": "rank-0 clock around fenced stretches of --steps steps each, after the timed region"}
         note(f"sustained: median {med:.2f} ms/step over {sustained['steps']} further steps")
 
-    # Secondary figure: the same step with the grad forward WRITING the attention maps (the reference's forward always
-    # materialises them, model/layers.py:68-73; its training_step then drops them, lightning_module.py:78-79).  The default
-    # step does not write them -- `config.alignments_written` says which -- so the <WRITE_A> cross-attention kernel gets its
-    # driver-visible time here.
+    # Secondary figure: the same step with the other setting of the attention maps.  The reference's forward always
+    # materialises them (model/layers.py:68-73) and its training_step then drops them (lightning_module.py:78-79): the headline
+    # step WRITES them, as the reference does (`config.alignments_written`); the secondary figure is the step that skips the
+    # maps nobody reads.
     with_alignments = None
-    if (not args.alignments and not args.no_alignments_figure and world == 1 and not cycling and args.accumulate == 1
+    if (not args.no_alignments_figure and world == 1 and not cycling and args.accumulate == 1
             and use_graph and not rehearsal):
-        lm.config["training"]["train_step_alignments"] = True
+        lm.config["training"]["train_step_alignments"] = not args.alignments
         ts2 = TrainStep(lm, optimizer, scheduler, batch, graph=True, seed=42 + rank, eager_warmup=2)
         for _ in range(2):
             ts2()
@@ -545,13 +547,15 @@ def main():
             ts2()
         fence()
         ms2 = (time.perf_counter() - ta) / args.steps * 1e3
-        lm.config["training"]["train_step_alignments"] = False
+        lm.config["training"]["train_step_alignments"] = bool(args.alignments)
         maps_mb = cfg["decoder_n_layers"] * args.batch * cfg["decoder_n_head"] * args.tm * args.tp * 4 / 1e6
         with_alignments = {"ms_per_step": ms2, "value": frames_all / (ms2 * 1e-3), "steps": args.steps,
-                           "alignment_bytes_written_per_step": maps_mb * 1e6,
-                           "note": "same step, grad forward writes the per-head cross-attention maps "
-                                   f"({maps_mb:.0f} MB); the no-grad forward needs none"}
-        note(f"with attention maps written: {ms2:.2f} ms/step")
+                           "alignments_written": not args.alignments,
+                           "alignment_bytes_per_step": maps_mb * 1e6,
+                           "note": ("same step, the grad forward SKIPS the per-head cross-attention maps training_step() discards "
+                                    if args.alignments else "same step, the grad forward writes the per-head cross-attention maps ")
+                                   + f"({maps_mb:.0f} MB; the no-grad forward needs none either way)"}
+        note(f"attention maps {'skipped' if args.alignments else 'written'}: {ms2:.2f} ms/step")
         del ts2
 
     rehearsal_check = None
@@ -600,11 +604,12 @@ def main():
                                               not ts.graphed or any(sl.tails for sl in ts._slots.values()))
                                           else "one collective after backward"),
                        "alignments_written": bool(args.alignments),
+                       "arithmetic": "3 x f16 MFMA terms per fp32 product (hi/lo f16 splits of both operands), fp32 accumulate",
                        "dma_gemms": not args.no_image_operands, "layernorm_images": bool(args.layernorm_images),
                        "final_loss": final_loss, "per_step_loss_item_sync": False},
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "sustained": sustained,
-            "with_alignments": with_alignments,
+            ("without_alignments" if args.alignments else "with_alignments"): with_alignments,
             "step_algorithmic_tflops": flops_all / 1e12,
             "step_achieved_tflops_per_gpu": flops_all / world / (elapsed / args.steps) / 1e12,
         }

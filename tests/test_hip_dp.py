@@ -175,6 +175,8 @@ def test_rccl_one_rank_group_matches_the_single_process_step():
     # ... and with the exchange overlapped on the FAST path: the step captured as two graphs cut where backward leaves the decoder,
     # the tail's all-reduce (RCCL, asynchronous) started between their replays -- same bits again
     assert out["split_graphs"] == 1 and out["overlap_losses_equal"] and out["overlap_state_equal"], out
+    # none of the three un-sabotaged runs may have taken the guarded fallback (one graph instead of two, or eager launches)
+    assert out["normal_path_fallbacks"] == [None, None, None], out
     # ... and when the two-graph capture cannot be made (the tail graph's capture_begin is made to raise): one graph per step, said
     # so on stderr and in `capture_fallback`, same bits
     assert out["fallback"] and out["fallback_split_graphs"] == 0 and out["fallback_losses_equal"] and out["fallback_state_equal"], out

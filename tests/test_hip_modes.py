@@ -815,9 +815,12 @@ def test_full_size_training_step_is_reproducible(cfg_name, B):
         torch.cuda.synchronize()
         return loss.detach().clone(), bucket.flat.clone()
 
-    l1, g1 = run(7)
-    l2, g2 = run(7)
-    l3, g3 = run(8)
+    try:
+        l1, g1 = run(7)
+        l2, g2 = run(7)
+        l3, g3 = run(8)
+    finally:
+        ops.seeds.follow_torch()          # later tests draw their masks from torch's seed again
     assert torch.isfinite(l1) and torch.equal(l1, l2) and torch.equal(g1, g2)
     assert not torch.equal(g1, g3)
     assert float(g1.abs().max()) > 0
@@ -876,3 +879,125 @@ def test_image_operand_gemm_agrees_with_fp64(M, N, K, scale):
                                                 1.0 / 0.9, None, _stream()), "bwd_h3i")
         refd = (dy.double() @ w.double()) * (h > 0).double() / 0.9 + skip.double()
         assert _rel(dx, refd) < 1e-6
+
+
+@pytest.mark.parametrize("raw", [True, False], ids=["fp32-by-dma", "image"])
+@pytest.mark.parametrize("M,N,K", [(55680, 1024, 256), (70001, 256, 256), (66000, 1024, 256), (55680, 256, 1024),
+                                   (70001, 256, 1024), (16512, 1020, 256)])
+def test_dma_gemm_streams_across_tiles(M, N, K, raw):
+    """gemm_h3i_kernel (128 x 256 tile, both operands by LDS-DMA; csrc/gemm_h3i.hip) in the regime it runs in at the BASELINE
+    batch: MORE tiles than the 512 resident workgroups, so every workgroup walks several tiles, the operand stream crosses the
+    tile boundary under the epilogue and the residual / gate operands are loaded with the next tile's k-tiles requested --
+    where round 4's ordering race lived (a few hundred wrong elements per launch, only where a workgroup has a next tile).
+    Through the C ABI, both operand forms (ttts_linear_*_h3d: fp32 rows split in place in LDS; ttts_linear_*_h3i: an image) and
+    every epilogue the training step instantiates: <res, gate, drop> = <0,0,0> (+ relu, published maxima), <1,0,0>, <1,0,1>,
+    <0,0,1>, <0,1,0>, <1,1,0>.  The WHOLE output is compared with fp64 (row chunks), a second run with the caches disturbed
+    must give the same bits, and the published maximum must be max|y| exactly.  (55 680, 256, 1024) has 435 tiles -- one per
+    workgroup: the FFN2 forward of the step as it stands; (70 001, 256, 1024) is its multi-tile neighbour; (16 512, 1020, 256)
+    has a ragged last column block.)"""
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib, dev = _lib.load(), _dev()
+    x, w, b = _rand(M, K, seed=31), _rand(N, K, seed=32, scale=K ** -0.5), _rand(N, seed=33)
+    res = _rand(M, N, seed=34)
+    xa = ops._amax(x)
+    pl = ops._planes(w, 8, N, K)
+    if not raw:
+        img, inv = torch.empty(M * K * 2, dtype=torch.int16, device=dev), torch.empty(M, device=dev)
+        _lib.check(lib.ttts_act_image(_p(x), _p(img), _p(inv), M, K, _stream()), "act_image")
+
+    def fwd(y, residual=None, act=0, p=0.0, seed=0, y_am=None):
+        if raw:
+            return lib.ttts_linear_fwd_h3d(_p(x), _p(pl), _p(b), _p(residual), _p(y), M, N, K, act, p, seed, None, _p(xa), _p(y_am), _stream())
+        return lib.ttts_linear_fwd_h3i(_p(img), _p(inv), _p(pl), _p(b), _p(residual), _p(y), M, N, K, act, p, seed, None, _p(y_am), _stream())
+
+    w64, b64 = w.double(), b.double()
+    CH = 8192
+
+    def whole(y, fn):
+        """rel-L2 of y against fn(row slice) -> fp64 reference rows, over every row of the output"""
+        num = den = 0.0
+        for r0 in range(0, M, CH):
+            sl = slice(r0, min(M, r0 + CH))
+            ref = fn(sl)
+            num += float(((y[sl].double() - ref) ** 2).sum())
+            den += float((ref ** 2).sum())
+        return (num / den) ** 0.5
+
+    def disturb():
+        torch.randn(1 << 24, device=dev)                      # 64 MB of something else through L2 / the Infinity Cache
+
+    # <0,0,0>: bias + relu, published maxima, same bits on a second run
+    y = torch.full((M, N), float("nan"), device=dev)
+    slots = torch.zeros(ops.AMAX_SLOTS, device=dev)
+    assert fwd(y, act=1, y_am=slots) == 0
+    assert torch.isfinite(y).all()
+    assert whole(y, lambda sl: torch.relu(x[sl].double() @ w64.t() + b64)) < TOL
+    assert slots.max().item() == y.abs().max().item()
+    y2 = torch.full((M, N), 3.0, device=dev)
+    disturb()
+    assert fwd(y2, act=1) == 0
+    assert torch.equal(y, y2)
+    # <1,0,0>: residual
+    assert fwd(y, residual=res) == 0
+    assert whole(y, lambda sl: x[sl].double() @ w64.t() + b64 + res[sl].double()) < TOL
+    disturb()
+    assert fwd(y2, residual=res) == 0
+    assert torch.equal(y, y2)
+    # <1,0,1> and <0,0,1>: dropout (+ residual).  Every element is either the kept value or the dropped one; the keep rate is
+    # 1 - p; the mask is a function of (seed, element) only, i.e. the one gemm_h3_kernel draws for the same seed.
+    p_drop = 0.1
+    yh = torch.empty(M, N, device=dev)
+    assert lib.ttts_linear_fwd_h3(_p(x), _p(ops._planes(w, 4, N, K)), _p(b), None, _p(yh), M, N, K, 0, p_drop, 4321, None, 0, 0,
+                                  _p(xa), None, _stream()) == 0
+    for residual in (res, None):
+        assert fwd(y, residual=residual, p=p_drop, seed=4321) == 0
+        num = den = kept_n = 0.0
+        agree = True
+        for r0 in range(0, M, CH):
+            sl = slice(r0, min(M, r0 + CH))
+            lin = x[sl].double() @ w64.t() + b64
+            add = residual[sl].double() if residual is not None else torch.zeros_like(lin)
+            d_keep = (y[sl].double() - (lin / (1 - p_drop) + add)).abs()
+            d_drop = (y[sl].double() - add).abs()
+            kept = d_keep < d_drop
+            num += float((torch.where(kept, d_keep, d_drop) ** 2).sum())
+            den += float((lin ** 2).sum())
+            kept_n += float(kept.sum())
+            sure = lin.abs() > 1e-3                                  # (a product that cancels to ~0 looks dropped either way)
+            agree = agree and bool(torch.equal(kept[sure], (yh[sl] != 0)[sure]))
+        assert (num / den) ** 0.5 < TOL and abs(kept_n / (M * N) - (1 - p_drop)) < 2e-3 and agree
+        disturb()
+        assert fwd(y2, residual=residual, p=p_drop, seed=4321) == 0
+        assert torch.equal(y, y2)
+    del yh
+    # data gradients with the same output width: dh (M x N) = dy (M x K) . Wt, Wt = weight (K, N) of a Linear N -> K:
+    # <0,1,0> the relu gate of h (FFN2's data gradient), <1,1,0> gate + skip gradient
+    dy = _rand(M, K, seed=35) * 1e-5
+    hgate = torch.relu(_rand(M, N, seed=36))
+    skip = _rand(M, N, seed=37) * 1e-5
+    wt = w.t().contiguous()                                          # (K, N)
+    plt = ops._planes(wt, 9, N, K)
+    dya = ops._amax(dy)
+    if not raw:
+        dimg, dinv = torch.empty(M * K * 2, dtype=torch.int16, device=dev), torch.empty(M, device=dev)
+        _lib.check(lib.ttts_act_image(_p(dy), _p(dimg), _p(dinv), M, K, _stream()), "act_image")
+
+    def bwd(dh, residual=None, gate=None, am=None):
+        if raw:
+            return lib.ttts_linear_bwd_data_h3d(_p(dy), _p(plt), _p(residual), _p(dh), M, K, N, _p(gate), 1.25, _p(dya), _p(am), _stream())
+        return lib.ttts_linear_bwd_data_h3i(_p(dimg), _p(dinv), _p(plt), _p(residual), _p(dh), M, K, N, _p(gate), 1.25, _p(am), _stream())
+
+    wt64 = wt.double()
+    for residual in (None, skip):
+        dslots = torch.zeros(ops.AMAX_SLOTS, device=dev)
+        assert bwd(y, residual=residual, gate=hgate, am=dslots) == 0
+
+        def ref_rows(sl):
+            r = (dy[sl].double() @ wt64) * (hgate[sl] > 0).double() * 1.25
+            return r + residual[sl].double() if residual is not None else r
+        assert whole(y, ref_rows) < TOL
+        assert dslots.max().item() == y.abs().max().item()
+        disturb()
+        assert bwd(y2, residual=residual, gate=hgate) == 0
+        assert torch.equal(y, y2)

@@ -338,3 +338,39 @@ def test_no_sgpr_hazard_in_front_of_inline_assembly_memory_instructions():
     assert len(isa_hazard_scan.scan(isa)) == 1
     isa.insert(1, "\ts_nop 4")
     assert isa_hazard_scan.scan(isa) == []
+
+
+def test_dropout_seed_stream_restarts_with_a_reseeded_module():
+    """train.py:24-28 of the reference seeds everything and then builds the module: doing that twice in one process with the
+    same seed must give the same dropout masks (the reference draws them from torch's generator, which the seed resets).  Here
+    the mask stream is `ops.seeds`; `torch.manual_seed(s)` with an unchanged s is invisible to it, so building a
+    LightningModule re-arms the stream.  An explicit `manual_seed` pins it until `follow_torch()`."""
+    from transformertts_amd import ops
+    from transformertts_amd.lightning_module import LightningModule
+    from transformertts_amd.workload import model_config
+    cfg = model_config("tiny")
+    config = {"model": dict(cfg, device="cpu"), "loss": {"stop_weight": 8.0},
+              "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000}}
+    s = ops.seeds
+    saved = (s.base, s.counter, s.explicit, s._derived_from)
+    try:
+        s.follow_torch()
+        draws = []
+        for seed in (5, 5, 6):
+            torch.manual_seed(seed)
+            LightningModule(config)
+            s.ensure_seeded()
+            draws.append([s.next() for _ in range(3)])
+            s.ensure_seeded()                          # a later step of the same module continues the stream
+            assert s.counter == 3
+        assert draws[0] == draws[1] and draws[0] != draws[2]
+        s.manual_seed(99)
+        a = [s.next() for _ in range(2)]
+        torch.manual_seed(5)
+        LightningModule(config)
+        s.ensure_seeded()                              # explicit: neither torch's seed nor a new module moves it
+        assert s.counter == 2
+        s.manual_seed(99)
+        assert [s.next() for _ in range(2)] == a
+    finally:
+        s.base, s.counter, s.explicit, s._derived_from = saved

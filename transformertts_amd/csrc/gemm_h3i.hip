@@ -262,11 +262,9 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         // ---------------- epilogue: each 32 x 32 accumulator block is scaled by its lane's row factor, turned through a 4 KB slab
-        // (row-major, 16-byte chunk ^= row & 7: conflict-free both ways) and leaves as whole 128-byte lines.
-        // vmcnt is ONE in-order counter for loads and stores: a block's auxiliary operands (residual, relu gate) are requested
-        // BEFORE the previous block's stores, so the wait in front of their first use counts those stores as younger and does not
-        // wait for them (a first version requested them behind the stores: every block then waited a full store round trip,
-        // 16.5k of a tile's 42k cycles); the variants without auxiliary operands issue no load at all.
+        // (row-major, 16-byte chunk ^= row & 7: conflict-free both ways) and leaves as whole 128-byte lines.  A block's auxiliary
+        // operands (residual, relu gate) are requested BEHIND the previous block's stores and waited for with everything older
+        // (see the note at the loads); the variants without auxiliary operands issue no load at all.
         {
             float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + ep_stage * I_STAGE) + wave * 1024;
             const int rsub = lane >> 3, ch = lane & 7;

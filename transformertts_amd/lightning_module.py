@@ -50,6 +50,8 @@ class LightningModule(_Base):
         # dropout / scheduled-sampling draws follow torch's process seed folded with the data-parallel rank (the reference
         # draws them from torch's global generator; replicas there differ because their generators advance differently).
         # Derived at the first training_step, not here: Lightning constructs the module before torch.distributed exists.
+        from . import ops
+        ops.seeds.rearm()          # a module built after a (re-)seed starts its mask stream from the beginning
 
     def forward(self, phoneme, melspec, phoneme_lens, melspec_lens, **kwargs):
         return self.model(phoneme, melspec, phoneme_lens, melspec_lens, **kwargs)

@@ -83,6 +83,17 @@ class _SeedStream:
         if self._derived_from != (torch.initial_seed(), int(rank)):
             self.seed_from_torch(rank)
 
+    def rearm(self) -> None:
+        """A new LightningModule was built (train.py:24-28: seed_everything, then the module): the next `ensure_seeded` derives
+        the base again and restarts the counter, so seeding the same value twice in one process reproduces the same masks --
+        `torch.manual_seed(s)` with an unchanged s is otherwise invisible from here.  No effect after `manual_seed()`."""
+        self._derived_from = None
+
+    def follow_torch(self) -> None:
+        """undo `manual_seed()`: the stream follows torch's process seed again (tests that seed explicitly call this on exit)"""
+        self.explicit = False
+        self._derived_from = None
+
     def next(self) -> int:
         self.counter += 1
         return ((self.base * 0x9E3779B97F4A7C15) ^ (self.counter * 0xD1B54A32D192ED03)) & 0xFFFFFFFFFFFFFFFF
@@ -620,6 +631,12 @@ def _dma_dims(red: int, out: int) -> bool:
     return DMA_GEMMS and red % 32 == 0 and out % 4 == 0 and ((red <= 256 and out >= 512) or (red == out and out in (256, 512)))
 
 
+def _image_dims(red: int, out: int) -> bool:
+    """could `_image_shape_ok` say yes for SOME row count while producers leave images (LAYERNORM_IMAGES)?  Same reason as
+    `_dma_dims`: the k16 weight image must exist before a capture that lands on the other side of IMAGE_MIN_ROWS."""
+    return LAYERNORM_IMAGES and red % 32 == 0 and red >= 32 and out >= 128 and out % 4 == 0
+
+
 def _both_images(w: torch.Tensor, used: int, other: int, rows: int, cols: int) -> torch.Tensor:
     """planes of `w` in mode `used`; outside a capture also make sure its sibling image (`other`) exists"""
     if not torch.cuda.is_current_stream_capturing():
@@ -656,12 +673,12 @@ class LinearFn(torch.autograd.Function):
         if r_ is not None and r_.shape != y.shape:
             raise ValueError("linear: residual shape mismatch")
         if x_image is not None and _fwd_h3(K, N) and row_shift == 0:
-            _lib.check(lib.ttts_linear_fwd_h3i(_p(x_image[0]), _p(x_image[1]), _p(_planes(w, 8, N, K)), _p(b_), _p(r_), _p(y), M, N, K,
+            _lib.check(lib.ttts_linear_fwd_h3i(_p(x_image[0]), _p(x_image[1]), _p(_both_images(w, 8, 4, N, K)), _p(b_), _p(r_), _p(y), M, N, K,
                                                act, float(drop_p), seed, _ss(), _p(y_amax), _stream()), "ttts_linear_fwd_h3i")
         elif _fwd_h3(K, N):
             if x_amax is None:
                 x_amax = _amax(x)
-            both = row_shift == 0 and _dma_dims(K, N)
+            both = row_shift == 0 and (_dma_dims(K, N) or _image_dims(K, N))
             if row_shift == 0 and _dma_shape_ok(M, K, N, False):
                 _lib.check(lib.ttts_linear_fwd_h3d(_p(x), _p(_both_images(w, 8, 4, N, K) if both else _planes(w, 8, N, K)), _p(b_), _p(r_),
                                                    _p(y), M, N, K, act,
@@ -742,12 +759,12 @@ class LinearFn(torch.autograd.Function):
                 # maxima on it
                 dx_am = _amax_slots(dx.device, True) if (tok_in is not None or ctx.sole_consumer) else None
                 if dacc_image is not None and _image_shape_ok(M, N, K):
-                    _lib.check(lib.ttts_linear_bwd_data_h3i(_p(dacc_image[0]), _p(dacc_image[1]), _p(_planes(w, 9, K, N)), _p(skip),
+                    _lib.check(lib.ttts_linear_bwd_data_h3i(_p(dacc_image[0]), _p(dacc_image[1]), _p(_both_images(w, 9, 5, K, N)), _p(skip),
                                                             _p(dx), M, N, K, _p(gate), gscale, _p(dx_am), _stream()),
                                "ttts_linear_bwd_data_h3i")
                 else:
                     am = am if am is not None else _amax(dacc)
-                    both = _dma_dims(N, K)
+                    both = _dma_dims(N, K) or _image_dims(N, K)
                     if _dma_shape_ok(M, N, K, gate is not None) and not (gate is not None and skip is not None):
                         _lib.check(lib.ttts_linear_bwd_data_h3d(_p(dacc), _p(_both_images(w, 9, 5, K, N) if both else _planes(w, 9, K, N)),
                                                                 _p(skip), _p(dx), M, N, K,
