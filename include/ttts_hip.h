@@ -188,6 +188,21 @@ int ttts_linear_fwd_h3d(const float* x, const void* w_planes, const float* bias,
 int ttts_linear_bwd_data_h3d(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
                              int K, const float* relu_out, float relu_scale, const float* dy_amax, float* dx_amax_out,
                              void* stream);
+/* ---- HEAD-IMAGE outputs (ABI v11; gemm_h3i.hip, attention_img.hip).  The output of an attention in-projection (the packed
+ * q/k/v of torch `_sa_block` / F.multi_head_attention_forward, torch/nn/functional.py:6206+, or the q and k/v row slices of
+ * model/layers.py:54-74) is read by nothing but the attention kernels, which form every product from f16 hi / lo pieces.  So the
+ * in-projection writes it in that form INSTEAD of fp32: y_image has the geometry of the fp32 output (M rows of N 4-byte cells),
+ * and the 256 bytes of (row, 64-column head) hold {64 f16 hi, 64 f16 lo} of (x W^T + b) * 2^e(row, head) with the power of
+ * two that puts the head row's maximum in [2^11, 2^12); y_row_inv[head * M + row] = 2^-e.  The attention kernels stage K / V
+ * tiles of it by LDS-DMA (no split arithmetic, two tiles deep).  y_amax_out: NULL, or N / amax_section_cols caller-zeroed
+ * TTTS_AMAX_SLOTS-float arrays (one per section of amax_section_cols columns: q / k / v) receiving max|y| of the section
+ * (amax_section_cols = 0: one array).  K % 32 == 0, N % 64 == 0, bias-only epilogue; weight planes = mode 8. */
+int ttts_linear_fwd_h3d_img(const float* x, const void* w_planes, const float* bias, void* y_image, float* y_row_inv,
+                            int64_t M, int N, int K, const float* x_amax, float* y_amax_out, int amax_section_cols,
+                            void* stream);
+/* the stand-alone conversion: fp32 rows (row stride ld_x floats) -> head image (row stride ld_image cells) + inverse scales
+ * [N / 64][M] (tests; operands no GEMM of this library produced) */
+int ttts_head_image(const float* x, int64_t ld_x, void* image, int64_t ld_image, float* row_inv, int64_t M, int N, void* stream);
 int ttts_conv1d_bwd_data_h3(const float* dy, const void* planes_bwd, float* dx, int B, int T, int cin, int cout, int taps,
                             const float* dy_amax, void* stream);
 int ttts_linear_bwd_data_x6(const float* dy, const void* wt_planes, const float* residual, float* dx, int64_t M, int N,
@@ -332,6 +347,25 @@ int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const 
                           int causal, float q_scale, float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
                           float* dq_amax_out, float* dkv_amax_out, const float* q_amax, const float* k_amax,
                           const float* v_amax, const float* rowstat /* of the h3 forward, or NULL: use lse */, void* stream);
+/* ---- attention on head-image operands (ABI v11; attention_img.hip): the same call sites as ttts_attention_fwd_h3 /
+ * ttts_attention_bwd_h3 (encoder self-attention and decoder `_sa_block`, torch/nn/modules/transformer.py:961-978,1158-1175 ->
+ * torch/nn/functional.py:6629; the decoder's `_mha_block`, model/layers.py:54-74), head_dim 64.  q / k / v point at head 0 of
+ * their section inside a head image (row strides ld* in 4-byte cells; a packed q/k/v image is passed as three pointers d cells
+ * apart), *_inv at the [head][rows] inverse scales of that section (B * Tq rows per head plane on the q side, B * Tk on the key
+ * side), v_amax at the TTTS_AMAX_SLOTS partial maxima of |v| (the section array ttts_linear_fwd_h3d_img filled).  o, lse, attn,
+ * o_amax_out as ttts_attention_fwd_h3.  rowstat_out: (5, B, H, Tq) floats -- the three planes of ttts_attention_fwd_h3 plus
+ * the query row's exponent multiplier 2^-e_q * q_scale * log2(e) and score multiplier 2^-e_q * q_scale; the backward
+ * requires it (it forms the forward's own probabilities from bit-identical accumulators). */
+int ttts_attention_fwd_img(const void* q, const void* k, const void* v, const float* q_inv, const float* k_inv,
+                           const float* v_inv, float* o, float* lse, float* attn, const int64_t* key_lens, int B, int H, int Tq,
+                           int Tk, int ldq, int ldk, int ldv, int ldo, int causal, float q_scale, float drop_p, uint64_t seed,
+                           const uint64_t* step_seed, const float* v_amax, float* o_amax_out, float* rowstat_out, void* stream);
+/* dq, dk, dv in fp32 (strides ldd*) from d_o; o / d_o fp32; do_amax = partial maxima of |d_o|; delta (B,H,Tq) is scratch */
+int ttts_attention_bwd_img(const void* q, const void* k, const void* v, const float* q_inv, const float* k_inv,
+                           const float* v_inv, const float* o, const float* d_o, const float* rowstat, float* delta, float* dq,
+                           float* dk, float* dv, const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv,
+                           int ldo, int lddq, int lddk, int lddv, int causal, float q_scale, float drop_p, uint64_t seed,
+                           const uint64_t* step_seed, const float* do_amax, float* dq_amax_out, float* dkv_amax_out, void* stream);
 
 /* ------------------------------------------------------------------ small row / element-wise pieces
  * nn.Embedding gather / scatter-add (model/model.py:168,288; no padding_idx) */

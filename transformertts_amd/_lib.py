@@ -44,6 +44,8 @@ SIGNATURES = {
     "ttts_linear_bwd_data_h3i": (I, [P, P, P, P, P, L, I, I, P, F, P, P]),
     "ttts_linear_fwd_h3d": (I, [P, P, P, P, P, L, I, I, I, F, U, P, P, P, P]),
     "ttts_linear_bwd_data_h3d": (I, [P, P, P, P, L, I, I, P, F, P, P, P]),
+    "ttts_linear_fwd_h3d_img": (I, [P, P, P, P, P, L, I, I, P, P, I, P]),
+    "ttts_head_image": (I, [P, L, P, L, P, L, I, P]),
     "ttts_conv1d_bwd_data_h3": (I, [P, P, P, I, I, I, I, I, P, P]),
     "ttts_linear_bwd_data_x6": (I, [P, P, P, P, L, I, I, P, F, P]),
     "ttts_conv1d_fwd_x6": (I, [P, P, P, P, I, I, I, I, I, P]),
@@ -72,6 +74,9 @@ SIGNATURES = {
     "ttts_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, P]),
     "ttts_attention_bwd_x6": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, P]),
     "ttts_attention_bwd_h3": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, P, P, P, P, P, P, P, P]),
+    "ttts_attention_fwd_img": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U, P, P, P, P, P]),
+    "ttts_attention_bwd_img": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, P, P, P,
+                                   P]),
     "ttts_heads_pad": (I, [P, L, P, L, I, I, P]),
     "ttts_heads_unpad": (I, [P, P, L, L, I, I, P]),
     "ttts_embedding_fwd": (I, [P, P, P, L, I, I, P, P]),

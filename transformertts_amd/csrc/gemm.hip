@@ -937,7 +937,7 @@ static GemmArgs base_args() {
     g.residual = nullptr; g.ldr = 0; g.colsum = nullptr; g.a_bytes = 0; g.b_bytes = 0;
     g.relu_out = nullptr; g.relu_scale = 1.f;
     g.a_amax = nullptr; g.a_amax_n = 0; g.b_amax = nullptr; g.b_amax_n = 0; g.c_amax = nullptr; g.bn_ws = nullptr;
-    g.a_row_inv = nullptr;
+    g.a_row_inv = nullptr; g.c_row_inv = nullptr; g.c_amax_sec = 0;
     return g;
 }
 

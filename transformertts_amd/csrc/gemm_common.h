@@ -56,6 +56,12 @@ struct GemmArgs {
     // image-operand kernel (gemm_h3i.hip) only: A is an activation IMAGE (rows of K/16 groups {16 f16 hi, 16 f16 lo} of
     // x * 2^e_row) and a_row_inv[row] = 2^-e_row, the factor its output row is scaled back by; NULL for every other kernel
     const float* a_row_inv;
+    // image-operand kernel only, HEAD-IMAGE output (ttts_linear_fwd_h3d_img): C is not fp32 but, per row and 64-column head group,
+    // {64 f16 hi, 64 f16 lo} of (x W^T + b) * 2^e(row, group) at the byte offset the fp32 columns would have (row stride ldc * 4
+    // bytes), with a per-(row, group) power of two that puts the group's maximum in [2^11, 2^12); c_row_inv[group * M + row] =
+    // 2^-e.  c_amax then is an array of N / c_amax_sec partial-maxima arrays, one per section of c_amax_sec columns (q / k / v).
+    float* c_row_inv;
+    int c_amax_sec;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

@@ -70,7 +70,10 @@ __device__ unsigned long long ttts_h3i_stamps[512 * 4 * 8];
 // landed (two 16-byte reads per lane, the split, two 16-byte writes: the raw row and its {hi, lo} planes are the same 64 bytes),
 // in front of the k-tile's barrier.  ~1.3 VALU instructions per MFMA instead of the 3.5 of gemm_h3's loader, no staging
 // registers, and everything global still moves by LDS-DMA, so the counted waits stay within one completion order.
-template <bool A_RAW, bool HAS_RES, bool HAS_GATE, bool DROP>
+// IMG: the output leaves as a HEAD IMAGE (GemmArgs::c_row_inv): attention is the only reader of an in-projection's output, and it
+// wants f16 hi / lo planes it can stage by LDS-DMA -- the same 4 bytes per element as fp32, written here instead of fp32, with a
+// power-of-two scale per (row, 64-column head) because the tile owns whole head rows (bias only; no residual / gate / dropout).
+template <bool A_RAW, bool HAS_RES, bool HAS_GATE, bool DROP, bool IMG = false>
 __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
 #ifdef TTTS_H3I_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -304,7 +307,102 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
                 idx0[j] = (uint64_t)row_l * (uint64_t)g.N + (uint64_t)col;
             }
             const uint32_t row_step = (uint32_t)g.ldc * 4u;
-            {
+            if constexpr (IMG) {
+                // lane -> (row r16 of a 16-row pass, 8-column group c8 of a 32-column block): after the slab turn a lane holds
+                // 8 consecutive columns of its row in each of the head's two blocks, so the row's maximum over the head is the
+                // lane's 16 values and two quad-permute steps, and each plane leaves in 16-byte pieces (4 lanes = 64 bytes of
+                // a head's 128-byte plane row)
+                const int r16 = lane >> 2, c8 = lane & 3;
+                const __amdgpu_buffer_rsrc_t rsrcI = __builtin_amdgcn_make_buffer_rsrc(g.c_row_inv, 0, (uint32_t)((long)(g.N / 64) * g.M * 4), 0x00020000);
+                // the wave's 128 bias values wait in LDS (behind the four slabs of the stage): 32 registers less than holding them
+                float* bias_s = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + ep_stage * I_STAGE + 16384) + wave * 128;
+                if (lane < 32) {
+                    const int col = n0 + wn * 128 + lane * 4;
+                    *reinterpret_cast<float4*>(bias_s + lane * 4) = buf_load4(rsrcBias, col < g.N ? (uint32_t)col * 4u : OOB);
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+                const int row_i = m0 + wm * 64 + r16;                    // this lane's row in pass 0 of row block 0
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int hcol = n0 + wn * 128 + g2 * 64;        // first column of this head (wave-uniform)
+                        float v[2][2][8];
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = 2 * g2 + jj;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                *reinterpret_cast<float4*>(slab + l31 * 32 + (((2 * q + half) ^ (l31 & 7)) * 4)) =
+                                    make_float4(acc[i][j][4 * q] * rs[i], acc[i][j][4 * q + 1] * rs[i], acc[i][j][4 * q + 2] * rs[i],
+                                                acc[i][j][4 * q + 3] * rs[i]);
+                            __builtin_amdgcn_wave_barrier();
+                            asm volatile("" ::: "memory");
+                            const float4 b0 = *reinterpret_cast<const float4*>(bias_s + j * 32 + c8 * 8);
+                            const float4 b1 = *reinterpret_cast<const float4*>(bias_s + j * 32 + c8 * 8 + 4);
+#pragma unroll
+                            for (int ps = 0; ps < 2; ++ps) {
+                                const int srow = ps * 16 + r16;
+                                const float4 a0 = *reinterpret_cast<const float4*>(slab + srow * 32 + (((2 * c8) ^ (srow & 7)) * 4));
+                                const float4 a1 = *reinterpret_cast<const float4*>(slab + srow * 32 + (((2 * c8 + 1) ^ (srow & 7)) * 4));
+                                v[jj][ps][0] = a0.x + b0.x; v[jj][ps][1] = a0.y + b0.y; v[jj][ps][2] = a0.z + b0.z; v[jj][ps][3] = a0.w + b0.w;
+                                v[jj][ps][4] = a1.x + b1.x; v[jj][ps][5] = a1.y + b1.y; v[jj][ps][6] = a1.z + b1.z; v[jj][ps][7] = a1.w + b1.w;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            asm volatile("" ::: "memory");
+                        }
+                        float hmax = 0.f;                                 // max|y| over this wave's part of the head's section
+#pragma unroll
+                        for (int ps = 0; ps < 2; ++ps) {
+                            float m = 0.f;
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[jj][ps][e]));
+                            m = fmaxf(m, __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(m), 0xB1, 0xF, 0xF, true)));   // lane ^ 1
+                            m = fmaxf(m, __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(m), 0x4E, 0xF, 0xF, true)));   // lane ^ 2
+                            float sc, inv;
+                            h3_pow2_scale(m, sc, inv);
+                            const int row = row_i + i * 32 + ps * 16;
+                            const bool live = row < g.M && hcol < g.N;
+                            hmax = live ? fmaxf(hmax, m) : hmax;
+                            const uint32_t soff = (uint32_t)(i * 32 + ps * 16) * row_step;
+                            const uint32_t loff = live ? (uint32_t)(((long)(m0 + wm * 64 + r16) * g.ldc + hcol) * 4) + (uint32_t)c8 * 16u : OOB;
+                            u32x4 hi[2], lo[2];
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj) {
+                                uint32_t hh, ll;
+                                split2_pair(f32x2{v[jj][ps][0], v[jj][ps][1]} * sc, hh, ll); hi[jj].x = hh; lo[jj].x = ll;
+                                split2_pair(f32x2{v[jj][ps][2], v[jj][ps][3]} * sc, hh, ll); hi[jj].y = hh; lo[jj].y = ll;
+                                split2_pair(f32x2{v[jj][ps][4], v[jj][ps][5]} * sc, hh, ll); hi[jj].z = hh; lo[jj].z = ll;
+                                split2_pair(f32x2{v[jj][ps][6], v[jj][ps][7]} * sc, hh, ll); hi[jj].w = hh; lo[jj].w = ll;
+                            }
+                            // (a live row's offset stays inside the descriptor: no row test; dead rows / heads carry OOB)
+                            const uint32_t so = live ? loff : OOB;
+                            __builtin_amdgcn_raw_buffer_store_b128(hi[0], rsrcC, (int)so, (int)soff, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(hi[1], rsrcC, (int)(live ? loff + 64u : OOB), (int)soff, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(lo[0], rsrcC, (int)(live ? loff + 128u : OOB), (int)soff, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(lo[1], rsrcC, (int)(live ? loff + 192u : OOB), (int)soff, 0);
+                            // The data registers of these stores are recycled by the next row's packed multiplies.  A
+                            // `buffer_store_dwordx4` reads its data some cycles after it issues: with the two VALU instructions hipcc
+                            // leaves between a store and the `v_pk_mul_f32` that overwrites its registers, the second dword of ~0.15 %
+                            // of the stores came out as the PRODUCT (tools/micro/store_war.hip: 5 % with one instruction between,
+                            // none seen from two on in isolation -- here, with LDS reads in flight, two were not enough).  The
+                            // statement keeps all four registers live and untouched for eight more states behind the last store.
+                            asm volatile("s_nop 7" :: "v"(hi[0]), "v"(hi[1]), "v"(lo[0]), "v"(lo[1]) : "memory");
+                            if (c8 == 0)
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(inv), rsrcI,
+                                                                     (int)(live ? (uint32_t)(((long)(hcol >> 6) * g.M + row) * 4) : OOB), 0, 0);
+                        }
+                        if (want_max) {
+                            const int sec = g.c_amax_sec > 0 ? hcol / g.c_amax_sec : 0;
+                            amax_publish(hmax, g.c_amax + (long)sec * TTTS_AMAX_SLOTS, bid);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
                 const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float*>(HAS_RES ? g.residual : g.A), 0, HAS_RES ? (uint32_t)((long)g.M * g.ldr * 4) : 0u, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc(
@@ -380,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
                     }
                 }
             }
-            if (want_max) amax_publish(cmax, g.c_amax, bid);
+            if (!IMG && want_max) amax_publish(cmax, g.c_amax, bid);
         }
         after_ep = true;
         IACC(3, ISTAMP() - s3); IACC(5, 1);
@@ -415,6 +513,16 @@ int dispatch_h3i(const GemmArgs& g, hipStream_t stream) {
     if (gsz > 512) gsz = 512;
     dim3 grid((unsigned)(ntiles < 512 ? ntiles : gsz), 1, 1);
     const bool res = g.residual != nullptr, gate = g.relu_out != nullptr, drop = g.drop_thr != 0u;
+    if (g.c_row_inv != nullptr) {
+        if (res || gate || drop || g.act != 0 || g.N % 64 != 0) {
+            set_error("fp16x3 GEMM (head-image output): bias-only epilogue and N %% 64 == 0 required (N=%d)", g.N);
+            return TTTS_ERR_INVALID;
+        }
+        if (g.a_row_inv != nullptr) hipLaunchKernelGGL((gemm_h3i_kernel<false, false, false, false, true>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_h3i_kernel<true, false, false, false, true>), grid, dim3(256), 0, stream, g);
+        TTTS_LAUNCH_CHECK("gemm_h3i_kernel<img>");
+        return TTTS_OK;
+    }
     if (gate && drop) {
         set_error("fp16x3 GEMM (image operand): a relu gate (data gradient) cannot be combined with dropout");
         return TTTS_ERR_INVALID;
@@ -450,6 +558,36 @@ __global__ __launch_bounds__(256) void act_image_kernel(const float* __restrict_
     image_emit_row<NV>(v, lane, row, M, K, img, row_inv);
 }
 
+// fp32 (M rows x N columns, row stride ld floats) -> HEAD IMAGE in `img` (same row stride, in 4-byte units) + per-(row, head)
+// inverse scales: the stand-alone form of the IMG epilogue (tests; operands that no GEMM of ours produced).  One wave per row
+// and pass of four heads; 16 lanes hold a head.
+__global__ __launch_bounds__(256) void head_image_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ img,
+                                                         long ldi, float* __restrict__ row_inv, long M, int N) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    for (int c0 = 0; c0 < N; c0 += 256) {
+        const int col = c0 + lane * 4;
+        const bool ok = col < N;
+        const float4 v = ok ? *reinterpret_cast<const float4*>(x + row * ldx + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float sc, inv;
+        h3_pow2_scale(m, sc, inv);
+        if (ok) {
+            uint2 hi, lo;
+            split2_pair(f32x2{v.x, v.y} * sc, hi.x, lo.x);
+            split2_pair(f32x2{v.z, v.w} * sc, hi.y, lo.y);
+            const int g64 = col >> 6, d = col & 63;
+            unsigned short* p = img + (row * ldi + g64 * 64) * 2 + d;
+            *reinterpret_cast<uint2*>(p) = hi;
+            *reinterpret_cast<uint2*>(p + 64) = lo;
+            if ((lane & 15) == 0) row_inv[(long)g64 * M + row] = inv;
+        }
+    }
+}
+
 static GemmArgs h3i_base_args() {
     GemmArgs g;
     g.A = g.B = nullptr; g.C = nullptr;
@@ -460,7 +598,7 @@ static GemmArgs h3i_base_args() {
     g.residual = nullptr; g.ldr = 0; g.colsum = nullptr; g.a_bytes = 0; g.b_bytes = 0;
     g.relu_out = nullptr; g.relu_scale = 1.f;
     g.a_amax = nullptr; g.a_amax_n = 0; g.b_amax = nullptr; g.b_amax_n = 0; g.c_amax = nullptr; g.bn_ws = nullptr;
-    g.a_row_inv = nullptr;
+    g.a_row_inv = nullptr; g.c_row_inv = nullptr; g.c_amax_sec = 0;
     return g;
 }
 
@@ -577,4 +715,45 @@ extern "C" int ttts_linear_bwd_data_h3d(const float* dy, const void* wt_planes, 
     g.b_amax = h3_plane_tail(wt_planes, K, N); g.b_amax_n = 1;
     g.c_amax = dx_amax_out;
     return dispatch_h3i(g, (hipStream_t)stream);
+}
+
+/* The in-projections of nn.MultiheadAttention (packed q/k/v, or its q and k/v row slices: torch/nn/functional.py:6206+ reached
+ * from model/layers.py:54-74 and torch _sa_block) with a HEAD-IMAGE output: y_image has the geometry of the fp32 output (M rows of
+ * N 4-byte cells) but holds, per row and 64-column head, {64 f16 hi, 64 f16 lo} of (x W^T + b) * 2^e(row, head);
+ * y_row_inv[head * M + row] = 2^-e.  y_amax_out: NULL, or N / amax_section_cols caller-zeroed TTTS_AMAX_SLOTS-float arrays (one per
+ * section: q / k / v), each receiving max|y| of its section. */
+extern "C" int ttts_linear_fwd_h3d_img(const float* x, const void* w_planes, const float* bias, void* y_image, float* y_row_inv,
+                                       int64_t M, int N, int K, const float* x_amax, float* y_amax_out, int amax_section_cols,
+                                       void* stream) {
+    TTTS_REQUIRE(x && w_planes && y_image && y_row_inv && x_amax, "linear_fwd_h3d_img: null pointer");
+    TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear_fwd_h3d_img: bad dims");
+    TTTS_REQUIRE(K % 32 == 0 && N % 64 == 0, "linear_fwd_h3d_img: K=%d must be a multiple of 32 and N=%d of 64", K, N);
+    TTTS_REQUIRE(al16(x) && al16(w_planes) && al16(y_image), "linear_fwd_h3d_img: pointers must be 16-byte aligned");
+    TTTS_REQUIRE(amax_section_cols >= 0 && (amax_section_cols == 0 || (amax_section_cols % 64 == 0 && N % amax_section_cols == 0)),
+                 "linear_fwd_h3d_img: amax sections must be whole heads that divide N");
+    TTTS_REQUIRE((uint64_t)M * K * 4 < (1ull << 32) && (uint64_t)N * K * 4 < (1ull << 32), "linear_fwd_h3d_img: operand larger than 4 GiB");
+    GemmArgs g = h3i_base_args();
+    g.A = x; g.B = (const float*)w_planes; g.C = (float*)y_image; g.M = (int)M; g.N = N; g.K = K;
+    g.lda = K; g.ldb = K; g.ldc = N;
+    g.a_bytes = (uint32_t)((uint64_t)M * K * 4); g.b_bytes = (uint32_t)((uint64_t)N * K * 4);
+    g.cin = K;
+    g.bias = bias;
+    g.a_amax = x_amax; g.a_amax_n = H3_AMAX_PARTIALS;
+    g.b_amax = h3_plane_tail(w_planes, N, K); g.b_amax_n = 1;
+    g.c_amax = y_amax_out; g.c_amax_sec = amax_section_cols;
+    g.c_row_inv = y_row_inv;
+    return dispatch_h3i(g, (hipStream_t)stream);
+}
+
+/* fp32 rows (row stride ld_x floats) -> head image (row stride ld_image 4-byte cells) + inverse scales [N / 64][M] */
+extern "C" int ttts_head_image(const float* x, int64_t ld_x, void* image, int64_t ld_image, float* row_inv, int64_t M, int N,
+                               void* stream) {
+    TTTS_REQUIRE(x && image && row_inv, "head_image: null pointer");
+    TTTS_REQUIRE(M > 0 && N > 0 && N % 64 == 0 && ld_x >= N && ld_image >= N && ld_x % 4 == 0 && ld_image % 4 == 0,
+                 "head_image: N=%d must be a multiple of 64 and the row strides multiples of 4 that cover it", N);
+    TTTS_REQUIRE(al16(x) && al16(image), "head_image: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(head_image_kernel, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ld_x,
+                       (unsigned short*)image, (long)ld_image, row_inv, (long)M, N);
+    TTTS_LAUNCH_CHECK("head_image_kernel");
+    return TTTS_OK;
 }

@@ -51,7 +51,10 @@ class MultiheadAttention(nn.Module):
     def self_attention(self, x: Tensor, lens: Tensor, causal: bool, residual: Tensor, out_drop: float) -> Tensor:
         """residual + drop(out_proj(attention(in_proj(x))))"""
         skip = ops.SkipToken() if residual is x else None      # the skip gradient rides in the in-projection's epilogue
-        qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias, skip_in=skip, publish_amax=True)
+        # 64-column heads: q / k / v leave the in-projection as a head image (f16 hi / lo pieces with per-(row, head) scales in the
+        # cells fp32 would occupy) and attention stages them by LDS-DMA; narrower heads take the fp32 path through padded copies
+        img = 3 if ops.head_image_ok(x, self.in_proj_weight, self.num_heads, 3) else 0
+        qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias, skip_in=skip, publish_amax=not img, head_image_sections=img)
         p = self._p()
         ctx = ops.self_attention(qkv, lens, self.num_heads, causal, p, ops.seeds.next() if p > 0 else 0)
         ctx._ttts_sole_consumer = True      # only the out-projection below reads it (see LinearFn.forward)
@@ -62,10 +65,12 @@ class MultiheadAttention(nn.Module):
                         need_weights: bool = True):
         d = self.embed_dim
         skip = ops.SkipToken() if residual is x else None
-        q = ops.linear(x, ops.param_rows(self.in_proj_weight, 0, d), ops.param_rows(self.in_proj_bias, 0, d), skip_in=skip,
-                       publish_amax=True)
-        kv = ops.linear(mem, ops.param_rows(self.in_proj_weight, d, 3 * d), ops.param_rows(self.in_proj_bias, d, 3 * d),
-                        publish_amax=True)
+        wq, wkv = ops.param_rows(self.in_proj_weight, 0, d), ops.param_rows(self.in_proj_weight, d, 3 * d)
+        img = ops.head_image_ok(x, wq, self.num_heads, 1) and ops.head_image_ok(mem, wkv, self.num_heads, 2)
+        q = ops.linear(x, wq, ops.param_rows(self.in_proj_bias, 0, d), skip_in=skip, publish_amax=not img,
+                       head_image_sections=1 if img else 0)
+        kv = ops.linear(mem, wkv, ops.param_rows(self.in_proj_bias, d, 3 * d), publish_amax=not img,
+                        head_image_sections=2 if img else 0)
         p = self._p()
         ctx, attn = ops.cross_attention(q, kv, mem_lens, self.num_heads, p, ops.seeds.next() if p > 0 else 0, need_weights)
         ctx._ttts_sole_consumer = True

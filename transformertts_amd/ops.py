@@ -244,11 +244,12 @@ class _AmaxArena:
         _lib.check(_lib.load().ttts_zero(_p(self.buf), self.buf.numel() * 4, _stream()), "ttts_zero")
         self.next, self.clean = 0, True
 
-    def take(self):
-        if not self.clean or self.next >= self.SLICES:
+    def take(self, n: int = 1):
+        """one zeroed slice, or (n > 1) n consecutive ones as an (n, AMAX_SLOTS) view"""
+        if not self.clean or self.next + n > self.SLICES:
             return None
-        self.next += 1
-        return self.buf[self.next - 1]
+        self.next += n
+        return self.buf[self.next - 1] if n == 1 else self.buf[self.next - n:self.next]
 
 
 _amax_arenas = {}
@@ -281,6 +282,17 @@ def _amax_slots(device, zero: bool) -> torch.Tensor:
     a = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=device)
     if zero:
         _lib.check(_lib.load().ttts_zero(_p(a), AMAX_SLOTS * 4, _stream()), "ttts_zero")
+    return a
+
+
+def _amax_slots_n(device, n: int) -> torch.Tensor:
+    """(n, AMAX_SLOTS) zeroed partial-maxima arrays, contiguous (the section maxima of a head-image output)"""
+    arena = _amax_arenas.get(device)
+    got = arena.take(n) if arena is not None else None
+    if got is not None:
+        return got.view(n, AMAX_SLOTS)
+    a = torch.empty(n, AMAX_SLOTS, dtype=torch.float32, device=device)
+    _lib.check(_lib.load().ttts_zero(_p(a), a.numel() * 4, _stream()), "ttts_zero")
     return a
 
 
@@ -654,7 +666,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out=None, tok_in=None, skip_in=None,
-                skip_out=None, tok_drop=None, x_amax=None, y_amax=None, x_image=None):
+                skip_out=None, tok_drop=None, x_amax=None, y_amax=None, x_image=None, y_himg=None):
         """x_amax: partial maxima of |x| (fp16x3 forms; None: measured here); y_amax: None, or a zeroed AMAX_SLOTS-slot array
         that receives max|y| (the wrapper attaches it to y for the next fp16x3 consumer); x_image: None, or (image, row_inv) of
         x left by its producer -- the GEMM then takes the image-operand kernel (ttts_linear_fwd_h3i)."""
@@ -672,7 +684,16 @@ class LinearFn(torch.autograd.Function):
         r_ = _chk(residual, "linear.residual") if residual is not None else None
         if r_ is not None and r_.shape != y.shape:
             raise ValueError("linear: residual shape mismatch")
-        if x_image is not None and _fwd_h3(K, N) and row_shift == 0:
+        if y_himg is not None:
+            # the output leaves as a HEAD IMAGE (attention in-projections: ttts_linear_fwd_h3d_img); y_himg = (row_inv, section maxima,
+            # columns per section).  `y` keeps its fp32 geometry and dtype, but its cells hold f16 hi / lo pairs: only the attention
+            # kernels may read it (ops.self_attention / cross_attention look for `_ttts_himg`).
+            if x_amax is None:
+                x_amax = _amax(x)
+            row_inv, sec_amax, sec_cols = y_himg
+            _lib.check(lib.ttts_linear_fwd_h3d_img(_p(x), _p(_both_images(w, 8, 4, N, K)), _p(b_), _p(y), _p(row_inv), M, N, K, _p(x_amax),
+                                                   _p(sec_amax), sec_cols, _stream()), "ttts_linear_fwd_h3d_img")
+        elif x_image is not None and _fwd_h3(K, N) and row_shift == 0:
             _lib.check(lib.ttts_linear_fwd_h3i(_p(x_image[0]), _p(x_image[1]), _p(_both_images(w, 8, 4, N, K)), _p(b_), _p(r_), _p(y), M, N, K,
                                                act, float(drop_p), seed, _ss(), _p(y_amax), _stream()), "ttts_linear_fwd_h3i")
         elif _fwd_h3(K, N):
@@ -799,7 +820,7 @@ class LinearFn(torch.autograd.Function):
         dres = dy if has_r else None
         if has_r and skip_out is not None:      # hand the skip gradient to the block's first Linear instead of autograd
             skip_out.grad, dres = dy, None
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 # Test seam: called with the output of every relu-epilogue Linear, in call order (which units the HIP path gated off).
@@ -837,8 +858,20 @@ class SkipToken:
         self.grad = None
 
 
+HEAD_IMAGES = True          # attention in-projections write head images and attention runs on them (csrc/attention_img.hip)
+
+
+def head_image_ok(x: torch.Tensor, w: torch.Tensor, n_head: int, sections: int) -> bool:
+    """can the in-projection x @ w.T (+ b) leave as a head image for `ops.self_attention` / `cross_attention`?  64-column heads,
+    reduction depth a multiple of 32, the fp16x3 forms selected, operands below 4 GiB."""
+    N, K = w.shape
+    M = x.numel() // K
+    return (HEAD_IMAGES and x.is_cuda and _fwd_h3(K, N) and ATTN_FWD_MODE == "h3" and ATTN_BWD_MODE == "h3" and K % 32 == 0
+            and N == sections * n_head * 64 and M * K * 4 < (1 << 32) and (M + 256) * N * 4 < (1 << 32))
+
+
 def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_shift=0, T=0, sole_consumer=False,
-           skip_in=None, skip_out=None, publish_amax=False):
+           skip_in=None, skip_out=None, publish_amax=False, head_image_sections: int = 0):
     """`sole_consumer=True` is the caller's promise that nothing but this Linear reads `x`; if `x` came out of a
     relu(+dropout) Linear, its backward mask is then fused into this Linear's data-gradient epilogue.
     `skip_in` / `skip_out`: see SkipToken.
@@ -864,8 +897,19 @@ def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_sh
     x_img = getattr(x, "_ttts_image", None) if (h3 and row_shift == 0) else None
     if x_img is not None and not _image_shape_ok(x.numel() // K, K, N):
         x_img = None
+    y_himg = None
+    if head_image_sections:
+        # (rows of inverse scales [N / 64][M], one partial-maxima array per section, columns per section)
+        if residual is not None or act != ACT_NONE or float(drop_p) > 0.0 or row_shift != 0 or N % (64 * head_image_sections) != 0:
+            raise ValueError("linear: a head-image output takes a bias-only epilogue and whole 64-column heads per section")
+        M = x.numel() // K
+        sec = _amax_slots_n(x.device, head_image_sections)
+        y_himg = (torch.empty(N // 64, M, dtype=torch.float32, device=x.device), sec, N // head_image_sections)
+        y_am = None
     y = LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out, tok_in, skip_in, skip_out, tok_drop,
-                       x_am, y_am, x_img)
+                       x_am, y_am, x_img, y_himg)
+    if y_himg is not None:
+        y._ttts_himg = y_himg
     if y_am is not None:
         y._ttts_amax = y_am
     if tok_drop is not None:
@@ -1219,6 +1263,100 @@ def _unpad_heads(src: torch.Tensor, dst: torch.Tensor, col0: int, ld: int, rows:
     _lib.check(_lib.load().ttts_heads_unpad(_p(src), _off(dst, col0), ld, rows, H, hd, _stream()), "ttts_heads_unpad")
 
 
+class SelfAttentionImgFn(torch.autograd.Function):
+    """o = softmax(mask(q k^T / 8)) v on a packed in-projection output that arrived as a HEAD IMAGE (`linear(...,
+    head_image_sections=3)`): K / V tiles are staged by LDS-DMA, no split arithmetic (csrc/attention_img.hip)."""
+
+    @staticmethod
+    def forward(ctx, qkv, row_inv, sec_amax, lens, n_head, causal, drop_p, seed, o_amax=None):
+        lib = _lib.load()
+        qkv = _chk(qkv, "self_attention.qkv")
+        lens = _chk(lens, "self_attention.lens", torch.int64)
+        B, T, d3 = qkv.shape
+        d, M = d3 // 3, B * T
+        o = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
+        stat = torch.empty(6, B, n_head, T, dtype=torch.float32, device=qkv.device)     # lse, then the five row-statistic planes
+        HM = n_head * M
+        _lib.check(lib.ttts_attention_fwd_img(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _off(row_inv, 0), _off(row_inv, HM),
+                                              _off(row_inv, 2 * HM), _p(o), _p(stat[0]), None, _p(lens), B, n_head, T, T, d3, d3, d3, d,
+                                              1 if causal else 0, 0.125, float(drop_p), seed, _ss(), _p(sec_amax[2]), _p(o_amax),
+                                              _p(stat[1:]), _stream()), "ttts_attention_fwd_img")
+        ctx.save_for_backward(qkv, row_inv, o, stat, lens)
+        ctx.cfg = (n_head, causal, float(drop_p), seed)
+        ctx.ss = _ss()
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        lib = _lib.load()
+        qkv, row_inv, o, stat, lens = ctx.saved_tensors
+        n_head, causal, drop_p, seed = ctx.cfg
+        B, T, d3 = qkv.shape
+        d, M = d3 // 3, B * T
+        HM = n_head * M
+        do = _chk(do, "self_attention.do")
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty(B, n_head, T, dtype=torch.float32, device=qkv.device)
+        am = _amax_slots(qkv.device, True)                                     # max|dqkv| for the in-projection gradients
+        _lib.check(lib.ttts_attention_bwd_img(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _off(row_inv, 0), _off(row_inv, HM),
+                                              _off(row_inv, 2 * HM), _p(o), _p(do), _p(stat[1:]), _p(delta), _off(dqkv, 0), _off(dqkv, d),
+                                              _off(dqkv, 2 * d), _p(lens), B, n_head, T, T, d3, d3, d3, d, d3, d3, d3, 1 if causal else 0,
+                                              0.125, drop_p, seed, ctx.ss, _p(_amax(do)), _p(am), _p(am), _stream()),
+                   "ttts_attention_bwd_img")
+        dqkv._ttts_amax = am
+        return dqkv, None, None, None, None, None, None, None, None
+
+
+class CrossAttentionImgFn(torch.autograd.Function):
+    """encoder-decoder attention on head images: q (B,Tq,d) and packed kv (B,Tk,2d), each with its inverse scales"""
+
+    @staticmethod
+    def forward(ctx, q, q_inv, kv, kv_inv, kv_sec_amax, lens, n_head, drop_p, seed, need_weights=True, o_amax=None):
+        lib = _lib.load()
+        q = _chk(q, "cross_attention.q")
+        kv = _chk(kv, "cross_attention.kv")
+        lens = _chk(lens, "cross_attention.lens", torch.int64)
+        B, Tq, d = q.shape
+        Tk = kv.shape[1]
+        o = torch.empty(B, Tq, d, dtype=torch.float32, device=q.device)
+        stat = torch.empty(6, B, n_head, Tq, dtype=torch.float32, device=q.device)
+        attn = torch.empty(B, n_head, Tq, Tk, dtype=torch.float32, device=q.device) if need_weights else None
+        HK = n_head * B * Tk
+        _lib.check(lib.ttts_attention_fwd_img(_p(q), _off(kv, 0), _off(kv, d), _p(q_inv), _off(kv_inv, 0), _off(kv_inv, HK), _p(o),
+                                              _p(stat[0]), _p(attn), _p(lens), B, n_head, Tq, Tk, d, 2 * d, 2 * d, d, 0, 0.125,
+                                              float(drop_p), seed, _ss(), _p(kv_sec_amax[1]), _p(o_amax), _p(stat[1:]), _stream()),
+                   "ttts_attention_fwd_img")
+        ctx.save_for_backward(q, q_inv, kv, kv_inv, o, stat, lens)
+        ctx.cfg = (n_head, float(drop_p), seed)
+        ctx.ss = _ss()
+        if attn is None:
+            attn = torch.empty(0, dtype=torch.float32, device=q.device)
+        ctx.mark_non_differentiable(attn)
+        ctx.set_materialize_grads(False)
+        return o, attn
+
+    @staticmethod
+    def backward(ctx, do, _dattn):
+        if do is None:
+            return (None,) * 11
+        lib = _lib.load()
+        q, q_inv, kv, kv_inv, o, stat, lens = ctx.saved_tensors
+        n_head, drop_p, seed = ctx.cfg
+        B, Tq, d = q.shape
+        Tk = kv.shape[1]
+        HK = n_head * B * Tk
+        do = _chk(do, "cross_attention.do")
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        delta = torch.empty(B, n_head, Tq, dtype=torch.float32, device=q.device)
+        am_q, am_kv = _amax_slots(q.device, True), _amax_slots(q.device, True)
+        _lib.check(lib.ttts_attention_bwd_img(_p(q), _off(kv, 0), _off(kv, d), _p(q_inv), _off(kv_inv, 0), _off(kv_inv, HK), _p(o), _p(do),
+                                              _p(stat[1:]), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk,
+                                              d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, 0, 0.125, drop_p, seed, ctx.ss, _p(_amax(do)),
+                                              _p(am_q), _p(am_kv), _stream()), "ttts_attention_bwd_img")
+        dq._ttts_amax, dkv._ttts_amax = am_q, am_kv
+        return dq, None, dkv, None, None, None, None, None, None, None, None
+
+
 class SelfAttentionFn(torch.autograd.Function):
     """o = softmax(mask(q k^T / sqrt(head_dim))) v over a packed in-proj output qkv (B,T,3d); head_dim <= 64 (heads of 64 are
     read in place, narrower ones through zero-padded copies)."""
@@ -1364,6 +1502,12 @@ class CrossAttentionFn(torch.autograd.Function):
 def self_attention(qkv, lens, n_head: int, causal: bool, drop_p: float, seed: int):
     """Self-attention over a packed in-projection output; the partial maxima of `qkv` ride on it when its producer left
     them (`linear(..., publish_amax=True)`), and the context leaves with its own for the out-projection."""
+    himg = getattr(qkv, "_ttts_himg", None)
+    if himg is not None:                       # the in-projection left a head image: the LDS-DMA kernels
+        o_am = _amax_slots(qkv.device, True)
+        o = SelfAttentionImgFn.apply(qkv, himg[0], himg[1], lens, n_head, causal, drop_p, seed, o_am)
+        o._ttts_amax = o_am
+        return o
     h3 = qkv.is_cuda and _attn_h3()
     am = _amax(qkv) if h3 else None
     o_am = _amax_slots(qkv.device, True) if (qkv.is_cuda and ATTN_FWD_MODE == "h3") else None
@@ -1374,6 +1518,14 @@ def self_attention(qkv, lens, n_head: int, causal: bool, drop_p: float, seed: in
 
 
 def cross_attention(q, kv, lens, n_head: int, drop_p: float, seed: int, need_weights: bool = True):
+    qi, kvi = getattr(q, "_ttts_himg", None), getattr(kv, "_ttts_himg", None)
+    if (qi is None) != (kvi is None):
+        raise ValueError("cross_attention: q and kv must both be head images or both fp32")
+    if qi is not None:
+        o_am = _amax_slots(q.device, True)
+        o, attn = CrossAttentionImgFn.apply(q, qi[0], kv, kvi[0], kvi[1], lens, n_head, drop_p, seed, need_weights, o_am)
+        o._ttts_amax = o_am
+        return o, attn
     h3 = q.is_cuda and _attn_h3()
     q_am, kv_am = (_amax(q), _amax(kv)) if h3 else (None, None)
     o_am = _amax_slots(q.device, True) if (q.is_cuda and ATTN_FWD_MODE == "h3") else None
