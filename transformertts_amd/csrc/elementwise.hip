@@ -196,9 +196,11 @@ __global__ __launch_bounds__(256) void posenc_bwd_kernel(const float* __restrict
                                                          float* __restrict__ dx, float* __restrict__ ws, long n4, int T,
                                                          int d, float drop_scale, uint32_t thr, uint64_t seed, const uint64_t* step_seed) {
     seed = site_seed(seed, step_seed);
-    __shared__ float red[4];
+    __shared__ double red[4];
     const long td = (long)T * d;
-    float s = 0.f;
+    // The sum over every position cancels heavily (d alpha is 5-50 x smaller than its terms' mass): accumulated in double, so that
+    // what is left of its error is what dy itself carries, not this kernel's summation order (the pass is memory-bound either way)
+    double s = 0.0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long e = i * 4;
         float4 gv = *reinterpret_cast<const float4*>(dy + e);
@@ -208,21 +210,24 @@ __global__ __launch_bounds__(256) void posenc_bwd_kernel(const float* __restrict
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] = keep_elem(seed, (uint64_t)(e + j), thr) ? g[j] * drop_scale : 0.f;
         }
-        s += g[0] * pv.x + g[1] * pv.y + g[2] * pv.z + g[3] * pv.w;
+        s += (double)g[0] * pv.x + (double)g[1] * pv.y + (double)g[2] * pv.z + (double)g[3] * pv.w;
         *reinterpret_cast<float4*>(dx + e) = make_float4(g[0], g[1], g[2], g[3]);
     }
-    s = wave_sum(s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) reinterpret_cast<double*>(ws)[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ void scalar_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int n, int accumulate) {
-    // single wave, fixed order
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 64) s += ws[i];
-    s = wave_sum(s);
-    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
+    // single wave, fixed order; double partials
+    const double* w8 = reinterpret_cast<const double*>(ws);
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += w8[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + (float)s : (float)s;      // (as autograd adds two fp32 results)
 }
 
 // ------------------------------------------------------------------ masks
@@ -427,7 +432,7 @@ int ttts_posenc_fwd(const float* x, const float* pe, const float* alpha, float* 
     return TTTS_OK;
 }
 
-size_t ttts_posenc_bwd_workspace_bytes(void) { return (size_t)PE_BWD_BLOCKS * sizeof(float); }
+size_t ttts_posenc_bwd_workspace_bytes(void) { return (size_t)PE_BWD_BLOCKS * sizeof(double); }
 
 int ttts_posenc_bwd(const float* dy, const float* pe, float* dx, float* dalpha, float* ws, size_t ws_bytes, int B, int T,
                     int d, float drop_p, uint64_t seed, const uint64_t* step_seed, int accumulate,

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
                                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(inv), rsrcI,
                                                                      (int)(live ? (uint32_t)(((long)(hcol >> 6) * g.M + row) * 4) : OOB), 0, 0);
                         }
-                        if (want_max) {
+                        if (want_max && hcol < g.N) {       // (a head past the last column belongs to no section: wave-uniform test)
                             const int sec = g.c_amax_sec > 0 ? hcol / g.c_amax_sec : 0;
                             amax_publish(hmax, g.c_amax + (long)sec * TTTS_AMAX_SLOTS, bid);
                         }
