@@ -373,6 +373,9 @@ def main():
     ap.add_argument("--no-image-operands", action="store_true",
                     help="A/B aid: keep every GEMM on the kernels that split the fp32 activation in their loader (gemm_h3): no launch "
                          "of the LDS-DMA kernel (gemm_h3i)")
+    ap.add_argument("--no-head-images", action="store_true",
+                    help="A/B aid: attention in-projections write fp32 and attention runs on the kernels that split q / k / v while they "
+                         "stage them (csrc/attention.hip) instead of head images + LDS-DMA (csrc/attention_img.hip)")
     ap.add_argument("--layernorm-images", action="store_true",
                     help="A/B aid: LayerNorm forward / backward also write the image operand of their output and the GEMMs behind "
                          "them take it (measured slower over the step: transformertts_amd/ops.py, LAYERNORM_IMAGES)")
@@ -415,6 +418,8 @@ def main():
         ops.DMA_GEMMS = False
     if args.layernorm_images:
         ops.LAYERNORM_IMAGES = True
+    if args.no_head_images:
+        ops.HEAD_IMAGES = False
     cfg = model_config(args.config)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
               "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,
@@ -606,6 +611,7 @@ def main():
                        "alignments_written": bool(args.alignments),
                        "arithmetic": "3 x f16 MFMA terms per fp32 product (hi/lo f16 splits of both operands), fp32 accumulate",
                        "dma_gemms": not args.no_image_operands, "layernorm_images": bool(args.layernorm_images),
+                       "head_images": not args.no_head_images,
                        "final_loss": final_loss, "per_step_loss_item_sync": False},
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "sustained": sustained,

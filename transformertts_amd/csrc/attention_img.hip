@@ -97,18 +97,57 @@ __device__ __forceinline__ void img_tensor_scale(const float* __restrict__ parti
     inv = h3_uniform(i);
 }
 
+#ifdef TTTS_AIMG_STAMPS
+// development aid (tools/aimg_stamps.py; never defined in the product build): per (workgroup, wave) sums of s_memtime ticks of the
+// causal forward: 0 waiting for a tile (vmcnt + barrier), 1 issuing the next tile's DMAs, 2 score products + key scales,
+// 3 softmax + dropout, 4 P split + V^T reads + products, 5 whole kernel, 6 sub-tiles done, 7 prologue
+__device__ unsigned long long ttts_aimg_stamps[2048 * 4 * 8];
+#define ASTAMP() __builtin_amdgcn_s_memtime()
+#define AACC(slot, v) do { if ((threadIdx.x & 63) == 0) st_acc[slot] += (v); } while (0)
+#else
+#define ASTAMP() 0ull
+#define AACC(slot, v)
+#endif
+
 // ===================================================================================== forward
-// LDS: two stages of {K planes 16 KB, V planes 16 KB, 64 key scales, 64 value scales}; the stages double as the per-wave fp32
-// scratch of the epilogue.
-constexpr int FI_STAGE = 2 * IMG_TILE + 512;
-template <bool CAUSAL, bool WRITE_A>
-__global__ __launch_bounds__(256, 2) void attn_fwd_img_kernel(AttnImgArgs a) {
+// LDS: two stages of {K planes, V planes, key scales, value scales} of KT keys; the stages double as the per-wave fp32 scratch of
+// the epilogue.  KT = 64: 16 KB per operand tile, two workgroups per CU; KT = 32: half of that and THREE workgroups per CU (the
+// kernel's 156 registers allow three waves per SIMD) -- twice the barriers per key, but a third more waves to cover the
+// latencies a wave cannot cover itself (exp, LDS, MFMA results): measured on the causal self-attention of the step.
+constexpr int FI_STAGE = 2 * IMG_TILE + 512;          // (KT = 64; the backward kernels)
+constexpr int OUT_LD = 68;                            // floats per row of the epilogue's scratch: 16-byte rows, 4-bank skew
+constexpr int OUT_BYTES = 4 * 32 * OUT_LD * 4;
+// write a 2 x (32x32) accumulator pair holding X^T[d][row] (row on the lane) as rows of 64 floats, 16 bytes per lane and store
+__device__ __forceinline__ void wave_store_rows4(const f32x16 (&acc)[2], float* scratch, float* gbase, long row0, long nrows_total,
+                                                 int ld, int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scratch[l31 * OUT_LD + blk * 32 + acc_row(r, half)] = acc[blk][r];
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + (lane >> 4), c4 = (lane & 15) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(scratch + row * OUT_LD + c4);
+        if (row0 + row < nrows_total) *reinterpret_cast<float4*>(gbase + (row0 + row) * ld + c4) = v;
+    }
+    wave_lds_sync();
+}
+template <bool CAUSAL, bool WRITE_A, int KT>
+__global__ __launch_bounds__(256, KT == 32 ? 3 : 2) void attn_fwd_img_kernel(AttnImgArgs a) {
+    constexpr int PL = KT * 128;                      // bytes of one plane of a tile
+    constexpr int TILE = 2 * PL, STG = 2 * TILE + 512, NSUB = KT / 32;
+    constexpr int XS = 2 * STG > OUT_BYTES ? 2 * STG : OUT_BYTES;
+#ifdef TTTS_AIMG_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_begin = ASTAMP();
+#endif
     const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
     const uint32_t thr16 = a.thr << 16;
-    __shared__ __attribute__((aligned(16))) char xs[2 * FI_STAGE];
+    __shared__ __attribute__((aligned(16))) char xs[XS];
     __shared__ float ptile_all[WRITE_A ? 4 * 32 * 17 : 1];   // per wave: 32 queries x 16 keys (+1 pad)
     __shared__ float red4[4];
-    static_assert(2 * FI_STAGE >= SMEM_FLOATS * 4, "per-wave fp32 scratch must fit the stages");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,15 +157,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_img_kernel(AttnImgArgs a) {
     const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
     const int q0 = qblk * QB, qw0 = q0 + wave * 32;
     const int qg = qw0 + l31;
-    float* scratch = reinterpret_cast<float*>(xs) + wave * 32 * KT_LD;
+    float* scratch = reinterpret_cast<float*>(xs) + wave * 32 * OUT_LD;
 
     int klen = (int)a.key_lens[b];
     if (klen > a.Tk) klen = a.Tk;
     if (klen < 0) klen = 0;
     int kend = klen;
     if (CAUSAL && kend > q0 + QB) kend = q0 + QB;
-    const int nst_live = (kend + KB - 1) / KB;
-    const int nst = WRITE_A ? (a.Tk + KB - 1) / KB : nst_live;
+    const int nst_live = (kend + KT - 1) / KT;
+    const int nst = WRITE_A ? (a.Tk + KT - 1) / KT : nst_live;
     int wave_kend = WRITE_A ? a.Tk : kend;
     if (CAUSAL && wave_kend > qw0 + 32) wave_kend = qw0 + 32;
 
@@ -147,8 +186,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_img_kernel(AttnImgArgs a) {
     const float c_q = a.q_inv[(long)h * a.q_rows + (long)b * a.Tq + qrow] * a.qscale;
     const float c2_q = c_q * 1.4426950408889634f;
 
-    // ---- K / V tiles by LDS-DMA.  This wave moves rows 16 w .. 16 w + 15 of each plane: lane -> (row 8 nn + lane / 8, chunk slot
-    // lane & 7), and the chunk it FETCHES is slot ^ isw(row).  Rows past the last key are clamped to it (finite data the masks
+    // ---- K / V tiles by LDS-DMA.  This wave moves rows (KT / 4) w .. of each plane in 8-row pieces: lane -> (row lane / 8 of the
+    // piece, chunk slot lane & 7), and the chunk it FETCHES is slot ^ isw(row).  Rows past the last key are clamped to it (finite data the masks
     // remove; nothing of another allocation is touched).
     const u32x4a rsK = make_rsrc(reinterpret_cast<const char*>(a.k) + ((long)b * a.Tk * a.ldk + h * HD) * 4, (uint32_t)a.Tk * (uint32_t)a.ldk * 4u);
     const u32x4a rsV = make_rsrc(reinterpret_cast<const char*>(a.v) + ((long)b * a.Tk * a.ldv + h * HD) * 4, (uint32_t)a.Tk * (uint32_t)a.ldv * 4u);
@@ -158,25 +197,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_img_kernel(AttnImgArgs a) {
     const int ld_r = lane >> 3;                                       // row within an 8-row piece
     const uint32_t ld_c0 = (uint32_t)((lane & 7) ^ isw(ld_r)) * 16u;  // chunk fetched for piece nn = 0; nn = 1: ^ 32 bytes
     auto issue = [&](int t, int stage, bool with_v) {
-        const uint32_t dst = lds0 + (uint32_t)stage * FI_STAGE;
+        const uint32_t dst = lds0 + (uint32_t)stage * STG;
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn) {
-            int row = t * KB + 16 * wave + 8 * nn + ld_r;
+        for (int nn = 0; nn < KT / 32; ++nn) {
+            const int piece_row = (KT / 4) * wave + 8 * nn;           // first row of this 8-row piece inside the tile
+            int row = t * KT + piece_row + ld_r;
             row = row < a.Tk ? row : a.Tk - 1;
-            const uint32_t cb = ld_c0 ^ (uint32_t)(nn * 32);
+            const uint32_t cb = ld_c0 ^ (uint32_t)(((piece_row >> 3) & 1) * 32);      // isw of the piece's rows: bit 3 of the row flips chunk bit 1
             const uint32_t ko = (uint32_t)row * (uint32_t)(a.ldk * 4) + cb, vo = (uint32_t)row * (uint32_t)(a.ldv * 4) + cb;
-            const uint32_t piece = (uint32_t)(16 * wave + 8 * nn) * 128u;
+            const uint32_t piece = (uint32_t)piece_row * 128u;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                dma16a(rsK, ko, (uint32_t)p * 128u, __builtin_amdgcn_readfirstlane(dst + (uint32_t)p * IMG_PLANE + piece));
-                if (with_v) dma16a(rsV, vo, (uint32_t)p * 128u, __builtin_amdgcn_readfirstlane(dst + IMG_TILE + (uint32_t)p * IMG_PLANE + piece));
+                dma16a(rsK, ko, (uint32_t)p * 128u, __builtin_amdgcn_readfirstlane(dst + (uint32_t)p * PL + piece));
+                if (with_v) dma16a(rsV, vo, (uint32_t)p * 128u, __builtin_amdgcn_readfirstlane(dst + TILE + (uint32_t)p * PL + piece));
             }
         }
-        if (wave < 2) {                                               // wave 0: the tile's 64 key scales; wave 1: its value scales
-            int key = t * KB + lane;
+        if (wave < 2) {                                               // wave 0: the tile's key scales; wave 1: its value scales
+            int key = t * KT + lane;                                  // (64 lanes: the KT = 32 tile takes its neighbour's along)
             key = key < a.Tk ? key : a.Tk - 1;
-            if (wave == 0) dma4a(rsKi, (uint32_t)key * 4u, __builtin_amdgcn_readfirstlane(dst + 2 * IMG_TILE));
-            else if (with_v) dma4a(rsVi, (uint32_t)key * 4u, __builtin_amdgcn_readfirstlane(dst + 2 * IMG_TILE + 256));
+            if (wave == 0) dma4a(rsKi, (uint32_t)key * 4u, __builtin_amdgcn_readfirstlane(dst + 2 * TILE));
+            else if (with_v) dma4a(rsVi, (uint32_t)key * 4u, __builtin_amdgcn_readfirstlane(dst + 2 * TILE + 256));
         }
     };
     auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -195,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_img_kernel(AttnImgArgs a) {
         for (int sc = 0; sc < 2; ++sc) {
             const int r = 8 * sc + 4 * half + q4;                    // row inside the 16-key step (isw of the full row: same bits)
             const int ch = 4 * i2 + 2 * g16 + (pc >> 1);
-            v_off[i2][sc] = (uint32_t)(IMG_TILE + r * 128 + ((ch ^ isw(r)) << 4) + (pc & 1) * 8);
+            v_off[i2][sc] = (uint32_t)(TILE + r * 128 + ((ch ^ isw(r)) << 4) + (pc & 1) * 8);
         }
 
     float m = NEG_INF, l = 0.f;
@@ -214,10 +254,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_img_kernel(AttnImgArgs a) {
         for (int st = 0; st < 4; ++st) {
             f16x8v kf[2];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) kf[p] = *reinterpret_cast<const f16x8v*>(st_ + p * IMG_PLANE + sub * 4096 + k_off[st]);
+            for (int p = 0; p < 2; ++p) kf[p] = *reinterpret_cast<const f16x8v*>(st_ + p * PL + sub * 4096 + k_off[st]);
             mfma_h3(s, kf, qf[st]);
         }
-        const float* ki = reinterpret_cast<const float*>(st_ + 2 * IMG_TILE) + sub * 32 + 4 * half;
+        const float* ki = reinterpret_cast<const float*>(st_ + 2 * TILE) + sub * 32 + 4 * half;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const float4 f = *reinterpret_cast<const float4*>(ki + 8 * g4);
@@ -243,10 +283,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_img_kernel(AttnImgArgs a) {
         landed();
         for (int t = 0; t < nst_live; ++t) {
             if (t + 1 < nst_live) issue(t + 1, (t + 1) & 1, false);
-            const char* st_ = xs + (t & 1) * FI_STAGE;
+            const char* st_ = xs + (t & 1) * STG;
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                const int key0 = t * KB + sub * 32;
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const int key0 = t * KT + sub * 32;
                 if (key0 >= kend) break;
                 f32x16 s;
                 scores(st_, sub, s);
@@ -277,18 +317,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_img_kernel(AttnImgArgs a) {
     const float mcs_fin = m_fin * c2_q;         // ONE rounded product per row, kept as it is (rowstat): see attention.hip
 
     // ---------------- main pass
+    AACC(7, ASTAMP() - st_begin);
     if (nst > 0) issue(0, 0, true);
     landed();
     for (int t = 0; t < nst; ++t) {
         // the tile of step t+1 goes into the stage every wave finished reading before the barrier that ended step t-1
+        [[maybe_unused]] const unsigned long long s_i0 = ASTAMP();
         if (t + 1 < nst) issue(t + 1, (t + 1) & 1, true);
-        const char* st_ = xs + (t & 1) * FI_STAGE;
+        AACC(1, ASTAMP() - s_i0);
+        const char* st_ = xs + (t & 1) * STG;
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int key0 = t * KB + sub * 32;
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int key0 = t * KT + sub * 32;
             if (key0 >= wave_kend) break;
             f32x16 s;
+            [[maybe_unused]] const unsigned long long s_a = ASTAMP();
             scores(st_, sub, s);
+            [[maybe_unused]] const unsigned long long s_b = ASTAMP();
             float p[16];
             const bool full = (key0 + 32 <= klen) && (!CAUSAL || key0 + 31 <= qw0);     // wave-uniform: no mask arithmetic
             if (WRITE_A) {
@@ -341,9 +386,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_img_kernel(AttnImgArgs a) {
                     wave_lds_sync();
                 }
             }
+            [[maybe_unused]] const unsigned long long s_c = ASTAMP();
             // O^T[d][q] += V'^T[d][key] P''^T[key][q], P'' = P (2^10) 2^-e_v(key) E: two 16-key steps, registers 8 t2 .. 8 t2 + 7 of
             // the lane are its B fragment and the transposed reads deliver V'^T in exactly that key order
-            const float* vi = reinterpret_cast<const float*>(st_ + 2 * IMG_TILE + 256) + sub * 32 + 4 * half;
+            const float* vi = reinterpret_cast<const float*>(st_ + 2 * TILE + 256) + sub * 32 + 4 * half;
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
                 const float4 f0 = *reinterpret_cast<const float4*>(vi + 16 * t2), f1 = *reinterpret_cast<const float4*>(vi + 16 * t2 + 8);
@@ -361,14 +407,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_img_kernel(AttnImgArgs a) {
                     f16x8v vf[2];
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl) {
-                        const char* vb = st_ + pl * IMG_PLANE + sub * 4096 + t2 * 2048;
+                        const char* vb = st_ + pl * PL + sub * 4096 + t2 * 2048;
                         vf[pl] = join_tr(lds_tr4(vb + v_off[i2][0]), lds_tr4(vb + v_off[i2][1]));
                     }
                     mfma_h3(o[i2], vf, pf);
                 }
             }
+#ifdef TTTS_AIMG_STAMPS
+            asm volatile("" :: "v"(o[0]), "v"(o[1]));
+            { const unsigned long long s_d = ASTAMP(); AACC(2, s_b - s_a); AACC(3, s_c - s_b); AACC(4, s_d - s_c); AACC(6, 1); }
+#endif
         }
+        [[maybe_unused]] const unsigned long long s_w = ASTAMP();
         landed();
+        AACC(0, ASTAMP() - s_w);
     }
 
     float out_scale = inv_Ev * (1.0f / H3A_P);          // the O accumulator holds (V')^T (P 2^10 E 2^-e_v)^T
@@ -401,7 +453,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_img_kernel(AttnImgArgs a) {
     }
     if (a.o_amax != nullptr) amax_publish(qg < a.Tq ? omax : 0.f, a.o_amax, blockIdx.y * gridDim.x + blockIdx.x);
     // (every wave passed the loop's last barrier after its last read of the stages: the scratch that aliases them is free)
-    wave_store_rows(o, scratch, a.o + (long)b * a.Tq * a.ldo + h * HD, qw0, a.Tq, a.ldo, lane, 1.f);
+    wave_store_rows4(o, scratch, a.o + (long)b * a.Tq * a.ldo + h * HD, qw0, a.Tq, a.ldo, lane);
+#ifdef TTTS_AIMG_STAMPS
+    st_acc[5] = ASTAMP() - st_begin;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((threadIdx.x & 63) == 0 && wg < 2048)
+        for (int i = 0; i < 8; ++i) ttts_aimg_stamps[(wg * 4 + (threadIdx.x >> 6)) * 8 + i] = st_acc[i];
+#endif
 }
 
 // ===================================================================================== backward: dQ (+ delta)
@@ -424,6 +482,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_img_kernel(AttnImgArgs a) 
     const int q0 = qblk * QB, qw0 = q0 + wave * 32;
     const int qg = qw0 + l31;
     float* scratch = reinterpret_cast<float*>(xs) + wave * 32 * KT_LD;
+    float* scratch4 = reinterpret_cast<float*>(xs) + wave * 32 * OUT_LD;     // the epilogue's (16-byte rows)
 
     int klen = (int)a.key_lens[b];
     if (klen > a.Tk) klen = a.Tk;
@@ -610,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_img_kernel(AttnImgArgs a) 
         }
         if (a.amax_dq != nullptr) amax_publish(qg < a.Tq ? mx : 0.f, a.amax_dq, blockIdx.y * gridDim.x + blockIdx.x);
     }
-    wave_store_rows(dq, scratch, a.dq + (long)b * a.Tq * a.lddq + h * HD, qw0, a.Tq, a.lddq, lane, 1.f);
+    wave_store_rows4(dq, scratch4, a.dq + (long)b * a.Tq * a.lddq + h * HD, qw0, a.Tq, a.lddq, lane);
 }
 
 // ===================================================================================== backward: dK, dV
@@ -626,7 +685,7 @@ template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_img_kernel(AttnImgArgs a) {
     const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
     const uint32_t thr16 = a.thr << 16;
-    __shared__ __attribute__((aligned(16))) char xs[(2 * DKI_STAGE > SMEM_FLOATS * 4) ? 2 * DKI_STAGE : SMEM_FLOATS * 4];
+    __shared__ __attribute__((aligned(16))) char xs[(2 * DKI_STAGE > OUT_BYTES) ? 2 * DKI_STAGE : OUT_BYTES];
     __shared__ float red4[4];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -637,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_img_kernel(AttnImgArgs a)
     const int k0 = kblk * QB, kw0 = k0 + wave * 32;
     const int kg = kw0 + l31;
     const uint32_t key_mult = attn_drop_mult((uint32_t)kg);
-    float* scratch = reinterpret_cast<float*>(xs) + wave * 32 * KT_LD;
+    float* scratch4 = reinterpret_cast<float*>(xs) + wave * 32 * OUT_LD;     // the epilogue's scratch (aliases the stages)
 
     int klen = (int)a.key_lens[b];
     if (klen > a.Tk) klen = a.Tk;
@@ -877,10 +936,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_img_kernel(AttnImgArgs a)
         }
         if (a.amax_dkv != nullptr) amax_publish(kg < a.Tk ? mx : 0.f, a.amax_dkv, blockIdx.y * gridDim.x + blockIdx.x);
     }
-    wave_store_rows(dk, scratch, a.dk + (long)b * a.Tk * a.lddk + h * HD, kw0, a.Tk, a.lddk, lane, 1.f);
-    wave_store_rows(dv, scratch, a.dv + (long)b * a.Tk * a.lddv + h * HD, kw0, a.Tk, a.lddv, lane, 1.f);
+    wave_store_rows4(dk, scratch4, a.dk + (long)b * a.Tk * a.lddk + h * HD, kw0, a.Tk, a.lddk, lane);
+    wave_store_rows4(dv, scratch4, a.dv + (long)b * a.Tk * a.lddv + h * HD, kw0, a.Tk, a.lddv, lane);
 }
 
+#ifndef TTTS_AIMG_KT
+#define TTTS_AIMG_KT 32
+#endif
 static int check_img(const char* name, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, float drop_p) {
     TTTS_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "%s: bad dims", name);
     TTTS_REQUIRE((long)B * H < (1L << 31) && cdiv(Tq, QB) <= 65535 && cdiv(Tk, QB) <= 65535, "%s: grid too large", name);
@@ -895,6 +957,12 @@ static int check_img(const char* name, int B, int H, int Tq, int Tk, int ldq, in
 }  // namespace ttts
 
 using namespace ttts;
+
+#ifdef TTTS_AIMG_STAMPS
+extern "C" int ttts_dbg_aimg_read_stamps(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ttts::ttts_aimg_stamps), n * sizeof(unsigned long long));
+}
+#endif
 
 /* Scaled dot-product attention forward on head-image operands (ttts_linear_fwd_h3d_img / ttts_head_image): replaces the same
  * call sites as ttts_attention_fwd_h3 (torch F.scaled_dot_product_attention inside nn.MultiheadAttention,
@@ -926,11 +994,11 @@ extern "C" int ttts_attention_fwd_img(const void* q, const void* k, const void* 
     a.v_amax = v_amax; a.o_amax = o_amax_out; a.rowstat = rowstat_out;
     dim3 grid(B * H, cdiv(Tq, QB), 1);
     if (causal)
-        hipLaunchKernelGGL((attn_fwd_img_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((attn_fwd_img_kernel<true, false, TTTS_AIMG_KT>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else if (attn)
-        hipLaunchKernelGGL((attn_fwd_img_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((attn_fwd_img_kernel<false, true, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL((attn_fwd_img_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((attn_fwd_img_kernel<false, false, TTTS_AIMG_KT>), grid, dim3(256), 0, (hipStream_t)stream, a);
     TTTS_LAUNCH_CHECK("attn_fwd_img_kernel");
     return TTTS_OK;
 }
