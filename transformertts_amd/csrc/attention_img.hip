@@ -113,7 +113,10 @@ __device__ unsigned long long ttts_aimg_stamps[2048 * 4 * 8];
 // LDS: two stages of {K planes, V planes, key scales, value scales} of KT keys; the stages double as the per-wave fp32 scratch of
 // the epilogue.  KT = 64: 16 KB per operand tile, two workgroups per CU; KT = 32: half of that and THREE workgroups per CU (the
 // kernel's 156 registers allow three waves per SIMD) -- twice the barriers per key, but a third more waves to cover the
-// latencies a wave cannot cover itself (exp, LDS, MFMA results): measured on the causal self-attention of the step.
+// latencies a wave cannot cover itself (exp, LDS, MFMA results): causal self-attention 64 x 4 x 870, back to back, 131-138 us
+// against 152 (tools/aimg_time.py).  Measured and not kept: the score products of tile t+1 issued BEFORE the softmax of tile t
+// (a ring of three 32-key stages, 150 registers, still three workgroups per CU): 133-138 us -- with three waves per SIMD
+// the hardware already runs one wave's products under another's arithmetic.
 constexpr int FI_STAGE = 2 * IMG_TILE + 512;          // (KT = 64; the backward kernels)
 constexpr int OUT_LD = 68;                            // floats per row of the epilogue's scratch: 16-byte rows, 4-bank skew
 constexpr int OUT_BYTES = 4 * 32 * OUT_LD * 4;
@@ -943,6 +946,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_img_kernel(AttnImgArgs a)
 #ifndef TTTS_AIMG_KT
 #define TTTS_AIMG_KT 32
 #endif
+
 static int check_img(const char* name, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, float drop_p) {
     TTTS_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "%s: bad dims", name);
     TTTS_REQUIRE((long)B * H < (1L << 31) && cdiv(Tq, QB) <= 65535 && cdiv(Tk, QB) <= 65535, "%s: grid too large", name);
@@ -995,10 +999,10 @@ extern "C" int ttts_attention_fwd_img(const void* q, const void* k, const void* 
     dim3 grid(B * H, cdiv(Tq, QB), 1);
     if (causal)
         hipLaunchKernelGGL((attn_fwd_img_kernel<true, false, TTTS_AIMG_KT>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else if (attn)
-        hipLaunchKernelGGL((attn_fwd_img_kernel<false, true, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else
+    else if (!attn)
         hipLaunchKernelGGL((attn_fwd_img_kernel<false, false, TTTS_AIMG_KT>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((attn_fwd_img_kernel<false, true, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);
     TTTS_LAUNCH_CHECK("attn_fwd_img_kernel");
     return TTTS_OK;
 }
