@@ -82,7 +82,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense
 
 
-TRAFFIC_FILES = ("r04_traffic.json",)     # see tools/collect_traffic.py; round 3's file mis-normalised WRITE_SIZE (x1.9) and is not read
+TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json")     # see tools/collect_traffic.py; round 3's file mis-normalised WRITE_SIZE (x1.9) and is not read
 
 
 def measured_traffic(kernel: str, workload: str = "base_b64"):
@@ -143,6 +143,8 @@ class GemmProbe:
         "ttts_linear_bwd_data_h3i": (2, lambda a: (a[5], a[7], a[6])),
         "ttts_linear_fwd_h3d": (2, lambda a: (a[5], a[6], a[7])),
         "ttts_linear_bwd_data_h3d": (2, lambda a: (a[4], a[6], a[5])),
+        # ... with a head-image output (attention in-projections): (x, planes, bias, image, row_inv, M, N, K, ...)
+        "ttts_linear_fwd_h3d_img": (2, lambda a: (a[5], a[6], a[7])),
     }
     # gemm_h3i_kernel<A_RAW, HAS_RES, HAS_GATE, DROP> as dispatch_h3i instantiates it: name -> argument positions of
     # (residual, relu gate or None, dropout probability or None)
@@ -165,6 +167,8 @@ class GemmProbe:
                 tile = self.lib.ttts_gemm_tile_choice(M, N, K, _x6)
                 if _x6 == 2 and tile == 6 and K >= 96 and _plain:
                     tile = 9        # unshifted operands on the 256 x 256 tile run on gemm_h3_wide_kernel (one wave per SIMD)
+                if _name == "ttts_linear_fwd_h3d_img":
+                    tile = "gemm_h3i_kernel<true,false,false,false,img>"
                 if _name in self.DMA:
                     raw, i_res, i_gate, i_p = self.DMA[_name]
                     flag = lambda v: "true" if v else "false"      # noqa: E731

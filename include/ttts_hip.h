@@ -360,12 +360,16 @@ int ttts_attention_fwd_img(const void* q, const void* k, const void* v, const fl
                            const float* v_inv, float* o, float* lse, float* attn, const int64_t* key_lens, int B, int H, int Tq,
                            int Tk, int ldq, int ldk, int ldv, int ldo, int causal, float q_scale, float drop_p, uint64_t seed,
                            const uint64_t* step_seed, const float* v_amax, float* o_amax_out, float* rowstat_out, void* stream);
-/* dq, dk, dv in fp32 (strides ldd*) from d_o; o / d_o fp32; do_amax = partial maxima of |d_o|; delta (B,H,Tq) is scratch */
+/* dq, dk, dv in fp32 (strides ldd*) from d_o; o / d_o fp32; do_amax = partial maxima of |d_o|; delta (B,H,Tq) is scratch.
+ * q_splits > 1 (non-causal, dk / dv the two halves of one packed (B, Tk, 2 H 64) gradient): the dK / dV kernel splits the query
+ * range over q_splits workgroups per key block, partial sums in dkv_partials, one fixed-order reduction at the end. */
 int ttts_attention_bwd_img(const void* q, const void* k, const void* v, const float* q_inv, const float* k_inv,
                            const float* v_inv, const float* o, const float* d_o, const float* rowstat, float* delta, float* dq,
                            float* dk, float* dv, const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv,
                            int ldo, int lddq, int lddk, int lddv, int causal, float q_scale, float drop_p, uint64_t seed,
-                           const uint64_t* step_seed, const float* do_amax, float* dq_amax_out, float* dkv_amax_out, void* stream);
+                           const uint64_t* step_seed, const float* do_amax, float* dq_amax_out, float* dkv_amax_out,
+                           float* dkv_partials /* NULL, or q_splits x B x Tk x lddk floats */, int q_splits /* 1: no split */,
+                           void* stream);
 
 /* ------------------------------------------------------------------ small row / element-wise pieces
  * nn.Embedding gather / scatter-add (model/model.py:168,288; no padding_idx) */

@@ -144,9 +144,22 @@ def _run_img(q, kv, do, lens, causal, H, p_drop=0.0, seed=0, want_attn=True):
     sq, sk = torch.zeros(ops.AMAX_SLOTS, device=dev), torch.zeros(ops.AMAX_SLOTS, device=dev)
     _lib.check(lib.ttts_attention_bwd_img(_p(qi), _off(kvi, 0), _off(kvi, d), _p(qinv), _off(kvinv, 0), _off(kvinv, HK), _p(o), _p(do),
                                           _p(stat[1:]), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d,
-                                          d, d, 2 * d, 2 * d, causal, 0.125, p_drop, seed, None, _p(ops._amax(do)), _p(sq), _p(sk),
+                                          d, d, 2 * d, 2 * d, causal, 0.125, p_drop, seed, None, _p(ops._amax(do)), _p(sq), _p(sk), None, 1,
                                           _stream()), "bwd_img")
-    return {"o": o, "attn": attn, "lse": stat[0], "dq": dq, "dkv": dkv, "o_amax": oslots, "dq_amax": sq, "dkv_amax": sk}
+    out = {"o": o, "attn": attn, "lse": stat[0], "dq": dq, "dkv": dkv, "o_amax": oslots, "dq_amax": sq, "dkv_amax": sk}
+    if not causal and Tq >= 64:
+        # the same backward with the query range of the dK / dV kernel split over 3 workgroups per key block: partial sums + one
+        # fixed-order reduction -- equal to fp32 rounding of the sum order, maxima published by the reduction
+        dq2, dkv2 = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
+        part = torch.full((3, B, Tk, 2 * d), float("nan"), device=dev)
+        sk2 = torch.zeros(ops.AMAX_SLOTS, device=dev)
+        _lib.check(lib.ttts_attention_bwd_img(_p(qi), _off(kvi, 0), _off(kvi, d), _p(qinv), _off(kvinv, 0), _off(kvinv, HK), _p(o), _p(do),
+                                              _p(stat[1:]), _p(delta), _p(dq2), _off(dkv2, 0), _off(dkv2, d), _p(kl), B, H, Tq, Tk, d, 2 * d,
+                                              2 * d, d, d, 2 * d, 2 * d, causal, 0.125, p_drop, seed, None, _p(ops._amax(do)), None, _p(sk2),
+                                              _p(part), 3, _stream()), "bwd_img split")
+        out["dkv_split"], out["dkv_split_amax"] = dkv2, sk2
+        assert torch.equal(dq2, dq)
+    return out
 
 
 CASES = [(1, 200, 200, [200, 131, 64]), (0, 150, 70, [70, 33, 1]), (0, 33, 129, [129, 128, 5]), (1, 870, 870, [870, 500]),
@@ -181,6 +194,10 @@ def test_attention_on_head_images(causal, Tq, Tk, lens, qk_scale):
     assert _rel(r["dkv"][live][..., :d], dkv_ref[live][..., :d]) < TOL and _rel(r["dkv"][live][..., d:], dkv_ref[live][..., d:]) < TOL, \
         (_rel(r["dkv"][live][..., :d], dkv_ref[live][..., :d]), _rel(r["dkv"][live][..., d:], dkv_ref[live][..., d:]))
     assert r["dq_amax"].max().item() == r["dq"].abs().max().item() and r["dkv_amax"].max().item() == r["dkv"].abs().max().item()
+    if "dkv_split" in r:
+        assert torch.isfinite(r["dkv_split"]).all()
+        assert _rel(r["dkv_split"][live], dkv_ref[live]) < TOL and _rel(r["dkv_split"], r["dkv"]) < 1e-6
+        assert r["dkv_split_amax"].max().item() == r["dkv_split"].abs().max().item()
     if min(lens) == 0 or Tq == 1:
         return
     # dropout: the kept weights ARE the fp32-operand kernel's for the same seed, and the fp64 reference that drops exactly the

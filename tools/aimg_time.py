@@ -47,6 +47,8 @@ for name, causal, Tq, Tk, attn_out in (("decoder self (causal)", 1, 870, 870, Fa
     attn = torch.empty(B, H, Tq, Tk, device=dev) if attn_out else None
     dq, dkv, delta = torch.empty(B, Tq, d, device=dev), torch.empty(B, Tk, 2 * d, device=dev), torch.empty(B, H, Tq, device=dev)
     doa = ops._amax(do)
+    nsp = 1 if causal else ops._dkv_query_splits(B * H * -(-Tk // 128), Tq)
+    part = torch.empty(nsp, B, Tk, 2 * d, device=dev) if nsp > 1 else None
     HK = H * B * Tk
     fwd = lambda: _lib.check(lib.ttts_attention_fwd_img(_p(qi), _off(kvi, 0), _off(kvi, d), _p(qinv), _off(kvinv, 0), _off(kvinv, HK), _p(o),
                                                         _p(stat[0]), _p(attn), _p(lens), B, H, Tq, Tk, d, 2 * d, 2 * d, d, causal, 0.125, p_drop, 7,
@@ -54,7 +56,7 @@ for name, causal, Tq, Tk, attn_out in (("decoder self (causal)", 1, 870, 870, Fa
     bwd = lambda: _lib.check(lib.ttts_attention_bwd_img(_p(qi), _off(kvi, 0), _off(kvi, d), _p(qinv), _off(kvinv, 0), _off(kvinv, HK), _p(o),
                                                         _p(do), _p(stat[1:]), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(lens), B, H, Tq,
                                                         Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, 0.125, p_drop, 7, None, _p(doa), None,
-                                                        None, _stream()), "bwd")
+                                                        None, _p(part), nsp, _stream()), "bwd")
     tf = timed(fwd)
     tb = timed(bwd)
     print(f"{name:26s} fwd {tf:7.1f} us   bwd (dq + dkv) {tb:7.1f} us   [p_drop {p_drop}]")

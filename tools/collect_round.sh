@@ -3,7 +3,7 @@
 # command, and the two --pmc passes (FETCH_SIZE / WRITE_SIZE) the HBM-traffic table is built from.  Everything lands in
 # gpurun_out/r02/; the files to keep are then copied into profiles/.   usage: bash tools/collect_round.sh <tag>
 set -o pipefail
-tag=${1:-r04}
+tag=${1:-r05}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp

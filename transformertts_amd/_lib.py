@@ -76,7 +76,7 @@ SIGNATURES = {
     "ttts_attention_bwd_h3": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, P, P, P, P, P, P, P, P]),
     "ttts_attention_fwd_img": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U, P, P, P, P, P]),
     "ttts_attention_bwd_img": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, P, P, P,
-                                   P]),
+                                   P, I, P]),
     "ttts_heads_pad": (I, [P, L, P, L, I, I, P]),
     "ttts_heads_unpad": (I, [P, P, L, L, I, I, P]),
     "ttts_embedding_fwd": (I, [P, P, P, L, I, I, P, P]),

@@ -37,6 +37,10 @@ struct AttnImgArgs {
     const float* v_amax;                                  // TTTS_AMAX_SLOTS partial maxima of |v| (the producer's section array)
     const float* do_amax;
     float* amax_dq; float* amax_dkv;
+    // dK / dV kernel with the QUERY range split over gridDim.z workgroups (cross-attention: one 128-key block per (batch, head) is
+    // 256 workgroups for 256 CUs, each streaming every query): split z writes its partial sums to dkv_part + z * part_stride in
+    // the layout of the packed (dk, dv) gradient, and attn_dkv_reduce_kernel adds the splits in fixed order
+    float* dkv_part; long part_stride;
     float* o_amax;
     // (5, B, H, Tq): 0 = exponent subtrahend mcs, 1 = log2 of the row sum, 2 = one-hot flag (as attention.hip), 3 = the row's
     // exponent multiplier c2 = 2^-e_q * qscale * log2(e), 4 = its score multiplier c = 2^-e_q * qscale
@@ -732,9 +736,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_img_kernel(AttnImgArgs a)
 
     const float dp_unscale = inv_g * vinv * a.drop_scale;       // dP accumulator units -> true dP, times the 1/(1-p) of kept weights
     float sds = 0.f;
-    const int nqs = (a.Tq + DKI_QS - 1) / DKI_QS;
-    int qs_begin = CAUSAL ? (k0 / DKI_QS) : 0;
-    if (k0 >= klen) qs_begin = nqs;
+    // (query stages of this workgroup: all of them, or the z-th of gridDim.z equal ranges)
+    const int nqs_all = (a.Tq + DKI_QS - 1) / DKI_QS;
+    const int per_z = (nqs_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int nqs = min(nqs_all, ((int)blockIdx.z + 1) * per_z);
+    int qs_begin = max(CAUSAL ? (k0 / DKI_QS) : 0, (int)blockIdx.z * per_z);
+    if (k0 >= klen || qs_begin > nqs) qs_begin = nqs;
 
     // ---- the ring.  This wave moves rows 8 w .. 8 w + 7 of a stage: one 1-KB piece per Q plane (source chunks swizzled) and two
     // raw pieces of dO; waves 0 / 1 also the row statistics.  Rows past Tq are clamped (finite data; masked below).
@@ -937,10 +944,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_img_kernel(AttnImgArgs a)
             dk[0][r] *= fk; dk[1][r] *= fk; dv[0][r] *= fv; dv[1][r] *= fv;
             mx = fmaxf(fmaxf(mx, fmaxf(fabsf(dk[0][r]), fabsf(dk[1][r]))), fmaxf(fabsf(dv[0][r]), fabsf(dv[1][r])));
         }
-        if (a.amax_dkv != nullptr) amax_publish(kg < a.Tk ? mx : 0.f, a.amax_dkv, blockIdx.y * gridDim.x + blockIdx.x);
+        if (a.amax_dkv != nullptr && gridDim.z == 1) amax_publish(kg < a.Tk ? mx : 0.f, a.amax_dkv, blockIdx.y * gridDim.x + blockIdx.x);
     }
-    wave_store_rows4(dk, scratch4, a.dk + (long)b * a.Tk * a.lddk + h * HD, kw0, a.Tk, a.lddk, lane);
-    wave_store_rows4(dv, scratch4, a.dv + (long)b * a.Tk * a.lddv + h * HD, kw0, a.Tk, a.lddv, lane);
+    float* dk_out = gridDim.z == 1 ? a.dk : a.dkv_part + (long)blockIdx.z * a.part_stride;
+    float* dv_out = gridDim.z == 1 ? a.dv : a.dkv_part + (long)blockIdx.z * a.part_stride + (a.dv - a.dk);
+    wave_store_rows4(dk, scratch4, dk_out + (long)b * a.Tk * a.lddk + h * HD, kw0, a.Tk, a.lddk, lane);
+    wave_store_rows4(dv, scratch4, dv_out + (long)b * a.Tk * a.lddv + h * HD, kw0, a.Tk, a.lddv, lane);
+}
+
+// out[i] = part[0][i] + part[1][i] + ... (fixed order), 16 bytes per lane; max|out| published
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n4, int zs,
+                                                              long stride, float* __restrict__ amax) {
+    float mx = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 acc = reinterpret_cast<const float4*>(part)[i];
+        for (int z = 1; z < zs; ++z) {
+            const float4 v = reinterpret_cast<const float4*>(part + (long)z * stride)[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = acc;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+    }
+    if (amax != nullptr) amax_publish(mx, amax, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 #ifndef TTTS_AIMG_KT
@@ -1009,7 +1034,10 @@ extern "C" int ttts_attention_fwd_img(const void* q, const void* k, const void* 
 
 /* dq, dk, dv (fp32, packed or separate: strides ldd*) from d_o on head-image operands; o, d_o fp32 as the forward wrote / the
  * out-projection's data gradient left them; rowstat = the five planes ttts_attention_fwd_img wrote; do_amax = partial maxima
- * of |d_o|; delta (B,H,Tq) is scratch; dq_amax_out / dkv_amax_out: NULL, or zeroed TTTS_AMAX_SLOTS floats.  Replaces the same
+ * of |d_o|; delta (B,H,Tq) is scratch; dq_amax_out / dkv_amax_out: NULL, or zeroed TTTS_AMAX_SLOTS floats; dkv_partials / q_splits:
+ * NULL / 1, or a workspace of q_splits x B x Tk x lddk floats: the dK / dV kernel then splits the QUERY range over q_splits
+ * workgroups per key block and a fixed-order reduction adds the partial sums (cross-attention's one key block per (batch, head)
+ * otherwise leaves three quarters of the chip's wave slots empty); non-causal, packed (dk, dv) of row stride 2 H 64 only.  Replaces the same
  * call sites as ttts_attention_bwd_h3 (autograd of F.scaled_dot_product_attention / the explicit softmax path,
  * torch/nn/functional.py:6576-6629). */
 extern "C" int ttts_attention_bwd_img(const void* q, const void* k, const void* v, const float* q_inv, const float* k_inv,
@@ -1017,7 +1045,7 @@ extern "C" int ttts_attention_bwd_img(const void* q, const void* k, const void* 
                                       float* dq, float* dk, float* dv, const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq,
                                       int ldk, int ldv, int ldo, int lddq, int lddk, int lddv, int causal, float q_scale,
                                       float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
-                                      float* dq_amax_out, float* dkv_amax_out, void* stream_) {
+                                      float* dq_amax_out, float* dkv_amax_out, float* dkv_partials, int q_splits, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(q && k && v && q_inv && k_inv && v_inv && o && d_o && rowstat && delta && dq && dk && dv && key_lens && do_amax,
                  "attention_bwd_img: null pointer");
@@ -1040,7 +1068,15 @@ extern "C" int ttts_attention_bwd_img(const void* q, const void* k, const void* 
     a.seed = seed; a.step_seed = step_seed;
     a.do_amax = do_amax; a.amax_dq = dq_amax_out; a.amax_dkv = dkv_amax_out;
     a.rowstat = const_cast<float*>(rowstat);
-    dim3 gq(B * H, cdiv(Tq, QB), 1), gk(B * H, cdiv(Tk, QB), 1);
+    // q_splits > 1: dk / dv as partial sums over q_splits query ranges in dkv_partials (q_splits x B x Tk x ldd floats), then
+    // one reduction -- only for a packed (dk, dv) gradient that is one contiguous (B, Tk, 2 H 64) tensor
+    TTTS_REQUIRE(q_splits >= 1 && q_splits <= 16, "attention_bwd_img: q_splits out of 1..16");
+    if (q_splits > 1) {
+        TTTS_REQUIRE(dkv_partials && !causal && dv == dk + H * HD && lddk == 2 * H * HD && lddv == lddk,
+                     "attention_bwd_img: query splits need a workspace and a packed (dk, dv) gradient of row stride 2 H 64");
+        a.dkv_part = dkv_partials; a.part_stride = (long)B * Tk * lddk;
+    }
+    dim3 gq(B * H, cdiv(Tq, QB), 1), gk(B * H, cdiv(Tk, QB), q_splits);
     if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_img_kernel<true>), gq, dim3(256), 0, stream, a);
         TTTS_LAUNCH_CHECK("attn_bwd_dq_img_kernel");
@@ -1051,5 +1087,12 @@ extern "C" int ttts_attention_bwd_img(const void* q, const void* k, const void* 
         hipLaunchKernelGGL((attn_bwd_dkv_img_kernel<false>), gk, dim3(256), 0, stream, a);
     }
     TTTS_LAUNCH_CHECK("attn_bwd_dkv_img_kernel");
+    if (q_splits > 1) {
+        const long n4 = a.part_stride / 4;
+        const long blocks = (n4 + 255) / 256;
+        hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, dkv_partials, dk, n4,
+                           q_splits, a.part_stride, dkv_amax_out);
+        TTTS_LAUNCH_CHECK("attn_dkv_reduce_kernel");
+    }
     return TTTS_OK;
 }

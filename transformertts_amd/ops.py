@@ -1301,10 +1301,17 @@ class SelfAttentionImgFn(torch.autograd.Function):
         _lib.check(lib.ttts_attention_bwd_img(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _off(row_inv, 0), _off(row_inv, HM),
                                               _off(row_inv, 2 * HM), _p(o), _p(do), _p(stat[1:]), _p(delta), _off(dqkv, 0), _off(dqkv, d),
                                               _off(dqkv, 2 * d), _p(lens), B, n_head, T, T, d3, d3, d3, d, d3, d3, d3, 1 if causal else 0,
-                                              0.125, drop_p, seed, ctx.ss, _p(_amax(do)), _p(am), _p(am), _stream()),
+                                              0.125, drop_p, seed, ctx.ss, _p(_amax(do)), _p(am), _p(am), None, 1, _stream()),
                    "ttts_attention_bwd_img")
         dqkv._ttts_amax = am
         return dqkv, None, None, None, None, None, None, None, None
+
+
+def _dkv_query_splits(key_blocks: int, Tq: int) -> int:
+    """query-range splits of the dK / dV kernel: enough workgroups for two per CU (512), each with at least four 32-query stages"""
+    if key_blocks >= 512 or Tq < 256:
+        return 1
+    return max(1, min(8, 512 // key_blocks, (Tq // 32) // 4))
 
 
 class CrossAttentionImgFn(torch.autograd.Function):
@@ -1349,10 +1356,13 @@ class CrossAttentionImgFn(torch.autograd.Function):
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         delta = torch.empty(B, n_head, Tq, dtype=torch.float32, device=q.device)
         am_q, am_kv = _amax_slots(q.device, True), _amax_slots(q.device, True)
+        # few key blocks and many queries (cross-attention: 256 workgroups of one 128-key block each): split the query range
+        nsp = _dkv_query_splits(B * n_head * -(-Tk // 128), Tq)
+        part = torch.empty(nsp, B, Tk, 2 * d, dtype=torch.float32, device=q.device) if nsp > 1 else None
         _lib.check(lib.ttts_attention_bwd_img(_p(q), _off(kv, 0), _off(kv, d), _p(q_inv), _off(kv_inv, 0), _off(kv_inv, HK), _p(o), _p(do),
                                               _p(stat[1:]), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk,
                                               d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, 0, 0.125, drop_p, seed, ctx.ss, _p(_amax(do)),
-                                              _p(am_q), _p(am_kv), _stream()), "ttts_attention_bwd_img")
+                                              _p(am_q), _p(am_kv), _p(part), nsp, _stream()), "ttts_attention_bwd_img")
         dq._ttts_amax, dkv._ttts_amax = am_q, am_kv
         return dq, None, dkv, None, None, None, None, None, None, None, None
 
