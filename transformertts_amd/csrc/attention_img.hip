@@ -469,6 +469,249 @@ __global__ __launch_bounds__(256, KT == 32 ? 3 : 2) void attn_fwd_img_kernel(Att
 #endif
 }
 
+// ===================================================================================== forward with the weights written, Tk <= 128
+// Cross-attention returns its per-head weights (model/layers.py:68-73), normalised by the whole row's sum -- the generic kernel
+// streams K twice for that (row maximum / sum first).  A phoneme sequence is at most 128 keys here: all of K and V (two 64-key
+// tiles = the two stages) sit in LDS at once and a lane's whole score row (4 x 16 registers) stays in registers, so ONE pass
+// does it: every score product once, one request of K and V.
+__global__ __launch_bounds__(256, 2) void attn_fwd_img_maps_kernel(AttnImgArgs a) {
+    constexpr int KT = 64, PL = KT * 128, TILE = 2 * PL, STG = 2 * TILE + 512;
+    constexpr int XS = 2 * STG > OUT_BYTES ? 2 * STG : OUT_BYTES;
+    const uint64_t seed_eff = site_seed(a.seed, a.step_seed);
+    const uint32_t thr16 = a.thr << 16;
+    __shared__ __attribute__((aligned(16))) char xs[XS];
+    __shared__ float red4[4];
+    constexpr int PT_LD = 36;                          // floats per row of a wave's 32 x 32 weight tile (16-byte rows, 4-bank skew)
+    static_assert(4 * 32 * PT_LD * 4 <= XS, "the weight tiles reuse the stages");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    float* ptile = reinterpret_cast<float*>(xs) + wave * 32 * PT_LD;     // (after the products: the stages are free then)
+    const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+    const int qw0 = blockIdx.y * QB + wave * 32;
+    const int qg = qw0 + l31;
+    float* scratch = reinterpret_cast<float*>(xs) + wave * 32 * OUT_LD;
+
+    int klen = (int)a.key_lens[b];
+    if (klen > a.Tk) klen = a.Tk;
+    if (klen < 0) klen = 0;
+    const int nsub = (a.Tk + 31) / 32;                 // <= 4 (the launcher checks Tk <= 128)
+
+    float Ev, inv_Ev;
+    img_tensor_scale(a.v_amax, lane, wave, red4, Ev, inv_Ev);
+
+    const int qrow = qg < a.Tq ? qg : a.Tq - 1;
+    f16x8v qf[4][2];
+    {
+        const char* qp = reinterpret_cast<const char*>(a.q) + ((long)(b * a.Tq + qrow) * a.ldq + h * HD) * 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) qf[s][p] = *reinterpret_cast<const f16x8v*>(qp + p * 128 + (2 * s + half) * 16);
+    }
+    const float c_q = a.q_inv[(long)h * a.q_rows + (long)b * a.Tq + qrow] * a.qscale;
+    const float c2_q = c_q * 1.4426950408889634f;
+
+    // both tiles at once (rows past the last key clamped to it: finite data the masks remove)
+    {
+        const u32x4a rsK = make_rsrc(reinterpret_cast<const char*>(a.k) + ((long)b * a.Tk * a.ldk + h * HD) * 4, (uint32_t)a.Tk * (uint32_t)a.ldk * 4u);
+        const u32x4a rsV = make_rsrc(reinterpret_cast<const char*>(a.v) + ((long)b * a.Tk * a.ldv + h * HD) * 4, (uint32_t)a.Tk * (uint32_t)a.ldv * 4u);
+        const u32x4a rsKi = make_rsrc(a.k_inv + (long)h * a.k_rows + (long)b * a.Tk, (uint32_t)a.Tk * 4u);
+        const u32x4a rsVi = make_rsrc(a.v_inv + (long)h * a.k_rows + (long)b * a.Tk, (uint32_t)a.Tk * 4u);
+        const uint32_t lds0 = lds_addr_a(xs);
+        const int ld_r = lane >> 3;
+        const uint32_t ld_c0 = (uint32_t)((lane & 7) ^ isw(ld_r)) * 16u;
+        const int ntile = (a.Tk + KT - 1) / KT;
+        for (int t = 0; t < ntile; ++t) {
+            const uint32_t dst = lds0 + (uint32_t)t * STG;
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn) {
+                int row = t * KT + 16 * wave + 8 * nn + ld_r;
+                row = row < a.Tk ? row : a.Tk - 1;
+                const uint32_t cb = ld_c0 ^ (uint32_t)(nn * 32);
+                const uint32_t ko = (uint32_t)row * (uint32_t)(a.ldk * 4) + cb, vo = (uint32_t)row * (uint32_t)(a.ldv * 4) + cb;
+                const uint32_t piece = (uint32_t)(16 * wave + 8 * nn) * 128u;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    dma16a(rsK, ko, (uint32_t)p * 128u, __builtin_amdgcn_readfirstlane(dst + (uint32_t)p * PL + piece));
+                    dma16a(rsV, vo, (uint32_t)p * 128u, __builtin_amdgcn_readfirstlane(dst + TILE + (uint32_t)p * PL + piece));
+                }
+            }
+            if (wave < 2) {
+                int key = t * KT + lane;
+                key = key < a.Tk ? key : a.Tk - 1;
+                if (wave == 0) dma4a(rsKi, (uint32_t)key * 4u, __builtin_amdgcn_readfirstlane(dst + 2 * TILE));
+                else dma4a(rsVi, (uint32_t)key * 4u, __builtin_amdgcn_readfirstlane(dst + 2 * TILE + 256));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    const int fsw = isw(l31);
+    uint32_t k_off[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) k_off[st] = (uint32_t)(l31 * 128 + (((2 * st + half) ^ fsw) << 4));
+    const int q4 = (lane & 15) >> 2, pc = lane & 3, g16 = (lane >> 4) & 1;
+    uint32_t v_off[2][2];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int sc = 0; sc < 2; ++sc) {
+            const int r = 8 * sc + 4 * half + q4;
+            const int ch = 4 * i2 + 2 * g16 + (pc >> 1);
+            v_off[i2][sc] = (uint32_t)(TILE + r * 128 + ((ch ^ isw(r)) << 4) + (pc & 1) * 8);
+        }
+
+    // ---- every score of the row, key scales applied, masked
+    f32x16 s[4];
+    float mx = NEG_INF;
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[sb][r] = NEG_INF;
+        if (sb < nsub) {
+            const char* st_ = xs + (sb >> 1) * STG;
+            const int sub = sb & 1;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                f16x8v kf[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) kf[p] = *reinterpret_cast<const f16x8v*>(st_ + p * PL + sub * 4096 + k_off[st]);
+                mfma_h3(acc, kf, qf[st]);
+            }
+            const float* ki = reinterpret_cast<const float*>(st_ + 2 * TILE) + sub * 32 + 4 * half;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 f = *reinterpret_cast<const float4*>(ki + 8 * g4);
+                const float kf4[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    const float v = (sb * 32 + acc_row(r, half) < klen) ? acc[r] * kf4[e] : NEG_INF;
+                    s[sb][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_fin = (mx == NEG_INF) ? 0.f : mx;
+    const float mcs_fin = m_fin * c2_q;                // ONE rounded product per row, kept as it is (rowstat)
+    float l = 0.f;
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                 // exp2(-inf) = 0 for the masked keys
+            s[sb][r] = fast_exp2(__builtin_fmaf(s[sb][r], c2_q, -mcs_fin));
+            l += s[sb][r];
+        }
+    l = l + __shfl_xor(l, 32, 64);
+    const float inv_l = (l > 0.f) ? 1.f / l : 0.f;
+
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    const long arow = ((long)(b * a.H + h) * a.Tq);
+    const uint32_t rowid = (uint32_t)(arow + qg);
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+        if (sb >= nsub) break;
+        const char* st_ = xs + (sb >> 1) * STG;
+        const int sub = sb & 1, key0 = sb * 32;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = s[sb][r] * inv_l;
+        if (a.thr != 0u) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                const uint32_t qh = attn_quad_hash(seed_eff, rowid, (uint32_t)(key0 + acc_row(r, half)) >> 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[r + e] = attn_keep_word(qh, attn_drop_mult(e), thr16) ? p[r + e] * a.drop_scale : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[sb][r] = p[r];          // kept for the write-out below
+        const float* vi = reinterpret_cast<const float*>(st_ + 2 * TILE + 256) + sub * 32 + 4 * half;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const float4 f0 = *reinterpret_cast<const float4*>(vi + 16 * t2), f1 = *reinterpret_cast<const float4*>(vi + 16 * t2 + 8);
+            const float vf8[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = p[8 * t2 + e] * fminf(vf8[e] * (H3A_P * Ev), H3A_P);
+            f16x8v pf[2];
+            split_frag8_h3(x, 1.0f, pf[0], pf[1]);
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                f16x8v vf[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const char* vb = st_ + pl * PL + sub * 4096 + t2 * 2048;
+                    vf[pl] = join_tr(lds_tr4(vb + v_off[i2][0]), lds_tr4(vb + v_off[i2][1]));
+                }
+                mfma_h3(o[i2], vf, pf);
+            }
+        }
+    }
+
+    // ---- the weights leave as whole 128-byte row segments: every wave is done with K / V, so each turns its 32 x 32 tiles
+    // through the freed stage memory and stores 16 bytes per lane (8 lanes per row); rows of Tk floats are 16-byte aligned when
+    // Tk % 4 == 0, else the tail keys of a row go out one by one
+    __syncthreads();
+    const bool rows16 = (a.Tk & 3) == 0;
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+        if (sb >= nsub) break;
+        const int key0 = sb * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ptile[l31 * PT_LD + acc_row(r, half)] = s[sb][r];
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qr = 8 * i + (lane >> 3), k4 = (lane & 7) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(ptile + qr * PT_LD + k4);
+            const int q_g = qw0 + qr, key_g = key0 + k4;
+            if (q_g < a.Tq && key_g < a.Tk) {
+                float* dst = a.attn + (arow + q_g) * a.Tk + key_g;
+                if (rows16 && key_g + 3 < a.Tk) {
+                    *reinterpret_cast<float4*>(dst) = v;
+                } else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (key_g + e < a.Tk) dst[e] = vv[e];
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+
+    const float out_scale = inv_Ev * (1.0f / H3A_P);
+    if (a.lse != nullptr && half == 0 && qg < a.Tq) a.lse[arow + qg] = m_fin * c_q + __logf(l > 0.f ? l : 1.f);
+    if (a.rowstat != nullptr && half == 0 && qg < a.Tq) {
+        const long plane = (long)a.B * a.H * a.Tq;
+        a.rowstat[arow + qg] = mcs_fin;
+        a.rowstat[plane + arow + qg] = l > 0.f ? __log2f(l) : 0.f;
+        const float top = (mx == NEG_INF) ? 0.f : fast_exp2(__builtin_fmaf(mx, c2_q, -mcs_fin));
+        a.rowstat[2 * plane + arow + qg] = (l > 0.f && l == top) ? 1.f : 0.f;
+        a.rowstat[3 * plane + arow + qg] = c2_q;
+        a.rowstat[4 * plane + arow + qg] = c_q;
+    }
+    float omax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        o[0][r] *= out_scale; o[1][r] *= out_scale;
+        omax = fmaxf(omax, fmaxf(fabsf(o[0][r]), fabsf(o[1][r])));
+    }
+    if (a.o_amax != nullptr) amax_publish(qg < a.Tq ? omax : 0.f, a.o_amax, blockIdx.y * gridDim.x + blockIdx.x);
+    __syncthreads();                                   // every wave is done with K / V: the scratch aliases them
+    wave_store_rows4(o, scratch, a.o + (long)b * a.Tq * a.ldo + h * HD, qw0, a.Tq, a.ldo, lane);
+}
+
 // ===================================================================================== backward: dQ (+ delta)
 // One workgroup = 128 queries of a (batch, head); K / V tiles stream through the same two-stage ring as in the forward.  Per
 // 32-key sub-tile: S^T = K' Q'^T and dP^T = V' dO'^T (row reads), P from the forward's row statistics, dS = P (dP - delta), and
@@ -1026,6 +1269,8 @@ extern "C" int ttts_attention_fwd_img(const void* q, const void* k, const void* 
         hipLaunchKernelGGL((attn_fwd_img_kernel<true, false, TTTS_AIMG_KT>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else if (!attn)
         hipLaunchKernelGGL((attn_fwd_img_kernel<false, false, TTTS_AIMG_KT>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (Tk <= 128)
+        hipLaunchKernelGGL(attn_fwd_img_maps_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((attn_fwd_img_kernel<false, true, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);
     TTTS_LAUNCH_CHECK("attn_fwd_img_kernel");

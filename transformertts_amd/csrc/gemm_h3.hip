@@ -627,8 +627,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
 // Measured at M = 55 680, K = 256 (s_memtime, tools/h3_stamps.py): main loop 32.7k ticks per tile against 36.7k of the
 // 8-wave kernel (MFMA-bound: 22.1k); K >= 1024 and the convolutions gain 7-9 % per launch.
 // Requires K >= 96 (three k-tiles); dispatched for unshifted operands (T == 0) only, see h3_wide_supports.
+#ifdef TTTS_CLOCK_STAMPS
+__device__ unsigned long long ttts_clock_h3_wide[2 * 512];
+#endif
 template <bool CLIP>
 __global__ __launch_bounds__(256, 1) void gemm_h3_wide_kernel(GemmArgs g) {
+    TTTS_CLOCK_BEGIN();
     constexpr int BM = 256, BN = 256, WM = 2, WN = 2, NT = 256;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int A_PLANE = BM * 16, B_PLANE = BN * 16, STAGE = 2 * (A_PLANE + B_PLANE);      // dwords
@@ -850,6 +854,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h3_wide_kernel(GemmArgs g) {
         ++dbg_iter;
 #endif
     }
+    TTTS_CLOCK_END(ttts_clock_h3_wide, 512);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -1257,6 +1262,11 @@ extern "C" int ttts_amax_partials(const float* x, int64_t n, float* partials, vo
     return TTTS_OK;
 }
 
+#ifdef TTTS_CLOCK_STAMPS
+extern "C" int ttts_dbg_read_clock_h3_wide(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ttts::ttts_clock_h3_wide), n * sizeof(unsigned long long));
+}
+#endif
 #ifdef TTTS_EXP_STAMPS
 extern "C" int ttts_dbg_read_stamps(unsigned long long* host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ttts::ttts_dbg_stamps), n * sizeof(unsigned long long));

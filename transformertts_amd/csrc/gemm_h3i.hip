@@ -73,8 +73,12 @@ __device__ unsigned long long ttts_h3i_stamps[512 * 4 * 8];
 // IMG: the output leaves as a HEAD IMAGE (GemmArgs::c_row_inv): attention is the only reader of an in-projection's output, and it
 // wants f16 hi / lo planes it can stage by LDS-DMA -- the same 4 bytes per element as fp32, written here instead of fp32, with a
 // power-of-two scale per (row, 64-column head) because the tile owns whole head rows (bias only; no residual / gate / dropout).
+#ifdef TTTS_CLOCK_STAMPS
+__device__ unsigned long long ttts_clock_h3i[2 * 512];
+#endif
 template <bool A_RAW, bool HAS_RES, bool HAS_GATE, bool DROP, bool IMG = false>
 __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
+    TTTS_CLOCK_BEGIN();
 #ifdef TTTS_H3I_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long st_begin = ISTAMP();
@@ -484,6 +488,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
         IACC(3, ISTAMP() - s3); IACC(5, 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // requests made for a tile that does not exist must not outlive the wave
+    TTTS_CLOCK_END(ttts_clock_h3i, 512);
 #ifdef TTTS_H3I_STAMPS
     st_acc[4] = ISTAMP() - st_begin;
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 512)
@@ -606,6 +611,11 @@ static GemmArgs h3i_base_args() {
 
 using namespace ttts;
 
+#ifdef TTTS_CLOCK_STAMPS
+extern "C" int ttts_dbg_read_clock_h3i(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ttts::ttts_clock_h3i), n * sizeof(unsigned long long));
+}
+#endif
 #ifdef TTTS_H3I_STAMPS
 extern "C" int ttts_dbg_h3i_read_stamps(unsigned long long* host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ttts::ttts_h3i_stamps), n * sizeof(unsigned long long));

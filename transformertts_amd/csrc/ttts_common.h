@@ -187,6 +187,24 @@ __device__ __forceinline__ void h3_operand_scale(const float* __restrict__ parti
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---------------------------------------------------------------- in-kernel clock (diagnostic builds: -DTTTS_CLOCK_STAMPS)
+// The clock a kernel actually ran at = delta s_memtime (shader cycles) / delta s_memrealtime (100 MHz), stamped once around
+// the whole kernel by wave 0 of each workgroup (MI355X_MICROARCH.md, DVFS give-back item 6: board power and sysfs sclk are not
+// the test).  The values go to a buffer of their own that nothing else reads; tools/gemm_clock.py reports the median.
+#ifdef TTTS_CLOCK_STAMPS
+#define TTTS_CLOCK_BEGIN() const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime()
+#define TTTS_CLOCK_END(buf, cap)                                                                                        \
+    do {                                                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < (cap)) {                                                                   \
+            (buf)[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_c0;                                              \
+            (buf)[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;                                      \
+        }                                                                                                               \
+    } while (0)
+#else
+#define TTTS_CLOCK_BEGIN()
+#define TTTS_CLOCK_END(buf, cap)
+#endif
+
 // ---------------------------------------------------------------- split precision (bf16 x 3)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
