@@ -257,7 +257,8 @@ def test_fp16x3_data_gradient_with_dynamic_scale(M, N, K, mag):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1024, 256), (777, 256, 1024), (129, 80, 256), (4000, 256, 80),
-                                   (25630, 768, 256), (25610, 300, 1024)])     # long row ranges: the 8-wave 256-wide tile
+                                   (25630, 768, 256), (25610, 300, 1024),      # long row ranges: the 8-wave 256-wide tile
+                                   (25990, 512, 512), (26001, 256, 768)])      # ... whole 256 x 256 tiles: rows by LDS-DMA (wgrad_dma.hip)
 @pytest.mark.parametrize("mag", [1.0, 3e-7])
 def test_fp16x3_weight_gradient(M, N, K, mag):
     """dW = dy^T x and db = column sums of dy in the fp16x3 form (dynamic pre-scale of dy, 32-row k-steps), stored and
@@ -293,7 +294,8 @@ def test_fp16x3_weight_gradient(M, N, K, mag):
 
 
 @pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128), (6, 45, 80, 256), (6, 45, 256, 80),
-                                          (30, 870, 256, 256)])                # five taps x one 256-wide tile
+                                          (30, 870, 256, 256),                 # five taps x one 256-wide tile (rows by LDS-DMA)
+                                          (31, 833, 512, 256), (1600, 16, 256, 256)])   # ... utterances of exactly one step
 def test_fp16x3_conv_weight_gradient(B, T, cin, cout):
     from transformertts_amd import _lib, ops
     from transformertts_amd.ops import _p, _stream

@@ -264,6 +264,9 @@ int dispatch_h3(const GemmArgs& g, hipStream_t stream);
 // row-chunk partials the fp16x3 forward writes into GemmArgs::bn_ws for an M x N x K problem (0: its tile shape cannot)
 int h3_bn_blocks(long M, long N, long K);
 int dispatch_wgrad_h3(const GemmArgs& g, int zdim, int tile, hipStream_t stream);
+// the same problem with LDS-DMA staged operand rows (wgrad_dma.hip): whole 256 x 256 tiles only
+bool wgrad_dma_supports(const GemmArgs& g, int tile);
+int launch_wgrad_dma(const GemmArgs& g, int zdim, hipStream_t stream);
 // image-operand fp16x3 GEMM (gemm_h3i.hip): both operands staged by LDS-DMA, 128 x 256 tile, two workgroups per CU
 bool h3i_supports(const GemmArgs& g);
 int dispatch_h3i(const GemmArgs& g, hipStream_t stream);

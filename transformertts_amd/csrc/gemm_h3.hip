@@ -1238,7 +1238,13 @@ static int launch_wgrad_h3(const GemmArgs& g, int zdim, hipStream_t stream) {
     return TTTS_OK;
 }
 
+// TTTS_WGRAD_DMA (compile-time, for same-box A/B builds): 0 = the register-turning kernel everywhere
+#ifndef TTTS_WGRAD_DMA
+#define TTTS_WGRAD_DMA 1
+#endif
+
 int dispatch_wgrad_h3(const GemmArgs& g, int zdim, int tile, hipStream_t stream) {
+    if (TTTS_WGRAD_DMA && wgrad_dma_supports(g, tile)) return launch_wgrad_dma(g, zdim, stream);
     switch (tile) {
         case TILE_64: return launch_wgrad_h3<64, 64, 2, 2>(g, zdim, stream);
         case TILE_128x96: return launch_wgrad_h3<128, 96, 4, 1>(g, zdim, stream);
