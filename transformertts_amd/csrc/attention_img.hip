@@ -658,36 +658,56 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_img_maps_kernel(AttnImgArgs a
         }
     }
 
-    // ---- the weights leave as whole 128-byte row segments: every wave is done with K / V, so each turns its 32 x 32 tiles
-    // through the freed stage memory and stores 16 bytes per lane (8 lanes per row); rows of Tk floats are 16-byte aligned when
-    // Tk % 4 == 0, else the tail keys of a row go out one by one
-    __syncthreads();
+    // ---- the weights: a workgroup's 128 queries x Tk keys are ONE contiguous block of the map (rows of Tk floats follow each
+    // other), so with 16-byte rows (Tk % 4 == 0) the block is assembled in the freed stage memory exactly as it lies in memory
+    // (a lane writes its four consecutive keys of a query as one 16-byte piece) and leaves as a linear copy: every store
+    // instruction writes 1 KB of consecutive bytes.  (Storing the 32 x 32 tiles directly put 128-byte segments at a 400-byte
+    // stride: 1.8 TB/s.)  Other Tk: the tiles go out row by row, tail keys one by one.
+    __syncthreads();                                   // every wave is done with K / V
     const bool rows16 = (a.Tk & 3) == 0;
+    if (rows16) {
+        float* blk = reinterpret_cast<float*>(xs);     // [128 queries][Tk]
+        static_assert(QB * 128 * 4 <= XS, "the block of weights fits the stages");
+        const int q_l = wave * 32 + l31;
 #pragma unroll
-    for (int sb = 0; sb < 4; ++sb) {
-        if (sb >= nsub) break;
-        const int key0 = sb * 32;
+        for (int sb = 0; sb < 4; ++sb) {
+            if (sb >= nsub) break;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ptile[l31 * PT_LD + acc_row(r, half)] = s[sb][r];
-        wave_lds_sync();
+            for (int r = 0; r < 16; r += 4) {
+                const int key = sb * 32 + acc_row(r, half);
+                if (key < a.Tk)
+                    *reinterpret_cast<float4*>(blk + q_l * a.Tk + key) = make_float4(s[sb][r], s[sb][r + 1], s[sb][r + 2], s[sb][r + 3]);
+            }
+        }
+        __syncthreads();
+        const int q0 = blockIdx.y * QB;
+        const int nq = (a.Tq - q0) < QB ? (a.Tq - q0) : QB;
+        const int n4 = nq * (a.Tk >> 2);
+        float4* dst = reinterpret_cast<float4*>(a.attn + (arow + q0) * a.Tk);
+        for (int i = tid; i < n4; i += 256) dst[i] = reinterpret_cast<const float4*>(blk)[i];
+    } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int qr = 8 * i + (lane >> 3), k4 = (lane & 7) * 4;
-            const float4 v = *reinterpret_cast<const float4*>(ptile + qr * PT_LD + k4);
-            const int q_g = qw0 + qr, key_g = key0 + k4;
-            if (q_g < a.Tq && key_g < a.Tk) {
-                float* dst = a.attn + (arow + q_g) * a.Tk + key_g;
-                if (rows16 && key_g + 3 < a.Tk) {
-                    *reinterpret_cast<float4*>(dst) = v;
-                } else {
+        for (int sb = 0; sb < 4; ++sb) {
+            if (sb >= nsub) break;
+            const int key0 = sb * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ptile[l31 * PT_LD + acc_row(r, half)] = s[sb][r];
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int qr = 8 * i + (lane >> 3), k4 = (lane & 7) * 4;
+                const float4 v = *reinterpret_cast<const float4*>(ptile + qr * PT_LD + k4);
+                const int q_g = qw0 + qr, key_g = key0 + k4;
+                if (q_g < a.Tq && key_g < a.Tk) {
+                    float* dst = a.attn + (arow + q_g) * a.Tk + key_g;
                     const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (key_g + e < a.Tk) dst[e] = vv[e];
                 }
             }
+            wave_lds_sync();
         }
-        wave_lds_sync();
     }
 
     const float out_scale = inv_Ev * (1.0f / H3A_P);
