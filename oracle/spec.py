@@ -44,6 +44,15 @@ CONFIGS = {
         decoder_n_head=2, decoder_d_ffn=64, decoder_dropout=0.1,
         postnet_n_layers=3, postnet_kernel_size=5, postnet_dropout=0.5,
         d_model=32, n_phon=20, n_mels=16),
+    # heads wider than the kernels' 64 columns (head_dim 128): the tensor-algebra attention path
+    "tiny1h": dict(
+        encoder_prenet_n_layers=2, encoder_prenet_in_channel=128,
+        encoder_prenet_out_channel=128, encoder_prenet_kernel_size=5,
+        encoder_prenet_dropout=0.5, encoder_n_layers=1, encoder_n_head=1,
+        encoder_d_ffn=256, encoder_dropout=0.1, decoder_n_layers=2,
+        decoder_n_head=1, decoder_d_ffn=256, decoder_dropout=0.1,
+        postnet_n_layers=3, postnet_kernel_size=5, postnet_dropout=0.5,
+        d_model=128, n_phon=30, n_mels=16),
     "scaled": dict(
         encoder_prenet_n_layers=3, encoder_prenet_in_channel=512,
         encoder_prenet_out_channel=512, encoder_prenet_kernel_size=5,

@@ -75,6 +75,7 @@ def _oracle64(cfg, w_seed):
                                                             ("base", 4, 100, 870, 13, 23), ("scaled", 2, 60, 300, 14, 24),
                                                             ("base", 16, 100, 870, 15, 25),
                                                             ("micro", 3, 12, 40, 16, 26),       # d_model 32, head_dim 16
+                                                            ("tiny1h", 3, 12, 40, 18, 28),      # d_model 128, ONE head of 128 columns
                                                             # utterances far beyond LJSpeech's longest (870 frames): 24
                                                             # query blocks, 47 key tiles, 3000 rows of the 5000-row pe table
                                                             ("base", 2, 200, 3000, 17, 27)])
@@ -546,6 +547,19 @@ def test_inference_kv_cache_vs_recompute_vs_oracle(golden_dir):
     # early stop: a threshold every item passes at once ends the loop after the first frame
     one = m.inference(ph, pl, max_len=L, stop_threshold=0.0)
     assert one["pred_melspec"].shape[1] == 1 and one["pred_stop"].shape[1] == 1
+
+
+def test_inference_with_heads_wider_than_64():
+    """`inference()` of a model whose heads are 128 columns wide (tensor-algebra attention, the recompute loop: the incremental
+    kernels read 64-wide heads) against the oracle loop in fp64."""
+    from oracle import synth_batch, oracle_inference
+    cfg, m = _build("tiny1h", 31)
+    batch = synth_batch(2, 12, 40, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=32)
+    ph, pl = batch["phoneme"].to("cuda"), batch["phoneme_lens"].to("cuda")
+    out = m.inference(ph, pl, max_len=10, stop_threshold=2.0)
+    ref = oracle_inference(_oracle64(cfg, 31), cfg, batch["phoneme"], batch["phoneme_lens"], max_len=10, stop_threshold=2.0)
+    for k in ("pred_melspec", "post_melspec", "pred_stop"):
+        assert out[k].shape == tuple(ref[k].shape) and rel_l2(out[k], ref[k]) < GATE, (k, rel_l2(out[k], ref[k]))
 
 
 @pytest.mark.parametrize("which", ["decoder", "encoder"])

@@ -181,10 +181,10 @@ def test_layernorm_backward_with_fused_dropout_backward(M, d):
 
 
 def _ref_attention(q, k, v, lens, causal):
-    """q,k,v (B,H,T,64) fp64; q.k^T with q pre-scaled by sqrt(1/64); -inf masks; softmax; weights @ v"""
+    """q,k,v (B,H,T,head_dim) fp64; q.k^T with q pre-scaled by sqrt(1/head_dim); -inf masks; softmax; weights @ v"""
     B, H, Tq, _ = q.shape
     Tk = k.shape[2]
-    s = (q * math.sqrt(1.0 / 64)) @ k.transpose(-1, -2)
+    s = (q * math.sqrt(1.0 / q.shape[-1])) @ k.transpose(-1, -2)
     dead = torch.arange(Tk).view(1, 1, 1, Tk) >= lens.view(B, 1, 1, 1)
     if causal:
         dead = dead | torch.triu(torch.ones(Tq, Tk, dtype=torch.bool), diagonal=1).view(1, 1, Tq, Tk)
@@ -291,6 +291,53 @@ def test_attention_on_random_shapes():
                 assert rel_l2(qg.grad, qd.grad) < TOL, ("cross dq", B, H, Tq, Tk, lens, need_w)
             if need_w:
                 assert rel_l2(attn, a) < TOL
+
+
+@pytest.mark.parametrize("hd", [128, 192])
+def test_attention_with_heads_wider_than_64(hd):
+    """head_dim > 64 (the reference takes any nhead: /root/reference/model/model.py:139-161): ops.self_attention /
+    cross_attention run as tensor algebra on library GEMMs (ops._attention_wide_heads) with the conventions of the kernels --
+    ragged key lengths, causal mask, weights returned, an utterance without keys gives zeros -- forward, weights and every
+    gradient against fp64; with dropout the weights are the dropped ones (as the kernels return them)."""
+    from transformertts_amd import ops
+    dev = _dev()
+    for case, (B, H, Tq, Tk, causal, lens) in enumerate([(2, 2, 70, 70, True, [70, 13]), (3, 1, 33, 33, False, [33, 1, 20]),
+                                                         (2, 2, 50, 19, False, [19, 7]), (2, 1, 5, 9, False, [9, 0])]):
+        d = H * hd
+        lens_t = torch.tensor(lens, dtype=torch.int64)
+        if Tq == Tk:
+            qkv, do = _rand(B, Tq, 3 * d, seed=case), _rand(B, Tq, d, seed=50 + case)
+            qd = qkv.double().requires_grad_()
+            q, k, v = [t.view(B, Tq, H, hd).transpose(1, 2) for t in qd.split(d, dim=-1)]
+            ref = _ref_attention(q, k, v, lens_t, causal)[0].transpose(1, 2).reshape(B, Tq, d)
+            ref.backward(do.double())
+            qg = _g(qkv)
+            out = ops.self_attention(qg, lens_t.to(dev), H, causal, 0.0, 0)
+            out.backward(do.to(dev))
+            assert rel_l2(out, ref) < TOL and rel_l2(qg.grad, qd.grad) < TOL, ("self", hd, B, H, Tq, causal, lens)
+        else:
+            q_, kv_, do = _rand(B, Tq, d, seed=60 + case), _rand(B, Tk, 2 * d, seed=70 + case), _rand(B, Tq, d, seed=80 + case)
+            qd, kvd = q_.double().requires_grad_(), kv_.double().requires_grad_()
+            qq = qd.view(B, Tq, H, hd).transpose(1, 2)
+            kk, vv = [t.view(B, Tk, H, hd).transpose(1, 2) for t in kvd.split(d, dim=-1)]
+            o, a = _ref_attention(qq, kk, vv, lens_t, False)
+            ref = o.transpose(1, 2).reshape(B, Tq, d)
+            if min(lens) == 0:                       # an utterance without keys: zeros (the reference softmax has no answer there)
+                live = (lens_t > 0).double()
+                ref, a = torch.nan_to_num(ref) * live[:, None, None], torch.nan_to_num(a) * live[:, None, None, None]
+            ref.backward(do.double())
+            qg, kvg = _g(q_), _g(kv_)
+            out, attn = ops.cross_attention(qg, kvg, lens_t.to(dev), H, 0.0, 0, True)
+            out.backward(do.to(dev))
+            assert torch.isfinite(out).all() and torch.isfinite(qg.grad).all() and torch.isfinite(kvg.grad).all()
+            assert rel_l2(out, ref) < TOL and rel_l2(attn, a) < TOL, ("cross", hd, B, H, Tq, Tk, lens)
+            if min(lens) > 0:
+                assert rel_l2(qg.grad, qd.grad) < TOL and rel_l2(kvg.grad, kvd.grad) < TOL
+    # dropout: the returned weights are the dropped ones, rescaled; about p of them are zero
+    q_, kv_ = _rand(2, 40, 2 * hd, seed=91), _rand(2, 30, 4 * hd, seed=92)
+    out, attn = ops.cross_attention(q_.to(dev), kv_.to(dev), torch.tensor([30, 30], device=dev), 2, 0.25, 7, True)
+    zero = float((attn == 0).float().mean())
+    assert 0.2 < zero < 0.3 and abs(float(attn.sum(-1).mean()) - 1.0) < 0.05
 
 
 def test_fanout_sums_consumer_gradients_in_one_launch():

@@ -30,13 +30,13 @@ def _lens_from_kpm(kpm: Optional[Tensor], B: int, T: int, device) -> Tensor:
 
 
 class MultiheadAttention(nn.Module):
-    """Parameter layout of nn.MultiheadAttention (packed in-proj, `out_proj` sub-module); head_dim <= 64."""
+    """Parameter layout of nn.MultiheadAttention (packed in-proj, `out_proj` sub-module).  Heads of 64 columns run on the
+    head-image kernels, narrower ones on the padded fp32 kernels, wider ones as tensor algebra (ops._attention_wide_heads)."""
 
     def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0.0):
         super().__init__()
-        if num_heads <= 0 or embed_dim % num_heads != 0 or embed_dim // num_heads > 64:
-            raise ValueError("MultiheadAttention: embed_dim must be divisible by num_heads with head_dim <= 64 (the gfx950 "
-                             "attention kernels work on 64-column heads; narrower heads are zero-padded)")
+        if num_heads <= 0 or embed_dim % num_heads != 0:
+            raise ValueError("MultiheadAttention: embed_dim must be divisible by num_heads")
         self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
         self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
         self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))

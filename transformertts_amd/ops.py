@@ -1243,13 +1243,46 @@ def _off(t: torch.Tensor, col: int):
 
 
 def _head_dim(d: int, n_head: int) -> int:
-    """Columns per head; the kernels work on 64-column heads and narrower ones are zero-padded to 64 (`_pad_heads`)."""
+    """Columns per head; the kernels work on 64-column heads and narrower ones are zero-padded to 64 (`_pad_heads`); wider
+    heads do not reach them (`_attention_wide_heads`)."""
     if n_head <= 0 or d % n_head != 0:
         raise ValueError(f"attention: d_model {d} is not divisible by {n_head} heads")
     hd = d // n_head
     if hd > 64:
         raise ValueError(f"attention kernels take head_dim <= 64 (d_model {d}, heads {n_head}: head_dim {hd})")
     return hd
+
+
+def _wide_heads(d: int, n_head: int) -> bool:
+    if n_head <= 0 or d % n_head != 0:
+        raise ValueError(f"attention: d_model {d} is not divisible by {n_head} heads")
+    return d // n_head > 64
+
+
+def _attention_wide_heads(q, k, v, lens, n_head: int, causal: bool, drop_p: float):
+    """Heads wider than 64 columns (the reference takes any `nhead`, model/model.py:139-161; no BASELINE configuration has
+    them): the hand-written kernels hold a 64-column head per fragment set, so this shape runs as plain tensor algebra on the
+    library's fp32 GEMMs -- same masks (keys past `lens`, causal), same conventions as the kernels (weights returned AFTER
+    dropout, rows without a live key give zeros), differentiated by autograd.  Correct, not tuned."""
+    B, Tq, d = q.shape
+    Tk = k.shape[1]
+    hd = d // n_head
+    qh = q.reshape(B, Tq, n_head, hd).transpose(1, 2)
+    kh = k.reshape(B, Tk, n_head, hd).transpose(1, 2)
+    vh = v.reshape(B, Tk, n_head, hd).transpose(1, 2)
+    s = torch.matmul(qh * hd ** -0.5, kh.transpose(-1, -2))                      # (B, H, Tq, Tk)
+    key = torch.arange(Tk, device=q.device)
+    dead = key[None, :] >= lens.to(q.device)[:, None]                             # (B, Tk)
+    big = torch.finfo(torch.float32).min
+    s = s.masked_fill(dead[:, None, None, :], big)                                # finite: no NaN in either direction
+    if causal:
+        s = s.masked_fill((key[None, :] > torch.arange(Tq, device=q.device)[:, None])[None, None], big)
+    p = torch.softmax(s, dim=-1)
+    p = p * (~dead)[:, None, None, :].to(p.dtype)                                 # (an utterance without keys: zeros, not 1 / Tk)
+    if drop_p > 0:
+        p = torch.nn.functional.dropout(p, drop_p, True)
+    o = torch.matmul(p, vh).transpose(1, 2).reshape(B, Tq, d)
+    return o, p
 
 
 def _pad_heads(src: torch.Tensor, col0: int, ld: int, rows: int, H: int, hd: int) -> torch.Tensor:
@@ -1512,6 +1545,9 @@ class CrossAttentionFn(torch.autograd.Function):
 def self_attention(qkv, lens, n_head: int, causal: bool, drop_p: float, seed: int):
     """Self-attention over a packed in-projection output; the partial maxima of `qkv` ride on it when its producer left
     them (`linear(..., publish_amax=True)`), and the context leaves with its own for the out-projection."""
+    d = qkv.shape[-1] // 3
+    if _wide_heads(d, n_head):
+        return _attention_wide_heads(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], lens, n_head, causal, drop_p)[0]
     himg = getattr(qkv, "_ttts_himg", None)
     if himg is not None:                       # the in-projection left a head image: the LDS-DMA kernels
         o_am = _amax_slots(qkv.device, True)
@@ -1528,6 +1564,10 @@ def self_attention(qkv, lens, n_head: int, causal: bool, drop_p: float, seed: in
 
 
 def cross_attention(q, kv, lens, n_head: int, drop_p: float, seed: int, need_weights: bool = True):
+    d = q.shape[-1]
+    if _wide_heads(d, n_head):
+        o, attn = _attention_wide_heads(q, kv[..., :d], kv[..., d:], lens, n_head, False, drop_p)
+        return o, (attn if need_weights else None)
     qi, kvi = getattr(q, "_ttts_himg", None), getattr(kv, "_ttts_himg", None)
     if (qi is None) != (kvi is None):
         raise ValueError("cross_attention: q and kv must both be head images or both fp32")

@@ -26,6 +26,7 @@ CONFIGS = {
     "scaled": _cfg(512, 8, 6, 2048),
     "tiny": dict(_cfg(128, 2, 1, 256, prenet_layers=2, post_layers=3, n_phon=30, n_mels=16), decoder_n_layers=2),
     "micro": _cfg(32, 2, 1, 64, prenet_layers=2, post_layers=3, n_phon=20, n_mels=16),      # head_dim 16 (SURVEY 8c's tiny golden)
+    "tiny1h": dict(_cfg(128, 1, 1, 256, prenet_layers=2, post_layers=3, n_phon=30, n_mels=16), decoder_n_layers=2),   # head_dim 128
 }
 
 
