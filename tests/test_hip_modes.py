@@ -498,15 +498,19 @@ def test_fp16x3_weight_images_bit_exact():
              (_rand(256, 80, 5, seed=14), 7), (_rand(48, 36, 9, seed=15) * 3e4, 6), (_rand(48, 36, 9, seed=16), 7),
              (_rand(40, 12, 3, seed=17), 6), (_rand(40, 12, 1, seed=18), 7),
              (big[1:].view(1024, 320), 4), (big[1:].view(1024, 64, 5), 7)]          # data_ptr % 16 == 4
+    # the images of ONE weight, adjacent in the table as ops.PlaneTable lists them: the batched refresh measures max|w| once (the
+    # first entry) and the others copy it -- forward / data-gradient, row-major / K16-major (modes 8, 9: against the single entry point)
+    shared, shared_c = _rand(512, 256, seed=20) * 7.0, _rand(96, 64, 5, seed=21) * 1e-3
+    specs += [(shared, 5), (shared, 4), (shared, 9), (shared, 8), (shared_c, 7), (shared_c, 6)]
     imgs, rows, blk = [], [], 0
     for w, mode in specs:
-        if mode == 4: R, C, c2, taps = w.shape[0], w.shape[1], 0, 0
-        elif mode == 5: R, C, c2, taps = w.shape[1], w.shape[0], 0, 0
+        if mode in (4, 8): R, C, c2, taps = w.shape[0], w.shape[1], 0, 0
+        elif mode in (5, 9): R, C, c2, taps = w.shape[1], w.shape[0], 0, 0
         elif mode == 6: R, C, c2, taps = w.shape[0], w.shape[1] * w.shape[2], w.shape[1], w.shape[2]
         else: R, C, c2, taps = w.shape[1], w.shape[0] * w.shape[2], w.shape[0], w.shape[2]
         amax = w.abs().max().item()
         k = 11 - int(np.floor(np.log2(amax)))
-        ref, Rr, Cp = _h3_image_ref(w, mode, k)
+        ref, Rr, Cp = _h3_image_ref(w, mode - 4 if mode >= 8 else mode, k)
         assert Rr == R and lib.ttts_split_image_bytes(R, C, mode, c2, taps) == 4 * R * Cp + 16
         a = torch.full((2 * R * Cp + 8,), 0x7e00, dtype=torch.int16, device=_dev())
         b = torch.full_like(a, 0x7e00)
@@ -518,8 +522,11 @@ def test_fp16x3_weight_images_bit_exact():
     assert lib.ttts_weight_split_batched(_p(table), len(rows), blk, _stream()) == 0
     torch.cuda.synchronize()
     for a, b, ref, amax, what in imgs:
+        n_img = ref.numel() + 2                                 # planes + the float that holds max|w| (the rest of the tail is padding)
+        assert torch.equal(a[:n_img], b[:n_img]), what          # single and batched entry points: the same bits
         for img in (a, b):
-            assert torch.equal(img[: ref.numel()], ref), what
+            if what[1] < 8:                                     # (the K16-major layouts hold the same values in another order)
+                assert torch.equal(img[: ref.numel()], ref), what
             assert img[ref.numel():ref.numel() + 2].view(torch.float32).item() == amax, what
 
 

@@ -439,10 +439,24 @@ __global__ __launch_bounds__(256) void weight_tail_zero_batched_kernel(const lon
         }
     }
 }
+// The images of ONE weight (forward / data-gradient, row-major / K16-major: up to four table entries, adjacent because the table
+// is built parameter by parameter) share max|w|: the first of them -- the leader -- measures it, the others copy it while they
+// are split (weight_split_batched_kernel).  Same source address and element count = same tensor.
+__device__ __forceinline__ const long* batched_leader(const long* __restrict__ descs, const long* d) {
+    const long* l = d;
+    while (l > descs && (l - 8)[0] == d[0] && (l - 8)[2] * (l - 8)[3] == d[2] * d[3] && (l - 8)[4] >= 4) l -= 8;
+    return l;
+}
+__device__ __forceinline__ const float* batched_tail(const long* d) {
+    const bool conv = h3_mode_base(d[4]) >= 2;
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(d[1]) +
+                                          h3_plane_bytes(d[2], h3_image_cols(d[3], conv ? (int)d[5] : 0, conv ? (int)d[6] : 0)));
+}
+
 __global__ __launch_bounds__(256) void weight_amax_batched_kernel(const long* __restrict__ descs, int n) {
     const long blk = blockIdx.x;
     const long* d = batched_desc(descs, n, blk);
-    if (d[4] >= 4) {
+    if (d[4] >= 4 && batched_leader(descs, d) == d) {
         const bool conv = h3_mode_base(d[4]) >= 2;
         weight_amax_h3_unit(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
                             h3_image_cols(d[3], conv ? (int)d[5] : 0, conv ? (int)d[6] : 0), blk - d[7],
@@ -454,10 +468,13 @@ __global__ __launch_bounds__(256) void weight_split_batched_kernel(const long* _
     __shared__ float t[H3_SPLIT_TAPS][32][33];
     const long blk = blockIdx.x;
     const long* d = batched_desc(descs, n, blk);
-    if (d[4] >= 4)      // modes 4-7: the fp16x3 image of modes 0-3 (block-uniform branch), a 32 x 32 tile per workgroup
+    if (d[4] >= 4) {    // modes 4-7: the fp16x3 image of modes 0-3 (block-uniform branch), a 32 x 32 tile per workgroup
+        const long* lead = batched_leader(descs, d);
+        const float* amax = batched_tail(lead);
+        if (lead != d && blk == d[7] && threadIdx.x == 0) *const_cast<float*>(batched_tail(d)) = *amax;      // the GEMMs read the image's own tail
         weight_split_h3_tile(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2],
-                             (int)d[3], h3_mode_base(d[4]), (int)d[5], (int)d[6], blk - d[7], t, h3_mode_k16(d[4]));
-    else
+                             (int)d[3], h3_mode_base(d[4]), (int)d[5], (int)d[6], blk - d[7], t, h3_mode_k16(d[4]), amax);
+    } else
         weight_split_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
                          (int)d[4], (int)d[5], (int)d[6], (blk - d[7]) * 256 + threadIdx.x);
 }

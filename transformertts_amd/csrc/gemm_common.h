@@ -193,7 +193,7 @@ __device__ __forceinline__ void weight_amax_h3_unit(const float* __restrict__ w,
 // k-tile in ONE contiguous run of whole 128-byte lines.  Same bytes, same padding, same tail.
 __device__ __forceinline__ void weight_split_h3_tile(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
                                                      int C, int mode, int c2, int taps, long unit, float (*t)[32][33],
-                                                     bool k16 = false) {
+                                                     bool k16 = false, const float* amax = nullptr) {
     const int chans = mode >= 2 ? c2 : C;
     if (mode < 2) taps = 1;
     const int ngc = (chans + 31) / 32;
@@ -201,7 +201,8 @@ __device__ __forceinline__ void weight_split_h3_tile(const float* __restrict__ w
     const int nr = min(32, R - r0), nc = min(32, chans - ch0);
     const int padc = h3_pad32(chans);
     float w_scale, w_inv;
-    h3_pow2_scale(*h3_plane_tail(planes, R, (long)taps * padc), w_scale, w_inv);
+    // (amax: where max|w| stands when it is not this image's own tail -- the batched refresh measures a weight once for all its images)
+    h3_pow2_scale(amax != nullptr ? *amax : *h3_plane_tail(planes, R, (long)taps * padc), w_scale, w_inv);
     const int tid = threadIdx.x;
     for (int tc0 = 0; tc0 < taps; tc0 += H3_SPLIT_TAPS) {
         const int tcn = min(H3_SPLIT_TAPS, taps - tc0), run = 32 * tcn;
