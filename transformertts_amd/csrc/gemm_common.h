@@ -142,16 +142,19 @@ __device__ __forceinline__ void image_emit_row(const float4 (&o)[NV], int lane, 
     if (lane == 0) row_inv[row] = inv;
 }
 
-// ---- the split of one weight into its fp16x3 image, in WORK UNITS of one 256-thread workgroup each: unit u is the 32-row x
-// 32-channel tile (row block u / channel blocks, channel block u % channel blocks) of the weight, all taps of it.
+// ---- the split of one weight into its fp16x3 image, in WORK UNITS of one 256-thread workgroup each: unit u is a run of
+// H3_SPLIT_RUN 32-row x 32-channel tiles along the channels (row block u / channel runs, channel run u % channel runs) of the
+// weight, all taps of them.  (One tile per workgroup made the batched refresh a latency chain per workgroup -- table
+// bisection, tail, tile -- of 23 000 workgroups: 75 us per step for 190 MB.)
 // h3_split_units = how many an entry has (host and device agree: the prefix sums of the batched table are built from it).
 // ttts_weight_split modes 4-7 and 8-11 are the fp16x3 images of modes 0-3: base = which matrix, k16 = which layout
 __host__ __device__ __forceinline__ int h3_mode_base(long mode) { return (int)((mode - 4) & 3); }
 __host__ __device__ __forceinline__ bool h3_mode_k16(long mode) { return mode >= 8; }
-constexpr int H3_SPLIT_TAPS = 8;        // taps staged per pass of a tile (longer kernels take several passes)
+constexpr int H3_SPLIT_TAPS = 4;        // taps staged per pass of a tile (longer kernels take several passes; 17 KB of LDS: 8 workgroups per CU)
+constexpr int H3_SPLIT_RUN = 4;         // 32-channel tiles per work unit
 __host__ __device__ __forceinline__ long h3_split_units(long R, long C, int mode, int c2) {
     const long chans = (mode & 3) >= 2 ? c2 : C;
-    return ((R + 31) / 32) * ((chans + 31) / 32);
+    return ((R + 31) / 32) * (((chans + 31) / 32 + H3_SPLIT_RUN - 1) / H3_SPLIT_RUN);
 }
 
 // |w| maximum of one weight into the tail of its plane image (atomic max on the bit pattern; the tail was zeroed first).
@@ -196,14 +199,17 @@ __device__ __forceinline__ void weight_split_h3_tile(const float* __restrict__ w
                                                      bool k16 = false, const float* amax = nullptr) {
     const int chans = mode >= 2 ? c2 : C;
     if (mode < 2) taps = 1;
-    const int ngc = (chans + 31) / 32;
-    const int r0 = (int)(unit / ngc) * 32, ch0 = (int)(unit % ngc) * 32;
-    const int nr = min(32, R - r0), nc = min(32, chans - ch0);
+    const int ngc = (chans + 31) / 32, nrun = (ngc + H3_SPLIT_RUN - 1) / H3_SPLIT_RUN;
+    const int r0 = (int)(unit / nrun) * 32, cb0 = (int)(unit % nrun) * H3_SPLIT_RUN;
+    const int nr = min(32, R - r0);
     const int padc = h3_pad32(chans);
     float w_scale, w_inv;
     // (amax: where max|w| stands when it is not this image's own tail -- the batched refresh measures a weight once for all its images)
     h3_pow2_scale(amax != nullptr ? *amax : *h3_plane_tail(planes, R, (long)taps * padc), w_scale, w_inv);
     const int tid = threadIdx.x;
+    for (int cb = cb0; cb < cb0 + H3_SPLIT_RUN && cb < ngc; ++cb) {
+    const int ch0 = cb * 32;
+    const int nc = min(32, chans - ch0);
     for (int tc0 = 0; tc0 < taps; tc0 += H3_SPLIT_TAPS) {
         const int tcn = min(H3_SPLIT_TAPS, taps - tc0), run = 32 * tcn;
         if (mode == 0) {
@@ -248,6 +254,7 @@ __device__ __forceinline__ void weight_split_h3_tile(const float* __restrict__ w
             }
         }
         __syncthreads();
+    }
     }
 }
 
