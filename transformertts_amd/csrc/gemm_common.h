@@ -207,6 +207,38 @@ __device__ __forceinline__ void weight_split_h3_tile(const float* __restrict__ w
     // (amax: where max|w| stands when it is not this image's own tail -- the batched refresh measures a weight once for all its images)
     h3_pow2_scale(amax != nullptr ? *amax : *h3_plane_tail(planes, R, (long)taps * padc), w_scale, w_inv);
     const int tid = threadIdx.x;
+    if (mode == 0 && (C & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        // a linear weight in its own orientation: image rows are weight rows, so a lane's four channels are one 16-byte load and
+        // nothing has to turn in LDS; the run's loads are all requested before the first conversion
+        const int rr = tid >> 3, q = (tid & 7) * 4;
+        float4 v4[H3_SPLIT_RUN];
+#pragma unroll
+        for (int u = 0; u < H3_SPLIT_RUN; ++u) {
+            const int c = (cb0 + u) * 32 + q;
+            v4[u] = (rr < nr && c < C) ? *reinterpret_cast<const float4*>(w + (long)(r0 + rr) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < H3_SPLIT_RUN; ++u) {
+            const int cp = (cb0 + u) * 32 + q;
+            if (rr < nr && cb0 + u < ngc) {
+                const float vv[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+                unsigned short h[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = vv[e] * w_scale;
+                    const _Float16 hh = (_Float16)v;
+                    const _Float16 ll = (_Float16)(v - (float)hh);
+                    h[e] = __builtin_bit_cast(unsigned short, hh);
+                    l[e] = __builtin_bit_cast(unsigned short, ll);
+                }
+                const long o = k16 ? ((long)(cp >> 4) * R + r0 + rr) * 32 + (cp & 15) : ((long)(cp >> 5) * 2 * R + r0 + rr) * 32 + (cp & 31);
+                *reinterpret_cast<uint2*>(planes + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+                *reinterpret_cast<uint2*>(planes + o + (k16 ? 16L : (long)R * 32)) =
+                    make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+            }
+        }
+        return;
+    }
     for (int cb = cb0; cb < cb0 + H3_SPLIT_RUN && cb < ngc; ++cb) {
     const int ch0 = cb * 32;
     const int nc = min(32, chans - ch0);
