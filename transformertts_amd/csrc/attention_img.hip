@@ -890,21 +890,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_img_kernel(AttnImgArgs a) 
             }
             float ds[16];
             const bool full = (key0 + 32 <= klen) && (!CAUSAL || key0 + 31 <= qw0);
+            // (no run-time test around a single element: hipcc turns `if (a.thr != 0u)` inside the unrolled loop into a scalar
+            // branch PER ELEMENT -- 41 branches per sub-tile in the ISA of round 5's first build, every one a basic-block
+            // boundary the MFMAs cannot be scheduled across.  thr16 == 0 keeps every weight, so the dropout arithmetic is
+            // unconditional; the key / causal masks are a property of the whole sub-tile.)
+            float pw[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)    // the forward's own exponent: fma(s' 2^-e_k, c2, -mcs), on bit-identical accumulators s'
+                pw[r] = fast_exp2(__builtin_fmaf(s[r] * kiv[r], c2_q, -m_q) - l2_q);
+            if (!full) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kg = key0 + acc_row(r, half);
+                    pw[r] = (kg < klen && (!CAUSAL || kg <= qg)) ? pw[r] : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
                 const int key_g = key0 + acc_row(r, half);
-                uint32_t qh = 0;
-                if (a.thr != 0u) qh = attn_quad_hash(seed_eff, rowid, (uint32_t)key_g >> 2);
+                const uint32_t qh = attn_quad_hash(seed_eff, rowid, (uint32_t)key_g >> 2);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int kg = key_g + e;
-                    // the forward's own exponent: fma(s' 2^-e_k, c2, -mcs), on bit-identical accumulators s'
-                    float p = fast_exp2(__builtin_fmaf(s[r + e] * kiv[r + e], c2_q, -m_q) - l2_q);
-                    if (!full) p = (kg < klen && (!CAUSAL || kg <= qg)) ? p : 0.f;
                     float g = dp[r + e] * (viv[r + e] * dp_unscale);
-                    if (a.thr != 0u) g = attn_keep_word(qh, attn_drop_mult(e), thr16) ? g : 0.f;
+                    g = attn_keep_word(qh, attn_drop_mult(e), thr16) ? g : 0.f;
                     // dS carries the key's 2^-e_k from here on: the K'^T it meets below is K 2^e_k
-                    ds[r + e] = saturated ? 0.f : p * (g - delta) * kiv[r + e];
+                    float dsv = pw[r + e] * (g - delta) * kiv[r + e];
+                    asm volatile("" : "+v"(dsv));            // (formed unconditionally, then selected: no exec-mask branch per element)
+                    ds[r + e] = saturated ? 0.f : dsv;
                 }
             }
             attn_h3_track_scale(ds, sds, dq);
@@ -1117,9 +1129,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_img_kernel(AttnImgArgs a)
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
                     const int q_g = qt0 + acc_row(r, half);
-                    float p = fast_exp2(__builtin_fmaf(s[r] * kinv, c24[e], -mq4[e]) - l24[e]);
-                    if (!full) p = (kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq) ? p : 0.f;
-                    pd[r] = p;
+                    pd[r] = fast_exp2(__builtin_fmaf(s[r] * kinv, c24[e], -mq4[e]) - l24[e]);
+                }
+            }
+            if (!full) {                                 // (one test per sub-tile, not one per element: see the dQ kernel)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q_g = qt0 + acc_row(r, half);
+                    pd[r] = (kg < klen && (!CAUSAL || kg <= q_g) && q_g < a.Tq) ? pd[r] : 0.f;
                 }
             }
 #pragma unroll
@@ -1132,8 +1149,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_img_kernel(AttnImgArgs a)
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
-                uint32_t hq[4] = {0u, 0u, 0u, 0u};
-                if (a.thr != 0u) {       // a quad of lanes (keys 4 j .. 4 j + 3) shares one hash word per query row (attention.hip)
+                uint32_t hq[4];
+                {                        // a quad of lanes (keys 4 j .. 4 j + 3) shares one hash word per query row (attention.hip);
+                    //                      unconditional: thr16 == 0 keeps every weight (see the dQ kernel)
                     const int rr = r + (lane & 3);
                     const uint32_t mine = attn_quad_hash(seed_eff, (uint32_t)(arow + qt0 + acc_row(rr, half)), (uint32_t)kg >> 2);
                     hq[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0x00, 0xF, 0xF, true);
@@ -1148,14 +1166,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_img_kernel(AttnImgArgs a)
                 for (int e = 0; e < 4; ++e) {
                     float g = dp[r + e] * dp_unscale;
                     float pk = pd[r + e];
-                    if (a.thr != 0u) {
+                    {
                         const bool keep = attn_keep_word(hq[e], key_mult, thr16);
                         g = keep ? g : 0.f;
                         pk = keep ? pk : 0.f;
                     }
                     // (one-hot row: exact zero, flagged by the dQ kernel's -0.0 sentinel in delta); dS carries the query's
                     // 2^-e_q / sqrt(d) from here on: the Q'^T it meets below is Q 2^e_q
-                    ds[r + e] = (__float_as_uint(dl4[e]) == 0x80000000u) ? 0.f : pd[r + e] * (g - dl4[e]) * cq4[e];
+                    // (the product is formed unconditionally and then selected: left to itself hipcc wraps each element's three
+                    // multiplies in an exec-mask branch on the sentinel -- sixteen s_and_saveexec / s_cbranch_execz per sub-tile)
+                    float dsv = pd[r + e] * (g - dl4[e]) * cq4[e];
+                    asm volatile("" : "+v"(dsv));
+                    ds[r + e] = (__float_as_uint(dl4[e]) == 0x80000000u) ? 0.f : dsv;
                     pd[r + e] = pk;
                 }
             }
