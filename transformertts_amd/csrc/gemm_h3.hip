@@ -1214,7 +1214,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_k
     }
 
     // accumulator row r_lds / column c_lds are LDS rows: map them back to matrix columns of dy / x (see the LDS row rule)
+    // (buffer stores: an element past the matrix edge gets an offset outside the descriptor and is dropped -- written as
+    // `if (in range) C[...] = v`, every one of the tile's stores sat behind an exec-mask branch of its own, 64-128 per lane)
     float* C = g.C + (long)z * g.c_zstride;
+    const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(C, 0, (uint32_t)((long)g.M * g.ldc * 4), 0x00020000);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1225,7 +1228,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_k
             for (int r = 0; r < 16; ++r) {
                 const int r_lds = wm * WTM + i * 32 + acc_row(r, half);
                 const int row = m0 + 4 * (r_lds % QA) + r_lds / QA;
-                if (row < g.M && col < g.N) C[(long)row * g.ldc + col] = acc[i][j][r] * out_scale;
+                const uint32_t off = (row < g.M && col < g.N) ? (uint32_t)(((long)row * g.ldc + col) * 4) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r] * out_scale), rsrcC, (int)off, 0, 0);
             }
         }
 }
