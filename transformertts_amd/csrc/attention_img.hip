@@ -796,8 +796,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_img_kernel(AttnImgArgs a) 
     load_lane_frags_h3(scratch, l31, half, s_g, gf);
     // row statistics of this query, as the forward left them
     const long plane = (long)a.B * a.H * a.Tq;
-    const float m_q = a.rowstat[arow + qrow], l2_q = a.rowstat[plane + arow + qrow];
+    const float m_q = a.rowstat[arow + qrow], l2_row = a.rowstat[plane + arow + qrow];
     const bool saturated = a.rowstat[2 * plane + arow + qrow] != 0.f;      // one-hot row: dS is the exact zero it is
+    // ... which costs nothing per element: the row's log-sum becomes +inf, its recomputed weights exp2(-inf) = 0, and with them dS
+    const float l2_q = saturated ? __builtin_inff() : l2_row;
     const float c2_q = a.rowstat[3 * plane + arow + qrow];
     if (half == 0 && qg < a.Tq) a.delta[arow + qg] = saturated ? -0.f : delta;
     const float dp_unscale = inv_g * a.drop_scale;      // dP accumulator units -> true dP (times the key's 2^-e_v), times 1/(1-p)
@@ -914,9 +916,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_img_kernel(AttnImgArgs a) 
                     float g = dp[r + e] * (viv[r + e] * dp_unscale);
                     g = attn_keep_word(qh, attn_drop_mult(e), thr16) ? g : 0.f;
                     // dS carries the key's 2^-e_k from here on: the K'^T it meets below is K 2^e_k
-                    float dsv = pw[r + e] * (g - delta) * kiv[r + e];
-                    asm volatile("" : "+v"(dsv));            // (formed unconditionally, then selected: no exec-mask branch per element)
-                    ds[r + e] = saturated ? 0.f : dsv;
+                    ds[r + e] = pw[r + e] * (g - delta) * kiv[r + e];
                 }
             }
             attn_h3_track_scale(ds, sds, dq);
