@@ -801,7 +801,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_img_kernel(AttnImgArgs a) 
     // ... which costs nothing per element: the row's log-sum becomes +inf, its recomputed weights exp2(-inf) = 0, and with them dS
     const float l2_q = saturated ? __builtin_inff() : l2_row;
     const float c2_q = a.rowstat[3 * plane + arow + qrow];
-    if (half == 0 && qg < a.Tq) a.delta[arow + qg] = saturated ? -0.f : delta;
+    if (half == 0 && qg < a.Tq) {
+        a.delta[arow + qg] = saturated ? -0.f : delta;
+        // the dK / dV kernel multiplies dS by the row's score multiplier (plane 4): a one-hot row's becomes zero here, and with it
+        // that row's dS there -- no test per element (nothing else reads plane 4 after the forward; zeroing it twice is the same)
+        if (saturated) a.rowstat[4 * plane + arow + qg] = 0.f;
+    }
     const float dp_unscale = inv_g * a.drop_scale;      // dP accumulator units -> true dP (times the key's 2^-e_v), times 1/(1-p)
     float sds = 0.f;                                    // this query's dS pre-scale (power of two), set / lowered on the fly
 
@@ -1171,13 +1176,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_img_kernel(AttnImgArgs a)
                         g = keep ? g : 0.f;
                         pk = keep ? pk : 0.f;
                     }
-                    // (one-hot row: exact zero, flagged by the dQ kernel's -0.0 sentinel in delta); dS carries the query's
+                    // (one-hot row: exact zero -- the dQ kernel zeroed its multiplier cq and left delta = -0.0); dS carries the query's
                     // 2^-e_q / sqrt(d) from here on: the Q'^T it meets below is Q 2^e_q
-                    // (the product is formed unconditionally and then selected: left to itself hipcc wraps each element's three
-                    // multiplies in an exec-mask branch on the sentinel -- sixteen s_and_saveexec / s_cbranch_execz per sub-tile)
-                    float dsv = pd[r + e] * (g - dl4[e]) * cq4[e];
-                    asm volatile("" : "+v"(dsv));
-                    ds[r + e] = (__float_as_uint(dl4[e]) == 0x80000000u) ? 0.f : dsv;
+                    ds[r + e] = pd[r + e] * (g - dl4[e]) * cq4[e];
                     pd[r + e] = pk;
                 }
             }
@@ -1321,7 +1322,8 @@ extern "C" int ttts_attention_fwd_img(const void* q, const void* k, const void* 
 
 /* dq, dk, dv (fp32, packed or separate: strides ldd*) from d_o on head-image operands; o, d_o fp32 as the forward wrote / the
  * out-projection's data gradient left them; rowstat = the five planes ttts_attention_fwd_img wrote; do_amax = partial maxima
- * of |d_o|; delta (B,H,Tq) is scratch; dq_amax_out / dkv_amax_out: NULL, or zeroed TTTS_AMAX_SLOTS floats; dkv_partials / q_splits:
+ * of |d_o|; delta (B,H,Tq) is scratch; plane 4 of rowstat (the rows' score multipliers) is ZEROED for one-hot rows by this call (the
+ * dK / dV kernel reads it after the dQ kernel; nothing else does); dq_amax_out / dkv_amax_out: NULL, or zeroed TTTS_AMAX_SLOTS floats; dkv_partials / q_splits:
  * NULL / 1, or a workspace of q_splits x B x Tk x lddk floats: the dK / dV kernel then splits the QUERY range over q_splits
  * workgroups per key block and a fixed-order reduction adds the partial sums (cross-attention's one key block per (batch, head)
  * otherwise leaves three quarters of the chip's wave slots empty); non-causal, packed (dk, dv) of row stride 2 H 64 only.  Replaces the same
