@@ -20,12 +20,17 @@ def step(i):
 for i in range(3): step(i)
 torch.cuda.synchronize()
 DIMS = {
-    "ttts_linear_fwd_x6": lambda a: ("lin fwd", a[5], a[6], a[7]),
-    "ttts_linear_bwd_data_x6": lambda a: ("lin dgrad", a[4], a[6], a[5]),
-    "ttts_conv1d_fwd_x6": lambda a: ("conv fwd", a[4] * a[5], a[7], a[6] * a[8]),
-    "ttts_conv1d_bwd_data_x6": lambda a: ("conv dgrad", a[3] * a[4], a[5], a[6] * a[7]),
-    "ttts_linear_bwd_weight_x6": lambda a: ("lin wgrad", a[6], a[7], a[8]),
-    "ttts_conv1d_bwd_weight_x6": lambda a: ("conv wgrad", a[6] * a[7], a[9], a[8] * a[10]),
+    "ttts_linear_fwd_h3": lambda a: ("lin fwd h3", a[5], a[6], a[7]),
+    "ttts_linear_fwd_h3d": lambda a: ("lin fwd h3d", a[5], a[6], a[7]),
+    "ttts_linear_fwd_h3i": lambda a: ("lin fwd h3i", a[6], a[7], a[8]),
+    "ttts_linear_fwd_h3d_img": lambda a: ("lin fwd img", a[5], a[6], a[7]),
+    "ttts_linear_bwd_data_h3": lambda a: ("lin dgrad h3", a[4], a[6], a[5]),
+    "ttts_linear_bwd_data_h3d": lambda a: ("lin dgrad h3d", a[4], a[6], a[5]),
+    "ttts_linear_bwd_data_h3i": lambda a: ("lin dgrad h3i", a[5], a[7], a[6]),
+    "ttts_conv1d_fwd_h3": lambda a: ("conv fwd", a[4] * a[5], a[7], a[6] * a[8]),
+    "ttts_conv1d_bwd_data_h3": lambda a: ("conv dgrad", a[3] * a[4], a[5], a[6] * a[7]),
+    "ttts_linear_bwd_weight_h3": lambda a: ("lin wgrad", a[6], a[7], a[8]),
+    "ttts_conv1d_bwd_weight_h3": lambda a: ("conv wgrad", a[6] * a[7], a[9], a[8] * a[10]),
 }
 rec = []
 orig = {}
@@ -44,6 +49,6 @@ for key, e0, e1 in rec:
 tot = 0
 for (kind, M, N, K), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     fl = 2.0 * M * N * K
-    print(f"{kind:10s} M={M:6d} N={N:5d} K={K:5d}  x{n:2d}  {ms/n*1e3:8.1f} us  {fl/(ms/n*1e-3)/1e12:6.1f} TF  total {ms:6.3f} ms")
+    print(f"{kind:14s} M={M:6d} N={N:5d} K={K:5d}  x{n:2d}  {ms/n*1e3:8.1f} us  {fl/(ms/n*1e-3)/1e12:6.1f} TF  total {ms:6.3f} ms")
     tot += ms
 print("total", tot)
