@@ -377,6 +377,8 @@ def main():
     ap.add_argument("--no-image-operands", action="store_true",
                     help="A/B aid: keep every GEMM on the kernels that split the fp32 activation in their loader (gemm_h3): no launch "
                          "of the LDS-DMA kernel (gemm_h3i)")
+    ap.add_argument("--no-dma-big-fwd", action="store_true",
+                    help="development A/B: 256 -> 1024 forward GEMMs on the gemm_h3 tile instead of the 256-row LDS-DMA tile")
     ap.add_argument("--no-head-images", action="store_true",
                     help="A/B aid: attention in-projections write fp32 and attention runs on the kernels that split q / k / v while they "
                          "stage them (csrc/attention.hip) instead of head images + LDS-DMA (csrc/attention_img.hip)")
@@ -424,6 +426,8 @@ def main():
         ops.LAYERNORM_IMAGES = True
     if args.no_head_images:
         ops.HEAD_IMAGES = False
+    if args.no_dma_big_fwd:
+        ops.DMA_BIG_FWD = False
     cfg = model_config(args.config)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
               "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,

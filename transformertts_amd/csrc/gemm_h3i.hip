@@ -29,9 +29,20 @@
 
 namespace ttts {
 
-constexpr int IBM = 128, IBN = 256, IBK = 16, INST = 3;
-constexpr int I_A_BYTES = IBM * 64, I_B_BYTES = IBN * 64, I_STAGE = I_A_BYTES + I_B_BYTES;
-constexpr int I_LOADS = 6;              // LDS-DMA instructions per wave and k-tile: 2 activation + 4 weight pieces of 1 KB
+constexpr int IBN = 256, IBK = 16;
+#ifndef TTTS_H3I_BIG_NST
+#define TTTS_H3I_BIG_NST 3
+#endif
+constexpr int I_B_BYTES = IBN * 64;
+// TM rows per tile: 128 (4 waves, two workgroups per CU: 24 KB stages) or 256 (8 waves, one workgroup per CU: 32 KB stages -- half
+// the weight bytes per flop through the CU's load path, which is what bounds the long-K and wide-N shapes)
+template <int TM> struct H3IGeo {
+    static constexpr int NW = TM / 32;                  // waves: a wave owns 64 x 128 of the tile
+    static constexpr int A_BYTES = TM * 64, STAGE = A_BYTES + I_B_BYTES;
+    static constexpr int B_PIECES = IBN / NW / 16;      // 1-KB weight pieces per wave and k-tile
+    static constexpr int LOADS = 2 + B_PIECES;          // LDS-DMA instructions per wave and k-tile (2 activation pieces)
+    static constexpr int NST = TM == 128 ? 3 : TTTS_H3I_BIG_NST;    // ring stages: NST - 1 k-tiles requested ahead of the one being multiplied
+};
 
 __device__ __forceinline__ uint32_t lds_addr_i(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
@@ -52,7 +63,7 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
 // development aid (tools/h3i_stamps.py; never defined in the product build): per (workgroup, wave) sums of s_memtime ticks spent
 // 0 waiting for a k-tile (vmcnt + barrier), 1 issuing the next k-tile's DMAs, 2 fragment reads + products, 3 epilogue,
 // 4 whole kernel, 5 tiles done, 6 k-tiles done, 7 the wait of each tile's FIRST k-tile
-__device__ unsigned long long ttts_h3i_stamps[512 * 4 * 8];
+__device__ unsigned long long ttts_h3i_stamps[512 * 8 * 8];
 #define ISTAMP() __builtin_amdgcn_s_memtime()
 #define IACC(slot, v) do { if ((threadIdx.x & 63) == 0) st_acc[slot] += (v); } while (0)
 #else
@@ -76,8 +87,12 @@ __device__ unsigned long long ttts_h3i_stamps[512 * 4 * 8];
 #ifdef TTTS_CLOCK_STAMPS
 __device__ unsigned long long ttts_clock_h3i[2 * 512];
 #endif
-template <bool A_RAW, bool HAS_RES, bool HAS_GATE, bool DROP, bool IMG = false>
-__global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
+template <int TM, bool A_RAW, bool HAS_RES, bool HAS_GATE, bool DROP, bool IMG = false>
+__global__ __launch_bounds__(TM * 2, TM == 128 ? 2 : 1) void gemm_h3i_kernel(GemmArgs g) {
+    using Geo = H3IGeo<TM>;
+    constexpr int IBM = TM, I_A_BYTES = Geo::A_BYTES, I_STAGE = Geo::STAGE, I_LOADS = Geo::LOADS, NW = Geo::NW, INST = Geo::NST;
+    constexpr int I_AHEAD = (INST - 2) * I_LOADS;        // requests that may still be in flight when the NEXT k-tile must have landed
+    static_assert(!IMG || TM == 128, "the head-image epilogue parks its bias behind four slabs of a 24 KB stage");
     TTTS_CLOCK_BEGIN();
 #ifdef TTTS_H3I_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
         int m0, n0;
         tile_coords(live ? bid : 0, m0, n0);
         ld_a0 = A_RAW ? (uint32_t)((long)(m0 + wave * 32) * a_row_bytes) : (uint32_t)(m0 + wave * 32) * 64u;
-        ld_b0 = (uint32_t)(n0 + wave * 64) * 64u;
+        ld_b0 = (uint32_t)(n0 + wave * (IBN / NW)) * 64u;
         ld_abytes = live ? g.a_bytes : 0u;
         ld_bbytes = live ? g.b_bytes : 0u;
     };
@@ -139,9 +154,9 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
             dma16b(rsrcA, a_lane_off, __builtin_amdgcn_readfirstlane(a_s + e * (A_RAW ? 16u * a_row_bytes : 1024u)),
                    __builtin_amdgcn_readfirstlane(dst + (uint32_t)(2 * wave + e) * 1024u));
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < Geo::B_PIECES; ++e)
             dma16b(rsrcB, lane_off, __builtin_amdgcn_readfirstlane(b_s + e * 1024u),
-                   __builtin_amdgcn_readfirstlane(dst + I_A_BYTES + (uint32_t)(4 * wave + e) * 1024u));
+                   __builtin_amdgcn_readfirstlane(dst + I_A_BYTES + (uint32_t)(Geo::B_PIECES * wave + e) * 1024u));
         ld_stage = ld_stage == INST - 1 ? 0 : ld_stage + 1;
         if (++ld_kt == nkt) {
             ld_kt = 0;
@@ -207,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
     int cstage = 0;                 // stage of the k-tile whose fragments sit in set 0 at the top of an (even) iteration
     bool after_ep = false;
     // one k-tile: `set` holds its fragments (compile-time), the other set receives the next k-tile's
-    auto ktile = [&](auto set_c, bool first_after_ep) {
+    auto ktile = [&](auto set_c, bool first_after_ep, bool landed) {
         constexpr int SET = decltype(set_c)::value;
         [[maybe_unused]] const unsigned long long s0 = ISTAMP();
         if (first_after_ep) asm volatile("s_barrier" ::: "memory");     // every wave has left its epilogue slab (this request's target)
@@ -217,14 +232,15 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
         [[maybe_unused]] const unsigned long long s2 = ISTAMP();
         // k-tile t+1 has landed when all but the I_LOADS requests behind it have: LDS-DMAs complete in the order they were issued
         // AMONG THEMSELVES, so "at most I_LOADS operations outstanding" implies it whatever else (stores) is still in flight.
-        // The first k-tile after an epilogue needs no count at all: the epilogue began with vmcnt(0) (see there).
+        // The first INST - 2 k-tiles after an epilogue need no count at all (`landed`): the epilogue began with vmcnt(0) (see there),
+        // so the wait that also covers the epilogue's stores comes INST - 2 k-tiles behind them.
         if (A_RAW) {
             // this wave's own requests for k-tile t+1 have landed: convert its 32 raw rows in place, then meet the others
-            if (!first_after_ep) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(I_LOADS) : "memory");
+            if (!landed) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(I_AHEAD) : "memory");
             convert_rows(cstage == INST - 1 ? 0 : cstage + 1);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        } else if (first_after_ep) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "i"(I_LOADS) : "memory");
+        } else if (landed) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "i"(I_AHEAD) : "memory");
         [[maybe_unused]] const unsigned long long s3 = ISTAMP();
         const int nstage = cstage == INST - 1 ? 0 : cstage + 1;
         read_frags(SET ^ 1, nstage);
@@ -234,14 +250,14 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
     };
 
     set_ld_tile(ld_bid);
-    issue();                        // k-tiles 0 and 1 of the first tile (K >= 32)
-    issue();
+#pragma unroll
+    for (int e = 0; e < INST - 1; ++e) issue();     // the first k-tiles of the first tile (the requests roll over into the next tile by themselves)
     if (A_RAW) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(I_LOADS) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(I_AHEAD) : "memory");
         convert_rows(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
-        wait_vm_barrier<I_LOADS>();
+        wait_vm_barrier<I_AHEAD>();
     }
     read_frags(0, 0);
     for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
@@ -254,8 +270,8 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int kt = 0; kt < nkt; kt += 2) {                        // (K % 32 == 0: an even number of k-tiles)
-            ktile(std::integral_constant<int, 0>{}, after_ep && kt == 0);
-            ktile(std::integral_constant<int, 1>{}, false);
+            ktile(std::integral_constant<int, 0>{}, after_ep && kt == 0, after_ep && kt < INST - 2);
+            ktile(std::integral_constant<int, 1>{}, false, after_ep && kt + 1 < INST - 2);
         }
         [[maybe_unused]] const unsigned long long s3 = ISTAMP();
         // cstage holds the NEXT tile's first k-tile (its fragments are in set 0 already), the stage behind it the second; the
@@ -492,13 +508,59 @@ __global__ __launch_bounds__(256, 2) void gemm_h3i_kernel(GemmArgs g) {
 #ifdef TTTS_H3I_STAMPS
     st_acc[4] = ISTAMP() - st_begin;
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 512)
-        for (int i = 0; i < 8; ++i) ttts_h3i_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i] = st_acc[i];
+        for (int i = 0; i < 8; ++i) ttts_h3i_stamps[(blockIdx.x * NW + (threadIdx.x >> 6)) * 8 + i] = st_acc[i];
 #endif
 }
 
 bool h3i_supports(const GemmArgs& g) {
     return (g.a_row_inv != nullptr || g.a_amax != nullptr) && g.K % 32 == 0 && g.K >= 32 && g.N % 4 == 0 && g.T <= 0 && g.bn_ws == nullptr &&
            (uint64_t)g.N * g.K * 4 < (1ull << 32);
+}
+
+// The 256-row tile (one 8-wave workgroup per CU) where it was measured ahead of the 128-row one AND of gemm_h3's 256 x 256 tile
+// (tools/h3i_bench.py): never for head-image outputs (their epilogue is written for the 24 KB stage).
+#ifndef TTTS_H3I_BIG
+#define TTTS_H3I_BIG 1
+#endif
+#ifndef TTTS_H3I_BIG_MAXK
+#define TTTS_H3I_BIG_MAXK 256
+#endif
+static bool h3i_big_tile(const GemmArgs& g) {
+    return TTTS_H3I_BIG != 0 && g.c_row_inv == nullptr && g.relu_out == nullptr && g.K <= TTTS_H3I_BIG_MAXK && g.N >= 1024 &&
+           (long)cdiv(g.N, IBN) * cdiv(g.M, 256) >= 256;
+}
+
+template <int TM>
+static int launch_h3i(const GemmArgs& g, hipStream_t stream) {
+    const long ntiles = (long)cdiv(g.N, IBN) * cdiv(g.M, TM);
+    // as many workgroups as the chip holds at once (two per CU at 128 rows, one at 256), and no more of them than level rounds
+    // need (a multiple of 8: virtual ids keep their XCD)
+    constexpr long slots = TM == 128 ? 512 : 256;
+    const long rounds = (ntiles + slots - 1) / slots;
+    long gsz = ((ntiles + rounds - 1) / rounds + 7) / 8 * 8;
+    if (gsz > slots) gsz = slots;
+    dim3 grid((unsigned)(ntiles < slots ? ntiles : gsz), 1, 1);
+    const dim3 block(TM * 2);
+    const bool res = g.residual != nullptr, gate = g.relu_out != nullptr, drop = g.drop_thr != 0u;
+    if (g.c_row_inv != nullptr) {
+        if constexpr (TM == 128) {
+            if (g.a_row_inv != nullptr) hipLaunchKernelGGL((gemm_h3i_kernel<128, false, false, false, false, true>), grid, block, 0, stream, g);
+            else hipLaunchKernelGGL((gemm_h3i_kernel<128, true, false, false, false, true>), grid, block, 0, stream, g);
+        }
+        TTTS_LAUNCH_CHECK("gemm_h3i_kernel<img>");
+        return TTTS_OK;
+    }
+#define TTTS_H3I(R, G, D)                                                                                   \
+    do {                                                                                                    \
+        if (g.a_row_inv != nullptr) hipLaunchKernelGGL((gemm_h3i_kernel<TM, false, R, G, D>), grid, block, 0, stream, g); \
+        else hipLaunchKernelGGL((gemm_h3i_kernel<TM, true, R, G, D>), grid, block, 0, stream, g);          \
+    } while (0)
+    if (gate) { if (res) TTTS_H3I(true, true, false); else TTTS_H3I(false, true, false); }
+    else if (drop) { if (res) TTTS_H3I(true, false, true); else TTTS_H3I(false, false, true); }
+    else { if (res) TTTS_H3I(true, false, false); else TTTS_H3I(false, false, false); }
+#undef TTTS_H3I
+    TTTS_LAUNCH_CHECK("gemm_h3i_kernel");
+    return TTTS_OK;
 }
 
 int dispatch_h3i(const GemmArgs& g, hipStream_t stream) {
@@ -511,38 +573,16 @@ int dispatch_h3i(const GemmArgs& g, hipStream_t stream) {
         set_error("fp16x3 GEMM (image operand): unsupported shape M=%d N=%d K=%d", g.M, g.N, g.K);
         return TTTS_ERR_INVALID;
     }
-    const long ntiles = (long)cdiv(g.N, IBN) * cdiv(g.M, IBM);
-    // two workgroups per CU, and no more of them than level rounds need (a multiple of 8: virtual ids keep their XCD)
-    const long rounds = (ntiles + 511) / 512;
-    long gsz = ((ntiles + rounds - 1) / rounds + 7) / 8 * 8;
-    if (gsz > 512) gsz = 512;
-    dim3 grid((unsigned)(ntiles < 512 ? ntiles : gsz), 1, 1);
     const bool res = g.residual != nullptr, gate = g.relu_out != nullptr, drop = g.drop_thr != 0u;
-    if (g.c_row_inv != nullptr) {
-        if (res || gate || drop || g.act != 0 || g.N % 64 != 0) {
-            set_error("fp16x3 GEMM (head-image output): bias-only epilogue and N %% 64 == 0 required (N=%d)", g.N);
-            return TTTS_ERR_INVALID;
-        }
-        if (g.a_row_inv != nullptr) hipLaunchKernelGGL((gemm_h3i_kernel<false, false, false, false, true>), grid, dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((gemm_h3i_kernel<true, false, false, false, true>), grid, dim3(256), 0, stream, g);
-        TTTS_LAUNCH_CHECK("gemm_h3i_kernel<img>");
-        return TTTS_OK;
+    if (g.c_row_inv != nullptr && (res || gate || drop || g.act != 0 || g.N % 64 != 0)) {
+        set_error("fp16x3 GEMM (head-image output): bias-only epilogue and N %% 64 == 0 required (N=%d)", g.N);
+        return TTTS_ERR_INVALID;
     }
     if (gate && drop) {
         set_error("fp16x3 GEMM (image operand): a relu gate (data gradient) cannot be combined with dropout");
         return TTTS_ERR_INVALID;
     }
-#define TTTS_H3I(R, G, D)                                                                                   \
-    do {                                                                                                    \
-        if (g.a_row_inv != nullptr) hipLaunchKernelGGL((gemm_h3i_kernel<false, R, G, D>), grid, dim3(256), 0, stream, g); \
-        else hipLaunchKernelGGL((gemm_h3i_kernel<true, R, G, D>), grid, dim3(256), 0, stream, g);          \
-    } while (0)
-    if (gate) { if (res) TTTS_H3I(true, true, false); else TTTS_H3I(false, true, false); }
-    else if (drop) { if (res) TTTS_H3I(true, false, true); else TTTS_H3I(false, false, true); }
-    else { if (res) TTTS_H3I(true, false, false); else TTTS_H3I(false, false, false); }
-#undef TTTS_H3I
-    TTTS_LAUNCH_CHECK("gemm_h3i_kernel");
-    return TTTS_OK;
+    return h3i_big_tile(g) ? launch_h3i<256>(g, stream) : launch_h3i<128>(g, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -624,11 +624,15 @@ def _dma_shape_ok(M: int, red: int, out: int, gate: bool) -> bool:
     """shapes on which the LDS-DMA kernel beats gemm_h3 with a plain fp32 activation (ttts_linear_*_h3d; tools/h3i_bench.py,
     h3 time / DMA time): data gradients with a relu gate, 256 -> 1024 columns: 1.09x at M = 13 920, 1.12x at 27 840, 1.15x at
     55 680 (512 -> 2048 at 27 840: 0.99x, not taken); square projections when their 128 x 256 tiles fill the chip: 256 -> 256
-    0.72x at M = 13 920, 0.95x at 27 840, 1.04x at 41 760 (326 tiles), 1.07x at 55 680; 512 -> 512 1.11x at 27 840 (436 tiles).
-    Level or slower elsewhere (K = 1024: 0.9x)."""
+    0.72x at M = 13 920, 0.95x at 27 840, 1.04x at 41 760 (326 tiles), 1.07x at 55 680; 512 -> 512 1.11x at 27 840 (436 tiles);
+    forward 256 -> 1024 on the 256-ROW tile of the same kernel (one 8-wave workgroup per CU, chosen inside the library when 256
+    of its tiles exist): 1.06x at 55 680, step -0.07 ms same-box (the 128-row tile is level there; 512 -> 2048 at 27 840 level on
+    either; no difference at M = 13 920).  Level or slower elsewhere (K = 1024: 0.9x)."""
     if not (DMA_GEMMS and M >= IMAGE_MIN_ROWS and red % 32 == 0 and out % 4 == 0):
         return False
     if gate and red <= 256 and out >= 512:
+        return True
+    if DMA_BIG_FWD and not gate and red <= 256 and out >= 1024 and -(-M // 256) * -(-out // 256) >= 256:
         return True
     return red == out and out in (256, 512) and -(-M // 128) * -(-out // 256) >= DMA_MIN_TILES
 
@@ -655,6 +659,7 @@ def _both_images(w: torch.Tensor, used: int, other: int, rows: int, cols: int) -
         _planes(w, other, rows, cols)
     return _planes(w, used, rows, cols)
 DMA_GEMMS = True
+DMA_BIG_FWD = True          # 256 -> 1024 forward GEMMs (FFN1) on the 256-row LDS-DMA tile when its tiles fill the chip (tools/h3i_bench.py)
 
 
 def _new_image(M: int, d: int, device):
