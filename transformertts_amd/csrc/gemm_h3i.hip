@@ -526,6 +526,9 @@ bool h3i_supports(const GemmArgs& g) {
 #define TTTS_H3I_BIG_MAXK 256
 #endif
 static bool h3i_big_tile(const GemmArgs& g) {
+#ifdef TTTS_H3I_BIG_ANY          // development A/B (tools/h3i_bench.py): every shape with enough tiles
+    if (g.c_row_inv == nullptr && (long)cdiv(g.N, IBN) * cdiv(g.M, 256) >= 128) return true;
+#endif
     return TTTS_H3I_BIG != 0 && g.c_row_inv == nullptr && g.relu_out == nullptr && g.K <= TTTS_H3I_BIG_MAXK && g.N >= 1024 &&
            (long)cdiv(g.N, IBN) * cdiv(g.M, 256) >= 256;
 }
