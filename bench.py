@@ -168,12 +168,15 @@ class GemmProbe:
                 if _x6 == 2 and tile == 6 and K >= 96 and _plain:
                     tile = 9        # unshifted operands on the 256 x 256 tile run on gemm_h3_wide_kernel (one wave per SIMD)
                 if _name == "ttts_linear_fwd_h3d_img":
-                    tile = "gemm_h3i_kernel<true,false,false,false,img>"
+                    tile = "gemm_h3i_kernel<128,true,false,false,false,true>"
                 if _name in self.DMA:
                     raw, i_res, i_gate, i_p = self.DMA[_name]
                     flag = lambda v: "true" if v else "false"      # noqa: E731
-                    tile = "gemm_h3i_kernel<%s,%s,%s,%s>" % (flag(raw), flag(a[i_res]), flag(i_gate is not None and a[i_gate]),
-                                                             flag(i_p is not None and a[i_p] > 0))
+                    gated = i_gate is not None and bool(a[i_gate])
+                    # rows per tile as csrc/gemm_h3i.hip h3i_big_tile picks them
+                    big = N >= 1024 and K <= 256 and not gated and (-(-M // 256)) * (-(-N // 256)) >= 256
+                    tile = "gemm_h3i_kernel<%d,%s,%s,%s,%s,false>" % (256 if big else 128, flag(raw), flag(a[i_res]), flag(gated),
+                                                                      flag(i_p is not None and a[i_p] > 0))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = _fn(*a)
@@ -184,7 +187,7 @@ class GemmProbe:
                 # tile loads its 256 x K activation block and its 256 x K weight block (re-reads come from L2, but through the same
                 # per-CU path) and stores 256 x 256 outputs
                 cu_bytes = (-(-M // 256)) * (-(-N // 256)) * (2.0 * 256 * K * 4) + 4.0 * M * N
-                if isinstance(tile, str):       # 128 x 256 tiles
+                if isinstance(tile, str) and not tile.startswith("gemm_h3i_kernel<256"):       # 128 x 256 tiles
                     cu_bytes = (-(-M // 128)) * (-(-N // 256)) * ((128 + 256) * K * 4.0) + 4.0 * M * N
                 self.records.append((e0, e1, 2.0 * M * N * K, (_x6, tile), 4.0 * (M * K + M * N + N * K), cu_bytes))
                 self.shapes.append((_name, int(M), int(N), int(K)))

@@ -7,7 +7,7 @@ tot = sum(float(r['TotalDurationNs']) for r in rows)
 cls = {}
 for r in rows:
     n = r['Name']
-    key = ('gemm fwd/dgrad' if re.search(r'gemm_(bf16x6|h3|f32)_kernel', n) else 'wgrad' if 'wgrad' in n else 'attention' if 'attn_' in n
+    key = ('gemm fwd/dgrad' if re.search(r'gemm_(bf16x6|h3|h3i|h3_wide|f32)_kernel', n) else 'wgrad' if 'wgrad' in n else 'attention' if 'attn_' in n
            else 'other ttts' if 'ttts::' in n else 'non-ttts')
     cls[key] = cls.get(key, 0) + float(r['TotalDurationNs'])
 for r in rows[:top]:
