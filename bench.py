@@ -358,8 +358,8 @@ def workload_name(args) -> str:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--tp", type=int, default=100)
     ap.add_argument("--tm", type=int, default=870)
