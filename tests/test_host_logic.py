@@ -374,3 +374,37 @@ def test_dropout_seed_stream_restarts_with_a_reseeded_module():
         assert [s.next() for _ in range(2)] == a
     finally:
         s.base, s.counter, s.explicit, s._derived_from = saved
+
+
+def test_mask_arguments_are_read_as_torch_reads_them():
+    """transformertts_amd/model/layers.py: which mask tensors become lengths / the causal flag (the kernels' forms) and which
+    stay tensors (reference model/layers.py:29-74 hands them to torch's MultiheadAttention)"""
+    from transformertts_amd.model import layers as L
+    B, T = 3, 9
+    lens = torch.tensor([9, 4, 0])
+    prefix = torch.arange(T)[None, :] >= lens[:, None]
+    got, dead = L._resolve_kpm(prefix, B, T, "cpu")
+    assert dead is None and torch.equal(got, lens)
+    got, dead = L._resolve_kpm(torch.zeros(B, T).masked_fill(prefix, float("-inf")), B, T, "cpu")     # float form of the same mask
+    assert dead is None and torch.equal(got, lens)
+    holes = prefix.clone()
+    holes[0, 3] = True
+    got, dead = L._resolve_kpm(holes, B, T, "cpu")
+    assert torch.equal(dead, holes) and got.tolist() == [8, 4, 0]
+    with pytest.raises(ValueError):
+        L._lens_from_kpm(holes, B, T, "cpu")
+    with pytest.raises(ValueError):
+        L._resolve_kpm(prefix[:, :5], B, T, "cpu")
+    assert L._resolve_kpm(None, B, T, "cpu")[0].tolist() == [T] * B
+    causal = torch.triu(torch.ones(T, T, dtype=torch.bool), 1)
+    assert L._is_causal_mask(causal, T, T)
+    assert L._is_causal_mask(torch.nn.Transformer.generate_square_subsequent_mask(T), T, T)
+    assert not L._is_causal_mask(~causal, T, T)
+    assert not L._is_causal_mask(torch.nn.Transformer.generate_square_subsequent_mask(T) + torch.eye(T), T, T)
+    assert not L._is_causal_mask(causal[:, :5], T, 5)
+    a = L._additive_mask(causal, B, 2, T, T)
+    assert a.shape == (1, 1, T, T) and a[0, 0, 0, 1] == torch.finfo(torch.float32).min and a[0, 0, 1, 0] == 0
+    f = torch.randn(B * 2, T, T)
+    assert torch.equal(L._additive_mask(f, B, 2, T, T), f.reshape(B, 2, T, T))
+    with pytest.raises(ValueError):
+        L._additive_mask(torch.zeros(T + 1, T), B, 2, T, T)

@@ -6,7 +6,10 @@ Class names, constructor signatures and parameter names follow the reference's
 `state_dict()` is key-for-key the reference's.  Differences by design (MI355X-first):
   * masks never exist as tensors: the stacks take per-utterance lengths (`*_lens`, int64 on the
     device) and the attention kernels derive key-padding and causal masks from them;
-    `*_key_padding_mask` / `tgt_mask` arguments are still accepted and converted (prefix masks only);
+    `*_key_padding_mask` / `tgt_mask` / `memory_mask` / `mask` arguments are still accepted: a key-padding mask that is a
+    prefix mask becomes lengths and a `tgt_mask` that is the causal mask becomes the kernels' causal flag (one host check per
+    call, only when a mask TENSOR is passed -- the model passes lengths); any other mask keeps its meaning and that attention
+    runs as tensor algebra on library GEMMs (`ops.masked_attention`: correct, not tuned);
   * post-norm (`norm_first=False`, the reference's configuration) and pre-norm (`norm_first=True`, the other branch of
     model/layers.py:41-50); batch-first only, relu FFN;
   * residual adds, biases, relu and dropout live in GEMM epilogues, not in separate ops.
@@ -23,10 +26,64 @@ from torch import Tensor
 from .. import ops
 
 
-def _lens_from_kpm(kpm: Optional[Tensor], B: int, T: int, device) -> Tensor:
+_NEG = torch.finfo(torch.float32).min
+
+
+def _dead_keys(kpm: Tensor) -> Tensor:
+    """torch `key_padding_mask` (B, T) -> bool, True = key ignored (a float mask: its -inf entries; anything else but 0 has no
+    length / hole reading and is refused)"""
+    if kpm.dtype == torch.bool:
+        return kpm
+    if kpm.is_floating_point():
+        dead = torch.isneginf(kpm)
+        if bool(((kpm != 0) & ~dead).any()):
+            raise ValueError("key_padding_mask: float masks may hold 0 and -inf only")
+        return dead
+    return kpm != 0
+
+
+def _resolve_kpm(kpm: Optional[Tensor], B: int, T: int, device):
+    """-> (lengths, dead): a prefix mask (live keys first) is what the kernels derive from lengths -> (lens, None); a mask with
+    holes stays a tensor -> (live-key counts, dead (B, T) bool) and the attention that uses it runs in `ops.masked_attention`."""
     if kpm is None:
-        return torch.full((B,), T, dtype=torch.int64, device=device)
-    return (~kpm.bool()).sum(dim=1).to(torch.int64)
+        return torch.full((B,), T, dtype=torch.int64, device=device), None
+    if kpm.dim() != 2 or kpm.shape[0] != B or kpm.shape[1] != T:
+        raise ValueError(f"key_padding_mask: expected ({B}, {T}), got {tuple(kpm.shape)}")
+    dead = _dead_keys(kpm)
+    lens = (~dead).sum(dim=1).to(torch.int64)
+    prefix = torch.arange(T, device=dead.device)[None, :] >= lens[:, None]
+    return lens, (None if bool(torch.equal(dead, prefix)) else dead)
+
+
+def _lens_from_kpm(kpm: Optional[Tensor], B: int, T: int, device) -> Tensor:
+    lens, dead = _resolve_kpm(kpm, B, T, device)
+    if dead is not None:
+        raise ValueError("key_padding_mask with holes: pass it to the layer / stack (it cannot be expressed as lengths)")
+    return lens
+
+
+def _is_causal_mask(mask: Tensor, Tq: int, Tk: int) -> bool:
+    """is `mask` exactly the mask torch's generate_square_subsequent_mask / the reference's model/model.py:251-255 build?"""
+    if mask.dim() != 2 or Tq != Tk or mask.shape[0] != Tq or mask.shape[1] != Tk:
+        return False
+    ref = torch.triu(torch.ones(Tq, Tk, dtype=torch.bool, device=mask.device), diagonal=1)
+    if mask.dtype == torch.bool:
+        return bool(torch.equal(mask, ref))
+    return bool(torch.equal(torch.isneginf(mask), ref)) and bool((mask.masked_fill(ref, 0) == 0).all())
+
+
+def _additive_mask(mask: Tensor, B: int, H: int, Tq: int, Tk: int) -> Tensor:
+    """torch `attn_mask` ((Tq, Tk) or (B * H, Tq, Tk); bool True = not allowed, float = added to the scores) -> finite fp32,
+    broadcastable to (B, H, Tq, Tk)"""
+    if mask.dim() == 2 and mask.shape[0] == Tq and mask.shape[1] == Tk:
+        m = mask[None, None]
+    elif mask.dim() == 3 and mask.shape[0] == B * H and mask.shape[1] == Tq and mask.shape[2] == Tk:
+        m = mask.reshape(B, H, Tq, Tk)
+    else:
+        raise ValueError(f"attention mask: expected ({Tq}, {Tk}) or ({B * H}, {Tq}, {Tk}), got {tuple(mask.shape)}")
+    if m.dtype == torch.bool:
+        return torch.zeros(m.shape, dtype=torch.float32, device=m.device).masked_fill(m, _NEG)
+    return m.to(torch.float32).clamp_min(_NEG)
 
 
 class MultiheadAttention(nn.Module):
@@ -48,9 +105,18 @@ class MultiheadAttention(nn.Module):
     def _p(self) -> float:
         return self.dropout if self.training else 0.0
 
-    def self_attention(self, x: Tensor, lens: Tensor, causal: bool, residual: Tensor, out_drop: float) -> Tensor:
-        """residual + drop(out_proj(attention(in_proj(x))))"""
+    def self_attention(self, x: Tensor, lens: Tensor, causal: bool, residual: Tensor, out_drop: float,
+                       dead: Optional[Tensor] = None, add_mask: Optional[Tensor] = None) -> Tensor:
+        """residual + drop(out_proj(attention(in_proj(x)))); `dead` / `add_mask`: masks the kernels do not derive from lengths
+        (`_resolve_kpm`, `_additive_mask`) -- that attention runs in `ops.masked_attention` between the same two GEMMs"""
         skip = ops.SkipToken() if residual is x else None      # the skip gradient rides in the in-projection's epilogue
+        if dead is not None or add_mask is not None:
+            d = self.embed_dim
+            qkv = ops.linear(x, self.in_proj_weight, self.in_proj_bias, skip_in=skip, publish_amax=True)
+            ctx, _ = ops.masked_attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], lens, self.num_heads, causal,
+                                          self._p(), dead, add_mask)
+            return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, drop_p=out_drop,
+                              seed=ops.seeds.next() if out_drop > 0 else 0, skip_out=skip)
         # 64-column heads: q / k / v leave the in-projection as a head image (f16 hi / lo pieces with per-(row, head) scales in the
         # cells fp32 would occupy) and attention stages them by LDS-DMA; narrower heads take the fp32 path through padded copies
         img = 3 if ops.head_image_ok(x, self.in_proj_weight, self.num_heads, 3) else 0
@@ -62,10 +128,17 @@ class MultiheadAttention(nn.Module):
                           seed=ops.seeds.next() if out_drop > 0 else 0, skip_out=skip)
 
     def cross_attention(self, x: Tensor, mem: Tensor, mem_lens: Tensor, residual: Tensor, out_drop: float,
-                        need_weights: bool = True):
+                        need_weights: bool = True, dead: Optional[Tensor] = None, add_mask: Optional[Tensor] = None):
         d = self.embed_dim
         skip = ops.SkipToken() if residual is x else None
         wq, wkv = ops.param_rows(self.in_proj_weight, 0, d), ops.param_rows(self.in_proj_weight, d, 3 * d)
+        if dead is not None or add_mask is not None:
+            q = ops.linear(x, wq, ops.param_rows(self.in_proj_bias, 0, d), skip_in=skip, publish_amax=True)
+            kv = ops.linear(mem, wkv, ops.param_rows(self.in_proj_bias, d, 3 * d), publish_amax=True)
+            ctx, attn = ops.masked_attention(q, kv[..., :d], kv[..., d:], mem_lens, self.num_heads, False, self._p(), dead, add_mask)
+            out = ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, drop_p=out_drop,
+                             seed=ops.seeds.next() if out_drop > 0 else 0, skip_out=skip)
+            return out, (attn if need_weights else None)
         img = ops.head_image_ok(x, wq, self.num_heads, 1) and ops.head_image_ok(mem, wkv, self.num_heads, 2)
         q = ops.linear(x, wq, ops.param_rows(self.in_proj_bias, 0, d), skip_in=skip, publish_amax=not img,
                        head_image_sections=1 if img else 0)
@@ -110,14 +183,14 @@ class TransformerEncoderLayer(nn.Module):
         self.dropout1 = nn.Dropout(dropout)
         self.dropout2 = nn.Dropout(dropout)
 
-    def forward(self, src: Tensor, src_lens: Tensor) -> Tensor:
+    def forward(self, src: Tensor, src_lens: Tensor, dead: Optional[Tensor] = None, add_mask: Optional[Tensor] = None) -> Tensor:
         p1 = self.dropout1.p if self.training else 0.0
         if self.norm_first:      # torch/nn/modules/transformer.py:944-950: x + SA(LN1(x)), then x + FF(LN2(x))
             x1 = ops.layer_norm(src, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-            s = self.self_attn.self_attention(x1, src_lens, False, residual=src, out_drop=p1)
+            s = self.self_attn.self_attention(x1, src_lens, False, residual=src, out_drop=p1, dead=dead, add_mask=add_mask)
             x2 = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps)
             return _ffn_block(self, x2, self.dropout2, residual=s)
-        s = self.self_attn.self_attention(src, src_lens, False, residual=src, out_drop=p1)
+        s = self.self_attn.self_attention(src, src_lens, False, residual=src, out_drop=p1, dead=dead, add_mask=add_mask)
         x = ops.layer_norm(s, self.norm1.weight, self.norm1.bias, self.norm1.eps, sole_consumer=True)
         x = ops.layer_norm(_ffn_block(self, x, self.dropout2), self.norm2.weight, self.norm2.bias, self.norm2.eps,
                            sole_consumer=True)
@@ -133,13 +206,14 @@ class TransformerEncoder(nn.Module):
 
     def forward(self, src: Tensor, mask=None, src_key_padding_mask: Optional[Tensor] = None,
                 src_lens: Optional[Tensor] = None) -> Tensor:
-        if mask is not None:
-            raise ValueError("TransformerEncoder: arbitrary attention masks are not supported, pass lengths")
+        B, T = src.size(0), src.size(1)
+        dead = None
         if src_lens is None:
-            src_lens = _lens_from_kpm(src_key_padding_mask, src.size(0), src.size(1), src.device)
+            src_lens, dead = _resolve_kpm(src_key_padding_mask, B, T, src.device)
+        add_mask = None if mask is None else _additive_mask(mask, B, self.layers[0].self_attn.num_heads, T, T)
         x = src
         for layer in self.layers:
-            x = layer(x, src_lens)
+            x = layer(x, src_lens, dead, add_mask)
         if self.norm is not None:
             x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x
@@ -173,29 +247,41 @@ class TransformerDecoderLayer(nn.Module):
                 memory_key_padding_mask: Optional[Tensor] = None, tgt_is_causal: bool = True,
                 memory_is_causal: bool = False, tgt_lens: Optional[Tensor] = None,
                 memory_lens: Optional[Tensor] = None, need_alignments: bool = True):
-        if memory_mask is not None or memory_is_causal:
-            raise ValueError("TransformerDecoderLayer: memory masks other than key padding are not supported")
-        B = tgt.size(0)
+        if memory_is_causal and memory_mask is None:
+            raise ValueError("TransformerDecoderLayer: memory_is_causal is a hint about memory_mask and needs one (as torch)")
+        B, Tq, Tk, H = tgt.size(0), tgt.size(1), memory.size(1), self.self_attn.num_heads
+        tgt_dead = mem_dead = None
         if tgt_lens is None:
-            tgt_lens = _lens_from_kpm(tgt_key_padding_mask, B, tgt.size(1), tgt.device)
+            tgt_lens, tgt_dead = _resolve_kpm(tgt_key_padding_mask, B, Tq, tgt.device)
         if memory_lens is None:
-            memory_lens = _lens_from_kpm(memory_key_padding_mask, B, memory.size(1), tgt.device)
-        causal = bool(tgt_is_causal) or tgt_mask is not None
+            memory_lens, mem_dead = _resolve_kpm(memory_key_padding_mask, B, Tk, tgt.device)
+        # tgt_mask: the causal mask (what the reference's model passes, model/model.py:251-255) is the kernels' causal flag; any
+        # other mask is applied as given.  Without a mask tensor `tgt_is_causal` (default True, model/layers.py:36) decides.
+        tgt_add = None
+        if tgt_mask is None:
+            causal = bool(tgt_is_causal)
+        elif _is_causal_mask(tgt_mask, Tq, Tq):
+            causal = True
+        else:
+            causal, tgt_add = False, _additive_mask(tgt_mask, B, H, Tq, Tq)
+        mem_add = None if memory_mask is None else _additive_mask(memory_mask, B, H, Tq, Tk)
         tr = self.training
+        sa = dict(dead=tgt_dead, add_mask=tgt_add)
+        ca = dict(dead=mem_dead, add_mask=mem_add)
         if self.norm_first:      # reference model/layers.py:41-45
             x1 = ops.layer_norm(tgt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-            s = self.self_attn.self_attention(x1, tgt_lens, causal, residual=tgt, out_drop=self.dropout1.p if tr else 0.0)
+            s = self.self_attn.self_attention(x1, tgt_lens, causal, residual=tgt, out_drop=self.dropout1.p if tr else 0.0, **sa)
             x2 = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps)
             s2, alignments = self.multihead_attn.cross_attention(x2, memory, memory_lens, residual=s,
                                                                  out_drop=self.dropout2.p if tr else 0.0,
-                                                                 need_weights=need_alignments)
+                                                                 need_weights=need_alignments, **ca)
             x3 = ops.layer_norm(s2, self.norm3.weight, self.norm3.bias, self.norm3.eps)
             return _ffn_block(self, x3, self.dropout3, residual=s2), alignments
-        s = self.self_attn.self_attention(tgt, tgt_lens, causal, residual=tgt, out_drop=self.dropout1.p if tr else 0.0)
+        s = self.self_attn.self_attention(tgt, tgt_lens, causal, residual=tgt, out_drop=self.dropout1.p if tr else 0.0, **sa)
         x = ops.layer_norm(s, self.norm1.weight, self.norm1.bias, self.norm1.eps, sole_consumer=True)
         s, alignments = self.multihead_attn.cross_attention(x, memory, memory_lens, residual=x,
                                                             out_drop=self.dropout2.p if tr else 0.0,
-                                                            need_weights=need_alignments)
+                                                            need_weights=need_alignments, **ca)
         x = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps, sole_consumer=True)
         x = ops.layer_norm(_ffn_block(self, x, self.dropout3), self.norm3.weight, self.norm3.bias, self.norm3.eps,
                            sole_consumer=True)
@@ -219,14 +305,23 @@ class TransformerDecoder(nn.Module):
                 memory_is_causal: Optional[bool] = None, tgt_lens: Optional[Tensor] = None,
                 memory_lens: Optional[Tensor] = None, need_alignments: bool = True):
         B = tgt.size(0)
-        if tgt_lens is None:
-            tgt_lens = _lens_from_kpm(tgt_key_padding_mask, B, tgt.size(1), tgt.device)
-        if memory_lens is None:
-            memory_lens = _lens_from_kpm(memory_key_padding_mask, B, memory.size(1), tgt.device)
+        # prefix key-padding masks become lengths once, here; masks with holes travel on to the layers as tensors
+        if tgt_lens is None and tgt_key_padding_mask is not None:
+            lens, dead = _resolve_kpm(tgt_key_padding_mask, B, tgt.size(1), tgt.device)
+            if dead is None:
+                tgt_lens, tgt_key_padding_mask = lens, None
+        if memory_lens is None and memory_key_padding_mask is not None:
+            lens, dead = _resolve_kpm(memory_key_padding_mask, B, memory.size(1), tgt.device)
+            if dead is None:
+                memory_lens, memory_key_padding_mask = lens, None
+        if tgt_mask is not None and _is_causal_mask(tgt_mask, tgt.size(1), tgt.size(1)):
+            tgt_mask, tgt_is_causal = None, True            # (checked once for the stack, not once per layer)
         alignments = []
         memories = ops.fanout(memory, len(self.layers))     # one handle per layer: their gradients meet in one launch
         for layer, memory in zip(self.layers, memories):
             tgt, alignment = layer(tgt, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                                   tgt_key_padding_mask=tgt_key_padding_mask,
+                                   memory_key_padding_mask=memory_key_padding_mask,
                                    tgt_is_causal=True if tgt_is_causal is None else tgt_is_causal,
                                    memory_is_causal=bool(memory_is_causal), tgt_lens=tgt_lens,
                                    memory_lens=memory_lens, need_alignments=need_alignments)

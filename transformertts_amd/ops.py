@@ -1264,11 +1264,15 @@ def _wide_heads(d: int, n_head: int) -> bool:
     return d // n_head > 64
 
 
-def _attention_wide_heads(q, k, v, lens, n_head: int, causal: bool, drop_p: float):
-    """Heads wider than 64 columns (the reference takes any `nhead`, model/model.py:139-161; no BASELINE configuration has
-    them): the hand-written kernels hold a 64-column head per fragment set, so this shape runs as plain tensor algebra on the
-    library's fp32 GEMMs -- same masks (keys past `lens`, causal), same conventions as the kernels (weights returned AFTER
-    dropout, rows without a live key give zeros), differentiated by autograd.  Correct, not tuned."""
+def _attention_wide_heads(q, k, v, lens, n_head: int, causal: bool, drop_p: float, dead=None, add_mask=None):
+    """Attention as plain tensor algebra on the library's fp32 GEMMs, for the two cases the hand-written kernels do not take:
+      * heads wider than 64 columns (the reference takes any `nhead`, model/model.py:139-161; no BASELINE configuration has them):
+        the kernels hold a 64-column head per fragment set;
+      * masks that are not "keys past a length" / causal (`masked_attention`: a key-padding mask with holes, `memory_mask`, an
+        arbitrary `tgt_mask` / `mask` -- arguments of the reference's layers, model/layers.py:29-74, that its model never passes).
+    Same conventions as the kernels (weights returned AFTER dropout, rows without an allowed key give zeros), differentiated by
+    autograd.  `dead` (B, Tk) bool replaces the keys-past-`lens` mask; `add_mask` (broadcastable to (B, H, Tq, Tk), finite) is
+    added to the scaled scores as torch adds a float `attn_mask`.  Correct, not tuned."""
     B, Tq, d = q.shape
     Tk = k.shape[1]
     hd = d // n_head
@@ -1277,17 +1281,28 @@ def _attention_wide_heads(q, k, v, lens, n_head: int, causal: bool, drop_p: floa
     vh = v.reshape(B, Tk, n_head, hd).transpose(1, 2)
     s = torch.matmul(qh * hd ** -0.5, kh.transpose(-1, -2))                      # (B, H, Tq, Tk)
     key = torch.arange(Tk, device=q.device)
-    dead = key[None, :] >= lens.to(q.device)[:, None]                             # (B, Tk)
+    if dead is None:
+        dead = key[None, :] >= lens.to(q.device)[:, None]                         # (B, Tk)
     big = torch.finfo(torch.float32).min
+    if add_mask is not None:
+        s = s + add_mask
     s = s.masked_fill(dead[:, None, None, :], big)                                # finite: no NaN in either direction
     if causal:
         s = s.masked_fill((key[None, :] > torch.arange(Tq, device=q.device)[:, None])[None, None], big)
-    p = torch.softmax(s, dim=-1)
-    p = p * (~dead)[:, None, None, :].to(p.dtype)                                 # (an utterance without keys: zeros, not 1 / Tk)
+    # a row without an allowed key (an utterance without keys, a padded query whose band holds dead keys only): zeros, as the
+    # kernels and torch's scaled_dot_product_attention give -- not the uniform row a finite fill would leave
+    p = torch.softmax(s, dim=-1) * (s > 0.5 * big).any(dim=-1, keepdim=True).to(s.dtype)
     if drop_p > 0:
         p = torch.nn.functional.dropout(p, drop_p, True)
     o = torch.matmul(p, vh).transpose(1, 2).reshape(B, Tq, d)
     return o, p
+
+
+def masked_attention(q, k, v, lens, n_head: int, causal: bool, drop_p: float, dead=None, add_mask=None):
+    """(context, per-head weights) under masks the kernels do not derive from lengths: see `_attention_wide_heads`."""
+    if n_head <= 0 or q.shape[-1] % n_head != 0:
+        raise ValueError(f"attention: d_model {q.shape[-1]} is not divisible by {n_head} heads")
+    return _attention_wide_heads(q, k, v, lens, n_head, causal, drop_p, dead, add_mask)
 
 
 def _pad_heads(src: torch.Tensor, col0: int, ld: int, rows: int, H: int, hd: int) -> torch.Tensor:
