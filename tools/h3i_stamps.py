@@ -26,7 +26,9 @@ raw = ctypes.CDLL(_lib.LIB_PATH)
 n = 512 * 4 * 8
 buf = (ctypes.c_ulonglong * n)()
 raw.ttts_dbg_h3i_read_stamps(buf, ctypes.c_size_t(n))
-st = np.frombuffer(buf, dtype=np.uint64).reshape(512, 4, 8).astype(np.float64)
+# rows per tile as csrc/gemm_h3i.hip h3i_big_tile picks them: the 256-row tile has eight waves per workgroup (at most 256 of them)
+NW = 8 if (N >= 1024 and K <= 256 and (-(-M // 256)) * (-(-N // 256)) >= 256) else 4
+st = np.frombuffer(buf, dtype=np.uint64).reshape(2048 // NW, NW, 8).astype(np.float64)
 live = st[:, 0, 5] > 0
 st = st[live]
 print(f"M={M} N={N} K={K}: {e0.elapsed_time(e1) * 1e3:.1f} us (with stamps), {int(live.sum())} workgroups")
@@ -38,4 +40,4 @@ for i, nm in enumerate(names):
     print(f"  {nm:32s} {per:9.0f} ticks per wave = {per / st[:, :, 4].mean() * 100:5.1f} %   per k-tile {per / kts:7.1f}" if i < 3 else
           f"  {nm:32s} {per:9.0f} ticks per wave = {per / st[:, :, 4].mean() * 100:5.1f} %   per tile {per / tiles:7.1f}")
 pass
-print("  by wave (wait, issue, compute, epilogue):", [[int(st[:, wv, i].mean()) for i in range(4)] for wv in range(4)])
+print("  by wave (wait, issue, compute, epilogue):", [[int(st[:, wv, i].mean()) for i in range(4)] for wv in range(NW)])

@@ -30,6 +30,9 @@
 namespace ttts {
 
 constexpr int IBN = 256, IBK = 16;
+#ifndef TTTS_H3I_SPREAD
+#define TTTS_H3I_SPREAD 0
+#endif
 #ifndef TTTS_H3I_BIG_NST
 #define TTTS_H3I_BIG_NST 3
 #endif
@@ -143,26 +146,33 @@ __global__ __launch_bounds__(TM * 2, TM == 128 ? 2 : 1) void gemm_h3i_kernel(Gem
         ld_abytes = live ? g.a_bytes : 0u;
         ld_bbytes = live ? g.b_bytes : 0u;
     };
-    auto issue = [&]() {
-        const u32x4 rsrcA = {(uint32_t)a_base, (uint32_t)(a_base >> 32) & 0xffffu, ld_abytes, 0x00020000u};
-        const u32x4 rsrcB = {(uint32_t)b_base, (uint32_t)(b_base >> 32) & 0xffffu, ld_bbytes, 0x00020000u};
+    // piece e of the I_LOADS requests of the loader's current k-tile (0, 1: activation rows; 2 ..: weight rows)
+    auto issue_piece = [&](int e) {
         const uint32_t dst = lds0 + (uint32_t)ld_stage * I_STAGE;
-        const uint32_t a_s = ld_a0 + (uint32_t)ld_kt * a_kstep;
-        const uint32_t b_s = ld_b0 + (uint32_t)ld_kt * b_kstep;
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
+        if (e < 2) {
+            const u32x4 rsrcA = {(uint32_t)a_base, (uint32_t)(a_base >> 32) & 0xffffu, ld_abytes, 0x00020000u};
+            const uint32_t a_s = ld_a0 + (uint32_t)ld_kt * a_kstep;
             dma16b(rsrcA, a_lane_off, __builtin_amdgcn_readfirstlane(a_s + e * (A_RAW ? 16u * a_row_bytes : 1024u)),
                    __builtin_amdgcn_readfirstlane(dst + (uint32_t)(2 * wave + e) * 1024u));
-#pragma unroll
-        for (int e = 0; e < Geo::B_PIECES; ++e)
-            dma16b(rsrcB, lane_off, __builtin_amdgcn_readfirstlane(b_s + e * 1024u),
-                   __builtin_amdgcn_readfirstlane(dst + I_A_BYTES + (uint32_t)(Geo::B_PIECES * wave + e) * 1024u));
+        } else {
+            const u32x4 rsrcB = {(uint32_t)b_base, (uint32_t)(b_base >> 32) & 0xffffu, ld_bbytes, 0x00020000u};
+            const uint32_t b_s = ld_b0 + (uint32_t)ld_kt * b_kstep;
+            dma16b(rsrcB, lane_off, __builtin_amdgcn_readfirstlane(b_s + (e - 2) * 1024u),
+                   __builtin_amdgcn_readfirstlane(dst + I_A_BYTES + (uint32_t)(Geo::B_PIECES * wave + (e - 2)) * 1024u));
+        }
+    };
+    auto issue_advance = [&]() {
         ld_stage = ld_stage == INST - 1 ? 0 : ld_stage + 1;
         if (++ld_kt == nkt) {
             ld_kt = 0;
             ld_bid += gridDim.x;
             set_ld_tile(ld_bid);
         }
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int e = 0; e < I_LOADS; ++e) issue_piece(e);
+        issue_advance();
     };
     // ---- fragments: lane -> row l31 of a 32-row block, chunk (plane * 2 + half) ^ swizzle
     const int sw = (l31 >> 2) & 3;
@@ -191,7 +201,9 @@ __global__ __launch_bounds__(TM * 2, TM == 128 ? 2 : 1) void gemm_h3i_kernel(Gem
             fa[set][1][i] = *reinterpret_cast<const f16x8*>(st + fa_off + i * 2048 + ch_lo);
         }
     };
-    auto products = [&](int set, int i) {
+    // (SPREAD: the k-tile's requests go out BETWEEN the products of the first row block -- an LDS-DMA instruction takes 70-90 cycles
+    // to issue (tools/h3i_stamps.py), which the wave otherwise spends in front of its first MFMA with the matrix pipe idle)
+    auto products = [&](int set, int i, bool spread = false) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // the WEIGHT fragment is the MFMA's first operand: the accumulator block is C^T (lane = output row, registers
@@ -201,6 +213,14 @@ __global__ __launch_bounds__(TM * 2, TM == 128 ? 2 : 1) void gemm_h3i_kernel(Gem
             cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[set][1][j], fa[set][0][i], cc, 0, 0, 0);
             cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[set][0][j], fa[set][0][i], cc, 0, 0, 0);
             acc[i][j] = cc;
+            if (spread) {       // (pinned: left alone, hipcc gathers the requests in front of the second MFMA)
+                constexpr int PER = (I_LOADS + 3) / 4;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < PER; ++c)
+                    if (j * PER + c < I_LOADS) issue_piece(j * PER + c);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     // A_RAW: lane -> (row 32 * wave + lane / 2, k-half lane & 1) of the wave's own piece: raw chunks 2h, 2h+1 -> chunks h (hi), 2 + h (lo)
@@ -226,9 +246,15 @@ __global__ __launch_bounds__(TM * 2, TM == 128 ? 2 : 1) void gemm_h3i_kernel(Gem
         constexpr int SET = decltype(set_c)::value;
         [[maybe_unused]] const unsigned long long s0 = ISTAMP();
         if (first_after_ep) asm volatile("s_barrier" ::: "memory");     // every wave has left its epilogue slab (this request's target)
+#if TTTS_H3I_SPREAD
+        [[maybe_unused]] const unsigned long long s1 = ISTAMP();
+        products(SET, 0, true);
+        issue_advance();
+#else
         issue();
         [[maybe_unused]] const unsigned long long s1 = ISTAMP();
         products(SET, 0);
+#endif
         [[maybe_unused]] const unsigned long long s2 = ISTAMP();
         // k-tile t+1 has landed when all but the I_LOADS requests behind it have: LDS-DMAs complete in the order they were issued
         // AMONG THEMSELVES, so "at most I_LOADS operations outstanding" implies it whatever else (stores) is still in flight.
