@@ -385,6 +385,9 @@ def main():
     ap.add_argument("--no-head-images", action="store_true",
                     help="A/B aid: attention in-projections write fp32 and attention runs on the kernels that split q / k / v while they "
                          "stage them (csrc/attention.hip) instead of head images + LDS-DMA (csrc/attention_img.hip)")
+    ap.add_argument("--no-fused-kv", action="store_true",
+                    help="A/B aid: every decoder layer projects the encoder memory to its cross-attention K/V itself (the reference's "
+                         "structure, model/layers.py:54-74) instead of ONE stacked projection for all layers (ops.cross_kv_projection)")
     ap.add_argument("--layernorm-images", action="store_true",
                     help="A/B aid: LayerNorm forward / backward also write the image operand of their output and the GEMMs behind "
                          "them take it (measured slower over the step: transformertts_amd/ops.py, LAYERNORM_IMAGES)")
@@ -431,6 +434,8 @@ def main():
         ops.HEAD_IMAGES = False
     if args.no_dma_big_fwd:
         ops.DMA_BIG_FWD = False
+    if args.no_fused_kv:
+        ops.FUSED_CROSS_KV = False
     cfg = model_config(args.config)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
               "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,
@@ -622,7 +627,7 @@ def main():
                        "alignments_written": bool(args.alignments),
                        "arithmetic": "3 x f16 MFMA terms per fp32 product (hi/lo f16 splits of both operands), fp32 accumulate",
                        "dma_gemms": not args.no_image_operands, "layernorm_images": bool(args.layernorm_images),
-                       "head_images": not args.no_head_images,
+                       "head_images": not args.no_head_images, "fused_cross_kv": not args.no_fused_kv,
                        "final_loss": final_loss, "per_step_loss_item_sync": False},
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "sustained": sustained,
@@ -633,10 +638,11 @@ def main():
         if rehearsal_check is not None:
             out["config"]["rehearsal_gradient_check"] = rehearsal_check
         if probe is not None:
-            # The dominant kernel forms every fp32 product from SIX bf16 x bf16 MFMA terms (3-way split operands), so the
-            # unit that bounds it is the bf16 matrix pipe: its ceiling in algorithmic (fp32-equivalent) FLOP/s is the dense
-            # bf16 peak / 6.  `frac` is priced against THAT ceiling; the fp32-MFMA peak (157.3 TF, what a plain
-            # v_mfma_f32 kernel is bound by, and the peak of the dtype) is reported beside it as a floor the kernel beats.
+            # The dominant kernel forms every fp32 product from THREE f16 x f16 MFMA terms (hi / lo splits of both operands,
+            # csrc/gemm_h3.hip), so the unit that bounds it is the f16 matrix pipe: its ceiling in algorithmic (fp32-equivalent)
+            # FLOP/s is the dense f16 peak / 3.  `frac` is priced against THAT ceiling (executed f16 flops over the dense f16
+            # peak: the same number); the fp32-MFMA peak (157.3 TF, what a plain v_mfma_f32 kernel is bound by, and the peak of
+            # the dtype) is reported beside it as a floor the kernel beats.
             traffic, traffic_src = measured_traffic(probe["kernel"], f"{args.config}_b{args.batch}")
             terms = (0, 6, 3)[probe["form"]]
             if terms:

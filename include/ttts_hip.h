@@ -138,7 +138,10 @@ int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode
  * first_block}, first_block = running sum of ttts_weight_split_units(rows, cols, mode, channels_per_tap) over the entries
  * before this one, total_blocks = the final sum.  (A unit is one workgroup: 256 elements of a bf16x6 image; a 32-row x
  * 32-channel tile, all taps of it, of an fp16x3 image -- read in the order the source is contiguous in and written as whole
- * 2 KB runs of the planes.) */
+ * 2 KB runs of the planes.)  A LINEAR fp16x3 entry (modes 4, 5, 8, 9) may be a WINDOW of a STACKED image that several
+ * weights share (the fused K/V projection of all decoder layers): channels_per_tap = (image rows << 32) | image columns and
+ * taps = (first image row << 32) | first image column of the window (a multiple of 32); `planes` then is the shared image,
+ * whose one tail -- one scale -- receives the maximum over every window's weight.  0 / 0: the entry is its own image. */
 int64_t ttts_weight_split_units(int64_t rows, int64_t cols, int mode, int channels_per_tap);
 int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks, void* stream);
 int ttts_linear_fwd_x6(const float* x, const void* w_planes, const float* bias, const float* residual, float* y,
@@ -227,6 +230,14 @@ int ttts_linear_bwd_weight_h3(const float* dy, const float* x, float* dw, float*
 int ttts_conv1d_bwd_weight_h3(const float* dy, const float* x, float* dw, float* dbias, float* ws, size_t ws_bytes, int B,
                               int T, int cin, int cout, int taps, int accumulate, const float* dy_amax, const float* x_amax,
                               ttts_reduce_queue* queue, void* stream);
+/* ONE weight-gradient GEMM dy^T x (N x K) whose N rows belong to `nparts` weights (equal row blocks): block i is reduced into
+ * dw_parts[i] ((N / nparts) x K floats) and its column sums into dbias_parts[i] (NULL array: no bias gradients); dw_parts /
+ * dbias_parts are HOST arrays of device pointers.  The backward of the cross-attention K/V projection of every decoder layer
+ * run as one GEMM on the encoder memory they all read (the reference runs it per layer: model/layers.py:54-74, rows d..3d of
+ * each layer's multihead_attn.in_proj_weight). */
+int ttts_linear_bwd_weight_h3_parts(const float* dy, const float* x, float* const* dw_parts, float* const* dbias_parts, int nparts,
+                                    float* ws, size_t ws_bytes, int64_t M, int N, int K, int accumulate, const float* dy_amax,
+                                    const float* x_amax, ttts_reduce_queue* queue, void* stream);
 
 /* ------------------------------------------------------------------ Conv1d (k taps, same padding) on (B,T,C)
  * Replaces ConvNormBN's permute -> nn.Conv1d(pad=(k-1)//2) -> permute (model/module.py:28-33) as an

@@ -25,6 +25,11 @@ def _rel(a, b):
     return rel_l2(a, b)
 
 
+def guarded(shape, fill, guard_rows=1):
+    from conftest import guarded as g
+    return g(shape, fill, guard_rows)
+
+
 def _decode(img, inv):
     """head image (M, N 4-byte cells) + inverse scales (N / 64, M) -> float64 (M, N)"""
     M, N = img.shape
@@ -66,11 +71,16 @@ def test_in_projection_writes_head_images(M, N, K):
     xa = ops._amax(x)
 
     def run():
-        img = torch.full((M, N), float("nan"), device=dev)
-        inv = torch.full((N // 64, M), float("nan"), device=dev)
-        am = torch.zeros(nsec, ops.AMAX_SLOTS, device=dev)
+        # guard rows behind every output: the section maxima (one more section of slots: where the publish of a head past the
+        # last column -- (129, 192, 96): hcol = 192 of a 256-column tile, section 3 of 3 -- landed before round 5's fix), the
+        # inverse scales (one more head plane) and the image (one more row block)
+        img, chk_img = guarded((M, N), float("nan"), guard_rows=128)
+        inv, chk_inv = guarded((N // 64, M), float("nan"))
+        am, chk_am = guarded((nsec, ops.AMAX_SLOTS), 0.0)
         _lib.check(lib.ttts_linear_fwd_h3d_img(_p(x), _p(pl), _p(b), _p(img), _p(inv), M, N, K, _p(xa), _p(am), N // nsec if nsec > 1 else 0,
                                                _stream()), "fwd_h3d_img")
+        torch.cuda.synchronize()
+        chk_img(); chk_inv(); chk_am()
         return img, inv, am
     img, inv, am = run()
     ref = x.double() @ w.double().t() + b.double()
@@ -131,17 +141,23 @@ def _run_img(q, kv, do, lens, causal, H, p_drop=0.0, seed=0, want_attn=True):
     qi, qinv = _himg(q.reshape(B * Tq, d).contiguous())
     kvi, kvinv = _himg(kv.reshape(B * Tk, 2 * d).contiguous())
     va = ops._amax(kv[..., d:].contiguous())
-    o = torch.full((B, Tq, d), float("nan"), device=dev)
-    stat = torch.full((6, B, H, Tq), float("nan"), device=dev)
-    attn = torch.full((B, H, Tq, Tk), float("nan"), device=dev) if (want_attn and not causal) else None
-    oslots = torch.zeros(ops.AMAX_SLOTS, device=dev)
+    checks = []
+
+    def G(shape, fill):       # every output with a sentinel block behind it (conftest.guarded)
+        t, chk = guarded(shape, fill)
+        checks.append(chk)
+        return t
+    o = G((B, Tq, d), float("nan"))
+    stat = G((6, B, H, Tq), float("nan"))
+    attn = G((B, H, Tq, Tk), float("nan")) if (want_attn and not causal) else None
+    oslots = G((1, ops.AMAX_SLOTS), 0.0)[0]
     HK = H * B * Tk
     _lib.check(lib.ttts_attention_fwd_img(_p(qi), _off(kvi, 0), _off(kvi, d), _p(qinv), _off(kvinv, 0), _off(kvinv, HK), _p(o), _p(stat[0]),
                                           _p(attn), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, causal, 0.125, p_drop, seed, None, _p(va),
                                           _p(oslots), _p(stat[1:]), _stream()), "fwd_img")
-    dq, dkv = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
-    delta = torch.empty(B, H, Tq, device=dev)
-    sq, sk = torch.zeros(ops.AMAX_SLOTS, device=dev), torch.zeros(ops.AMAX_SLOTS, device=dev)
+    dq, dkv = G(tuple(q.shape), float("nan")), G(tuple(kv.shape), float("nan"))
+    delta = G((B, H, Tq), 0.0)
+    sq, sk = G((1, ops.AMAX_SLOTS), 0.0)[0], G((1, ops.AMAX_SLOTS), 0.0)[0]
     _lib.check(lib.ttts_attention_bwd_img(_p(qi), _off(kvi, 0), _off(kvi, d), _p(qinv), _off(kvinv, 0), _off(kvinv, HK), _p(o), _p(do),
                                           _p(stat[1:]), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d,
                                           d, d, 2 * d, 2 * d, causal, 0.125, p_drop, seed, None, _p(ops._amax(do)), _p(sq), _p(sk), None, 1,
@@ -150,15 +166,18 @@ def _run_img(q, kv, do, lens, causal, H, p_drop=0.0, seed=0, want_attn=True):
     if not causal and Tq >= 64:
         # the same backward with the query range of the dK / dV kernel split over 3 workgroups per key block: partial sums + one
         # fixed-order reduction -- equal to fp32 rounding of the sum order, maxima published by the reduction
-        dq2, dkv2 = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
-        part = torch.full((3, B, Tk, 2 * d), float("nan"), device=dev)
-        sk2 = torch.zeros(ops.AMAX_SLOTS, device=dev)
+        dq2, dkv2 = G(tuple(q.shape), float("nan")), G(tuple(kv.shape), float("nan"))
+        part = G((3, B, Tk, 2 * d), float("nan"))
+        sk2 = G((1, ops.AMAX_SLOTS), 0.0)[0]
         _lib.check(lib.ttts_attention_bwd_img(_p(qi), _off(kvi, 0), _off(kvi, d), _p(qinv), _off(kvinv, 0), _off(kvinv, HK), _p(o), _p(do),
                                               _p(stat[1:]), _p(delta), _p(dq2), _off(dkv2, 0), _off(dkv2, d), _p(kl), B, H, Tq, Tk, d, 2 * d,
                                               2 * d, d, d, 2 * d, 2 * d, causal, 0.125, p_drop, seed, None, _p(ops._amax(do)), None, _p(sk2),
                                               _p(part), 3, _stream()), "bwd_img split")
         out["dkv_split"], out["dkv_split_amax"] = dkv2, sk2
         assert torch.equal(dq2, dq)
+    torch.cuda.synchronize()
+    for chk in checks:
+        chk()
     return out
 
 
@@ -305,3 +324,95 @@ def test_full_size_attention_on_head_images_is_reproducible():
             assert torch.isfinite(a[k]).all() and torch.equal(a[k], b[k]), k
         if a["attn"] is not None:
             assert torch.equal(a["attn"], b["attn"])
+
+
+def _decoder_stack(layers=3, d=256, h=4, ff=512, scales=(1.0, 30.0, 0.01)):
+    from transformertts_amd.model import layers as L
+    torch.manual_seed(21)
+    dec = L.TransformerDecoder(L.TransformerDecoderLayer(d, h, ff, dropout=0.0), layers)
+    for p in dec.parameters():                 # (deep copies of one layer: make the layers differ)
+        torch.nn.init.normal_(p, std=0.06) if p.dim() > 1 else torch.nn.init.normal_(p, mean=0.3, std=0.2)
+    with torch.no_grad():                      # K/V projections of very different magnitude per layer: ONE image scale serves them all
+        for layer, sc in zip(dec.layers, scales):
+            layer.multihead_attn.in_proj_weight[d:] *= sc
+            layer.multihead_attn.in_proj_bias[d:] *= sc
+    return dec.cuda().train()
+
+
+def test_one_kv_projection_for_all_decoder_layers():
+    """ops.cross_kv_projection: the K/V projections of every decoder layer's cross-attention as ONE head-image GEMM over the
+    encoder memory (N = layers x 2 d_model) on a STACKED weight image, one data-gradient GEMM of reduction depth N, one
+    weight-gradient GEMM reduced into each layer's rows -- against the reference's structure (model/layers.py:54-74: one
+    projection per layer; torch.nn.TransformerDecoder in fp64 with the same state dict): outputs, per-head alignments, input
+    and parameter gradients; and against this library's own per-layer path (FUSED_CROSS_KV off).  The layers' K/V weights differ
+    by x30 / x0.01: rows of the stacked image share one power-of-two scale, their per-(row, head) output scales do the rest."""
+    from conftest import rel_l2
+    from transformertts_amd import ops
+    d, h, ff, B, Tq, Tk = 256, 4, 512, 3, 150, 70
+    dec = _decoder_stack(3, d, h, ff)
+    ref = torch.nn.TransformerDecoder(torch.nn.TransformerDecoderLayer(d, h, ff, dropout=0.0, batch_first=True), 3)
+    ref.load_state_dict(dec.state_dict(), strict=True)
+    ref = ref.double().train()
+    g = torch.Generator().manual_seed(8)
+    tgt, mem, dy = torch.randn(B, Tq, d, generator=g), torch.randn(B, Tk, d, generator=g), torch.randn(B, Tq, d, generator=g)
+    tl, ml = [150, 97, 33], [70, 41, 9]
+    t64, m64 = tgt.double().requires_grad_(True), mem.double().requires_grad_(True)
+    causal = torch.triu(torch.ones(Tq, Tq, dtype=torch.bool), 1)
+    tk = torch.arange(Tq)[None, :] >= torch.tensor(tl)[:, None]
+    mk = torch.arange(Tk)[None, :] >= torch.tensor(ml)[:, None]
+    y_ref = ref(t64, m64, tgt_mask=causal, tgt_key_padding_mask=tk, memory_key_padding_mask=mk)
+    y_ref.backward(dy.double())
+    live = (~tk).unsqueeze(-1).double()
+
+    def run(fused):
+        ops.FUSED_CROSS_KV = fused
+        try:
+            for p in dec.parameters():
+                p.grad = None
+            tc, mc = tgt.cuda().requires_grad_(True), mem.cuda().requires_grad_(True)
+            y, al = dec(tc, mc, tgt_lens=torch.tensor(tl).cuda(), memory_lens=torch.tensor(ml).cuda())
+            y.backward(dy.cuda())
+            return y.detach(), [a.detach() for a in al], tc.grad, mc.grad, {n: p.grad.clone() for n, p in dec.named_parameters()}
+        finally:
+            ops.FUSED_CROSS_KV = True
+    assert ops.cross_kv_ok(mem.cuda(), [l.multihead_attn for l in dec.layers], h)
+    yf, af, dtf, dmf, gf = run(True)
+    yu, au, dtu, dmu, gu = run(False)
+    # vs torch fp64 (padded query rows are not comparable: torch's -inf rows; compare live rows)
+    assert rel_l2(yf.cpu().double() * live, y_ref.detach() * live) < 2e-5
+    assert rel_l2(dmf.cpu(), m64.grad) < 2e-5 and rel_l2(dtf.cpu().double() * live, t64.grad * live) < 2e-5
+    for (n, q) in ref.named_parameters():
+        if q.grad.norm() > 1e-9 and not n.endswith("in_proj_bias"):
+            assert rel_l2(gf[n].cpu(), q.grad) < 3e-5, (n, rel_l2(gf[n].cpu(), q.grad))
+    # vs the per-layer path of this library: same arithmetic up to the weight image's shared scale
+    assert rel_l2(yf, yu) < 5e-6 and rel_l2(dmf, dmu) < 5e-6 and rel_l2(dtf, dtu) < 5e-6
+    for a, b in zip(af, au):
+        assert rel_l2(a, b) < 5e-6
+    for n in gf:
+        if gu[n].norm() > 1e-9:
+            assert rel_l2(gf[n], gu[n]) < 1e-5, (n, rel_l2(gf[n], gu[n]))
+    # a second fused run gives the same bits (fixed-order reductions, no atomics on values)
+    y2, _, dt2, dm2, g2 = run(True)
+    assert torch.equal(yf, y2) and torch.equal(dmf, dm2) and all(torch.equal(gf[n], g2[n]) for n in gf)
+
+
+def test_head_image_is_not_a_tensor():
+    """`linear(..., head_image_sections=n)` returns a HeadImage: typed-fp32 cells that hold f16 pairs must not be sliced,
+    cloned, hooked or fed to the fp32 kernels by accident -- the wrapper has no tensor interface, and the attention
+    wrappers refuse a mix of image and fp32 operands."""
+    from transformertts_amd import ops
+    x, w, b = _rand(2, 40, 256, seed=1), _rand(768, 256, seed=2, scale=0.06), _rand(768, seed=3)
+    qkv = ops.linear(x, w, b, head_image_sections=3)
+    assert isinstance(qkv, ops.HeadImage) and not isinstance(qkv, torch.Tensor) and tuple(qkv.shape) == (2, 40, 768)
+    for misuse in (lambda: qkv[..., :256], lambda: qkv.clone(), lambda: qkv.contiguous(), lambda: qkv + 1, lambda: torch.isfinite(qkv),
+                   lambda: qkv.register_hook(print)):
+        with pytest.raises((TypeError, AttributeError)):
+            misuse()
+    lens = torch.tensor([40, 17], device=_dev())
+    o = ops.self_attention(qkv, lens, 4, True, 0.0, 0)
+    ref = ops.self_attention(ops.linear(x, w, b, publish_amax=True), lens, 4, True, 0.0, 0)
+    assert _rel(o, ref) < 1e-5
+    q = ops.linear(x, w[:256].contiguous(), b[:256].contiguous(), head_image_sections=1)
+    kv32 = ops.linear(x, w[256:].contiguous(), b[256:].contiguous(), publish_amax=True)
+    with pytest.raises(ValueError):
+        ops.cross_attention(q, kv32, lens, 4, 0.0, 0)

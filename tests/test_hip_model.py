@@ -178,15 +178,13 @@ def test_forward_backward_vs_oracle(cfg_name, B, Tp, Tm, w_seed, b_seed):
     over = {k: v for k, v in gerrs.items() if not v < gate}
     if over:
         # a parameter above the flat gate (seen: 2.6e-5 on a BatchNorm bias at 3000 frames, 7e-5 on pe.alpha of the scaled model --
-        # both sums with heavy cancellation) is still held to what stock fp32 torch achieves UNDER THE SAME GATES: twice its error
-        # (a SCALAR parameter's rel-L2 is the relative error of ONE such sum -- pe.alpha: d alpha = sum over every position of dy . pe,
-        # 5-50 x smaller than its terms' mass, so the 2.6e-5 every tensor gradient of the scaled model carries shows up amplified
-        # and with the sign of chance: 7e-5 in round 4, 1.1e-4 in round 5 while every tensor gradient got better.  One sample of
-        # stock fp32's error is no tighter a yardstick than that: three times it for scalars.)
+        # both sums with heavy cancellation) is still held to what stock fp32 torch achieves UNDER THE SAME GATES: twice its error,
+        # and never more than the contract's 1e-4 (north_star).  (Round 5 allowed a scalar parameter three times stock fp32's
+        # error while pe.alpha of the scaled model read 1.1e-4 mid-round; the final build reads 4.6e-5 and no case needs it.)
         stock, _ = _oracle_gated_grads(cfg, w_seed, batch, hip_gates, dtype=torch.float32)
         for k, v in over.items():
             e32 = rel_l2(stock[k], gated[k])
-            if not v < (3.0 if gated[k].numel() == 1 else 2.0) * e32:
+            if not (v < 2.0 * e32 and v < GATE):
                 bad[k] = (v, e32)
     assert not bad, bad
 
@@ -289,12 +287,12 @@ def test_golden_gradients_direct(golden_dir, fixture):
         elif not e_hip <= e_exact + 2.0 * gate:
             bad[name] = ("farther from the reference's fp32 gradients than exact arithmetic is", e_hip, e_exact)
     if over:
-        # above the flat gate: held to what stock fp32 torch achieves under the same gates -- twice its error, three times for a
-        # scalar (pe.alpha; see test_forward_backward_vs_oracle)
+        # above the flat gate: held to what stock fp32 torch achieves under the same gates -- twice its error, and never above the
+        # contract's 1e-4 (see test_forward_backward_vs_oracle)
         stock, _ = _oracle_gated_grads(cfg, w_seed, batch, hip_gates, dtype=torch.float32)
         for k, v in over.items():
             e32 = rel_l2(stock[k], exact[k])
-            if not v < (3.0 if exact[k].numel() == 1 else 2.0) * e32:
+            if not (v < 2.0 * e32 and v < 1e-4):
                 bad[k] = ("vs exact arithmetic under the same gates", v, "stock fp32", e32)
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/parity_golden_gradients_{fixture}.txt", "w") as f:

@@ -343,8 +343,10 @@ def test_no_sgpr_hazard_in_front_of_inline_assembly_memory_instructions():
 def test_dropout_seed_stream_restarts_with_a_reseeded_module():
     """train.py:24-28 of the reference seeds everything and then builds the module: doing that twice in one process with the
     same seed must give the same dropout masks (the reference draws them from torch's generator, which the seed resets).  Here
-    the mask stream is `ops.seeds`; `torch.manual_seed(s)` with an unchanged s is invisible to it, so building a
-    LightningModule re-arms the stream.  An explicit `manual_seed` pins it until `follow_torch()`."""
+    the mask stream is `ops.seeds`; `torch.manual_seed(s)` with an unchanged s leaves torch.initial_seed() as it was, so the calls
+    are counted (ops._torch_seed_calls) and a re-seed restarts the stream.  Building a module WITHOUT seeding again (evaluation
+    copy, EMA / teacher, load_from_checkpoint) does not: the training module must not replay the masks of step 0.
+    An explicit `manual_seed` pins the stream until `follow_torch()`."""
     from transformertts_amd import ops
     from transformertts_amd.lightning_module import LightningModule
     from transformertts_amd.workload import model_config
@@ -364,6 +366,13 @@ def test_dropout_seed_stream_restarts_with_a_reseeded_module():
             s.ensure_seeded()                          # a later step of the same module continues the stream
             assert s.counter == 3
         assert draws[0] == draws[1] and draws[0] != draws[2]
+        LightningModule(config)                        # a second module mid-run, no re-seed: the stream goes on
+        s.ensure_seeded()
+        assert s.counter == 3 and s.next() not in draws[2]
+        s.counter = 3
+        torch.random.manual_seed(6)                    # the other public spelling is counted too
+        s.ensure_seeded()
+        assert s.counter == 0 and [s.next() for _ in range(3)] == draws[2]
         s.manual_seed(99)
         a = [s.next() for _ in range(2)]
         torch.manual_seed(5)
@@ -408,3 +417,19 @@ def test_mask_arguments_are_read_as_torch_reads_them():
     assert torch.equal(L._additive_mask(f, B, 2, T, T), f.reshape(B, 2, T, T))
     with pytest.raises(ValueError):
         L._additive_mask(torch.zeros(T + 1, T), B, 2, T, T)
+    # non-finite float masks would reach the softmax: refused like a bad float key-padding mask
+    for bad in (float("nan"), float("inf")):
+        g = f.clone()
+        g[0, 0, 0] = bad
+        with pytest.raises(ValueError):
+            L._additive_mask(g, B, 2, T, T)
+    assert torch.isfinite(L._additive_mask(f.masked_fill(f > 1, float("-inf")), B, 2, T, T)).all()
+    # lengths AND a key-padding mask: the mask must be the prefix mask of those lengths, or its holes would be lost silently
+    got, dead = L._lens_and_kpm(lens, prefix, B, T, "cpu", "x")
+    assert dead is None and torch.equal(got, lens)
+    with pytest.raises(ValueError):
+        L._lens_and_kpm(lens, holes, B, T, "cpu", "x")
+    with pytest.raises(ValueError):
+        L._lens_and_kpm(torch.tensor([9, 5, 0]), prefix, B, T, "cpu", "x")
+    got, dead = L._lens_and_kpm(None, holes, B, T, "cpu", "x")
+    assert torch.equal(dead, holes)

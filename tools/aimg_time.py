@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-launch times of the head-image attention kernels at the BASELINE shapes (causal self-attention 64 x 4 x 870, cross
 870 x 100 with weights, encoder 100 x 100): HIP events around back-to-back launches; run under
-`rocprofv3 --kernel-trace --stats` for the per-kernel split of the backward.  usage: tools/aimg_time.py [p_drop] [reps]"""
+`rocprofv3 --kernel-trace --stats` for the per-kernel split of the backward.  usage: python3 tools/aimg_time.py [p_drop] [reps]   (under the profiler: `rocprofv3 --kernel-trace --stats -- python3 tools/aimg_time.py ...` -- the interpreter itself behind `--`, never the script through its env shebang: that is an exec hop behind the profiler's preloaded library, which this pool forbids)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

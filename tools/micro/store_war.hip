@@ -8,6 +8,9 @@
 //      buffer_store_dwordx4 v[100:103] ; K fillers ; v_pk_mul_f32 v[100:101] *= 2 ; v_pk_mul_f32 v[102:103] *= 2
 // with K = 0..7 fillers of two kinds (s_nop 0, or an independent VALU instruction as a compiler would put there), on a chip
 // whose every CU is storing, with and without LDS reads in flight, and counts the stored dwords that came out doubled.
+// Round 6: the same with the store's row offset in an SGPR soffset (`sgpr_soffset` rows) -- the form for which hipcc inserts NO
+// wait states at all (GCNHazardRecognizer::createsVALUHazard exempts MUBUF stores with a register soffset), which is what the
+// head-image epilogue's damaged stores had in common.
 //   hipcc --offload-arch=gfx950 -O3 tools/micro/store_war.hip -o tools/micro/store_war && tools/micro/store_war
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -31,7 +34,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define REP16(x) REP8(x) REP8(x)
 
 // MODE 0: s_nop fillers; 1: VALU fillers (v_add_f32 on an unrelated register)
-#define KERNEL(NAME, FILL)                                                                                                   \
+#define KERNEL(NAME, FILL, SOFF, VOFF_IT)                                                                                                   \
     __global__ __launch_bounds__(256) void NAME(float* out, int iters, int lds_traffic) {                                   \
         __shared__ float lbuf[4096];                                                                                        \
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;                                                         \
@@ -46,17 +49,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 two = {2.0f, 2.0f};                                                                          \
         for (int it = 0; it < iters; ++it) {                                                                                \
             const float p0 = 1.0f + lane + 64.f * (it & 63), p1 = p0 + 0.25f, p2 = p0 + 0.5f, p3 = p0 + 0.75f;              \
-            const uint32_t voff = (uint32_t)it * 1024u + (uint32_t)lane * 16u;                                              \
+            const uint32_t voff = (uint32_t)it * (VOFF_IT) + (uint32_t)lane * 16u;                                          \
+            const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(it * (1024 - (VOFF_IT)));                        \
             float4 l = make_float4(0.f, 0.f, 0.f, 0.f);                                                                     \
             if (lds_traffic) l = *reinterpret_cast<const float4*>(lbuf + ((lane * 4 + it * 64) & 4092));                    \
             asm volatile("v_mov_b32 v100, %2\n\tv_mov_b32 v101, %3\n\tv_mov_b32 v102, %4\n\tv_mov_b32 v103, %5\n\t"          \
                          "s_nop 4\n\t"                                                                                     \
-                         "buffer_store_dwordx4 v[100:103], %6, %7, 0 offen\n\t" FILL                                         \
+                         "buffer_store_dwordx4 v[100:103], %6, %7, " SOFF " offen\n\t" FILL                                        \
                          "v_pk_mul_f32 v[100:101], v[100:101], %8\n\t"                                                     \
                          "v_pk_mul_f32 v[102:103], v[102:103], %8\n\t"                                                     \
                          "v_add_f32 %0, v100, v103\n\t"                                                                      \
                          : "+v"(junk), "+v"(fill)                                                                            \
-                         : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(voff), "s"(rsrc), "v"(two)                                  \
+                         : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(voff), "s"(rsrc), "v"(two), "s"(soff)                       \
                          : "v100", "v101", "v102", "v103", "memory");                                                      \
             junk += l.x + l.y + l.z + l.w;                                                                                  \
         }                                                                                                                   \
@@ -65,10 +69,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define NOP(k) REP##k("s_nop 0\n\t")
 #define VAL(k) REP##k("v_add_f32 %1, %1, %1\n\t")
-KERNEL(kn0, NOP(0)) KERNEL(kn1, NOP(1)) KERNEL(kn2, NOP(2)) KERNEL(kn3, NOP(3)) KERNEL(kn4, NOP(4)) KERNEL(kn5, NOP(5))
-KERNEL(kn6, NOP(6)) KERNEL(kn7, NOP(7)) KERNEL(kn8, NOP(8)) KERNEL(kn12, NOP(12)) KERNEL(kn16, NOP(16))
-KERNEL(kv0, VAL(0)) KERNEL(kv1, VAL(1)) KERNEL(kv2, VAL(2)) KERNEL(kv3, VAL(3)) KERNEL(kv4, VAL(4)) KERNEL(kv5, VAL(5))
-KERNEL(kv6, VAL(6)) KERNEL(kv7, VAL(7)) KERNEL(kv8, VAL(8)) KERNEL(kv12, VAL(12)) KERNEL(kv16, VAL(16))
+#define KX(...) KERNEL(__VA_ARGS__)
+#define IMM "0", 1024u
+#define SGP "%9", 0u          /* the row offset rides in an SGPR soffset: the form LLVM's hazard recogniser exempts */
+KX(kn0, NOP(0), IMM) KX(kn1, NOP(1), IMM) KX(kn2, NOP(2), IMM) KX(kn3, NOP(3), IMM) KX(kn4, NOP(4), IMM) KX(kn5, NOP(5), IMM)
+KX(kn6, NOP(6), IMM) KX(kn7, NOP(7), IMM) KX(kn8, NOP(8), IMM) KX(kn12, NOP(12), IMM) KX(kn16, NOP(16), IMM)
+KX(kv0, VAL(0), IMM) KX(kv1, VAL(1), IMM) KX(kv2, VAL(2), IMM) KX(kv3, VAL(3), IMM) KX(kv4, VAL(4), IMM) KX(kv5, VAL(5), IMM)
+KX(kv6, VAL(6), IMM) KX(kv7, VAL(7), IMM) KX(kv8, VAL(8), IMM) KX(kv12, VAL(12), IMM) KX(kv16, VAL(16), IMM)
+KX(ks0, NOP(0), SGP) KX(ks1, NOP(1), SGP) KX(ks2, NOP(2), SGP) KX(ks3, NOP(3), SGP) KX(ks4, NOP(4), SGP)
 
 typedef void (*kern_t)(float*, int, int);
 
@@ -82,7 +90,9 @@ int main() {
         {"s_nop", kn0, 0}, {"s_nop", kn1, 1}, {"s_nop", kn2, 2}, {"s_nop", kn3, 3}, {"s_nop", kn4, 4}, {"s_nop", kn5, 5}, {"s_nop", kn6, 6},
         {"s_nop", kn7, 7}, {"s_nop", kn8, 8}, {"s_nop", kn12, 12}, {"s_nop", kn16, 16},
         {"valu", kv0, 0}, {"valu", kv1, 1}, {"valu", kv2, 2}, {"valu", kv3, 3}, {"valu", kv4, 4}, {"valu", kv5, 5}, {"valu", kv6, 6},
-        {"valu", kv7, 7}, {"valu", kv8, 8}, {"valu", kv12, 12}, {"valu", kv16, 16}};
+        {"valu", kv7, 7}, {"valu", kv8, 8}, {"valu", kv12, 12}, {"valu", kv16, 16},
+        {"sgpr_soffset+s_nop", ks0, 0}, {"sgpr_soffset+s_nop", ks1, 1}, {"sgpr_soffset+s_nop", ks2, 2}, {"sgpr_soffset+s_nop", ks3, 3},
+        {"sgpr_soffset+s_nop", ks4, 4}};
     printf("# buffer_store_dwordx4 v[100:103]; K fillers; v_pk_mul_f32 v[100:101]; v_pk_mul_f32 v[102:103]  -- %d workgroups x 4 waves x %d stores\n", blocks, iters);
     printf("# filler K lds_reads  stored_dwords  doubled(dword0 dword1 dword2 dword3)  other_wrong\n");
     for (auto& e : ks)
@@ -103,7 +113,7 @@ int main() {
                             if (c[q] == 2.f * want) ++dbl[q]; else ++other;
                         }
                     }
-            printf("%-6s %2d %d  %zu  %ld %ld %ld %ld  %ld\n", e.name, e.fill, lds, n, dbl[0], dbl[1], dbl[2], dbl[3], other);
+            printf("%-18s %2d %d  %zu  %ld %ld %ld %ld  %ld\n", e.name, e.fill, lds, n, dbl[0], dbl[1], dbl[2], dbl[3], other);
         }
     hipFree(d);
     return 0;

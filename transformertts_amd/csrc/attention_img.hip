@@ -41,6 +41,7 @@ struct AttnImgArgs {
     // 256 workgroups for 256 CUs, each streaming every query): split z writes its partial sums to dkv_part + z * part_stride in
     // the layout of the packed (dk, dv) gradient, and attn_dkv_reduce_kernel adds the splits in fixed order
     float* dkv_part; long part_stride;
+    int ldp;                                              // row stride of the partial sums: 2 H 64 (dk | dv packed), whatever lddk is
     float* o_amax;
     // (5, B, H, Tq): 0 = exponent subtrahend mcs, 1 = log2 of the row sum, 2 = one-hot flag (as attention.hip), 3 = the row's
     // exponent multiplier c2 = 2^-e_q * qscale * log2(e), 4 = its score multiplier c = 2^-e_q * qscale
@@ -100,6 +101,17 @@ __device__ __forceinline__ void img_tensor_scale(const float* __restrict__ parti
     scale = h3_uniform(s);
     inv = h3_uniform(i);
 }
+
+// development ablation (never defined in the product build; results are WRONG, timing only): -DTTTS_AIMG_ABL_SAMEKV makes every
+// workgroup stream the K / V (dK / dV kernel: the Q / dO) of (batch 0, head 0) -- every tile request then hits L2 --, the upper
+// bound of what ANY K / V reuse scheme between a head's query blocks could buy
+#ifdef TTTS_AIMG_ABL_SAMEKV
+#define AIMG_SB(b) 0
+#define AIMG_SH(h) 0
+#else
+#define AIMG_SB(b) (b)
+#define AIMG_SH(h) (h)
+#endif
 
 #ifdef TTTS_AIMG_STAMPS
 // development aid (tools/aimg_stamps.py; never defined in the product build): per (workgroup, wave) sums of s_memtime ticks of the
@@ -196,10 +208,10 @@ __global__ __launch_bounds__(256, KT == 32 ? 3 : 2) void attn_fwd_img_kernel(Att
     // ---- K / V tiles by LDS-DMA.  This wave moves rows (KT / 4) w .. of each plane in 8-row pieces: lane -> (row lane / 8 of the
     // piece, chunk slot lane & 7), and the chunk it FETCHES is slot ^ isw(row).  Rows past the last key are clamped to it (finite data the masks
     // remove; nothing of another allocation is touched).
-    const u32x4a rsK = make_rsrc(reinterpret_cast<const char*>(a.k) + ((long)b * a.Tk * a.ldk + h * HD) * 4, (uint32_t)a.Tk * (uint32_t)a.ldk * 4u);
-    const u32x4a rsV = make_rsrc(reinterpret_cast<const char*>(a.v) + ((long)b * a.Tk * a.ldv + h * HD) * 4, (uint32_t)a.Tk * (uint32_t)a.ldv * 4u);
-    const u32x4a rsKi = make_rsrc(a.k_inv + (long)h * a.k_rows + (long)b * a.Tk, (uint32_t)a.Tk * 4u);
-    const u32x4a rsVi = make_rsrc(a.v_inv + (long)h * a.k_rows + (long)b * a.Tk, (uint32_t)a.Tk * 4u);
+    const u32x4a rsK = make_rsrc(reinterpret_cast<const char*>(a.k) + ((long)AIMG_SB(b) * a.Tk * a.ldk + AIMG_SH(h) * HD) * 4, (uint32_t)a.Tk * (uint32_t)a.ldk * 4u);
+    const u32x4a rsV = make_rsrc(reinterpret_cast<const char*>(a.v) + ((long)AIMG_SB(b) * a.Tk * a.ldv + AIMG_SH(h) * HD) * 4, (uint32_t)a.Tk * (uint32_t)a.ldv * 4u);
+    const u32x4a rsKi = make_rsrc(a.k_inv + (long)AIMG_SH(h) * a.k_rows + (long)AIMG_SB(b) * a.Tk, (uint32_t)a.Tk * 4u);
+    const u32x4a rsVi = make_rsrc(a.v_inv + (long)AIMG_SH(h) * a.k_rows + (long)AIMG_SB(b) * a.Tk, (uint32_t)a.Tk * 4u);
     const uint32_t lds0 = lds_addr_a(xs);
     const int ld_r = lane >> 3;                                       // row within an 8-row piece
     const uint32_t ld_c0 = (uint32_t)((lane & 7) ^ isw(ld_r)) * 16u;  // chunk fetched for piece nn = 0; nn = 1: ^ 32 bytes
@@ -814,10 +826,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_img_kernel(AttnImgArgs a) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
 
-    const u32x4a rsK = make_rsrc(reinterpret_cast<const char*>(a.k) + ((long)b * a.Tk * a.ldk + h * HD) * 4, (uint32_t)a.Tk * (uint32_t)a.ldk * 4u);
-    const u32x4a rsV = make_rsrc(reinterpret_cast<const char*>(a.v) + ((long)b * a.Tk * a.ldv + h * HD) * 4, (uint32_t)a.Tk * (uint32_t)a.ldv * 4u);
-    const u32x4a rsKi = make_rsrc(a.k_inv + (long)h * a.k_rows + (long)b * a.Tk, (uint32_t)a.Tk * 4u);
-    const u32x4a rsVi = make_rsrc(a.v_inv + (long)h * a.k_rows + (long)b * a.Tk, (uint32_t)a.Tk * 4u);
+    const u32x4a rsK = make_rsrc(reinterpret_cast<const char*>(a.k) + ((long)AIMG_SB(b) * a.Tk * a.ldk + AIMG_SH(h) * HD) * 4, (uint32_t)a.Tk * (uint32_t)a.ldk * 4u);
+    const u32x4a rsV = make_rsrc(reinterpret_cast<const char*>(a.v) + ((long)AIMG_SB(b) * a.Tk * a.ldv + AIMG_SH(h) * HD) * 4, (uint32_t)a.Tk * (uint32_t)a.ldv * 4u);
+    const u32x4a rsKi = make_rsrc(a.k_inv + (long)AIMG_SH(h) * a.k_rows + (long)AIMG_SB(b) * a.Tk, (uint32_t)a.Tk * 4u);
+    const u32x4a rsVi = make_rsrc(a.v_inv + (long)AIMG_SH(h) * a.k_rows + (long)AIMG_SB(b) * a.Tk, (uint32_t)a.Tk * 4u);
     const uint32_t lds0 = lds_addr_a(xs);
     const int ld_r = lane >> 3;
     const uint32_t ld_c0 = (uint32_t)((lane & 7) ^ isw(ld_r)) * 16u;
@@ -1025,8 +1037,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_img_kernel(AttnImgArgs a)
 
     // ---- the ring.  This wave moves rows 8 w .. 8 w + 7 of a stage: one 1-KB piece per Q plane (source chunks swizzled) and two
     // raw pieces of dO; waves 0 / 1 also the row statistics.  Rows past Tq are clamped (finite data; masked below).
-    const u32x4a rsQ = make_rsrc(reinterpret_cast<const char*>(a.q) + ((long)b * a.Tq * a.ldq + h * HD) * 4, (uint32_t)a.Tq * (uint32_t)a.ldq * 4u);
-    const u32x4a rsG = make_rsrc(a.dout + (long)b * a.Tq * a.ldo + h * HD, (uint32_t)a.Tq * (uint32_t)a.ldo * 4u);
+    const u32x4a rsQ = make_rsrc(reinterpret_cast<const char*>(a.q) + ((long)AIMG_SB(b) * a.Tq * a.ldq + AIMG_SH(h) * HD) * 4, (uint32_t)a.Tq * (uint32_t)a.ldq * 4u);
+    const u32x4a rsG = make_rsrc(a.dout + (long)AIMG_SB(b) * a.Tq * a.ldo + AIMG_SH(h) * HD, (uint32_t)a.Tq * (uint32_t)a.ldo * 4u);
     const long plane = (long)a.B * a.H * a.Tq;
     const u32x4a rsS0 = make_rsrc(a.rowstat + arow, (uint32_t)a.Tq * 4u), rsS1 = make_rsrc(a.rowstat + plane + arow, (uint32_t)a.Tq * 4u);
     const u32x4a rsS3 = make_rsrc(a.rowstat + 3 * plane + arow, (uint32_t)a.Tq * 4u), rsS4 = make_rsrc(a.rowstat + 4 * plane + arow, (uint32_t)a.Tq * 4u);
@@ -1232,15 +1244,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_img_kernel(AttnImgArgs a)
         }
         if (a.amax_dkv != nullptr && gridDim.z == 1) amax_publish(kg < a.Tk ? mx : 0.f, a.amax_dkv, blockIdx.y * gridDim.x + blockIdx.x);
     }
-    float* dk_out = gridDim.z == 1 ? a.dk : a.dkv_part + (long)blockIdx.z * a.part_stride;
-    float* dv_out = gridDim.z == 1 ? a.dv : a.dkv_part + (long)blockIdx.z * a.part_stride + (a.dv - a.dk);
-    wave_store_rows4(dk, scratch4, dk_out + (long)b * a.Tk * a.lddk + h * HD, kw0, a.Tk, a.lddk, lane);
-    wave_store_rows4(dv, scratch4, dv_out + (long)b * a.Tk * a.lddv + h * HD, kw0, a.Tk, a.lddv, lane);
+    if (gridDim.z == 1) {
+        wave_store_rows4(dk, scratch4, a.dk + (long)b * a.Tk * a.lddk + h * HD, kw0, a.Tk, a.lddk, lane);
+        wave_store_rows4(dv, scratch4, a.dv + (long)b * a.Tk * a.lddv + h * HD, kw0, a.Tk, a.lddv, lane);
+    } else {            // partial sums: packed rows of (dk | dv), 2 H 64 floats each
+        float* part = a.dkv_part + (long)blockIdx.z * a.part_stride + (long)b * a.Tk * a.ldp + h * HD;
+        wave_store_rows4(dk, scratch4, part, kw0, a.Tk, a.ldp, lane);
+        wave_store_rows4(dv, scratch4, part + a.H * HD, kw0, a.Tk, a.ldp, lane);
+    }
 }
 
-// out[i] = part[0][i] + part[1][i] + ... (fixed order), 16 bytes per lane; max|out| published
+// out[row][c] = part[0][row][c] + part[1][row][c] + ... (fixed order), 16 bytes per lane; the partial sums are packed rows of
+// cols4 float4s, the output has a row stride of its own (a layer's window of the stacked K/V gradient); max|out| published
 __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n4, int zs,
-                                                              long stride, float* __restrict__ amax) {
+                                                              long stride, float* __restrict__ amax, int cols4, long out_ld) {
     float mx = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 acc = reinterpret_cast<const float4*>(part)[i];
@@ -1248,7 +1265,8 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const float* __res
             const float4 v = reinterpret_cast<const float4*>(part + (long)z * stride)[i];
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        reinterpret_cast<float4*>(out)[i] = acc;
+        const long row = i / cols4;
+        *reinterpret_cast<float4*>(out + row * out_ld + (i - row * cols4) * 4) = acc;
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
     }
     if (amax != nullptr) amax_publish(mx, amax, blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -1324,9 +1342,10 @@ extern "C" int ttts_attention_fwd_img(const void* q, const void* k, const void* 
  * out-projection's data gradient left them; rowstat = the five planes ttts_attention_fwd_img wrote; do_amax = partial maxima
  * of |d_o|; delta (B,H,Tq) is scratch; plane 4 of rowstat (the rows' score multipliers) is ZEROED for one-hot rows by this call (the
  * dK / dV kernel reads it after the dQ kernel; nothing else does); dq_amax_out / dkv_amax_out: NULL, or zeroed TTTS_AMAX_SLOTS floats; dkv_partials / q_splits:
- * NULL / 1, or a workspace of q_splits x B x Tk x lddk floats: the dK / dV kernel then splits the QUERY range over q_splits
+ * NULL / 1, or a workspace of q_splits x B x Tk x 2 H 64 floats: the dK / dV kernel then splits the QUERY range over q_splits
  * workgroups per key block and a fixed-order reduction adds the partial sums (cross-attention's one key block per (batch, head)
- * otherwise leaves three quarters of the chip's wave slots empty); non-causal, packed (dk, dv) of row stride 2 H 64 only.  Replaces the same
+ * otherwise leaves three quarters of the chip's wave slots empty); non-causal, dv = dk + H 64 with one row stride >= 2 H 64 (a
+ * layer's window of a wider gradient tensor: the fused K/V projection of all decoder layers).  Replaces the same
  * call sites as ttts_attention_bwd_h3 (autograd of F.scaled_dot_product_attention / the explicit softmax path,
  * torch/nn/functional.py:6576-6629). */
 extern "C" int ttts_attention_bwd_img(const void* q, const void* k, const void* v, const float* q_inv, const float* k_inv,
@@ -1357,13 +1376,14 @@ extern "C" int ttts_attention_bwd_img(const void* q, const void* k, const void* 
     a.seed = seed; a.step_seed = step_seed;
     a.do_amax = do_amax; a.amax_dq = dq_amax_out; a.amax_dkv = dkv_amax_out;
     a.rowstat = const_cast<float*>(rowstat);
-    // q_splits > 1: dk / dv as partial sums over q_splits query ranges in dkv_partials (q_splits x B x Tk x ldd floats), then
-    // one reduction -- only for a packed (dk, dv) gradient that is one contiguous (B, Tk, 2 H 64) tensor
+    // q_splits > 1: dk / dv as partial sums over q_splits query ranges in dkv_partials (q_splits x B x Tk x 2 H 64 floats), then
+    // one reduction into rows that hold dk then dv
     TTTS_REQUIRE(q_splits >= 1 && q_splits <= 16, "attention_bwd_img: q_splits out of 1..16");
     if (q_splits > 1) {
-        TTTS_REQUIRE(dkv_partials && !causal && dv == dk + H * HD && lddk == 2 * H * HD && lddv == lddk,
-                     "attention_bwd_img: query splits need a workspace and a packed (dk, dv) gradient of row stride 2 H 64");
-        a.dkv_part = dkv_partials; a.part_stride = (long)B * Tk * lddk;
+        TTTS_REQUIRE(dkv_partials && !causal && dv == dk + H * HD && lddk >= 2 * H * HD && lddv == lddk,
+                     "attention_bwd_img: query splits need a workspace and a (dk | dv) gradient whose rows hold dk then dv");
+        a.ldp = 2 * H * HD;
+        a.dkv_part = dkv_partials; a.part_stride = (long)B * Tk * a.ldp;
     }
     dim3 gq(B * H, cdiv(Tq, QB), 1), gk(B * H, cdiv(Tk, QB), q_splits);
     if (causal) {
@@ -1380,7 +1400,7 @@ extern "C" int ttts_attention_bwd_img(const void* q, const void* k, const void* 
         const long n4 = a.part_stride / 4;
         const long blocks = (n4 + 255) / 256;
         hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, dkv_partials, dk, n4,
-                           q_splits, a.part_stride, dkv_amax_out);
+                           q_splits, a.part_stride, dkv_amax_out, a.ldp / 4, (long)lddk);
         TTTS_LAUNCH_CHECK("attn_dkv_reduce_kernel");
     }
     return TTTS_OK;

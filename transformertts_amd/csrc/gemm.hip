@@ -429,28 +429,43 @@ __device__ __forceinline__ const long* batched_desc(const long* __restrict__ des
 }
 
 // fp16x3 images (modes 4-7) carry max|w| in their tail: zero the tails, then one atomic max per wave
+// A LINEAR entry (modes 4, 5, 8, 9) may describe a WINDOW of a stacked image (weight_split_h3_tile): d[5] = (image rows << 32) |
+// image columns, d[6] = (first image row << 32) | first image column of the window; d[5] = 0: the entry is its own image.
+struct DescGeom { long Rimg, Cimg; int r_off, c_off; bool stacked; };
+__device__ __forceinline__ DescGeom desc_geom(const long* d) {
+    DescGeom g;
+    const bool conv = h3_mode_base(d[4]) >= 2;
+    g.stacked = !conv && d[5] != 0;
+    g.Rimg = g.stacked ? (d[5] >> 32) : d[2];
+    g.Cimg = g.stacked ? (d[5] & 0xffffffffL) : d[3];
+    g.r_off = g.stacked ? (int)(d[6] >> 32) : 0;
+    g.c_off = g.stacked ? (int)(d[6] & 0xffffffffL) : 0;
+    return g;
+}
+__device__ __forceinline__ float* batched_tail(const long* d) {
+    const bool conv = h3_mode_base(d[4]) >= 2;
+    const DescGeom g = desc_geom(d);
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(d[1]) +
+                                    h3_plane_bytes(g.Rimg, h3_image_cols(g.Cimg, conv ? (int)d[5] : 0, conv ? (int)d[6] : 0)));
+}
 __global__ __launch_bounds__(256) void weight_tail_zero_batched_kernel(const long* __restrict__ descs, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const long* d = descs + i * 8;
-        if (d[4] >= 4) {
-            const bool conv = h3_mode_base(d[4]) >= 2;
-            *reinterpret_cast<float*>(reinterpret_cast<char*>(d[1]) +
-                                      h3_plane_bytes(d[2], h3_image_cols(d[3], conv ? (int)d[5] : 0, conv ? (int)d[6] : 0))) = 0.f;
-        }
+        if (d[4] >= 4) *batched_tail(d) = 0.f;
     }
 }
 // The images of ONE weight (forward / data-gradient, row-major / K16-major: up to four table entries, adjacent because the table
 // is built parameter by parameter) share max|w|: the first of them -- the leader -- measures it, the others copy it while they
-// are split (weight_split_batched_kernel).  Same source address and element count = same tensor.
+// are split (weight_split_batched_kernel).  Same source address and element count = same tensor.  Windows of stacked images
+// share only among themselves: the tail they publish into holds the maximum over EVERY weight of the stack (each window's
+// leader adds its own), which a plain image of one of those weights must not take for its own scale.
 __device__ __forceinline__ const long* batched_leader(const long* __restrict__ descs, const long* d) {
     const long* l = d;
-    while (l > descs && (l - 8)[0] == d[0] && (l - 8)[2] * (l - 8)[3] == d[2] * d[3] && (l - 8)[4] >= 4) l -= 8;
+    const bool stacked = desc_geom(d).stacked;
+    while (l > descs && (l - 8)[0] == d[0] && (l - 8)[2] * (l - 8)[3] == d[2] * d[3] && (l - 8)[4] >= 4 &&
+           desc_geom(l - 8).stacked == stacked)
+        l -= 8;
     return l;
-}
-__device__ __forceinline__ const float* batched_tail(const long* d) {
-    const bool conv = h3_mode_base(d[4]) >= 2;
-    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(d[1]) +
-                                          h3_plane_bytes(d[2], h3_image_cols(d[3], conv ? (int)d[5] : 0, conv ? (int)d[6] : 0)));
 }
 
 __global__ __launch_bounds__(256) void weight_amax_batched_kernel(const long* __restrict__ descs, int n) {
@@ -460,7 +475,7 @@ __global__ __launch_bounds__(256) void weight_amax_batched_kernel(const long* __
         const bool conv = h3_mode_base(d[4]) >= 2;
         weight_amax_h3_unit(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
                             h3_image_cols(d[3], conv ? (int)d[5] : 0, conv ? (int)d[6] : 0), blk - d[7],
-                            h3_split_units(d[2], d[3], h3_mode_base(d[4]), (int)d[5]));
+                            h3_split_units(d[2], d[3], h3_mode_base(d[4]), conv ? (int)d[5] : 0), batched_tail(d));
     }
 }
 
@@ -471,9 +486,13 @@ __global__ __launch_bounds__(256) void weight_split_batched_kernel(const long* _
     if (d[4] >= 4) {    // modes 4-7: the fp16x3 image of modes 0-3 (block-uniform branch), a 32 x 32 tile per workgroup
         const long* lead = batched_leader(descs, d);
         const float* amax = batched_tail(lead);
-        if (lead != d && blk == d[7] && threadIdx.x == 0) *const_cast<float*>(batched_tail(d)) = *amax;      // the GEMMs read the image's own tail
+        // the GEMMs read the image's own tail (for the windows of a stacked image: every window writes the same value)
+        if (lead != d && blk == d[7] && threadIdx.x == 0) *batched_tail(d) = *amax;
+        const DescGeom g = desc_geom(d);
+        const bool conv = h3_mode_base(d[4]) >= 2;
         weight_split_h3_tile(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2],
-                             (int)d[3], h3_mode_base(d[4]), (int)d[5], (int)d[6], blk - d[7], t, h3_mode_k16(d[4]), amax);
+                             (int)d[3], h3_mode_base(d[4]), conv ? (int)d[5] : 0, conv ? (int)d[6] : 0, blk - d[7], t, h3_mode_k16(d[4]), amax,
+                             g.stacked ? (int)g.Rimg : 0, g.r_off, g.c_off);
     } else
         weight_split_one(reinterpret_cast<const float*>(d[0]), reinterpret_cast<unsigned short*>(d[1]), (int)d[2], (int)d[3],
                          (int)d[4], (int)d[5], (int)d[6], (blk - d[7]) * 256 + threadIdx.x);
@@ -1130,6 +1149,36 @@ int ttts_linear_bwd_weight_h3(const float* dy, const float* x, float* dw, float*
                                   x_amax);
 }
 
+int ttts_linear_bwd_weight_h3_parts(const float* dy, const float* x, float* const* dw_parts, float* const* dbias_parts, int nparts,
+                                    float* ws, size_t ws_bytes, int64_t M, int N, int K, int accumulate, const float* dy_amax,
+                                    const float* x_amax, ttts_reduce_queue* queue, void* stream_) {
+    // ONE weight-gradient GEMM dy^T x (N x K) whose N rows belong to `nparts` different weights (equal row blocks): block i is
+    // reduced into dw_parts[i] ((N / nparts) x K, contiguous) and its column sums into dbias_parts[i] -- the fused K/V
+    // projection of all decoder layers' cross-attention (model/layers.py:54-74 runs it once per layer on the same memory)
+    hipStream_t stream = (hipStream_t)stream_;
+    TTTS_REQUIRE(dy && x && dw_parts && ws && dy_amax && x_amax, "linear_bwd_weight_h3_parts: null pointer");
+    TTTS_REQUIRE(nparts > 0 && nparts <= 64 && N % nparts == 0 && (N / nparts) % 4 == 0, "linear_bwd_weight_h3_parts: N=%d does not split in %d blocks of whole float4s", N, nparts);
+    TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1LL << 31) && K % 4 == 0, "linear_bwd_weight_h3_parts: bad dims");
+    TTTS_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(ws), "linear_bwd_weight_h3_parts: pointers must be 16-byte aligned");
+    TTTS_REQUIRE(ws_bytes >= ttts_wgrad_workspace_bytes(M, N, K, 1), "linear_bwd_weight_h3_parts: workspace too small");
+    for (int i = 0; i < nparts; ++i) TTTS_REQUIRE(dw_parts[i] != nullptr, "linear_bwd_weight_h3_parts: null destination");
+    WgradPlan p;
+    const long n = (long)N * K;
+    const bool x6 = wgrad_use_x6(N, K);
+    const bool want_b = dbias_parts != nullptr && dbias_parts[0] != nullptr;
+    float* colsum_ws = want_b ? ws + (size_t)plan_wgrad(M, N, K, 1, x6, x6 ? HBK : BK).nsplit * n : nullptr;
+    int rc = wgrad_common(dy, x, ws, colsum_ws, M, N, K, 1, 0, 0, 0, &p, x6, stream, x6 ? dy_amax : nullptr, x_amax);
+    if (rc) return rc;
+    const int Np = N / nparts;
+    const long np = (long)Np * K;
+    for (int i = 0; i < nparts; ++i) {
+        rc = launch_reduce_rows_pair(ws + (size_t)i * np, n, p.nsplit, np, dw_parts[i], want_b ? colsum_ws + (size_t)i * Np : nullptr, N, Np,
+                                     want_b ? dbias_parts[i] : nullptr, accumulate != 0, stream, queue);
+        if (rc) return rc;
+    }
+    return TTTS_OK;
+}
+
 size_t ttts_conv1d_pack_bytes(int cout, int cin, int taps) { return (size_t)cout * cin * taps * sizeof(float); }
 
 int ttts_conv1d_pack_weight(const float* w, float* w_fwd, float* w_bwd, int cout, int cin, int taps, void* stream) {
@@ -1260,7 +1309,8 @@ int ttts_weight_split(const float* w, void* planes, int rows, int cols, int mode
 int64_t ttts_weight_split_units(int64_t rows, int64_t cols, int mode, int channels_per_tap) {
     // workgroups an entry of ttts_weight_split_batched takes: 256 elements each (bf16x6 images), a 32-row x 32-channel
     // tile over all taps each (fp16x3 images)
-    return mode >= 4 ? h3_split_units(rows, cols, h3_mode_base(mode), channels_per_tap) : (rows * cols + 255) / 256;
+    // (linear entries may carry the geometry of a stacked image in channels_per_tap / taps: no part of their unit count)
+    return mode >= 4 ? h3_split_units(rows, cols, h3_mode_base(mode), h3_mode_base(mode) >= 2 ? channels_per_tap : 0) : (rows * cols + 255) / 256;
 }
 
 int ttts_weight_split_batched(const int64_t* descs, int n, int64_t total_blocks, void* stream) {

@@ -77,10 +77,17 @@ __device__ __forceinline__ float4 buf_load4s(__amdgpu_buffer_rsrc_t rsrc, uint32
     const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, (int)soff, 0);
     return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 }
+// STORE-DATA HAZARD: a 16-byte buffer store fetches its data registers a few cycles after it issues; a VALU
+// instruction that overwrites one of them needs two wait states behind the store (tools/micro/store_war.hip: with fewer, 5 % of
+// the stored dwords are the NEW value).  hipcc pads for that itself -- except when the store's soffset is an SGPR
+// (GCNHazardRecognizer::createsVALUHazard exempts that form, a rule from older chips; gfx950 is not exempt: round 5's head-image
+// corruption).  Every wide store with a scalar offset therefore goes through this helper: the statement behind the store reads
+// the four data registers two wait states later, so nothing can recycle them earlier; tools/isa_hazard_scan.py checks the ISA.
+__device__ __forceinline__ void store_data_guard(u32x4 v) { asm volatile("s_nop 1" :: "v"(v) : "memory"); }
 __device__ __forceinline__ void buf_store4s(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint32_t soff, float4 x) {
-    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-    const u32x4_ v = {__float_as_uint(x.x), __float_as_uint(x.y), __float_as_uint(x.z), __float_as_uint(x.w)};
+    const u32x4 v = {__float_as_uint(x.x), __float_as_uint(x.y), __float_as_uint(x.z), __float_as_uint(x.w)};
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, (int)soff, 0);
+    store_data_guard(v);
 }
 
 // ---- fp16x3 ("h3") split: constants and the weight-plane image (see gemm_h3.hip)
@@ -161,8 +168,10 @@ __host__ __device__ __forceinline__ long h3_split_units(long R, long C, int mode
 // The source is R * C contiguous floats whatever the mode: unit u of `units` takes the u-th chunk of it, a float4 per lane
 // and trip.  One atomic per wave, behind a look at the tail -- every wave of a weight aims at the same word, and after the
 // first few arrivals almost none has anything to add.
+// `tail`: where the maximum goes when it is not behind THIS weight's own R x image_cols planes (a stacked image: several
+// weights publish into the one tail of the image they share)
 __device__ __forceinline__ void weight_amax_h3_unit(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
-                                                    int C, long image_cols, long unit, long units) {
+                                                    int C, long image_cols, long unit, long units, float* tail_at = nullptr) {
     const long n = (long)R * C;
     const long chunk = ((n + units - 1) / units + 3) & ~3L;
     const long i0 = unit * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
@@ -180,7 +189,8 @@ __device__ __forceinline__ void weight_amax_h3_unit(const float* __restrict__ w,
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.f) {
-        unsigned int* tail = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(planes) + h3_plane_bytes(R, image_cols));
+        unsigned int* tail = tail_at != nullptr ? reinterpret_cast<unsigned int*>(tail_at)
+                                                : reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(planes) + h3_plane_bytes(R, image_cols));
         if (__float_as_uint(m) > __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(tail, __float_as_uint(m));
     }
 }
@@ -194,11 +204,18 @@ __device__ __forceinline__ void weight_amax_h3_unit(const float* __restrict__ w,
 // k16 = true (modes 8-11 of ttts_weight_split): the K16-MAJOR image the image-operand kernel (gemm_h3i.hip) stages by LDS-DMA --
 // [c'/16][r][{16 f16 hi, 16 f16 lo}], i.e. one 64-byte group per (16-deep k-tile, row) and the 16 KB a 256-row tile needs per
 // k-tile in ONE contiguous run of whole 128-byte lines.  Same bytes, same padding, same tail.
+// STACKED images (linear weights only; the fused cross-attention K/V projection of all decoder layers): the R x C block this
+// call splits is a WINDOW of a larger image of Rimg rows -- image rows r_off .. r_off + R - 1 (the forward image: the output
+// columns of several weights side by side) or image columns c_off .. (the data-gradient image: their reduction indices one
+// behind the other; c_off a multiple of 32).  Rimg = 0: the image is the block itself.  All windows of an image share its
+// tail, i.e. one scale (`amax` then points at it).
 __device__ __forceinline__ void weight_split_h3_tile(const float* __restrict__ w, unsigned short* __restrict__ planes, int R,
                                                      int C, int mode, int c2, int taps, long unit, float (*t)[32][33],
-                                                     bool k16 = false, const float* amax = nullptr) {
+                                                     bool k16 = false, const float* amax = nullptr, int Rimg = 0, int r_off = 0,
+                                                     int c_off = 0) {
     const int chans = mode >= 2 ? c2 : C;
     if (mode < 2) taps = 1;
+    if (Rimg <= 0) { Rimg = R; r_off = 0; c_off = 0; }
     const int ngc = (chans + 31) / 32, nrun = (ngc + H3_SPLIT_RUN - 1) / H3_SPLIT_RUN;
     const int r0 = (int)(unit / nrun) * 32, cb0 = (int)(unit % nrun) * H3_SPLIT_RUN;
     const int nr = min(32, R - r0);
@@ -219,7 +236,7 @@ __device__ __forceinline__ void weight_split_h3_tile(const float* __restrict__ w
         }
 #pragma unroll
         for (int u = 0; u < H3_SPLIT_RUN; ++u) {
-            const int cp = (cb0 + u) * 32 + q;
+            const int cp = c_off + (cb0 + u) * 32 + q;
             if (rr < nr && cb0 + u < ngc) {
                 const float vv[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
                 unsigned short h[4], l[4];
@@ -231,9 +248,10 @@ __device__ __forceinline__ void weight_split_h3_tile(const float* __restrict__ w
                     h[e] = __builtin_bit_cast(unsigned short, hh);
                     l[e] = __builtin_bit_cast(unsigned short, ll);
                 }
-                const long o = k16 ? ((long)(cp >> 4) * R + r0 + rr) * 32 + (cp & 15) : ((long)(cp >> 5) * 2 * R + r0 + rr) * 32 + (cp & 31);
+                const long o = k16 ? ((long)(cp >> 4) * Rimg + r_off + r0 + rr) * 32 + (cp & 15)
+                                   : ((long)(cp >> 5) * 2 * Rimg + r_off + r0 + rr) * 32 + (cp & 31);
                 *reinterpret_cast<uint2*>(planes + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
-                *reinterpret_cast<uint2*>(planes + o + (k16 ? 16L : (long)R * 32)) =
+                *reinterpret_cast<uint2*>(planes + o + (k16 ? 16L : (long)Rimg * 32)) =
                     make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
             }
         }
@@ -269,7 +287,7 @@ __device__ __forceinline__ void weight_split_h3_tile(const float* __restrict__ w
         const int rr = tid >> 3, q = (tid & 7) * 4;
         if (rr < nr) {
             for (int tt = 0; tt < tcn; ++tt) {
-                const int cp = (mode >= 2 ? (tc0 + tt) * padc : 0) + ch0 + q;
+                const int cp = c_off + (mode >= 2 ? (tc0 + tt) * padc : 0) + ch0 + q;
                 unsigned short h[4], l[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -279,9 +297,10 @@ __device__ __forceinline__ void weight_split_h3_tile(const float* __restrict__ w
                     h[e] = __builtin_bit_cast(unsigned short, hh);
                     l[e] = __builtin_bit_cast(unsigned short, ll);
                 }
-                const long o = k16 ? ((long)(cp >> 4) * R + r0 + rr) * 32 + (cp & 15) : ((long)(cp >> 5) * 2 * R + r0 + rr) * 32 + (cp & 31);
+                const long o = k16 ? ((long)(cp >> 4) * Rimg + r_off + r0 + rr) * 32 + (cp & 15)
+                                   : ((long)(cp >> 5) * 2 * Rimg + r_off + r0 + rr) * 32 + (cp & 31);
                 *reinterpret_cast<uint2*>(planes + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
-                *reinterpret_cast<uint2*>(planes + o + (k16 ? 16L : (long)R * 32)) =
+                *reinterpret_cast<uint2*>(planes + o + (k16 ? 16L : (long)Rimg * 32)) =
                     make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
             }
         }

@@ -430,12 +430,11 @@ __global__ __launch_bounds__(TM * 2, TM == 128 ? 2 : 1) void gemm_h3i_kernel(Gem
                             __builtin_amdgcn_raw_buffer_store_b128(hi[1], rsrcC, (int)(live ? loff + 64u : OOB), (int)soff, 0);
                             __builtin_amdgcn_raw_buffer_store_b128(lo[0], rsrcC, (int)(live ? loff + 128u : OOB), (int)soff, 0);
                             __builtin_amdgcn_raw_buffer_store_b128(lo[1], rsrcC, (int)(live ? loff + 192u : OOB), (int)soff, 0);
-                            // The data registers of these stores are recycled by the next row's packed multiplies.  A
-                            // `buffer_store_dwordx4` reads its data some cycles after it issues: with the two VALU instructions hipcc
-                            // leaves between a store and the `v_pk_mul_f32` that overwrites its registers, the second dword of ~0.15 %
-                            // of the stores came out as the PRODUCT (tools/micro/store_war.hip: 5 % with one instruction between,
-                            // none seen from two on in isolation -- here, with LDS reads in flight, two were not enough).  The
-                            // statement keeps all four registers live and untouched for eight more states behind the last store.
+                            // STORE-DATA HAZARD (gemm_common.h): the data registers of these stores are recycled by the next
+                            // row's packed multiplies (and, in some instantiations, as the next store's ADDRESS register in the very next
+                            // instruction), and hipcc pads no wait states behind a wide buffer store whose soffset is an SGPR -- every
+                            // store of rows i, ps != 0, 0 here.  Round 5 met it as ~0.15 % of stores whose second dword was the next
+                            // product.  The statement keeps all four registers live and untouched behind the last store.
                             asm volatile("s_nop 7" :: "v"(hi[0]), "v"(hi[1]), "v"(lo[0]), "v"(lo[1]) : "memory");
                             if (c8 == 0)
                                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(inv), rsrcI,

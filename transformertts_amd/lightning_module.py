@@ -50,8 +50,8 @@ class LightningModule(_Base):
         # dropout / scheduled-sampling draws follow torch's process seed folded with the data-parallel rank (the reference
         # draws them from torch's global generator; replicas there differ because their generators advance differently).
         # Derived at the first training_step, not here: Lightning constructs the module before torch.distributed exists.
-        from . import ops
-        ops.seeds.rearm()          # a module built after a (re-)seed starts its mask stream from the beginning
+        # A (re-)seed of torch restarts the mask stream (ops.seeds.ensure_seeded sees it); building a module does not -- a
+        # second module in the process (evaluation copy, EMA / teacher, load_from_checkpoint) must not replay the masks of step 0.
 
     def forward(self, phoneme, melspec, phoneme_lens, melspec_lens, **kwargs):
         return self.model(phoneme, melspec, phoneme_lens, melspec_lens, **kwargs)
@@ -69,7 +69,7 @@ class LightningModule(_Base):
         # forward #1 (no grad, train mode: dropout on, BN statistics updated) -> the model's own prediction
         with torch.no_grad():   # only pred_melspec is used: do not materialise the attention maps
             pred_melspec = self.forward(phoneme, melspec, phoneme_lens, melspec_lens,
-                                        need_alignments=False)['pred_melspec']
+                                        need_alignments=False, need_stop=False)['pred_melspec']
         p_tf = self.teacher_forcing_ratio()
         mel_mixed = apply_teacher_forcing(pred_melspec, melspec, melspec_lens, p_tf, self.device)
         # forward #2 (with grad) on the mixed input, loss against the ground truth.  The loss reads the three prediction tensors

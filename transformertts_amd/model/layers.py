@@ -83,7 +83,22 @@ def _additive_mask(mask: Tensor, B: int, H: int, Tq: int, Tk: int) -> Tensor:
         raise ValueError(f"attention mask: expected ({Tq}, {Tk}) or ({B * H}, {Tq}, {Tk}), got {tuple(mask.shape)}")
     if m.dtype == torch.bool:
         return torch.zeros(m.shape, dtype=torch.float32, device=m.device).masked_fill(m, _NEG)
+    if bool((torch.isnan(m) | torch.isposinf(m)).any()):
+        raise ValueError("attention mask: float masks may hold finite values and -inf only (NaN / +inf would reach the softmax)")
     return m.to(torch.float32).clamp_min(_NEG)
+
+
+def _lens_and_kpm(lens: Optional[Tensor], kpm: Optional[Tensor], B: int, T: int, device, what: str):
+    """-> (lens, dead) of one side of an attention.  Lengths alone are the model's own call; a key-padding mask alone is torch's;
+    BOTH: the mask must be the prefix mask of those very lengths (anything else would silently lose its holes -- refused)."""
+    if lens is None:
+        return _resolve_kpm(kpm, B, T, device)
+    if kpm is not None:
+        got, dead = _resolve_kpm(kpm, B, T, device)
+        if dead is not None or not bool(torch.equal(got.to(lens.device), lens.to(torch.int64).clamp(0, T))):
+            raise ValueError(f"{what}: both lengths and a key-padding mask were given and the mask is not the prefix mask of those "
+                             "lengths; pass one of them")
+    return lens, None
 
 
 class MultiheadAttention(nn.Module):
@@ -128,10 +143,22 @@ class MultiheadAttention(nn.Module):
                           seed=ops.seeds.next() if out_drop > 0 else 0, skip_out=skip)
 
     def cross_attention(self, x: Tensor, mem: Tensor, mem_lens: Tensor, residual: Tensor, out_drop: float,
-                        need_weights: bool = True, dead: Optional[Tensor] = None, add_mask: Optional[Tensor] = None):
+                        need_weights: bool = True, dead: Optional[Tensor] = None, add_mask: Optional[Tensor] = None, kv=None):
+        """`kv`: None, or this layer's (k | v) HeadImage from the stack's one K/V projection of the memory
+        (`ops.cross_kv_projection`, TransformerDecoder.forward): the layer then projects only its queries"""
         d = self.embed_dim
         skip = ops.SkipToken() if residual is x else None
         wq, wkv = ops.param_rows(self.in_proj_weight, 0, d), ops.param_rows(self.in_proj_weight, d, 3 * d)
+        if kv is not None:
+            if dead is not None or add_mask is not None:
+                raise ValueError("cross_attention: a pre-projected K/V image takes length masks only")
+            q = ops.linear(x, wq, ops.param_rows(self.in_proj_bias, 0, d), skip_in=skip, head_image_sections=1)
+            p = self._p()
+            ctx, attn = ops.cross_attention(q, kv, mem_lens, self.num_heads, p, ops.seeds.next() if p > 0 else 0, need_weights)
+            ctx._ttts_sole_consumer = True
+            out = ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual, drop_p=out_drop,
+                             seed=ops.seeds.next() if out_drop > 0 else 0, skip_out=skip)
+            return out, (attn if need_weights else None)
         if dead is not None or add_mask is not None:
             q = ops.linear(x, wq, ops.param_rows(self.in_proj_bias, 0, d), skip_in=skip, publish_amax=True)
             kv = ops.linear(mem, wkv, ops.param_rows(self.in_proj_bias, d, 3 * d), publish_amax=True)
@@ -207,9 +234,7 @@ class TransformerEncoder(nn.Module):
     def forward(self, src: Tensor, mask=None, src_key_padding_mask: Optional[Tensor] = None,
                 src_lens: Optional[Tensor] = None) -> Tensor:
         B, T = src.size(0), src.size(1)
-        dead = None
-        if src_lens is None:
-            src_lens, dead = _resolve_kpm(src_key_padding_mask, B, T, src.device)
+        src_lens, dead = _lens_and_kpm(src_lens, src_key_padding_mask, B, T, src.device, "TransformerEncoder")
         add_mask = None if mask is None else _additive_mask(mask, B, self.layers[0].self_attn.num_heads, T, T)
         x = src
         for layer in self.layers:
@@ -246,15 +271,12 @@ class TransformerDecoderLayer(nn.Module):
                 memory_mask: Optional[Tensor] = None, tgt_key_padding_mask: Optional[Tensor] = None,
                 memory_key_padding_mask: Optional[Tensor] = None, tgt_is_causal: bool = True,
                 memory_is_causal: bool = False, tgt_lens: Optional[Tensor] = None,
-                memory_lens: Optional[Tensor] = None, need_alignments: bool = True):
+                memory_lens: Optional[Tensor] = None, need_alignments: bool = True, memory_kv=None):
         if memory_is_causal and memory_mask is None:
             raise ValueError("TransformerDecoderLayer: memory_is_causal is a hint about memory_mask and needs one (as torch)")
         B, Tq, Tk, H = tgt.size(0), tgt.size(1), memory.size(1), self.self_attn.num_heads
-        tgt_dead = mem_dead = None
-        if tgt_lens is None:
-            tgt_lens, tgt_dead = _resolve_kpm(tgt_key_padding_mask, B, Tq, tgt.device)
-        if memory_lens is None:
-            memory_lens, mem_dead = _resolve_kpm(memory_key_padding_mask, B, Tk, tgt.device)
+        tgt_lens, tgt_dead = _lens_and_kpm(tgt_lens, tgt_key_padding_mask, B, Tq, tgt.device, "TransformerDecoderLayer (tgt)")
+        memory_lens, mem_dead = _lens_and_kpm(memory_lens, memory_key_padding_mask, B, Tk, tgt.device, "TransformerDecoderLayer (memory)")
         # tgt_mask: the causal mask (what the reference's model passes, model/model.py:251-255) is the kernels' causal flag; any
         # other mask is applied as given.  Without a mask tensor `tgt_is_causal` (default True, model/layers.py:36) decides.
         tgt_add = None
@@ -274,14 +296,14 @@ class TransformerDecoderLayer(nn.Module):
             x2 = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps)
             s2, alignments = self.multihead_attn.cross_attention(x2, memory, memory_lens, residual=s,
                                                                  out_drop=self.dropout2.p if tr else 0.0,
-                                                                 need_weights=need_alignments, **ca)
+                                                                 need_weights=need_alignments, kv=memory_kv, **ca)
             x3 = ops.layer_norm(s2, self.norm3.weight, self.norm3.bias, self.norm3.eps)
             return _ffn_block(self, x3, self.dropout3, residual=s2), alignments
         s = self.self_attn.self_attention(tgt, tgt_lens, causal, residual=tgt, out_drop=self.dropout1.p if tr else 0.0, **sa)
         x = ops.layer_norm(s, self.norm1.weight, self.norm1.bias, self.norm1.eps, sole_consumer=True)
         s, alignments = self.multihead_attn.cross_attention(x, memory, memory_lens, residual=x,
                                                             out_drop=self.dropout2.p if tr else 0.0,
-                                                            need_weights=need_alignments, **ca)
+                                                            need_weights=need_alignments, kv=memory_kv, **ca)
         x = ops.layer_norm(s, self.norm2.weight, self.norm2.bias, self.norm2.eps, sole_consumer=True)
         x = ops.layer_norm(_ffn_block(self, x, self.dropout3), self.norm3.weight, self.norm3.bias, self.norm3.eps,
                            sole_consumer=True)
@@ -306,25 +328,40 @@ class TransformerDecoder(nn.Module):
                 memory_lens: Optional[Tensor] = None, need_alignments: bool = True):
         B = tgt.size(0)
         # prefix key-padding masks become lengths once, here; masks with holes travel on to the layers as tensors
-        if tgt_lens is None and tgt_key_padding_mask is not None:
-            lens, dead = _resolve_kpm(tgt_key_padding_mask, B, tgt.size(1), tgt.device)
+        if tgt_key_padding_mask is not None:
+            lens, dead = _lens_and_kpm(tgt_lens, tgt_key_padding_mask, B, tgt.size(1), tgt.device, "TransformerDecoder (tgt)")
             if dead is None:
                 tgt_lens, tgt_key_padding_mask = lens, None
-        if memory_lens is None and memory_key_padding_mask is not None:
-            lens, dead = _resolve_kpm(memory_key_padding_mask, B, memory.size(1), tgt.device)
+        if memory_key_padding_mask is not None:
+            lens, dead = _lens_and_kpm(memory_lens, memory_key_padding_mask, B, memory.size(1), tgt.device, "TransformerDecoder (memory)")
             if dead is None:
                 memory_lens, memory_key_padding_mask = lens, None
         if tgt_mask is not None and _is_causal_mask(tgt_mask, tgt.size(1), tgt.size(1)):
             tgt_mask, tgt_is_causal = None, True            # (checked once for the stack, not once per layer)
         alignments = []
-        memories = ops.fanout(memory, len(self.layers))     # one handle per layer: their gradients meet in one launch
-        for layer, memory in zip(self.layers, memories):
+        # The layers' cross-attentions all project the SAME memory (reference model/layers.py:54-74, once per layer): with plain
+        # length masks and 64-column heads that is ONE GEMM of N = layers x 2 d_model columns (ops.cross_kv_projection) whose
+        # backward also sums the layers' memory gradients; otherwise one handle per layer, their gradients meeting in one launch
+        attns = [layer.multihead_attn for layer in self.layers]
+        H = attns[0].num_heads
+        fused = (memory_mask is None and memory_key_padding_mask is None and memory.dim() == 3 and
+                 ops.cross_kv_ok(memory, attns, H) and
+                 ops.head_image_ok(tgt, attns[0].in_proj_weight.detach()[:memory.size(-1)], H, 1))
+        if fused:
+            if memory_lens is None:
+                memory_lens = torch.full((B,), memory.size(1), dtype=torch.int64, device=tgt.device)
+            kvs = ops.cross_kv_projection(memory, attns, self)
+            memories = [memory] * len(self.layers)          # (shapes only: the layers do not read it)
+        else:
+            kvs = [None] * len(self.layers)
+            memories = ops.fanout(memory, len(self.layers))     # one handle per layer: their gradients meet in one launch
+        for layer, memory, kv in zip(self.layers, memories, kvs):
             tgt, alignment = layer(tgt, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
                                    tgt_key_padding_mask=tgt_key_padding_mask,
                                    memory_key_padding_mask=memory_key_padding_mask,
                                    tgt_is_causal=True if tgt_is_causal is None else tgt_is_causal,
                                    memory_is_causal=bool(memory_is_causal), tgt_lens=tgt_lens,
-                                   memory_lens=memory_lens, need_alignments=need_alignments)
+                                   memory_lens=memory_lens, need_alignments=need_alignments, memory_kv=kv)
             alignments.append(alignment)
         if self.norm is not None:
             tgt = ops.layer_norm(tgt, self.norm.weight, self.norm.bias, self.norm.eps)

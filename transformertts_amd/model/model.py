@@ -180,11 +180,14 @@ class TransformerTTS(nn.Module):
         return self.encoder(x, src_lens=phoneme_lens)
 
     def forward(self, phoneme: Tensor, melspec: Tensor, phoneme_lens: Tensor, melspec_lens: Tensor,
-                need_alignments: bool = True) -> dict:
+                need_alignments: bool = True, need_stop: bool = True) -> dict:
         """
         `need_alignments=False` (an extension; the reference always returns them) skips writing the per-head
         cross-attention maps -- 267 MB per forward at batch 64 -- for callers that only want the mels, e.g. the
         no-grad first forward of `training_step`.  `alignments` is then a list of None.
+        `need_stop=False` (no-grad only; same caller): `pred_stop` is None -- the stop head is stateless and its logits have no
+        reader there (reference lightning_module.py:53-59 keeps `pred_melspec` alone).  The post-net still runs: its BatchNorm
+        running statistics are updated by that forward too.
 
         Args:
           - phoneme (B, T_phon) int64, melspec (B, T_mel, n_mels) fp32, phoneme_lens / melspec_lens (B,) int64,
@@ -204,7 +207,8 @@ class TransformerTTS(nn.Module):
                                            tgt_lens=melspec_lens, memory_lens=phoneme_lens,
                                            need_alignments=need_alignments)
         pred_melspec, pred_stop = ops.heads(tgt_out, self.linear1.linear.weight, self.linear1.linear.bias,
-                                            self.linear2.linear.weight, self.linear2.linear.bias)
+                                            self.linear2.linear.weight, self.linear2.linear.bias,
+                                            need_stop=need_stop or torch.is_grad_enabled())
         # three consumers of the prediction (the loss, the post-net, its residual): one handle each
         pred_melspec, pred_in, pred_res = ops.fanout(pred_melspec, 3)
         post_melspec = ops.AddFn.apply(self.postnet(pred_in), pred_res)

@@ -48,6 +48,32 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty((max(int(nbytes), 16) + 3) // 4, dtype=torch.float32, device=device)
 
 
+# `torch.manual_seed(s)` with an unchanged s leaves torch.initial_seed() as it was, so a re-seed is invisible from the value
+# alone; the reference's dropout draws restart with it (they come from torch's generator).  The two public spellings of the call
+# are therefore counted: a thin wrapper that bumps a counter and calls the original (Lightning's seed_everything goes through
+# torch.manual_seed).  Seeding a Generator object directly is not seen -- nor does the reference's module-level code do it.
+_torch_seed_calls = [0]
+
+
+def _count_torch_seeding() -> None:
+    if getattr(torch.manual_seed, "_ttts_counted", False):
+        return
+    orig = torch.manual_seed
+
+    def manual_seed(seed):
+        _torch_seed_calls[0] += 1
+        return orig(seed)
+    manual_seed.__doc__ = orig.__doc__
+    manual_seed._ttts_counted = True
+    manual_seed._ttts_orig = orig
+    torch.manual_seed = manual_seed
+    if getattr(torch.random, "manual_seed", None) is orig:
+        torch.random.manual_seed = manual_seed
+
+
+_count_torch_seeding()
+
+
 class _SeedStream:
     """64-bit dropout seeds: one per dropout site per forward call (the kernels hash seed + element index)."""
 
@@ -70,23 +96,25 @@ class _SeedStream:
             rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         self.base = (torch.initial_seed() ^ (0x9E3779B9 * (int(rank) + 1))) & 0xFFFFFFFFFFFF
         self.counter = 0
-        self._derived_from = (torch.initial_seed(), int(rank))
+        self._derived_from = (torch.initial_seed(), int(rank), _torch_seed_calls[0])
 
     def ensure_seeded(self) -> None:
         """Called at the first use of a step (training_step / TrainStep), i.e. when the process group exists -- Lightning
         builds the module BEFORE it initialises torch.distributed, so the rank read in a constructor is 0 on every replica.
-        Derives the base from (torch seed, rank) whenever that pair changed; does nothing after an explicit manual_seed()."""
+        Derives the base from (torch seed, rank) whenever that pair changed OR torch was seeded again (`_torch_seed_calls`: seeding
+        the same value twice in one process -- train.py:24-28 run twice -- reproduces the same masks, as the reference's draws
+        from torch's generator do); does nothing after an explicit manual_seed().  Building a second module (an evaluation copy,
+        an EMA / teacher model, load_from_checkpoint) does NOT restart the stream: only a (re-)seed does."""
         if self.explicit:
             return
         import torch.distributed as dist
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
-        if self._derived_from != (torch.initial_seed(), int(rank)):
+        if self._derived_from != (torch.initial_seed(), int(rank), _torch_seed_calls[0]):
             self.seed_from_torch(rank)
 
     def rearm(self) -> None:
-        """A new LightningModule was built (train.py:24-28: seed_everything, then the module): the next `ensure_seeded` derives
-        the base again and restarts the counter, so seeding the same value twice in one process reproduces the same masks --
-        `torch.manual_seed(s)` with an unchanged s is otherwise invisible from here.  No effect after `manual_seed()`."""
+        """The next `ensure_seeded` derives the base again and restarts the counter (explicit use; nothing on the product path
+        calls it -- a re-seed is seen through `_torch_seed_calls`).  No effect after `manual_seed()`."""
         self._derived_from = None
 
     def follow_torch(self) -> None:
@@ -215,6 +243,39 @@ def _bwd_h3(K: int, N: int, channels: int = 0) -> bool:
     return GEMM_MODE == "x6" and BWD_MODE == "h3" and K % 4 == 0 and channels % 4 == 0 and N % 4 == 0
 
 
+# ---- guard regions (TEST seam; tests/conftest.py switches it on around every -m gpu test).  The arrays kernels publish into
+# through plain pointers (partial maxima: `amax_publish`, an atomic on `slots + (slot & 1023)`; the per-(head, row) inverse scales
+# of a head image) then get one extra row behind them that holds a sentinel, and `check_guards()` asserts it is untouched: a
+# publish one section past an array (round 5: `sec = hcol / c_amax_sec` for a head past column N, csrc/gemm_h3i.hip) lands there
+# instead of in a neighbour's allocation.  (An atomic max of 0.0 -- what a head whose operands are all out of range publishes --
+# changes no value anywhere; the guard sees every write that could have changed a result.)
+GUARD = False
+GUARD_VALUE = 1.0e-30
+_guards: list = []
+
+
+def _guarded(rows: int, cols: int, device, what: str, keep: bool = False) -> torch.Tensor:
+    """(rows, cols) fp32, uninitialised, with a sentinel row behind it (GUARD mode only); `keep`: a long-lived array, checked by
+    every later `check_guards()` too"""
+    if torch.cuda.is_current_stream_capturing():
+        # memory of a graph's private pool is handed out again when the graph is dropped (TrainStep's shape-keyed cache evicts):
+        # a sentinel there would be "overwritten" by whoever gets the block next.  Captures run unguarded; the eager steps in
+        # front of every capture launch the same kernels on the same shapes.
+        return torch.empty(rows, cols, dtype=torch.float32, device=device)
+    a = torch.empty(rows + 1, cols, dtype=torch.float32, device=device)
+    a[rows].fill_(GUARD_VALUE)
+    _guards.append((what, a, keep))
+    return a[:rows]
+
+
+def check_guards() -> None:
+    """every sentinel row handed out since the last call is intact (raises AssertionError naming the arrays otherwise)"""
+    bad = [what for what, a, _ in _guards if not bool((a[-1] == GUARD_VALUE).all())]
+    _guards[:] = [g for g in _guards if g[2]]
+    if bad:
+        raise AssertionError(f"a kernel wrote behind: {sorted(set(bad))}")
+
+
 def _amax(t: torch.Tensor) -> torch.Tensor:
     """AMAX_SLOTS partial maxima of |t| (device), the dynamic pre-scale input of the fp16x3 gradient GEMMs: the array the kernel
     that produced `t` left on it (`_ttts_amax`, see _amax_slots), or a separate pass over `t`."""
@@ -223,7 +284,7 @@ def _amax(t: torch.Tensor) -> torch.Tensor:
         return ready
     if not t.is_contiguous():
         t = t.contiguous()
-    out = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=t.device)
+    out = _guarded(1, AMAX_SLOTS, t.device, "amax partials")[0] if GUARD else torch.empty(AMAX_SLOTS, dtype=torch.float32, device=t.device)
     _lib.check(_lib.load().ttts_amax_partials(_p(t), t.numel(), _p(out), _stream()), "ttts_amax_partials")
     return out
 
@@ -236,7 +297,8 @@ class _AmaxArena:
     SLICES = 512
 
     def __init__(self, device):
-        self.buf = torch.empty(self.SLICES, AMAX_SLOTS, dtype=torch.float32, device=device)
+        self.buf = _guarded(self.SLICES, AMAX_SLOTS, device, "amax arena", keep=True) if GUARD else \
+            torch.empty(self.SLICES, AMAX_SLOTS, dtype=torch.float32, device=device)
         self.next = 0
         self.clean = False          # True between reset() and release(): unissued slices are known to be zero
 
@@ -279,7 +341,7 @@ def _amax_slots(device, zero: bool) -> torch.Tensor:
         got = arena.take() if arena is not None else None
         if got is not None:
             return got
-    a = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=device)
+    a = _guarded(1, AMAX_SLOTS, device, "amax slots")[0] if GUARD else torch.empty(AMAX_SLOTS, dtype=torch.float32, device=device)
     if zero:
         _lib.check(_lib.load().ttts_zero(_p(a), AMAX_SLOTS * 4, _stream()), "ttts_zero")
     return a
@@ -291,7 +353,7 @@ def _amax_slots_n(device, n: int) -> torch.Tensor:
     got = arena.take(n) if arena is not None else None
     if got is not None:
         return got.view(n, AMAX_SLOTS)
-    a = torch.empty(n, AMAX_SLOTS, dtype=torch.float32, device=device)
+    a = _guarded(n, AMAX_SLOTS, device, "section maxima") if GUARD else torch.empty(n, AMAX_SLOTS, dtype=torch.float32, device=device)
     _lib.check(_lib.load().ttts_zero(_p(a), a.numel() * 4, _stream()), "ttts_zero")
     return a
 
@@ -406,6 +468,13 @@ _plane_entries: list = []        # every (weight, mode) split so far, for the on
 _plane_tables: dict = {}         # flat-storage address -> (signature, device descriptor table, pinned host copy, total blocks)
 
 
+def _split_units(rows: int, cols: int, mode: int, c2: int) -> int:
+    """work units of one entry of the batched refresh; a LINEAR entry's c2 / taps may hold the geometry of a stacked image
+    (64-bit packed, `_StackedPlanes`), which is no part of the count"""
+    conv = mode >= 4 and ((mode - 4) & 3) >= 2 or mode in (2, 3)
+    return int(_lib.load().ttts_weight_split_units(rows, cols, mode, c2 if conv else 0))
+
+
 def _refresh_all_planes(storage: int) -> None:
     """Re-split every registered weight that lives in the flat parameter storage at address `storage` (one model under
     one FlatAdam) and whose storage and version are unchanged (only the parameter epoch moved, i.e. an optimizer stepped
@@ -432,10 +501,9 @@ def _refresh_all_planes(storage: int) -> None:
     table = _plane_tables.get(storage)
     if table is None or table[0] != sig_t:
         rows, blk = [], 0
-        units = _lib.load().ttts_weight_split_units
         for s in sig:
             rows.append(list(s) + [blk])
-            blk += units(s[2], s[3], s[4], s[5])
+            blk += _split_units(s[2], s[3], s[4], s[5])
         host = torch.tensor(rows, dtype=torch.int64).pin_memory()      # page-locked: the upload does not synchronise
         table = _plane_tables[storage] = (sig_t, host.to(mine[0].planes.device, non_blocking=True), host, blk)
     lib = _lib.load()
@@ -466,12 +534,11 @@ class PlaneTable:
             raise RuntimeError("PlaneTable: the module has no weight planes yet (run one forward + backward first)")
         rows, blk = [], 0
         self.sig = []
-        units = _lib.load().ttts_weight_split_units
         for prm, e in self.entries:
             src = prm.data_ptr() + e.off
             self.sig.append((src, e.planes.data_ptr(), prm._version))
             rows.append([src, e.planes.data_ptr(), e.rows, e.cols, e.mode, e.c2, e.taps, blk])
-            blk += units(e.rows, e.cols, e.mode, e.c2)
+            blk += _split_units(e.rows, e.cols, e.mode, e.c2)
         self.blocks = blk
         self.host = torch.tensor(rows, dtype=torch.int64).pin_memory()
         self.dev = self.host.to(self.entries[0][1].planes.device, non_blocking=True)
@@ -692,7 +759,7 @@ class LinearFn(torch.autograd.Function):
         if y_himg is not None:
             # the output leaves as a HEAD IMAGE (attention in-projections: ttts_linear_fwd_h3d_img); y_himg = (row_inv, section maxima,
             # columns per section).  `y` keeps its fp32 geometry and dtype, but its cells hold f16 hi / lo pairs: only the attention
-            # kernels may read it (ops.self_attention / cross_attention look for `_ttts_himg`).
+            # kernels may read it (`linear` hands it out wrapped in a HeadImage, which is not a Tensor).
             if x_amax is None:
                 x_amax = _amax(x)
             row_inv, sec_amax, sec_cols = y_himg
@@ -864,6 +931,49 @@ class SkipToken:
 
 
 HEAD_IMAGES = True          # attention in-projections write head images and attention runs on them (csrc/attention_img.hip)
+FUSED_CROSS_KV = True       # ONE K/V projection of the encoder memory for all decoder layers (cross_kv_projection)
+
+
+class HeadImage:
+    """What an attention in-projection returns when its output leaves as a HEAD IMAGE (`linear(..., head_image_sections=n)`,
+    `cross_kv_projection`): per row and 64-column head {64 f16 hi, 64 f16 lo} of (x W^T + b) 2^e(row, head) in the 256 bytes
+    the fp32 columns would occupy, 2^-e in `row_inv`.  Deliberately NOT a Tensor: the cells are typed float32 and hold f16 pairs,
+    so anything but the attention kernels that read them (`self_attention`, `cross_attention`) would compute on garbage -- a
+    slice, a clone, a hook or a finite-check cannot be taken of this object by accident.
+      cells     the (B, T, width) tensor autograd tracks (row stride `ld` cells: a layer's window of a stacked projection)
+      row_inv   (all heads of the projection, B * T) inverse scales; this handle's heads start at head `col0 // 64`
+      sec_amax  (sections, AMAX_SLOTS) partial maxima per section of `sec_cols` columns of the projection
+      col0      first column of this handle inside the projection its row_inv / sec_amax describe
+      slab      None, or the gradient slab the producer wants this handle's gradient written into (`_KVGradSlab`)"""
+    __slots__ = ("cells", "row_inv", "sec_amax", "sec_cols", "col0", "slab", "index")
+
+    def __init__(self, cells, row_inv, sec_amax, sec_cols: int, col0: int = 0, slab=None, index: int = 0):
+        self.cells, self.row_inv, self.sec_amax, self.sec_cols, self.col0, self.slab, self.index = \
+            cells, row_inv, sec_amax, int(sec_cols), int(col0), slab, int(index)
+
+    @property
+    def shape(self):
+        return self.cells.shape
+
+    @property
+    def device(self):
+        return self.cells.device
+
+    @property
+    def ld(self) -> int:
+        return self.cells.stride(-2)
+
+    def inv_of(self, col: int):
+        """pointer to the inverse scales of the head that starts at column `col` of this handle"""
+        rows = self.row_inv.shape[1]
+        return _off(self.row_inv, ((self.col0 + col) // 64) * rows)
+
+    def amax_of(self, col: int) -> torch.Tensor:
+        """partial maxima of the section that holds column `col` of this handle"""
+        return self.sec_amax[(self.col0 + col) // self.sec_cols]
+
+    def __repr__(self):
+        return f"HeadImage(shape={tuple(self.shape)}, ld={self.ld}, col0={self.col0})"
 
 
 def head_image_ok(x: torch.Tensor, w: torch.Tensor, n_head: int, sections: int) -> bool:
@@ -880,6 +990,7 @@ def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_sh
     """`sole_consumer=True` is the caller's promise that nothing but this Linear reads `x`; if `x` came out of a
     relu(+dropout) Linear, its backward mask is then fused into this Linear's data-gradient epilogue.
     `skip_in` / `skip_out`: see SkipToken.
+    `head_image_sections` = n > 0: the output leaves as a head image of n sections (q | k | v) and a `HeadImage` is returned.
     `publish_amax`: the output feeds another fp16x3 GEMM / attention kernel, so the epilogue leaves its partial maxima on
     it (`y._ttts_amax`) and that consumer needs no pass of its own over y.  True, or a zeroed AMAX_SLOTS-float array to add the
     maxima to (a running maximum over several calls: the K/V cache of `inference`)."""
@@ -909,12 +1020,14 @@ def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_sh
             raise ValueError("linear: a head-image output takes a bias-only epilogue and whole 64-column heads per section")
         M = x.numel() // K
         sec = _amax_slots_n(x.device, head_image_sections)
-        y_himg = (torch.empty(N // 64, M, dtype=torch.float32, device=x.device), sec, N // head_image_sections)
+        inv = _guarded(N // 64, M, x.device, "head-image inverse scales") if GUARD else \
+            torch.empty(N // 64, M, dtype=torch.float32, device=x.device)
+        y_himg = (inv, sec, N // head_image_sections)
         y_am = None
     y = LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out, tok_in, skip_in, skip_out, tok_drop,
                        x_am, y_am, x_img, y_himg)
     if y_himg is not None:
-        y._ttts_himg = y_himg
+        return HeadImage(y, y_himg[0], y_himg[1], y_himg[2])
     if y_am is not None:
         y._ttts_amax = y_am
     if tok_drop is not None:
@@ -924,6 +1037,221 @@ def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_sh
         if _relu_observer is not None:
             _relu_observer(y)
     return y
+
+
+# ----------------------------------------------------------------------------------------------- fused cross-attention K/V
+def _pack2(hi: int, lo: int) -> int:
+    return (int(hi) << 32) | int(lo)
+
+
+class _StackedPlanes:
+    """ONE fp16x3 weight image of several parameter row slices (all (rows, cols)) STACKED: along the image's rows for the forward
+    image (mode 8: the slices' output columns side by side, N = n * rows) or along its reduction index for the data-gradient
+    image (mode 5: w^T of the slices one behind the other).  Each slice is an ordinary entry of the batched weight refresh
+    (`_plane_entries`, `PlaneTable`) whose descriptor names its window of the shared image (include/ttts_hip.h,
+    ttts_weight_split_batched); all windows share the image's tail, i.e. ONE scale from the maximum over every slice.  The
+    entries are cached on the parameters the slices were cut from, so the refresh after an optimizer step and the table a
+    captured graph replays cover them like any other weight."""
+
+    def __init__(self, slices, mode: int):
+        lib = _lib.load()
+        self.mode, self.n = mode, len(slices)
+        rows, cols = slices[0].shape
+        self.rows, self.cols = rows, cols
+        base = (mode - 4) & 3
+        if base == 0:
+            self.Rimg, self.Cimg = self.n * rows, cols          # forward image: (n rows, cols)
+            wins = [(_pack2(self.Rimg, self.Cimg), _pack2(i * rows, 0), rows, cols) for i in range(self.n)]
+        else:
+            if rows % 32 != 0:
+                raise ValueError("stacked data-gradient image: the slices' row counts must be multiples of 32")
+            self.Rimg, self.Cimg = cols, self.n * rows          # image of w^T: (cols, n rows)
+            wins = [(_pack2(self.Rimg, self.Cimg), _pack2(0, i * rows), cols, rows) for i in range(self.n)]
+        nwords = (int(lib.ttts_split_image_bytes(self.Rimg, self.Cimg, mode, 0, 0)) + 1) // 2
+        self.planes = torch.empty(nwords, dtype=torch.int16, device=slices[0].device)
+        self.entries = []
+        key = ("stack", mode, tuple(id(getattr(sl, "_ttts_planes_owner", (sl, 0))[0]) for sl in slices))
+        for sl, (geo, off, R, C) in zip(slices, wins):
+            holder, sub = getattr(sl, "_ttts_planes_owner", (sl, 0))
+            cache = getattr(holder, "_ttts_planes", None)
+            if cache is None:
+                cache = {}
+                holder._ttts_planes = cache
+            ent = _PlaneEntry()
+            ent.wref = weakref.ref(holder)
+            ent.off = sl.data_ptr() - holder.data_ptr()
+            ent.mode, ent.rows, ent.cols, ent.c2, ent.taps, ent.planes = mode, R, C, geo, off, self.planes
+            ent.tag = (holder._version, sl.data_ptr(), -1)
+            cache[(key, sub)] = ent
+            _plane_entries.append(ent)
+            self.entries.append((holder, ent))
+        # its own small refresh table (first build, and whenever the process-wide / TrainStep refresh has not covered it)
+        tab, blk = [], 0
+        for holder, e in self.entries:
+            tab.append([holder.data_ptr() + e.off, self.planes.data_ptr(), e.rows, e.cols, e.mode, e.c2, e.taps, blk])
+            blk += _split_units(e.rows, e.cols, e.mode, 0)
+        self.blocks = blk
+        self.sig = [(holder.data_ptr() + e.off) for holder, e in self.entries]
+        self.table = torch.tensor(tab, dtype=torch.int64).to(self.planes.device)
+
+    def alive(self, slices) -> bool:
+        return len(slices) == self.n and all(h.data_ptr() + e.off == sl.data_ptr() and e.planes is self.planes
+                                             for (h, e), sl in zip(self.entries, slices))
+
+    def current(self) -> bool:
+        return all(e.tag == (h._version, h.data_ptr() + e.off, _param_epoch) for h, e in self.entries)
+
+    def get(self) -> torch.Tensor:
+        if not self.current():
+            h0 = self.entries[0][0]
+            only_epoch = all(e.tag[0] == h._version and e.tag[1] == h.data_ptr() + e.off for h, e in self.entries)
+            if _BATCHED_SPLIT and only_epoch and not torch.cuda.is_current_stream_capturing():
+                _refresh_all_planes(h0.untyped_storage().data_ptr())       # the optimizer stepped: this model's images at once
+            if not self.current():
+                _lib.check(_lib.load().ttts_weight_split_batched(_p(self.table), self.n, self.blocks, _stream()),
+                           "ttts_weight_split_batched (stacked image)")
+                for h, e in self.entries:
+                    e.tag = (h._version, h.data_ptr() + e.off, _param_epoch)
+        return self.planes
+
+
+def _stacked_planes(owner, slices, mode: int) -> torch.Tensor:
+    """the stacked image of `slices` in `mode`, cached on `owner` (the module that owns the fused op)"""
+    cache = owner.__dict__.setdefault("_ttts_stacked", {})
+    st = cache.get(mode)
+    if st is None or not st.alive(slices):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("stacked weight planes must exist before a HIP-graph capture: run the eager warm-up steps first")
+        st = cache[mode] = _StackedPlanes(slices, mode)
+    return st.get()
+
+
+def _stacked_bias(owner, bs) -> torch.Tensor:
+    """the slices' biases one behind the other (L 2d floats), gathered again only when a parameter changed: one 6 KB copy per
+    optimizer step, recorded in the step's graph with the forward that first asks"""
+    cache = owner.__dict__.setdefault("_ttts_stacked", {})
+    tag = tuple((b._version, b.data_ptr()) for b in bs) + (_param_epoch,)
+    ent = cache.get("bias")
+    if ent is None or ent[0].numel() != sum(b.numel() for b in bs) or ent[0].device != bs[0].device:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("stacked bias must exist before a HIP-graph capture: run the eager warm-up steps first")
+        ent = cache["bias"] = [torch.empty(sum(b.numel() for b in bs), dtype=torch.float32, device=bs[0].device), None]
+    if ent[1] != tag:        # (a capture pass meets a moved epoch -- the optimizer stepped since the last forward -- so the gather
+        torch.cat([b.detach() for b in bs], out=ent[0])      # is recorded once per graph that begins an accumulation window)
+        ent[1] = tag
+    return ent[0]
+
+
+class CrossKVProjFn(torch.autograd.Function):
+    """(k_l | v_l) = mem W_l[d:3d]^T + b_l[d:3d] for EVERY decoder layer l in one GEMM (N = L 2d), written as a head image: the
+    reference projects the same encoder memory once per layer (model/layers.py:54-74 -> F.multi_head_attention_forward's
+    in-projection of `key` / `value`, torch/nn/functional.py:6206+).  One launch instead of L per forward, and in backward ONE
+    data-gradient GEMM with reduction depth L 2d (which also adds the layers' memory gradients: no fan-out, no add kernel) and
+    ONE weight-gradient GEMM whose row blocks are reduced straight into each layer's gradient sink.
+    Outputs: L windows (B, Tk, 2d) of the image (B, Tk, L 2d); their gradients arrive in `slab` (see _KVGradSlab)."""
+
+    @staticmethod
+    def forward(ctx, mem, owner, slab, row_inv, sec_amax, mem_amax, *wb):
+        lib = _lib.load()
+        mem = _chk(mem, "cross_kv_projection.memory")
+        L = len(wb) // 2
+        ws, bs = wb[:L], wb[L:]
+        rows, K = ws[0].shape                     # 2d, d
+        if mem.shape[-1] != K:
+            raise ValueError("cross_kv_projection: memory width does not match the in-projections")
+        B, Tk = mem.shape[0], mem.shape[1]
+        M, N = B * Tk, L * rows
+        y = torch.empty(B, Tk, N, dtype=torch.float32, device=mem.device)
+        bias = _stacked_bias(owner, bs)
+        if mem_amax is None:
+            mem_amax = _amax(mem)
+        planes = _stacked_planes(owner, ws, 8)
+        _stacked_planes(owner, ws, 5)             # the backward's image exists before any capture
+        _lib.check(lib.ttts_linear_fwd_h3d_img(_p(mem), _p(planes), _p(bias), _p(y), _p(row_inv), M, N, K, _p(mem_amax), _p(sec_amax),
+                                               rows // 2, _stream()), "ttts_linear_fwd_h3d_img (stacked K/V)")
+        ctx.save_for_backward(mem)
+        ctx.params = (ws, bs)
+        ctx.owner, ctx.slab, ctx.mem_amax = owner, slab, mem_amax
+        ctx.sinks = _sinks(*ws, *bs)
+        ctx.set_materialize_grads(False)
+        return tuple(y[:, :, l * rows:(l + 1) * rows] for l in range(L))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        (mem,) = ctx.saved_tensors
+        ws, bs = ctx.params
+        L = len(ws)
+        rows, K = ws[0].shape
+        B, Tk = mem.shape[0], mem.shape[1]
+        M, N = B * Tk, L * rows
+        dy, am, written = ctx.slab.take()
+        if dy is None:
+            if all(g is None for g in grads):
+                return (None,) * (6 + 2 * L)
+            dy, am, written = torch.empty(B, Tk, N, dtype=torch.float32, device=mem.device), None, set()
+        for l, g in enumerate(grads):             # whatever did not arrive through the slab (a layer that ran another path)
+            win = dy[:, :, l * rows:(l + 1) * rows]
+            if g is None:
+                if l * rows not in written:
+                    win.zero_()
+            elif g.data_ptr() != win.data_ptr() or g.stride() != win.stride():
+                win.copy_(g)
+                am = None
+        if am is None:
+            am = _amax(dy)
+        dmem = None
+        if ctx.needs_input_grad[0]:
+            dmem = torch.empty_like(mem)
+            _lib.check(lib.ttts_linear_bwd_data_h3(_p(dy), _p(_stacked_planes(ctx.owner, ws, 5)), None, _p(dmem), M, N, K, None, 1.0,
+                                                   _p(am), None, _stream()), "ttts_linear_bwd_data_h3 (stacked K/V)")
+        out_w = [None] * L
+        out_b = [None] * L
+        if any(ctx.needs_input_grad[6:6 + L]):
+            import ctypes
+            sk, acc, queue = ctx.sinks
+            if sk is not None:
+                dws, dbs = sk[:L], sk[L:]
+            else:
+                dws = [torch.empty(rows, K, dtype=torch.float32, device=mem.device) for _ in range(L)]
+                dbs = [torch.empty(rows, dtype=torch.float32, device=mem.device) if bs[0] is not None else None for _ in range(L)]
+                out_w, out_b = list(dws), list(dbs)
+            nbytes = lib.ttts_wgrad_workspace_bytes(M, N, K, 1)
+            wsp = _ws(nbytes, mem.device)
+            PA = ctypes.c_void_p * L
+            dwp = PA(*[t.data_ptr() for t in dws])
+            dbp = PA(*[t.data_ptr() for t in dbs]) if dbs[0] is not None else None
+            _lib.check(lib.ttts_linear_bwd_weight_h3_parts(_p(dy), _p(mem), dwp, dbp, L, _p(wsp), wsp.numel() * 4, M, N, K, acc, _p(am),
+                                                           _p(ctx.mem_amax), _qarg(queue, wsp), _stream()),
+                       "ttts_linear_bwd_weight_h3_parts")
+        return (dmem, None, None, None, None, None, *out_w, *out_b)
+
+
+def cross_kv_ok(mem: torch.Tensor, attns, n_head: int) -> bool:
+    """can the K/V projections of `attns` (the decoder layers' MultiheadAttention modules) run as one head-image GEMM?"""
+    if not (FUSED_CROSS_KV and HEAD_IMAGES and len(attns) > 1 and mem.is_cuda and WGRAD_MODE == "h3" and BWD_MODE == "h3"):
+        return False
+    w0 = attns[0].in_proj_weight
+    d = w0.shape[1]
+    same = all(a.in_proj_weight.shape == w0.shape and a.num_heads == n_head and (a.in_proj_bias is not None) for a in attns)
+    return (same and d == n_head * 64 and d % 32 == 0 and _wgrad_is_split(len(attns) * 2 * d, d) and
+            head_image_ok(mem, w0.detach()[d:], n_head, 2) and mem.numel() // d * (len(attns) * 2 * d + 256) * 4 < (1 << 32))
+
+
+def cross_kv_projection(mem: torch.Tensor, attns, owner):
+    """-> one HeadImage (k | v) per module of `attns` from ONE GEMM over `mem` (see CrossKVProjFn); `owner`: the module the
+    stacked weight images are cached on (the decoder stack)."""
+    L = len(attns)
+    d = attns[0].in_proj_weight.shape[1]
+    B, Tk = mem.shape[0], mem.shape[1]
+    M, N = B * Tk, L * 2 * d
+    ws = [param_rows(a.in_proj_weight, d, 3 * d) for a in attns]
+    bs = [param_rows(a.in_proj_bias, d, 3 * d) for a in attns]
+    sec = _amax_slots_n(mem.device, 2 * L)
+    inv = _guarded(N // 64, M, mem.device, "stacked K/V inverse scales") if GUARD else torch.empty(N // 64, M, dtype=torch.float32, device=mem.device)
+    slab = _KVGradSlab(B, Tk, N) if torch.is_grad_enabled() else None
+    outs = CrossKVProjFn.apply(mem, owner, slab, inv, sec, _amax(mem), *ws, *bs)
+    return [HeadImage(o, inv, sec, d, col0=l * 2 * d, slab=slab, index=l) for l, o in enumerate(outs)]
 
 
 # ----------------------------------------------------------------------------------------------- heads
@@ -997,9 +1325,16 @@ class HeadsFn(torch.autograd.Function):
         return dx, dw_mel, db_mel, dw_stop, db_stop, None, None
 
 
-def heads(x, w_mel, b_mel, w_stop, b_stop):
+def heads(x, w_mel, b_mel, w_stop, b_stop, need_stop: bool = True):
     """(mel, stop) heads; x's partial maxima ride on it (LayerNorm left them), and the mel output leaves with its own for
-    the post-net's first convolution (its weight gradient reads pred_melspec as an fp16x3 operand)."""
+    the post-net's first convolution (its weight gradient reads pred_melspec as an fp16x3 operand).
+    `need_stop=False` (no-grad callers only): the stop logits have no reader -- the first forward of training_step keeps
+    `pred_melspec` alone (reference lightning_module.py:53-59) and the stop head has no state -- so they are not computed and
+    None is returned for them."""
+    if not need_stop:
+        if torch.is_grad_enabled() and (x.requires_grad or w_stop.requires_grad):
+            raise ValueError("heads(need_stop=False) is for no-grad forwards: the stop head's gradients would be lost")
+        return linear(x, w_mel, b_mel, publish_amax=True), None
     N, K = w_mel.shape
     h3 = x.is_cuda and _fwd_h3(K, N)
     x_am = _amax(x) if h3 else None
@@ -1367,26 +1702,68 @@ def _dkv_query_splits(key_blocks: int, Tq: int) -> int:
     return max(1, min(8, 512 // key_blocks, (Tq // 32) // 4))
 
 
+def _chk_window(t: torch.Tensor, name: str) -> torch.Tensor:
+    """a (B, T, w) fp32 CUDA tensor whose rows are `ld` cells apart (ld >= w: contiguous, or a column window of a wider
+    contiguous tensor) -- never copied: the cells of a head image mean nothing to a copy kernel's consumer but are legal to move,
+    yet a window must stay inside the tensor its inverse scales describe"""
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 3:
+        raise ValueError(f"{name}: expected a (B, T, w) fp32 CUDA tensor")
+    B, T, w = t.shape
+    if t.stride(2) != 1 or t.stride(1) < w or t.stride(0) != T * t.stride(1) or t.stride(1) % 4 != 0 or t.data_ptr() % 16 != 0:
+        raise ValueError(f"{name}: rows must be equally spaced, 16-byte aligned windows of one tensor (strides {t.stride()})")
+    return t
+
+
+class _KVGradSlab:
+    """Where the gradients of the L windows of a stacked K/V projection meet: ONE (B, Tk, L 2d) buffer allocated by the first
+    cross-attention backward of a pass and ONE partial-maxima array, both consumed by CrossKVProjFn.backward.  Each layer's
+    dK / dV kernel writes its window in place (row stride L 2d), so no copy, no zero-fill and no accumulation kernel runs."""
+    __slots__ = ("shape", "buf", "amax", "written")
+
+    def __init__(self, B: int, Tk: int, width: int):
+        self.shape = (B, Tk, width)
+        self.buf = self.amax = None
+        self.written = set()
+
+    def window(self, device, col0: int, w: int) -> torch.Tensor:
+        if self.buf is None:
+            self.buf = torch.empty(self.shape, dtype=torch.float32, device=device)
+            self.amax = _amax_slots(device, True)
+            self.written = set()
+        self.written.add(col0)
+        return self.buf[:, :, col0:col0 + w]
+
+    def take(self):
+        buf, am, wr = self.buf, self.amax, self.written
+        self.buf = self.amax = None
+        self.written = set()
+        return buf, am, wr
+
+
 class CrossAttentionImgFn(torch.autograd.Function):
-    """encoder-decoder attention on head images: q (B,Tq,d) and packed kv (B,Tk,2d), each with its inverse scales"""
+    """encoder-decoder attention on head images: q (B,Tq,d) and kv (B,Tk,2d: k | v), the cells of two HeadImages (`qh`, `kvh`
+    carry their inverse scales and maxima; kv may be a window of a stacked projection with row stride ld >= 2d)"""
 
     @staticmethod
-    def forward(ctx, q, q_inv, kv, kv_inv, kv_sec_amax, lens, n_head, drop_p, seed, need_weights=True, o_amax=None):
+    def forward(ctx, q, qh, kv, kvh, lens, n_head, drop_p, seed, need_weights=True, o_amax=None):
         lib = _lib.load()
-        q = _chk(q, "cross_attention.q")
-        kv = _chk(kv, "cross_attention.kv")
+        q = _chk_window(q, "cross_attention.q")
+        kv = _chk_window(kv, "cross_attention.kv")
         lens = _chk(lens, "cross_attention.lens", torch.int64)
         B, Tq, d = q.shape
         Tk = kv.shape[1]
+        if kv.shape[2] != 2 * d or qh.row_inv.shape[1] != B * Tq or kvh.row_inv.shape[1] != B * Tk:
+            raise ValueError("cross_attention: q / kv head images do not match")
+        ldq, ldk = q.stride(1), kv.stride(1)
         o = torch.empty(B, Tq, d, dtype=torch.float32, device=q.device)
         stat = torch.empty(6, B, n_head, Tq, dtype=torch.float32, device=q.device)
         attn = torch.empty(B, n_head, Tq, Tk, dtype=torch.float32, device=q.device) if need_weights else None
-        HK = n_head * B * Tk
-        _lib.check(lib.ttts_attention_fwd_img(_p(q), _off(kv, 0), _off(kv, d), _p(q_inv), _off(kv_inv, 0), _off(kv_inv, HK), _p(o),
-                                              _p(stat[0]), _p(attn), _p(lens), B, n_head, Tq, Tk, d, 2 * d, 2 * d, d, 0, 0.125,
-                                              float(drop_p), seed, _ss(), _p(kv_sec_amax[1]), _p(o_amax), _p(stat[1:]), _stream()),
+        _lib.check(lib.ttts_attention_fwd_img(_p(q), _off(kv, 0), _off(kv, d), qh.inv_of(0), kvh.inv_of(0), kvh.inv_of(d), _p(o),
+                                              _p(stat[0]), _p(attn), _p(lens), B, n_head, Tq, Tk, ldq, ldk, ldk, d, 0, 0.125,
+                                              float(drop_p), seed, _ss(), _p(kvh.amax_of(d)), _p(o_amax), _p(stat[1:]), _stream()),
                    "ttts_attention_fwd_img")
-        ctx.save_for_backward(q, q_inv, kv, kv_inv, o, stat, lens)
+        ctx.save_for_backward(q, kv, o, stat, lens)
+        ctx.himg = (qh, kvh)
         ctx.cfg = (n_head, float(drop_p), seed)
         ctx.ss = _ss()
         if attn is None:
@@ -1398,26 +1775,36 @@ class CrossAttentionImgFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, do, _dattn):
         if do is None:
-            return (None,) * 11
+            return (None,) * 10
         lib = _lib.load()
-        q, q_inv, kv, kv_inv, o, stat, lens = ctx.saved_tensors
+        q, kv, o, stat, lens = ctx.saved_tensors
+        qh, kvh = ctx.himg
         n_head, drop_p, seed = ctx.cfg
         B, Tq, d = q.shape
         Tk = kv.shape[1]
-        HK = n_head * B * Tk
+        ldq, ldk = q.stride(1), kv.stride(1)
         do = _chk(do, "cross_attention.do")
-        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        dq = torch.empty(B, Tq, d, dtype=torch.float32, device=q.device)
         delta = torch.empty(B, n_head, Tq, dtype=torch.float32, device=q.device)
-        am_q, am_kv = _amax_slots(q.device, True), _amax_slots(q.device, True)
+        am_q = _amax_slots(q.device, True)
+        slab = kvh.slab
+        if slab is not None:         # the producer gathers its windows' gradients in one buffer (and one maxima array)
+            dkv = slab.window(q.device, kvh.col0, 2 * d)
+            am_kv = slab.amax
+        else:
+            dkv, am_kv = torch.empty(B, Tk, 2 * d, dtype=torch.float32, device=q.device), _amax_slots(q.device, True)
+        ldg = dkv.stride(1)
         # few key blocks and many queries (cross-attention: 256 workgroups of one 128-key block each): split the query range
         nsp = _dkv_query_splits(B * n_head * -(-Tk // 128), Tq)
         part = torch.empty(nsp, B, Tk, 2 * d, dtype=torch.float32, device=q.device) if nsp > 1 else None
-        _lib.check(lib.ttts_attention_bwd_img(_p(q), _off(kv, 0), _off(kv, d), _p(q_inv), _off(kv_inv, 0), _off(kv_inv, HK), _p(o), _p(do),
+        _lib.check(lib.ttts_attention_bwd_img(_p(q), _off(kv, 0), _off(kv, d), qh.inv_of(0), kvh.inv_of(0), kvh.inv_of(d), _p(o), _p(do),
                                               _p(stat[1:]), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk,
-                                              d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, 0, 0.125, drop_p, seed, ctx.ss, _p(_amax(do)),
+                                              ldq, ldk, ldk, d, d, ldg, ldg, 0, 0.125, drop_p, seed, ctx.ss, _p(_amax(do)),
                                               _p(am_q), _p(am_kv), _p(part), nsp, _stream()), "ttts_attention_bwd_img")
-        dq._ttts_amax, dkv._ttts_amax = am_q, am_kv
-        return dq, None, dkv, None, None, None, None, None, None, None, None
+        dq._ttts_amax = am_q
+        if slab is None:
+            dkv._ttts_amax = am_kv
+        return dq, None, dkv, None, None, None, None, None, None, None
 
 
 class SelfAttentionFn(torch.autograd.Function):
@@ -1563,15 +1950,17 @@ class CrossAttentionFn(torch.autograd.Function):
 
 
 def self_attention(qkv, lens, n_head: int, causal: bool, drop_p: float, seed: int):
-    """Self-attention over a packed in-projection output; the partial maxima of `qkv` ride on it when its producer left
-    them (`linear(..., publish_amax=True)`), and the context leaves with its own for the out-projection."""
+    """Self-attention over a packed in-projection output (a Tensor, or the HeadImage `linear(..., head_image_sections=3)`
+    returned); the partial maxima of a fp32 `qkv` ride on it when its producer left them (`linear(..., publish_amax=True)`), and
+    the context leaves with its own for the out-projection."""
     d = qkv.shape[-1] // 3
     if _wide_heads(d, n_head):
+        if isinstance(qkv, HeadImage):
+            raise ValueError("self_attention: head images hold 64-column heads")
         return _attention_wide_heads(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], lens, n_head, causal, drop_p)[0]
-    himg = getattr(qkv, "_ttts_himg", None)
-    if himg is not None:                       # the in-projection left a head image: the LDS-DMA kernels
+    if isinstance(qkv, HeadImage):             # the in-projection left a head image: the LDS-DMA kernels
         o_am = _amax_slots(qkv.device, True)
-        o = SelfAttentionImgFn.apply(qkv, himg[0], himg[1], lens, n_head, causal, drop_p, seed, o_am)
+        o = SelfAttentionImgFn.apply(qkv.cells, qkv.row_inv, qkv.sec_amax, lens, n_head, causal, drop_p, seed, o_am)
         o._ttts_amax = o_am
         return o
     h3 = qkv.is_cuda and _attn_h3()
@@ -1584,16 +1973,18 @@ def self_attention(qkv, lens, n_head: int, causal: bool, drop_p: float, seed: in
 
 
 def cross_attention(q, kv, lens, n_head: int, drop_p: float, seed: int, need_weights: bool = True):
+    """q (B,Tq,d), kv (B,Tk,2d): both fp32 tensors, or both HeadImages (kv may be one layer's window of `cross_kv_projection`)"""
     d = q.shape[-1]
     if _wide_heads(d, n_head):
+        if isinstance(q, HeadImage) or isinstance(kv, HeadImage):
+            raise ValueError("cross_attention: head images hold 64-column heads")
         o, attn = _attention_wide_heads(q, kv[..., :d], kv[..., d:], lens, n_head, False, drop_p)
         return o, (attn if need_weights else None)
-    qi, kvi = getattr(q, "_ttts_himg", None), getattr(kv, "_ttts_himg", None)
-    if (qi is None) != (kvi is None):
+    if isinstance(q, HeadImage) != isinstance(kv, HeadImage):
         raise ValueError("cross_attention: q and kv must both be head images or both fp32")
-    if qi is not None:
+    if isinstance(q, HeadImage):
         o_am = _amax_slots(q.device, True)
-        o, attn = CrossAttentionImgFn.apply(q, qi[0], kv, kvi[0], kvi[1], lens, n_head, drop_p, seed, need_weights, o_am)
+        o, attn = CrossAttentionImgFn.apply(q.cells, q, kv.cells, kv, lens, n_head, drop_p, seed, need_weights, o_am)
         o._ttts_amax = o_am
         return o, attn
     h3 = q.is_cuda and _attn_h3()
