@@ -388,6 +388,9 @@ def main():
     ap.add_argument("--no-fused-kv", action="store_true",
                     help="A/B aid: every decoder layer projects the encoder memory to its cross-attention K/V itself (the reference's "
                          "structure, model/layers.py:54-74) instead of ONE stacked projection for all layers (ops.cross_kv_projection)")
+    ap.add_argument("--no-wgrad-groups", action="store_true",
+                    help="A/B aid: every small weight gradient is a launch of its own instead of a member of a grouped launch "
+                         "(ops.ReduceQueue.defer_wgrad, ttts_linear_bwd_weight_h3_group)")
     ap.add_argument("--layernorm-images", action="store_true",
                     help="A/B aid: LayerNorm forward / backward also write the image operand of their output and the GEMMs behind "
                          "them take it (measured slower over the step: transformertts_amd/ops.py, LAYERNORM_IMAGES)")
@@ -436,6 +439,8 @@ def main():
         ops.DMA_BIG_FWD = False
     if args.no_fused_kv:
         ops.FUSED_CROSS_KV = False
+    if args.no_wgrad_groups:
+        ops.WGRAD_GROUPS = False
     cfg = model_config(args.config)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
               "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,
@@ -627,7 +632,7 @@ def main():
                        "alignments_written": bool(args.alignments),
                        "arithmetic": "3 x f16 MFMA terms per fp32 product (hi/lo f16 splits of both operands), fp32 accumulate",
                        "dma_gemms": not args.no_image_operands, "layernorm_images": bool(args.layernorm_images),
-                       "head_images": not args.no_head_images, "fused_cross_kv": not args.no_fused_kv,
+                       "head_images": not args.no_head_images, "fused_cross_kv": not args.no_fused_kv, "wgrad_groups": not args.no_wgrad_groups,
                        "final_loss": final_loss, "per_step_loss_item_sync": False},
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "sustained": sustained,

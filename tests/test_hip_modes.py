@@ -293,6 +293,73 @@ def test_fp16x3_weight_gradient(M, N, K, mag):
         assert _rel(dw, dy.double().t() @ xs.view(M, K).double()) < TOL
 
 
+@pytest.mark.parametrize("M,shapes", [(13920, [(256, 256), (256, 256), (256, 256), (256, 256)]),       # a decoder layer's small linears at B = 16
+                                      (6401, [(768, 256), (256, 256), (1024, 256), (256, 1024)]),        # an encoder layer (ragged last k-step)
+                                      (300, [(256, 256), (128, 384)]), (55680, [(256, 256)])])
+def test_grouped_weight_gradients(M, shapes):
+    """ttts_linear_bwd_weight_h3_group: up to four independent dW_i = dy_i^T x_i (+ bias column sums) as ONE launch of the
+    128 x 128 fp16x3 tile with the row splits planned for the group -- every member against fp64, stored into zeroed sinks and
+    accumulated on a second call (the sinks' contract), same bits on a third run into fresh sinks (fixed-order reductions);
+    members of very different magnitude (each has its own dynamic pre-scales)."""
+    import ctypes
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _stream
+    lib, dev = _lib.load(), _dev()
+    n = len(shapes)
+    xs = [_rand(M, K, seed=10 + i) * (1e-3 if i == 1 else 1.0) for i, (N, K) in enumerate(shapes)]
+    dys = [_rand(M, N, seed=20 + i) * (3e-7 if i == 0 else 1.0 if i == 2 else 40.0) for i, (N, K) in enumerate(shapes)]
+    for (N, K) in shapes:
+        assert lib.ttts_wgrad_group_ok(M, N, K) == 1
+    assert lib.ttts_wgrad_group_ok(55680, 1024, 256) == 0 and lib.ttts_wgrad_group_ok(55680, 256, 80) == 0      # tiles of their own
+    ams, xms = [ops._amax(t) for t in dys], [ops._amax(t) for t in xs]
+    wss = [torch.empty(lib.ttts_wgrad_workspace_bytes(M, N, K, 1) // 4, device=dev) for (N, K) in shapes]
+    PA, ZA, LA, IA = ctypes.c_void_p * n, ctypes.c_size_t * n, ctypes.c_int64 * n, ctypes.c_int * n
+    ptr = lambda ts: PA(*[(t.data_ptr() if t is not None else None) for t in ts])      # noqa: E731
+
+    def run(dws, dbs):
+        rc = lib.ttts_linear_bwd_weight_h3_group(n, ptr(dys), ptr(xs), ptr(dws), ptr(dbs), ptr(wss), ZA(*[w.numel() * 4 for w in wss]),
+                                                 LA(*[M] * n), IA(*[N for N, K in shapes]), IA(*[K for N, K in shapes]), 1, ptr(ams),
+                                                 ptr(xms), None, _stream())
+        assert rc == 0, _lib.last_error()
+    dws = [torch.zeros(N, K, device=dev) for (N, K) in shapes]
+    dbs = [torch.zeros(N, device=dev) if i != 1 else None for i, (N, K) in enumerate(shapes)]      # (a member without a bias)
+    run(dws, dbs)
+    refs = [(dy.double().t() @ x.double(), dy.double().sum(0)) for dy, x in zip(dys, xs)]
+    for i, (dw, db) in enumerate(zip(dws, dbs)):
+        assert _rel(dw, refs[i][0]) < TOL, (i, _rel(dw, refs[i][0]))
+        assert db is None or _rel(db, refs[i][1]) < TOL
+    first = [dw.clone() for dw in dws]
+    run(dws, dbs)                                           # accumulate: the sinks now hold twice the gradient
+    for i, (dw, db) in enumerate(zip(dws, dbs)):
+        assert _rel(dw, 2 * refs[i][0]) < TOL and (db is None or _rel(db, 2 * refs[i][1]) < TOL)
+    dws2 = [torch.zeros(N, K, device=dev) for (N, K) in shapes]
+    torch.randn(1 << 23, device=dev)
+    run(dws2, [torch.zeros(N, device=dev) if i != 1 else None for i, (N, K) in enumerate(shapes)])
+    assert all(torch.equal(a, b) for a, b in zip(first, dws2))
+
+
+def test_weight_gradient_into_several_destinations():
+    """ttts_linear_bwd_weight_h3_parts: ONE weight-gradient GEMM whose row blocks belong to different weights (the stacked K/V
+    projection of all decoder layers): block i accumulated into destination i, bias column sums likewise."""
+    import ctypes
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _stream
+    lib, dev = _lib.load(), _dev()
+    M, L, Np, K = 6400, 3, 512, 256
+    x, dy = _rand(M, K, seed=1), _rand(M, L * Np, seed=2) * 1e-3
+    dws = [torch.full((Np, K), 0.5, device=dev) for _ in range(L)]
+    dbs = [torch.full((Np,), -0.25, device=dev) for _ in range(L)]
+    ws = torch.empty(lib.ttts_wgrad_workspace_bytes(M, L * Np, K, 1) // 4, device=dev)
+    PA = ctypes.c_void_p * L
+    rc = lib.ttts_linear_bwd_weight_h3_parts(_p(dy), _p(x), PA(*[t.data_ptr() for t in dws]), PA(*[t.data_ptr() for t in dbs]), L, _p(ws),
+                                             ws.numel() * 4, M, L * Np, K, 1, _p(ops._amax(dy)), _p(ops._amax(x)), None, _stream())
+    assert rc == 0, _lib.last_error()
+    ref = dy.double().t() @ x.double()
+    for i in range(L):
+        assert _rel(dws[i].double() - 0.5, ref[i * Np:(i + 1) * Np]) < TOL
+        assert _rel(dbs[i].double() + 0.25, dy.double()[:, i * Np:(i + 1) * Np].sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128), (6, 45, 80, 256), (6, 45, 256, 80),
                                           (30, 870, 256, 256),                 # five taps x one 256-wide tile (rows by LDS-DMA)
                                           (31, 833, 512, 256), (1600, 16, 256, 256)])   # ... utterances of exactly one step

@@ -1179,6 +1179,72 @@ int ttts_linear_bwd_weight_h3_parts(const float* dy, const float* x, float* cons
     return TTTS_OK;
 }
 
+int ttts_wgrad_group_ok(int64_t M, int N, int K) {
+    // can dw[N,K] = dy[M,N]^T x[M,K] be a member of a grouped launch?  (the fp16x3 form on the 4-wave 128 x 128 tile: small outputs;
+    // the 256-wide LDS-DMA tile and the 96-wide mel tiles keep their own launches)
+    return M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0 && wgrad_use_x6(N, K) && plan_wgrad(M, N, K, 1, true, HBK).tile == TILE_128;
+}
+
+int ttts_linear_bwd_weight_h3_group(int n, const float* const* dy, const float* const* x, float* const* dw, float* const* dbias,
+                                    float* const* ws, const size_t* ws_bytes, const int64_t* M, const int* N, const int* K,
+                                    int accumulate, const float* const* dy_amax, const float* const* x_amax,
+                                    ttts_reduce_queue* queue, void* stream_) {
+    // n <= 4 independent weight gradients dw_i[N_i,K_i] (+)= dy_i^T x_i, dbias_i (+)= column sums of dy_i, as ONE grid of the
+    // 4-wave 128 x 128 fp16x3 kernel: the row splits are planned for the group (same chip-filling target as a single launch,
+    // shared by the members), so every member writes 1/n of the partial sums a launch of its own would and its workgroups
+    // walk n times the rows.  Each member's partial sums go to its own workspace and are reduced (queued) as usual.
+    hipStream_t stream = (hipStream_t)stream_;
+    TTTS_REQUIRE(n >= 1 && n <= 4 && dy && x && dw && ws && ws_bytes && M && N && K && dy_amax && x_amax, "linear_bwd_weight_h3_group: bad arguments");
+    GemmArgs gs[4];
+    int zd[4];
+    float* colsum[4];
+    long tiles_total = 0, nkt_max = 0;
+    for (int i = 0; i < n; ++i) {
+        TTTS_REQUIRE(dy[i] && x[i] && dw[i] && ws[i] && dy_amax[i] && x_amax[i], "linear_bwd_weight_h3_group: null pointer (member %d)", i);
+        TTTS_REQUIRE(ttts_wgrad_group_ok(M[i], N[i], K[i]) && M[i] < (1LL << 31), "linear_bwd_weight_h3_group: member %d (M=%lld N=%d K=%d) does not take the grouped tile",
+                     i, (long long)M[i], N[i], K[i]);
+        TTTS_REQUIRE(aligned16(dy[i]) && aligned16(x[i]) && aligned16(ws[i]), "linear_bwd_weight_h3_group: pointers must be 16-byte aligned");
+        TTTS_REQUIRE((uint64_t)M[i] * N[i] * 4 < (1ull << 32) && (uint64_t)M[i] * K[i] * 4 < (1ull << 32), "linear_bwd_weight_h3_group: operand larger than 4 GiB");
+        tiles_total += (long)cdiv(N[i], 128) * cdiv(K[i], 128);
+        const long nkt = (M[i] + HBK - 1) / HBK;
+        nkt_max = nkt > nkt_max ? nkt : nkt_max;
+    }
+    // plan_wgrad's rule for this tile, applied to the group as a whole
+    const long target = (tiles_total > 12 && nkt_max >= 800) ? 512 : 256;
+    long want = target / tiles_total;
+    if (want < 1) want = 1;
+    for (int i = 0; i < n; ++i) {
+        const long nkt = (M[i] + HBK - 1) / HBK;
+        long w = want > nkt ? nkt : want;
+        long per = (nkt + w - 1) / w;
+        if (per < 8 && nkt >= 8) per = 8;
+        const int nsplit = (int)((nkt + per - 1) / per);
+        const long nk = (long)N[i] * K[i];
+        TTTS_REQUIRE(ws_bytes[i] >= ((size_t)nsplit * nk + (size_t)nsplit * N[i]) * sizeof(float), "linear_bwd_weight_h3_group: workspace %d too small", i);
+        GemmArgs g = base_args();
+        g.A = dy[i]; g.B = x[i]; g.C = ws[i]; g.M = N[i]; g.N = K[i]; g.K = (int)M[i];
+        g.lda = N[i]; g.ldb = K[i]; g.ldc = K[i];
+        g.a_bytes = (uint32_t)((uint64_t)M[i] * N[i] * 4); g.b_bytes = (uint32_t)((uint64_t)M[i] * K[i] * 4);
+        g.T = 0; g.shift0 = 0; g.shift_step = 0; g.ztaps = 1;
+        g.kt_per_split = (int)per; g.c_zstride = nk;
+        colsum[i] = (dbias != nullptr && dbias[i] != nullptr) ? ws[i] + (size_t)nsplit * nk : nullptr;
+        g.colsum = colsum[i];
+        g.a_amax = dy_amax[i]; g.a_amax_n = H3_AMAX_PARTIALS;
+        g.b_amax = x_amax[i]; g.b_amax_n = H3_AMAX_PARTIALS;
+        gs[i] = g;
+        zd[i] = nsplit;
+    }
+    int rc = launch_wgrad_h3_group(gs, zd, n, stream);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        const long nk = (long)N[i] * K[i];
+        rc = launch_reduce_rows_pair(ws[i], nk, zd[i], nk, dw[i], colsum[i], N[i], N[i], colsum[i] ? dbias[i] : nullptr, accumulate != 0,
+                                     stream, queue);
+        if (rc) return rc;
+    }
+    return TTTS_OK;
+}
+
 size_t ttts_conv1d_pack_bytes(int cout, int cin, int taps) { return (size_t)cout * cin * taps * sizeof(float); }
 
 int ttts_conv1d_pack_weight(const float* w, float* w_fwd, float* w_bwd, int cout, int cin, int taps, void* stream) {

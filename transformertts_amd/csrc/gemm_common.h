@@ -323,6 +323,8 @@ int dispatch_h3(const GemmArgs& g, hipStream_t stream);
 // row-chunk partials the fp16x3 forward writes into GemmArgs::bn_ws for an M x N x K problem (0: its tile shape cannot)
 int h3_bn_blocks(long M, long N, long K);
 int dispatch_wgrad_h3(const GemmArgs& g, int zdim, int tile, hipStream_t stream);
+// n <= 4 independent problems on the 4-wave 128 x 128 tile as ONE grid (gemm_h3.hip, wgrad_h3_group_kernel)
+int launch_wgrad_h3_group(const GemmArgs* gs, const int* zdims, int n, hipStream_t stream);
 // the same problem with LDS-DMA staged operand rows (wgrad_dma.hip): whole 256 x 256 tiles only
 bool wgrad_dma_supports(const GemmArgs& g, int tile);
 int launch_wgrad_dma(const GemmArgs& g, int zdim, hipStream_t stream);

@@ -986,8 +986,9 @@ int dispatch_h3(const GemmArgs& g, hipStream_t stream) {
 // of 32 rows, colsum = per-split column sums of dy (bias gradient, from the fp32 values).
 __device__ __forceinline__ int wg_swz(int row) { return (((row >> 1) ^ (row >> 3)) & 1) | (((row >> 2) & 1) << 1); }
 
+// (the kernel's body, shared by the one-problem kernel and the GROUPED one below: workgroup (bx, by, z) of problem g)
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_kernel(GemmArgs g) {
+__device__ __forceinline__ void wgrad_h3_body(const GemmArgs& g, int bx, int by, int z) {
     constexpr int NT = WM * WN * 64, HALF = NT / 2;             // half of the threads stage dy, the other half x
     constexpr bool TWO_SETS = (WM * WN == 4);                   // 8 waves: 128 accumulator registers leave room for one set
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -1004,22 +1005,6 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_k
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    // XCD-aware numbering (as the forward kernel): workgroups are dealt round-robin to the 8 XCDs in x-fastest order, so the
-    // tiles of one row split -- which read the same rows of dy and x -- would land on different L2s and each fetch its
-    // operands from HBM again (a 1024 x 256 weight asks for 3.2x the unique bytes).  Renumbered, XCD e works on one
-    // contiguous run of (split, tile) pairs: the tiles of a split start together on the CUs of one XCD and share its L2.
-    int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
-    {
-        const int gx = gridDim.x, gy = gridDim.y;
-        const int total = gx * gy * (int)gridDim.z;
-        const int bid = bx + gx * (by + gy * z);
-        const int per = total >> 3, rem = total & 7;
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int t = xcd * per + min(xcd, rem) + slot;
-        bx = t % gx;
-        by = (t / gx) % gy;
-        z = t / (gx * gy);
-    }
     const int m0 = by * BM, n0 = bx * BN;
     const int ztap = (g.ztaps > 1) ? (z % g.ztaps) : 0;
     const int zsplit = (g.ztaps > 1) ? (z / g.ztaps) : z;
@@ -1232,6 +1217,68 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_k
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r] * out_scale), rsrcC, (int)off, 0, 0);
             }
         }
+}
+
+// XCD-aware numbering (as the forward kernel): workgroups are dealt round-robin to the 8 XCDs in x-fastest order, so the
+// tiles of one row split -- which read the same rows of dy and x -- would land on different L2s and each fetch its
+// operands from HBM again (a 1024 x 256 weight asks for 3.2x the unique bytes).  Renumbered, XCD e works on one
+// contiguous run of (split, tile) pairs: the tiles of a split start together on the CUs of one XCD and share its L2.
+__device__ __forceinline__ int xcd_renumber(int bid, int total) {
+    const int per = total >> 3, rem = total & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    return xcd * per + min(xcd, rem) + slot;
+}
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_kernel(GemmArgs g) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int t = xcd_renumber(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * (int)gridDim.z);
+    wgrad_h3_body<BM, BN, WM, WN>(g, t % gx, (t / gx) % gy, t / (gx * gy));
+}
+
+// GROUPED launch: up to WG_GROUP_MAX independent weight gradients (the small 256 x 256-class outputs of one layer, whose
+// operands are all at hand when backward leaves the layer and whose results nobody reads before the optimizer) as ONE grid.
+// Alone, such an output has 4 tiles and needs 64 row splits to fill the chip -- 64 partial tiles written and read back, 8-27
+// k-steps per workgroup in front of a fixed prologue / epilogue; grouped, the splits per problem drop by the group size (so do the
+// partial sums and the reduction's bytes) and each workgroup's row range grows by it.  first[p] = first flat workgroup of
+// problem p (first[n] = total); inside a problem the numbering is (tile x, tile y, split) as in the one-problem kernel.
+constexpr int WG_GROUP_MAX = 4;
+struct WgradGroupArgs {
+    GemmArgs g[WG_GROUP_MAX];
+    int first[WG_GROUP_MAX + 1];
+    int n;
+};
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_group_kernel(WgradGroupArgs gg) {
+    const int t = xcd_renumber(blockIdx.x, gg.first[gg.n]);
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < WG_GROUP_MAX; ++i)
+        if (i < gg.n && t >= gg.first[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const GemmArgs& g = gg.g[p];
+    const int local = t - gg.first[p];
+    const int gx = (g.N + BN - 1) / BN, gy = (g.M + BM - 1) / BM;
+    wgrad_h3_body<BM, BN, WM, WN>(g, local % gx, (local / gx) % gy, local / (gx * gy));
+}
+
+int launch_wgrad_h3_group(const GemmArgs* gs, const int* zdims, int n, hipStream_t stream) {
+    // 128 x 128 tiles, 4 waves (the tile of every problem the planner groups: plan_wgrad's TILE_128)
+    WgradGroupArgs gg = {};
+    if (n < 1 || n > WG_GROUP_MAX) {
+        set_error("grouped weight gradient: %d problems (1..%d)", n, WG_GROUP_MAX);
+        return TTTS_ERR_INVALID;
+    }
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        gg.g[i] = gs[i];
+        gg.first[i] = total;
+        total += cdiv(gs[i].N, 128) * cdiv(gs[i].M, 128) * zdims[i];
+    }
+    for (int i = n; i <= WG_GROUP_MAX; ++i) gg.first[i] = total;
+    gg.n = n;
+    hipLaunchKernelGGL((wgrad_h3_group_kernel<128, 128, 2, 2>), dim3((unsigned)total), dim3(256), 0, stream, gg);
+    TTTS_LAUNCH_CHECK("wgrad_h3_group_kernel");
+    return TTTS_OK;
 }
 
 template <int BM, int BN, int WM, int WN>

@@ -210,7 +210,8 @@ class cross_check_forms:
     as it occurs instead of batching them at the end of backward."""
 
     _NAMES = {"gemm": "GEMM_MODE", "fwd": "FWD_MODE", "bwd": "BWD_MODE", "wgrad": "WGRAD_MODE", "attn": "ATTN_MODE",
-              "attn_fwd": "ATTN_FWD_MODE", "attn_bwd": "ATTN_BWD_MODE", "defer_reduce": "DEFER_REDUCE"}
+              "attn_fwd": "ATTN_FWD_MODE", "attn_bwd": "ATTN_BWD_MODE", "defer_reduce": "DEFER_REDUCE",
+              "wgrad_groups": "WGRAD_GROUPS"}
 
     def __init__(self, **forms):
         unknown = set(forms) - set(self._NAMES)
@@ -317,8 +318,12 @@ class _AmaxArena:
 _amax_arenas = {}
 
 
+_pass_id = [0]          # micro-batch passes begun (amax_arena_reset): lets per-pass host state tell one capture pass from the next
+
+
 def amax_arena_reset(device) -> None:
     """Call once at the start of a step (step.TrainStep does); everything handed out before is dead by then."""
+    _pass_id[0] += 1
     arena = _amax_arenas.get(device)
     if arena is None:
         arena = _amax_arenas[device] = _AmaxArena(device)
@@ -370,9 +375,17 @@ def _amax_slots_n(device, n: int) -> torch.Tensor:
 DEFER_REDUCE = True          # tests flip it through `cross_check_forms(defer_reduce=False)`
 
 
+WGRAD_GROUPS = True          # small weight gradients of a backward pass run as grouped launches (ReduceQueue.defer_wgrad)
+WGRAD_GROUP_MAX = 4          # WG_GROUP_MAX of csrc/gemm_h3.hip
+
+
 class ReduceQueue:
     """Host-side queue of deferred second-stage reductions (include/ttts_hip.h, ttts_reduce_queue) plus the workspaces
-    the queued reductions still read."""
+    the queued reductions still read -- and, in front of it, the small weight gradients that wait to be launched as a GROUP
+    (`defer_wgrad`): a parameter gradient has no reader before the optimizer, so the 256 x 256-class outputs of a layer
+    (out-projections, the cross-attention query projection, the encoder's linears) are collected as backward produces their
+    operands and run as ONE grid of up to WGRAD_GROUP_MAX problems (ttts_linear_bwd_weight_h3_group): 1/n of the partial sums,
+    n times the rows per workgroup, 1/n of the launches."""
 
     def __init__(self):
         self._lib = _lib.load()
@@ -380,16 +393,47 @@ class ReduceQueue:
         if not self.handle:
             raise MemoryError("ttts_reduce_queue_create failed")
         self.keep: list = []
+        self.wg: list = []          # pending members of the next grouped weight-gradient launch
         self._armed = False         # a final callback of the running backward pass will flush
+
+    def _arm(self) -> None:
+        if not self._armed:
+            torch.autograd.Variable._execution_engine.queue_callback(self._final)
+            self._armed = True
 
     def arg(self, ws: torch.Tensor):
         """`queue` argument for an entry point whose reduction may wait for the flush; keeps `ws` alive until then.
         Called from backward nodes only (the engine's final-callback queue is open there)."""
-        if not self._armed:
-            torch.autograd.Variable._execution_engine.queue_callback(self._final)
-            self._armed = True
+        self._arm()
         self.keep.append(ws)
         return self.handle
+
+    def defer_wgrad(self, dy, dy_am, x, x_am, dw, db, M: int, N: int, K: int) -> None:
+        """dw (+)= dy^T x, db (+)= column sums of dy -- later, in a grouped launch (backward nodes only).  Members of one group
+        share a row count: their workgroups then walk equally long row ranges."""
+        self._arm()
+        if self.wg and (self.wg[0][6] != M or self.wg[0][0].device != dy.device):
+            self.launch_wgrads()
+        ws = _ws(self._lib.ttts_wgrad_workspace_bytes(M, N, K, 1), x.device)
+        self.wg.append((dy, dy_am, x, x_am, dw, db, M, N, K, ws))
+        if len(self.wg) >= WGRAD_GROUP_MAX:
+            self.launch_wgrads()
+
+    def launch_wgrads(self) -> None:
+        """launch the pending group now, on the current stream (its reductions join the queue)"""
+        if not self.wg:
+            return
+        import ctypes
+        wg, self.wg = self.wg, []
+        n = len(wg)
+        PA, ZA, LA, IA = ctypes.c_void_p * n, ctypes.c_size_t * n, ctypes.c_int64 * n, ctypes.c_int * n
+        col = lambda i: [m[i] for m in wg]      # noqa: E731
+        ptr = lambda ts: PA(*[(t.data_ptr() if t is not None else None) for t in ts])      # noqa: E731
+        _lib.check(self._lib.ttts_linear_bwd_weight_h3_group(
+            n, ptr(col(0)), ptr(col(2)), ptr(col(4)), ptr(col(5)), ptr(col(9)), ZA(*[m[9].numel() * 4 for m in wg]), LA(*col(6)),
+            IA(*col(7)), IA(*col(8)), 1, ptr(col(1)), ptr(col(3)), self.handle if DEFER_REDUCE else None, _stream()),
+            "ttts_linear_bwd_weight_h3_group")
+        self.keep.extend(m[9] for m in wg)
 
     def _final(self) -> None:
         self._armed = False
@@ -399,7 +443,8 @@ class ReduceQueue:
         return int(self._lib.ttts_reduce_queue_pending(self.handle))
 
     def flush(self) -> None:
-        """Run every queued reduction now, on the current stream."""
+        """Run every queued reduction now, on the current stream (the pending grouped weight gradients first)."""
+        self.launch_wgrads()
         if self.keep or self.pending():
             _lib.check(self._lib.ttts_reduce_queue_flush(self.handle, _stream()), "ttts_reduce_queue_flush")
             self.keep.clear()
@@ -407,6 +452,7 @@ class ReduceQueue:
     def clear(self) -> None:
         _lib.check(self._lib.ttts_reduce_queue_clear(self.handle), "ttts_reduce_queue_clear")
         self.keep.clear()
+        self.wg.clear()
         self._armed = False
 
     def __del__(self):
@@ -879,16 +925,22 @@ class LinearFn(torch.autograd.Function):
             if tok_in is not None:
                 tok_in.premasked = True
         if ctx.needs_input_grad[1]:
-            nbytes = lib.ttts_wgrad_workspace_bytes(M, N, K, 1)
-            ws = _ws(nbytes, x.device)
             sk, acc, queue = ctx.sinks
-            if sk is not None:
-                dw_t, db_t = sk
+            if (WGRAD_GROUPS and DEFER_REDUCE and sk is not None and queue is not None and WGRAD_MODE == "h3" and row_shift == 0
+                    and _wgrad_is_split(N, K) and lib.ttts_wgrad_group_ok(M, N, K)):
+                # a small output with a gradient sink: nobody reads it before the optimizer, so it waits for the group
+                queue.defer_wgrad(dacc, am if am is not None else _amax(dacc), x, ctx.x_amax if ctx.x_amax is not None else _amax(x),
+                                  sk[0], sk[1], M, N, K)
             else:
-                dw_t = dw = torch.empty_like(w)
-                db_t = db = torch.empty(N, dtype=torch.float32, device=x.device) if has_b else None
-            _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dacc, am, x, ctx.x_amax, _wgrad_is_split(N, K), _qarg(queue, ws),
-                              _p(dw_t), _p(db_t), _p(ws), ws.numel() * 4, M, N, K, row_shift, T, acc), "ttts_linear_bwd_weight")
+                nbytes = lib.ttts_wgrad_workspace_bytes(M, N, K, 1)
+                ws = _ws(nbytes, x.device)
+                if sk is not None:
+                    dw_t, db_t = sk
+                else:
+                    dw_t = dw = torch.empty_like(w)
+                    db_t = db = torch.empty(N, dtype=torch.float32, device=x.device) if has_b else None
+                _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dacc, am, x, ctx.x_amax, _wgrad_is_split(N, K), _qarg(queue, ws),
+                                  _p(dw_t), _p(db_t), _p(ws), ws.numel() * 4, M, N, K, row_shift, T, acc), "ttts_linear_bwd_weight")
         dres = dy if has_r else None
         if has_r and skip_out is not None:      # hand the skip gradient to the block's first Linear instead of autograd
             skip_out.grad, dres = dy, None
@@ -1130,14 +1182,16 @@ def _stacked_bias(owner, bs) -> torch.Tensor:
     """the slices' biases one behind the other (L 2d floats), gathered again only when a parameter changed: one 6 KB copy per
     optimizer step, recorded in the step's graph with the forward that first asks"""
     cache = owner.__dict__.setdefault("_ttts_stacked", {})
-    tag = tuple((b._version, b.data_ptr()) for b in bs) + (_param_epoch,)
+    # During a capture the gather must be RECORDED by whichever forward of the pass comes first, whatever an earlier capture pass
+    # that was abandoned (TrainStep._capture_guarded's fallback) left in this host-side tag: the pass number is part of it.
+    tag = tuple((b._version, b.data_ptr()) for b in bs) + (_param_epoch, _pass_id[0] if torch.cuda.is_current_stream_capturing() else -1)
     ent = cache.get("bias")
     if ent is None or ent[0].numel() != sum(b.numel() for b in bs) or ent[0].device != bs[0].device:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("stacked bias must exist before a HIP-graph capture: run the eager warm-up steps first")
         ent = cache["bias"] = [torch.empty(sum(b.numel() for b in bs), dtype=torch.float32, device=bs[0].device), None]
-    if ent[1] != tag:        # (a capture pass meets a moved epoch -- the optimizer stepped since the last forward -- so the gather
-        torch.cat([b.detach() for b in bs], out=ent[0])      # is recorded once per graph that begins an accumulation window)
+    if ent[1] != tag:
+        torch.cat([b.detach() for b in bs], out=ent[0])
         ent[1] = tag
     return ent[0]
 
