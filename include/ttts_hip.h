@@ -236,11 +236,12 @@ int ttts_conv1d_bwd_weight_h3(const float* dy, const float* x, float* dw, float*
  * run as one GEMM on the encoder memory they all read (the reference runs it per layer: model/layers.py:54-74, rows d..3d of
  * each layer's multihead_attn.in_proj_weight). */
 /* GROUPED weight gradients: n <= 4 independent problems dw_i[N_i,K_i] (+)= dy_i[M_i,N_i]^T x_i[M_i,K_i] (dbias_i: column sums of
- * dy_i, or NULL) as ONE launch of the 4-wave 128 x 128 fp16x3 kernel -- the small (256 x 256-class) outputs of a layer, whose
- * operands are all at hand when backward leaves the layer and whose results nobody reads before the optimizer.  Every array
+ * dy_i, or NULL) as ONE launch of an fp16x3 weight-gradient kernel -- the linear weights of a layer, whose operands are all at
+ * hand when backward leaves the layer and whose results nobody reads before the optimizer.  Every array
  * argument is a HOST array of n entries; ws_i / ws_bytes_i as ttts_wgrad_workspace_bytes(M_i, N_i, K_i, 1).  The row splits are
- * planned for the group, so each member writes 1/n of the partial sums of a launch of its own.  ttts_wgrad_group_ok: may a
- * problem be a member?  (the autograd of torch.nn.Linear runs these one by one: torch/nn/modules/linear.py via model/module.py:36-53
+ * planned for the group, so each member writes 1/n of the partial sums of a launch of its own.  ttts_wgrad_group_ok: the CLASS
+ * of a problem -- 0: no member of any group; 1: the 4-wave 128 x 128 tile; 2: whole 256 x 256 tiles on the 8-wave LDS-DMA kernel
+ * (the FFN and packed in-projection weights over long row ranges) -- the members of one launch share a class.  (the autograd of torch.nn.Linear runs these one by one: torch/nn/modules/linear.py via model/module.py:36-53
  * and the torch layers of model/model.py:189-213) */
 int ttts_wgrad_group_ok(int64_t M, int N, int K);
 int ttts_linear_bwd_weight_h3_group(int n, const float* const* dy, const float* const* x, float* const* dw, float* const* dbias,

@@ -295,10 +295,12 @@ def test_fp16x3_weight_gradient(M, N, K, mag):
 
 @pytest.mark.parametrize("M,shapes", [(13920, [(256, 256), (256, 256), (256, 256), (256, 256)]),       # a decoder layer's small linears at B = 16
                                       (6401, [(768, 256), (256, 256), (1024, 256), (256, 1024)]),        # an encoder layer (ragged last k-step)
-                                      (300, [(256, 256), (128, 384)]), (55680, [(256, 256)])])
+                                      (300, [(256, 256), (128, 384)]), (55680, [(256, 256)]),
+                                      (25630, [(256, 1024), (1024, 256), (768, 256)]),                   # a decoder layer's big weights: the LDS-DMA tile
+                                      (27001, [(512, 512)])])
 def test_grouped_weight_gradients(M, shapes):
     """ttts_linear_bwd_weight_h3_group: up to four independent dW_i = dy_i^T x_i (+ bias column sums) as ONE launch of the
-    128 x 128 fp16x3 tile with the row splits planned for the group -- every member against fp64, stored into zeroed sinks and
+    128 x 128 fp16x3 tile (class 1) or of the 256 x 256 LDS-DMA tile (class 2) with the row splits planned for the group -- every member against fp64, stored into zeroed sinks and
     accumulated on a second call (the sinks' contract), same bits on a third run into fresh sinks (fixed-order reductions);
     members of very different magnitude (each has its own dynamic pre-scales)."""
     import ctypes
@@ -308,9 +310,12 @@ def test_grouped_weight_gradients(M, shapes):
     n = len(shapes)
     xs = [_rand(M, K, seed=10 + i) * (1e-3 if i == 1 else 1.0) for i, (N, K) in enumerate(shapes)]
     dys = [_rand(M, N, seed=20 + i) * (3e-7 if i == 0 else 1.0 if i == 2 else 40.0) for i, (N, K) in enumerate(shapes)]
+    cls = lib.ttts_wgrad_group_ok(M, *shapes[0])
+    assert cls == (2 if M > 25600 and shapes[0] != (256, 256) else 1)
     for (N, K) in shapes:
-        assert lib.ttts_wgrad_group_ok(M, N, K) == 1
-    assert lib.ttts_wgrad_group_ok(55680, 1024, 256) == 0 and lib.ttts_wgrad_group_ok(55680, 256, 80) == 0      # tiles of their own
+        assert lib.ttts_wgrad_group_ok(M, N, K) == cls                       # the members of a launch share a class
+    assert lib.ttts_wgrad_group_ok(55680, 1024, 256) == 2 and lib.ttts_wgrad_group_ok(55680, 256, 256) == 1
+    assert lib.ttts_wgrad_group_ok(55680, 256, 80) == 0 and lib.ttts_wgrad_group_ok(55680, 300, 1024) == 0      # launches of their own
     ams, xms = [ops._amax(t) for t in dys], [ops._amax(t) for t in xs]
     wss = [torch.empty(lib.ttts_wgrad_workspace_bytes(M, N, K, 1) // 4, device=dev) for (N, K) in shapes]
     PA, ZA, LA, IA = ctypes.c_void_p * n, ctypes.c_size_t * n, ctypes.c_int64 * n, ctypes.c_int * n

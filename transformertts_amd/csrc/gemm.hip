@@ -1180,37 +1180,45 @@ int ttts_linear_bwd_weight_h3_parts(const float* dy, const float* x, float* cons
 }
 
 int ttts_wgrad_group_ok(int64_t M, int N, int K) {
-    // can dw[N,K] = dy[M,N]^T x[M,K] be a member of a grouped launch?  (the fp16x3 form on the 4-wave 128 x 128 tile: small outputs;
-    // the 256-wide LDS-DMA tile and the 96-wide mel tiles keep their own launches)
-    return M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0 && wgrad_use_x6(N, K) && plan_wgrad(M, N, K, 1, true, HBK).tile == TILE_128;
+    // can dw[N,K] = dy[M,N]^T x[M,K] be a member of a grouped launch, and of which CLASS (members of one launch share it)?
+    // 1: the fp16x3 form on the 4-wave 128 x 128 tile (small outputs); 2: whole 256 x 256 tiles on the 8-wave LDS-DMA kernel (long
+    // row ranges); 0: neither (the 96-wide mel tiles, the fp32-MFMA shapes, ragged 256-tiles keep launches of their own)
+    if (!(M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0 && wgrad_use_x6(N, K))) return 0;
+    const int tile = plan_wgrad(M, N, K, 1, true, HBK).tile;
+    if (tile == TILE_128) return 1;
+    if (tile == H3_TILE_256 && N % 256 == 0 && K % 256 == 0) return 2;
+    return 0;
 }
 
 int ttts_linear_bwd_weight_h3_group(int n, const float* const* dy, const float* const* x, float* const* dw, float* const* dbias,
                                     float* const* ws, const size_t* ws_bytes, const int64_t* M, const int* N, const int* K,
                                     int accumulate, const float* const* dy_amax, const float* const* x_amax,
                                     ttts_reduce_queue* queue, void* stream_) {
-    // n <= 4 independent weight gradients dw_i[N_i,K_i] (+)= dy_i^T x_i, dbias_i (+)= column sums of dy_i, as ONE grid of the
-    // 4-wave 128 x 128 fp16x3 kernel: the row splits are planned for the group (same chip-filling target as a single launch,
-    // shared by the members), so every member writes 1/n of the partial sums a launch of its own would and its workgroups
-    // walk n times the rows.  Each member's partial sums go to its own workspace and are reduced (queued) as usual.
+    // n <= 4 independent weight gradients dw_i[N_i,K_i] (+)= dy_i^T x_i, dbias_i (+)= column sums of dy_i, as ONE grid (all
+    // members of one class, ttts_wgrad_group_ok): the row splits are planned for the group (same chip-filling target as a single
+    // launch, shared by the members), so every member writes 1/n of the partial sums a launch of its own would and its
+    // workgroups walk n times the rows.  Each member's partial sums go to its own workspace and are reduced (queued) as usual.
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(n >= 1 && n <= 4 && dy && x && dw && ws && ws_bytes && M && N && K && dy_amax && x_amax, "linear_bwd_weight_h3_group: bad arguments");
     GemmArgs gs[4];
     int zd[4];
     float* colsum[4];
     long tiles_total = 0, nkt_max = 0;
+    const int cls = ttts_wgrad_group_ok(M[0], N[0], K[0]);
+    const int edge = cls == 2 ? 256 : 128;
     for (int i = 0; i < n; ++i) {
         TTTS_REQUIRE(dy[i] && x[i] && dw[i] && ws[i] && dy_amax[i] && x_amax[i], "linear_bwd_weight_h3_group: null pointer (member %d)", i);
-        TTTS_REQUIRE(ttts_wgrad_group_ok(M[i], N[i], K[i]) && M[i] < (1LL << 31), "linear_bwd_weight_h3_group: member %d (M=%lld N=%d K=%d) does not take the grouped tile",
-                     i, (long long)M[i], N[i], K[i]);
+        TTTS_REQUIRE(cls != 0 && ttts_wgrad_group_ok(M[i], N[i], K[i]) == cls && M[i] < (1LL << 31),
+                     "linear_bwd_weight_h3_group: member %d (M=%lld N=%d K=%d) is not of the group's class %d", i, (long long)M[i], N[i], K[i], cls);
         TTTS_REQUIRE(aligned16(dy[i]) && aligned16(x[i]) && aligned16(ws[i]), "linear_bwd_weight_h3_group: pointers must be 16-byte aligned");
         TTTS_REQUIRE((uint64_t)M[i] * N[i] * 4 < (1ull << 32) && (uint64_t)M[i] * K[i] * 4 < (1ull << 32), "linear_bwd_weight_h3_group: operand larger than 4 GiB");
-        tiles_total += (long)cdiv(N[i], 128) * cdiv(K[i], 128);
+        tiles_total += (long)cdiv(N[i], edge) * cdiv(K[i], edge);
         const long nkt = (M[i] + HBK - 1) / HBK;
         nkt_max = nkt > nkt_max ? nkt : nkt_max;
     }
-    // plan_wgrad's rule for this tile, applied to the group as a whole
-    const long target = (tiles_total > 12 && nkt_max >= 800) ? 512 : 256;
+    // plan_wgrad's rule for the class, applied to the group as a whole: the 8-wave tile holds one workgroup per CU, the 4-wave
+    // tile two (a second round only for many tiles over long row ranges)
+    const long target = cls == 2 ? 256 : ((tiles_total > 12 && nkt_max >= 800) ? 512 : 256);
     long want = target / tiles_total;
     if (want < 1) want = 1;
     for (int i = 0; i < n; ++i) {
@@ -1234,7 +1242,7 @@ int ttts_linear_bwd_weight_h3_group(int n, const float* const* dy, const float* 
         gs[i] = g;
         zd[i] = nsplit;
     }
-    int rc = launch_wgrad_h3_group(gs, zd, n, stream);
+    int rc = cls == 2 ? launch_wgrad_dma_group(gs, zd, n, stream) : launch_wgrad_h3_group(gs, zd, n, stream);
     if (rc) return rc;
     for (int i = 0; i < n; ++i) {
         const long nk = (long)N[i] * K[i];

@@ -323,11 +323,30 @@ int dispatch_h3(const GemmArgs& g, hipStream_t stream);
 // row-chunk partials the fp16x3 forward writes into GemmArgs::bn_ws for an M x N x K problem (0: its tile shape cannot)
 int h3_bn_blocks(long M, long N, long K);
 int dispatch_wgrad_h3(const GemmArgs& g, int zdim, int tile, hipStream_t stream);
+// XCD-aware numbering of the weight-gradient grids: workgroups are dealt round-robin to the 8 XCDs in x-fastest order, so the
+// tiles of one row split -- which read the same rows of dy and x -- would land on different L2s and each fetch its
+// operands from HBM again (a 1024 x 256 weight asks for 3.2x the unique bytes).  Renumbered, XCD e works on one
+// contiguous run of (split, tile) pairs: the tiles of a split start together on the CUs of one XCD and share its L2.
+__device__ __forceinline__ int xcd_renumber(int bid, int total) {
+    const int per = total >> 3, rem = total & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    return xcd * per + min(xcd, rem) + slot;
+}
+// GROUPED weight-gradient launches (wgrad_h3_group_kernel, wgrad_dma_group_kernel): up to WG_GROUP_MAX independent problems as
+// one grid; first[p] = first flat workgroup of problem p (first[n] = total); inside a problem the numbering is (tile x, tile y,
+// split) as in the one-problem kernels
+constexpr int WG_GROUP_MAX = 4;
+struct WgradGroupArgs {
+    GemmArgs g[WG_GROUP_MAX];
+    int first[WG_GROUP_MAX + 1];
+    int n;
+};
 // n <= 4 independent problems on the 4-wave 128 x 128 tile as ONE grid (gemm_h3.hip, wgrad_h3_group_kernel)
 int launch_wgrad_h3_group(const GemmArgs* gs, const int* zdims, int n, hipStream_t stream);
 // the same problem with LDS-DMA staged operand rows (wgrad_dma.hip): whole 256 x 256 tiles only
 bool wgrad_dma_supports(const GemmArgs& g, int tile);
 int launch_wgrad_dma(const GemmArgs& g, int zdim, hipStream_t stream);
+int launch_wgrad_dma_group(const GemmArgs* gs, const int* zdims, int n, hipStream_t stream);
 // image-operand fp16x3 GEMM (gemm_h3i.hip): both operands staged by LDS-DMA, 128 x 256 tile, two workgroups per CU
 bool h3i_supports(const GemmArgs& g);
 int dispatch_h3i(const GemmArgs& g, hipStream_t stream);

@@ -1219,15 +1219,6 @@ __device__ __forceinline__ void wgrad_h3_body(const GemmArgs& g, int bx, int by,
         }
 }
 
-// XCD-aware numbering (as the forward kernel): workgroups are dealt round-robin to the 8 XCDs in x-fastest order, so the
-// tiles of one row split -- which read the same rows of dy and x -- would land on different L2s and each fetch its
-// operands from HBM again (a 1024 x 256 weight asks for 3.2x the unique bytes).  Renumbered, XCD e works on one
-// contiguous run of (split, tile) pairs: the tiles of a split start together on the CUs of one XCD and share its L2.
-__device__ __forceinline__ int xcd_renumber(int bid, int total) {
-    const int per = total >> 3, rem = total & 7;
-    const int xcd = bid & 7, slot = bid >> 3;
-    return xcd * per + min(xcd, rem) + slot;
-}
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_kernel(GemmArgs g) {
     const int gx = gridDim.x, gy = gridDim.y;
@@ -1241,12 +1232,6 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_k
 // k-steps per workgroup in front of a fixed prologue / epilogue; grouped, the splits per problem drop by the group size (so do the
 // partial sums and the reduction's bytes) and each workgroup's row range grows by it.  first[p] = first flat workgroup of
 // problem p (first[n] = total); inside a problem the numbering is (tile x, tile y, split) as in the one-problem kernel.
-constexpr int WG_GROUP_MAX = 4;
-struct WgradGroupArgs {
-    GemmArgs g[WG_GROUP_MAX];
-    int first[WG_GROUP_MAX + 1];
-    int n;
-};
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_group_kernel(WgradGroupArgs gg) {
     const int t = xcd_renumber(blockIdx.x, gg.first[gg.n]);

@@ -74,8 +74,9 @@ __device__ unsigned long long ttts_wg_stamps[2048 * 8 * 8];
 #define WACC(slot, v)
 #endif
 
+// (the kernel's body, shared by the one-problem kernel and the grouped one: workgroup (bx, by, z) of problem g)
 template <int BT, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_dma_kernel(GemmArgs g) {
+__device__ __forceinline__ void wgrad_dma_body(const GemmArgs& g, int bx, int by, int z) {
     constexpr int WM = 2, WN = NW / 2;
     constexpr int WTM = BT / WM, WTN = BT / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int KS = 16;                               // rows per step = one MFMA k-step
@@ -98,19 +99,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_dma_kernel(Gem
     const unsigned long long st_t0 = WSTAMP(), st_r0 = __builtin_amdgcn_s_memrealtime();
     const int st_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
 #endif
-    // XCD-aware numbering, as wgrad_h3_kernel: the tiles (and taps) of one row split read the same rows and share an L2
-    int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
-    {
-        const int gx = gridDim.x, gy = gridDim.y;
-        const int total = gx * gy * (int)gridDim.z;
-        const int bid = bx + gx * (by + gy * z);
-        const int per = total >> 3, rem = total & 7;
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int t = xcd * per + min(xcd, rem) + slot;
-        bx = t % gx;
-        by = (t / gx) % gy;
-        z = t / (gx * gy);
-    }
     const int m0 = by * BT, n0 = bx * BT;
     const int ztap = (g.ztaps > 1) ? (z % g.ztaps) : 0;
     const int zsplit = (g.ztaps > 1) ? (z / g.ztaps) : z;
@@ -355,12 +343,59 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_dma_kernel(Gem
 #endif
 }
 
+// XCD-aware numbering, as wgrad_h3_kernel: the tiles (and taps) of one row split read the same rows and share an L2
+template <int BT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_dma_kernel(GemmArgs g) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int t = xcd_renumber(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * (int)gridDim.z);
+    wgrad_dma_body<BT, NW>(g, t % gx, (t / gx) % gy, t / (gx * gy));
+}
+// GROUPED launch (WgradGroupArgs, gemm_common.h): the 256-wide weight gradients of one decoder layer -- FFN1, FFN2, the packed
+// self-attention in-projection -- as ONE grid with the row splits planned for the group: 11 output tiles share the chip's 256
+// workgroup slots, 23 splits each instead of 64-85, a third of the partial sums (65 MB per launch before) and of the epilogues.
+template <int BT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_dma_group_kernel(WgradGroupArgs gg) {
+    const int t = xcd_renumber(blockIdx.x, gg.first[gg.n]);
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < WG_GROUP_MAX; ++i)
+        if (i < gg.n && t >= gg.first[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const GemmArgs& g = gg.g[p];
+    const int local = t - gg.first[p];
+    const int gx = g.N / BT, gy = g.M / BT;
+    wgrad_dma_body<BT, NW>(g, local % gx, (local / gx) % gy, local / (gx * gy));
+}
+
 // shapes the DMA kernel takes: whole 256 x 256 tiles, 16-byte aligned rows, utterances of at least one step (operands the 32-bit
 // DMA offsets can reach are checked by the caller)
 bool wgrad_dma_supports(const GemmArgs& g, int tile) {
     if (tile != H3_TILE_256) return false;
     return g.M % 256 == 0 && g.N % 256 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && g.K >= 1 && (g.T == 0 || g.T >= 16) &&
            ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15) == 0;
+}
+
+int launch_wgrad_dma_group(const GemmArgs* gs, const int* zdims, int n, hipStream_t stream) {
+    WgradGroupArgs gg = {};
+    if (n < 1 || n > WG_GROUP_MAX) {
+        set_error("grouped weight gradient: %d problems (1..%d)", n, WG_GROUP_MAX);
+        return TTTS_ERR_INVALID;
+    }
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!wgrad_dma_supports(gs[i], H3_TILE_256)) {
+            set_error("grouped weight gradient: member %d does not take the 256 x 256 LDS-DMA tile", i);
+            return TTTS_ERR_INVALID;
+        }
+        gg.g[i] = gs[i];
+        gg.first[i] = total;
+        total += (gs[i].N / 256) * (gs[i].M / 256) * zdims[i];
+    }
+    for (int i = n; i <= WG_GROUP_MAX; ++i) gg.first[i] = total;
+    gg.n = n;
+    hipLaunchKernelGGL((wgrad_dma_group_kernel<256, 8>), dim3((unsigned)total), dim3(512), 0, stream, gg);
+    TTTS_LAUNCH_CHECK("wgrad_dma_group_kernel");
+    return TTTS_OK;
 }
 
 int launch_wgrad_dma(const GemmArgs& g, int zdim, hipStream_t stream) {

@@ -376,7 +376,11 @@ DEFER_REDUCE = True          # tests flip it through `cross_check_forms(defer_re
 
 
 WGRAD_GROUPS = True          # small weight gradients of a backward pass run as grouped launches (ReduceQueue.defer_wgrad)
-WGRAD_GROUP_MAX = 4          # WG_GROUP_MAX of csrc/gemm_h3.hip
+WGRAD_GROUP_MAX = 4          # WG_GROUP_MAX of csrc/gemm_common.h
+# members per launch: class 1 (4-wave 128 x 128 tile: out-projections, cross-attention q, the encoder's linears) fills up; class 2
+# (8-wave 256 x 256 LDS-DMA tile) takes the three big weights of ONE decoder layer -- FFN2, FFN1, the packed in-projection, 11
+# tiles: 23 row splits each on 253 workgroups -- so that no layer's last member is left to run alone
+WGRAD_GROUP_SIZE = {1: 4, 2: 3}
 
 
 class ReduceQueue:
@@ -393,7 +397,7 @@ class ReduceQueue:
         if not self.handle:
             raise MemoryError("ttts_reduce_queue_create failed")
         self.keep: list = []
-        self.wg: list = []          # pending members of the next grouped weight-gradient launch
+        self.wg = {1: [], 2: []}    # pending members of the next grouped weight-gradient launch, per class (ttts_wgrad_group_ok)
         self._armed = False         # a final callback of the running backward pass will flush
 
     def _arm(self) -> None:
@@ -408,23 +412,29 @@ class ReduceQueue:
         self.keep.append(ws)
         return self.handle
 
-    def defer_wgrad(self, dy, dy_am, x, x_am, dw, db, M: int, N: int, K: int) -> None:
-        """dw (+)= dy^T x, db (+)= column sums of dy -- later, in a grouped launch (backward nodes only).  Members of one group
-        share a row count: their workgroups then walk equally long row ranges."""
+    def defer_wgrad(self, cls: int, dy, dy_am, x, x_am, dw, db, M: int, N: int, K: int) -> None:
+        """dw (+)= dy^T x, db (+)= column sums of dy -- later, in a grouped launch of class `cls` (backward nodes only).  Members
+        of one group share a row count: their workgroups then walk equally long row ranges."""
         self._arm()
-        if self.wg and (self.wg[0][6] != M or self.wg[0][0].device != dy.device):
-            self.launch_wgrads()
+        pend = self.wg[cls]
+        if pend and (pend[0][6] != M or pend[0][0].device != dy.device):
+            self.launch_wgrads(cls)
+            pend = self.wg[cls]
         ws = _ws(self._lib.ttts_wgrad_workspace_bytes(M, N, K, 1), x.device)
-        self.wg.append((dy, dy_am, x, x_am, dw, db, M, N, K, ws))
-        if len(self.wg) >= WGRAD_GROUP_MAX:
-            self.launch_wgrads()
+        pend.append((dy, dy_am, x, x_am, dw, db, M, N, K, ws))
+        if len(pend) >= WGRAD_GROUP_SIZE[cls]:
+            self.launch_wgrads(cls)
 
-    def launch_wgrads(self) -> None:
-        """launch the pending group now, on the current stream (its reductions join the queue)"""
-        if not self.wg:
+    def launch_wgrads(self, cls: int = 0) -> None:
+        """launch the pending group(s) now, on the current stream (their reductions join the queue)"""
+        if cls == 0:
+            self.launch_wgrads(1)
+            self.launch_wgrads(2)
+            return
+        if not self.wg[cls]:
             return
         import ctypes
-        wg, self.wg = self.wg, []
+        wg, self.wg[cls] = self.wg[cls], []
         n = len(wg)
         PA, ZA, LA, IA = ctypes.c_void_p * n, ctypes.c_size_t * n, ctypes.c_int64 * n, ctypes.c_int * n
         col = lambda i: [m[i] for m in wg]      # noqa: E731
@@ -452,7 +462,7 @@ class ReduceQueue:
     def clear(self) -> None:
         _lib.check(self._lib.ttts_reduce_queue_clear(self.handle), "ttts_reduce_queue_clear")
         self.keep.clear()
-        self.wg.clear()
+        self.wg = {1: [], 2: []}
         self._armed = False
 
     def __del__(self):
@@ -926,11 +936,12 @@ class LinearFn(torch.autograd.Function):
                 tok_in.premasked = True
         if ctx.needs_input_grad[1]:
             sk, acc, queue = ctx.sinks
-            if (WGRAD_GROUPS and DEFER_REDUCE and sk is not None and queue is not None and WGRAD_MODE == "h3" and row_shift == 0
-                    and _wgrad_is_split(N, K) and lib.ttts_wgrad_group_ok(M, N, K)):
-                # a small output with a gradient sink: nobody reads it before the optimizer, so it waits for the group
-                queue.defer_wgrad(dacc, am if am is not None else _amax(dacc), x, ctx.x_amax if ctx.x_amax is not None else _amax(x),
-                                  sk[0], sk[1], M, N, K)
+            cls = lib.ttts_wgrad_group_ok(M, N, K) if (WGRAD_GROUPS and DEFER_REDUCE and sk is not None and queue is not None and
+                                                       WGRAD_MODE == "h3" and row_shift == 0 and _wgrad_is_split(N, K)) else 0
+            if cls:
+                # an output with a gradient sink: nobody reads it before the optimizer, so it waits for its group
+                queue.defer_wgrad(cls, dacc, am if am is not None else _amax(dacc), x,
+                                  ctx.x_amax if ctx.x_amax is not None else _amax(x), sk[0], sk[1], M, N, K)
             else:
                 nbytes = lib.ttts_wgrad_workspace_bytes(M, N, K, 1)
                 ws = _ws(nbytes, x.device)
