@@ -391,6 +391,8 @@ def main():
     ap.add_argument("--no-wgrad-groups", action="store_true",
                     help="A/B aid: every small weight gradient is a launch of its own instead of a member of a grouped launch "
                          "(ops.ReduceQueue.defer_wgrad, ttts_linear_bwd_weight_h3_group)")
+    ap.add_argument("--wgrad-side-stream", action="store_true",
+                    help="development A/B: the grouped weight-gradient launches run on a side stream beside the data-gradient chain")
     ap.add_argument("--layernorm-images", action="store_true",
                     help="A/B aid: LayerNorm forward / backward also write the image operand of their output and the GEMMs behind "
                          "them take it (measured slower over the step: transformertts_amd/ops.py, LAYERNORM_IMAGES)")
@@ -441,6 +443,8 @@ def main():
         ops.FUSED_CROSS_KV = False
     if args.no_wgrad_groups:
         ops.WGRAD_GROUPS = False
+    if args.wgrad_side_stream:
+        ops.WGRAD_SIDE_STREAM = True
     cfg = model_config(args.config)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
               "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,

@@ -299,7 +299,7 @@ def test_fp16x3_weight_gradient(M, N, K, mag):
                                       (25630, [(256, 1024), (1024, 256), (768, 256)]),                   # a decoder layer's big weights: the LDS-DMA tile
                                       (27001, [(512, 512)])])
 def test_grouped_weight_gradients(M, shapes):
-    """ttts_linear_bwd_weight_h3_group: up to four independent dW_i = dy_i^T x_i (+ bias column sums) as ONE launch of the
+    """ttts_wgrad_group: up to four independent dW_i = dy_i^T x_i (+ bias column sums) as ONE launch of the
     128 x 128 fp16x3 tile (class 1) or of the 256 x 256 LDS-DMA tile (class 2) with the row splits planned for the group -- every member against fp64, stored into zeroed sinks and
     accumulated on a second call (the sinks' contract), same bits on a third run into fresh sinks (fixed-order reductions);
     members of very different magnitude (each has its own dynamic pre-scales)."""
@@ -310,21 +310,21 @@ def test_grouped_weight_gradients(M, shapes):
     n = len(shapes)
     xs = [_rand(M, K, seed=10 + i) * (1e-3 if i == 1 else 1.0) for i, (N, K) in enumerate(shapes)]
     dys = [_rand(M, N, seed=20 + i) * (3e-7 if i == 0 else 1.0 if i == 2 else 40.0) for i, (N, K) in enumerate(shapes)]
-    cls = lib.ttts_wgrad_group_ok(M, *shapes[0])
+    cls = lib.ttts_wgrad_group_ok(M, *shapes[0], 1)
     assert cls == (2 if M > 25600 and shapes[0] != (256, 256) else 1)
     for (N, K) in shapes:
-        assert lib.ttts_wgrad_group_ok(M, N, K) == cls                       # the members of a launch share a class
-    assert lib.ttts_wgrad_group_ok(55680, 1024, 256) == 2 and lib.ttts_wgrad_group_ok(55680, 256, 256) == 1
-    assert lib.ttts_wgrad_group_ok(55680, 256, 80) == 0 and lib.ttts_wgrad_group_ok(55680, 300, 1024) == 0      # launches of their own
+        assert lib.ttts_wgrad_group_ok(M, N, K, 1) == cls                       # the members of a launch share a class
+    assert lib.ttts_wgrad_group_ok(55680, 1024, 256, 1) == 2 and lib.ttts_wgrad_group_ok(55680, 256, 256, 1) == 1
+    assert lib.ttts_wgrad_group_ok(55680, 256, 80, 1) == 0 and lib.ttts_wgrad_group_ok(55680, 300, 1024, 1) == 0      # launches of their own
     ams, xms = [ops._amax(t) for t in dys], [ops._amax(t) for t in xs]
     wss = [torch.empty(lib.ttts_wgrad_workspace_bytes(M, N, K, 1) // 4, device=dev) for (N, K) in shapes]
     PA, ZA, LA, IA = ctypes.c_void_p * n, ctypes.c_size_t * n, ctypes.c_int64 * n, ctypes.c_int * n
     ptr = lambda ts: PA(*[(t.data_ptr() if t is not None else None) for t in ts])      # noqa: E731
 
     def run(dws, dbs):
-        rc = lib.ttts_linear_bwd_weight_h3_group(n, ptr(dys), ptr(xs), ptr(dws), ptr(dbs), ptr(wss), ZA(*[w.numel() * 4 for w in wss]),
-                                                 LA(*[M] * n), IA(*[N for N, K in shapes]), IA(*[K for N, K in shapes]), 1, ptr(ams),
-                                                 ptr(xms), None, _stream())
+        rc = lib.ttts_wgrad_group(n, ptr(dys), ptr(xs), ptr(dws), ptr(dbs), ptr(wss), ZA(*[w.numel() * 4 for w in wss]),
+                                  LA(*[M] * n), IA(*[N for N, K in shapes]), IA(*[K for N, K in shapes]), IA(*[1] * n), IA(*[0] * n), 1,
+                                  ptr(ams), ptr(xms), None, _stream())
         assert rc == 0, _lib.last_error()
     dws = [torch.zeros(N, K, device=dev) for (N, K) in shapes]
     dbs = [torch.zeros(N, device=dev) if i != 1 else None for i, (N, K) in enumerate(shapes)]      # (a member without a bias)
@@ -341,6 +341,48 @@ def test_grouped_weight_gradients(M, shapes):
     torch.randn(1 << 23, device=dev)
     run(dws2, [torch.zeros(N, device=dev) if i != 1 else None for i, (N, K) in enumerate(shapes)])
     assert all(torch.equal(a, b) for a, b in zip(first, dws2))
+
+
+@pytest.mark.parametrize("B,T,chans", [(64, 100, [(256, 256), (256, 256), (256, 256)]),       # the encoder pre-net's convolutions
+                                       (30, 870, [(256, 256), (256, 256), (256, 256)]),        # the post-net's: the LDS-DMA tile, 5 taps each
+                                       (7, 33, [(256, 128), (128, 256)])])
+def test_grouped_conv_weight_gradients(B, T, chans):
+    """ttts_wgrad_group with convolution members (five taps, same padding, utterance clipping): one grid for the weight gradients of
+    a stack of convolutions against torch's conv1d autograd in fp64; with a linear member beside them in the small class."""
+    import ctypes
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _stream
+    lib, dev = _lib.load(), _dev()
+    M, taps = B * T, 5
+    members = [(cout, cin, taps) for cout, cin in chans]
+    cls = lib.ttts_wgrad_group_ok(M, chans[0][0], chans[0][1], taps)
+    assert cls in (1, 2)
+    if cls == 1:
+        members.append((256, 256, 1))                    # a linear weight in the same launch
+    n = len(members)
+    xs = [_rand(B, T, cin, seed=30 + i) for i, (cout, cin, tp) in enumerate(members)]
+    dys = [_rand(B, T, cout, seed=40 + i) * (2e-7 if i == 0 else 1.0) for i, (cout, cin, tp) in enumerate(members)]
+    refs = []
+    for (cout, cin, tp), x, dy in zip(members, xs, dys):
+        if tp == 1:
+            refs.append((dy.double().view(M, cout).t() @ x.double().view(M, cin), dy.double().view(M, cout).sum(0)))
+            continue
+        wd = torch.zeros(cout, cin, tp, dtype=torch.float64, device=dev, requires_grad=True)
+        bd = torch.zeros(cout, dtype=torch.float64, device=dev, requires_grad=True)
+        torch.nn.functional.conv1d(x.double().transpose(1, 2), wd, bd, padding=tp // 2).transpose(1, 2).backward(dy.double())
+        refs.append((wd.grad, bd.grad))
+    dws = [torch.zeros(cout, cin, tp, device=dev) if tp > 1 else torch.zeros(cout, cin, device=dev) for cout, cin, tp in members]
+    dbs = [torch.zeros(cout, device=dev) for cout, cin, tp in members]
+    wss = [torch.empty(lib.ttts_wgrad_workspace_bytes(M, cout, cin, tp) // 4, device=dev) for cout, cin, tp in members]
+    ams, xms = [ops._amax(t) for t in dys], [ops._amax(t) for t in xs]
+    PA, ZA, LA, IA = ctypes.c_void_p * n, ctypes.c_size_t * n, ctypes.c_int64 * n, ctypes.c_int * n
+    ptr = lambda ts: PA(*[t.data_ptr() for t in ts])      # noqa: E731
+    rc = lib.ttts_wgrad_group(n, ptr(dys), ptr(xs), ptr(dws), ptr(dbs), ptr(wss), ZA(*[w.numel() * 4 for w in wss]), LA(*[M] * n),
+                              IA(*[m[0] for m in members]), IA(*[m[1] for m in members]), IA(*[m[2] for m in members]),
+                              IA(*[T if m[2] > 1 else 0 for m in members]), 1, ptr(ams), ptr(xms), None, _stream())
+    assert rc == 0, _lib.last_error()
+    for i in range(n):
+        assert _rel(dws[i], refs[i][0]) < TOL and _rel(dbs[i], refs[i][1]) < TOL, (i, _rel(dws[i], refs[i][0]), _rel(dbs[i], refs[i][1]))
 
 
 def test_weight_gradient_into_several_destinations():

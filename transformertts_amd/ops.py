@@ -381,6 +381,10 @@ WGRAD_GROUP_MAX = 4          # WG_GROUP_MAX of csrc/gemm_common.h
 # (8-wave 256 x 256 LDS-DMA tile) takes the three big weights of ONE decoder layer -- FFN2, FFN1, the packed in-projection, 11
 # tiles: 23 row splits each on 253 workgroups -- so that no layer's last member is left to run alone
 WGRAD_GROUP_SIZE = {1: 4, 2: 3}
+# The grouped launches depend on nothing later in backward and nothing depends on them before the optimizer: on a SIDE stream they
+# run beside the data-gradient chain and fill the CUs its launches leave idle (partial last rounds of the persistent GEMMs, the
+# memory-bound normalisation kernels between them); joined where the queue is flushed.  Captured as a parallel graph branch.
+WGRAD_SIDE_STREAM = False
 
 
 class ReduceQueue:
@@ -399,6 +403,8 @@ class ReduceQueue:
         self.keep: list = []
         self.wg = {1: [], 2: []}    # pending members of the next grouped weight-gradient launch, per class (ttts_wgrad_group_ok)
         self._armed = False         # a final callback of the running backward pass will flush
+        self._side = None           # side stream of the grouped launches (WGRAD_SIDE_STREAM) and whether it has unjoined work
+        self._side_busy = False
 
     def _arm(self) -> None:
         if not self._armed:
@@ -412,16 +418,17 @@ class ReduceQueue:
         self.keep.append(ws)
         return self.handle
 
-    def defer_wgrad(self, cls: int, dy, dy_am, x, x_am, dw, db, M: int, N: int, K: int) -> None:
-        """dw (+)= dy^T x, db (+)= column sums of dy -- later, in a grouped launch of class `cls` (backward nodes only).  Members
-        of one group share a row count: their workgroups then walk equally long row ranges."""
+    def defer_wgrad(self, cls: int, dy, dy_am, x, x_am, dw, db, M: int, N: int, K: int, taps: int = 1, T: int = 0) -> None:
+        """dw (+)= dy^T x, db (+)= column sums of dy (taps > 1: a convolution's weight gradient over utterances of T rows) --
+        later, in a grouped launch of class `cls` (backward nodes only).  Members of one group share a row count: their
+        workgroups then walk equally long row ranges."""
         self._arm()
         pend = self.wg[cls]
         if pend and (pend[0][6] != M or pend[0][0].device != dy.device):
             self.launch_wgrads(cls)
             pend = self.wg[cls]
-        ws = _ws(self._lib.ttts_wgrad_workspace_bytes(M, N, K, 1), x.device)
-        pend.append((dy, dy_am, x, x_am, dw, db, M, N, K, ws))
+        ws = _ws(self._lib.ttts_wgrad_workspace_bytes(M, N, K, taps), x.device)
+        pend.append((dy, dy_am, x, x_am, dw, db, M, N, K, ws, taps, T))
         if len(pend) >= WGRAD_GROUP_SIZE[cls]:
             self.launch_wgrads(cls)
 
@@ -439,11 +446,30 @@ class ReduceQueue:
         PA, ZA, LA, IA = ctypes.c_void_p * n, ctypes.c_size_t * n, ctypes.c_int64 * n, ctypes.c_int * n
         col = lambda i: [m[i] for m in wg]      # noqa: E731
         ptr = lambda ts: PA(*[(t.data_ptr() if t is not None else None) for t in ts])      # noqa: E731
-        _lib.check(self._lib.ttts_linear_bwd_weight_h3_group(
-            n, ptr(col(0)), ptr(col(2)), ptr(col(4)), ptr(col(5)), ptr(col(9)), ZA(*[m[9].numel() * 4 for m in wg]), LA(*col(6)),
-            IA(*col(7)), IA(*col(8)), 1, ptr(col(1)), ptr(col(3)), self.handle if DEFER_REDUCE else None, _stream()),
-            "ttts_linear_bwd_weight_h3_group")
+        def go(stream):
+            _lib.check(self._lib.ttts_wgrad_group(
+                n, ptr(col(0)), ptr(col(2)), ptr(col(4)), ptr(col(5)), ptr(col(9)), ZA(*[m[9].numel() * 4 for m in wg]), LA(*col(6)),
+                IA(*col(7)), IA(*col(8)), IA(*col(10)), IA(*col(11)), 1, ptr(col(1)), ptr(col(3)), self.handle if DEFER_REDUCE else None,
+                stream), "ttts_wgrad_group")
+        if WGRAD_SIDE_STREAM and DEFER_REDUCE:
+            dev = wg[0][0].device
+            if self._side is None or self._side.device != dev:
+                self._side = torch.cuda.Stream(device=dev)
+            cur = torch.cuda.current_stream(dev)
+            self._side.wait_stream(cur)                # the operands (and the zeroed sinks) are ready
+            with torch.cuda.stream(self._side):
+                go(c_void_p(self._side.cuda_stream))
+            self._side_busy = True
+            # the operands were allocated on the main stream: they must outlive the side stream's reads -- kept until the join
+            self.keep.extend(t for m in wg for t in (m[0], m[1], m[2], m[3]))
+        else:
+            go(_stream())
         self.keep.extend(m[9] for m in wg)
+
+    def join_side(self) -> None:
+        if self._side_busy:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+            self._side_busy = False
 
     def _final(self) -> None:
         self._armed = False
@@ -455,12 +481,14 @@ class ReduceQueue:
     def flush(self) -> None:
         """Run every queued reduction now, on the current stream (the pending grouped weight gradients first)."""
         self.launch_wgrads()
+        self.join_side()            # (the queued reductions read the partial sums the side stream writes)
         if self.keep or self.pending():
             _lib.check(self._lib.ttts_reduce_queue_flush(self.handle, _stream()), "ttts_reduce_queue_flush")
             self.keep.clear()
 
     def clear(self) -> None:
         _lib.check(self._lib.ttts_reduce_queue_clear(self.handle), "ttts_reduce_queue_clear")
+        self.join_side()
         self.keep.clear()
         self.wg = {1: [], 2: []}
         self._armed = False
@@ -936,7 +964,7 @@ class LinearFn(torch.autograd.Function):
                 tok_in.premasked = True
         if ctx.needs_input_grad[1]:
             sk, acc, queue = ctx.sinks
-            cls = lib.ttts_wgrad_group_ok(M, N, K) if (WGRAD_GROUPS and DEFER_REDUCE and sk is not None and queue is not None and
+            cls = lib.ttts_wgrad_group_ok(M, N, K, 1) if (WGRAD_GROUPS and DEFER_REDUCE and sk is not None and queue is not None and
                                                        WGRAD_MODE == "h3" and row_shift == 0 and _wgrad_is_split(N, K)) else 0
             if cls:
                 # an output with a gradient sink: nobody reads it before the optimizer, so it waits for its group
@@ -1514,10 +1542,16 @@ class ConvBNFn(torch.autograd.Function):
                            "ttts_conv1d_pack_weight")
                 _lib.check(lib.ttts_conv1d_bwd_data(_p(dy), _p(w_bwd), _p(dx), B, T, cin, cout, taps, _stream()),
                            "ttts_conv1d_bwd_data")
-        ws2 = _ws(lib.ttts_wgrad_workspace_bytes(M, cout, cin, taps), dev)
-        _lib.check(_wgrad(lib, "ttts_conv1d_bwd_weight", dy, am, x, ctx.x_amax, _wgrad_is_split(cout, cin),
-                          _qarg(queue, ws2) if sk is not None else None, _p(t_w), _p(t_b), _p(ws2), ws2.numel() * 4, B, T, cin,
-                          cout, taps, acc), "ttts_conv1d_bwd_weight")
+        cls = lib.ttts_wgrad_group_ok(M, cout, cin, taps) if (WGRAD_GROUPS and DEFER_REDUCE and sk is not None and queue is not None and
+                                                              WGRAD_MODE == "h3" and _wgrad_is_split(cout, cin)) else 0
+        if cls:       # a gradient sink: nobody reads the result before the optimizer, so it waits for its group
+            queue.defer_wgrad(cls, dy, am if am is not None else _amax(dy), x, ctx.x_amax if ctx.x_amax is not None else _amax(x),
+                              t_w, t_b, M, cout, cin, taps, T)
+        else:
+            ws2 = _ws(lib.ttts_wgrad_workspace_bytes(M, cout, cin, taps), dev)
+            _lib.check(_wgrad(lib, "ttts_conv1d_bwd_weight", dy, am, x, ctx.x_amax, _wgrad_is_split(cout, cin),
+                              _qarg(queue, ws2) if sk is not None else None, _p(t_w), _p(t_b), _p(ws2), ws2.numel() * 4, B, T, cin,
+                              cout, taps, acc), "ttts_conv1d_bwd_weight")
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
