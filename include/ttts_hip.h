@@ -237,18 +237,20 @@ int ttts_conv1d_bwd_weight_h3(const float* dy, const float* x, float* dw, float*
  * each layer's multihead_attn.in_proj_weight). */
 /* GROUPED weight gradients: n <= 4 independent problems as ONE launch of an fp16x3 weight-gradient kernel -- the weights of a layer,
  * whose operands are all at hand when backward leaves the layer and whose results nobody reads before the optimizer.  Member i
- * with taps_i = 1: dw_i[N_i,K_i] (+)= dy_i[M_i,N_i]^T x_i[M_i,K_i] (ttts_linear_bwd_weight_h3); taps_i > 1: the weight gradient
+ * with taps_i = 1: dw_i[N_i,K_i] (+)= dy_i[M_i,N_i]^T x_i[M_i,K_i] (ttts_linear_bwd_weight_h3; row_shift_i / T_i as its row_shift /
+ * T); taps_i > 1: the weight gradient
  * of a same-padded convolution over utterances of T_i rows, dw_i[N_i = cout, K_i = cin, taps_i], M_i = B T_i
  * (ttts_conv1d_bwd_weight_h3).  dbias_i: column sums of dy_i, or NULL.  Every array argument is a HOST array of n entries; ws_i /
  * ws_bytes_i as ttts_wgrad_workspace_bytes(M_i, N_i, K_i, taps_i).  The row splits are planned for the group, so each member writes
  * 1/n of the partial sums of a launch of its own.  ttts_wgrad_group_ok: the CLASS of a problem -- 0: no member of any group; 1: the
  * 4-wave 128 x 128 tile; 2: whole 256 x 256 tiles on the 8-wave LDS-DMA kernel (the FFN, packed in-projection and post-net
- * convolution weights over long row ranges) -- the members of one launch share a class.  (The autograd of torch.nn.Linear /
+ * convolution weights over long row ranges); 3 / 4: the 128 x 96 / 96 x 128 tiles of weights with 80 input / output channels
+ * (the mel side) -- the members of one launch share a class.  (The autograd of torch.nn.Linear /
  * nn.Conv1d runs these one by one: model/module.py:4-53 and the torch layers of model/model.py:189-213.) */
 int ttts_wgrad_group_ok(int64_t M, int N, int K, int taps);
 int ttts_wgrad_group(int n, const float* const* dy, const float* const* x, float* const* dw, float* const* dbias,
                      float* const* ws, const size_t* ws_bytes, const int64_t* M, const int* N, const int* K, const int* taps,
-                     const int* T, int accumulate, const float* const* dy_amax, const float* const* x_amax,
+                     const int* T, const int* row_shift, int accumulate, const float* const* dy_amax, const float* const* x_amax,
                      ttts_reduce_queue* queue, void* stream);
 int ttts_linear_bwd_weight_h3_parts(const float* dy, const float* x, float* const* dw_parts, float* const* dbias_parts, int nparts,
                                     float* ws, size_t ws_bytes, int64_t M, int N, int K, int accumulate, const float* dy_amax,

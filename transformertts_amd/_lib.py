@@ -56,7 +56,7 @@ SIGNATURES = {
     "ttts_conv1d_bwd_weight_h3": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, P, P, P, P]),
     "ttts_linear_bwd_weight_h3_parts": (I, [P, P, P, P, I, P, Z, L, I, I, I, P, P, P, P]),
     "ttts_wgrad_group_ok": (I, [L, I, I, I]),
-    "ttts_wgrad_group": (I, [I, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P]),
+    "ttts_wgrad_group": (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P]),
     "ttts_conv1d_pack_bytes": (Z, [I, I, I]),
     "ttts_conv1d_pack_weight": (I, [P, P, P, I, I, I, P]),
     "ttts_conv1d_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),

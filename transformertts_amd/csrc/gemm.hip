@@ -1182,41 +1182,47 @@ int ttts_linear_bwd_weight_h3_parts(const float* dy, const float* x, float* cons
 int ttts_wgrad_group_ok(int64_t M, int N, int K, int taps) {
     // can dw[N,K(,tap)] = dy[M,N]^T x[M(+tap shift),K] be a member of a grouped launch, and of which CLASS (members of one launch
     // share it)?  1: the fp16x3 form on the 4-wave 128 x 128 tile (small outputs); 2: whole 256 x 256 tiles on the 8-wave LDS-DMA
-    // kernel (long row ranges); 0: neither (the 96-wide mel tiles, the fp32-MFMA shapes, ragged 256-tiles keep launches of
-    // their own).  taps = 1: a linear weight; taps > 1: a convolution's (cout = N, cin = K).
+    // kernel (long row ranges); 3 / 4: the 96-wide tiles of the 80-channel mel side; 0: none (the fp32-MFMA shapes, ragged
+    // 256-tiles keep launches of their own).  taps = 1: a linear weight; taps > 1: a convolution's (cout = N, cin = K).
     if (!(M > 0 && N > 0 && K > 0 && taps >= 1 && taps <= 64 && N % 4 == 0 && K % 4 == 0 && wgrad_use_x6(N, K))) return 0;
     const int tile = plan_wgrad(M, N, K, taps, true, HBK).tile;
     if (tile == TILE_128) return 1;
     if (tile == H3_TILE_256 && N % 256 == 0 && K % 256 == 0) return 2;
+    if (tile == TILE_128x96) return 3;            // 80 input channels: the decoder pre-net's first linear, the post-net's first convolution
+    if (tile == TILE_96x128) return 4;            // 80 output channels: the mel head, the post-net's last convolution
     return 0;
 }
 
 int ttts_wgrad_group(int n, const float* const* dy, const float* const* x, float* const* dw, float* const* dbias,
                      float* const* ws, const size_t* ws_bytes, const int64_t* M, const int* N, const int* K, const int* taps,
-                     const int* T, int accumulate, const float* const* dy_amax, const float* const* x_amax,
+                     const int* T, const int* row_shift, int accumulate, const float* const* dy_amax, const float* const* x_amax,
                      ttts_reduce_queue* queue, void* stream_) {
     // n <= 4 independent weight gradients as ONE grid (all members of one class, ttts_wgrad_group_ok).  Member i with taps_i = 1:
-    // dw_i[N_i,K_i] (+)= dy_i^T x_i (a linear weight); taps_i > 1: dw_i[N_i,K_i,tap] (+)= sum over (b, t) of dy_i[b,t,:] x_i[b,
+    // dw_i[N_i,K_i] (+)= dy_i^T x_i (a linear weight; row_shift_i != 0: x_i read row_shift_i rows further inside utterances of T_i
+    // rows, as ttts_linear_bwd_weight's row_shift -- the decoder pre-net's go-frame shift); taps_i > 1: dw_i[N_i,K_i,tap] (+)= sum over (b, t) of dy_i[b,t,:] x_i[b,
     // t + tap - (taps-1)/2, :] with utterances of T_i rows (a same-padded convolution; M_i = B T_i).  dbias_i (+)= column sums of
     // dy_i.  The row splits are planned for the group (same chip-filling target as a single launch, shared by the members), so
     // every member writes 1/n of the partial sums a launch of its own would and its workgroups walk n times the rows.  Each
     // member's partial sums go to its own workspace and are reduced (queued) as usual.
     hipStream_t stream = (hipStream_t)stream_;
-    TTTS_REQUIRE(n >= 1 && n <= 4 && dy && x && dw && ws && ws_bytes && M && N && K && taps && T && dy_amax && x_amax, "wgrad_group: bad arguments");
+    TTTS_REQUIRE(n >= 1 && n <= 4 && dy && x && dw && ws && ws_bytes && M && N && K && taps && T && row_shift && dy_amax && x_amax, "wgrad_group: bad arguments");
     GemmArgs gs[4];
     int zd[4], ns[4];
     float* colsum[4];
     long tiles_total = 0, nkt_max = 0;
     const int cls = ttts_wgrad_group_ok(M[0], N[0], K[0], taps[0]);
-    const int edge = cls == 2 ? 256 : 128;
+    const int edge_n = cls == 2 ? 256 : cls == 4 ? 96 : 128, edge_k = cls == 2 ? 256 : cls == 3 ? 96 : 128;      // tile: output rows x columns
+    const int tile = cls == 3 ? TILE_128x96 : cls == 4 ? TILE_96x128 : TILE_128;
     for (int i = 0; i < n; ++i) {
         TTTS_REQUIRE(dy[i] && x[i] && dw[i] && ws[i] && dy_amax[i] && x_amax[i], "wgrad_group: null pointer (member %d)", i);
         TTTS_REQUIRE(cls != 0 && ttts_wgrad_group_ok(M[i], N[i], K[i], taps[i]) == cls && M[i] < (1LL << 31),
                      "wgrad_group: member %d (M=%lld N=%d K=%d taps=%d) is not of the group's class %d", i, (long long)M[i], N[i], K[i], taps[i], cls);
-        TTTS_REQUIRE(taps[i] == 1 || (T[i] > 0 && M[i] % T[i] == 0 && (cls != 2 || T[i] >= 16)), "wgrad_group: member %d: a convolution needs its utterance length", i);
+        TTTS_REQUIRE((taps[i] == 1 && row_shift[i] == 0) || (T[i] > 0 && M[i] % T[i] == 0 && (cls != 2 || T[i] >= 16)),
+                     "wgrad_group: member %d: a convolution / a shifted linear needs its utterance length", i);
+        TTTS_REQUIRE(taps[i] == 1 || row_shift[i] == 0, "wgrad_group: member %d: a convolution takes no row shift of its own", i);
         TTTS_REQUIRE(aligned16(dy[i]) && aligned16(x[i]) && aligned16(ws[i]), "wgrad_group: pointers must be 16-byte aligned");
         TTTS_REQUIRE((uint64_t)M[i] * N[i] * 4 < (1ull << 32) && (uint64_t)M[i] * K[i] * 4 < (1ull << 32), "wgrad_group: operand larger than 4 GiB");
-        tiles_total += (long)cdiv(N[i], edge) * cdiv(K[i], edge) * taps[i];
+        tiles_total += (long)cdiv(N[i], edge_n) * cdiv(K[i], edge_k) * taps[i];
         const long nkt = (M[i] + HBK - 1) / HBK;
         nkt_max = nkt > nkt_max ? nkt : nkt_max;
     }
@@ -1238,7 +1244,8 @@ int ttts_wgrad_group(int n, const float* const* dy, const float* const* x, float
         g.lda = N[i]; g.ldb = K[i]; g.ldc = K[i];
         g.a_bytes = (uint32_t)((uint64_t)M[i] * N[i] * 4); g.b_bytes = (uint32_t)((uint64_t)M[i] * K[i] * 4);
         const bool conv = taps[i] > 1;
-        g.T = conv ? T[i] : 0; g.shift0 = conv ? -((taps[i] - 1) / 2) : 0; g.shift_step = conv ? 1 : 0; g.ztaps = taps[i];
+        g.T = (conv || row_shift[i] != 0) ? T[i] : 0; g.shift0 = conv ? -((taps[i] - 1) / 2) : row_shift[i]; g.shift_step = conv ? 1 : 0;
+        g.ztaps = taps[i];
         g.kt_per_split = (int)per; g.c_zstride = nk;
         colsum[i] = (dbias != nullptr && dbias[i] != nullptr) ? ws[i] + (size_t)nsplit * taps[i] * nk : nullptr;
         g.colsum = colsum[i];
@@ -1248,7 +1255,7 @@ int ttts_wgrad_group(int n, const float* const* dy, const float* const* x, float
         ns[i] = nsplit;
         zd[i] = nsplit * taps[i];
     }
-    int rc = cls == 2 ? launch_wgrad_dma_group(gs, zd, n, stream) : launch_wgrad_h3_group(gs, zd, n, stream);
+    int rc = cls == 2 ? launch_wgrad_dma_group(gs, zd, n, stream) : launch_wgrad_h3_group(gs, zd, n, tile, stream);
     if (rc) return rc;
     for (int i = 0; i < n; ++i) {
         const long nk = (long)N[i] * K[i];

@@ -342,7 +342,7 @@ struct WgradGroupArgs {
     int n;
 };
 // n <= 4 independent problems on the 4-wave 128 x 128 tile as ONE grid (gemm_h3.hip, wgrad_h3_group_kernel)
-int launch_wgrad_h3_group(const GemmArgs* gs, const int* zdims, int n, hipStream_t stream);
+int launch_wgrad_h3_group(const GemmArgs* gs, const int* zdims, int n, int tile, hipStream_t stream);
 // the same problem with LDS-DMA staged operand rows (wgrad_dma.hip): whole 256 x 256 tiles only
 bool wgrad_dma_supports(const GemmArgs& g, int tile);
 int launch_wgrad_dma(const GemmArgs& g, int zdim, hipStream_t stream);

@@ -1246,24 +1246,34 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void wgrad_h3_g
     wgrad_h3_body<BM, BN, WM, WN>(g, local % gx, (local / gx) % gy, local / (gx * gy));
 }
 
-int launch_wgrad_h3_group(const GemmArgs* gs, const int* zdims, int n, hipStream_t stream) {
-    // 128 x 128 tiles, 4 waves (the tile of every problem the planner groups: plan_wgrad's TILE_128)
+template <int BM, int BN, int WM, int WN>
+static int launch_wgrad_h3_group_t(const GemmArgs* gs, const int* zdims, int n, hipStream_t stream) {
     WgradGroupArgs gg = {};
-    if (n < 1 || n > WG_GROUP_MAX) {
-        set_error("grouped weight gradient: %d problems (1..%d)", n, WG_GROUP_MAX);
-        return TTTS_ERR_INVALID;
-    }
     int total = 0;
     for (int i = 0; i < n; ++i) {
         gg.g[i] = gs[i];
         gg.first[i] = total;
-        total += cdiv(gs[i].N, 128) * cdiv(gs[i].M, 128) * zdims[i];
+        total += cdiv(gs[i].N, BN) * cdiv(gs[i].M, BM) * zdims[i];
     }
     for (int i = n; i <= WG_GROUP_MAX; ++i) gg.first[i] = total;
     gg.n = n;
-    hipLaunchKernelGGL((wgrad_h3_group_kernel<128, 128, 2, 2>), dim3((unsigned)total), dim3(256), 0, stream, gg);
+    hipLaunchKernelGGL((wgrad_h3_group_kernel<BM, BN, WM, WN>), dim3((unsigned)total), dim3(WM * WN * 64), 0, stream, gg);
     TTTS_LAUNCH_CHECK("wgrad_h3_group_kernel");
     return TTTS_OK;
+}
+
+int launch_wgrad_h3_group(const GemmArgs* gs, const int* zdims, int n, int tile, hipStream_t stream) {
+    // the register-turning kernel on one of the planner's 4-wave tiles: TILE_128 (128 x 128), or the 96-wide tiles of the 80-channel
+    // mel side (TILE_128x96: output rows x 96 input channels; TILE_96x128: 96 output rows)
+    if (n < 1 || n > WG_GROUP_MAX) {
+        set_error("grouped weight gradient: %d problems (1..%d)", n, WG_GROUP_MAX);
+        return TTTS_ERR_INVALID;
+    }
+    switch (tile) {
+        case TILE_128x96: return launch_wgrad_h3_group_t<128, 96, 4, 1>(gs, zdims, n, stream);
+        case TILE_96x128: return launch_wgrad_h3_group_t<96, 128, 1, 4>(gs, zdims, n, stream);
+        default: return launch_wgrad_h3_group_t<128, 128, 2, 2>(gs, zdims, n, stream);
+    }
 }
 
 template <int BM, int BN, int WM, int WN>

@@ -156,12 +156,22 @@ __device__ __forceinline__ void wgrad_dma_body(const GemmArgs& g, int bx, int by
     // products of the step: `fetch` issues the reads, `emit` converts and writes.
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
     const int cv_row = lane / LPR, cv_c4 = lane % LPR;                         // row within the wave's rows = i * RPI + cv_row
-    auto fetch = [&](int s, float4 (&va)[NI], float4 (&vb)[NI]) {
+    // `live`: the step exists, i.e. its rows were requested.  A step past the split's end was NOT -- its stage holds whatever an
+    // earlier kernel left in LDS, and `garbage * 0` is NaN when the garbage is an infinity or a NaN (round 6: a NaN in one bias
+    // gradient of the 768 x 256 case after tests that fill their outputs with NaN had run): such a step reads nothing.
+    auto fetch = [&](int s, bool live, float4 (&va)[NI], float4 (&vb)[NI]) {
         const char* base = smem + s * STAGE + wave * RPW * ROWB;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            va[i] = *reinterpret_cast<const float4*>(base + (i * 64 + lane) * 16);
-            vb[i] = *reinterpret_cast<const float4*>(base + OPB + (i * 64 + lane) * 16);
+            va[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (live) {                                     // (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                va[i] = *reinterpret_cast<const float4*>(base + (i * 64 + lane) * 16);
+                vb[i] = *reinterpret_cast<const float4*>(base + OPB + (i * 64 + lane) * 16);
+            }
         }
     };
     // `st` = the step the rows belong to, `live` = it exists (the step after the last converts nothing real), tb = position of
@@ -221,7 +231,7 @@ __device__ __forceinline__ void wgrad_dma_body(const GemmArgs& g, int bx, int by
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
             float4 va[NI], vb[NI];
-            fetch(d, va, vb);
+            fetch(d, st_begin + d < st_end, va, vb);
             emit(st_begin + d, d, st_begin + d < st_end, tb, va, vb);
             tb += KS;
             tb = (tb >= Tm) ? tb - Tm : tb;
@@ -277,7 +287,7 @@ __device__ __forceinline__ void wgrad_dma_body(const GemmArgs& g, int bx, int by
             [[maybe_unused]] const unsigned long long w1 = WSTAMP();
             float4 va[NI], vb[NI];
 #if !(TTTS_WG_ABL & 2)
-            fetch(s2, va, vb);
+            fetch(s2, st + 2 < st_end, va, vb);
 #endif
 #pragma unroll
             for (int i = TM / 2; i < TM; ++i) block_row(i);

@@ -380,7 +380,7 @@ WGRAD_GROUP_MAX = 4          # WG_GROUP_MAX of csrc/gemm_common.h
 # members per launch: class 1 (4-wave 128 x 128 tile: out-projections, cross-attention q, the encoder's linears) fills up; class 2
 # (8-wave 256 x 256 LDS-DMA tile) takes the three big weights of ONE decoder layer -- FFN2, FFN1, the packed in-projection, 11
 # tiles: 23 row splits each on 253 workgroups -- so that no layer's last member is left to run alone
-WGRAD_GROUP_SIZE = {1: 4, 2: 3}
+WGRAD_GROUP_SIZE = {1: 4, 2: 3, 3: 2, 4: 2}     # (classes 3 / 4: the two 80-channel weights of each kind -- a linear and a convolution)
 # The grouped launches depend on nothing later in backward and nothing depends on them before the optimizer: on a SIDE stream they
 # run beside the data-gradient chain and fill the CUs its launches leave idle (partial last rounds of the persistent GEMMs, the
 # memory-bound normalisation kernels between them); joined where the queue is flushed.  Captured as a parallel graph branch.
@@ -401,7 +401,7 @@ class ReduceQueue:
         if not self.handle:
             raise MemoryError("ttts_reduce_queue_create failed")
         self.keep: list = []
-        self.wg = {1: [], 2: []}    # pending members of the next grouped weight-gradient launch, per class (ttts_wgrad_group_ok)
+        self.wg = {1: [], 2: [], 3: [], 4: []}    # pending members of the next grouped launch, per class (ttts_wgrad_group_ok)
         self._armed = False         # a final callback of the running backward pass will flush
         self._side = None           # side stream of the grouped launches (WGRAD_SIDE_STREAM) and whether it has unjoined work
         self._side_busy = False
@@ -418,7 +418,8 @@ class ReduceQueue:
         self.keep.append(ws)
         return self.handle
 
-    def defer_wgrad(self, cls: int, dy, dy_am, x, x_am, dw, db, M: int, N: int, K: int, taps: int = 1, T: int = 0) -> None:
+    def defer_wgrad(self, cls: int, dy, dy_am, x, x_am, dw, db, M: int, N: int, K: int, taps: int = 1, T: int = 0,
+                    row_shift: int = 0) -> None:
         """dw (+)= dy^T x, db (+)= column sums of dy (taps > 1: a convolution's weight gradient over utterances of T rows) --
         later, in a grouped launch of class `cls` (backward nodes only).  Members of one group share a row count: their
         workgroups then walk equally long row ranges."""
@@ -428,15 +429,15 @@ class ReduceQueue:
             self.launch_wgrads(cls)
             pend = self.wg[cls]
         ws = _ws(self._lib.ttts_wgrad_workspace_bytes(M, N, K, taps), x.device)
-        pend.append((dy, dy_am, x, x_am, dw, db, M, N, K, ws, taps, T))
+        pend.append((dy, dy_am, x, x_am, dw, db, M, N, K, ws, taps, T, row_shift))
         if len(pend) >= WGRAD_GROUP_SIZE[cls]:
             self.launch_wgrads(cls)
 
     def launch_wgrads(self, cls: int = 0) -> None:
         """launch the pending group(s) now, on the current stream (their reductions join the queue)"""
         if cls == 0:
-            self.launch_wgrads(1)
-            self.launch_wgrads(2)
+            for c in (1, 2, 3, 4):
+                self.launch_wgrads(c)
             return
         if not self.wg[cls]:
             return
@@ -449,8 +450,8 @@ class ReduceQueue:
         def go(stream):
             _lib.check(self._lib.ttts_wgrad_group(
                 n, ptr(col(0)), ptr(col(2)), ptr(col(4)), ptr(col(5)), ptr(col(9)), ZA(*[m[9].numel() * 4 for m in wg]), LA(*col(6)),
-                IA(*col(7)), IA(*col(8)), IA(*col(10)), IA(*col(11)), 1, ptr(col(1)), ptr(col(3)), self.handle if DEFER_REDUCE else None,
-                stream), "ttts_wgrad_group")
+                IA(*col(7)), IA(*col(8)), IA(*col(10)), IA(*col(11)), IA(*col(12)), 1, ptr(col(1)), ptr(col(3)),
+                self.handle if DEFER_REDUCE else None, stream), "ttts_wgrad_group")
         if WGRAD_SIDE_STREAM and DEFER_REDUCE:
             dev = wg[0][0].device
             if self._side is None or self._side.device != dev:
@@ -490,7 +491,7 @@ class ReduceQueue:
         _lib.check(self._lib.ttts_reduce_queue_clear(self.handle), "ttts_reduce_queue_clear")
         self.join_side()
         self.keep.clear()
-        self.wg = {1: [], 2: []}
+        self.wg = {1: [], 2: [], 3: [], 4: []}
         self._armed = False
 
     def __del__(self):
@@ -965,11 +966,14 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             sk, acc, queue = ctx.sinks
             cls = lib.ttts_wgrad_group_ok(M, N, K, 1) if (WGRAD_GROUPS and DEFER_REDUCE and sk is not None and queue is not None and
-                                                       WGRAD_MODE == "h3" and row_shift == 0 and _wgrad_is_split(N, K)) else 0
+                                                       WGRAD_MODE == "h3" and _wgrad_is_split(N, K)) else 0
+            if cls == 2 and row_shift != 0:
+                cls = 0                      # (the LDS-DMA tile clips utterances of at least 16 rows only: keep the checked single launch)
             if cls:
                 # an output with a gradient sink: nobody reads it before the optimizer, so it waits for its group
                 queue.defer_wgrad(cls, dacc, am if am is not None else _amax(dacc), x,
-                                  ctx.x_amax if ctx.x_amax is not None else _amax(x), sk[0], sk[1], M, N, K)
+                                  ctx.x_amax if ctx.x_amax is not None else _amax(x), sk[0], sk[1], M, N, K, 1, T if row_shift else 0,
+                                  row_shift)
             else:
                 nbytes = lib.ttts_wgrad_workspace_bytes(M, N, K, 1)
                 ws = _ws(nbytes, x.device)
@@ -1411,8 +1415,14 @@ class HeadsFn(torch.autograd.Function):
             t_bm = db_mel = torch.empty(N, dtype=torch.float32, device=x.device)
             t_ws = dw_stop = torch.empty_like(w_stop)
             t_bs = db_stop = torch.empty(1, dtype=torch.float32, device=x.device)
-        _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dmel, dmel_am, x, ctx.x_amax, _wgrad_is_split(N, K), _qarg(queue, ws),
-                          _p(t_wm), _p(t_bm), _p(ws), ws.numel() * 4, M, N, K, 0, 0, acc), "ttts_linear_bwd_weight")
+        cls = lib.ttts_wgrad_group_ok(M, N, K, 1) if (WGRAD_GROUPS and DEFER_REDUCE and sk is not None and queue is not None and
+                                                       WGRAD_MODE == "h3" and _wgrad_is_split(N, K)) else 0
+        if cls:
+            queue.defer_wgrad(cls, dmel, dmel_am if dmel_am is not None else _amax(dmel), x,
+                              ctx.x_amax if ctx.x_amax is not None else _amax(x), t_wm, t_bm, M, N, K)
+        else:
+            _lib.check(_wgrad(lib, "ttts_linear_bwd_weight", dmel, dmel_am, x, ctx.x_amax, _wgrad_is_split(N, K), _qarg(queue, ws),
+                              _p(t_wm), _p(t_bm), _p(ws), ws.numel() * 4, M, N, K, 0, 0, acc), "ttts_linear_bwd_weight")
         _lib.check(lib.ttts_rowdot_bwd(_p(dstop), _p(x), _p(w_stop), _p(dx), _p(t_ws), _p(t_bs), _p(ws2),
                                        ws2.numel() * 4, M, K, acc, _qarg(queue, ws2), _stream()), "ttts_rowdot_bwd")
         return dx, dw_mel, db_mel, dw_stop, db_stop, None, None
