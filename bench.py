@@ -82,7 +82,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense
 
 
-TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json")     # see tools/collect_traffic.py; round 3's file mis-normalised WRITE_SIZE (x1.9) and is not read
+TRAFFIC_FILES = ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json")     # see tools/collect_traffic.py; round 3's file mis-normalised WRITE_SIZE (x1.9) and is not read
 
 
 def measured_traffic(kernel: str, workload: str = "base_b64"):
@@ -533,6 +533,25 @@ def main():
     frames_all, flops_all = float(tot[0].item()), float(tot[1].item())
     final_loss = float(loss.item())
 
+    probe = None
+    if not args.no_probe:
+        # one extra, untimed step on EVERY rank (it contains the gradient all-reduce); rank 0 instruments it
+        # (taken right behind the timed steps, BEFORE the sustained stretch: the kernel's clock then is the timed region's, not that
+        # of a chip ten seconds into a soak -- round 5's probe read 108 us per launch where the step's own launches took 98)
+        graph_was = ts.use_graph
+        ts.use_graph = False                     # the probe times individual launches: this step runs eagerly
+        if rank == 0:
+            with GemmProbe(_lib.load()) as gp:
+                step(args.warmup + args.steps)
+            probe = gp.summary()
+            note("instrumented step done")
+            if args.gemm_shapes:
+                print("\n".join(gp.shape_table()), file=sys.stderr, flush=True)
+        else:
+            step(args.warmup + args.steps)
+    fence()
+    if not args.no_probe:
+        ts.use_graph = graph_was                 # the sustained stretch replays the graphs again
     # sustained figure: keep stepping for args.sustain seconds, in stretches of `args.steps` steps fenced like the timed ones
     sustained = None
     if args.sustain > 0 and not rehearsal:
@@ -595,20 +614,6 @@ def main():
         if not rehearsal_check["rel_l2_vs_mean_of_rank_gradients"] <= 1e-6:
             raise SystemExit(f"rehearsal: reduced gradients differ from the mean of the rank gradients: {rehearsal_check}")
 
-    probe = None
-    if not args.no_probe:
-        # one extra, untimed step on EVERY rank (it contains the gradient all-reduce); rank 0 instruments it
-        ts.use_graph = False                     # the probe times individual launches: this step runs eagerly
-        if rank == 0:
-            with GemmProbe(_lib.load()) as gp:
-                step(args.warmup + args.steps)
-            probe = gp.summary()
-            note("instrumented step done")
-            if args.gemm_shapes:
-                print("\n".join(gp.shape_table()), file=sys.stderr, flush=True)
-        else:
-            step(args.warmup + args.steps)
-    fence()
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

@@ -630,10 +630,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
 #ifdef TTTS_CLOCK_STAMPS
 __device__ unsigned long long ttts_clock_h3_wide[2 * 512];
 #endif
-template <bool CLIP>
+// BM = 224, WM x WN = 1 x 4 (a wave owns 224 x 64: 7 x 2 accumulator blocks, 224 registers): the SAME kernel on a tile 7/8 as
+// high.  M = 55 680 rows are 217.5 tiles of 256 rows -- for a 256-column output ONE round on 256 CUs with 38 of them idle, for
+// 1024 columns 3.4 rounds run as four -- and 248.6 tiles of 224 rows: the same rounds, every one 12.5 % shorter (VERDICT r05
+// "Next" 5 asked for the partial round to be split; a shorter tile for EVERY round needs no second code path).  7 row blocks do
+// not divide over two wave rows, so the four waves sit side by side (64 columns each) and all read the tile's seven A
+// fragments: 18 fragment reads, 14 A-piece halves and 8 B pieces per k-step still fit the 42 MFMA slots.
+template <bool CLIP, int BM_ = 256, int WM_ = 2, int WN_ = 2>
 __global__ __launch_bounds__(256, 1) void gemm_h3_wide_kernel(GemmArgs g) {
     TTTS_CLOCK_BEGIN();
-    constexpr int BM = 256, BN = 256, WM = 2, WN = 2, NT = 256;
+    constexpr int BM = BM_, BN = 256, WM = WM_, WN = WN_, NT = 256;
+    static_assert(WM * WN == 4 && BM % (32 * WM) == 0 && (BM * 8) % NT == 0, "four waves, whole 32-row blocks and A pieces");
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int A_PLANE = BM * 16, B_PLANE = BN * 16, STAGE = 2 * (A_PLANE + B_PLANE);      // dwords
     constexpr int NLA = BM * 8 / NT, NLB = BN * 4 / NT;
@@ -876,7 +883,28 @@ static int launch_h3(const GemmArgs& g, hipStream_t stream) {
 // launches took 124.7 us against 119.7)
 static bool h3_wide_supports(const GemmArgs& g) { return g.K >= 3 * HBK && g.T <= 0; }
 
+// rows per tile of the one-wave-per-SIMD kernel for an M x N output: 224 where that is fewer row-units on the busiest CU
+// (rounds x tile height), else 256
+#ifndef TTTS_H3_WIDE_224
+#define TTTS_H3_WIDE_224 1
+#endif
+static int h3_wide_rows(long M, long N) {
+    const long nx = cdiv(N, 256);
+    const long r256 = (nx * cdiv(M, 256) + 255) / 256 * 256, r224 = (nx * cdiv(M, 224) + 255) / 256 * 224;
+    return (TTTS_H3_WIDE_224 && r224 < r256) ? 224 : 256;
+}
+
 static int launch_h3_wide(const GemmArgs& g, hipStream_t stream) {
+    if (h3_wide_rows(g.M, g.N) == 224) {
+        const long ntiles = (long)cdiv(g.N, 256) * cdiv(g.M, 224);
+        const long rounds = (ntiles + 255) / 256;
+        long gsz = ((ntiles + rounds - 1) / rounds + 7) / 8 * 8;
+        if (gsz > 256) gsz = 256;
+        dim3 grid((unsigned)(ntiles < 256 ? ntiles : gsz), 1, 1);
+        hipLaunchKernelGGL((gemm_h3_wide_kernel<false, 224, 1, 4>), grid, dim3(256), 0, stream, g);
+        TTTS_LAUNCH_CHECK("gemm_h3_wide_kernel<224>");
+        return TTTS_OK;
+    }
     const long ntiles = (long)cdiv(g.N, 256) * cdiv(g.M, 256);
     // one workgroup per CU, and no more of them than level rounds need: 872 tiles are four rounds on 256 workgroups (104 busy
     // in the last) and four on 224 (200 busy in the last) -- the same rounds with fewer CUs pulling on L2 / HBM at a time
@@ -897,7 +925,16 @@ bool h3_supports(const GemmArgs& g) {
 }
 
 
+#ifdef TTTS_TUNE
+// development builds only (tools/tile_sweep.py): force the tile of every fp16x3 forward / data-gradient launch
+static int g_force_h3_tile = 0;
+extern "C" void ttts_dbg_force_h3_tile(int tile) { g_force_h3_tile = tile; }
+#endif
+
 int h3_tile_choice(long M, long N, long K) {
+#ifdef TTTS_TUNE
+    if (g_force_h3_tile) return g_force_h3_tile;
+#endif
     if (N <= 96 && (long)cdiv(M, 128) >= 384) return TILE_128x96;
     // busiest-CU cost model of gemm.hip's choose_tile: workgroups a CU runs one after the other x tile area / efficiency
     // (a 256-wide tile is one workgroup per CU at a time, the 128-wide ones two)
