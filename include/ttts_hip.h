@@ -235,7 +235,9 @@ int ttts_conv1d_bwd_weight_h3(const float* dy, const float* x, float* dw, float*
  * dbias_parts are HOST arrays of device pointers.  The backward of the cross-attention K/V projection of every decoder layer
  * run as one GEMM on the encoder memory they all read (the reference runs it per layer: model/layers.py:54-74, rows d..3d of
  * each layer's multihead_attn.in_proj_weight). */
-/* GROUPED weight gradients: n <= 4 independent problems as ONE launch of an fp16x3 weight-gradient kernel -- the weights of a layer,
+/* ---- ABI v12 (round 6): grouped weight gradients, the multi-destination weight gradient, stacked weight images
+ * (ttts_weight_split_batched).
+ * GROUPED weight gradients: n <= 4 independent problems as ONE launch of an fp16x3 weight-gradient kernel -- the weights of a layer,
  * whose operands are all at hand when backward leaves the layer and whose results nobody reads before the optimizer.  Member i
  * with taps_i = 1: dw_i[N_i,K_i] (+)= dy_i[M_i,N_i]^T x_i[M_i,K_i] (ttts_linear_bwd_weight_h3; row_shift_i / T_i as its row_shift /
  * T); taps_i > 1: the weight gradient
