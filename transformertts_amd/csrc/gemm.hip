@@ -1228,7 +1228,10 @@ int ttts_wgrad_group(int n, const float* const* dy, const float* const* x, float
     }
     // plan_wgrad's rule for the class, applied to the group as a whole: the 8-wave tile holds one workgroup per CU, the 4-wave
     // tile two (a second round only for many tiles over long row ranges)
-    const long target = cls == 2 ? 256 : ((tiles_total > 12 && nkt_max >= 800) ? 512 : 256);
+    // (the 96-wide tiles' workgroups are long -- 10 + 2 tiles of the mel side over 55 680 rows were 140 us on 252 workgroups -- and
+    // their partial tiles small: both workgroup slots of every CU from 8 tiles on)
+    const long many = (cls == 3 || cls == 4) ? 8 : 13;
+    const long target = cls == 2 ? 256 : ((tiles_total >= many && nkt_max >= 800) ? 512 : 256);
     long want = target / tiles_total;
     if (want < 1) want = 1;
     for (int i = 0; i < n; ++i) {
