@@ -469,7 +469,8 @@ def test_fp16x3_conv_weight_gradient(B, T, cin, cout):
 
 
 @pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128), (4, 33, 80, 64), (6, 41, 512, 80),
-                                          (3, 870, 256, 80), (2, 9, 64, 20)])
+                                          (3, 870, 256, 80), (2, 9, 64, 20),
+                                          (48, 870, 256, 256)])         # the 224-row one-wave-per-SIMD tile, clipping loader
 def test_fp16x3_conv_data_gradient(B, T, cin, cout):
     from transformertts_amd import _lib, ops
     from transformertts_amd.ops import _p, _stream
@@ -486,7 +487,7 @@ def test_fp16x3_conv_data_gradient(B, T, cin, cout):
 
 
 @pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128), (4, 33, 64, 80), (6, 41, 80, 512),
-                                          (3, 870, 80, 256), (2, 9, 20, 64)])
+                                          (3, 870, 80, 256), (2, 9, 20, 64), (48, 870, 256, 256)])
 def test_fp16x3_conv_forward_agrees_with_fp64(B, T, cin, cout):
     from transformertts_amd import _lib, ops
     from transformertts_amd.ops import _p, _stream
@@ -504,7 +505,9 @@ def test_fp16x3_conv_forward_agrees_with_fp64(B, T, cin, cout):
 
 
 @pytest.mark.parametrize("B,T,cin,cout,offset", [(3, 50, 128, 256, 0.0), (7, 333, 256, 256, 0.0), (2, 7, 256, 128, 40.0),
-                                                 (30, 870, 256, 256, 3.0), (5, 97, 64, 64, 0.0)])
+                                                 (30, 870, 256, 256, 3.0), (5, 97, 64, 64, 0.0),
+                                                 (48, 870, 256, 256, 3.0),      # 41 760 rows: the 224-row one-wave-per-SIMD tile with the
+                                                 (61, 401, 256, 256, 0.0)])     # clipping loader + this epilogue (ragged last tile too)
 def test_batchnorm_statistics_from_the_conv_epilogue(B, T, cin, cout, offset):
     """The fp16x3 convolution leaves BatchNorm's row-chunk partials (count, mean, M2 per channel) behind in its epilogue and
     ttts_bn_train_stats_from_partials merges them: same mean / invstd / running statistics as the separate two-pass

@@ -881,7 +881,15 @@ static int launch_h3(const GemmArgs& g, hipStream_t stream) {
 // (row-shifted / utterance-clipped operands -- convolutions, the go-frame shift -- stay on the 8-wave kernel: with the clip
 // arithmetic and the BatchNorm-partials epilogue the 512-register kernel spills, and measured in the step its convolution
 // launches took 124.7 us against 119.7)
-static bool h3_wide_supports(const GemmArgs& g) { return g.K >= 3 * HBK && g.T <= 0; }
+// ... on its 256-row tile.  The 224-row variant (below) holds 14 accumulator blocks instead of 16 and takes the clip arithmetic
+// and the BatchNorm-partials epilogue without scratch (504 registers): convolutions whose row count favours 224-row tiles run on it.
+#ifndef TTTS_H3_WIDE_CLIP
+#define TTTS_H3_WIDE_CLIP 1
+#endif
+static int h3_wide_rows(long M, long N);
+static bool h3_wide_supports(const GemmArgs& g) {
+    return g.K >= 3 * HBK && (g.T <= 0 || (TTTS_H3_WIDE_CLIP && h3_wide_rows(g.M, g.N) == 224));
+}
 
 // rows per tile of the one-wave-per-SIMD kernel for an M x N output: 224 where that is fewer row-units on the busiest CU
 // (rounds x tile height), else 256
@@ -901,7 +909,10 @@ static int launch_h3_wide(const GemmArgs& g, hipStream_t stream) {
         long gsz = ((ntiles + rounds - 1) / rounds + 7) / 8 * 8;
         if (gsz > 256) gsz = 256;
         dim3 grid((unsigned)(ntiles < 256 ? ntiles : gsz), 1, 1);
-        hipLaunchKernelGGL((gemm_h3_wide_kernel<false, 224, 1, 4>), grid, dim3(256), 0, stream, g);
+        if (g.T > 0)
+            hipLaunchKernelGGL((gemm_h3_wide_kernel<true, 224, 1, 4>), grid, dim3(256), 0, stream, g);
+        else
+            hipLaunchKernelGGL((gemm_h3_wide_kernel<false, 224, 1, 4>), grid, dim3(256), 0, stream, g);
         TTTS_LAUNCH_CHECK("gemm_h3_wide_kernel<224>");
         return TTTS_OK;
     }
@@ -973,7 +984,11 @@ static bool h3_tile_geometry(int tile, int& bm, int& wm) {
 
 int h3_bn_blocks(long M, long N, long K) {
     int bm, wm;
-    if (!h3_tile_geometry(h3_tile_choice(M, N, K), bm, wm)) return 0;
+    const int tile = h3_tile_choice(M, N, K);
+    if (!h3_tile_geometry(tile, bm, wm)) return 0;
+    // (only convolutions ask: T > 0.  On the 256 x 256 tile they run on the one-wave-per-SIMD kernel's 224-row variant where the
+    // row count favours it -- dispatch_h3 / h3_wide_supports -- whose four waves sit side by side: one row chunk per tile)
+    if (tile == H3_TILE_256 && TTTS_H3_WIDE_CLIP && K >= 3 * HBK && h3_wide_rows(M, N) == 224) { bm = 224; wm = 1; }
     const long nb = (long)cdiv(M, bm) * wm;
     return (nb <= 512 && N % 4 == 0 && (long)(M + 256) * N * 4 < (1L << 32)) ? (int)nb : 0;   // 512 = BN_MAXBLK of norm.hip
 }
