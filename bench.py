@@ -165,8 +165,15 @@ class GemmProbe:
                 _plain = _name == "ttts_linear_bwd_data_h3" or (_name == "ttts_linear_fwd_h3" and a[13] <= 0)
                 M, N, K = _dims(a)
                 tile = self.lib.ttts_gemm_tile_choice(M, N, K, _x6)
-                if _x6 == 2 and tile == 6 and K >= 96 and _plain:
-                    tile = 9        # unshifted operands on the 256 x 256 tile run on gemm_h3_wide_kernel (one wave per SIMD)
+                rows = 256
+                if _x6 == 2 and tile == 6 and K >= 96:
+                    # csrc/gemm_h3.hip h3_wide_rows: 224-row tiles where rounds x height is smaller; shifted / clipped operands
+                    # (convolutions, the go-frame shift) take the one-wave-per-SIMD kernel on its 224-row variant only
+                    nx = -(-N // 256)
+                    r256, r224 = -(-(nx * -(-M // 256)) // 256) * 256, -(-(nx * -(-M // 224)) // 256) * 224
+                    rows = 224 if r224 < r256 else 256
+                    if _plain or rows == 224:
+                        tile = 9    # gemm_h3_wide_kernel (one wave per SIMD)
                 if _name == "ttts_linear_fwd_h3d_img":
                     tile = "gemm_h3i_kernel<128,true,false,false,false,true>"
                 if _name in self.DMA:
@@ -186,7 +193,7 @@ class GemmProbe:
                 # bytes that cross the CUs' global-memory paths on a 256 x 256 tiling (any form of the 256-wide kernels): every
                 # tile loads its 256 x K activation block and its 256 x K weight block (re-reads come from L2, but through the same
                 # per-CU path) and stores 256 x 256 outputs
-                cu_bytes = (-(-M // 256)) * (-(-N // 256)) * (2.0 * 256 * K * 4) + 4.0 * M * N
+                cu_bytes = (-(-M // rows)) * (-(-N // 256)) * ((rows + 256.0) * K * 4) + 4.0 * M * N
                 if isinstance(tile, str) and not tile.startswith("gemm_h3i_kernel<256"):       # 128 x 256 tiles
                     cu_bytes = (-(-M // 128)) * (-(-N // 256)) * ((128 + 256) * K * 4.0) + 4.0 * M * N
                 self.records.append((e0, e1, 2.0 * M * N * K, (_x6, tile), 4.0 * (M * K + M * N + N * K), cu_bytes))
