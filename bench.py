@@ -400,6 +400,9 @@ def main():
                          "(ops.ReduceQueue.defer_wgrad, ttts_linear_bwd_weight_h3_group)")
     ap.add_argument("--wgrad-side-stream", action="store_true",
                     help="development A/B: the grouped weight-gradient launches run on a side stream beside the data-gradient chain")
+    ap.add_argument("--no-twin-encoder", action="store_true",
+                    help="A/B aid: each forward of the step encodes its phonemes itself (the reference's structure) instead of ONE "
+                         "encoder pass over a batch of 2 B for both (model.encode_twin)")
     ap.add_argument("--layernorm-images", action="store_true",
                     help="A/B aid: LayerNorm forward / backward also write the image operand of their output and the GEMMs behind "
                          "them take it (measured slower over the step: transformertts_amd/ops.py, LAYERNORM_IMAGES)")
@@ -452,6 +455,8 @@ def main():
         ops.WGRAD_GROUPS = False
     if args.wgrad_side_stream:
         ops.WGRAD_SIDE_STREAM = True
+    if args.no_twin_encoder:
+        ops.TWIN_ENCODER = False
     cfg = model_config(args.config)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
               "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,
@@ -648,7 +653,7 @@ def main():
                        "alignments_written": bool(args.alignments),
                        "arithmetic": "3 x f16 MFMA terms per fp32 product (hi/lo f16 splits of both operands), fp32 accumulate",
                        "dma_gemms": not args.no_image_operands, "layernorm_images": bool(args.layernorm_images),
-                       "head_images": not args.no_head_images, "fused_cross_kv": not args.no_fused_kv, "wgrad_groups": not args.no_wgrad_groups,
+                       "head_images": not args.no_head_images, "fused_cross_kv": not args.no_fused_kv, "wgrad_groups": not args.no_wgrad_groups, "twin_encoder": not args.no_twin_encoder,
                        "final_loss": final_loss, "per_step_loss_item_sync": False},
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "sustained": sustained,

@@ -156,6 +156,9 @@ int ttts_linear_fwd_h3(const float* x, const void* w_planes, const float* bias, 
  * ttts_bn_train_stats_from_partials finishes the statistics without a pass over y.  nblk = ttts_conv1d_fwd_h3_bn_blocks(...);
  * 0 means this shape's tile cannot emit them (pass NULL and use ttts_bn_train_stats). */
 int ttts_conv1d_fwd_h3_bn_blocks(int B, int T, int cin, int cout, int taps);
+/* rows of (b, t) one partial covers (partial i: rows i * chunk ..; 0: this shape emits none): the statistics of a row range that is
+ * a whole number of chunks can be finished from its own partials, bn_partials + first_chunk * 3 * cout (ABI v12) */
+int ttts_conv1d_fwd_h3_bn_chunk_rows(int B, int T, int cin, int cout, int taps);
 int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
                        int taps, const float* x_amax, float* bn_partials, void* stream);
 /* fp16x3 data gradients: as the forward, with the gradient as the activation operand (dy_amax: its partial maxima;
@@ -385,11 +388,14 @@ int ttts_attention_bwd_h3(const float* q, const float* k, const float* v, const 
  * side), v_amax at the TTTS_AMAX_SLOTS partial maxima of |v| (the section array ttts_linear_fwd_h3d_img filled).  o, lse, attn,
  * o_amax_out as ttts_attention_fwd_h3.  rowstat_out: (5, B, H, Tq) floats -- the three planes of ttts_attention_fwd_h3 plus
  * the query row's exponent multiplier 2^-e_q * q_scale * log2(e) and score multiplier 2^-e_q * q_scale; the backward
- * requires it (it forms the forward's own probabilities from bit-identical accumulators). */
+ * requires it (it forms the forward's own probabilities from bit-identical accumulators).  q_inv_rows / k_inv_rows / stat_plane (ABI v12): rows per head plane of the inverse scales and
+ * floats per plane of the row statistics -- 0: B * Tq, B * Tk, B * H * Tq; larger when the batch is the FIRST part of a bigger
+ * image (the encoder of both forwards of a training step run as one batch: ops.twin). */
 int ttts_attention_fwd_img(const void* q, const void* k, const void* v, const float* q_inv, const float* k_inv,
                            const float* v_inv, float* o, float* lse, float* attn, const int64_t* key_lens, int B, int H, int Tq,
                            int Tk, int ldq, int ldk, int ldv, int ldo, int causal, float q_scale, float drop_p, uint64_t seed,
-                           const uint64_t* step_seed, const float* v_amax, float* o_amax_out, float* rowstat_out, void* stream);
+                           const uint64_t* step_seed, const float* v_amax, float* o_amax_out, float* rowstat_out, int64_t q_inv_rows, int64_t k_inv_rows, int64_t stat_plane,
+                           void* stream);
 /* dq, dk, dv in fp32 (strides ldd*) from d_o; o / d_o fp32; do_amax = partial maxima of |d_o|; delta (B,H,Tq) is scratch.
  * q_splits > 1 (non-causal, dk / dv the two halves of one packed (B, Tk, 2 H 64) gradient): the dK / dV kernel splits the query
  * range over q_splits workgroups per key block, partial sums in dkv_partials, one fixed-order reduction at the end. */
@@ -399,7 +405,7 @@ int ttts_attention_bwd_img(const void* q, const void* k, const void* v, const fl
                            int ldo, int lddq, int lddk, int lddv, int causal, float q_scale, float drop_p, uint64_t seed,
                            const uint64_t* step_seed, const float* do_amax, float* dq_amax_out, float* dkv_amax_out,
                            float* dkv_partials /* NULL, or q_splits x B x Tk x lddk floats */, int q_splits /* 1: no split */,
-                           void* stream);
+                           int64_t q_inv_rows, int64_t k_inv_rows, int64_t stat_plane, void* stream);
 
 /* ------------------------------------------------------------------ small row / element-wise pieces
  * nn.Embedding gather / scatter-add (model/model.py:168,288; no padding_idx) */

@@ -154,14 +154,14 @@ def _run_img(q, kv, do, lens, causal, H, p_drop=0.0, seed=0, want_attn=True):
     HK = H * B * Tk
     _lib.check(lib.ttts_attention_fwd_img(_p(qi), _off(kvi, 0), _off(kvi, d), _p(qinv), _off(kvinv, 0), _off(kvinv, HK), _p(o), _p(stat[0]),
                                           _p(attn), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d, d, causal, 0.125, p_drop, seed, None, _p(va),
-                                          _p(oslots), _p(stat[1:]), _stream()), "fwd_img")
+                                          _p(oslots), _p(stat[1:]), 0, 0, 0, _stream()), "fwd_img")
     dq, dkv = G(tuple(q.shape), float("nan")), G(tuple(kv.shape), float("nan"))
     delta = G((B, H, Tq), 0.0)
     sq, sk = G((1, ops.AMAX_SLOTS), 0.0)[0], G((1, ops.AMAX_SLOTS), 0.0)[0]
     _lib.check(lib.ttts_attention_bwd_img(_p(qi), _off(kvi, 0), _off(kvi, d), _p(qinv), _off(kvinv, 0), _off(kvinv, HK), _p(o), _p(do),
                                           _p(stat[1:]), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(kl), B, H, Tq, Tk, d, 2 * d, 2 * d,
                                           d, d, 2 * d, 2 * d, causal, 0.125, p_drop, seed, None, _p(ops._amax(do)), _p(sq), _p(sk), None, 1,
-                                          _stream()), "bwd_img")
+                                          0, 0, 0, _stream()), "bwd_img")
     out = {"o": o, "attn": attn, "lse": stat[0], "dq": dq, "dkv": dkv, "o_amax": oslots, "dq_amax": sq, "dkv_amax": sk}
     if not causal and Tq >= 64:
         # the same backward with the query range of the dK / dV kernel split over 3 workgroups per key block: partial sums + one
@@ -172,7 +172,7 @@ def _run_img(q, kv, do, lens, causal, H, p_drop=0.0, seed=0, want_attn=True):
         _lib.check(lib.ttts_attention_bwd_img(_p(qi), _off(kvi, 0), _off(kvi, d), _p(qinv), _off(kvinv, 0), _off(kvinv, HK), _p(o), _p(do),
                                               _p(stat[1:]), _p(delta), _p(dq2), _off(dkv2, 0), _off(dkv2, d), _p(kl), B, H, Tq, Tk, d, 2 * d,
                                               2 * d, d, d, 2 * d, 2 * d, causal, 0.125, p_drop, seed, None, _p(ops._amax(do)), None, _p(sk2),
-                                              _p(part), 3, _stream()), "bwd_img split")
+                                              _p(part), 3, 0, 0, 0, _stream()), "bwd_img split")
         out["dkv_split"], out["dkv_split_amax"] = dkv2, sk2
         assert torch.equal(dq2, dq)
     torch.cuda.synchronize()

@@ -490,6 +490,57 @@ def test_training_step_surface():
             assert int(buf.item()) == 2
 
 
+@pytest.mark.parametrize("B,Tp,Tm", [(4, 64, 200), (3, 37, 150)])
+def test_twin_encoder_is_the_two_encodes(B, Tp, Tm):
+    """model.encode_twin: the encoder of BOTH forwards of training_step as one pass over a batch of 2 B (the reference encodes the
+    same phonemes twice, lightning_module.py:53-59,77).  With dropout off the step must be the step of two separate encodes:
+    loss, every parameter gradient, the pre-net's BatchNorm running statistics (updated TWICE, by each forward's own batch
+    statistics -- identical here, the inputs being identical) and num_batches_tracked.  (4, 64): the halves are whole row chunks
+    of the convolution's BatchNorm partials; (3, 37): they are not, and each half takes its own statistics pass.  p_tf < 1: the
+    no-grad forward's prediction -- built on the no-grad half of the twin batch -- enters the grad forward's input."""
+    import transformertts_amd.utils.util as U
+    from oracle import model_config, fill_state, synth_batch
+    from transformertts_amd import ops
+    from transformertts_amd.lightning_module import LightningModule
+    cfg = model_config("base")
+    config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
+              "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000}}
+    batch = synth_batch(B, Tp, Tm, cfg["n_mels"], cfg["n_phon"], ragged=True, seed=31)
+    u = torch.rand(B, 1, batch["melspec"].size(1), generator=torch.Generator().manual_seed(6))
+    res = []
+    for twin in (True, False):
+        ops.TWIN_ENCODER = twin
+        try:
+            lm = LightningModule(config).to("cuda")
+            lm.model.load_state_dict(fill_state(cfg, 12), strict=True)
+            _no_dropout(lm)
+            lm.train()
+            lm.current_epoch = 120
+            assert lm.model.twin_encode_ok(batch["phoneme"].to("cuda")) == twin
+            U._uniform_draw = lambda B_, T_, device: u.to(device)
+            try:
+                loss = lm.training_step(dict(batch), 1)
+            finally:
+                U._uniform_draw = None
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((loss.item(), {n: p.grad.clone() for n, p in lm.model.named_parameters()},
+                        {n: b.clone() for n, b in lm.model.named_buffers() if "running" in n or "num_batches" in n}))
+        finally:
+            ops.TWIN_ENCODER = True
+    (l1, g1, b1), (l0, g0, b0) = res
+    assert abs(l1 - l0) < 2e-6 * abs(l0), (l1, l0)
+    for n in g0:
+        if g0[n].norm().item() < 1e-7:
+            continue
+        assert rel_l2(g1[n], g0[n]) < 2e-5, (n, rel_l2(g1[n], g0[n]))
+    for n in b0:
+        if "num_batches" in n:
+            assert int(b1[n]) == int(b0[n]) == 2, n
+        else:
+            assert rel_l2(b1[n], b0[n]) < 2e-6, (n, rel_l2(b1[n], b0[n]))
+
+
 def test_grad_sinks_match_autograd():
     """Gradients written straight into the flat data-parallel bucket (accumulate=1 sinks) are bit-identical to the
     ones autograd returns without a bucket, and survive a second accumulation step as 2x."""

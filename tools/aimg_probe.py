@@ -21,9 +21,9 @@ HM = H * B * T
 for _ in range(3):
     _lib.check(lib.ttts_attention_fwd_img(_off(img, 0), _off(img, d), _off(img, 2 * d), _off(inv, 0), _off(inv, HM), _off(inv, 2 * HM), _p(o),
                                           _p(stat[0]), None, _p(lens), B, H, T, T, 3 * d, 3 * d, 3 * d, d, 1, 0.125, 0.1, 5, None, _p(va), None,
-                                          _p(stat[1:]), _stream()), "fwd")
+                                          _p(stat[1:]), 0, 0, 0, _stream()), "fwd")
     _lib.check(lib.ttts_attention_bwd_img(_off(img, 0), _off(img, d), _off(img, 2 * d), _off(inv, 0), _off(inv, HM), _off(inv, 2 * HM), _p(o),
                                           _p(do), _p(stat[1:]), _p(delta), _off(dqkv, 0), _off(dqkv, d), _off(dqkv, 2 * d), _p(lens), B, H, T, T,
                                           3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d, 1, 0.125, 0.1, 5, None, _p(doa), None, None, None, 1,
-                                          _stream()), "bwd")
+                                          0, 0, 0, _stream()), "bwd")
 torch.cuda.synchronize()

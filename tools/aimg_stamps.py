@@ -22,7 +22,7 @@ o = torch.empty(B, T, d, device=dev); stat = torch.empty(6, B, H, T, device=dev)
 HM = H * B * T
 run = lambda: lib.ttts_attention_fwd_img(_off(img, 0), _off(img, d), _off(img, 2 * d), _off(inv, 0), _off(inv, HM), _off(inv, 2 * HM), _p(o),
                                          _p(stat[0]), None, _p(lens), B, H, T, T, 3 * d, 3 * d, 3 * d, d, 1, 0.125, p_drop, 5, None, _p(va), None,
-                                         _p(stat[1:]), _stream())
+                                         _p(stat[1:]), 0, 0, 0, _stream())
 for _ in range(5):
     assert run() == 0
 torch.cuda.synchronize()

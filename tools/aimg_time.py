@@ -52,11 +52,11 @@ for name, causal, Tq, Tk, attn_out in (("decoder self (causal)", 1, 870, 870, Fa
     HK = H * B * Tk
     fwd = lambda: _lib.check(lib.ttts_attention_fwd_img(_p(qi), _off(kvi, 0), _off(kvi, d), _p(qinv), _off(kvinv, 0), _off(kvinv, HK), _p(o),
                                                         _p(stat[0]), _p(attn), _p(lens), B, H, Tq, Tk, d, 2 * d, 2 * d, d, causal, 0.125, p_drop, 7,
-                                                        None, _p(va), None, _p(stat[1:]), _stream()), "fwd")
+                                                        None, _p(va), None, _p(stat[1:]), 0, 0, 0, _stream()), "fwd")
     bwd = lambda: _lib.check(lib.ttts_attention_bwd_img(_p(qi), _off(kvi, 0), _off(kvi, d), _p(qinv), _off(kvinv, 0), _off(kvinv, HK), _p(o),
                                                         _p(do), _p(stat[1:]), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(lens), B, H, Tq,
                                                         Tk, d, 2 * d, 2 * d, d, d, 2 * d, 2 * d, causal, 0.125, p_drop, 7, None, _p(doa), None,
-                                                        None, _p(part), nsp, _stream()), "bwd")
+                                                        None, _p(part), nsp, 0, 0, 0, _stream()), "bwd")
     tf = timed(fwd)
     tb = timed(bwd)
     print(f"{name:26s} fwd {tf:7.1f} us   bwd (dq + dkv) {tb:7.1f} us   [p_drop {p_drop}]")

@@ -36,6 +36,7 @@ SIGNATURES = {
     "ttts_linear_fwd_h3": (I, [P, P, P, P, P, L, I, I, I, F, U, P, I, I, P, P, P]),
     "ttts_conv1d_fwd_h3": (I, [P, P, P, P, I, I, I, I, I, P, P, P]),
     "ttts_conv1d_fwd_h3_bn_blocks": (I, [I, I, I, I, I]),
+    "ttts_conv1d_fwd_h3_bn_chunk_rows": (I, [I, I, I, I, I]),
     "ttts_bn_train_stats_from_partials": (I, [P, I, P, P, P, P, P, I, F, F, P]),
     "ttts_amax_partials": (I, [P, L, P, P]),
     "ttts_linear_bwd_data_h3": (I, [P, P, P, P, L, I, I, P, F, P, P, P]),
@@ -77,9 +78,9 @@ SIGNATURES = {
     "ttts_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, P]),
     "ttts_attention_bwd_x6": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, P]),
     "ttts_attention_bwd_h3": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, P, P, P, P, P, P, P, P]),
-    "ttts_attention_fwd_img": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U, P, P, P, P, P]),
+    "ttts_attention_fwd_img": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U, P, P, P, P, L, L, L, P]),
     "ttts_attention_bwd_img": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, P, P, P,
-                                   P, I, P]),
+                                   P, I, L, L, L, P]),
     "ttts_heads_pad": (I, [P, L, P, L, I, I, P]),
     "ttts_heads_unpad": (I, [P, P, L, L, I, I, P]),
     "ttts_embedding_fwd": (I, [P, P, P, L, I, I, P, P]),

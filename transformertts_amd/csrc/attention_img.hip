@@ -26,7 +26,9 @@ namespace ttts {
 struct AttnImgArgs {
     const void* q; const void* k; const void* v;          // head images, already offset to (section, head 0): 4-byte cells
     const float* q_inv; const float* k_inv; const float* v_inv;   // inverse scales of head 0 of the section: [head][rows]
-    long q_rows, k_rows;                                  // rows of the q-side / key-side tensors (B * Tq, B * Tk)
+    long q_rows, k_rows;                                  // rows per head plane of the q-side / key-side inverse scales (B * Tq, B * Tk,
+    //                                                       or more: a batch that is the first part of a larger image)
+    long stat_plane;                                      // floats per row-statistic plane (B * H * Tq, or more, likewise)
     float* o; float* lse; float* attn;
     const float* dout; float* delta; float* dq; float* dk; float* dv;
     const int64_t* key_lens;
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 3 : 2) void attn_fwd_img_kernel(Att
     if (a.lse != nullptr && half == 0 && qg < a.Tq) a.lse[arow + qg] = lse_v;
     const float lsum = WRITE_A ? l : (l + __shfl_xor(l, 32, 64));
     if (a.rowstat != nullptr && half == 0 && qg < a.Tq) {
-        const long plane = (long)a.B * a.H * a.Tq;
+        const long plane = a.stat_plane;
         const float mcs_w = WRITE_A ? mcs_fin : ((m == NEG_INF) ? -10.f : __builtin_fmaf(m, c2_q, -10.f));
         a.rowstat[arow + qg] = mcs_w;
         a.rowstat[plane + arow + qg] = lsum > 0.f ? __log2f(lsum) : 0.f;
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_img_maps_kernel(AttnImgArgs a
     const float out_scale = inv_Ev * (1.0f / H3A_P);
     if (a.lse != nullptr && half == 0 && qg < a.Tq) a.lse[arow + qg] = m_fin * c_q + __logf(l > 0.f ? l : 1.f);
     if (a.rowstat != nullptr && half == 0 && qg < a.Tq) {
-        const long plane = (long)a.B * a.H * a.Tq;
+        const long plane = a.stat_plane;
         a.rowstat[arow + qg] = mcs_fin;
         a.rowstat[plane + arow + qg] = l > 0.f ? __log2f(l) : 0.f;
         const float top = (mx == NEG_INF) ? 0.f : fast_exp2(__builtin_fmaf(mx, c2_q, -mcs_fin));
@@ -807,7 +809,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_img_kernel(AttnImgArgs a) 
     delta += __shfl_xor(delta, 32, 64);
     load_lane_frags_h3(scratch, l31, half, s_g, gf);
     // row statistics of this query, as the forward left them
-    const long plane = (long)a.B * a.H * a.Tq;
+    const long plane = a.stat_plane;
     const float m_q = a.rowstat[arow + qrow], l2_row = a.rowstat[plane + arow + qrow];
     const bool saturated = a.rowstat[2 * plane + arow + qrow] != 0.f;      // one-hot row: dS is the exact zero it is
     // ... which costs nothing per element: the row's log-sum becomes +inf, its recomputed weights exp2(-inf) = 0, and with them dS
@@ -1039,7 +1041,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_img_kernel(AttnImgArgs a)
     // raw pieces of dO; waves 0 / 1 also the row statistics.  Rows past Tq are clamped (finite data; masked below).
     const u32x4a rsQ = make_rsrc(reinterpret_cast<const char*>(a.q) + ((long)AIMG_SB(b) * a.Tq * a.ldq + AIMG_SH(h) * HD) * 4, (uint32_t)a.Tq * (uint32_t)a.ldq * 4u);
     const u32x4a rsG = make_rsrc(a.dout + (long)AIMG_SB(b) * a.Tq * a.ldo + AIMG_SH(h) * HD, (uint32_t)a.Tq * (uint32_t)a.ldo * 4u);
-    const long plane = (long)a.B * a.H * a.Tq;
+    const long plane = a.stat_plane;
     const u32x4a rsS0 = make_rsrc(a.rowstat + arow, (uint32_t)a.Tq * 4u), rsS1 = make_rsrc(a.rowstat + plane + arow, (uint32_t)a.Tq * 4u);
     const u32x4a rsS3 = make_rsrc(a.rowstat + 3 * plane + arow, (uint32_t)a.Tq * 4u), rsS4 = make_rsrc(a.rowstat + 4 * plane + arow, (uint32_t)a.Tq * 4u);
     const u32x4a rsD = make_rsrc(a.delta + arow, (uint32_t)a.Tq * 4u);
@@ -1301,13 +1303,14 @@ extern "C" int ttts_dbg_aimg_read_stamps(unsigned long long* host, size_t n) {
  * call sites as ttts_attention_fwd_h3 (torch F.scaled_dot_product_attention inside nn.MultiheadAttention,
  * torch/nn/functional.py:6576-6629, reached from model/layers.py:54-74 and torch _sa_block).  q / k / v point at head 0 of
  * their section inside the image (row strides ld* in 4-byte cells), *_inv at the [head][rows] inverse scales of that section
- * (q_rows = B * Tq, k_rows = B * Tk rows per head plane); v_amax: TTTS_AMAX_SLOTS partial maxima of |v|.  Outputs as
+ * (q_inv_rows / k_inv_rows rows per head plane: 0 = B * Tq / B * Tk, more when the batch is the first part of a larger image;
+ * stat_plane: floats per plane of rowstat_out, 0 = B * H * Tq, likewise); v_amax: TTTS_AMAX_SLOTS partial maxima of |v|.  Outputs as
  * ttts_attention_fwd_h3; rowstat_out has FIVE planes (B, H, Tq) -- the backward on images needs them all. */
 extern "C" int ttts_attention_fwd_img(const void* q, const void* k, const void* v, const float* q_inv, const float* k_inv,
                                       const float* v_inv, float* o, float* lse, float* attn, const int64_t* key_lens, int B, int H,
                                       int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int causal, float q_scale, float drop_p,
                                       uint64_t seed, const uint64_t* step_seed, const float* v_amax, float* o_amax_out,
-                                      float* rowstat_out, void* stream) {
+                                      float* rowstat_out, int64_t q_inv_rows, int64_t k_inv_rows, int64_t stat_plane, void* stream) {
     TTTS_REQUIRE(q && k && v && q_inv && k_inv && v_inv && o && key_lens && v_amax, "attention_fwd_img: null pointer");
     int rc = check_img("attention_fwd_img", B, H, Tq, Tk, ldq, ldk, ldv, ldo, drop_p);
     if (rc) return rc;
@@ -1317,7 +1320,10 @@ extern "C" int ttts_attention_fwd_img(const void* q, const void* k, const void* 
                  "attention_fwd_img: q/k/v/o/v_amax must be 16-byte aligned");
     AttnImgArgs a = {};
     a.q = q; a.k = k; a.v = v; a.q_inv = q_inv; a.k_inv = k_inv; a.v_inv = v_inv;
-    a.q_rows = (long)B * Tq; a.k_rows = (long)B * Tk;
+    TTTS_REQUIRE((q_inv_rows == 0 || q_inv_rows >= (int64_t)B * Tq) && (k_inv_rows == 0 || k_inv_rows >= (int64_t)B * Tk) &&
+                 (stat_plane == 0 || stat_plane >= (int64_t)B * H * Tq), "attention_fwd_img: plane strides smaller than the batch");
+    a.q_rows = q_inv_rows ? q_inv_rows : (long)B * Tq; a.k_rows = k_inv_rows ? k_inv_rows : (long)B * Tk;
+    a.stat_plane = stat_plane ? stat_plane : (long)B * H * Tq;
     a.o = o; a.lse = lse; a.attn = attn; a.key_lens = key_lens;
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
@@ -1353,7 +1359,8 @@ extern "C" int ttts_attention_bwd_img(const void* q, const void* k, const void* 
                                       float* dq, float* dk, float* dv, const int64_t* key_lens, int B, int H, int Tq, int Tk, int ldq,
                                       int ldk, int ldv, int ldo, int lddq, int lddk, int lddv, int causal, float q_scale,
                                       float drop_p, uint64_t seed, const uint64_t* step_seed, const float* do_amax,
-                                      float* dq_amax_out, float* dkv_amax_out, float* dkv_partials, int q_splits, void* stream_) {
+                                      float* dq_amax_out, float* dkv_amax_out, float* dkv_partials, int q_splits,
+                                      int64_t q_inv_rows, int64_t k_inv_rows, int64_t stat_plane, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TTTS_REQUIRE(q && k && v && q_inv && k_inv && v_inv && o && d_o && rowstat && delta && dq && dk && dv && key_lens && do_amax,
                  "attention_bwd_img: null pointer");
@@ -1366,7 +1373,10 @@ extern "C" int ttts_attention_bwd_img(const void* q, const void* k, const void* 
     TTTS_REQUIRE((uint64_t)Tq * ldo * 4 < (1ull << 32), "attention_bwd_img: one utterance's d_o exceeds 4 GiB");
     AttnImgArgs a = {};
     a.q = q; a.k = k; a.v = v; a.q_inv = q_inv; a.k_inv = k_inv; a.v_inv = v_inv;
-    a.q_rows = (long)B * Tq; a.k_rows = (long)B * Tk;
+    TTTS_REQUIRE((q_inv_rows == 0 || q_inv_rows >= (int64_t)B * Tq) && (k_inv_rows == 0 || k_inv_rows >= (int64_t)B * Tk) &&
+                 (stat_plane == 0 || stat_plane >= (int64_t)B * H * Tq), "attention_bwd_img: plane strides smaller than the batch");
+    a.q_rows = q_inv_rows ? q_inv_rows : (long)B * Tq; a.k_rows = k_inv_rows ? k_inv_rows : (long)B * Tk;
+    a.stat_plane = stat_plane ? stat_plane : (long)B * H * Tq;
     a.o = const_cast<float*>(o); a.dout = d_o; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv; a.key_lens = key_lens;
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;

@@ -1476,6 +1476,13 @@ int ttts_conv1d_fwd_h3_bn_blocks(int B, int T, int cin, int cout, int taps) {
     return h3_bn_blocks((long)B * T, cout, (long)taps * h3_pad32(cin));
 }
 
+int ttts_conv1d_fwd_h3_bn_chunk_rows(int B, int T, int cin, int cout, int taps) {
+    // rows of (b, t) one partial covers (0: no partials for this shape): partial i holds rows i * chunk .. of the B T rows, so a
+    // caller may finish the statistics of a row range that is a whole number of chunks on its own (the two forwards of a
+    // training step run as one batch: ops.ConvBNFn, twin batches)
+    return h3_bn_blocks((long)B * T, cout, (long)taps * h3_pad32(cin)) > 0 ? h3_bn_chunk_rows((long)B * T, cout, (long)taps * h3_pad32(cin)) : 0;
+}
+
 int ttts_conv1d_fwd_h3(const float* x, const void* planes_fwd, const float* bias, float* y, int B, int T, int cin, int cout,
                        int taps, const float* x_amax, float* bn_partials, void* stream) {
     TTTS_REQUIRE(x && planes_fwd && y && x_amax, "conv1d_fwd_h3: null pointer (x_amax, the partial maxima of |x|, is required)");

@@ -322,6 +322,7 @@ void launch_weight_split_h3(const float* w, void* planes, int rows, int cols, in
 int dispatch_h3(const GemmArgs& g, hipStream_t stream);
 // row-chunk partials the fp16x3 forward writes into GemmArgs::bn_ws for an M x N x K problem (0: its tile shape cannot)
 int h3_bn_blocks(long M, long N, long K);
+int h3_bn_chunk_rows(long M, long N, long K);
 int dispatch_wgrad_h3(const GemmArgs& g, int zdim, int tile, hipStream_t stream);
 // XCD-aware numbering of the weight-gradient grids: workgroups are dealt round-robin to the 8 XCDs in x-fastest order, so the
 // tiles of one row split -- which read the same rows of dy and x -- would land on different L2s and each fetch its

@@ -982,6 +982,15 @@ static bool h3_tile_geometry(int tile, int& bm, int& wm) {
     }
 }
 
+// rows of the matrix one BatchNorm partial (row chunk) covers on the tile h3_bn_blocks assumes: tile rows / waves along the rows
+int h3_bn_chunk_rows(long M, long N, long K) {
+    int bm, wm;
+    const int tile = h3_tile_choice(M, N, K);
+    if (!h3_tile_geometry(tile, bm, wm)) return 0;
+    if (tile == H3_TILE_256 && TTTS_H3_WIDE_CLIP && K >= 3 * HBK && h3_wide_rows(M, N) == 224) return 224;
+    return bm / wm;
+}
+
 int h3_bn_blocks(long M, long N, long K) {
     int bm, wm;
     const int tile = h3_tile_choice(M, N, K);

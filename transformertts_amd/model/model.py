@@ -179,12 +179,45 @@ class TransformerTTS(nn.Module):
         x = self.pe(self.enc_prenet(x))
         return self.encoder(x, src_lens=phoneme_lens)
 
+    def twin_encode_ok(self, phoneme: Tensor) -> bool:
+        """can `encode_twin` serve this model?  (64-column heads: the encoder's attention then runs on head images, the only form
+        the twin batch takes; fp16x3 forms selected; training mode -- in eval mode there is one forward)"""
+        d = self.emb.weight.shape[1]
+        layers = list(self.encoder.layers)
+        return (ops.TWIN_ENCODER and self.training and phoneme.is_cuda and len(layers) > 0 and self.encoder.norm is None and
+                all(l.self_attn.embed_dim == d and d == l.self_attn.num_heads * 64 and not l.norm_first for l in layers) and
+                ops.HEAD_IMAGES and ops.ATTN_FWD_MODE == "h3" and ops.ATTN_BWD_MODE == "h3" and ops._fwd_h3(d, 3 * d) and
+                2 * phoneme.numel() * 3 * d * 4 < (1 << 31))
+
+    def encode_twin(self, phoneme: Tensor, phoneme_lens: Tensor):
+        """-> (memory of a forward WITH grad, memory of a forward without) from ONE pass over a batch of 2 B.  The reference's
+        training_step encodes the same phonemes twice -- under no_grad for the scheduled-sampling prediction and with grad
+        (lightning_module.py:53-59,77) --, each time with fresh dropout masks and with the pre-net's BatchNorm in training
+        mode.  The encoder is row-parallel, so both encodes run as one batch: the grad forward's utterances first, the no-grad
+        forward's behind them (`ops._twin`); autograd sees the first half only, BatchNorm statistics (and their two updates of
+        the running statistics, no-grad forward first) stay per forward, dropout masks are independent (one stream over 2 B
+        utterances).  Half the launches and twice the rows per launch for the whole encoder side of the step."""
+        B = phoneme.size(0)
+        ids_g, _ = ops.twin_pair(torch.cat([phoneme, phoneme], dim=0))
+        lens_g, _ = ops.twin_pair(torch.cat([phoneme_lens, phoneme_lens], dim=0).to(torch.int64))
+        mem = self.encode(ids_g, lens_g)
+        full = ops._twin(mem)
+        if full is None:
+            raise RuntimeError("encode_twin: the encoder dropped the twin batch")
+        mem_ng = full[B:].detach()
+        am = getattr(mem, "_ttts_amax", None)
+        if am is not None:
+            mem_ng._ttts_amax = am           # (published over the whole buffer: a bound for either half)
+        return mem, mem_ng
+
     def forward(self, phoneme: Tensor, melspec: Tensor, phoneme_lens: Tensor, melspec_lens: Tensor,
-                need_alignments: bool = True, need_stop: bool = True) -> dict:
+                need_alignments: bool = True, need_stop: bool = True, memory: Tensor = None) -> dict:
         """
         `need_alignments=False` (an extension; the reference always returns them) skips writing the per-head
         cross-attention maps -- 267 MB per forward at batch 64 -- for callers that only want the mels, e.g. the
         no-grad first forward of `training_step`.  `alignments` is then a list of None.
+        `memory` (an extension): the encoder output of `phoneme`, when the caller has it already (`encode_twin`: the two forwards
+        of a training step encoded as one batch); None: encoded here.
         `need_stop=False` (no-grad only; same caller): `pred_stop` is None -- the stop head is stateless and its logits have no
         reader there (reference lightning_module.py:53-59 keeps `pred_melspec` alone).  The post-net still runs: its BatchNorm
         running statistics are updated by that forward too.
@@ -201,7 +234,10 @@ class TransformerTTS(nn.Module):
             raise ValueError("TransformerTTS.forward: lengths must live on the same device as the batch")
         phoneme_lens = phoneme_lens.to(torch.int64)
         melspec_lens = melspec_lens.to(torch.int64)
-        memory = self.encode(phoneme, phoneme_lens)
+        if memory is None:
+            memory = self.encode(phoneme, phoneme_lens)
+        elif memory.dim() != 3 or memory.size(0) != phoneme.size(0) or memory.size(1) != phoneme.size(1):
+            raise ValueError("TransformerTTS.forward: `memory` must be the encoder output of these phonemes")
         tgt = self.pe(self.dec_prenet(melspec, shift_right=True))
         tgt_out, alignments = self.decoder(tgt, memory, tgt_is_causal=True, memory_is_causal=False,
                                            tgt_lens=melspec_lens, memory_lens=phoneme_lens,

@@ -44,6 +44,33 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ---- twin batches.  The two forwards of a training step encode the SAME phonemes (reference
+# lightning_module.py:53-59 under no_grad, :77 with grad); the encoder is row-parallel, so both run as ONE batch of 2 B: the
+# GRAD forward's utterances first, the no-grad forward's behind them.  Autograd only ever sees the first half -- a tensor `t`
+# of B utterances that is the leading part of a (2 B, ...) buffer, `t._ttts_twin` -- and every forward kernel is launched on
+# the buffer (same pointer, twice the rows); the backward kernels run on the halves they saved, unchanged, and regenerate the
+# same dropout masks because the grad half's element indices start at zero.  BatchNorm statistics stay per forward.
+TWIN_ENCODER = True
+
+
+def _twin(t):
+    """the (2 B, ...) buffer whose first half `t` is, or None"""
+    f = getattr(t, "_ttts_twin", None) if t is not None else None
+    if f is None:
+        return None
+    if f.data_ptr() != t.data_ptr() or f.shape[0] != 2 * t.shape[0] or f.shape[1:] != t.shape[1:] or not f.is_contiguous():
+        raise RuntimeError("twin batch: the tensor no longer is the first half of its buffer")
+    return f
+
+
+def twin_pair(full: torch.Tensor):
+    """(grad half, no-grad half) of a (2 B, ...) buffer; the grad half carries the buffer (`_ttts_twin`)"""
+    B = full.shape[0] // 2
+    a = full[:B]
+    a._ttts_twin = full
+    return a, full[B:]
+
+
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty((max(int(nbytes), 16) + 3) // 4, dtype=torch.float32, device=device)
 
@@ -823,7 +850,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out=None, tok_in=None, skip_in=None,
-                skip_out=None, tok_drop=None, x_amax=None, y_amax=None, x_image=None, y_himg=None):
+                skip_out=None, tok_drop=None, x_amax=None, y_amax=None, x_image=None, y_himg=None, twin=None):
         """x_amax: partial maxima of |x| (fp16x3 forms; None: measured here); y_amax: None, or a zeroed AMAX_SLOTS-slot array
         that receives max|y| (the wrapper attaches it to y for the next fp16x3 consumer); x_image: None, or (image, row_inv) of
         x left by its producer -- the GEMM then takes the image-operand kernel (ttts_linear_fwd_h3i)."""
@@ -836,9 +863,19 @@ class LinearFn(torch.autograd.Function):
         if act == ACT_RELU and residual is not None:
             raise ValueError("linear: relu epilogue cannot be combined with a residual")
         M = x.numel() // K
-        y = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
         b_ = _chk(b, "linear.bias") if b is not None else None
         r_ = _chk(residual, "linear.residual") if residual is not None else None
+        if twin is not None:
+            # x (and the residual) are the first halves of 2 B-utterance buffers: the kernel runs on the buffers -- same pointers,
+            # twice the rows --, autograd gets the first half of the output (`twin`: [x buffer, residual buffer or None, out list])
+            if x_image is not None or row_shift != 0:
+                raise ValueError("linear: a twin batch takes plain fp32 operands without a row shift")
+            M = 2 * M
+            y_full = torch.empty(2 * x.shape[0], *x.shape[1:-1], N, dtype=torch.float32, device=x.device)
+            y = y_full[:x.shape[0]]
+            twin[2].append(y_full)
+        else:
+            y = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
         if r_ is not None and r_.shape != y.shape:
             raise ValueError("linear: residual shape mismatch")
         if y_himg is not None:
@@ -987,7 +1024,7 @@ class LinearFn(torch.autograd.Function):
         dres = dy if has_r else None
         if has_r and skip_out is not None:      # hand the skip gradient to the block's first Linear instead of autograd
             skip_out.grad, dres = dy, None
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 # Test seam: called with the output of every relu-epilogue Linear, in call order (which units the HIP path gated off).
@@ -1092,7 +1129,15 @@ def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_sh
     grad_on = torch.is_grad_enabled()
     N, K = w.shape
     h3 = x.is_cuda and _fwd_h3(K, N)
-    x_am = _amax(x) if h3 else None
+    x_full = _twin(x)
+    twin = None
+    if x_full is not None:
+        r_full = _twin(residual)
+        if residual is not None and r_full is None:
+            raise ValueError("linear: the residual of a twin batch must be a twin batch too")
+        twin = [x_full, r_full, []]
+    # (a twin batch's maxima cover BOTH halves: its producer published them over the whole buffer)
+    x_am = (_amax(x) if getattr(x, "_ttts_amax", None) is not None or x_full is None else _amax(x_full)) if h3 else None
     y_am = None
     if h3 and publish_amax is not False and publish_amax is not None:
         y_am = publish_amax if isinstance(publish_amax, torch.Tensor) else _amax_slots(x.device, True)
@@ -1113,14 +1158,18 @@ def linear(x, w, b=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, row_sh
         # (rows of inverse scales [N / 64][M], one partial-maxima array per section, columns per section)
         if residual is not None or act != ACT_NONE or float(drop_p) > 0.0 or row_shift != 0 or N % (64 * head_image_sections) != 0:
             raise ValueError("linear: a head-image output takes a bias-only epilogue and whole 64-column heads per section")
-        M = x.numel() // K
+        M = x.numel() // K * (2 if twin is not None else 1)
         sec = _amax_slots_n(x.device, head_image_sections)
         inv = _guarded(N // 64, M, x.device, "head-image inverse scales") if GUARD else \
             torch.empty(N // 64, M, dtype=torch.float32, device=x.device)
         y_himg = (inv, sec, N // head_image_sections)
         y_am = None
+    if twin is not None:
+        x_img = None
     y = LinearFn.apply(x, w, b, residual, act, drop_p, seed, row_shift, T, tok_out, tok_in, skip_in, skip_out, tok_drop,
-                       x_am, y_am, x_img, y_himg)
+                       x_am, y_am, x_img, y_himg, twin)
+    if twin is not None:
+        y._ttts_twin = twin[2][0]
     if y_himg is not None:
         return HeadImage(y, y_himg[0], y_himg[1], y_himg[2])
     if y_am is not None:
@@ -1454,7 +1503,7 @@ class ConvBNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act,
-                drop_p, seed, x_amax=None, z_amax=None):
+                drop_p, seed, x_amax=None, z_amax=None, twin=None):
         lib = _lib.load()
         x = _chk(x, "conv_bn.x")
         B, T, cin = x.shape
@@ -1463,6 +1512,9 @@ class ConvBNFn(torch.autograd.Function):
             raise ValueError(f"conv_bn: x has {cin} channels, weight expects {cin_w}")
         dev = x.device
         conv_w = _chk(conv_w, "conv.weight")
+        if twin is not None:
+            return ConvBNFn._forward_twin(ctx, lib, x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum,
+                                          eps, act, drop_p, seed, x_amax, z_amax, twin)
         y = torch.empty(B, T, cout, dtype=torch.float32, device=dev)
         M = B * T
         bn_nblk, bn_ws = 0, None
@@ -1508,6 +1560,61 @@ class ConvBNFn(torch.autograd.Function):
         ctx.ss = _ss()
         ctx.sinks = _sinks(conv_w, conv_b, gamma, beta)
         return z
+
+    @staticmethod
+    def _forward_twin(ctx, lib, x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act, drop_p,
+                      seed, x_amax, z_amax, twin):
+        """x is the first half of a twin batch (`_twin`): ONE convolution over all 2 B utterances; BatchNorm stays per forward --
+        statistics of each half from its own row chunks of the epilogue's partials (or its own pass), the no-grad forward's
+        first (its update of the running statistics precedes the grad forward's, as the reference's two forwards order them),
+        normalisation + activation + dropout per half with a mask stream of its own."""
+        B, T, cin = x.shape
+        cout, _, taps = conv_w.shape
+        dev = x.device
+        if not _fwd_h3(taps * cin, cout, cin):
+            raise ValueError("conv_bn: a twin batch runs on the fp16x3 form only")
+        Bk, M = 2 * B, B * T
+        y_k = torch.empty(Bk, T, cout, dtype=torch.float32, device=dev)
+        z_k = torch.empty(Bk, T, cout, dtype=torch.float32, device=dev)
+        if x_amax is None:
+            x_amax = _amax(twin[0])
+        bn_ws, per_half = None, 0
+        if training and M > 1:
+            nblk = lib.ttts_conv1d_fwd_h3_bn_blocks(Bk, T, cin, cout, taps)
+            chunk = lib.ttts_conv1d_fwd_h3_bn_chunk_rows(Bk, T, cin, cout, taps)
+            if nblk > 0 and chunk > 0 and M % chunk == 0 and nblk == 2 * (M // chunk):
+                bn_ws, per_half = _ws(lib.ttts_bn_workspace_bytes(2 * M, cout), dev), M // chunk
+        _lib.check(lib.ttts_conv1d_fwd_h3(_p(x), _p(_planes(conv_w, 6, cout, taps * cin, cin, taps)), _p(conv_b), _p(y_k),
+                                          Bk, T, cin, cout, taps, _p(x_amax), _p(bn_ws), _stream()), "ttts_conv1d_fwd_h3")
+        stats = {}
+        for h in (1, 0):                      # the no-grad forward's half first
+            y_h, z_h = y_k[h * B:(h + 1) * B], z_k[h * B:(h + 1) * B]
+            mean = torch.empty(cout, dtype=torch.float32, device=dev)
+            invstd = torch.empty(cout, dtype=torch.float32, device=dev)
+            if training and bn_ws is not None:
+                _lib.check(lib.ttts_bn_train_stats_from_partials(_off(bn_ws, h * per_half * 3 * cout), per_half, _p(mean), _p(invstd),
+                                                                 _p(running_mean), _p(running_var), _p(nbt), cout, float(momentum),
+                                                                 float(eps), _stream()), "ttts_bn_train_stats_from_partials")
+            elif training:
+                ws = _ws(lib.ttts_bn_workspace_bytes(M, cout), dev)
+                _lib.check(lib.ttts_bn_train_stats(_p(y_h), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(nbt),
+                                                   _p(ws), ws.numel() * 4, M, cout, float(momentum), float(eps), _stream()),
+                           "ttts_bn_train_stats")
+            else:
+                _lib.check(lib.ttts_bn_eval_stats(_p(running_mean), _p(running_var), _p(mean), _p(invstd), cout, float(eps),
+                                                  _stream()), "ttts_bn_eval_stats")
+            # (each half is a launch of its own whose element indices start at zero: the no-grad half draws from another seed)
+            seed_h = seed if (h == 0 or seed == 0) else ((seed * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF)
+            _lib.check(lib.ttts_bn_apply_fwd(_p(y_h), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(z_h), M, cout, act,
+                                             float(drop_p), seed_h, _ss(), _p(z_amax), _stream()), "ttts_bn_apply_fwd")
+            stats[h] = (mean, invstd)
+        twin[1].append(z_k)
+        ctx.save_for_backward(x, conv_w, y_k[:B], stats[0][0], stats[0][1], gamma, beta)
+        ctx.x_amax = x_amax
+        ctx.cfg = (training, act, float(drop_p), seed, conv_b is not None)
+        ctx.ss = _ss()
+        ctx.sinks = _sinks(conv_w, conv_b, gamma, beta)
+        return z_k[:B]
 
     @staticmethod
     def backward(ctx, dz):
@@ -1562,17 +1669,23 @@ class ConvBNFn(torch.autograd.Function):
             _lib.check(_wgrad(lib, "ttts_conv1d_bwd_weight", dy, am, x, ctx.x_amax, _wgrad_is_split(cout, cin),
                               _qarg(queue, ws2) if sk is not None else None, _p(t_w), _p(t_b), _p(ws2), ws2.numel() * 4, B, T, cin,
                               cout, taps, acc), "ttts_conv1d_bwd_weight")
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn(x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum=0.1, eps=1e-5,
             act=ACT_NONE, drop_p=0.0, seed=0, publish_amax=True):
     """`publish_amax`: leave the partial maxima of the output on it (`z._ttts_amax`) for the fp16x3 GEMM that reads it."""
     cout, cin, taps = conv_w.shape
-    x_am = _amax(x) if (x.is_cuda and _fwd_h3(taps * cin, cout, cin)) else None
+    x_full = _twin(x)
+    twin = [x_full, []] if x_full is not None else None
+    x_am = None
+    if x.is_cuda and _fwd_h3(taps * cin, cout, cin):
+        x_am = _amax(x) if (getattr(x, "_ttts_amax", None) is not None or x_full is None) else _amax(x_full)
     z_am = _amax_slots(x.device, True) if (publish_amax and x.is_cuda) else None
     z = ConvBNFn.apply(x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act,
-                       drop_p, seed, x_am, z_am)
+                       drop_p, seed, x_am, z_am, twin)
+    if twin is not None:
+        z._ttts_twin = twin[1][0]
     if z_am is not None:
         z._ttts_amax = z_am
     return z
@@ -1581,7 +1694,7 @@ def conv_bn(x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, trai
 # ----------------------------------------------------------------------------------------------- layer norm
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, tok_drop=None, y_amax=None, y_image=None, bwd_image=False):
+    def forward(ctx, x, gamma, beta, eps, tok_drop=None, y_amax=None, y_image=None, bwd_image=False, twin=None):
         """y_image: None, or (image, row_inv) buffers the kernel fills with the image operand of y; bwd_image: the backward leaves
         the image of the gradient it hands to the Linear that produced x (on the drop token, or on dx)."""
         lib = _lib.load()
@@ -1590,12 +1703,17 @@ class LayerNormFn(torch.autograd.Function):
         x = _chk(x, "layernorm.x")
         d = x.shape[-1]
         M = x.numel() // d
-        y = torch.empty_like(x)
-        mean = torch.empty(M, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-        yi, yv = y_image if y_image is not None else (None, None)
-        _lib.check(lib.ttts_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, d, float(eps),
+        Mk = 2 * M if twin is not None else M              # (twin batch, see `_twin`: the kernel normalises both halves)
+        y_k = torch.empty(2 * x.shape[0], *x.shape[1:], dtype=torch.float32, device=x.device) if twin is not None else torch.empty_like(x)
+        mean = torch.empty(Mk, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(Mk, dtype=torch.float32, device=x.device)
+        yi, yv = y_image if (y_image is not None and twin is None) else (None, None)
+        _lib.check(lib.ttts_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y_k), _p(mean), _p(rstd), Mk, d, float(eps),
                                           _p(y_amax), _p(yi), _p(yv), _stream()), "ttts_layernorm_fwd")
+        y = y_k
+        if twin is not None:
+            twin[1].append(y_k)
+            y, mean, rstd = y_k[:x.shape[0]], mean[:M], rstd[:M]
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.sinks = _sinks(gamma, beta)
         return y
@@ -1634,7 +1752,7 @@ class LayerNormFn(torch.autograd.Function):
                        "ttts_layernorm_bwd")
             if img[0] is not None:
                 dx._ttts_image = img
-        return dx, dgamma, dbeta, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, sole_consumer=False, publish_amax=True, emit_image=None):
@@ -1649,8 +1767,12 @@ def layer_norm(x, gamma, beta, eps=1e-5, sole_consumer=False, publish_amax=True,
     # else reads -- of the gradient that Linear's backward consumes
     if emit_image is None:
         emit_image = LAYERNORM_IMAGES
-    y_img = _new_image(M, d, x.device) if (emit_image and x.is_cuda and _image_rows_ok(M, d)) else None
-    y = LayerNormFn.apply(x, gamma, beta, eps, tok, y_am, y_img, bool(emit_image and sole_consumer))
+    x_full = _twin(x)
+    twin = [x_full, []] if x_full is not None else None
+    y_img = _new_image(M, d, x.device) if (emit_image and x.is_cuda and _image_rows_ok(M, d) and twin is None) else None
+    y = LayerNormFn.apply(x, gamma, beta, eps, tok, y_am, y_img, bool(emit_image and sole_consumer and twin is None), twin)
+    if twin is not None:
+        y._ttts_twin = twin[1][0]
     if y_am is not None:
         y._ttts_amax = y_am
     if y_img is not None:
@@ -1762,24 +1884,33 @@ def _unpad_heads(src: torch.Tensor, dst: torch.Tensor, col0: int, ld: int, rows:
 
 class SelfAttentionImgFn(torch.autograd.Function):
     """o = softmax(mask(q k^T / 8)) v on a packed in-projection output that arrived as a HEAD IMAGE (`linear(...,
-    head_image_sections=3)`): K / V tiles are staged by LDS-DMA, no split arithmetic (csrc/attention_img.hip)."""
+    head_image_sections=3)`): K / V tiles are staged by LDS-DMA, no split arithmetic (csrc/attention_img.hip).
+    `twin` = [image buffer, lengths buffer, out list]: qkv / lens are the first halves of a twin batch (see `_twin`): the forward
+    runs on all 2 B utterances, the backward on the first B (the inverse scales' head planes and the row statistics' planes keep the
+    buffer's strides: q_inv_rows / k_inv_rows / stat_plane of the C ABI)."""
 
     @staticmethod
-    def forward(ctx, qkv, row_inv, sec_amax, lens, n_head, causal, drop_p, seed, o_amax=None):
+    def forward(ctx, qkv, row_inv, sec_amax, lens, n_head, causal, drop_p, seed, o_amax=None, twin=None):
         lib = _lib.load()
         qkv = _chk(qkv, "self_attention.qkv")
         lens = _chk(lens, "self_attention.lens", torch.int64)
         B, T, d3 = qkv.shape
-        d, M = d3 // 3, B * T
-        o = torch.empty(B, T, d, dtype=torch.float32, device=qkv.device)
-        stat = torch.empty(6, B, n_head, T, dtype=torch.float32, device=qkv.device)     # lse, then the five row-statistic planes
+        Bk = 2 * B if twin is not None else B             # utterances the kernel sees
+        d, M = d3 // 3, Bk * T
+        if row_inv.shape[1] != M or (twin is not None and (twin[1] is None or twin[1].shape[0] != Bk)):
+            raise ValueError("self_attention: inverse scales / lengths do not match the image")
+        o_k = torch.empty(Bk, T, d, dtype=torch.float32, device=qkv.device)
+        stat = torch.empty(6, Bk, n_head, T, dtype=torch.float32, device=qkv.device)     # lse, then the five row-statistic planes
         HM = n_head * M
         _lib.check(lib.ttts_attention_fwd_img(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _off(row_inv, 0), _off(row_inv, HM),
-                                              _off(row_inv, 2 * HM), _p(o), _p(stat[0]), None, _p(lens), B, n_head, T, T, d3, d3, d3, d,
+                                              _off(row_inv, 2 * HM), _p(o_k), _p(stat[0]), None, _p(lens), Bk, n_head, T, T, d3, d3, d3, d,
                                               1 if causal else 0, 0.125, float(drop_p), seed, _ss(), _p(sec_amax[2]), _p(o_amax),
-                                              _p(stat[1:]), _stream()), "ttts_attention_fwd_img")
+                                              _p(stat[1:]), 0, 0, 0, _stream()), "ttts_attention_fwd_img")
+        o = o_k[:B] if twin is not None else o_k
+        if twin is not None:
+            twin[2].append(o_k)
         ctx.save_for_backward(qkv, row_inv, o, stat, lens)
-        ctx.cfg = (n_head, causal, float(drop_p), seed)
+        ctx.cfg = (n_head, causal, float(drop_p), seed, Bk)
         ctx.ss = _ss()
         return o
 
@@ -1787,10 +1918,10 @@ class SelfAttentionImgFn(torch.autograd.Function):
     def backward(ctx, do):
         lib = _lib.load()
         qkv, row_inv, o, stat, lens = ctx.saved_tensors
-        n_head, causal, drop_p, seed = ctx.cfg
+        n_head, causal, drop_p, seed, Bk = ctx.cfg
         B, T, d3 = qkv.shape
-        d, M = d3 // 3, B * T
-        HM = n_head * M
+        d, Mk = d3 // 3, Bk * T
+        HM = n_head * Mk
         do = _chk(do, "self_attention.do")
         dqkv = torch.empty_like(qkv)
         delta = torch.empty(B, n_head, T, dtype=torch.float32, device=qkv.device)
@@ -1798,10 +1929,10 @@ class SelfAttentionImgFn(torch.autograd.Function):
         _lib.check(lib.ttts_attention_bwd_img(_off(qkv, 0), _off(qkv, d), _off(qkv, 2 * d), _off(row_inv, 0), _off(row_inv, HM),
                                               _off(row_inv, 2 * HM), _p(o), _p(do), _p(stat[1:]), _p(delta), _off(dqkv, 0), _off(dqkv, d),
                                               _off(dqkv, 2 * d), _p(lens), B, n_head, T, T, d3, d3, d3, d, d3, d3, d3, 1 if causal else 0,
-                                              0.125, drop_p, seed, ctx.ss, _p(_amax(do)), _p(am), _p(am), None, 1, _stream()),
-                   "ttts_attention_bwd_img")
+                                              0.125, drop_p, seed, ctx.ss, _p(_amax(do)), _p(am), _p(am), None, 1,
+                                              Mk, Mk, Bk * n_head * T, _stream()), "ttts_attention_bwd_img")
         dqkv._ttts_amax = am
-        return dqkv, None, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None, None
 
 
 def _dkv_query_splits(key_blocks: int, Tq: int) -> int:
@@ -1861,7 +1992,7 @@ class CrossAttentionImgFn(torch.autograd.Function):
         lens = _chk(lens, "cross_attention.lens", torch.int64)
         B, Tq, d = q.shape
         Tk = kv.shape[1]
-        if kv.shape[2] != 2 * d or qh.row_inv.shape[1] != B * Tq or kvh.row_inv.shape[1] != B * Tk:
+        if kv.shape[2] != 2 * d or qh.row_inv.shape[1] < B * Tq or kvh.row_inv.shape[1] < B * Tk:
             raise ValueError("cross_attention: q / kv head images do not match")
         ldq, ldk = q.stride(1), kv.stride(1)
         o = torch.empty(B, Tq, d, dtype=torch.float32, device=q.device)
@@ -1869,7 +2000,8 @@ class CrossAttentionImgFn(torch.autograd.Function):
         attn = torch.empty(B, n_head, Tq, Tk, dtype=torch.float32, device=q.device) if need_weights else None
         _lib.check(lib.ttts_attention_fwd_img(_p(q), _off(kv, 0), _off(kv, d), qh.inv_of(0), kvh.inv_of(0), kvh.inv_of(d), _p(o),
                                               _p(stat[0]), _p(attn), _p(lens), B, n_head, Tq, Tk, ldq, ldk, ldk, d, 0, 0.125,
-                                              float(drop_p), seed, _ss(), _p(kvh.amax_of(d)), _p(o_amax), _p(stat[1:]), _stream()),
+                                              float(drop_p), seed, _ss(), _p(kvh.amax_of(d)), _p(o_amax), _p(stat[1:]),
+                                              qh.row_inv.shape[1], kvh.row_inv.shape[1], 0, _stream()),
                    "ttts_attention_fwd_img")
         ctx.save_for_backward(q, kv, o, stat, lens)
         ctx.himg = (qh, kvh)
@@ -1909,7 +2041,8 @@ class CrossAttentionImgFn(torch.autograd.Function):
         _lib.check(lib.ttts_attention_bwd_img(_p(q), _off(kv, 0), _off(kv, d), qh.inv_of(0), kvh.inv_of(0), kvh.inv_of(d), _p(o), _p(do),
                                               _p(stat[1:]), _p(delta), _p(dq), _off(dkv, 0), _off(dkv, d), _p(lens), B, n_head, Tq, Tk,
                                               ldq, ldk, ldk, d, d, ldg, ldg, 0, 0.125, drop_p, seed, ctx.ss, _p(_amax(do)),
-                                              _p(am_q), _p(am_kv), _p(part), nsp, _stream()), "ttts_attention_bwd_img")
+                                              _p(am_q), _p(am_kv), _p(part), nsp, qh.row_inv.shape[1], kvh.row_inv.shape[1], 0,
+                                              _stream()), "ttts_attention_bwd_img")
         dq._ttts_amax = am_q
         if slab is None:
             dkv._ttts_amax = am_kv
@@ -2069,9 +2202,15 @@ def self_attention(qkv, lens, n_head: int, causal: bool, drop_p: float, seed: in
         return _attention_wide_heads(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], lens, n_head, causal, drop_p)[0]
     if isinstance(qkv, HeadImage):             # the in-projection left a head image: the LDS-DMA kernels
         o_am = _amax_slots(qkv.device, True)
-        o = SelfAttentionImgFn.apply(qkv.cells, qkv.row_inv, qkv.sec_amax, lens, n_head, causal, drop_p, seed, o_am)
+        q_full = _twin(qkv.cells)
+        twin = [q_full, _twin(lens), []] if q_full is not None else None
+        o = SelfAttentionImgFn.apply(qkv.cells, qkv.row_inv, qkv.sec_amax, lens, n_head, causal, drop_p, seed, o_am, twin)
+        if twin is not None:
+            o._ttts_twin = twin[2][0]
         o._ttts_amax = o_am
         return o
+    if _twin(qkv) is not None:
+        raise ValueError("self_attention: a twin batch runs on head images only")
     h3 = qkv.is_cuda and _attn_h3()
     am = _amax(qkv) if h3 else None
     o_am = _amax_slots(qkv.device, True) if (qkv.is_cuda and ATTN_FWD_MODE == "h3") else None
@@ -2108,14 +2247,18 @@ def cross_attention(q, kv, lens, n_head: int, drop_p: float, seed: int, need_wei
 # ----------------------------------------------------------------------------------------------- small pieces
 class EmbeddingFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, table, out_amax=None):
+    def forward(ctx, ids, table, out_amax=None, twin=None):
         lib = _lib.load()
         ids = _chk(ids, "embedding.ids", torch.int64)
         table = _chk(table, "embedding.weight")
         vocab, d = table.shape
-        out = torch.empty(*ids.shape, d, dtype=torch.float32, device=table.device)
-        _lib.check(lib.ttts_embedding_fwd(_p(ids), _p(table), _p(out), ids.numel(), vocab, d, _p(out_amax), _stream()),
+        k = 2 if twin is not None else 1                   # (twin batch, see `_twin`)
+        out_k = torch.empty(k * ids.shape[0], *ids.shape[1:], d, dtype=torch.float32, device=table.device)
+        _lib.check(lib.ttts_embedding_fwd(_p(ids), _p(table), _p(out_k), k * ids.numel(), vocab, d, _p(out_amax), _stream()),
                    "ttts_embedding_fwd")
+        out = out_k[:ids.shape[0]] if twin is not None else out_k
+        if twin is not None:
+            twin[1].append(out_k)
         ctx.save_for_backward(ids)
         ctx.shape = (vocab, d)
         ctx.sinks = _sinks(table)
@@ -2135,12 +2278,16 @@ class EmbeddingFn(torch.autograd.Function):
             t = dtable = torch.empty(vocab, d, dtype=torch.float32, device=dout.device)
         _lib.check(lib.ttts_embedding_bwd(_p(ids), _p(dout), _p(t), ids.numel(), vocab, d, acc, _stream()),
                    "ttts_embedding_bwd")
-        return None, dtable, None
+        return None, dtable, None, None
 
 
 def embedding(ids, table):
     out_am = _amax_slots(table.device, True) if table.is_cuda else None
-    out = EmbeddingFn.apply(ids, table, out_am)
+    i_full = _twin(ids)
+    twin = [i_full, []] if i_full is not None else None
+    out = EmbeddingFn.apply(ids, table, out_am, twin)
+    if twin is not None:
+        out._ttts_twin = twin[1][0]
     if out_am is not None:
         out._ttts_amax = out_am
     return out
@@ -2150,15 +2297,19 @@ class PosEncFn(torch.autograd.Function):
     """y = drop(x + alpha * pe[:T])"""
 
     @staticmethod
-    def forward(ctx, x, pe, alpha, drop_p, seed, y_amax=None):
+    def forward(ctx, x, pe, alpha, drop_p, seed, y_amax=None, twin=None):
         lib = _lib.load()
         x = _chk(x, "posenc.x")
         B, T, d = x.shape
         if T > pe.shape[0] or d != pe.shape[1]:
             raise ValueError("posenc: sequence longer than the table or width mismatch")
-        y = torch.empty_like(x)
-        _lib.check(lib.ttts_posenc_fwd(_p(x), _p(pe), _p(alpha), _p(y), B, T, d, float(drop_p), seed, _ss(), _p(y_amax),
+        k = 2 if twin is not None else 1                   # (twin batch, see `_twin`)
+        y_k = torch.empty(k * B, T, d, dtype=torch.float32, device=x.device)
+        _lib.check(lib.ttts_posenc_fwd(_p(x), _p(pe), _p(alpha), _p(y_k), k * B, T, d, float(drop_p), seed, _ss(), _p(y_amax),
                                        _stream()), "ttts_posenc_fwd")
+        y = y_k[:B] if twin is not None else y_k
+        if twin is not None:
+            twin[1].append(y_k)
         ctx.save_for_backward(pe)
         ctx.cfg = (float(drop_p), seed)
         ctx.ss = _ss()
@@ -2182,12 +2333,16 @@ class PosEncFn(torch.autograd.Function):
         ws = _ws(lib.ttts_posenc_bwd_workspace_bytes(), dy.device)
         _lib.check(lib.ttts_posenc_bwd(_p(dy), _p(pe), _p(dx), _p(t), _p(ws), ws.numel() * 4, B, T, d, drop_p, seed, ctx.ss, acc,
                                        _stream()), "ttts_posenc_bwd")
-        return dx, None, dalpha, None, None, None
+        return dx, None, dalpha, None, None, None, None
 
 
 def posenc(x, pe, alpha, drop_p: float, seed: int):
     y_am = _amax_slots(x.device, True) if x.is_cuda else None
-    y = PosEncFn.apply(x, pe, alpha, drop_p, seed, y_am)
+    x_full = _twin(x)
+    twin = [x_full, []] if x_full is not None else None
+    y = PosEncFn.apply(x, pe, alpha, drop_p, seed, y_am, twin)
+    if twin is not None:
+        y._ttts_twin = twin[1][0]
     if y_am is not None:
         y._ttts_amax = y_am
     return y
