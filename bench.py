@@ -403,6 +403,9 @@ def main():
     ap.add_argument("--no-twin-encoder", action="store_true",
                     help="A/B aid: each forward of the step encodes its phonemes itself (the reference's structure) instead of ONE "
                          "encoder pass over a batch of 2 B for both (model.encode_twin)")
+    ap.add_argument("--no-twin-postnet", action="store_true",
+                    help="A/B switch: the no-grad forward runs its own post-net pass (as the reference does) instead of sharing the "
+                         "grad forward's as a twin batch (ops.PostnetTwin)")
     ap.add_argument("--layernorm-images", action="store_true",
                     help="A/B aid: LayerNorm forward / backward also write the image operand of their output and the GEMMs behind "
                          "them take it (measured slower over the step: transformertts_amd/ops.py, LAYERNORM_IMAGES)")
@@ -457,6 +460,8 @@ def main():
         ops.WGRAD_SIDE_STREAM = True
     if args.no_twin_encoder:
         ops.TWIN_ENCODER = False
+    if args.no_twin_postnet:
+        ops.TWIN_POSTNET = False
     cfg = model_config(args.config)
     config = {"model": dict(cfg, device="cuda"), "loss": {"stop_weight": 8.0},
               "training": {"num_epochs": 300, "teacher_forcing_mode": "linear", "warmup_steps": 4000,
@@ -653,7 +658,7 @@ def main():
                        "alignments_written": bool(args.alignments),
                        "arithmetic": "3 x f16 MFMA terms per fp32 product (hi/lo f16 splits of both operands), fp32 accumulate",
                        "dma_gemms": not args.no_image_operands, "layernorm_images": bool(args.layernorm_images),
-                       "head_images": not args.no_head_images, "fused_cross_kv": not args.no_fused_kv, "wgrad_groups": not args.no_wgrad_groups, "twin_encoder": not args.no_twin_encoder,
+                       "head_images": not args.no_head_images, "fused_cross_kv": not args.no_fused_kv, "wgrad_groups": not args.no_wgrad_groups, "twin_encoder": not args.no_twin_encoder, "twin_postnet": not args.no_twin_postnet,
                        "final_loss": final_loss, "per_step_loss_item_sync": False},
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "sustained": sustained,

@@ -286,6 +286,12 @@ int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* runni
 int ttts_bn_train_stats_from_partials(const float* partials, int nblk, float* mean, float* invstd, float* running_mean,
                                       float* running_var, int64_t* num_batches_tracked, int C, float momentum, float eps,
                                       void* stream);
+/* as above, merged with n_rows (0 .. 256) rows of the matrix itself (row stride C; `rows` their first) that none of the nblk (>= 0)
+ * partials covers: a row range that does not end on a chunk boundary takes its whole chunks from the epilogue's partials and the rest
+ * from y (the halves of a twin batch).  (ABI v13) */
+int ttts_bn_train_stats_from_partials_rows(const float* partials, int nblk, const float* rows, int n_rows, float* mean,
+                                           float* invstd, float* running_mean, float* running_var,
+                                           int64_t* num_batches_tracked, int C, float momentum, float eps, void* stream);
 int ttts_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C, float eps,
                        void* stream);
 /* z = drop(act((x - mean) * invstd * gamma + beta)); z_amax_out: NULL, or a caller-zeroed TTTS_AMAX_SLOTS-float array receiving max|z| */

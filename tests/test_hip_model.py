@@ -490,14 +490,18 @@ def test_training_step_surface():
             assert int(buf.item()) == 2
 
 
-@pytest.mark.parametrize("B,Tp,Tm", [(4, 64, 200), (3, 37, 150)])
-def test_twin_encoder_is_the_two_encodes(B, Tp, Tm):
+@pytest.mark.parametrize("flag,B,Tp,Tm", [("TWIN_ENCODER", 4, 64, 200), ("TWIN_ENCODER", 3, 37, 150), ("TWIN_POSTNET", 4, 64, 200),
+                                          ("TWIN_POSTNET", 3, 37, 150), ("TWIN_POSTNET", 32, 50, 870)])
+def test_twin_batches_are_the_two_forwards(flag, B, Tp, Tm):
     """model.encode_twin: the encoder of BOTH forwards of training_step as one pass over a batch of 2 B (the reference encodes the
     same phonemes twice, lightning_module.py:53-59,77).  With dropout off the step must be the step of two separate encodes:
     loss, every parameter gradient, the pre-net's BatchNorm running statistics (updated TWICE, by each forward's own batch
     statistics -- identical here, the inputs being identical) and num_batches_tracked.  (4, 64): the halves are whole row chunks
     of the convolution's BatchNorm partials; (3, 37): they are not, and each half takes its own statistics pass.  p_tf < 1: the
-    no-grad forward's prediction -- built on the no-grad half of the twin batch -- enters the grad forward's input."""
+    no-grad forward's prediction -- built on the no-grad half of the twin batch -- enters the grad forward's input.
+    TWIN_POSTNET (ops.PostnetTwin): the same for the post-net, which the reference runs in the no-grad forward for nothing but its
+    BatchNorm running statistics (model/model.py:310, lightning_module.py:53-59) -- here the grad forward runs it once over both
+    predictions; (32, 50, 870): its convolutions on the 224-row tile, whose row chunk the halves share."""
     import transformertts_amd.utils.util as U
     from oracle import model_config, fill_state, synth_batch
     from transformertts_amd import ops
@@ -509,14 +513,15 @@ def test_twin_encoder_is_the_two_encodes(B, Tp, Tm):
     u = torch.rand(B, 1, batch["melspec"].size(1), generator=torch.Generator().manual_seed(6))
     res = []
     for twin in (True, False):
-        ops.TWIN_ENCODER = twin
+        setattr(ops, flag, twin)
         try:
             lm = LightningModule(config).to("cuda")
             lm.model.load_state_dict(fill_state(cfg, 12), strict=True)
             _no_dropout(lm)
             lm.train()
             lm.current_epoch = 120
-            assert lm.model.twin_encode_ok(batch["phoneme"].to("cuda")) == twin
+            assert (lm.model.twin_encode_ok(batch["phoneme"].to("cuda")) if flag == "TWIN_ENCODER" else
+                    lm.model.twin_postnet_ok(batch["melspec"].to("cuda"))) == twin
             U._uniform_draw = lambda B_, T_, device: u.to(device)
             try:
                 loss = lm.training_step(dict(batch), 1)
@@ -527,7 +532,7 @@ def test_twin_encoder_is_the_two_encodes(B, Tp, Tm):
             res.append((loss.item(), {n: p.grad.clone() for n, p in lm.model.named_parameters()},
                         {n: b.clone() for n, b in lm.model.named_buffers() if "running" in n or "num_batches" in n}))
         finally:
-            ops.TWIN_ENCODER = True
+            setattr(ops, flag, True)
     (l1, g1, b1), (l0, g0, b0) = res
     assert abs(l1 - l0) < 2e-6 * abs(l0), (l1, l0)
     for n in g0:

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const float* 
 
 // ------------------------------------------------------------------------------------------ BatchNorm
 constexpr int BN_MAXBLK = 512;   // row chunks: enough waves (and bytes in flight) to stream at HBM rate
+constexpr int BN_XROWS = 4;      // bn_stats_final_kernel: rows of the matrix itself merged with the partials, per merge lane (64 lanes)
 
 // per (row-chunk, channel): count, mean, M2 = sum (x - mean)^2.  Block = 64 channels x 4 row-lanes; two passes over the
 // chunk (the second one hits L2) so no division sits in the streaming loops; merged deterministically afterwards.
@@ -317,7 +318,8 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ ws, float* __restrict__ mean_out,
                                                              float* __restrict__ invstd_out, float* __restrict__ running_mean,
                                                              float* __restrict__ running_var, int64_t* __restrict__ nbt,
-                                                             int nblk, int C, float momentum, float eps) {
+                                                             int nblk, int C, float momentum, float eps,
+                                                             const float* __restrict__ xr, int nxr) {
     // merge of the row-chunk partials without a serial chain of divisions: N = sum n_b, mean = sum n_b mean_b / N, then
     // M2 = sum [M2_b + n_b (mean_b - mean)^2] (the pooled-variance identity, centred on the global mean).  4 channels
     // x 64 chunk-lanes per block (the loop is latency bound: short trips, many lanes), fixed summation order.
@@ -337,9 +339,19 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
         pm[i] = ok ? w[C] : 0.f;
         pq[i] = ok ? w[2 * C] : 0.f;
     }
+    // xr: nxr (<= 64 * BN_XROWS) more rows of the matrix itself, each a partial (1, x, 0): the rows of a row chunk that only
+    // partly belongs to this set of rows (a twin batch whose halves do not end on a chunk boundary, ops.ConvBNFn._forward_twin)
+    float xv[BN_XROWS];
+#pragma unroll
+    for (int i = 0; i < BN_XROWS; ++i) {
+        const int r = rl + 64 * i;
+        xv[i] = (c < C && r < nxr) ? xr[(long)r * C + c] : 0.f;
+    }
     float n = 0.f, sw = 0.f;
 #pragma unroll
     for (int i = 0; i < PER; ++i) { n += pn[i]; sw += pn[i] * pm[i]; }
+#pragma unroll
+    for (int i = 0; i < BN_XROWS; ++i) { n += (rl + 64 * i < nxr) ? 1.f : 0.f; sw += xv[i]; }
     sn[rl][cl] = n; sm[rl][cl] = sw;
     __syncthreads();
     n = 0.f; sw = 0.f;
@@ -351,6 +363,11 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
     for (int i = 0; i < PER; ++i) {
         const float dlt = pm[i] - mean;
         m2 += pq[i] + pn[i] * dlt * dlt;
+    }
+#pragma unroll
+    for (int i = 0; i < BN_XROWS; ++i) {
+        const float dlt = xv[i] - mean;
+        m2 += (rl + 64 * i < nxr) ? dlt * dlt : 0.f;
     }
     sq[rl][cl] = m2;
     __syncthreads();
@@ -630,7 +647,23 @@ int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* runni
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(cdiv(C, 64), nb), dim3(256), 0, stream, x, ws, (long)M, C, rpb);
     TTTS_LAUNCH_CHECK("bn_stats_partial_kernel");
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, ws, mean, invstd, running_mean,
-                       running_var, num_batches_tracked, nb, C, momentum, eps);
+                       running_var, num_batches_tracked, nb, C, momentum, eps, (const float*)nullptr, 0);
+    TTTS_LAUNCH_CHECK("bn_stats_final_kernel");
+    return TTTS_OK;
+}
+
+int ttts_bn_train_stats_from_partials_rows(const float* partials, int nblk, const float* rows, int n_rows, float* mean,
+                                           float* invstd, float* running_mean, float* running_var,
+                                           int64_t* num_batches_tracked, int C, float momentum, float eps, void* stream) {
+    // the second half of ttts_bn_train_stats on row-chunk partials [nblk][3][C] = (count, mean, M2) that somebody else wrote
+    // (the fp16x3 convolution's epilogue: ttts_conv1d_fwd_h3 with bn_partials), plus n_rows rows of the matrix itself (row
+    // stride C) that no partial of the run covers
+    TTTS_REQUIRE(mean && invstd && (partials || nblk == 0) && (rows || n_rows == 0), "bn_train_stats_from_partials: null pointer");
+    TTTS_REQUIRE(nblk >= 0 && nblk <= BN_MAXBLK && C > 0, "bn_train_stats_from_partials: nblk=%d must be in 0..%d", nblk, BN_MAXBLK);
+    TTTS_REQUIRE(n_rows >= 0 && n_rows <= 64 * BN_XROWS, "bn_train_stats_from_partials: n_rows=%d must be in 0..%d", n_rows, 64 * BN_XROWS);
+    TTTS_REQUIRE(nblk + n_rows > 0, "bn_train_stats_from_partials: nothing to merge");
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, mean, invstd,
+                       running_mean, running_var, num_batches_tracked, nblk, C, momentum, eps, rows, n_rows);
     TTTS_LAUNCH_CHECK("bn_stats_final_kernel");
     return TTTS_OK;
 }
@@ -638,14 +671,9 @@ int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* runni
 int ttts_bn_train_stats_from_partials(const float* partials, int nblk, float* mean, float* invstd, float* running_mean,
                                       float* running_var, int64_t* num_batches_tracked, int C, float momentum, float eps,
                                       void* stream) {
-    // the second half of ttts_bn_train_stats on row-chunk partials [nblk][3][C] = (count, mean, M2) that somebody else wrote
-    // (the fp16x3 convolution's epilogue: ttts_conv1d_fwd_h3 with bn_partials)
-    TTTS_REQUIRE(partials && mean && invstd, "bn_train_stats_from_partials: null pointer");
-    TTTS_REQUIRE(nblk > 0 && nblk <= BN_MAXBLK && C > 0, "bn_train_stats_from_partials: nblk=%d must be in 1..%d", nblk, BN_MAXBLK);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, mean, invstd,
-                       running_mean, running_var, num_batches_tracked, nblk, C, momentum, eps);
-    TTTS_LAUNCH_CHECK("bn_stats_final_kernel");
-    return TTTS_OK;
+    TTTS_REQUIRE(partials && nblk > 0, "bn_train_stats_from_partials: null pointer");
+    return ttts_bn_train_stats_from_partials_rows(partials, nblk, nullptr, 0, mean, invstd, running_mean, running_var,
+                                                  num_batches_tracked, C, momentum, eps, stream);
 }
 
 int ttts_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C, float eps,

@@ -70,17 +70,21 @@ class LightningModule(_Base):
         mem_grad = mem_nograd = None
         if self.model.twin_encode_ok(phoneme):
             mem_grad, mem_nograd = self.model.encode_twin(phoneme, phoneme_lens)
+        # ... and both run the post-net, the no-grad forward for its BatchNorm running statistics alone (its post_melspec has no
+        # reader): one pass over both predictions, made by the grad forward (ops.PostnetTwin)
+        post_twin = ops.PostnetTwin() if self.model.twin_postnet_ok(melspec) else None
         # forward #1 (no grad, train mode: dropout on, BN statistics updated) -> the model's own prediction
         with torch.no_grad():   # only pred_melspec is used: do not materialise the attention maps
-            pred_melspec = self.forward(phoneme, melspec, phoneme_lens, melspec_lens,
-                                        need_alignments=False, need_stop=False, memory=mem_nograd)['pred_melspec']
+            pred_melspec = self.forward(phoneme, melspec, phoneme_lens, melspec_lens, need_alignments=False, need_stop=False,
+                                        memory=mem_nograd, postnet_twin=post_twin)['pred_melspec']
         p_tf = self.teacher_forcing_ratio()
         mel_mixed = apply_teacher_forcing(pred_melspec, melspec, melspec_lens, p_tf, self.device)
         # forward #2 (with grad) on the mixed input, loss against the ground truth.  The loss reads the three prediction tensors
         # only (lightning_module.py:78-79 of the reference discards the alignments of its output dict as well), so the per-head
         # attention maps are not written here either; `validation_step` / `forward()` return them as the reference does.
         output = self.forward(phoneme, mel_mixed, phoneme_lens, melspec_lens,
-                              need_alignments=self.config['training'].get('train_step_alignments', False), memory=mem_grad)
+                              need_alignments=self.config['training'].get('train_step_alignments', False), memory=mem_grad,
+                              postnet_twin=post_twin)
         loss = self.criterion(output, melspec, melspec_lens)
         if self.sync_loss:
             self.train_losses.append(loss['total'].item())

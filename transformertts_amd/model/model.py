@@ -112,7 +112,7 @@ class PostNet(nn.Module):
             if i < len(mods) and isinstance(mods[i], nn.Dropout):
                 p = mods[i].p
                 i += 1
-            x = conv.fused(x, act, p)
+            x = conv.fused(x, act, p, twin_last=i >= len(mods))      # (a twin batch ends here: ops.PostnetTwin)
         return x
 
 
@@ -189,6 +189,14 @@ class TransformerTTS(nn.Module):
                 ops.HEAD_IMAGES and ops.ATTN_FWD_MODE == "h3" and ops.ATTN_BWD_MODE == "h3" and ops._fwd_h3(d, 3 * d) and
                 2 * phoneme.numel() * 3 * d * 4 < (1 << 31))
 
+    def twin_postnet_ok(self, melspec: Tensor) -> bool:
+        """can both forwards of a training step share ONE post-net pass (ops.PostnetTwin)?  Training mode (in eval mode BatchNorm
+        has no batch statistics to keep apart and there is one forward), fp16x3 convolutions throughout."""
+        convs = [m for m in self.postnet.layers if hasattr(m, "conv")]
+        return (ops.TWIN_POSTNET and self.training and melspec.is_cuda and len(convs) > 0 and
+                all(ops._fwd_h3(c.conv.weight.shape[2] * c.conv.weight.shape[1], c.conv.weight.shape[0], c.conv.weight.shape[1])
+                    for c in convs) and 2 * melspec.shape[0] * melspec.shape[1] * max(c.conv.weight.shape[0] for c in convs) * 4 < (1 << 31))
+
     def encode_twin(self, phoneme: Tensor, phoneme_lens: Tensor):
         """-> (memory of a forward WITH grad, memory of a forward without) from ONE pass over a batch of 2 B.  The reference's
         training_step encodes the same phonemes twice -- under no_grad for the scheduled-sampling prediction and with grad
@@ -211,13 +219,18 @@ class TransformerTTS(nn.Module):
         return mem, mem_ng
 
     def forward(self, phoneme: Tensor, melspec: Tensor, phoneme_lens: Tensor, melspec_lens: Tensor,
-                need_alignments: bool = True, need_stop: bool = True, memory: Tensor = None) -> dict:
+                need_alignments: bool = True, need_stop: bool = True, memory: Tensor = None,
+                postnet_twin: "ops.PostnetTwin" = None) -> dict:
         """
         `need_alignments=False` (an extension; the reference always returns them) skips writing the per-head
         cross-attention maps -- 267 MB per forward at batch 64 -- for callers that only want the mels, e.g. the
         no-grad first forward of `training_step`.  `alignments` is then a list of None.
         `memory` (an extension): the encoder output of `phoneme`, when the caller has it already (`encode_twin`: the two forwards
         of a training step encoded as one batch); None: encoded here.
+        `postnet_twin` (an extension; `training_step` alone passes it, the same object to both of its forwards): the no-grad
+        forward leaves its prediction there and returns `post_melspec` None WITHOUT running the post-net; the grad forward runs
+        the post-net once over both predictions (ops.PostnetTwin: the BatchNorm running statistics receive both forwards'
+        updates, in the reference's order).
         `need_stop=False` (no-grad only; same caller): `pred_stop` is None -- the stop head is stateless and its logits have no
         reader there (reference lightning_module.py:53-59 keeps `pred_melspec` alone).  The post-net still runs: its BatchNorm
         running statistics are updated by that forward too.
@@ -244,7 +257,9 @@ class TransformerTTS(nn.Module):
                                            need_alignments=need_alignments)
         pred_melspec, pred_stop = ops.heads(tgt_out, self.linear1.linear.weight, self.linear1.linear.bias,
                                             self.linear2.linear.weight, self.linear2.linear.bias,
-                                            need_stop=need_stop or torch.is_grad_enabled())
+                                            need_stop=need_stop or torch.is_grad_enabled(), box=postnet_twin)
+        if postnet_twin is not None and not torch.is_grad_enabled():
+            return {'pred_melspec': pred_melspec, 'post_melspec': None, 'pred_stop': pred_stop, 'alignments': alignments}
         # three consumers of the prediction (the loss, the post-net, its residual): one handle each
         pred_melspec, pred_in, pred_res = ops.fanout(pred_melspec, 3)
         post_melspec = ops.AddFn.apply(self.postnet(pred_in), pred_res)

@@ -29,13 +29,14 @@ class ConvNormBN(nn.Module):
         nn.init.constant_(self.bn.weight, 1.0)
         nn.init.constant_(self.bn.bias, 0.0)
 
-    def fused(self, x: Tensor, act: int = ops.ACT_NONE, drop_p: float = 0.0) -> Tensor:
-        """conv -> batch-norm -> optional tanh -> optional dropout in one autograd node, (B,T,C) in and out."""
+    def fused(self, x: Tensor, act: int = ops.ACT_NONE, drop_p: float = 0.0, twin_last: bool = False) -> Tensor:
+        """conv -> batch-norm -> optional tanh -> optional dropout in one autograd node, (B,T,C) in and out.
+        twin_last: see ops.conv_bn (the last layer of a pass over a twin batch)."""
         bn = self.bn
         p = drop_p if self.training else 0.0
         return ops.conv_bn(x, self.conv.weight, self.conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                            bn.num_batches_tracked, self.training, bn.momentum, bn.eps, act, p,
-                           ops.seeds.next() if p > 0.0 else 0)
+                           ops.seeds.next() if p > 0.0 else 0, twin_last=twin_last)
 
     def forward(self, x: Tensor) -> Tensor:
         return self.fused(x)

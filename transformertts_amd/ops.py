@@ -1401,30 +1401,53 @@ def cross_kv_projection(mem: torch.Tensor, attns, owner):
 
 
 # ----------------------------------------------------------------------------------------------- heads
+def _mel_head(lib, x, w_mel, b_mel, mel, M, N, K, x_amax, mel_amax):
+    """mel = x w_mel^T + b_mel into the given buffer, in the configured form; -> the partial maxima of x it used (or None)"""
+    if _fwd_h3(K, N):
+        if x_amax is None:
+            x_amax = _amax(x)
+        _lib.check(lib.ttts_linear_fwd_h3(_p(x), _p(_planes(w_mel, 4, N, K)), _p(b_mel), None, _p(mel), M, N, K,
+                                          ACT_NONE, 0.0, 0, None, 0, 0, _p(x_amax), _p(mel_amax), _stream()),
+                   "ttts_linear_fwd_h3")
+    elif GEMM_MODE == "x6":
+        _lib.check(lib.ttts_linear_fwd_x6(_p(x), _p(_planes(w_mel, 0, N, K)), _p(b_mel), None, _p(mel), M, N, K,
+                                          ACT_NONE, 0.0, 0, None, 0, 0, _stream()), "ttts_linear_fwd_x6")
+    else:
+        _lib.check(lib.ttts_linear_fwd(_p(x), _p(w_mel), _p(b_mel), None, _p(mel), M, N, K, ACT_NONE, 0.0,
+                                       0, None, 0, 0, _stream()), "ttts_linear_fwd")
+    return x_amax
+
+
+class PostnetTwin:
+    """The mel predictions of BOTH forwards of a training step as one twin batch (see `_twin`): the no-grad forward, which runs
+    first, leaves its prediction in the SECOND half of `full` (2 B, T, n_mels) and does not run the post-net; the grad forward
+    writes its own into the first half and runs the post-net once over both.  The reference runs the post-net in the no-grad
+    forward too (model/model.py:310) and drops the result (lightning_module.py:53-59 keeps `pred_melspec`): what stays of it
+    are the updates of its BatchNorm running statistics, which the twin pass makes per half, the no-grad forward's first.
+    `amax`: partial maxima of |prediction| over both halves (each forward's mel head adds its own)."""
+    __slots__ = ("full", "amax")
+
+    def __init__(self):
+        self.full = self.amax = None
+
+
+TWIN_POSTNET = True
+
+
 class HeadsFn(torch.autograd.Function):
     """mel = x @ w_mel.T + b_mel  (B,T,n_mels);  stop = x @ w_stop.T + b_stop  (B,T)  -- one read of dx."""
 
     @staticmethod
-    def forward(ctx, x, w_mel, b_mel, w_stop, b_stop, x_amax=None, mel_amax=None):
+    def forward(ctx, x, w_mel, b_mel, w_stop, b_stop, x_amax=None, mel_amax=None, box=None):
         lib = _lib.load()
         x = _chk(x, "heads.x")
         N, K = w_mel.shape
         M = x.numel() // K
-        mel = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
+        # box: the mel prediction is written as the first half of the twin batch whose second half the no-grad forward left
+        mel = box.full[:x.shape[0]] if box is not None else torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
         stop = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
         w_mel = _chk(w_mel, "w_mel")
-        if _fwd_h3(K, N):
-            if x_amax is None:
-                x_amax = _amax(x)
-            _lib.check(lib.ttts_linear_fwd_h3(_p(x), _p(_planes(w_mel, 4, N, K)), _p(b_mel), None, _p(mel), M, N, K,
-                                              ACT_NONE, 0.0, 0, None, 0, 0, _p(x_amax), _p(mel_amax), _stream()),
-                       "ttts_linear_fwd_h3")
-        elif GEMM_MODE == "x6":
-            _lib.check(lib.ttts_linear_fwd_x6(_p(x), _p(_planes(w_mel, 0, N, K)), _p(b_mel), None, _p(mel), M, N, K,
-                                              ACT_NONE, 0.0, 0, None, 0, 0, _stream()), "ttts_linear_fwd_x6")
-        else:
-            _lib.check(lib.ttts_linear_fwd(_p(x), _p(w_mel), _p(b_mel), None, _p(mel), M, N, K, ACT_NONE, 0.0,
-                                           0, None, 0, 0, _stream()), "ttts_linear_fwd")
+        x_amax = _mel_head(lib, x, w_mel, b_mel, mel, M, N, K, x_amax, mel_amax)
         _lib.check(lib.ttts_rowdot_fwd(_p(x), _p(_chk(w_stop, "w_stop")), _p(b_stop), _p(stop), M, K, _stream()),
                    "ttts_rowdot_fwd")
         ctx.save_for_backward(x, w_mel, w_stop)
@@ -1474,26 +1497,44 @@ class HeadsFn(torch.autograd.Function):
                               _p(t_wm), _p(t_bm), _p(ws), ws.numel() * 4, M, N, K, 0, 0, acc), "ttts_linear_bwd_weight")
         _lib.check(lib.ttts_rowdot_bwd(_p(dstop), _p(x), _p(w_stop), _p(dx), _p(t_ws), _p(t_bs), _p(ws2),
                                        ws2.numel() * 4, M, K, acc, _qarg(queue, ws2), _stream()), "ttts_rowdot_bwd")
-        return dx, dw_mel, db_mel, dw_stop, db_stop, None, None
+        return dx, dw_mel, db_mel, dw_stop, db_stop, None, None, None
 
 
-def heads(x, w_mel, b_mel, w_stop, b_stop, need_stop: bool = True):
+def heads(x, w_mel, b_mel, w_stop, b_stop, need_stop: bool = True, box: Optional[PostnetTwin] = None):
     """(mel, stop) heads; x's partial maxima ride on it (LayerNorm left them), and the mel output leaves with its own for
     the post-net's first convolution (its weight gradient reads pred_melspec as an fp16x3 operand).
     `need_stop=False` (no-grad callers only): the stop logits have no reader -- the first forward of training_step keeps
     `pred_melspec` alone (reference lightning_module.py:53-59) and the stop head has no state -- so they are not computed and
     None is returned for them."""
+    N, K = w_mel.shape
+    if box is not None and box.full is None:
+        # the no-grad forward of a twin post-net: the prediction goes behind the place of the grad forward's
+        if torch.is_grad_enabled() or need_stop or x.dim() != 3:
+            raise ValueError("heads(box=<empty PostnetTwin>) is the no-grad forward's call (need_stop=False, (B, T, d) input)")
+        lib = _lib.load()
+        x = _chk(x, "heads.x")
+        B = x.shape[0]
+        box.full = torch.empty(2 * B, x.shape[1], N, dtype=torch.float32, device=x.device)
+        box.amax = _amax_slots(x.device, True) if _fwd_h3(K, N) else None
+        _mel_head(lib, x, _chk(w_mel, "w_mel"), b_mel, box.full[B:], x.numel() // K, N, K, None, box.amax)
+        return box.full[B:], None
     if not need_stop:
         if torch.is_grad_enabled() and (x.requires_grad or w_stop.requires_grad):
             raise ValueError("heads(need_stop=False) is for no-grad forwards: the stop head's gradients would be lost")
         return linear(x, w_mel, b_mel, publish_amax=True), None
-    N, K = w_mel.shape
     h3 = x.is_cuda and _fwd_h3(K, N)
     x_am = _amax(x) if h3 else None
-    mel_am = _amax_slots(x.device, True) if h3 else None
-    mel, stop = HeadsFn.apply(x, w_mel, b_mel, w_stop, b_stop, x_am, mel_am)
+    if box is not None:
+        if box.full.shape != (2 * x.shape[0], x.shape[1], N) or box.full.device != x.device:
+            raise ValueError("heads: the twin post-net's buffer was left by a forward over another batch")
+        mel_am = box.amax
+    else:
+        mel_am = _amax_slots(x.device, True) if h3 else None
+    mel, stop = HeadsFn.apply(x, w_mel, b_mel, w_stop, b_stop, x_am, mel_am, box)
     if mel_am is not None:
         mel._ttts_amax = mel_am
+    if box is not None:
+        mel._ttts_twin = box.full
     return mel, stop
 
 
@@ -1578,12 +1619,19 @@ class ConvBNFn(torch.autograd.Function):
         z_k = torch.empty(Bk, T, cout, dtype=torch.float32, device=dev)
         if x_amax is None:
             x_amax = _amax(twin[0])
-        bn_ws, per_half = None, 0
+        bn_ws, runs = None, None
         if training and M > 1:
             nblk = lib.ttts_conv1d_fwd_h3_bn_blocks(Bk, T, cin, cout, taps)
             chunk = lib.ttts_conv1d_fwd_h3_bn_chunk_rows(Bk, T, cin, cout, taps)
-            if nblk > 0 and chunk > 0 and M % chunk == 0 and nblk == 2 * (M // chunk):
-                bn_ws, per_half = _ws(lib.ttts_bn_workspace_bytes(2 * M, cout), dev), M // chunk
+            if nblk > 0 and 0 < chunk <= 256 and nblk == -(-2 * M // chunk):
+                # each half takes its whole row chunks from the epilogue's partials; the chunk the halves share (M is no multiple
+                # of the chunk) is read from y itself, row by row: (first partial, partials, first row, rows) per half
+                bn_ws = _ws(lib.ttts_bn_workspace_bytes(2 * M, cout), dev)
+                s_, cut = divmod(M, chunk)
+                if cut == 0:
+                    runs = {0: (0, s_, 0, 0), 1: (s_, nblk - s_, 0, 0)}
+                else:
+                    runs = {0: (0, s_, s_ * chunk, cut), 1: (s_ + 1, nblk - s_ - 1, M, min((s_ + 1) * chunk, 2 * M) - M)}
         _lib.check(lib.ttts_conv1d_fwd_h3(_p(x), _p(_planes(conv_w, 6, cout, taps * cin, cin, taps)), _p(conv_b), _p(y_k),
                                           Bk, T, cin, cout, taps, _p(x_amax), _p(bn_ws), _stream()), "ttts_conv1d_fwd_h3")
         stats = {}
@@ -1592,9 +1640,12 @@ class ConvBNFn(torch.autograd.Function):
             mean = torch.empty(cout, dtype=torch.float32, device=dev)
             invstd = torch.empty(cout, dtype=torch.float32, device=dev)
             if training and bn_ws is not None:
-                _lib.check(lib.ttts_bn_train_stats_from_partials(_off(bn_ws, h * per_half * 3 * cout), per_half, _p(mean), _p(invstd),
-                                                                 _p(running_mean), _p(running_var), _p(nbt), cout, float(momentum),
-                                                                 float(eps), _stream()), "ttts_bn_train_stats_from_partials")
+                b0, nb, r0, nr = runs[h]
+                _lib.check(lib.ttts_bn_train_stats_from_partials_rows(_off(bn_ws, b0 * 3 * cout) if nb else None, nb,
+                                                                      _off(y_k, r0 * cout) if nr else None, nr, _p(mean), _p(invstd),
+                                                                      _p(running_mean), _p(running_var), _p(nbt), cout,
+                                                                      float(momentum), float(eps), _stream()),
+                           "ttts_bn_train_stats_from_partials_rows")
             elif training:
                 ws = _ws(lib.ttts_bn_workspace_bytes(M, cout), dev)
                 _lib.check(lib.ttts_bn_train_stats(_p(y_h), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(nbt),
@@ -1603,11 +1654,14 @@ class ConvBNFn(torch.autograd.Function):
             else:
                 _lib.check(lib.ttts_bn_eval_stats(_p(running_mean), _p(running_var), _p(mean), _p(invstd), cout, float(eps),
                                                   _stream()), "ttts_bn_eval_stats")
+            if h == 1 and len(twin) > 2 and twin[2]:
+                continue                      # the no-grad half of the LAST layer of a twin pass: its statistics were all anybody wanted
             # (each half is a launch of its own whose element indices start at zero: the no-grad half draws from another seed)
             seed_h = seed if (h == 0 or seed == 0) else ((seed * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF)
             _lib.check(lib.ttts_bn_apply_fwd(_p(y_h), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(z_h), M, cout, act,
                                              float(drop_p), seed_h, _ss(), _p(z_amax), _stream()), "ttts_bn_apply_fwd")
-            stats[h] = (mean, invstd)
+            if h == 0:
+                stats[h] = (mean, invstd)
         twin[1].append(z_k)
         ctx.save_for_backward(x, conv_w, y_k[:B], stats[0][0], stats[0][1], gamma, beta)
         ctx.x_amax = x_amax
@@ -1673,18 +1727,21 @@ class ConvBNFn(torch.autograd.Function):
 
 
 def conv_bn(x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum=0.1, eps=1e-5,
-            act=ACT_NONE, drop_p=0.0, seed=0, publish_amax=True):
-    """`publish_amax`: leave the partial maxima of the output on it (`z._ttts_amax`) for the fp16x3 GEMM that reads it."""
+            act=ACT_NONE, drop_p=0.0, seed=0, publish_amax=True, twin_last=False):
+    """`publish_amax`: leave the partial maxima of the output on it (`z._ttts_amax`) for the fp16x3 GEMM that reads it.
+    `twin_last`: if x is the first half of a twin batch (`_twin`), nobody reads the other half's output: the no-grad forward's
+    rows still enter the convolution and update the running statistics, but are not normalised, and the result is an ordinary
+    tensor of B utterances."""
     cout, cin, taps = conv_w.shape
     x_full = _twin(x)
-    twin = [x_full, []] if x_full is not None else None
+    twin = [x_full, [], bool(twin_last)] if x_full is not None else None
     x_am = None
     if x.is_cuda and _fwd_h3(taps * cin, cout, cin):
         x_am = _amax(x) if (getattr(x, "_ttts_amax", None) is not None or x_full is None) else _amax(x_full)
     z_am = _amax_slots(x.device, True) if (publish_amax and x.is_cuda) else None
     z = ConvBNFn.apply(x, conv_w, conv_b, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act,
                        drop_p, seed, x_am, z_am, twin)
-    if twin is not None:
+    if twin is not None and not twin_last:
         z._ttts_twin = twin[1][0]
     if z_am is not None:
         z._ttts_amax = z_am
@@ -2396,6 +2453,10 @@ def fanout(x: torch.Tensor, n: int):
     if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
         return (x,) * max(n, 1)
     outs = FanoutFn.apply(x, n)
+    full = getattr(x, "_ttts_twin", None)
+    if full is not None:               # aliases of the first half of a twin batch are first halves of it
+        for o in outs:
+            o._ttts_twin = full
     amax = getattr(x, "_ttts_amax", None)
     if amax is not None:               # the producer's partial maxima describe every alias: consumers need no amax pass
         for o in outs:
