@@ -1231,7 +1231,12 @@ int ttts_wgrad_group(int n, const float* const* dy, const float* const* x, float
     // (the 96-wide tiles' workgroups are long -- 10 + 2 tiles of the mel side over 55 680 rows were 140 us on 252 workgroups -- and
     // their partial tiles small: both workgroup slots of every CU from 8 tiles on)
     const long many = (cls == 3 || cls == 4) ? 8 : 13;
-    const long target = cls == 2 ? 256 : ((tiles_total >= many && nkt_max >= 800) ? 512 : 256);
+    // (row ranges from 200 k-tiles on -- 6 400 rows: at 13 920 rows a group on ONE workgroup slot per CU ran its 109 k-tiles per
+    // workgroup at a fifth of the MFMA rate, nothing covering its operand latencies: batch 16 -0.08 ms, `profiles/r06_ab_wgrad_target.txt`)
+#ifndef TTTS_WG_NKT512
+#define TTTS_WG_NKT512 200
+#endif
+    const long target = cls == 2 ? 256 : ((tiles_total >= many && nkt_max >= TTTS_WG_NKT512) ? 512 : 256);
     long want = target / tiles_total;
     if (want < 1) want = 1;
     for (int i = 0; i < n; ++i) {

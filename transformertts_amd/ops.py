@@ -1623,7 +1623,7 @@ class ConvBNFn(torch.autograd.Function):
         if training and M > 1:
             nblk = lib.ttts_conv1d_fwd_h3_bn_blocks(Bk, T, cin, cout, taps)
             chunk = lib.ttts_conv1d_fwd_h3_bn_chunk_rows(Bk, T, cin, cout, taps)
-            if nblk > 0 and 0 < chunk <= 256 and nblk == -(-2 * M // chunk):
+            if nblk > 0 and 0 < chunk <= 256 and nblk >= -(-2 * M // chunk):      # (chunks past the last row are (0, 0, 0))
                 # each half takes its whole row chunks from the epilogue's partials; the chunk the halves share (M is no multiple
                 # of the chunk) is read from y itself, row by row: (first partial, partials, first row, rows) per half
                 bn_ws = _ws(lib.ttts_bn_workspace_bytes(2 * M, cout), dev)
