@@ -552,6 +552,50 @@ def test_batchnorm_statistics_from_the_conv_epilogue(B, T, cin, cout, offset):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("B,T,cin,cout,offset", [(6, 50, 128, 256, 0.0), (14, 333, 256, 256, 2.0), (4, 7, 256, 128, 40.0),
+                                                 (64, 870, 256, 256, 3.0),      # the 224-row tile: 55 680 = 248 chunks + 128 rows
+                                                 (32, 870, 256, 256, 0.0)])     # 27 840 rows: 64-row chunks, the last tile's last chunk empty
+def test_batchnorm_statistics_of_each_half_of_a_twin_batch(B, T, cin, cout, offset):
+    """ttts_bn_train_stats_from_partials_rows: the statistics of EACH HALF of the rows of one convolution (a twin batch)
+    from the epilogue's row-chunk partials -- a half's whole chunks -- plus the rows of the chunk the halves share, read from y
+    itself: mean / invstd / running statistics of each half against fp64 over its own rows, the no-grad half (the second) first."""
+    from transformertts_amd import _lib, ops
+    from transformertts_amd.ops import _p, _off, _stream
+    lib = _lib.load()
+    M2, M = B * T, B * T // 2
+    x, w = _rand(B, T, cin, seed=1), _rand(cout, cin, 5, seed=2, scale=(5 * cin) ** -0.5)
+    x[B // 2:] *= 1.7                                               # (the halves differ)
+    b = _rand(cout, seed=3) + offset
+    nblk = lib.ttts_conv1d_fwd_h3_bn_blocks(B, T, cin, cout, 5)
+    chunk = lib.ttts_conv1d_fwd_h3_bn_chunk_rows(B, T, cin, cout, 5)
+    assert 0 < nblk <= 512 and 0 < chunk <= 256 and nblk >= -(-M2 // chunk)
+    y = torch.empty(B, T, cout, device=_dev())
+    ws = ops._ws(lib.ttts_bn_workspace_bytes(M2, cout), _dev())
+    pl = ops._planes(w, 6, cout, 5 * cin, cin, 5)
+    assert lib.ttts_conv1d_fwd_h3(_p(x), _p(pl), _p(b), _p(y), B, T, cin, cout, 5, _p(ops._amax(x)), _p(ws), _stream()) == 0
+    s_, cut = divmod(M, chunk)
+    runs = {0: (0, s_, s_ * chunk, cut), 1: (s_ + 1, nblk - s_ - 1, M, min((s_ + 1) * chunk, M2) - M)} if cut else \
+           {0: (0, s_, 0, 0), 1: (s_, nblk - s_, 0, 0)}
+    rm, rv, nbt = torch.zeros(cout, device=_dev()), torch.ones(cout, device=_dev()), torch.zeros((), dtype=torch.int64, device=_dev())
+    yd = y.double().view(M2, cout)
+    rm64, rv64 = torch.zeros(cout, dtype=torch.float64, device=_dev()), torch.ones(cout, dtype=torch.float64, device=_dev())
+    for h in (1, 0):
+        b0, nb, r0, nr = runs[h]
+        mean, invstd = torch.empty(cout, device=_dev()), torch.empty(cout, device=_dev())
+        assert lib.ttts_bn_train_stats_from_partials_rows(_off(ws, b0 * 3 * cout) if nb else None, nb, _off(y, r0 * cout) if nr else None, nr,
+                                                          _p(mean), _p(invstd), _p(rm), _p(rv), _p(nbt), cout, 0.1, 1e-5, _stream()) == 0
+        half = yd[h * M:(h + 1) * M]
+        mean64, var64 = half.mean(0), half.var(0, unbiased=False)
+        rm64 = 0.9 * rm64 + 0.1 * mean64
+        rv64 = 0.9 * rv64 + 0.1 * half.var(0, unbiased=True)
+        assert float((mean.double() - mean64).abs().max()) < 2e-6 * (1.0 + abs(offset)), (h, float((mean.double() - mean64).abs().max()))
+        assert _rel(invstd, 1.0 / torch.sqrt(var64 + 1e-5)) < 2e-6, (h, _rel(invstd, 1.0 / torch.sqrt(var64 + 1e-5)))
+    assert int(nbt) == 2 and _rel(rv, rv64) < 2e-6 and float((rm.double() - rm64).abs().max()) < 2e-6 * (1.0 + abs(offset))
+    # refusals: nothing to merge, more rows than the kernel folds
+    assert lib.ttts_bn_train_stats_from_partials_rows(None, 0, None, 0, _p(rm), _p(rv), _p(rm), _p(rv), _p(nbt), cout, 0.1, 1e-5, _stream()) != 0
+    assert lib.ttts_bn_train_stats_from_partials_rows(_p(ws), 1, _p(y), 257, _p(rm), _p(rv), _p(rm), _p(rv), _p(nbt), cout, 0.1, 1e-5, _stream()) != 0
+
+
 @pytest.mark.parametrize("B,T,cin,cout", [(3, 50, 128, 256), (2, 7, 256, 128), (5, 1, 128, 128)])
 def test_conv_weight_gradient_forms(B, T, cin, cout):
     """Both weight-gradient kernels on the conv form (shifted rows, utterance clipping, utterances shorter than a k-step)."""
