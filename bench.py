@@ -398,6 +398,8 @@ def main():
     ap.add_argument("--no-wgrad-groups", action="store_true",
                     help="A/B aid: every small weight gradient is a launch of its own instead of a member of a grouped launch "
                          "(ops.ReduceQueue.defer_wgrad, ttts_linear_bwd_weight_h3_group)")
+    ap.add_argument("--wgrad-side-rows", type=int, default=0,
+                    help="A/B aid: grouped weight gradients over at most this many rows run on a side stream (0: none unless --wgrad-side-stream)")
     ap.add_argument("--wgrad-side-stream", action="store_true",
                     help="development A/B: the grouped weight-gradient launches run on a side stream beside the data-gradient chain")
     ap.add_argument("--no-twin-encoder", action="store_true",
@@ -456,8 +458,9 @@ def main():
         ops.FUSED_CROSS_KV = False
     if args.no_wgrad_groups:
         ops.WGRAD_GROUPS = False
-    if args.wgrad_side_stream:
+    if args.wgrad_side_stream or args.wgrad_side_rows > 0:
         ops.WGRAD_SIDE_STREAM = True
+        ops.WGRAD_SIDE_MAX_ROWS = args.wgrad_side_rows
     if args.no_twin_encoder:
         ops.TWIN_ENCODER = False
     if args.no_twin_postnet:

@@ -347,7 +347,14 @@ __device__ __forceinline__ void h3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
 __device__ unsigned long long ttts_dbg_stamps[512 * 8 * 6 * 8];
 #endif
 
-template <int BM, int BN, int WM, int WN, bool CLIP>
+// PD: k-tiles of operand requests in flight per workgroup, in PD register sets (1: the form above).  On small problems the
+// smallest tile waits for its operands: 400 workgroups of 64 x 64 are 1.5 per CU, a k-tile's products take ~150 cycles, and the
+// request of tile kt + 2 is issued while tile kt is multiplied.  With PD sets the wait in front of a staging block covers a
+// request issued PD k-tiles earlier (-14 % per launch; not the 2-3 x a pure round-trip bound would give: see launch_h3).  The loop body is straight-line (no branch around a request or a staging block: hipcc's waitcnt
+// insertion assumes the conservative side of every join, i.e. vmcnt(0)): requests past the last k-tile are clipped by the
+// buffer descriptor (their voffset becomes OOB: no memory traffic, zeros), the staging block behind the last tile writes those
+// zeros into the free stage.  K / 32 must be a multiple of PD (the k loop is unrolled by PD so that set indices are static).
+template <int BM, int BN, int WM, int WN, bool CLIP, int PD = 1>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
     const uint64_t seed_eff = site_seed(g.seed, g.step_seed);
     constexpr int NT = WM * WN * 64;                            // threads per workgroup (4 or 8 waves)
@@ -420,8 +427,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[NLA];
-    u32x4 rb[2][NLB];
+    float4 ra[PD][NLA];
+    u32x4 rb[PD][2][NLB];
 
     // A: thread -> (row = idx >> 3, float4 chunk = idx & 7) for idx = tid + i*NT; rows past M fall outside the buffer
     // descriptor (hardware zero), shifted rows outside their utterance are clipped on the offset (CLIP).  Per-thread
@@ -450,14 +457,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
     uint32_t k_off = (uint32_t)((long)g.shift0 * g.lda * 4);       // scalar: byte offset of the current k position in a row
     const uint32_t tap_step = (uint32_t)(((long)g.shift_step * g.lda - g.cin) * 4);
 
-    auto load_a_piece = [&](int i) {
+    // (`live`: PD > 1 only -- a request past the last k-tile is issued all the same, with an out-of-range voffset)
+    auto load_a_piece = [&](int set, int i, bool live) {
         if (CLIP) {
             uint32_t off = a_off0 + k_off + i * a_piece_step;
-            off = ((unsigned)(a_t[i] + k_shift) < (unsigned)g.T) ? off : OOB;
-            ra[i] = buf_load4(rsrcA, off);
+            off = (((unsigned)(a_t[i] + k_shift) < (unsigned)g.T) && live) ? off : OOB;
+            ra[set][i] = buf_load4(rsrcA, off);
         } else {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (int)a_off0, (int)(k_off + i * a_piece_step), 0);
-            ra[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (int)(live ? a_off0 : OOB), (int)(k_off + i * a_piece_step), 0);
+            ra[set][i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
     };
     // Order of the k-tiles.  A shifted operand (CLIP: a convolution, K = taps x cin) walks TAPS INNERMOST: the `taps`
@@ -483,11 +491,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
             if (k_c0 == g.cin) { k_c0 = 0; k_shift += g.shift_step; k_off += tap_step; }
         }
     };
-    auto load_b_piece = [&](int j) {
+    auto load_b_piece = [&](int set, int j, bool live) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-            rb[p][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)b_off0,
-                                                             (int)(b_cur + p * b_plane_bytes + j * (B_ROWS_PER_PIECE * 64)), 0);
+            rb[set][p][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)(live ? b_off0 : OOB),
+                                                                  (int)(b_cur + p * b_plane_bytes + j * (B_ROWS_PER_PIECE * 64)), 0);
     };
     auto advance_b = [&]() {                                       // (always called right behind advance_a)
         if (CLIP) {
@@ -498,39 +506,52 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
             b_cur += 2u * b_plane_bytes;
         }
     };
-    auto store_a_piece = [&](int buf, int i) {
+    auto store_a_piece = [&](int set, int buf, int i) {
         uint32_t* as = lds + buf * STAGE;
         uint2 hi, lo;
-        split2_pair(f32x2{ra[i].x, ra[i].y} * a_scale, hi.x, lo.x);
-        split2_pair(f32x2{ra[i].z, ra[i].w} * a_scale, hi.y, lo.y);
+        split2_pair(f32x2{ra[set][i].x, ra[set][i].y} * a_scale, hi.x, lo.x);
+        split2_pair(f32x2{ra[set][i].z, ra[set][i].w} * a_scale, hi.y, lo.y);
         *reinterpret_cast<uint2*>(as + a_lds0 + i * (A_ROWS_PER_PIECE * 16)) = hi;
         *reinterpret_cast<uint2*>(as + A_PLANE + a_lds0 + i * (A_ROWS_PER_PIECE * 16)) = lo;
     };
-    auto store_b_piece = [&](int buf, int j) {
+    auto store_b_piece = [&](int set, int buf, int j) {
         uint32_t* bs = lds + buf * STAGE + 2 * A_PLANE;
         if (B_ALL || (tid + j * NT) < BN * 4) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                *reinterpret_cast<u32x4*>(bs + p * B_PLANE + b_lds0 + j * (B_ROWS_PER_PIECE * 16)) = rb[p][j];
+                *reinterpret_cast<u32x4*>(bs + p * B_PLANE + b_lds0 + j * (B_ROWS_PER_PIECE * 16)) = rb[set][p][j];
         }
     };
     // All staging of a k-tile in one block: write the registers (tile kt+1, requested a whole k-tile ago, so the single
     // s_waitcnt vmcnt(0) in front of it is free) to LDS[buf^1], then re-use them at once to request tile kt+2.  Spreading
     // the pieces over the MFMA gaps does not work with hipcc: every piece then waits vmcnt(0), i.e. for the loads issued
     // a few instructions earlier (measured: 0.65x).
-    auto stage_all = [&](int buf, bool stage, bool fetch) {
+    auto stage_all = [&](int buf, bool stage, bool fetch, int set = 0) {
+        if (PD > 1) {                       // straight-line: see the note at the template
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) store_a_piece(set, buf ^ 1, i);
+#pragma unroll
+            for (int j = 0; j < NLB; ++j) store_b_piece(set, buf ^ 1, j);
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) load_a_piece(set, i, fetch);
+            advance_a();
+#pragma unroll
+            for (int j = 0; j < NLB; ++j) load_b_piece(set, j, fetch);
+            advance_b();
+            return;
+        }
         if (stage) {
 #pragma unroll
-            for (int i = 0; i < NLA; ++i) store_a_piece(buf ^ 1, i);
+            for (int i = 0; i < NLA; ++i) store_a_piece(0, buf ^ 1, i);
 #pragma unroll
-            for (int j = 0; j < NLB; ++j) store_b_piece(buf ^ 1, j);
+            for (int j = 0; j < NLB; ++j) store_b_piece(0, buf ^ 1, j);
         }
         if (fetch) {
 #pragma unroll
-            for (int i = 0; i < NLA; ++i) load_a_piece(i);
+            for (int i = 0; i < NLA; ++i) load_a_piece(0, i, true);
             advance_a();
 #pragma unroll
-            for (int j = 0; j < NLB; ++j) load_b_piece(j);
+            for (int j = 0; j < NLB; ++j) load_b_piece(0, j, true);
             advance_b();
         }
     };
@@ -541,7 +562,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
     // program in lockstep (one barrier per k-tile), and offsetting their VALU-heavy staging blocks lets one wave's MFMAs
     // run under the other's staging.
     const bool late = (NT == 512) && wave >= (NT / 128);
-    auto step = [&](int buf, bool stage, bool fetch) {
+    auto step = [&](int buf, bool stage, bool fetch, int set = 0) {
         const uint32_t* as = lds + buf * STAGE;
         const uint32_t* bs = as + 2 * A_PLANE;
         const int sw = (l31 >> 2) & 3;
@@ -570,8 +591,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[0][j], a[0][i], c, 0, 0, 0);
                     acc[i][j] = c;
                     const int visit = (s * TM + i) * TN + j;
-                    if (visit == 0 && !late) stage_all(buf, stage, fetch);
-                    if (NT == 512 && visit == NTILE / 2 && late) stage_all(buf, stage, fetch);
+                    if (visit == 0 && !late) stage_all(buf, stage, fetch, set);
+                    if (NT == 512 && visit == NTILE / 2 && late) stage_all(buf, stage, fetch, set);
                 }
         }
     };
@@ -583,6 +604,30 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_h3_kernel(GemmArgs g) {
             __syncthreads();
             step(0, false, false);                              // products only
             __syncthreads();                                    // LDS[0] free again
+        }
+    } else if (PD > 1) {
+        static_assert(PD == 1 || (NT == 256 && !SINGLE), "the deep request ring is for the small 4-wave tiles");
+        // sets 0 .. PD-1 <- tiles 0 .. PD-1; tile 0 -> LDS[0], set 0 <- tile PD; then tile kt + u is multiplied from LDS[buf]
+        // while set (u + 1) % PD (tile kt + u + 1) goes to LDS[buf ^ 1] and is re-requested for tile kt + u + 1 + PD
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) load_a_piece(u, i, u < nkt);
+            advance_a();
+#pragma unroll
+            for (int j = 0; j < NLB; ++j) load_b_piece(u, j, u < nkt);
+            advance_b();
+        }
+        stage_all(1, true, PD < nkt, 0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = 0; kt < nkt; kt += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                step(buf, true, kt + u + 1 + PD < nkt, (u + 1) % PD);
+                __syncthreads();
+                buf ^= 1;
+            }
         }
     } else if (nkt > 0) {
         stage_all(1, false, true);              // request tile 0
@@ -864,12 +909,32 @@ __global__ __launch_bounds__(256, 1) void gemm_h3_wide_kernel(GemmArgs g) {
     TTTS_CLOCK_END(ttts_clock_h3_wide, 512);
 }
 
+#ifndef TTTS_H3_PD
+#define TTTS_H3_PD 4
+#endif
 template <int BM, int BN, int WM, int WN>
 static int launch_h3(const GemmArgs& g, hipStream_t stream) {
     // persistent grid: one workgroup per CU for the 8-wave tiles (128 KB / 96 KB of LDS), two for the 4-wave ones
     const long ntiles = (long)cdiv(g.N, BN) * cdiv(g.M, BM);
     const long cap = 256L * (WM * WN == 8 ? 1 : 2);                        // 4-wave tiles: two workgroups per CU
     dim3 grid((unsigned)(ntiles < cap ? ntiles : cap), 1, 1);
+    // the small 4-wave tiles keep TTTS_H3_PD k-tiles of requests in flight when the k-tiles divide (see gemm_h3_kernel)
+    // (the 64 x 64 tile only.  Per launch in the B = 16 step, `profiles/r06_ab_request_ring.txt`: 64 x 64 15.4 -> 13.4 us and
+    // 25.1 -> 21.3 us with shifted rows; 64 x 128 21.6 -> 23.4 us -- four tiles of requests before its first product and 190
+    // registers buy it nothing, its k-tiles are paced by the bytes a CU can pull (16 KB per k-tile and workgroup: 7 TB/s chip-wide
+    // at M = 6 400, the cu_path_view roof), not by a round trip; the 128-row tiles spill with four sets beside 64 accumulators)
+    constexpr bool SMALL = (WM * WN == 4) && BM <= 64 && BN <= 64;
+    if constexpr (SMALL && TTTS_H3_PD > 1) {
+        const int nkt = g.K / HBK;
+        if (nkt % TTTS_H3_PD == 0 && nkt >= 2 * TTTS_H3_PD) {
+            if (g.T > 0)
+                hipLaunchKernelGGL((gemm_h3_kernel<BM, BN, WM, WN, true, TTTS_H3_PD>), grid, dim3(WM * WN * 64), 0, stream, g);
+            else
+                hipLaunchKernelGGL((gemm_h3_kernel<BM, BN, WM, WN, false, TTTS_H3_PD>), grid, dim3(WM * WN * 64), 0, stream, g);
+            TTTS_LAUNCH_CHECK("gemm_h3_kernel<PD>");
+            return TTTS_OK;
+        }
+    }
     if (g.T > 0)
         hipLaunchKernelGGL((gemm_h3_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, stream, g);
     else

@@ -412,6 +412,7 @@ WGRAD_GROUP_SIZE = {1: 4, 2: 3, 3: 2, 4: 2}     # (classes 3 / 4: the two 80-cha
 # run beside the data-gradient chain and fill the CUs its launches leave idle (partial last rounds of the persistent GEMMs, the
 # memory-bound normalisation kernels between them); joined where the queue is flushed.  Captured as a parallel graph branch.
 WGRAD_SIDE_STREAM = False
+WGRAD_SIDE_MAX_ROWS = 0      # > 0: only groups over at most this many rows take the side stream (the small-batch / encoder groups)
 
 
 class ReduceQueue:
@@ -479,7 +480,7 @@ class ReduceQueue:
                 n, ptr(col(0)), ptr(col(2)), ptr(col(4)), ptr(col(5)), ptr(col(9)), ZA(*[m[9].numel() * 4 for m in wg]), LA(*col(6)),
                 IA(*col(7)), IA(*col(8)), IA(*col(10)), IA(*col(11)), IA(*col(12)), 1, ptr(col(1)), ptr(col(3)),
                 self.handle if DEFER_REDUCE else None, stream), "ttts_wgrad_group")
-        if WGRAD_SIDE_STREAM and DEFER_REDUCE:
+        if WGRAD_SIDE_STREAM and DEFER_REDUCE and (WGRAD_SIDE_MAX_ROWS <= 0 or wg[0][6] <= WGRAD_SIDE_MAX_ROWS):
             dev = wg[0][0].device
             if self._side is None or self._side.device != dev:
                 self._side = torch.cuda.Stream(device=dev)
