@@ -292,6 +292,12 @@ int ttts_bn_train_stats_from_partials(const float* partials, int nblk, float* me
 int ttts_bn_train_stats_from_partials_rows(const float* partials, int nblk, const float* rows, int n_rows, float* mean,
                                            float* invstd, float* running_mean, float* running_var,
                                            int64_t* num_batches_tracked, int C, float momentum, float eps, void* stream);
+/* ttts_bn_train_stats_from_partials_rows for TWO row sets of one matrix in one launch (the halves of a twin batch); the running
+ * statistics and the batch counter receive set a's update first, then set b's -- two calls in that order, one launch (ABI v14) */
+int ttts_bn_train_stats_twin(const float* partials_a, int nblk_a, const float* rows_a, int n_rows_a, float* mean_a, float* invstd_a,
+                             const float* partials_b, int nblk_b, const float* rows_b, int n_rows_b, float* mean_b, float* invstd_b,
+                             float* running_mean, float* running_var, int64_t* num_batches_tracked, int C, float momentum,
+                             float eps, void* stream);
 int ttts_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C, float eps,
                        void* stream);
 /* z = drop(act((x - mean) * invstd * gamma + beta)); z_amax_out: NULL, or a caller-zeroed TTTS_AMAX_SLOTS-float array receiving max|z| */

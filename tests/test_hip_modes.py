@@ -591,6 +591,16 @@ def test_batchnorm_statistics_of_each_half_of_a_twin_batch(B, T, cin, cout, offs
         assert float((mean.double() - mean64).abs().max()) < 2e-6 * (1.0 + abs(offset)), (h, float((mean.double() - mean64).abs().max()))
         assert _rel(invstd, 1.0 / torch.sqrt(var64 + 1e-5)) < 2e-6, (h, _rel(invstd, 1.0 / torch.sqrt(var64 + 1e-5)))
     assert int(nbt) == 2 and _rel(rv, rv64) < 2e-6 and float((rm.double() - rm64).abs().max()) < 2e-6 * (1.0 + abs(offset))
+    # ttts_bn_train_stats_twin: both halves in ONE launch, the same results bit for bit (running statistics: first set first)
+    rm2, rv2, nbt2 = torch.zeros(cout, device=_dev()), torch.ones(cout, device=_dev()), torch.zeros((), dtype=torch.int64, device=_dev())
+    mi = torch.empty(2, 2, cout, device=_dev())
+    sets = []
+    for h in (1, 0):
+        b0, nb, r0, nr = runs[h]
+        sets += [_off(ws, b0 * 3 * cout) if nb else None, nb, _off(y, r0 * cout) if nr else None, nr, _p(mi[h, 0]), _p(mi[h, 1])]
+    assert lib.ttts_bn_train_stats_twin(*sets, _p(rm2), _p(rv2), _p(nbt2), cout, 0.1, 1e-5, _stream()) == 0
+    assert int(nbt2) == 2 and torch.equal(rm2, rm) and torch.equal(rv2, rv)
+    assert torch.equal(mi[0, 0], mean) and torch.equal(mi[0, 1], invstd)          # (the loop's last half was h = 0)
     # refusals: nothing to merge, more rows than the kernel folds
     assert lib.ttts_bn_train_stats_from_partials_rows(None, 0, None, 0, _p(rm), _p(rv), _p(rm), _p(rv), _p(nbt), cout, 0.1, 1e-5, _stream()) != 0
     assert lib.ttts_bn_train_stats_from_partials_rows(_p(ws), 1, _p(y), 257, _p(rm), _p(rv), _p(rm), _p(rv), _p(nbt), cout, 0.1, 1e-5, _stream()) != 0

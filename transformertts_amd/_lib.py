@@ -39,6 +39,7 @@ SIGNATURES = {
     "ttts_conv1d_fwd_h3_bn_chunk_rows": (I, [I, I, I, I, I]),
     "ttts_bn_train_stats_from_partials": (I, [P, I, P, P, P, P, P, I, F, F, P]),
     "ttts_bn_train_stats_from_partials_rows": (I, [P, I, P, I, P, P, P, P, P, I, F, F, P]),
+    "ttts_bn_train_stats_twin": (I, [P, I, P, I, P, P, P, I, P, I, P, P, P, P, P, I, F, F, P]),
     "ttts_amax_partials": (I, [P, L, P, P]),
     "ttts_linear_bwd_data_h3": (I, [P, P, P, P, L, I, I, P, F, P, P, P]),
     "ttts_act_image": (I, [P, P, P, L, I, P]),

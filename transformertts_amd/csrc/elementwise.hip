@@ -375,7 +375,7 @@ using namespace ttts;
 extern "C" {
 
 const char* ttts_last_error(void) { return ttts::g_err; }
-int ttts_abi_version(void) { return 13; }
+int ttts_abi_version(void) { return 14; }
 
 int ttts_zero(void* p, size_t nbytes, void* stream) { return ::ttts::launch_zero(p, nbytes, (hipStream_t)stream); }
 

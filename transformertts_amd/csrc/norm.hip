@@ -315,16 +315,31 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 
 // Merge the per-chunk (count, mean, M2) partials of a channel (Chan et al.), 16 channels x 16 merge-lanes per
 // workgroup: each lane folds every 16th partial in order, lane 0 then folds the 16 lane results in order.
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ ws, float* __restrict__ mean_out,
-                                                             float* __restrict__ invstd_out, float* __restrict__ running_mean,
-                                                             float* __restrict__ running_var, int64_t* __restrict__ nbt,
-                                                             int nblk, int C, float momentum, float eps,
-                                                             const float* __restrict__ xr, int nxr) {
+struct BnStatSet {          // one set of rows of a matrix: row-chunk partials [nblk][3][C] and / or nxr rows of the matrix itself
+    const float* ws;
+    const float* xr;
+    float* mean;
+    float* invstd;
+    int nblk, nxr;
+};
+
+// NSETS = 2: the statistics of TWO row sets of one matrix (the halves of a twin batch) in one launch -- 256 threads per set --, the
+// running statistics updated with set a's first, then set b's, by one thread per channel.
+template <int NSETS>
+__global__ __launch_bounds__(256 * NSETS) void bn_stats_final_kernel(BnStatSet sa, BnStatSet sb, float* __restrict__ running_mean,
+                                                                     float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                                     int C, float momentum, float eps) {
     // merge of the row-chunk partials without a serial chain of divisions: N = sum n_b, mean = sum n_b mean_b / N, then
     // M2 = sum [M2_b + n_b (mean_b - mean)^2] (the pooled-variance identity, centred on the global mean).  4 channels
     // x 64 chunk-lanes per block (the loop is latency bound: short trips, many lanes), fixed summation order.
-    __shared__ float sn[64][5], sm[64][5], sq[64][5];
-    const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    __shared__ float sn[NSETS][64][5], sm[NSETS][64][5], sq[NSETS][64][5];
+    __shared__ float fin[NSETS][2][4];
+    const int set = NSETS > 1 ? (int)(threadIdx.x >> 8) : 0, t = threadIdx.x & 255;
+    const BnStatSet& s = (NSETS > 1 && set) ? sb : sa;
+    const float* __restrict__ ws = s.ws;
+    const float* __restrict__ xr = s.xr;
+    const int nblk = s.nblk, nxr = s.nxr;
+    const int cl = t & 3, rl = t >> 2;
     const int c = blockIdx.x * 4 + cl;
     // a lane's partials (every 64th chunk: at most BN_MAXBLK / 64 = 8) are all requested up front and kept for the second
     // pass: the kernel is two dependent trips to L2 otherwise repeated per chunk (10 -> 4 us)
@@ -352,11 +367,11 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
     for (int i = 0; i < PER; ++i) { n += pn[i]; sw += pn[i] * pm[i]; }
 #pragma unroll
     for (int i = 0; i < BN_XROWS; ++i) { n += (rl + 64 * i < nxr) ? 1.f : 0.f; sw += xv[i]; }
-    sn[rl][cl] = n; sm[rl][cl] = sw;
+    sn[set][rl][cl] = n; sm[set][rl][cl] = sw;
     __syncthreads();
     n = 0.f; sw = 0.f;
 #pragma unroll 8
-    for (int i = 0; i < 64; ++i) { n += sn[i][cl]; sw += sm[i][cl]; }
+    for (int i = 0; i < 64; ++i) { n += sn[set][i][cl]; sw += sm[set][i][cl]; }
     const float mean = (n > 0.f) ? sw / n : 0.f;
     float m2 = 0.f;
 #pragma unroll
@@ -369,22 +384,27 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
         const float dlt = xv[i] - mean;
         m2 += (rl + 64 * i < nxr) ? dlt * dlt : 0.f;
     }
-    sq[rl][cl] = m2;
+    sq[set][rl][cl] = m2;
     __syncthreads();
     if (rl == 0 && c < C) {
         m2 = 0.f;
 #pragma unroll 8
-        for (int i = 0; i < 64; ++i) m2 += sq[i][cl];
-        float var = m2 / n;
-        mean_out[c] = mean;
-        invstd_out[c] = 1.0f / sqrtf(var + eps);
-        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        if (running_var) {
-            float unbiased = (n > 1.f) ? m2 / (n - 1.f) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        for (int i = 0; i < 64; ++i) m2 += sq[set][i][cl];
+        const float var = m2 / n;
+        s.mean[c] = mean;
+        s.invstd[c] = 1.0f / sqrtf(var + eps);
+        fin[set][0][cl] = mean;
+        fin[set][1][cl] = (n > 1.f) ? m2 / (n - 1.f) : var;
+    }
+    __syncthreads();
+    if (set == 0 && rl == 0 && c < C) {
+#pragma unroll
+        for (int k = 0; k < NSETS; ++k) {              // set a's update first, then set b's
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fin[k][0][cl];
+            if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * fin[k][1][cl];
         }
     }
-    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += NSETS;
 }
 
 __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ mean,
@@ -646,8 +666,9 @@ int ttts_bn_train_stats(const float* x, float* mean, float* invstd, float* runni
     int nb = bn_blocks(M, &rpb);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(cdiv(C, 64), nb), dim3(256), 0, stream, x, ws, (long)M, C, rpb);
     TTTS_LAUNCH_CHECK("bn_stats_partial_kernel");
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, ws, mean, invstd, running_mean,
-                       running_var, num_batches_tracked, nb, C, momentum, eps, (const float*)nullptr, 0);
+    const BnStatSet st = {ws, nullptr, mean, invstd, nb, 0};
+    hipLaunchKernelGGL(bn_stats_final_kernel<1>, dim3(cdiv(C, 4)), dim3(256), 0, stream, st, st, running_mean, running_var,
+                       num_batches_tracked, C, momentum, eps);
     TTTS_LAUNCH_CHECK("bn_stats_final_kernel");
     return TTTS_OK;
 }
@@ -662,9 +683,29 @@ int ttts_bn_train_stats_from_partials_rows(const float* partials, int nblk, cons
     TTTS_REQUIRE(nblk >= 0 && nblk <= BN_MAXBLK && C > 0, "bn_train_stats_from_partials: nblk=%d must be in 0..%d", nblk, BN_MAXBLK);
     TTTS_REQUIRE(n_rows >= 0 && n_rows <= 64 * BN_XROWS, "bn_train_stats_from_partials: n_rows=%d must be in 0..%d", n_rows, 64 * BN_XROWS);
     TTTS_REQUIRE(nblk + n_rows > 0, "bn_train_stats_from_partials: nothing to merge");
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, mean, invstd,
-                       running_mean, running_var, num_batches_tracked, nblk, C, momentum, eps, rows, n_rows);
+    const BnStatSet st = {partials, rows, mean, invstd, nblk, n_rows};
+    hipLaunchKernelGGL(bn_stats_final_kernel<1>, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, st, st, running_mean,
+                       running_var, num_batches_tracked, C, momentum, eps);
     TTTS_LAUNCH_CHECK("bn_stats_final_kernel");
+    return TTTS_OK;
+}
+
+int ttts_bn_train_stats_twin(const float* partials_a, int nblk_a, const float* rows_a, int n_rows_a, float* mean_a, float* invstd_a,
+                             const float* partials_b, int nblk_b, const float* rows_b, int n_rows_b, float* mean_b, float* invstd_b,
+                             float* running_mean, float* running_var, int64_t* num_batches_tracked, int C, float momentum,
+                             float eps, void* stream) {
+    // ttts_bn_train_stats_from_partials_rows for TWO row sets of one matrix in one launch: the running statistics (and the batch
+    // counter) are updated with set a's statistics first, then with set b's, as two calls in that order would
+    TTTS_REQUIRE(mean_a && invstd_a && mean_b && invstd_b && (partials_a || nblk_a == 0) && (rows_a || n_rows_a == 0) &&
+                 (partials_b || nblk_b == 0) && (rows_b || n_rows_b == 0), "bn_train_stats_twin: null pointer");
+    TTTS_REQUIRE(nblk_a >= 0 && nblk_a <= BN_MAXBLK && nblk_b >= 0 && nblk_b <= BN_MAXBLK && C > 0, "bn_train_stats_twin: nblk out of 0..%d", BN_MAXBLK);
+    TTTS_REQUIRE(n_rows_a >= 0 && n_rows_a <= 64 * BN_XROWS && n_rows_b >= 0 && n_rows_b <= 64 * BN_XROWS,
+                 "bn_train_stats_twin: n_rows out of 0..%d", 64 * BN_XROWS);
+    TTTS_REQUIRE(nblk_a + n_rows_a > 0 && nblk_b + n_rows_b > 0, "bn_train_stats_twin: nothing to merge");
+    const BnStatSet sa = {partials_a, rows_a, mean_a, invstd_a, nblk_a, n_rows_a}, sb = {partials_b, rows_b, mean_b, invstd_b, nblk_b, n_rows_b};
+    hipLaunchKernelGGL(bn_stats_final_kernel<2>, dim3(cdiv(C, 4)), dim3(512), 0, (hipStream_t)stream, sa, sb, running_mean,
+                       running_var, num_batches_tracked, C, momentum, eps);
+    TTTS_LAUNCH_CHECK("bn_stats_final_kernel<2>");
     return TTTS_OK;
 }
 

@@ -1636,17 +1636,19 @@ class ConvBNFn(torch.autograd.Function):
         _lib.check(lib.ttts_conv1d_fwd_h3(_p(x), _p(_planes(conv_w, 6, cout, taps * cin, cin, taps)), _p(conv_b), _p(y_k),
                                           Bk, T, cin, cout, taps, _p(x_amax), _p(bn_ws), _stream()), "ttts_conv1d_fwd_h3")
         stats = {}
+        mi = torch.empty(2, 2, cout, dtype=torch.float32, device=dev)          # [half][mean, invstd]
+        if training and bn_ws is not None:        # both halves' statistics in one launch, the no-grad forward's update first
+            sets = []
+            for h in (1, 0):
+                b0, nb, r0, nr = runs[h]
+                sets += [_off(bn_ws, b0 * 3 * cout) if nb else None, nb, _off(y_k, r0 * cout) if nr else None, nr, _p(mi[h, 0]), _p(mi[h, 1])]
+            _lib.check(lib.ttts_bn_train_stats_twin(*sets, _p(running_mean), _p(running_var), _p(nbt), cout, float(momentum),
+                                                    float(eps), _stream()), "ttts_bn_train_stats_twin")
         for h in (1, 0):                      # the no-grad forward's half first
             y_h, z_h = y_k[h * B:(h + 1) * B], z_k[h * B:(h + 1) * B]
-            mean = torch.empty(cout, dtype=torch.float32, device=dev)
-            invstd = torch.empty(cout, dtype=torch.float32, device=dev)
+            mean, invstd = mi[h, 0], mi[h, 1]
             if training and bn_ws is not None:
-                b0, nb, r0, nr = runs[h]
-                _lib.check(lib.ttts_bn_train_stats_from_partials_rows(_off(bn_ws, b0 * 3 * cout) if nb else None, nb,
-                                                                      _off(y_k, r0 * cout) if nr else None, nr, _p(mean), _p(invstd),
-                                                                      _p(running_mean), _p(running_var), _p(nbt), cout,
-                                                                      float(momentum), float(eps), _stream()),
-                           "ttts_bn_train_stats_from_partials_rows")
+                pass
             elif training:
                 ws = _ws(lib.ttts_bn_workspace_bytes(M, cout), dev)
                 _lib.check(lib.ttts_bn_train_stats(_p(y_h), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(nbt),
