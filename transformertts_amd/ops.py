@@ -1635,26 +1635,24 @@ class ConvBNFn(torch.autograd.Function):
                     runs = {0: (0, s_, s_ * chunk, cut), 1: (s_ + 1, nblk - s_ - 1, M, min((s_ + 1) * chunk, 2 * M) - M)}
         _lib.check(lib.ttts_conv1d_fwd_h3(_p(x), _p(_planes(conv_w, 6, cout, taps * cin, cin, taps)), _p(conv_b), _p(y_k),
                                           Bk, T, cin, cout, taps, _p(x_amax), _p(bn_ws), _stream()), "ttts_conv1d_fwd_h3")
-        stats = {}
         mi = torch.empty(2, 2, cout, dtype=torch.float32, device=dev)          # [half][mean, invstd]
-        if training and bn_ws is not None:        # both halves' statistics in one launch, the no-grad forward's update first
+        halves = (1, 0)                           # the no-grad forward's half first
+        if training and bn_ws is not None:        # both halves' statistics in one launch (running statistics: first set first)
             sets = []
-            for h in (1, 0):
+            for h in halves:
                 b0, nb, r0, nr = runs[h]
                 sets += [_off(bn_ws, b0 * 3 * cout) if nb else None, nb, _off(y_k, r0 * cout) if nr else None, nr, _p(mi[h, 0]), _p(mi[h, 1])]
             _lib.check(lib.ttts_bn_train_stats_twin(*sets, _p(running_mean), _p(running_var), _p(nbt), cout, float(momentum),
                                                     float(eps), _stream()), "ttts_bn_train_stats_twin")
-        for h in (1, 0):                      # the no-grad forward's half first
+        for h in halves:
             y_h, z_h = y_k[h * B:(h + 1) * B], z_k[h * B:(h + 1) * B]
             mean, invstd = mi[h, 0], mi[h, 1]
-            if training and bn_ws is not None:
-                pass
-            elif training:
+            if training and bn_ws is None:        # (a tile that leaves no partials: a statistics pass per half)
                 ws = _ws(lib.ttts_bn_workspace_bytes(M, cout), dev)
                 _lib.check(lib.ttts_bn_train_stats(_p(y_h), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(nbt),
                                                    _p(ws), ws.numel() * 4, M, cout, float(momentum), float(eps), _stream()),
                            "ttts_bn_train_stats")
-            else:
+            elif not training:
                 _lib.check(lib.ttts_bn_eval_stats(_p(running_mean), _p(running_var), _p(mean), _p(invstd), cout, float(eps),
                                                   _stream()), "ttts_bn_eval_stats")
             if h == 1 and len(twin) > 2 and twin[2]:
@@ -1663,10 +1661,8 @@ class ConvBNFn(torch.autograd.Function):
             seed_h = seed if (h == 0 or seed == 0) else ((seed * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF)
             _lib.check(lib.ttts_bn_apply_fwd(_p(y_h), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(z_h), M, cout, act,
                                              float(drop_p), seed_h, _ss(), _p(z_amax), _stream()), "ttts_bn_apply_fwd")
-            if h == 0:
-                stats[h] = (mean, invstd)
         twin[1].append(z_k)
-        ctx.save_for_backward(x, conv_w, y_k[:B], stats[0][0], stats[0][1], gamma, beta)
+        ctx.save_for_backward(x, conv_w, y_k[:B], mi[0, 0], mi[0, 1], gamma, beta)
         ctx.x_amax = x_amax
         ctx.cfg = (training, act, float(drop_p), seed, conv_b is not None)
         ctx.ss = _ss()
