@@ -490,6 +490,37 @@ def test_training_step_surface():
             assert int(buf.item()) == 2
 
 
+def test_twin_keywords_refuse_misuse():
+    """`forward(memory=, postnet_twin=)` are for training_step's pair of forwards over ONE batch: a memory of another shape, a
+    post-net box left by another batch, a box handed to a forward that wants the stop logits or to a grad forward first are
+    refused with a ValueError naming what is wrong (never a silently wrong post-net pass)."""
+    from oracle import model_config, synth_batch
+    from transformertts_amd import ops
+    from transformertts_amd.model import TransformerTTS
+    cfg = model_config("base")
+    m = TransformerTTS(**cfg, device="cuda").to("cuda").train()
+    b = {k: v.to("cuda") for k, v in synth_batch(2, 16, 40, cfg["n_mels"], cfg["n_phon"], ragged=False, seed=3).items()}
+    args = (b["phoneme"], b["melspec"], b["phoneme_lens"], b["melspec_lens"])
+    with torch.no_grad():
+        mem = m.encode(b["phoneme"], b["phoneme_lens"])
+        with pytest.raises(ValueError, match="memory"):
+            m(*args, memory=mem[:, :-1])
+        with pytest.raises(ValueError, match="no-grad forward"):
+            m(*args, postnet_twin=ops.PostnetTwin())                      # (need_stop defaults to True)
+        box = ops.PostnetTwin()
+        out = m(*args, need_alignments=False, need_stop=False, postnet_twin=box)
+        assert out["post_melspec"] is None and out["pred_stop"] is None and box.full.shape == (4, 40, cfg["n_mels"])
+        assert out["pred_melspec"].data_ptr() == box.full[2:].data_ptr()
+    with pytest.raises(ValueError, match="no-grad forward"):
+        m(*args, postnet_twin=ops.PostnetTwin())                          # an EMPTY box reaches a grad forward
+    b3 = {k: v.to("cuda") for k, v in synth_batch(3, 16, 40, cfg["n_mels"], cfg["n_phon"], ragged=False, seed=4).items()}
+    with pytest.raises(ValueError, match="another batch"):
+        m(b3["phoneme"], b3["melspec"], b3["phoneme_lens"], b3["melspec_lens"], postnet_twin=box)
+    out = m(*args, postnet_twin=box)                                      # the pair it was made for
+    assert out["post_melspec"].shape == (2, 40, cfg["n_mels"]) and out["pred_melspec"].data_ptr() == box.full.data_ptr()
+    out["post_melspec"].sum().backward()
+
+
 @pytest.mark.parametrize("flag,B,Tp,Tm", [("TWIN_ENCODER", 4, 64, 200), ("TWIN_ENCODER", 3, 37, 150), ("TWIN_POSTNET", 4, 64, 200),
                                           ("TWIN_POSTNET", 3, 37, 150), ("TWIN_POSTNET", 32, 50, 870)])
 def test_twin_batches_are_the_two_forwards(flag, B, Tp, Tm):
