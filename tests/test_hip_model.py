@@ -519,6 +519,11 @@ def test_twin_keywords_refuse_misuse():
     out = m(*args, postnet_twin=box)                                      # the pair it was made for
     assert out["post_melspec"].shape == (2, 40, cfg["n_mels"]) and out["pred_melspec"].data_ptr() == box.full.data_ptr()
     out["post_melspec"].sum().backward()
+    with torch.no_grad():                                                 # a whole pair without grad (a dry run of training_step)
+        box2 = ops.PostnetTwin()
+        m(*args, need_alignments=False, need_stop=False, postnet_twin=box2)
+        out2 = m(*args, postnet_twin=box2)
+    assert out2["post_melspec"] is not None and torch.isfinite(out2["post_melspec"]).all() and out2["pred_stop"] is not None
 
 
 @pytest.mark.parametrize("flag,B,Tp,Tm", [("TWIN_ENCODER", 4, 64, 200), ("TWIN_ENCODER", 3, 37, 150), ("TWIN_POSTNET", 4, 64, 200),

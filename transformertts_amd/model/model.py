@@ -255,10 +255,11 @@ class TransformerTTS(nn.Module):
         tgt_out, alignments = self.decoder(tgt, memory, tgt_is_causal=True, memory_is_causal=False,
                                            tgt_lens=melspec_lens, memory_lens=phoneme_lens,
                                            need_alignments=need_alignments)
+        first_of_pair = postnet_twin is not None and postnet_twin.full is None
         pred_melspec, pred_stop = ops.heads(tgt_out, self.linear1.linear.weight, self.linear1.linear.bias,
                                             self.linear2.linear.weight, self.linear2.linear.bias,
                                             need_stop=need_stop or torch.is_grad_enabled(), box=postnet_twin)
-        if postnet_twin is not None and not torch.is_grad_enabled():
+        if first_of_pair:          # its prediction waits in the box for the second forward's post-net pass
             return {'pred_melspec': pred_melspec, 'post_melspec': None, 'pred_stop': pred_stop, 'alignments': alignments}
         # three consumers of the prediction (the loss, the post-net, its residual): one handle each
         pred_melspec, pred_in, pred_res = ops.fanout(pred_melspec, 3)
