@@ -807,7 +807,8 @@ def _dma_shape_ok(M: int, red: int, out: int, gate: bool) -> bool:
     0.72x at M = 13 920, 0.95x at 27 840, 1.04x at 41 760 (326 tiles), 1.07x at 55 680; 512 -> 512 1.11x at 27 840 (436 tiles);
     forward 256 -> 1024 on the 256-ROW tile of the same kernel (one 8-wave workgroup per CU, chosen inside the library when 256
     of its tiles exist): 1.06x at 55 680, step -0.07 ms same-box (the 128-row tile is level there; 512 -> 2048 at 27 840 level on
-    either; no difference at M = 13 920).  Level or slower elsewhere (K = 1024: 0.9x)."""
+    either; no difference at M = 13 920); the gated 256 -> 1024 data gradient on it too (round 6: step -0.02 ms same-box).  Level or
+    slower elsewhere (K = 1024: 0.9x)."""
     if not (DMA_GEMMS and M >= IMAGE_MIN_ROWS and red % 32 == 0 and out % 4 == 0):
         return False
     if gate and red <= 256 and out >= 512:
