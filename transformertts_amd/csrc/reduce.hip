@@ -48,7 +48,16 @@ __device__ __forceinline__ void reduce_narrow_body(const float* __restrict__ ws,
     const long c = (long)block * 16 + cl;
     float s = 0.f;
     if (c < ncols) {
-        for (int r = rl; r < nrows; r += 16) s += ws[(long)r * ld + c];
+        // eight independent loads in flight per lane (a few hundred rows: the loop used to be one dependent trip to L2 per row,
+        // 11 us for BatchNorm's 511 x 512 backward sums); fixed order all the same
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int r = rl;
+        for (; r + 7 * 16 < nrows; r += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += ws[(long)(r + 16 * u) * ld + c];
+        }
+        for (; r < nrows; r += 16) a[0] += ws[(long)r * ld + c];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     red[rl][cl] = s;
     __syncthreads();
