@@ -409,7 +409,7 @@ int ttts_attention_fwd_img(const void* q, const void* k, const void* v, const fl
                            const uint64_t* step_seed, const float* v_amax, float* o_amax_out, float* rowstat_out, int64_t q_inv_rows, int64_t k_inv_rows, int64_t stat_plane,
                            void* stream);
 /* dq, dk, dv in fp32 (strides ldd*) from d_o; o / d_o fp32; do_amax = partial maxima of |d_o|; delta (B,H,Tq) is scratch.
- * q_splits > 1 (non-causal, dk / dv the two halves of one packed (B, Tk, 2 H 64) gradient): the dK / dV kernel splits the query
+ * q_splits > 1 (dk / dv the two halves of one packed (B, Tk, 2 H 64) gradient; causal too since round 6): the dK / dV kernel splits the query
  * range over q_splits workgroups per key block, partial sums in dkv_partials, one fixed-order reduction at the end. */
 int ttts_attention_bwd_img(const void* q, const void* k, const void* v, const float* q_inv, const float* k_inv,
                            const float* v_inv, const float* o, const float* d_o, const float* rowstat, float* delta, float* dq,

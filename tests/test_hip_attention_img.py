@@ -163,7 +163,7 @@ def _run_img(q, kv, do, lens, causal, H, p_drop=0.0, seed=0, want_attn=True):
                                           d, d, 2 * d, 2 * d, causal, 0.125, p_drop, seed, None, _p(ops._amax(do)), _p(sq), _p(sk), None, 1,
                                           0, 0, 0, _stream()), "bwd_img")
     out = {"o": o, "attn": attn, "lse": stat[0], "dq": dq, "dkv": dkv, "o_amax": oslots, "dq_amax": sq, "dkv_amax": sk}
-    if not causal and Tq >= 64:
+    if Tq >= 64:
         # the same backward with the query range of the dK / dV kernel split over 3 workgroups per key block: partial sums + one
         # fixed-order reduction -- equal to fp32 rounding of the sum order, maxima published by the reduction
         dq2, dkv2 = G(tuple(q.shape), float("nan")), G(tuple(kv.shape), float("nan"))

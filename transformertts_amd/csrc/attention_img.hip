@@ -1350,7 +1350,8 @@ extern "C" int ttts_attention_fwd_img(const void* q, const void* k, const void* 
  * dK / dV kernel reads it after the dQ kernel; nothing else does); dq_amax_out / dkv_amax_out: NULL, or zeroed TTTS_AMAX_SLOTS floats; dkv_partials / q_splits:
  * NULL / 1, or a workspace of q_splits x B x Tk x 2 H 64 floats: the dK / dV kernel then splits the QUERY range over q_splits
  * workgroups per key block and a fixed-order reduction adds the partial sums (cross-attention's one key block per (batch, head)
- * otherwise leaves three quarters of the chip's wave slots empty); non-causal, dv = dk + H 64 with one row stride >= 2 H 64 (a
+ * otherwise leaves three quarters of the chip's wave slots empty; causal self-attention at small batches is as long as its first
+ * key block's walk over every query); dv = dk + H 64 with one row stride >= 2 H 64 (a
  * layer's window of a wider gradient tensor: the fused K/V projection of all decoder layers).  Replaces the same
  * call sites as ttts_attention_bwd_h3 (autograd of F.scaled_dot_product_attention / the explicit softmax path,
  * torch/nn/functional.py:6576-6629). */
@@ -1390,7 +1391,7 @@ extern "C" int ttts_attention_bwd_img(const void* q, const void* k, const void* 
     // one reduction into rows that hold dk then dv
     TTTS_REQUIRE(q_splits >= 1 && q_splits <= 16, "attention_bwd_img: q_splits out of 1..16");
     if (q_splits > 1) {
-        TTTS_REQUIRE(dkv_partials && !causal && dv == dk + H * HD && lddk >= 2 * H * HD && lddv == lddk,
+        TTTS_REQUIRE(dkv_partials && dv == dk + H * HD && lddk >= 2 * H * HD && lddv == lddk,
                      "attention_bwd_img: query splits need a workspace and a (dk | dv) gradient whose rows hold dk then dv");
         a.ldp = 2 * H * HD;
         a.dkv_part = dkv_partials; a.part_stride = (long)B * Tk * a.ldp;
